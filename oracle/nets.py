@@ -1,0 +1,182 @@
+"""
+UNet / FAN / TwitterDCN graphs restated on the oracle ops.  TEST INFRASTRUCTURE.
+
+Parameters are ordered dicts {name: tensor} in the Keras layouts the reference's checkpoints use:
+Conv2D kernel (kh,kw,Cin,Cout), Conv2DTranspose kernel (kh,kw,Cout,Cin), Dense kernel (in,out).
+
+  unet_*   models/pipelines.py:175-226
+  fan_*    models/forensics.py:29-94  (+ ConstrainedConv2D models/layers.py:36-57)
+  dcn_*    models/compression.py:49-138, 197-279 (+ DiscreteLatent models/layers.py:183-203)
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import tables
+from . import tfops as T
+
+
+# ---------------------------------------------------------------------------------------------
+# initialisation (Keras defaults: glorot_uniform kernels, zero biases) with an explicit generator
+def _glorot(gen, shape, fan_in, fan_out, dtype):
+    limit = np.sqrt(6.0 / (fan_in + fan_out))
+    return ((torch.rand(shape, generator=gen, dtype=torch.float64) * 2 - 1) * limit).to(dtype)
+
+
+def _conv_param(p, name, gen, kh, kw, cin, cout, dtype, transpose=False):
+    rf = kh * kw
+    shape = (kh, kw, cout, cin) if transpose else (kh, kw, cin, cout)
+    p[name + '/kernel'] = _glorot(gen, shape, cin * rf, cout * rf, dtype)
+    p[name + '/bias'] = torch.zeros(cout, dtype=dtype)
+
+
+def unet_init(seed=1234, in_channels=4, n_steps=5, dtype=torch.float64):
+    gen = torch.Generator().manual_seed(seed)
+    p = OrderedDict()
+    cin = in_channels
+    for n in range(1, n_steps + 1):
+        c = 32 * 2 ** (n - 1)
+        _conv_param(p, 'ec{}1'.format(n), gen, 3, 3, cin, c, dtype)
+        _conv_param(p, 'ec{}2'.format(n), gen, 3, 3, c, c, dtype)
+        cin = c
+    for n in range(1, n_steps):
+        c = 32 * 2 ** (n_steps - n - 1)
+        _conv_param(p, 'dct{}'.format(n), gen, 2, 2, cin, c, dtype, transpose=True)
+        _conv_param(p, 'dc{}1'.format(n), gen, 3, 3, 2 * c, c, dtype)
+        _conv_param(p, 'dc{}2'.format(n), gen, 3, 3, c, c, dtype)
+        cin = c
+    _conv_param(p, 'dc{}'.format(n_steps), gen, 3, 3, cin, 12, dtype)
+    return p
+
+
+def unet_forward(p, x, n_steps=5, return_tensors=False):
+    t = OrderedDict()
+    t['ep0'] = x
+    for n in range(1, n_steps + 1):
+        a = T.leaky_relu(T.conv2d(t['ep{}'.format(n - 1)], p['ec{}1/kernel'.format(n)], p['ec{}1/bias'.format(n)]))
+        t['ec{}1'.format(n)] = a
+        a = T.leaky_relu(T.conv2d(a, p['ec{}2/kernel'.format(n)], p['ec{}2/bias'.format(n)]))
+        t['ec{}2'.format(n)] = a
+        if n < n_steps:
+            t['ep{}'.format(n)] = T.max_pool2(a)
+    t['dc02'] = t['ec{}2'.format(n_steps)]
+    for n in range(1, n_steps):
+        up = T.conv2d_transpose_2x2(t['dc{}2'.format(n - 1)], p['dct{}/kernel'.format(n)], p['dct{}/bias'.format(n)])
+        t['dct{}'.format(n)] = up
+        cat = torch.cat([up, t['ec{}2'.format(n_steps - n)]], dim=-1)        # [upsampled, skip]  pipelines.py:211
+        a = T.leaky_relu(T.conv2d(cat, p['dc{}1/kernel'.format(n)], p['dc{}1/bias'.format(n)]))
+        t['dc{}1'.format(n)] = a
+        a = T.leaky_relu(T.conv2d(a, p['dc{}2/kernel'.format(n)], p['dc{}2/bias'.format(n)]))
+        t['dc{}2'.format(n)] = a
+    z = T.conv2d(t['dc{}2'.format(n_steps - 1)], p['dc{}/kernel'.format(n_steps)], p['dc{}/bias'.format(n_steps)])
+    t['dc{}'.format(n_steps)] = z
+    y = T.clip_ste(T.depth_to_space(z, 2))
+    t['y'] = y
+    return (y, t) if return_tensors else y
+
+
+# ---------------------------------------------------------------------------------------------
+def fan_init(n_classes, seed=4321, n_filters=32, n_fscale=2, n_convolutions=4, kernel=5, dtype=torch.float64):
+    gen = torch.Generator().manual_seed(seed)
+    p = OrderedDict()
+    p['constrained/kernel'] = torch.tensor(tables.fan_residual_init(), dtype=dtype)
+    cin, nf = 3, n_filters
+    for i in range(n_convolutions):
+        _conv_param(p, 'conv{}'.format(i + 1), gen, kernel, kernel, cin, nf, dtype)
+        cin, nf = nf, int(nf * n_fscale)
+    nf = int(nf // n_fscale)
+    _conv_param(p, 'conv1x1', gen, 1, 1, cin, nf, dtype)
+    p['dense/kernel'] = _glorot(gen, (nf, n_classes), nf, n_classes, dtype)
+    p['dense/bias'] = torch.zeros(n_classes, dtype=dtype)
+    return p
+
+
+def fan_forward(p, x, n_convolutions=4, return_tensors=False):
+    t = OrderedDict()
+    mask = torch.tensor(tables.center_mask_2dfilter(5, 3), dtype=x.dtype)
+    net = T.constrained_conv(x, p['constrained/kernel'], mask)
+    t['constrained'] = net
+    for i in range(n_convolutions):
+        net = T.leaky_relu(T.conv2d(net, p['conv{}/kernel'.format(i + 1)], p['conv{}/bias'.format(i + 1)]))
+        t['conv{}'.format(i + 1)] = net
+        net = T.max_pool2(net)
+        t['pool{}'.format(i + 1)] = net
+    net = T.leaky_relu(T.conv2d(net, p['conv1x1/kernel'], p['conv1x1/bias']))
+    t['conv1x1'] = net
+    gap = net.mean(dim=(1, 2))
+    t['gap'] = gap
+    logits = gap @ p['dense/kernel'] + p['dense/bias']
+    t['logits'] = logits
+    probs = torch.softmax(logits, dim=1)
+    return (probs, t) if return_tensors else probs
+
+
+# ---------------------------------------------------------------------------------------------
+def dcn_init(seed=777, n_features=32, dtype=torch.float64):
+    gen = torch.Generator().manual_seed(seed)
+    p = OrderedDict()
+    _conv_param(p, 'e1', gen, 5, 5, 3, 64, dtype)
+    _conv_param(p, 'e2', gen, 5, 5, 64, 128, dtype)
+    for b in range(1, 4):
+        _conv_param(p, 'er{}a'.format(b), gen, 3, 3, 128, 128, dtype)
+        _conv_param(p, 'er{}b'.format(b), gen, 3, 3, 128, 128, dtype)
+    _conv_param(p, 'elat', gen, 5, 5, 128, n_features, dtype)
+    p['latent_scaling'] = torch.ones((), dtype=dtype)
+    _conv_param(p, 'd512', gen, 3, 3, n_features, 512, dtype)
+    for b in range(1, 4):
+        _conv_param(p, 'dr{}a'.format(b), gen, 3, 3, 128, 128, dtype)
+        _conv_param(p, 'dr{}b'.format(b), gen, 3, 3, 128, 128, dtype)
+    _conv_param(p, 'd256', gen, 3, 3, 128, 256, dtype)
+    _conv_param(p, 'd12', gen, 3, 3, 64, 12, dtype)
+    return p
+
+
+def dcn_encode(p, x, latent_bpf=5, rounding='soft-codebook', v=50, gamma=25):
+    """compression.py:219-241. Returns (latent, entropy, pre-quantisation latent)."""
+    net = 2 * (x - 0.5)
+    net = T.leaky_relu(T.conv2d(net, p['e1/kernel'], p['e1/bias'], stride=2))
+    net = T.conv2d(net, p['e2/kernel'], p['e2/bias'], stride=2)
+    # block 1: fed LReLU(net), skip adds the PRE-activation net (compression.py:224-227)
+    r = T.leaky_relu(T.conv2d(T.leaky_relu(net), p['er1a/kernel'], p['er1a/bias']))
+    r = T.conv2d(r, p['er1b/kernel'], p['er1b/bias'])
+    net = net + r
+    for b in (2, 3):
+        r = T.leaky_relu(T.conv2d(net, p['er{}a/kernel'.format(b)], p['er{}a/bias'.format(b)]))
+        r = T.conv2d(r, p['er{}b/kernel'.format(b)], p['er{}b/bias'.format(b)])
+        net = net + r
+    z = T.conv2d(net, p['elat/kernel'], p['elat/bias'], stride=2)
+    cb = torch.tensor(tables.codebook(latent_bpf), dtype=x.dtype)
+    zs = z * p['latent_scaling']                                   # layers.py:195-198 (scale always trainable)
+    if rounding == 'soft-codebook':
+        lat = T.soft_codebook(zs, cb, v, gamma)
+    else:
+        lat = T.quantization(zs, rounding)
+    ent, _ = T.entropy(lat, cb, v, gamma)                          # layers.py:201
+    return lat, ent, zs
+
+
+def dcn_decode(p, lat):
+    """compression.py:245-271"""
+    net = T.depth_to_space(T.conv2d(lat, p['d512/kernel'], p['d512/bias']), 2)
+    for b in (1, 2, 3):
+        r = T.leaky_relu(T.conv2d(net, p['dr{}a/kernel'.format(b)], p['dr{}a/bias'.format(b)]))
+        r = T.conv2d(r, p['dr{}b/kernel'.format(b)], p['dr{}b/bias'.format(b)])
+        net = net + r
+    net = T.depth_to_space(T.leaky_relu(T.conv2d(net, p['d256/kernel'], p['d256/bias'])), 2)
+    net = T.depth_to_space(T.conv2d(net, p['d12/kernel'], p['d12/bias']), 2)
+    return T.clip_ste((net + 1) / 2)
+
+
+def dcn_forward(p, x, **kw):
+    lat, ent, _ = dcn_encode(p, x, **kw)
+    return dcn_decode(p, lat), ent, lat
+
+
+def dcn_loss(x, y, ent, entropy_weight=250.0):
+    """compression.py:92-93"""
+    return T.l2_loss(x - y) + entropy_weight * ent
+
+
+def count_params(p):
+    return int(sum(int(np.prod(v.shape)) for v in p.values()))

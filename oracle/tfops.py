@@ -1,0 +1,291 @@
+"""
+TensorFlow-2.1 op semantics restated on torch-CPU tensors (NHWC at the interface).
+TEST INFRASTRUCTURE - see oracle/__init__.py.
+
+PARITY UNPINNED: these ops' arithmetic lives in tensorflow-gpu==2.1.2 (requirements.txt:2),
+which is absent from /root/reference and cannot be installed here.  Semantics follow the TF
+documentation / kernels as listed in SURVEY.md section 7 "hard parts":
+  * SAME padding is asymmetric for strided convs (extra pad goes after)
+  * depth_to_space is DCR, Conv2DTranspose kernels are (kh,kw,Cout,Cin)
+  * tf.round is round-half-to-even; tf.image.resize uses half-pixel centres, no antialias
+  * tf.pad SYMMETRIC repeats the edge sample, REFLECT does not
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# ---------------------------------------------------------------------------------------------
+# layout helpers
+def _nchw(x):
+    return x.permute(0, 3, 1, 2)
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1)
+
+
+def same_pads(size, k, s):
+    """TF SAME: pad_total = max((ceil(in/s)-1)*s + k - in, 0); before = total//2, rest after."""
+    out = -(-size // s)
+    total = max((out - 1) * s + k - size, 0)
+    return total // 2, total - total // 2
+
+
+# ---------------------------------------------------------------------------------------------
+# convolution family
+def conv2d(x, w, b=None, stride=1, padding='SAME'):
+    """tf.nn.conv2d / keras Conv2D. x NHWC, w HWIO (kh,kw,Cin,Cout)."""
+    kh, kw = w.shape[0], w.shape[1]
+    xc = _nchw(x)
+    if padding == 'SAME':
+        pt, pb = same_pads(x.shape[1], kh, stride)
+        pl, pr = same_pads(x.shape[2], kw, stride)
+        xc = F.pad(xc, (pl, pr, pt, pb))
+    y = F.conv2d(xc, w.permute(3, 2, 0, 1), b, stride=stride)
+    return _nhwc(y)
+
+
+def conv2d_transpose_2x2(x, w, b=None):
+    """keras Conv2DTranspose(k=2, s=2, SAME). w is (kh,kw,Cout,Cin):
+       out[n,2y+i,2x+j,co] = sum_ci in[n,y,x,ci] * w[i,j,co,ci] + b[co]   (models/pipelines.py:205)."""
+    y = F.conv_transpose2d(_nchw(x), w.permute(3, 2, 0, 1), b, stride=2)
+    return _nhwc(y)
+
+
+def max_pool2(x):
+    """MaxPool2D([2,2]) - SAME == VALID on even sizes (pipelines.py:197, forensics.py:70)."""
+    return _nhwc(F.max_pool2d(_nchw(x), 2))
+
+
+def avg_pool(x, f):
+    return _nhwc(F.avg_pool2d(_nchw(x), f))
+
+
+def depth_to_space(x, bs):
+    """tf.nn.depth_to_space, DCR: out[n, y*bs+i, x*bs+j, c] = in[n, y, x, (i*bs+j)*C + c]."""
+    n, h, w, c = x.shape
+    co = c // (bs * bs)
+    x = x.reshape(n, h, w, bs, bs, co).permute(0, 1, 3, 2, 4, 5)
+    return x.reshape(n, h * bs, w * bs, co)
+
+
+def space_to_depth(x, bs):
+    n, h, w, c = x.shape
+    x = x.reshape(n, h // bs, bs, w // bs, bs, c).permute(0, 1, 3, 2, 4, 5)
+    return x.reshape(n, h // bs, w // bs, bs * bs * c)
+
+
+def leaky_relu(x, alpha=0.2):
+    """tf.keras.layers.LeakyReLU(alpha=0.2) (tf_helpers.py:23); tf.nn.leaky_relu default alpha is 0.2 too."""
+    return torch.where(x > 0, x, alpha * x)
+
+
+def clip_ste(y):
+    """stop_gradient(clip(y,0,1) - y) + y  (pipelines.py:223, compression.py:271)."""
+    return (torch.clamp(y, 0, 1) - y).detach() + y
+
+
+def pad2d(x, p, mode):
+    """tf.pad on H,W by p with mode SYMMETRIC | REFLECT."""
+    if p == 0:
+        return x
+    n, h, w, c = x.shape
+    if mode == 'REFLECT':
+        iy = list(range(p, 0, -1)) + list(range(h)) + list(range(h - 2, h - 2 - p, -1))
+        ix = list(range(p, 0, -1)) + list(range(w)) + list(range(w - 2, w - 2 - p, -1))
+    elif mode == 'SYMMETRIC':
+        iy = list(range(p - 1, -1, -1)) + list(range(h)) + list(range(h - 1, h - 1 - p, -1))
+        ix = list(range(p - 1, -1, -1)) + list(range(w)) + list(range(w - 1, w - 1 - p, -1))
+    else:
+        raise ValueError(mode)
+    return x[:, iy][:, :, ix]
+
+
+def resize_axis_table(in_size, out_size):
+    """tf.image.resize(bilinear, half_pixel_centers, antialias=False) interpolation table for one axis:
+       in = (o + 0.5) * in/out - 0.5; lo = max(floor(in),0); hi = min(ceil(in), in_size-1); t = in - floor(in)."""
+    scale = in_size / out_size
+    lo, hi, t = [], [], []
+    for o in range(out_size):
+        src = (o + 0.5) * scale - 0.5
+        f = math.floor(src)
+        lo.append(max(f, 0))
+        hi.append(min(math.ceil(src), in_size - 1))
+        t.append(src - f)
+    return np.array(lo), np.array(hi), np.array(t)
+
+
+def resize_bilinear(x, out_h, out_w):
+    n, h, w, c = x.shape
+    ylo, yhi, yt = resize_axis_table(h, out_h)
+    xlo, xhi, xt = resize_axis_table(w, out_w)
+    yt = torch.tensor(yt, dtype=x.dtype).view(1, -1, 1, 1)
+    xt = torch.tensor(xt, dtype=x.dtype).view(1, 1, -1, 1)
+    top = x[:, ylo]
+    bot = x[:, yhi]
+    tl, tr = top[:, :, xlo], top[:, :, xhi]
+    bl, br = bot[:, :, xlo], bot[:, :, xhi]
+    t = tl + (tr - tl) * xt
+    b = bl + (br - bl) * xt
+    return t + (b - t) * yt
+
+
+# ---------------------------------------------------------------------------------------------
+# colour spaces (tf.image.rgb_to_hsv / hsv_to_rgb; tensorflow/core/kernels/colorspace_op.h)
+def rgb_to_hsv(x):
+    r, g, b = x[..., 0], x[..., 1], x[..., 2]
+    # max / min with an explicit selection order so that the (sub)gradient goes to ONE channel:
+    # R first, then G, then B - the same order the H branch uses.
+    v = torch.where((r >= g) & (r >= b), r, torch.where(g >= b, g, b))
+    mn = torch.where((r <= g) & (r <= b), r, torch.where(g <= b, g, b))
+    rng = v - mn
+    zero = torch.zeros_like(v)
+    safe_v = torch.where(v > 0, v, torch.ones_like(v))
+    s = torch.where(v > 0, rng / safe_v, zero)
+    safe_rng = torch.where(rng > 0, rng, torch.ones_like(rng))
+    norm = 1.0 / (6.0 * safe_rng)
+    h = torch.where(r == v, norm * (g - b),
+                    torch.where(g == v, norm * (b - r) + 2.0 / 6.0, norm * (r - g) + 4.0 / 6.0))
+    h = torch.where(rng > 0, h, zero)
+    h = torch.where(h < 0, h + 1, h)
+    return torch.stack([h, s, v], dim=-1)
+
+
+def hsv_to_rgb(x):
+    h, s, v = x[..., 0], x[..., 1], x[..., 2]
+    dh = h * 6
+    dr = torch.clamp(torch.abs(dh - 3) - 1, 0, 1)
+    dg = torch.clamp(2 - torch.abs(dh - 2), 0, 1)
+    db = torch.clamp(2 - torch.abs(dh - 4), 0, 1)
+    one_s = 1 - s
+    return torch.stack([(one_s + s * dr) * v, (one_s + s * dg) * v, (one_s + s * db) * v], dim=-1)
+
+
+# ---------------------------------------------------------------------------------------------
+# quantisation (models/layers.py:118-172)
+class _SoftRound(torch.autograd.Function):
+    """'soft': forward round(x) [half-to-even], backward d/dx (x - sin(2 pi x)/(2 pi)) = 1 - cos(2 pi x)
+       (layers.py:126-128)."""
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.round(x)      # torch.round is half-to-even like tf.round
+
+    @staticmethod
+    def backward(ctx, g):
+        x, = ctx.saved_tensors
+        return g * (1 - torch.cos(2 * math.pi * x))
+
+
+def quantization(x, mode='soft', taylor_terms=1):
+    if mode == 'round':
+        return torch.round(x).detach() + 0 * x
+    if mode == 'sin':
+        return x - torch.sin(2 * math.pi * x) / (2 * math.pi)
+    if mode == 'soft':
+        return _SoftRound.apply(x)
+    if mode == 'harmonic':
+        xa = x - torch.sin(2 * math.pi * x) / math.pi
+        for k in range(2, taylor_terms):
+            xa = xa + (-1.0) ** k * torch.sin(2 * math.pi * k * x) / (k * math.pi)
+        return xa
+    if mode == 'identity':
+        return x
+    raise ValueError('Unsupported quantization: {}'.format(mode))
+
+
+def soft_quantization(x, alpha=255):
+    """helpers/tf_helpers.py:271-277"""
+    return _SoftRound.apply(alpha * x) / alpha
+
+
+def _codebook_weights(values, codebook, v, gamma):
+    """float64 kernel weights (layers.py:146-158 / tf_helpers.py:311-323)."""
+    eps = 1e-72
+    vals = values.reshape(-1, 1).to(torch.float64)
+    cb = codebook.reshape(1, -1).to(torch.float64)
+    dff = vals - cb
+    if v <= 0:
+        w = torch.exp(-gamma * dff ** 2)
+    else:
+        dff = gamma * dff
+        w = (1 + dff ** 2 / v) ** (-(v + 1) / 2)
+    return (w + eps) / (w + eps).sum(dim=1, keepdim=True)
+
+
+def soft_codebook(x, codebook, v=50, gamma=25):
+    """Quantization('soft-codebook') (layers.py:139-170): float64 inside, float32 (x.dtype) out."""
+    w = _codebook_weights(x, codebook, v, gamma)
+    cb = codebook.reshape(-1).to(torch.float64)
+    soft = (w @ cb.reshape(-1, 1)).mean(dim=1).to(x.dtype).reshape(x.shape)
+    hard = codebook.reshape(-1)[torch.argmax(w, dim=1)].to(x.dtype).reshape(x.shape)
+    return (hard - soft).detach() + soft
+
+
+def entropy(values, codebook, v=50, gamma=25):
+    """Differentiable entropy (helpers/tf_helpers.py:290-333). Returns (entropy[float32-like], histogram)."""
+    w = _codebook_weights(values, codebook, v, gamma)
+    hist = w.mean(dim=0)
+    hist = torch.clamp(hist, min=1e-9)
+    hist = hist / hist.sum()
+    ent = -(hist * torch.log(hist)).sum() / 0.6931
+    return ent.to(values.dtype), hist
+
+
+# ---------------------------------------------------------------------------------------------
+# ConstrainedConv2D (models/layers.py:45-57)
+def constrained_kernel(kernel, mask, strength=100.0):
+    nf = kernel * (1 - mask)
+    df = nf.sum(dim=(0, 1, 2)).reshape(1, 1, 1, -1)
+    nf = strength * nf / df
+    return nf - strength * mask
+
+
+def constrained_conv(x, kernel, mask, strength=100.0):
+    nf = constrained_kernel(kernel, mask, strength)
+    xp = pad2d(x, 2, 'SYMMETRIC')
+    return conv2d(xp, nf, None, 1, 'VALID')
+
+
+# ---------------------------------------------------------------------------------------------
+# classifier head + losses
+def sparse_ce_from_probs(probs, labels):
+    """tf.keras.losses.SparseCategoricalCrossentropy() on probabilities, eager path
+       (keras/backend.py sparse_categorical_crossentropy, from_logits=False): clip to [1e-7, 1-1e-7],
+       log, then sparse_softmax_cross_entropy_with_logits(log p) ; reduction = mean over the batch."""
+    eps = 1e-7
+    p = torch.clamp(probs, eps, 1 - eps)
+    logp = torch.log(p)
+    lse = torch.logsumexp(logp, dim=1)
+    idx = torch.as_tensor(labels, dtype=torch.long)
+    return (lse - logp[torch.arange(p.shape[0]), idx]).mean()
+
+
+def mse255(a, b):
+    """helpers/tf_helpers.py:31-32"""
+    return ((255 * a - 255 * b) ** 2).mean()
+
+
+def mae255(a, b):
+    """helpers/tf_helpers.py:35-36"""
+    return (255 * a - 255 * b).abs().mean()
+
+
+def l2_loss(d):
+    """tf.nn.l2_loss = sum(d^2)/2"""
+    return (d ** 2).sum() / 2
+
+
+# ---------------------------------------------------------------------------------------------
+# Keras Adam (tf.keras.optimizers.Adam defaults: beta1 .9, beta2 .999, eps 1e-7, no amsgrad)
+def adam_step(params, grads, m, v, t, lr, beta1=0.9, beta2=0.999, eps=1e-7):
+    """In-place on lists of tensors. t is the 1-based step count AFTER increment.
+       theta -= lr * sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps)     (epsilon OUTSIDE the corrected sqrt)."""
+    lr_t = lr * math.sqrt(1 - beta2 ** t) / (1 - beta1 ** t)
+    for p, g, mi, vi in zip(params, grads, m, v):
+        mi.mul_(beta1).add_(g, alpha=1 - beta1)
+        vi.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+        p.sub_(lr_t * mi / (vi.sqrt() + eps))
