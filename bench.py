@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""
+bench.py - raw patches/s (forward + backward + Adam) of the imaging channel  UNet ISP -> manipulations -> dJPEG -> FAN
+at 256x256 RGB (BASELINE.json metric; workload = configs[3] = SURVEY 8d "C4").
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" = ManipulationClassification.training_step on a synthetic batch already resident in HBM: B raw patches
+(B,128,128,4) -> UNet -> (5B,256,256,3) [native, sharpen:1, resample:50, gaussian:0.83, jpeg:80] -> dJPEG(80) -> FAN ->
+CE + 0.1 * mse255 -> backward to the UNet and FAN weights -> gradient all-reduce (N>1) -> Keras Adam.  Weak scaling:
+every rank processes its own B patches.  Prints ONE JSON line (rank 0).
+
+Extra objects on the line:
+  roofline     - dominant kernel (the FAN 5x5 convolution family) timed live with HIP events on the launch stream:
+                 algorithmic FLOPs of one launch / average launch time, against the f32 MFMA peak
+  cpu_baseline - the oracle's CPU port (torch float32, all host cores) of the SAME step on a bounded sample
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+F32_MFMA_PEAK_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+GMAC_FWD_PER_PATCH = 3.079 + 5 * 2.705          # UNet + 5 x FAN, forward
+GFLOP_PER_PATCH = 2 * 3 * GMAC_FWD_PER_PATCH    # fwd + dgrad + wgrad
+
+
+def synthetic_batch(b, raw_patch, seed):
+    from util import bayer_from_rgb, natural_images
+    rgb = natural_images(b, 2 * raw_patch, 2 * raw_patch, seed=seed)
+    return bayer_from_rgb(rgb), rgb
+
+
+def time_dominant_kernel(dev, b_images, reps=5):
+    """FAN conv3 forward (5x5, 64 -> 128 @ 64x64, the 839 MMAC/image layer) - one launch, HIP events on the
+    stream it runs on (the kernels are launched on torch's current stream, so torch.cuda.Event brackets them)."""
+    from neural_imaging_amd import ops
+    n = b_images
+    x = torch.randn((n, 64, 64, 64), device=dev)
+    w = torch.randn((5, 5, 64, 128), device=dev) * 0.05
+    b = torch.zeros((128,), device=dev)
+    out = torch.empty((n, 64, 64, 128), device=dev)
+    ops.conv2d(x, w, b, act='leaky_relu', out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.conv2d(x, w, b, act='leaky_relu', out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flops = 2.0 * 25 * 64 * 128 * 64 * 64 * n
+    return {'kernel': 'conv_fwd_kernel<5,1,16,16,1,64,8> (FAN conv3 fwd, {}x64x64x64->128)'.format(n),
+            'flops_per_launch': flops, 'ms_per_launch': ms, 'tflops': flops / (ms * 1e-3) / 1e12}
+
+
+def cpu_baseline(raw_patch, budget_s=20.0):
+    """Oracle port on the host cores: torch float32 CPU, same step, B=2 raw patches, bounded to ~budget_s."""
+    from oracle import workflow as owf
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    b = 2
+    wf = owf.Workflow(trainable=('nip',), jpeg_quality=80, dtype=torch.float32)
+    raw, rgb = synthetic_batch(b, raw_patch, seed=99)
+    bx, by = torch.from_numpy(raw), torch.from_numpy(rgb)
+    wf.training_step(bx, by, lambda_nip=0.1, learning_rate=1e-4)       # warm-up
+    t0, steps = time.time(), 0
+    while steps < 3 and (time.time() - t0) < budget_s:
+        wf.training_step(bx, by, lambda_nip=0.1, learning_rate=1e-4)
+        steps += 1
+    dt = (time.time() - t0) / max(steps, 1)
+    return {'value': b / dt, 'unit': 'patches/s', 'cores': cores, 'kind': 'port',
+            'sample': '{} step(s) of B={} raw patches {}x{}x4, torch-CPU float32 restatement (TF2 unavailable)'.format(
+                steps, b, raw_patch, raw_patch)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=32, help='raw patches per GPU per step')
+    ap.add_argument('--raw-patch', type=int, default=128)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    importlib.import_module('neural-imaging_amd')
+    from neural_imaging_amd import _lib, parallel
+    from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
+
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU; there is no CPU fallback')
+    world = parallel.init_from_env()
+    rank = parallel.rank()
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    _lib.load()
+    if world != args.gpus and rank == 0:
+        print('warning: --gpus {} but WORLD_SIZE {}'.format(args.gpus, world), file=sys.stderr)
+
+    dist_cfg = {'downsampling': 'none', 'compression': 'jpeg', 'compression_params': {'quality': 80, 'codec': 'soft'}}
+    wf = ManipulationClassification('UNet', manipulations=['sharpen:1', 'resample:50', 'gaussian:0.83', 'jpeg:80'],
+                                    distribution=dist_cfg, trainable={'nip'}, raw_patch_size=args.raw_patch,
+                                    device=dev, nan_check='deferred')
+    raw, rgb = synthetic_batch(args.batch, args.raw_patch, seed=1234 + rank)
+    bx, by = torch.from_numpy(raw).to(dev), torch.from_numpy(rgb).to(dev)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        wf.training_step(bx, by, lambda_nip=0.1, learning_rate=1e-4)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, parts = wf.training_step(bx, by, lambda_nip=0.1, learning_rate=1e-4)
+    barrier()
+    dt = time.perf_counter() - t0
+    wf.check_nan()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms = 1e3 * dt / args.steps
+        value = world * args.batch * args.steps / dt
+        dom = time_dominant_kernel(dev, 5 * args.batch)
+        line = {
+            'metric': 'patches/s (fwd+bwd) ISP->JPEG->FAN @256^2', 'value': value, 'unit': 'patches/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic (natural-image-like RAW/RGB pairs, random-init weights)',
+            'config': {'workload': 'train_manipulation UNet->[native,sharpen:1,resample:50,gaussian:0.83,jpeg:80]->'
+                                   'dJPEG(QF80,soft)->FAN, ds none, trainable nip+fan, lambda_nip 0.1',
+                       'raw_patch': args.raw_patch, 'rgb_patch': 2 * args.raw_patch,
+                       'batch_per_gpu': args.batch, 'global_batch': world * args.batch, 'parallelism': 'dp%d' % world,
+                       'loss': float(loss), 'achieved_tflops_whole_step': value * GFLOP_PER_PATCH / 1e3},
+            'roofline': {'bound': 'mfma', 'achieved': dom['tflops'], 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': dom['tflops'] / F32_MFMA_PEAK_TFLOPS, 'traffic': None, 'kernel': dom['kernel'],
+                         'ms_per_launch': dom['ms_per_launch']},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line['cpu_baseline'] = cpu_baseline(args.raw_patch)
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

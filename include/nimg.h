@@ -1,0 +1,165 @@
+/*
+ * nimg.h - C ABI of libnimg.so: MI355X (gfx950) HIP kernels for the neural-imaging channel hot path
+ *          RAW -> UNet ISP -> manipulations -> differentiable JPEG -> FAN classifier, forward + backward.
+ *
+ * The reference (pkorus/neural-imaging, TF 2.1, pure Python) has NO FFI: its seam is the Python duck type
+ * TFModel (models/tfmodel.py:86-294).  This header is the native boundary underneath the build's Python mirror of
+ * that surface (neural-imaging_amd/models/ *.py): every entry point replaces one TensorFlow op call site of the
+ * reference, cited per function.  INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions (all entry points):
+ *   - plain C types only; every buffer is a CALLER-ALLOCATED DEVICE pointer (no hidden hipMalloc)
+ *   - tensors are NHWC float32 unless stated; weights in the Keras layouts the reference's checkpoints use:
+ *     Conv2D (kh,kw,Cin,Cout), Conv2DTranspose (kh,kw,Cout,Cin), Dense (in,out)
+ *   - asynchronous on `stream` (a hipStream_t passed as void*), no internal synchronisation, capturable in a hipGraph
+ *   - returns NIMG_OK (0) or a negative NIMG_ERR_* code; never throws, never exits
+ *   - re-entrant: no mutable global state (Q tables etc. are passed per call)
+ */
+#ifndef NIMG_H
+#define NIMG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NIMG_OK 0
+#define NIMG_ERR_ARG (-1)     /* invalid shape / null pointer / unsupported configuration */
+#define NIMG_ERR_LAUNCH (-2)  /* HIP launch failure (hipGetLastError) */
+#define NIMG_ERR_WORKSPACE (-3) /* workspace too small */
+
+/* library / ABI version, bumped on any signature change */
+int nimg_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Differentiable JPEG - replaces DifferentiableJPEG.call, models/jpeg.py:91-159, and the Quantization layer it uses,
+ * models/layers.py:118-134.  One fused kernel per direction (the reference runs ~25 TF ops).
+ * rounding modes = Quantization.rounding (models/layers.py:97): */
+#define NIMG_ROUND_ROUND 0    /* tf.round, no gradient            (layers.py:122-123) */
+#define NIMG_ROUND_SOFT 1     /* fwd round, bwd 1-cos(2 pi x)     (layers.py:126-128)  <- dJPEG default 'soft' */
+#define NIMG_ROUND_SIN 2      /* x - sin(2 pi x)/(2 pi)           (layers.py:125)     */
+#define NIMG_ROUND_HARMONIC 3 /* x - sin(2 pi x)/pi (taylor_terms=1; layers.py:130-134) */
+#define NIMG_ROUND_IDENTITY 4 /* layers.py:136-137 */
+
+/* x,y: (n,h,w,3) in [0,1]; h,w multiples of 8.   qtab: (3,8,8) float32 tables for Y,Cb,Cr (device).
+ * mask (optional, may be NULL): (n,h,w) uint8, bit c set <=> channel c was NOT clipped (needed by the backward).
+ * idx  (optional): (n,3,h/8,w/8,8,8) int16  rint(X/Q) quantisation indices - the bit-exact sub-contract.
+ * xdq  (optional): same shape float32, dequantised coefficients = 2nd output of the reference model (jpeg.py:159). */
+int nimg_djpeg_fwd(const float* x, float* y, const float* qtab, uint8_t* mask, int16_t* idx, float* xdq,
+                   int n, int h, int w, int rounding, void* stream);
+/* gx = d loss / d x given gy = d loss / d y.  Recomputes the forward DCT from x (no saved coefficients). */
+int nimg_djpeg_bwd(const float* x, const float* gy, const uint8_t* mask, const float* qtab, float* gx,
+                   int n, int h, int w, int rounding, void* stream);
+/* IJG quality scaling - replaces jpeg_qtable, compression/jpeg_helpers.py:264-305.  HOST function: out64 is a host
+ * pointer to 64 floats (row-major 8x8).  channel 0 = luma, >0 = chroma. */
+int nimg_jpeg_qtable(int quality, int channel, float* out64);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Convolutions on the matrix cores (float32 MFMA, exact f32).  Replace tf.keras.layers.Conv2D / tf.nn.conv2d call sites:
+ *   UNet  models/pipelines.py:191-192,207-208,216 ; FAN models/forensics.py:69,76 ; ConstrainedConv2D models/layers.py:56-57
+ *   TwitterDCN models/compression.py:221-237,247-265.
+ * in1/in2: the input may be split over two NHWC tensors with c1 + c2 channels (concat-free skip connections,
+ *          pipelines.py:206,211); in2 = NULL, c2 = 0 otherwise.   w: (ks,ks,c1+c2,o1+o2) HWIO.   bias: (o1+o2) or NULL.
+ * out1/out2: the output may be split the same way (o2 = 0 normally; used by the dgrad of a concat input).
+ * act_mask (optional): tensor shaped like out1; out1 is multiplied by LeakyReLU'(act_mask) - fuses the previous
+ *          layer's activation derivative into an input-gradient pass.
+ * pad_mode: 0 zeros, 1 SYMMETRIC, 2 REFLECT (tf.pad modes folded into the tile load).  act: 0 none, 1 LeakyReLU(alpha).
+ * Supported (ks,stride): (1,1) (3,1) (5,1) (2,2) (5,2).  hout/wout/pad_t/pad_l are explicit so TF's asymmetric SAME
+ * padding is the caller's choice.  Input gradients = this same entry point on nimg_conv_flip_weights output. */
+int nimg_conv2d_fwd(const float* in1, int c1, const float* in2, int c2, const float* w, const float* bias,
+                    float* out1, int o1, float* out2, int o2, const float* act_mask, int n, int h, int wd, int ks,
+                    int stride, int pad_t, int pad_l, int pad_mode, int hout, int wout, int act, float alpha,
+                    void* stream);
+/* wt[ks*ks-1-t][co][ci] = w[t][ci][co]: spatially flipped, channel-transposed weights for the input-gradient pass */
+int nimg_conv_flip_weights(const float* w, float* wt, int ks_h, int ks_w, int cin, int cout, void* stream);
+/* dw (ks,ks,c1+c2,cout) (+)= sum over pixels of in (x) dz - the weight half of tape.gradient (pipelines.py:84-88,
+ * forensics.py:118-124, workflows/manipulation_classification.py:280).  Deterministic split-K through `workspace`. */
+size_t nimg_conv2d_wgrad_workspace_bytes(int cin, int cout, int ks_h, int ks_w, int n, int hout, int wout);
+int nimg_conv2d_wgrad(const float* in1, int c1, const float* in2, int c2, const float* dz, int cout, float* dw,
+                      int n, int h, int wd, int ks, int stride, int pad_t, int pad_l, int pad_mode, int hout,
+                      int wout, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* db (cout) (+)= sum over npix pixels of dz (npix, cout) */
+size_t nimg_bias_grad_workspace_bytes(long npix, int cout);
+int nimg_bias_grad(const float* dz, float* db, long npix, int cout, int accumulate, void* workspace,
+                   size_t workspace_bytes, void* stream);
+/* Conv2DTranspose(k=2,s=2,SAME), kernel (2,2,cout,cin) - models/pipelines.py:205.  Its input gradient is
+ * nimg_conv2d_fwd(ks=2,stride=2) on the same kernel, its weight gradient nimg_conv2d_wgrad(ks=2,stride=2) with the
+ * roles of input and output gradient swapped (see neural-imaging_amd/models/pipelines.py). */
+int nimg_convt2x2_fwd(const float* x, const float* w, const float* bias, float* y, int n, int h, int wd, int cin,
+                      int cout, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Pooling / layout / element-wise */
+/* MaxPool2D 2x2 (pipelines.py:197 SAME, forensics.py:70 VALID; identical on even sizes) */
+int nimg_maxpool2_fwd(const float* x, float* y, int n, int h, int w, int c, void* stream);
+/* dz = (route dp to the FIRST arg-max of each window) [+ add] [* LeakyReLU'(yact)]; add may alias dz */
+int nimg_maxpool2_bwd(const float* dp, const float* yact, const float* add, float* dz, int n, int h, int w, int c,
+                      int apply_lrelu_mask, float alpha, void* stream);
+/* y = [clip01](scale * depth_to_space_DCR(x, 2) + shift); x (n,h,w,4*cout) -> y (n,2h,2w,cout).
+ * pipelines.py:218-223 (scale 1, shift 0, clip 1), compression.py:248,263,266-271.  The clip is straight-through:
+ * the backward is dx = scale * space_to_depth(dy). */
+int nimg_d2s_clip_fwd(const float* x, float* y, int n, int h, int w, int cout, float scale, float shift, int clip,
+                      void* stream);
+int nimg_d2s_clip_bwd(const float* dy, float* dx, int n, int h, int w, int cout, float scale, void* stream);
+int nimg_lrelu_bwd(const float* dy, const float* yact, float* dz, long count, float alpha, void* stream);
+int nimg_add(const float* a, const float* b, float* out, long count, void* stream);
+/* avg_pool downsampling of the channel, workflows/manipulation_classification.py:235 */
+int nimg_avgpool_fwd(const float* x, float* y, int n, int h, int w, int c, int factor, void* stream);
+int nimg_avgpool_bwd(const float* dy, float* dx, int n, int h, int w, int c, int factor, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Losses, classifier head, optimiser */
+/* helpers/tf_helpers.py:31-32  loss = mean((255a - 255b)^2); grad_a (+)= grad_scale * dloss/da (grad_a may be NULL) */
+size_t nimg_mse255_workspace_bytes(void);
+int nimg_mse255(const float* a, const float* b, float* loss, float* grad_a, long count, float grad_scale,
+                int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* FAN head, models/forensics.py:80-94: GAP -> Dense(k, softmax) -> SparseCategoricalCrossentropy on probabilities
+ * (Keras eager semantics: clip to [1e-7, 1-1e-7], renormalise).  act (n,hw,c) is the 1x1-conv output AFTER LeakyReLU.
+ * labels may be NULL (inference: only gap/probs are written).  loss_scale = 1/batch (mean reduction). */
+int nimg_fan_head_fwd(const float* act, const float* w, const float* b, const int* labels, float* gap, float* probs,
+                      float* loss_per, float* dlogits, int n, int hw, int c, int k, float loss_scale, void* stream);
+/* dact = gradient wrt the 1x1 conv PRE-activation (LeakyReLU' fused), dw (c,k), db (k), loss (1) */
+int nimg_fan_head_bwd(const float* act, const float* gap, const float* w, const float* dlogits,
+                      const float* loss_per, float* dact, float* dw, float* db, float* loss, int n, int hw, int c,
+                      int k, float loss_scale, float alpha, void* stream);
+/* tf.keras.optimizers.Adam over a flat buffer: theta -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps); g is pre-scaled
+ * by grad_scale (e.g. 1/world_size after a sum all-reduce).  step is the 1-based iteration count.  skip_flag (optional
+ * device int): when non-zero the update is skipped - the device-side form of the NaN guard at workflows/...:281-283. */
+int nimg_adam_step(float* params, const float* grads, float* m, float* v, long count, float lr, float beta1,
+                   float beta2, float eps, int step, float grad_scale, const int* skip_flag, void* stream);
+/* flag[0] |= 1 if any gradient is NaN (device-side version of workflows/manipulation_classification.py:281-282) */
+int nimg_nan_flag(const float* g, long count, int* flag, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * ConstrainedConv2D kernel re-normalisation, models/layers.py:45-53 (ks=5, channels=3, strength=100) */
+int nimg_constrained_kernel_fwd(const float* kernel, float* nf, int ks, int channels, float strength, void* stream);
+int nimg_constrained_kernel_bwd(const float* kernel, const float* dnf, float* dkernel, int ks, int channels,
+                                float strength, void* stream);
+/* backward of tf.pad(SYMMETRIC|REFLECT): fold a gradient on the padded domain (n,h+2p,w+2p,c) onto (n,h,w,c) */
+int nimg_fold_pad(const float* dpad, float* dx, int n, int h, int w, int c, int pad, int pad_mode, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Photo manipulations, helpers/tf_helpers.py.  Images (n,h,w,3).  mask: (n,h,w) uint8 clip mask written by the forward
+ * (bit c set <=> channel c not clipped), consumed by the backward. */
+/* manipulation_gaussian :113-125 - gk25 = 5x5 normalised kernel (device), REFLECT pad */
+int nimg_gaussian_fwd(const float* x, float* y, uint8_t* mask, const float* gk25, int n, int h, int w, int clip,
+                      void* stream);
+int nimg_gaussian_bwd(const float* dy, const uint8_t* mask, float* dx, const float* gk25, int n, int h, int w,
+                      void* stream);
+/* manipulation_sharpen(hsv=True) :156-184 - gk9 = 3x3 H/V filter (device); aux_hsv (n,h,w,3) scratch kept between
+ * forward and backward (filtered HSV; overwritten by the backward) */
+int nimg_sharpen_fwd(const float* x, float* y, float* aux_hsv, uint8_t* mask, const float* gk9, int n, int h, int w,
+                     void* stream);
+int nimg_sharpen_bwd(const float* x, const float* dy, float* aux_hsv, const uint8_t* mask, float* dx,
+                     const float* gk9, int n, int h, int w, void* stream);
+/* banded linear operator along one spatial axis (CSR rows = output index): manipulation_resample :68-76 and
+ * tf.image.resize bilinear down-sampling are two such passes; their backward uses the transposed CSR. */
+int nimg_sparse_axis_apply(const float* in, float* out, const int* rowptr, const int* col, const float* val, int n,
+                           int hin, int win, int c, int axis, int out_size, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NIMG_H */

@@ -1,0 +1,84 @@
+"""
+ctypes binding of libnimg.so (the C ABI declared in include/nimg.h).
+
+The library is built in-tree by neural-imaging_amd/csrc/build.sh (hipcc --offload-arch=gfx950).  There is NO
+fallback: if the library is missing, or an entry point returns an error code, a RuntimeError is raised.
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_long, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libnimg.so')
+
+P = c_void_p  # every device pointer / stream is passed as an opaque pointer
+
+# name -> (restype, argtypes); must list every symbol of include/nimg.h (tests/test_abi.py checks this)
+PROTOTYPES = {
+    'nimg_abi_version': (c_int, []),
+    'nimg_djpeg_fwd': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    'nimg_djpeg_bwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    'nimg_jpeg_qtable': (c_int, [c_int, c_int, P]),
+    'nimg_conv2d_fwd': (c_int, [P, c_int, P, c_int, P, P, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int,
+                                c_int, c_int, c_int, c_int, c_int, c_int, c_float, P]),
+    'nimg_conv_flip_weights': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'nimg_conv2d_wgrad_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    'nimg_conv2d_wgrad': (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                  c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    'nimg_bias_grad_workspace_bytes': (c_size_t, [c_long, c_int]),
+    'nimg_bias_grad': (c_int, [P, P, c_long, c_int, c_int, P, c_size_t, P]),
+    'nimg_convt2x2_fwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'nimg_maxpool2_fwd': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'nimg_maxpool2_bwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, P]),
+    'nimg_d2s_clip_fwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, P]),
+    'nimg_d2s_clip_bwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, P]),
+    'nimg_lrelu_bwd': (c_int, [P, P, P, c_long, c_float, P]),
+    'nimg_add': (c_int, [P, P, P, c_long, P]),
+    'nimg_avgpool_fwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'nimg_avgpool_bwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'nimg_mse255_workspace_bytes': (c_size_t, []),
+    'nimg_mse255': (c_int, [P, P, P, P, c_long, c_float, c_int, P, c_size_t, P]),
+    'nimg_fan_head_fwd': (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
+    'nimg_fan_head_bwd': (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P]),
+    'nimg_adam_step': (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_int, c_float, P, P]),
+    'nimg_nan_flag': (c_int, [P, c_long, P, P]),
+    'nimg_constrained_kernel_fwd': (c_int, [P, P, c_int, c_int, c_float, P]),
+    'nimg_constrained_kernel_bwd': (c_int, [P, P, P, c_int, c_int, c_float, P]),
+    'nimg_fold_pad': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    'nimg_gaussian_fwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    'nimg_gaussian_bwd': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    'nimg_sharpen_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
+    'nimg_sharpen_bwd': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, P]),
+    'nimg_sparse_axis_apply': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+}
+
+ERRORS = {-1: 'NIMG_ERR_ARG (invalid argument / unsupported configuration)',
+          -2: 'NIMG_ERR_LAUNCH (HIP kernel launch failed)',
+          -3: 'NIMG_ERR_WORKSPACE (workspace too small)'}
+
+_lib = None
+
+
+def load():
+    """Load libnimg.so (once) and attach prototypes.  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError('libnimg.so not found at {} - build it with neural-imaging_amd/csrc/build.sh '
+                           '(or __graft_entry__.build()); there is no CPU fallback'.format(LIB_PATH))
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError here == ABI drift; let it propagate
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Call an int-returning entry point and raise on a non-zero status."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise RuntimeError('{} failed: {}'.format(name, ERRORS.get(rc, rc)))
+    return rc

@@ -1,0 +1,285 @@
+// NHWC implicit-GEMM convolution on the CDNA4 matrix cores, float32 in / float32 accumulate
+// (v_mfma_f32_32x32x2_f32: exact f32, bitwise an fmaf chain - the parity mode of the channel).
+//
+// Replaces the tf.keras.layers.Conv2D call sites of the reference:
+//   UNet 3x3 s1 SAME (+bias +LeakyReLU)      models/pipelines.py:191-192,207-208,216
+//   FAN  5x5 s1 SAME (+bias +LeakyReLU), 1x1 models/forensics.py:69,76
+//   DCN  5x5 s2 SAME (TF asymmetric pad), 3x3 models/compression.py:221-237,247-265
+// and their input gradients (dgrad = the same kernel run on flipped/transposed weights, see
+// nimg_conv_flip_weights), with the LeakyReLU derivative of the PREVIOUS layer fused in the epilogue.
+//
+// im2col-free: GEMM  M = output pixels (32 per MFMA tile = one 2-D patch row group), N = Cout, K = taps x Cin.
+//   A operand  A[i][k] = in[pixel_i + tap][ci0 + k]   read from an LDS halo tile stored CHANNEL-MAJOR
+//              [ci][pixel] (plane stride = 2 mod 32 banks): lanes 0-31 read 32 consecutive pixels of channel k,
+//              lanes 32-63 the same pixels of channel k+1  -> conflict-free ds_read_b32
+//   B operand  B[k][j] = w[tap][ci0 + k][co0 + j]      LDS [tap][ci][co], lanes read consecutive co
+//   HBM reads  float4 per lane along the channel axis (NHWC => coalesced), transposed on the LDS write.
+//   Concat-free: the input may be split over two tensors (UNet skip connections, pipelines.py:206,211),
+//   the output over two tensors (dgrad of a concat input).
+#include "common.h"
+
+namespace {
+
+using namespace nimg;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvParams {
+    const float* in1;
+    const float* in2;
+    const float* w;       // [KS*KS][Cin][Cout]
+    const float* bias;    // [Cout] or nullptr
+    float* out1;
+    float* out2;
+    const float* act1;    // optional saved activation, same shape as out1: out1 *= lrelu'(act1)
+    int C1, C2, O1, O2;   // Cin = C1 + C2, Cout = O1 + O2
+    int N, H, W, Hout, Wout, pad_t, pad_l;
+    int tiles_y, tiles_x;
+    int act;              // 0 none, 1 leaky relu
+    int pad_mode;         // 0 zeros, 1 SYMMETRIC, 2 REFLECT (tf.pad modes folded into the tile load)
+    float alpha;
+};
+
+template <int KS, int STRIDE, int TH, int TW, int NB, int TN, int CK, bool VEC>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
+    constexpr int THH = (TH - 1) * STRIDE + KS, TWH = (TW - 1) * STRIDE + KS;
+    constexpr int NPIXH = NB * THH * TWH;
+    constexpr int PS = ((NPIXH + 31) / 32) * 32 + 2;
+    constexpr int MFRAGS = NB * TH * TW / 32;
+    constexpr int NFRAGS = TN / 32;
+    constexpr int WAVES_M = MFRAGS >= 4 ? 4 : MFRAGS;
+    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int MI = MFRAGS / WAVES_M;
+    constexpr int NI = NFRAGS / WAVES_N;
+    constexpr int TAPS = KS * KS;
+    static_assert(MFRAGS % WAVES_M == 0 && NFRAGS % WAVES_N == 0 && NI >= 1, "bad tile configuration");
+    static_assert((NB * TH * TW) % 32 == 0 && CK % 4 == 0, "bad tile configuration");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;                 // [CK][PS]
+    float* sB = smem + CK * PS;       // [TAPS][CK][TN]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
+    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+    const int Cin = p.C1 + p.C2, Cout = p.O1 + p.O2;
+
+    // block -> (co tile, spatial tile, image group); co tile fastest so neighbours reuse the input tile in L2/MALL
+    const int cot = (Cout + TN - 1) / TN;
+    int bid = blockIdx.x;
+    const int co0 = (bid % cot) * TN;
+    bid /= cot;
+    const int tiles = p.tiles_y * p.tiles_x;
+    const int tile = bid % tiles, grp = bid / tiles;
+    const int ty0 = (tile / p.tiles_x) * TH, tx0 = (tile % p.tiles_x) * TW;
+    const int iy0 = ty0 * STRIDE - p.pad_t, ix0 = tx0 * STRIDE - p.pad_l;
+
+    // per-lane A base offsets (pixel part) for its MI fragments
+    int abase[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int P = (wm * MI + mi) * 32 + (lane & 31);
+        const int img = P / (TH * TW), rem = P % (TH * TW);
+        abase[mi] = img * (THH * TWH) + (rem / TW) * STRIDE * TWH + (rem % TW) * STRIDE;
+    }
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[mi][ni][j] = 0.0f;
+
+    for (int ci0 = 0; ci0 < Cin; ci0 += CK) {
+        __syncthreads();   // previous chunk's MFMA reads are done before the tiles are overwritten
+        // ---- stage A: halo tile of CK input channels, transposed to channel-major
+        if (VEC) {
+            constexpr int C4 = CK / 4;
+            for (int item = tid; item < NPIXH * C4; item += 256) {
+                const int pix = item / C4, c = ci0 + (item % C4) * 4;
+                const int img = pix / (THH * TWH), rem = pix % (THH * TWH);
+                int gy = iy0 + rem / TWH, gx = ix0 + rem % TWH;
+                const int n = grp * NB + img;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (n < p.N && c < Cin && map_coord(gy, p.H, p.pad_mode) && map_coord(gx, p.W, p.pad_mode)) {
+                    const long pixoff = ((long)n * p.H + gy) * p.W + gx;
+                    v = c < p.C1 ? *reinterpret_cast<const float4*>(p.in1 + pixoff * p.C1 + c)
+                                 : *reinterpret_cast<const float4*>(p.in2 + pixoff * p.C2 + (c - p.C1));
+                }
+                float* d = sA + ((item % C4) * 4) * PS + pix;
+                d[0] = v.x; d[PS] = v.y; d[2 * PS] = v.z; d[3 * PS] = v.w;
+            }
+        } else {
+            for (int item = tid; item < NPIXH * CK; item += 256) {
+                const int pix = item / CK, k = item % CK, c = ci0 + k;
+                const int img = pix / (THH * TWH), rem = pix % (THH * TWH);
+                int gy = iy0 + rem / TWH, gx = ix0 + rem % TWH;
+                const int n = grp * NB + img;
+                float v = 0.f;
+                if (n < p.N && c < Cin && map_coord(gy, p.H, p.pad_mode) && map_coord(gx, p.W, p.pad_mode)) {
+                    const long pixoff = ((long)n * p.H + gy) * p.W + gx;
+                    v = c < p.C1 ? p.in1[pixoff * p.C1 + c] : p.in2[pixoff * p.C2 + (c - p.C1)];
+                }
+                sA[k * PS + pix] = v;
+            }
+        }
+        // ---- stage B: weights of this channel chunk, all taps
+        if (VEC) {
+            constexpr int J4 = TN / 4;
+            for (int item = tid; item < TAPS * CK * J4; item += 256) {
+                const int j = (item % J4) * 4, k = (item / J4) % CK, tap = item / (J4 * CK);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ci0 + k < Cin && co0 + j < Cout)
+                    v = *reinterpret_cast<const float4*>(p.w + ((long)tap * Cin + ci0 + k) * Cout + co0 + j);
+                *reinterpret_cast<float4*>(sB + (tap * CK + k) * TN + j) = v;
+            }
+        } else {
+            for (int item = tid; item < TAPS * CK * TN; item += 256) {
+                const int j = item % TN, k = (item / TN) % CK, tap = item / (TN * CK);
+                float v = 0.f;
+                if (ci0 + k < Cin && co0 + j < Cout) v = p.w[((long)tap * Cin + ci0 + k) * Cout + co0 + j];
+                sB[(tap * CK + k) * TN + j] = v;
+            }
+        }
+        __syncthreads();
+        // ---- MFMA: taps x channel pairs
+        const int kpairs = min(CK, (Cin - ci0 + 1) & ~1) / 2;
+        const float* aL = sA + (lane >> 5) * PS;
+        const float* bL = sB + (lane >> 5) * TN + wn * NI * 32 + (lane & 31);
+#pragma unroll 1
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int toff = (tap / KS) * TWH + (tap % KS);
+            for (int kp = 0; kp < kpairs; ++kp) {
+                float a[MI], b[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) a[mi] = aL[(2 * kp) * PS + abase[mi] + toff];
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) b[ni] = bL[(tap * CK + 2 * kp) * TN + ni * 32];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: bias, activation, optional lrelu' mask of the previous layer, NHWC store (128 B per half-wave)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int co = co0 + (wn * NI + ni) * 32 + (lane & 31);
+        if (co >= Cout) continue;
+        const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int row = (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5);
+                const int P = (wm * MI + mi) * 32 + row;
+                const int img = P / (TH * TW), rem = P % (TH * TW);
+                const int oy = ty0 + rem / TW, ox = tx0 + rem % TW, n = grp * NB + img;
+                if (n >= p.N || oy >= p.Hout || ox >= p.Wout) continue;
+                const long pixoff = ((long)n * p.Hout + oy) * p.Wout + ox;
+                float v = acc[mi][ni][j] + bv;
+                if (p.act == 1) v = lrelu(v, p.alpha);
+                if (co < p.O1) {
+                    if (p.act1) v *= (p.act1[pixoff * p.O1 + co] > 0.f ? 1.0f : p.alpha);
+                    p.out1[pixoff * p.O1 + co] = v;
+                } else {
+                    p.out2[pixoff * p.O2 + (co - p.O1)] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int KS, int STRIDE, int TH, int TW, int NB, int TN, int CK, bool VEC>
+int launch_conv(const ConvParams& p, hipStream_t stream) {
+    constexpr int THH = (TH - 1) * STRIDE + KS, TWH = (TW - 1) * STRIDE + KS;
+    constexpr int NPIXH = NB * THH * TWH;
+    constexpr int PS = ((NPIXH + 31) / 32) * 32 + 2;
+    constexpr size_t lds = (size_t)(CK * PS + KS * KS * CK * TN) * sizeof(float);
+    ConvParams q = p;
+    q.tiles_y = cdiv(p.Hout, TH);
+    q.tiles_x = cdiv(p.Wout, TW);
+    const int Cout = p.O1 + p.O2;
+    const long blocks = (long)cdiv(Cout, TN) * q.tiles_y * q.tiles_x * cdiv(p.N, NB);
+    auto kern = conv_fwd_kernel<KS, STRIDE, TH, TW, NB, TN, CK, VEC>;
+    static bool attr_set = false;   // opt in to > 64 KiB dynamic LDS once per instantiation
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, q);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+template <int KS, int STRIDE, int CK>
+int dispatch_tiles(const ConvParams& p, bool vec, hipStream_t stream) {
+    const int Cout = p.O1 + p.O2;
+    const bool small = (p.Hout <= 8 && p.Wout <= 8);
+    // narrow N tile when the problem is short of workgroups (keeps >= ~2 blocks per CU)
+    const long blocks64 = (long)cdiv(Cout, 64) * cdiv(p.Hout, small ? 8 : 16) * cdiv(p.Wout, small ? 8 : 16) *
+                          cdiv(p.N, small ? 4 : 1);
+    const bool tn32 = (Cout <= 32) || (blocks64 < 512 && Cout % 64 != 0) || (blocks64 < 384);
+#define NIMG_LAUNCH(TH_, TW_, NB_, TN_)                                                            \
+    (vec ? launch_conv<KS, STRIDE, TH_, TW_, NB_, TN_, CK, true>(p, stream)                          \
+         : launch_conv<KS, STRIDE, TH_, TW_, NB_, TN_, CK, false>(p, stream))
+    if (small) return tn32 ? NIMG_LAUNCH(8, 8, 4, 32) : NIMG_LAUNCH(8, 8, 4, 64);
+    return tn32 ? NIMG_LAUNCH(16, 16, 1, 32) : NIMG_LAUNCH(16, 16, 1, 64);
+#undef NIMG_LAUNCH
+}
+
+__global__ void flip_weights_kernel(const float* __restrict__ w, float* __restrict__ wt, int taps, int cin,
+                                    int cout) {
+    // wt[taps-1-t][co][ci] = w[t][ci][co]
+    const long total = (long)taps * cin * cout;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % cin);
+        const int co = (int)((i / cin) % cout);
+        const int t = (int)(i / ((long)cin * cout));
+        wt[i] = w[((long)(taps - 1 - t) * cin + ci) * cout + co];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int nimg_conv2d_fwd(const float* in1, int c1, const float* in2, int c2, const float* w, const float* bias,
+                    float* out1, int o1, float* out2, int o2, const float* act_mask, int n, int h, int wd, int ks,
+                    int stride, int pad_t, int pad_l, int pad_mode, int hout, int wout, int act, float alpha,
+                    void* stream) {
+    if (!in1 || !w || !out1 || c1 <= 0 || c2 < 0 || o1 <= 0 || o2 < 0 || n < 0 || h <= 0 || wd <= 0) return NIMG_ERR_ARG;
+    if ((c2 > 0 && !in2) || (o2 > 0 && !out2) || hout <= 0 || wout <= 0 || pad_t < 0 || pad_l < 0) return NIMG_ERR_ARG;
+    if (act < 0 || act > 1 || pad_mode < 0 || pad_mode > 2) return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    ConvParams p;
+    p.in1 = in1; p.in2 = in2; p.w = w; p.bias = bias; p.out1 = out1; p.out2 = out2; p.act1 = act_mask;
+    p.C1 = c1; p.C2 = c2; p.O1 = o1; p.O2 = o2; p.N = n; p.H = h; p.W = wd; p.Hout = hout; p.Wout = wout;
+    p.pad_t = pad_t; p.pad_l = pad_l; p.tiles_y = p.tiles_x = 0; p.act = act; p.alpha = alpha; p.pad_mode = pad_mode;
+    const bool vec = (c1 % 4 == 0) && (c2 % 4 == 0) && ((o1 + o2) % 4 == 0);
+    hipStream_t s = (hipStream_t)stream;
+    if (stride == 1) {
+        if (ks == 1) return dispatch_tiles<1, 1, 16>(p, vec, s);
+        if (ks == 3) return dispatch_tiles<3, 1, 16>(p, vec, s);
+        if (ks == 5) return dispatch_tiles<5, 1, 8>(p, vec, s);
+    } else if (stride == 2) {
+        if (ks == 2) return dispatch_tiles<2, 2, 16>(p, vec, s);
+        if (ks == 5) return dispatch_tiles<5, 2, 8>(p, vec, s);
+    }
+    return NIMG_ERR_ARG;
+}
+
+int nimg_conv_flip_weights(const float* w, float* wt, int ks_h, int ks_w, int cin, int cout, void* stream) {
+    if (!w || !wt || ks_h <= 0 || ks_w <= 0 || cin <= 0 || cout <= 0) return NIMG_ERR_ARG;
+    const long total = (long)ks_h * ks_w * cin * cout;
+    const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    hipLaunchKernelGGL(flip_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, wt, ks_h * ks_w, cin,
+                       cout);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+}  // extern "C"

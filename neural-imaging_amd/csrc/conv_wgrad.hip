@@ -1,0 +1,285 @@
+// Weight (and bias) gradients of the NHWC convolutions on the CDNA4 matrix cores, float32.
+//
+//   dw[tap][ci][co] = sum_{n,y,x} in[n, y*s + ky - pt, x*s + kx - pl, ci] * dz[n, y, x, co]
+//
+// i.e. the tape.gradient(..., weights) half of the reference's training steps
+// (models/pipelines.py:84-88, models/forensics.py:118-124, workflows/manipulation_classification.py:280).
+//
+// GEMM view: M = ci (32 / MFMA tile), N = co (32 / tile), K = output pixels (2 per v_mfma_f32_32x32x2_f32).
+// Both operands are read from LDS tiles kept in their natural NHWC order (channel contiguous), so staging is a straight
+// float4 copy and the per-lane ds_read_b32 is conflict-free (lanes 0-31 = 32 consecutive channels of one pixel, lanes
+// 32-63 the next pixel).  The dz fragment is shared by all taps; the taps are split over the 4 waves of a workgroup so
+// the accumulators (taps/4 x 2 x 16 registers) stay in the register file for the whole K loop.
+// Split-K over (image, tile) ranges: every workgroup writes its partial dw to a workspace slab and a second kernel
+// reduces the slabs in a fixed order (deterministic; no float atomics) and also produces the bias gradient.
+#include "common.h"
+
+namespace {
+
+using namespace nimg;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgradParams {
+    const float* in1;
+    const float* in2;
+    const float* dz;
+    float* partial;       // [splits][taps][Cin][Cout]
+    int C1, C2, Cout;
+    int N, H, W, Hout, Wout, pad_t, pad_l;
+    int tiles_y, tiles_x, splits, work_per_split, pad_mode;
+};
+
+constexpr int WG_TH = 8, WG_TW = 16;     // output-pixel tile per K iteration
+constexpr int CI_T = 32, CO_T = 64;      // dw block per workgroup
+
+template <int KS, int STRIDE, bool VEC>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+    constexpr int TAPS = KS * KS;
+    constexpr int NT = (TAPS + 3) / 4;                 // taps per wave
+    constexpr int THH = (WG_TH - 1) * STRIDE + KS, TWH = (WG_TW - 1) * STRIDE + KS;
+    constexpr int NPIXH = THH * TWH, NPIX = WG_TH * WG_TW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sI = smem;                  // [NPIXH][CI_T]
+    float* sZ = smem + NPIXH * CI_T;   // [NPIX][CO_T]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
+    const int Cin = p.C1 + p.C2;
+    const int cib = (Cin + CI_T - 1) / CI_T, cob = (p.Cout + CO_T - 1) / CO_T;
+    int bid = blockIdx.x;
+    const int ci0 = (bid % cib) * CI_T;
+    bid /= cib;
+    const int co0 = (bid % cob) * CO_T;
+    const int split = bid / cob;
+
+    f32x16 acc[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[t][ni][j] = 0.0f;
+
+    const int tiles = p.tiles_y * p.tiles_x;
+    const long work_total = (long)p.N * tiles;
+    const long w_begin = (long)split * p.work_per_split;
+    const long w_end = min(work_total, w_begin + p.work_per_split);
+
+    for (long wk = w_begin; wk < w_end; ++wk) {
+        const int n = (int)(wk / tiles), tile = (int)(wk % tiles);
+        const int ty0 = (tile / p.tiles_x) * WG_TH, tx0 = (tile % p.tiles_x) * WG_TW;
+        const int iy0 = ty0 * STRIDE - p.pad_t, ix0 = tx0 * STRIDE - p.pad_l;
+        __syncthreads();
+        // ---- stage the input halo tile [pixel][ci] and the dz tile [pixel][co]
+        if (VEC) {
+            for (int item = tid; item < NPIXH * (CI_T / 4); item += 256) {
+                const int pix = item / (CI_T / 4), c = ci0 + (item % (CI_T / 4)) * 4;
+                int gy = iy0 + pix / TWH, gx = ix0 + pix % TWH;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < Cin && map_coord(gy, p.H, p.pad_mode) && map_coord(gx, p.W, p.pad_mode)) {
+                    const long pixoff = ((long)n * p.H + gy) * p.W + gx;
+                    v = c < p.C1 ? *reinterpret_cast<const float4*>(p.in1 + pixoff * p.C1 + c)
+                                 : *reinterpret_cast<const float4*>(p.in2 + pixoff * p.C2 + (c - p.C1));
+                }
+                *reinterpret_cast<float4*>(sI + pix * CI_T + (item % (CI_T / 4)) * 4) = v;
+            }
+            for (int item = tid; item < NPIX * (CO_T / 4); item += 256) {
+                const int pix = item / (CO_T / 4), c = co0 + (item % (CO_T / 4)) * 4;
+                const int oy = ty0 + pix / WG_TW, ox = tx0 + pix % WG_TW;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (oy < p.Hout && ox < p.Wout && c < p.Cout)
+                    v = *reinterpret_cast<const float4*>(p.dz + (((long)n * p.Hout + oy) * p.Wout + ox) * p.Cout + c);
+                *reinterpret_cast<float4*>(sZ + pix * CO_T + (item % (CO_T / 4)) * 4) = v;
+            }
+        } else {
+            for (int item = tid; item < NPIXH * CI_T; item += 256) {
+                const int pix = item / CI_T, c = ci0 + item % CI_T;
+                int gy = iy0 + pix / TWH, gx = ix0 + pix % TWH;
+                float v = 0.f;
+                if (c < Cin && map_coord(gy, p.H, p.pad_mode) && map_coord(gx, p.W, p.pad_mode)) {
+                    const long pixoff = ((long)n * p.H + gy) * p.W + gx;
+                    v = c < p.C1 ? p.in1[pixoff * p.C1 + c] : p.in2[pixoff * p.C2 + (c - p.C1)];
+                }
+                sI[item] = v;
+            }
+            for (int item = tid; item < NPIX * CO_T; item += 256) {
+                const int pix = item / CO_T, c = co0 + item % CO_T;
+                const int oy = ty0 + pix / WG_TW, ox = tx0 + pix % WG_TW;
+                float v = 0.f;
+                if (oy < p.Hout && ox < p.Wout && c < p.Cout)
+                    v = p.dz[(((long)n * p.Hout + oy) * p.Wout + ox) * p.Cout + c];
+                sZ[item] = v;
+            }
+        }
+        __syncthreads();
+        // ---- K loop over pixel pairs; lane half (lane>>5) selects the pixel of the pair
+        const float* zL = sZ + (lane >> 5) * CO_T + (lane & 31);
+        const float* iL = sI + (lane >> 5) * STRIDE * CI_T + (lane & 31);
+#pragma unroll 1
+        for (int r = 0; r < WG_TH; ++r) {
+#pragma unroll 2
+            for (int cp = 0; cp < WG_TW / 2; ++cp) {
+                const int pix = r * WG_TW + 2 * cp;
+                const float b0 = zL[pix * CO_T], b1 = zL[pix * CO_T + 32];
+                const int ibase = (r * STRIDE * TWH + 2 * cp * STRIDE) * CI_T;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int tap = wave + 4 * t;
+                    if (tap < TAPS) {
+                        const float a = iL[ibase + ((tap / KS) * TWH + (tap % KS)) * CI_T];
+                        acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[t][0], 0, 0, 0);
+                        acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[t][1], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- write the partial slab: rows = ci (M), cols = co (N)
+    float* slab = p.partial + (long)split * TAPS * Cin * p.Cout;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tap = wave + 4 * t;
+        if (tap >= TAPS) continue;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int co = co0 + ni * 32 + (lane & 31);
+            if (co >= p.Cout) continue;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int ci = ci0 + (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5);
+                if (ci < Cin) slab[((long)tap * Cin + ci) * p.Cout + co] = acc[t][ni][j];
+            }
+        }
+    }
+}
+
+// dw[i] = sum_s partial[s][i]   (fixed order => deterministic)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, long count,
+                                    int splits, int accumulate) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += partial[(long)k * count + i];
+        dw[i] = accumulate ? dw[i] + s : s;
+    }
+}
+
+// db[co] = sum_pixels dz[pixel][co]: one workgroup per slice of pixels, two-stage (partials then fixed-order reduce)
+__global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __restrict__ dz,
+                                                                float* __restrict__ partial, long npix, int cout,
+                                                                long pix_per_block) {
+    // thread -> channel (tid % cpad), pixel phase (tid / cpad)
+    extern __shared__ float red[];
+    const int tid = threadIdx.x;
+    const int cpad = cout >= 256 ? 256 : (cout > 128 ? 256 : (cout > 64 ? 128 : (cout > 32 ? 64 : 32)));
+    const int phases = 256 / cpad;
+    const int c = tid % cpad, ph = tid / cpad;
+    const long p0 = (long)blockIdx.x * pix_per_block, p1 = min(npix, p0 + pix_per_block);
+    for (int cb = 0; cb < cout; cb += cpad) {
+        float s = 0.f;
+        if (cb + c < cout)
+            for (long px = p0 + ph; px < p1; px += phases) s += dz[px * cout + cb + c];
+        red[tid] = s;
+        __syncthreads();
+        if (ph == 0 && cb + c < cout) {
+            for (int k = 1; k < phases; ++k) s += red[k * cpad + c];
+            partial[(long)blockIdx.x * cout + cb + c] = s;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// number of split-K slabs the launcher will use for this problem (so the caller can size the workspace)
+static int wgrad_splits(int cin, int cout, int n, int hout, int wout) {
+    const long blocks_io = (long)nimg::cdiv(cin, CI_T) * nimg::cdiv(cout, CO_T);
+    const long work = (long)n * nimg::cdiv(hout, WG_TH) * nimg::cdiv(wout, WG_TW);
+    long splits = (1024 + blocks_io - 1) / blocks_io;
+    if (splits > work) splits = work;
+    if (splits < 1) splits = 1;
+    const long wps = (work + splits - 1) / splits;
+    return (int)((work + wps - 1) / wps);
+}
+
+size_t nimg_conv2d_wgrad_workspace_bytes(int cin, int cout, int ks_h, int ks_w, int n, int hout, int wout) {
+    if (cin <= 0 || cout <= 0 || n <= 0) return 0;
+    const size_t slab = (size_t)ks_h * ks_w * cin * cout * sizeof(float);
+    return slab * wgrad_splits(cin, cout, n, hout, wout);
+}
+
+int nimg_conv2d_wgrad(const float* in1, int c1, const float* in2, int c2, const float* dz, int cout, float* dw,
+                      int n, int h, int wd, int ks, int stride, int pad_t, int pad_l, int pad_mode, int hout,
+                      int wout, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!in1 || !dz || !dw || c1 <= 0 || c2 < 0 || cout <= 0 || n <= 0 || h <= 0 || wd <= 0) return NIMG_ERR_ARG;
+    if ((c2 > 0 && !in2) || hout <= 0 || wout <= 0 || !workspace || pad_mode < 0 || pad_mode > 2) return NIMG_ERR_ARG;
+    const int cin = c1 + c2;
+    if (workspace_bytes < nimg_conv2d_wgrad_workspace_bytes(cin, cout, ks, ks, n, hout, wout)) return NIMG_ERR_WORKSPACE;
+    WgradParams p;
+    p.in1 = in1; p.in2 = in2; p.dz = dz; p.partial = (float*)workspace;
+    p.C1 = c1; p.C2 = c2; p.Cout = cout; p.N = n; p.H = h; p.W = wd; p.Hout = hout; p.Wout = wout;
+    p.pad_t = pad_t; p.pad_l = pad_l; p.pad_mode = pad_mode;
+    p.tiles_y = nimg::cdiv(hout, WG_TH); p.tiles_x = nimg::cdiv(wout, WG_TW);
+    p.splits = wgrad_splits(cin, cout, n, hout, wout);
+    const long work = (long)n * p.tiles_y * p.tiles_x;
+    p.work_per_split = (int)((work + p.splits - 1) / p.splits);
+    const bool vec = (c1 % 4 == 0) && (c2 % 4 == 0) && (cout % 4 == 0);
+    const long blocks = (long)nimg::cdiv(cin, CI_T) * nimg::cdiv(cout, CO_T) * p.splits;
+    hipStream_t s = (hipStream_t)stream;
+
+#define NIMG_WG(KS_, ST_)                                                                                     \
+    do {                                                                                                      \
+        constexpr int THH = (WG_TH - 1) * ST_ + KS_, TWH = (WG_TW - 1) * ST_ + KS_;                           \
+        constexpr size_t lds = (size_t)(THH * TWH * CI_T + WG_TH * WG_TW * CO_T) * sizeof(float);             \
+        if (vec) {                                                                                            \
+            auto k = conv_wgrad_kernel<KS_, ST_, true>;                                                       \
+            (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+            hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, s, p);                              \
+        } else {                                                                                              \
+            auto k = conv_wgrad_kernel<KS_, ST_, false>;                                                      \
+            (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+            hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, s, p);                              \
+        }                                                                                                     \
+    } while (0)
+
+    if (stride == 1 && ks == 1) NIMG_WG(1, 1);
+    else if (stride == 1 && ks == 3) NIMG_WG(3, 1);
+    else if (stride == 1 && ks == 5) NIMG_WG(5, 1);
+    else if (stride == 2 && ks == 2) NIMG_WG(2, 2);
+    else if (stride == 2 && ks == 5) NIMG_WG(5, 2);
+    else return NIMG_ERR_ARG;
+#undef NIMG_WG
+    NIMG_CHECK_LAUNCH();
+    const long count = (long)ks * ks * cin * cout;
+    const int grid = (int)((count + 255) / 256 > 4096 ? 4096 : (count + 255) / 256);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, s, (const float*)workspace, dw, count,
+                       p.splits, accumulate);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+size_t nimg_bias_grad_workspace_bytes(long npix, int cout) {
+    const long blocks = npix < 1024 ? 1 : (npix / 1024 > 512 ? 512 : npix / 1024);
+    return (size_t)blocks * cout * sizeof(float);
+}
+
+int nimg_bias_grad(const float* dz, float* db, long npix, int cout, int accumulate, void* workspace,
+                   size_t workspace_bytes, void* stream) {
+    if (!dz || !db || npix <= 0 || cout <= 0 || !workspace) return NIMG_ERR_ARG;
+    if (workspace_bytes < nimg_bias_grad_workspace_bytes(npix, cout)) return NIMG_ERR_WORKSPACE;
+    const long blocks = npix < 1024 ? 1 : (npix / 1024 > 512 ? 512 : npix / 1024);
+    const long ppb = (npix + blocks - 1) / blocks;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bias_grad_partial_kernel, dim3((unsigned)blocks), dim3(256), 256 * sizeof(float), s, dz,
+                       (float*)workspace, npix, cout, ppb);
+    NIMG_CHECK_LAUNCH();
+    const int grid = (cout + 255) / 256;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, s, (const float*)workspace, db, (long)cout,
+                       (int)blocks, accumulate);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,404 @@
+// Fused differentiable JPEG for gfx950 (CDNA4): colour transform, 8x8 block DCT, quantise, IDCT, inverse colour
+// and clip in ONE kernel per direction.  Replaces models/jpeg.py:91-159 (about 25 TensorFlow ops with >=12
+// materialised intermediates).  HBM-bound: forward reads 12 B + writes 12 B (+1 B mask) per pixel.
+//
+// Work decomposition (wave64-native):
+//   one wavefront = one strip of 8 image rows x 64 pixels = 8 JPEG blocks x 3 channels
+//   lane (b = lane>>3, r = lane&7) owns row r of block b for all three channels (24 values in registers)
+//   pass 1 (along the row, in registers) -> 8x8 transpose through LDS (stride-9 tiles, conflict-free)
+//   pass 2 (along the column, in registers) -> quantise -> inverse pass 2 -> transpose back -> inverse pass 1
+//   global <-> LDS staging moves whole 768-byte row segments as float4 (coalesced), 6 per lane.
+//
+// CANONICAL float32 ORDER (shared with oracle/djpeg_ref.c, compared bit-for-bit on the index tensor):
+//   every dot product is an fmaf chain in ascending index order starting from the first product;
+//   row pass first (T = b * F^T), column pass second (X = F * T); IDCT column pass first, row pass second.
+//   Compiled with -ffp-contract=off so the explicit fmaf()s are the only fused operations.
+#include "common.h"
+
+namespace {
+
+using namespace nimg;
+
+constexpr int STRIP_PX = 64;              // pixels per wave strip
+constexpr int ROW_STRIDE = 196;           // padded LDS row stride (floats), 16-byte aligned
+constexpr int STAGE_F = 8 * ROW_STRIDE;   // staging floats per wave
+constexpr int TILE_F = 3 * 8 * 72;        // transpose tiles: [ch][block][8][9]
+constexpr int WAVE_LDS_F = (STAGE_F > TILE_F ? STAGE_F : TILE_F);
+constexpr int WAVES_PER_BLOCK = 4;
+
+// 4-decimal DCT matrix, literal (models/jpeg.py:78-85)
+__device__ constexpr float kF[8][8] = {
+    {0.3536f, 0.3536f, 0.3536f, 0.3536f, 0.3536f, 0.3536f, 0.3536f, 0.3536f},
+    {0.4904f, 0.4157f, 0.2778f, 0.0975f, -0.0975f, -0.2778f, -0.4157f, -0.4904f},
+    {0.4619f, 0.1913f, -0.1913f, -0.4619f, -0.4619f, -0.1913f, 0.1913f, 0.4619f},
+    {0.4157f, -0.0975f, -0.4904f, -0.2778f, 0.2778f, 0.4904f, 0.0975f, -0.4157f},
+    {0.3536f, -0.3536f, -0.3536f, 0.3536f, 0.3536f, -0.3536f, -0.3536f, 0.3536f},
+    {0.2778f, -0.4904f, 0.0975f, 0.4157f, -0.4157f, -0.0975f, 0.4904f, -0.2778f},
+    {0.1913f, -0.4619f, 0.4619f, -0.1913f, -0.1913f, 0.4619f, -0.4619f, 0.1913f},
+    {0.0975f, -0.2778f, 0.4157f, -0.4904f, 0.4904f, -0.4157f, 0.2778f, -0.0975f}};
+
+// colour matrices, bias in column 0 (models/jpeg.py:74-75)
+__device__ constexpr float kCF[3][4] = {{0.0f, 0.299f, 0.587f, 0.114f},
+                                        {128.0f, -0.168736f, -0.331264f, 0.5f},
+                                        {128.0f, 0.5f, -0.418688f, -0.081312f}};
+__device__ constexpr float kCI[3][4] = {{(float)(-1.402 * 128), 1.0f, 0.0f, 1.402f},
+                                        {(float)(1.058272 * 128), 1.0f, -0.344136f, -0.714136f},
+                                        {(float)(-1.772 * 128), 1.0f, 1.772f, 0.0f}};
+
+// out[k] = sum_m in[m] * F[k][m]      (forward DCT along the register axis)
+__device__ __forceinline__ void dct_fwd8(const float (&in)[8], float (&out)[8]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float acc = in[0] * kF[k][0];
+#pragma unroll
+        for (int m = 1; m < 8; ++m) acc = __builtin_fmaf(in[m], kF[k][m], acc);
+        out[k] = acc;
+    }
+}
+// out[m] = sum_k in[k] * F[k][m]      (inverse DCT along the register axis)
+__device__ __forceinline__ void dct_inv8(const float (&in)[8], float (&out)[8]) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        float acc = in[0] * kF[0][m];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) acc = __builtin_fmaf(in[k], kF[k][m], acc);
+        out[m] = acc;
+    }
+}
+
+struct Task {
+    int n, by, x0;     // image, block row, first pixel of the strip
+    bool valid;
+};
+
+__device__ __forceinline__ Task decode_task(long task, long n_tasks, int hb, int strips) {
+    Task t;
+    t.valid = task < n_tasks;
+    const long tt = t.valid ? task : 0;
+    t.x0 = (int)(tt % strips) * STRIP_PX;
+    t.by = (int)((tt / strips) % hb);
+    t.n = (int)(tt / ((long)strips * hb));
+    return t;
+}
+
+// global (8 rows x up to 64 px x 3 ch) -> LDS staging rows, float4 granularity (w % 8 == 0 => 24-float = 96-byte
+// block granules, always 16-byte aligned)
+__device__ __forceinline__ void load_strip(const float* __restrict__ src, float* lds, const Task& t, int h, int w,
+                                           int lane) {
+    const int strip_f = min(STRIP_PX, w - t.x0) * 3;      // valid floats per row
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+        const int idx = it * 64 + lane;                   // 0..383 float4 slots
+        const int row = idx / 48, c4 = idx % 48;
+        if (t.valid && c4 * 4 < strip_f) {
+            const float4 v = *reinterpret_cast<const float4*>(
+                src + (((long)t.n * h + t.by * 8 + row) * w + t.x0) * 3 + c4 * 4);
+            *reinterpret_cast<float4*>(lds + row * ROW_STRIDE + c4 * 4) = v;
+        }
+    }
+}
+
+__device__ __forceinline__ void store_strip(float* __restrict__ dst, const float* lds, const Task& t, int h, int w,
+                                            int lane) {
+    const int strip_f = min(STRIP_PX, w - t.x0) * 3;
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+        const int idx = it * 64 + lane;
+        const int row = idx / 48, c4 = idx % 48;
+        if (t.valid && c4 * 4 < strip_f) {
+            const float4 v = *reinterpret_cast<const float4*>(lds + row * ROW_STRIDE + c4 * 4);
+            *reinterpret_cast<float4*>(dst + (((long)t.n * h + t.by * 8 + row) * w + t.x0) * 3 + c4 * 4) = v;
+        }
+    }
+}
+
+// lane (b,r): read its 8 pixels x 3 channels from the staging rows
+__device__ __forceinline__ void read_row24(const float* lds, int b, int r, float (&px)[24]) {
+    const float4* p = reinterpret_cast<const float4*>(lds + r * ROW_STRIDE + b * 24);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const float4 v = p[k];
+        px[4 * k + 0] = v.x; px[4 * k + 1] = v.y; px[4 * k + 2] = v.z; px[4 * k + 3] = v.w;
+    }
+}
+__device__ __forceinline__ void write_row24(float* lds, int b, int r, const float (&px)[24]) {
+    float4* p = reinterpret_cast<float4*>(lds + r * ROW_STRIDE + b * 24);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) p[k] = make_float4(px[4 * k], px[4 * k + 1], px[4 * k + 2], px[4 * k + 3]);
+}
+
+// 8x8 transposes among the 8 lanes of a block through LDS tiles [ch][block][8][9]
+// "rows -> cols": lane (b,r) holds v[c][k] = M_c[r][k]; afterwards lane (b,r) holds M_c[k][r]  (its column r)
+__device__ __forceinline__ void transpose24(float* tile, int b, int r, float (&v)[3][8]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tile[((c * 8 + b) * 8 + r) * 9 + k] = v[c][k];
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[c][k] = tile[((c * 8 + b) * 8 + k) * 9 + r];
+    __syncthreads();
+}
+
+__device__ __forceinline__ float quantise(float u, int rounding) {
+    switch (rounding) {
+        case NIMG_ROUND_ROUND:
+        case NIMG_ROUND_SOFT:
+            return rintf(u);                                   // half-to-even == tf.round
+        case NIMG_ROUND_SIN:
+            return u - sinpif(2.0f * (u - rintf(u))) * 0.15915494309189535f;   // sin(2 pi u)/(2 pi), periodic
+        case NIMG_ROUND_HARMONIC:
+            return u - sinpif(2.0f * (u - rintf(u))) * 0.3183098861837907f;    // sin(2 pi u)/pi
+        default:
+            return u;
+    }
+}
+
+__device__ __forceinline__ float quantise_grad(float u, int rounding) {
+    // v_cos_f32 takes revolutions: cos(2 pi u) = amdgcn_cos(fract(u))
+    const float c = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(u));
+    switch (rounding) {
+        case NIMG_ROUND_SOFT:
+        case NIMG_ROUND_SIN:
+            return 1.0f - c;
+        case NIMG_ROUND_HARMONIC:
+            return 1.0f - 2.0f * c;
+        case NIMG_ROUND_IDENTITY:
+            return 1.0f;
+        default:
+            return 0.0f;
+    }
+}
+
+// rgb (x255) -> ycbcr - 127, for the 8 pixels of this lane's row; out[c][j]
+__device__ __forceinline__ void colour_fwd(const float (&px)[24], float (&ycc)[3][8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float r = 255.0f * px[3 * j], g = 255.0f * px[3 * j + 1], bb = 255.0f * px[3 * j + 2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float acc = kCF[c][0];
+            acc = __builtin_fmaf(r, kCF[c][1], acc);
+            acc = __builtin_fmaf(g, kCF[c][2], acc);
+            acc = __builtin_fmaf(bb, kCF[c][3], acc);
+            ycc[c][j] = acc - 127.0f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void djpeg_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                        const float* __restrict__ qtab, uint8_t* __restrict__ mask,
+                                                        int16_t* __restrict__ idx, float* __restrict__ xdq, int n,
+                                                        int h, int w, int rounding) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = lane >> 3, r = lane & 7;
+    float* lds = smem + wave * WAVE_LDS_F;
+    const int hb = h / 8, wb = w / 8, strips = (w + STRIP_PX - 1) / STRIP_PX;
+    const long n_tasks = (long)n * hb * strips;
+    const Task t = decode_task((long)blockIdx.x * WAVES_PER_BLOCK + wave, n_tasks, hb, strips);
+    const bool active = t.valid && (t.x0 + b * 8 < w);
+
+    load_strip(x, lds, t, h, w, lane);
+    __syncthreads();
+    float px[24];
+    float v[3][8];
+    if (active) {
+        read_row24(lds, b, r, px);
+        float ycc[3][8];
+        colour_fwd(px, ycc);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dct_fwd8(ycc[c], v[c]);          // T[r][k] = sum_j b[r][j] F[k][j]
+    }
+    __syncthreads();
+    transpose24(lds, b, r, v);                                       // lane now holds T[0..7][col r]
+    if (active) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float X[8];
+            dct_fwd8(v[c], X);                                       // X[u][col r] = sum_i F[u][i] T[i][r]
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float q = qtab[c * 64 + u * 8 + r];
+                const float qi = quantise(X[u] / q, rounding);
+                X[u] = qi * q;
+                const long o = ((((long)t.n * 3 + c) * hb + t.by) * wb + (t.x0 / 8 + b)) * 64 + u * 8 + r;
+                if (idx) idx[o] = (int16_t)qi;
+                if (xdq) xdq[o] = X[u];
+            }
+            dct_inv8(X, v[c]);                                       // S[i][col r] = sum_u F[u][i] Xd[u][r]
+        }
+    }
+    transpose24(lds, b, r, v);                                       // lane holds S[row r][0..7]
+    if (active) {
+        float q3[3][8];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            dct_inv8(v[c], q3[c]);                                   // xi[r][j] = sum_v S[r][v] F[v][j]
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q3[c][j] += 127.0f;
+        }
+        uint32_t mlo = 0, mhi = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float acc = kCI[c][0];
+                acc = __builtin_fmaf(q3[0][j], kCI[c][1], acc);
+                acc = __builtin_fmaf(q3[1][j], kCI[c][2], acc);
+                acc = __builtin_fmaf(q3[2][j], kCI[c][3], acc);
+                acc = acc / 255.0f;
+                m |= (acc >= 0.0f && acc <= 1.0f) ? (1u << c) : 0u;
+                px[3 * j + c] = fminf(fmaxf(acc, 0.0f), 1.0f);
+            }
+            if (j < 4) mlo |= m << (8 * j); else mhi |= m << (8 * (j - 4));
+        }
+        write_row24(lds, b, r, px);
+        if (mask)
+            *reinterpret_cast<uint2*>(mask + ((long)t.n * h + t.by * 8 + r) * w + t.x0 + b * 8) = make_uint2(mlo, mhi);
+    }
+    __syncthreads();
+    store_strip(y, lds, t, h, w, lane);
+}
+
+__global__ __launch_bounds__(256) void djpeg_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                        const uint8_t* __restrict__ mask,
+                                                        const float* __restrict__ qtab, float* __restrict__ gx,
+                                                        int n, int h, int w, int rounding) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = lane >> 3, r = lane & 7;
+    float* lds = smem + wave * WAVE_LDS_F;
+    const int hb = h / 8, strips = (w + STRIP_PX - 1) / STRIP_PX;
+    const long n_tasks = (long)n * hb * strips;
+    const Task t = decode_task((long)blockIdx.x * WAVES_PER_BLOCK + wave, n_tasks, hb, strips);
+    const bool active = t.valid && (t.x0 + b * 8 < w);
+
+    float px[24];
+    float tx[3][8];    // forward coefficients path (from x)
+    float tg[3][8];    // gradient path (from gy)
+
+    // ---- recompute the forward row pass from x
+    load_strip(x, lds, t, h, w, lane);
+    __syncthreads();
+    if (active) {
+        read_row24(lds, b, r, px);
+        float ycc[3][8];
+        colour_fwd(px, ycc);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dct_fwd8(ycc[c], tx[c]);
+    }
+    __syncthreads();
+    // ---- gradient: clip mask, /255, transpose(colour_I), row pass (d xi = F^T dXd F  =>  dXd = F g F^T)
+    load_strip(gy, lds, t, h, w, lane);
+    __syncthreads();
+    if (active) {
+        read_row24(lds, b, r, px);
+        const uint2 mm = *reinterpret_cast<const uint2*>(mask + ((long)t.n * h + t.by * 8 + r) * w + t.x0 + b * 8);
+        float gq[3][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t m = ((j < 4 ? mm.x >> (8 * j) : mm.y >> (8 * (j - 4)))) & 0xffu;
+            float g[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g[c] = (m >> c) & 1u ? px[3 * j + c] * (1.0f / 255.0f) : 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)       // d/d(q_c) = sum_c' g_c' * CI[c'][1+c]
+                gq[c][j] = g[0] * kCI[0][1 + c] + g[1] * kCI[1][1 + c] + g[2] * kCI[2][1 + c];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dct_fwd8(gq[c], tg[c]);
+    }
+    __syncthreads();
+    transpose24(lds, b, r, tx);
+    transpose24(lds, b, r, tg);
+    if (active) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float X[8], G[8];
+            dct_fwd8(tx[c], X);
+            dct_fwd8(tg[c], G);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float q = qtab[c * 64 + u * 8 + r];
+                G[u] *= quantise_grad(X[u] / q, rounding);       // (X/Q -> quant -> *Q): the Q factors cancel
+            }
+            dct_inv8(G, tg[c]);                                  // d b = F^T gX F : column pass
+        }
+    }
+    transpose24(lds, b, r, tg);
+    if (active) {
+        float gb[3][8];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dct_inv8(tg[c], gb[c]);      // row pass
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)       // d/d(x_c) = 255 * sum_c' gycc_c' * CF[c'][1+c]
+                px[3 * j + c] =
+                    255.0f * (gb[0][j] * kCF[0][1 + c] + gb[1][j] * kCF[1][1 + c] + gb[2][j] * kCF[2][1 + c]);
+        write_row24(lds, b, r, px);
+    }
+    __syncthreads();
+    store_strip(gx, lds, t, h, w, lane);
+}
+
+}  // namespace
+
+extern "C" {
+
+int nimg_abi_version(void) { return 1; }
+
+int nimg_djpeg_fwd(const float* x, float* y, const float* qtab, uint8_t* mask, int16_t* idx, float* xdq, int n,
+                   int h, int w, int rounding, void* stream) {
+    if (!x || !y || !qtab || n < 0 || h <= 0 || w <= 0 || (h % 8) || (w % 8)) return NIMG_ERR_ARG;
+    if (rounding < NIMG_ROUND_ROUND || rounding > NIMG_ROUND_IDENTITY) return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    const long tasks = (long)n * (h / 8) * ((w + STRIP_PX - 1) / STRIP_PX);
+    const int grid = nimg::cdiv(tasks, WAVES_PER_BLOCK);
+    const size_t lds = (size_t)WAVES_PER_BLOCK * WAVE_LDS_F * sizeof(float);
+    hipLaunchKernelGGL(djpeg_fwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, x, y, qtab, mask, idx,
+                       xdq, n, h, w, rounding);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_djpeg_bwd(const float* x, const float* gy, const uint8_t* mask, const float* qtab, float* gx, int n, int h,
+                   int w, int rounding, void* stream) {
+    if (!x || !gy || !mask || !qtab || !gx || n < 0 || h <= 0 || w <= 0 || (h % 8) || (w % 8)) return NIMG_ERR_ARG;
+    if (rounding < NIMG_ROUND_ROUND || rounding > NIMG_ROUND_IDENTITY) return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    const long tasks = (long)n * (h / 8) * ((w + STRIP_PX - 1) / STRIP_PX);
+    const int grid = nimg::cdiv(tasks, WAVES_PER_BLOCK);
+    const size_t lds = (size_t)WAVES_PER_BLOCK * WAVE_LDS_F * sizeof(float);
+    hipLaunchKernelGGL(djpeg_bwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, x, gy, mask, qtab, gx, n,
+                       h, w, rounding);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+// IJG quality scaling (compression/jpeg_helpers.py:264-305), host side
+int nimg_jpeg_qtable(int quality, int channel, float* out64) {
+    static const float luma[64] = {16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55,
+                                   14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+                                   18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92,
+                                   49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+    static const float chroma[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99,
+                                     24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
+                                     99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
+                                     99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+    if (!out64) return NIMG_ERR_ARG;
+    quality = quality > 100 ? 100 : (quality < 1 ? 1 : quality);
+    const float s = quality < 50 ? (float)(5000.0 / quality) : (float)(200 - 2 * quality);
+    const float* t = channel == 0 ? luma : chroma;
+    for (int k = 0; k < 64; ++k) {
+        float v = __builtin_floorf((t[k] * s + 50.0f) / 100.0f);
+        out64[k] = v < 1.0f ? 1.0f : (v > 255.0f ? 255.0f : v);
+    }
+    return NIMG_OK;
+}
+
+}  // extern "C"

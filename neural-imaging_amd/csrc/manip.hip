@@ -1,0 +1,424 @@
+// Photo-manipulation stencils of the channel (HBM-bound, 3-channel NHWC images), forward and backward:
+//   manipulation_sharpen   helpers/tf_helpers.py:156-184  (SYMMETRIC pad, rgb->hsv, 3x3 filter incl. the S-channel
+//                                                          corner-tap quirk of :167-169, hsv->rgb, hard clip)
+//   manipulation_gaussian  helpers/tf_helpers.py:113-125  (REFLECT pad, 5x5 depthwise gaussian, hard clip)
+//   manipulation_resample  helpers/tf_helpers.py:68-76    (bilinear down + up == one banded linear operator per axis,
+//                                                          applied as a sparse row gather; the backward uses its transpose)
+//   fold of a padded-domain gradient back onto the image (backward of tf.pad SYMMETRIC / REFLECT; used by the
+//   ConstrainedConv2D input gradient, models/layers.py:56)
+// One thread per pixel; neighbour reads are served by L1/L2 (a 3-channel image row is 3 KB).
+#include "common.h"
+
+namespace {
+
+using namespace nimg;
+
+inline int grid_for(long items) {
+    long g = (items + 255) / 256;
+    return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+// padded-domain indices that map onto image index y (own + at most one mirrored), pad P, mode 1 SYMMETRIC / 2 REFLECT
+__device__ __forceinline__ int pad_sources(int y, int size, int P, int mode, int (&out)[2]) {
+    out[0] = y + P;
+    int cnt = 1;
+    if (mode == 1) {
+        if (y < P) out[cnt++] = P - 1 - y;
+        else if (y >= size - P) out[cnt++] = 2 * size + P - 1 - y;
+    } else if (mode == 2) {
+        if (y >= 1 && y <= P) out[cnt++] = P - y;
+        else if (y >= size - 1 - P && y <= size - 2) out[cnt++] = 2 * size + P - 2 - y;
+    }
+    return cnt;
+}
+
+__device__ __forceinline__ void rgb2hsv(float r, float g, float b, float& h, float& s, float& v) {
+    // tf.image.rgb_to_hsv; max/min selection order R, G, B (matches the branch order of the hue)
+    v = (r >= g && r >= b) ? r : (g >= b ? g : b);
+    const float mn = (r <= g && r <= b) ? r : (g <= b ? g : b);
+    const float rng = v - mn;
+    s = v > 0.f ? rng / v : 0.f;
+    const float norm = 1.0f / (6.0f * (rng > 0.f ? rng : 1.0f));
+    float hh = (r == v) ? norm * (g - b) : ((g == v) ? norm * (b - r) + 2.0f / 6.0f : norm * (r - g) + 4.0f / 6.0f);
+    hh = rng > 0.f ? hh : 0.f;
+    h = hh < 0.f ? hh + 1.0f : hh;
+}
+
+__device__ __forceinline__ void hsv2rgb(float h, float s, float v, float& r, float& g, float& b) {
+    const float dh = h * 6.0f;
+    const float dr = fminf(fmaxf(fabsf(dh - 3.0f) - 1.0f, 0.f), 1.f);
+    const float dg = fminf(fmaxf(2.0f - fabsf(dh - 2.0f), 0.f), 1.f);
+    const float db = fminf(fmaxf(2.0f - fabsf(dh - 4.0f), 0.f), 1.f);
+    const float one_s = 1.0f - s;
+    r = (one_s + s * dr) * v;
+    g = (one_s + s * dg) * v;
+    b = (one_s + s * db) * v;
+}
+
+__device__ __forceinline__ float sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void gaussian_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ mask,
+                                    const float* __restrict__ gk, int n, int h, int w, int clip) {
+    const long total = (long)n * h * w;
+    float g[25];
+#pragma unroll
+    for (int k = 0; k < 25; ++k) g[k] = gk[k];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int px = (int)(i % w), py = (int)((i / w) % h);
+        const long im = i / ((long)w * h);
+        float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 5; ++ky) {
+            int yy = py + ky - 2;
+            map_coord(yy, h, 2);
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) {
+                int xx = px + kx - 2;
+                map_coord(xx, w, 2);
+                const float* p = x + ((im * h + yy) * w + xx) * 3;
+                const float wv = g[ky * 5 + kx];
+                acc[0] = fmaf(p[0], wv, acc[0]);
+                acc[1] = fmaf(p[1], wv, acc[1]);
+                acc[2] = fmaf(p[2], wv, acc[2]);
+            }
+        }
+        uint32_t m = 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            m |= (acc[c] >= 0.f && acc[c] <= 1.f) ? (1u << c) : 0u;
+            y[i * 3 + c] = clip ? fminf(fmaxf(acc[c], 0.f), 1.f) : acc[c];
+        }
+        if (mask) mask[i] = clip ? (uint8_t)m : (uint8_t)7;
+    }
+}
+
+__global__ void gaussian_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ mask,
+                                    float* __restrict__ dx, const float* __restrict__ gk, int n, int h, int w) {
+    const long total = (long)n * h * w;
+    float g[25];
+#pragma unroll
+    for (int k = 0; k < 25; ++k) g[k] = gk[k];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int px = (int)(i % w), py = (int)((i / w) % h);
+        const long im = i / ((long)w * h);
+        int ys[2], xs[2];
+        const int ny = pad_sources(py, h, 2, 2, ys), nx = pad_sources(px, w, 2, 2, xs);
+        float acc[3] = {0.f, 0.f, 0.f};
+        for (int a = 0; a < ny; ++a)
+            for (int b = 0; b < nx; ++b) {
+#pragma unroll
+                for (int ky = 0; ky < 5; ++ky) {
+                    const int oy = ys[a] - ky;           // output row that read padded row ys[a] with tap ky
+                    if (oy < 0 || oy >= h) continue;
+#pragma unroll
+                    for (int kx = 0; kx < 5; ++kx) {
+                        const int ox = xs[b] - kx;
+                        if (ox < 0 || ox >= w) continue;
+                        const long o = (im * h + oy) * w + ox;
+                        const uint32_t m = mask ? mask[o] : 7u;
+                        const float wv = g[ky * 5 + kx];
+                        const float* p = dy + o * 3;
+                        if (m & 1u) acc[0] = fmaf(p[0], wv, acc[0]);
+                        if (m & 2u) acc[1] = fmaf(p[1], wv, acc[1]);
+                        if (m & 4u) acc[2] = fmaf(p[2], wv, acc[2]);
+                    }
+                }
+            }
+        dx[i * 3 + 0] = acc[0];
+        dx[i * 3 + 1] = acc[1];
+        dx[i * 3 + 2] = acc[2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// sharpen forward: y = clip(hsv2rgb(filter(rgb2hsv(sympad(x))))); aux = filtered hsv (needed by the backward)
+__global__ void sharpen_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ aux,
+                                   uint8_t* __restrict__ mask, const float* __restrict__ gk9, int n, int h, int w) {
+    const long total = (long)n * h * w;
+    float g[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) g[k] = gk9[k];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int px = (int)(i % w), py = (int)((i / w) % h);
+        const long im = i / ((long)w * h);
+        float ho = 0.f, vo = 0.f, so = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            int yy = py + ky - 1;
+            map_coord(yy, h, 1);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                int xx = px + kx - 1;
+                map_coord(xx, w, 1);
+                const float* p = x + ((im * h + yy) * w + xx) * 3;
+                float hh, ss, vv;
+                rgb2hsv(p[0], p[1], p[2], hh, ss, vv);
+                ho = fmaf(hh, g[ky * 3 + kx], ho);
+                vo = fmaf(vv, g[ky * 3 + kx], vo);
+                if (ky == 2 && kx == 2) so = ss;          // S channel: single corner tap [2,2] = 1
+            }
+        }
+        float r, gg, b;
+        hsv2rgb(ho, so, vo, r, gg, b);
+        const float o[3] = {r, gg, b};
+        uint32_t m = 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            m |= (o[c] >= 0.f && o[c] <= 1.f) ? (1u << c) : 0u;
+            y[i * 3 + c] = fminf(fmaxf(o[c], 0.f), 1.f);
+        }
+        if (aux) { aux[i * 3] = ho; aux[i * 3 + 1] = so; aux[i * 3 + 2] = vo; }
+        if (mask) mask[i] = (uint8_t)m;
+    }
+}
+
+// backward stage A (per output pixel): d(filtered hsv) = J_hsv2rgb^T (dy * clipmask); written in place of aux
+__global__ void sharpen_bwd_a_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ mask, float* aux,
+                                     long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const float h = aux[i * 3], s = aux[i * 3 + 1], v = aux[i * 3 + 2];
+        const uint32_t m = mask[i];
+        const float gr = (m & 1u) ? dy[i * 3] : 0.f, gg = (m & 2u) ? dy[i * 3 + 1] : 0.f,
+                    gb = (m & 4u) ? dy[i * 3 + 2] : 0.f;
+        const float dh = h * 6.0f;
+        const float ar = fabsf(dh - 3.0f) - 1.0f, ag = 2.0f - fabsf(dh - 2.0f), ab = 2.0f - fabsf(dh - 4.0f);
+        const float dr = fminf(fmaxf(ar, 0.f), 1.f), dg = fminf(fmaxf(ag, 0.f), 1.f), db = fminf(fmaxf(ab, 0.f), 1.f);
+        // clamp passes gradient on the closed interval [0,1]; d|x| = sign(x) with sign(0) = 0
+        const float ddr = (ar >= 0.f && ar <= 1.f) ? 6.0f * sgn(dh - 3.0f) : 0.f;
+        const float ddg = (ag >= 0.f && ag <= 1.f) ? -6.0f * sgn(dh - 2.0f) : 0.f;
+        const float ddb = (ab >= 0.f && ab <= 1.f) ? -6.0f * sgn(dh - 4.0f) : 0.f;
+        const float one_s = 1.0f - s;
+        aux[i * 3] = s * v * (gr * ddr + gg * ddg + gb * ddb);
+        aux[i * 3 + 1] = v * (gr * (dr - 1.0f) + gg * (dg - 1.0f) + gb * (db - 1.0f));
+        aux[i * 3 + 2] = gr * (one_s + s * dr) + gg * (one_s + s * dg) + gb * (one_s + s * db);
+    }
+}
+
+// backward stage B (per input pixel): gather the filter transpose + pad fold, then J_rgb2hsv^T
+__global__ void sharpen_bwd_b_kernel(const float* __restrict__ x, const float* __restrict__ dhsv,
+                                     float* __restrict__ dx, const float* __restrict__ gk9, int n, int h, int w) {
+    const long total = (long)n * h * w;
+    float g[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) g[k] = gk9[k];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int px = (int)(i % w), py = (int)((i / w) % h);
+        const long im = i / ((long)w * h);
+        int ys[2], xs[2];
+        const int ny = pad_sources(py, h, 1, 1, ys), nx = pad_sources(px, w, 1, 1, xs);
+        float gh = 0.f, gs = 0.f, gv = 0.f;
+        for (int a = 0; a < ny; ++a)
+            for (int b = 0; b < nx; ++b) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int oy = ys[a] - ky;
+                    if (oy < 0 || oy >= h) continue;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int ox = xs[b] - kx;
+                        if (ox < 0 || ox >= w) continue;
+                        const float* p = dhsv + ((im * h + oy) * w + ox) * 3;
+                        gh = fmaf(p[0], g[ky * 3 + kx], gh);
+                        gv = fmaf(p[2], g[ky * 3 + kx], gv);
+                        if (ky == 2 && kx == 2) gs += p[1];
+                    }
+                }
+            }
+        // rgb_to_hsv backward at this pixel
+        const float r = x[i * 3], gg = x[i * 3 + 1], bb = x[i * 3 + 2];
+        const int imax = (r >= gg && r >= bb) ? 0 : (gg >= bb ? 1 : 2);
+        const int imin = (r <= gg && r <= bb) ? 0 : (gg <= bb ? 1 : 2);
+        const float c3[3] = {r, gg, bb};
+        const float v = c3[imax], mn = c3[imin], rng = v - mn;
+        float d[3] = {0.f, 0.f, 0.f};
+        float g_rng = 0.f, g_v = gv;
+        if (v > 0.f) { g_rng += gs / v; g_v -= gs * rng / (v * v); }
+        if (rng > 0.f) {
+            const float norm = 1.0f / (6.0f * rng);
+            // hue branch (same order as the forward): operands (a - b)
+            int ia, ib;
+            if (r == v) { ia = 1; ib = 2; } else if (gg == v) { ia = 2; ib = 0; } else { ia = 0; ib = 1; }
+            d[ia] += gh * norm;
+            d[ib] -= gh * norm;
+            g_rng -= gh * norm * (c3[ia] - c3[ib]) / rng;
+        }
+        d[imax] += g_v + g_rng;
+        d[imin] -= g_rng;
+        dx[i * 3] = d[0];
+        dx[i * 3 + 1] = d[1];
+        dx[i * 3 + 2] = d[2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// out[n, o, x, c] (axis 0) or out[n, y, o, c] (axis 1) = sum_e val[e] * in[.., col[e], ..],  e in [rowptr[o], rowptr[o+1])
+__global__ void sparse_axis_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                   const int* __restrict__ rowptr, const int* __restrict__ col,
+                                   const float* __restrict__ val, int n, int hin, int win, int hout, int wout, int c,
+                                   int axis) {
+    const long total = (long)n * hout * wout * c;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % c);
+        long r = i / c;
+        const int ox = (int)(r % wout);
+        r /= wout;
+        const int oy = (int)(r % hout);
+        const long im = r / hout;
+        const int o = axis == 0 ? oy : ox;
+        float acc = 0.f;
+        for (int e = rowptr[o]; e < rowptr[o + 1]; ++e) {
+            const int src = col[e];
+            const long idx = axis == 0 ? ((im * hin + src) * win + ox) * c + ch : ((im * hin + oy) * win + src) * c + ch;
+            acc = fmaf(val[e], in[idx], acc);
+        }
+        out[i] = acc;
+    }
+}
+
+// fold a gradient defined on the padded domain (h+2P, w+2P) back onto the image
+__global__ void fold_pad_kernel(const float* __restrict__ dpad, float* __restrict__ dx, int n, int h, int w, int c,
+                                int P, int mode) {
+    const long total = (long)n * h * w * c;
+    const int hp = h + 2 * P, wp = w + 2 * P;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % c);
+        long r = i / c;
+        const int px = (int)(r % w);
+        r /= w;
+        const int py = (int)(r % h);
+        const long im = r / h;
+        int ys[2], xs[2];
+        const int ny = pad_sources(py, h, P, mode, ys), nx = pad_sources(px, w, P, mode, xs);
+        float acc = 0.f;
+        for (int a = 0; a < ny; ++a)
+            for (int b = 0; b < nx; ++b) acc += dpad[((im * hp + ys[a]) * wp + xs[b]) * c + ch];
+        dx[i] = acc;
+    }
+}
+
+// 2x2 (factor f) average pooling fwd / bwd  (workflows/manipulation_classification.py:235 'pool' downsampling)
+__global__ void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int h, int w, int c,
+                                   int f) {
+    const int ho = h / f, wo = w / f;
+    const long total = (long)n * ho * wo * c;
+    const float inv = 1.0f / (float)(f * f);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % c);
+        long r = i / c;
+        const int ox = (int)(r % wo);
+        r /= wo;
+        const int oy = (int)(r % ho);
+        const long im = r / ho;
+        float s = 0.f;
+        for (int a = 0; a < f; ++a)
+            for (int b = 0; b < f; ++b) s += x[((im * h + oy * f + a) * w + ox * f + b) * c + ch];
+        y[i] = s * inv;
+    }
+}
+__global__ void avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int n, int h, int w, int c,
+                                   int f) {
+    const int ho = h / f, wo = w / f;
+    const long total = (long)n * h * w * c;
+    const float inv = 1.0f / (float)(f * f);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % c);
+        long r = i / c;
+        const int px = (int)(r % w);
+        r /= w;
+        const int py = (int)(r % h);
+        const long im = r / h;
+        dx[i] = (py / f < ho && px / f < wo) ? inv * dy[((im * ho + py / f) * wo + px / f) * c + ch] : 0.f;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int nimg_gaussian_fwd(const float* x, float* y, uint8_t* mask, const float* gk25, int n, int h, int w, int clip,
+                      void* stream) {
+    if (!x || !y || !gk25 || n < 0 || h < 5 || w < 5) return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    hipLaunchKernelGGL(gaussian_fwd_kernel, dim3(grid_for((long)n * h * w)), dim3(256), 0, (hipStream_t)stream, x, y,
+                       mask, gk25, n, h, w, clip);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_gaussian_bwd(const float* dy, const uint8_t* mask, float* dx, const float* gk25, int n, int h, int w,
+                      void* stream) {
+    if (!dy || !dx || !gk25 || n < 0 || h < 5 || w < 5) return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    hipLaunchKernelGGL(gaussian_bwd_kernel, dim3(grid_for((long)n * h * w)), dim3(256), 0, (hipStream_t)stream, dy,
+                       mask, dx, gk25, n, h, w);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_sharpen_fwd(const float* x, float* y, float* aux_hsv, uint8_t* mask, const float* gk9, int n, int h, int w,
+                     void* stream) {
+    if (!x || !y || !gk9 || n < 0 || h < 3 || w < 3) return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    hipLaunchKernelGGL(sharpen_fwd_kernel, dim3(grid_for((long)n * h * w)), dim3(256), 0, (hipStream_t)stream, x, y,
+                       aux_hsv, mask, gk9, n, h, w);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_sharpen_bwd(const float* x, const float* dy, float* aux_hsv, const uint8_t* mask, float* dx,
+                     const float* gk9, int n, int h, int w, void* stream) {
+    if (!x || !dy || !aux_hsv || !mask || !dx || !gk9 || n < 0 || h < 3 || w < 3) return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)n * h * w;
+    hipLaunchKernelGGL(sharpen_bwd_a_kernel, dim3(grid_for(total)), dim3(256), 0, s, dy, mask, aux_hsv, total);
+    NIMG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sharpen_bwd_b_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, (const float*)aux_hsv, dx,
+                       gk9, n, h, w);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_sparse_axis_apply(const float* in, float* out, const int* rowptr, const int* col, const float* val, int n,
+                           int hin, int win, int c, int axis, int out_size, void* stream) {
+    if (!in || !out || !rowptr || !col || !val || n < 0 || hin <= 0 || win <= 0 || c <= 0 || out_size <= 0)
+        return NIMG_ERR_ARG;
+    if (axis != 0 && axis != 1) return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    const int hout = axis == 0 ? out_size : hin, wout = axis == 1 ? out_size : win;
+    hipLaunchKernelGGL(sparse_axis_kernel, dim3(grid_for((long)n * hout * wout * c)), dim3(256), 0,
+                       (hipStream_t)stream, in, out, rowptr, col, val, n, hin, win, hout, wout, c, axis);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_fold_pad(const float* dpad, float* dx, int n, int h, int w, int c, int pad, int pad_mode, void* stream) {
+    if (!dpad || !dx || n < 0 || h <= 2 * pad || w <= 2 * pad || c <= 0 || pad < 0 || pad_mode < 1 || pad_mode > 2)
+        return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    hipLaunchKernelGGL(fold_pad_kernel, dim3(grid_for((long)n * h * w * c)), dim3(256), 0, (hipStream_t)stream, dpad,
+                       dx, n, h, w, c, pad, pad_mode);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_avgpool_fwd(const float* x, float* y, int n, int h, int w, int c, int factor, void* stream) {
+    if (!x || !y || n < 0 || h <= 0 || w <= 0 || c <= 0 || factor < 1 || h % factor || w % factor) return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid_for((long)n * (h / factor) * (w / factor) * c)), dim3(256), 0,
+                       (hipStream_t)stream, x, y, n, h, w, c, factor);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_avgpool_bwd(const float* dy, float* dx, int n, int h, int w, int c, int factor, void* stream) {
+    if (!dy || !dx || n < 0 || h <= 0 || w <= 0 || c <= 0 || factor < 1 || h % factor || w % factor) return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for((long)n * h * w * c)), dim3(256), 0, (hipStream_t)stream, dy,
+                       dx, n, h, w, c, factor);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+}  // extern "C"

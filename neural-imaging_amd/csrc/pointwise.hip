@@ -1,0 +1,465 @@
+// HBM-bound element-wise / pooling / reduction kernels of the imaging channel (gfx950).
+// float4 along the NHWC channel axis wherever C % 4 == 0, grid-stride loops capped at 2048 workgroups.
+//
+//   max-pool 2x2 fwd / bwd(+skip add, +LeakyReLU')        models/pipelines.py:197, models/forensics.py:70
+//   Conv2DTranspose 2x2 s2 fwd                            models/pipelines.py:205
+//   depth_to_space (DCR) + straight-through clip fwd/bwd  models/pipelines.py:218-223, models/compression.py:248-271
+//   mse on 255-scaled images (loss + gradient)            helpers/tf_helpers.py:31-32
+//   GAP + Dense + softmax + sparse CE head, fwd + bwd     models/forensics.py:80-94
+//   Keras Adam over a flat parameter buffer               tf.keras.optimizers.Adam (pipelines.py:51 etc.)
+#include "common.h"
+
+namespace {
+
+using namespace nimg;
+
+inline int grid_for(long items) {
+    long g = (items + 255) / 256;
+    return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <int V>
+__global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int h, int w, int c) {
+    const int ho = h / 2, wo = w / 2, cv = c / V;
+    const long total = (long)n * ho * wo * cv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % cv) * V;
+        long r = i / cv;
+        const int ox = (int)(r % wo);
+        r /= wo;
+        const int oy = (int)(r % ho), im = (int)(r / ho);
+        const float* p00 = x + (((long)im * h + 2 * oy) * w + 2 * ox) * c + cc;
+        const float* p10 = p00 + (long)w * c;
+        float o[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) o[k] = fmaxf(fmaxf(p00[k], p00[c + k]), fmaxf(p10[k], p10[c + k]));
+        float* q = y + (((long)im * ho + oy) * wo + ox) * c + cc;
+#pragma unroll
+        for (int k = 0; k < V; ++k) q[k] = o[k];
+    }
+}
+
+// dz[n,y,x,c] = (first arg-max of the window ? dp : 0) [+ add] ) * [lrelu'(y)]
+template <int V>
+__global__ void maxpool2_bwd_kernel(const float* __restrict__ dp, const float* __restrict__ yact,
+                                    const float* add, float* dz, int n, int h, int w, int c, int apply_mask,
+                                    float alpha) {
+    const int ho = h / 2, wo = w / 2, cv = c / V;
+    const long total = (long)n * ho * wo * cv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % cv) * V;
+        long r = i / cv;
+        const int ox = (int)(r % wo);
+        r /= wo;
+        const int oy = (int)(r % ho), im = (int)(r / ho);
+        const long base = (((long)im * h + 2 * oy) * w + 2 * ox) * c + cc;
+        const long offs[4] = {0, (long)c, (long)w * c, (long)w * c + c};
+        const float* g = dp + (((long)im * ho + oy) * wo + ox) * c + cc;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = yact[base + offs[q] + k];
+            const float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+            int sel = 3;
+            if (v[0] == m) sel = 0; else if (v[1] == m) sel = 1; else if (v[2] == m) sel = 2;
+            const float gv = g[k];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float o = (q == sel) ? gv : 0.f;
+                if (add) o += add[base + offs[q] + k];
+                if (apply_mask) o *= (v[q] > 0.f ? 1.0f : alpha);
+                dz[base + offs[q] + k] = o;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Conv2DTranspose(k=2,s=2): out[n,2y+i,2x+j,co] = sum_ci in[n,y,x,ci] * w[i,j,co,ci] + b[co]
+// One workgroup: 16 input pixels x 64 output channels x the 4 taps, Cin streamed through LDS in chunks of 32.
+__global__ __launch_bounds__(256) void convt2x2_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y,
+                                                           long npix, int h, int wd, int cin, int cout) {
+    __shared__ float sx[16][33];
+    __shared__ float sw[4][64][33];
+    const int tid = threadIdx.x;
+    const int cot = (cout + 63) / 64;
+    const int co0 = (blockIdx.x % cot) * 64;
+    const long p0 = (long)(blockIdx.x / cot) * 16;
+    const int co = tid & 63, pg = tid >> 6;          // thread: channel co, pixels pg*4..pg*4+3, all 4 taps
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+    for (int c0 = 0; c0 < cin; c0 += 32) {
+        __syncthreads();
+        for (int it = tid; it < 16 * 32; it += 256) {
+            const int pp = it / 32, k = it % 32;
+            sx[pp][k] = (p0 + pp < npix && c0 + k < cin) ? x[(p0 + pp) * cin + c0 + k] : 0.f;
+        }
+        for (int it = tid; it < 4 * 64 * 32; it += 256) {
+            const int k = it % 32, oc = (it / 32) % 64, t = it / (32 * 64);
+            sw[t][oc][k] = (co0 + oc < cout && c0 + k < cin) ? w[((long)t * cout + co0 + oc) * cin + c0 + k] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int k = 0; k < 32; ++k) {
+            float xv[4], wv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) xv[a] = sx[pg * 4 + a][k];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wv[t] = sw[t][co][k];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[a][t] = fmaf(xv[a], wv[t], acc[a][t]);
+        }
+    }
+    if (co0 + co >= cout) return;
+    const float bv = bias ? bias[co0 + co] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const long pp = p0 + pg * 4 + a;
+        if (pp >= npix) continue;
+        const int xx = (int)(pp % wd);
+        const long rest = pp / wd;
+        const int yy = (int)(rest % h);
+        const long im = rest / h;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            y[(((im * 2 * h) + 2 * yy + (t >> 1)) * (2L * wd) + 2 * xx + (t & 1)) * cout + co0 + co] = acc[a][t] + bv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// depth_to_space(DCR, block 2) with optional affine + straight-through clip: y = clip(scale*d2s(x)+shift, 0, 1)
+__global__ void d2s_clip_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int h, int w, int co,
+                                    float scale, float shift, int clip) {
+    const long total = (long)n * h * w * 4 * co;        // output elements
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % co);
+        long r = i / co;
+        const int X = (int)(r % (2 * w));
+        r /= 2 * w;
+        const int Y = (int)(r % (2 * h)), im = (int)(r / (2 * h));
+        const float v = x[(((long)im * h + (Y >> 1)) * w + (X >> 1)) * (4 * co) + ((Y & 1) * 2 + (X & 1)) * co + c];
+        float o = scale * v + shift;
+        if (clip) o = fminf(fmaxf(o, 0.f), 1.f);
+        y[i] = o;
+    }
+}
+// gradient: straight-through (identity through the clip), dx = scale * space_to_depth(dy)
+__global__ void d2s_clip_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int n, int h, int w,
+                                    int co, float scale) {
+    const long total = (long)n * h * w * 4 * co;        // input elements
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % (4 * co));
+        long r = i / (4 * co);
+        const int xx = (int)(r % w);
+        r /= w;
+        const int yy = (int)(r % h), im = (int)(r / h);
+        const int blk = ch / co, c = ch % co;
+        dx[i] = scale * dy[(((long)im * 2 * h + 2 * yy + (blk >> 1)) * (2L * w) + 2 * xx + (blk & 1)) * co + c];
+    }
+}
+
+// dz = dy * lrelu'(y)
+__global__ void lrelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ yact, float* dz, long count,
+                                 float alpha) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+        dz[i] = dy[i] * (yact[i] > 0.f ? 1.0f : alpha);
+}
+
+// out = a + b (residual adds; out may alias a)
+__global__ void add_kernel(const float* a, const float* __restrict__ b, float* out, long count) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+        out[i] = a[i] + b[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// mse on 255-scaled images: loss = mean((255a-255b)^2); grad_a (+)= gscale * 2*255^2*(a-b)/count
+__global__ __launch_bounds__(256) void mse255_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                     float* grad_a, double* __restrict__ partial, long count,
+                                                     float gscale, int accumulate) {
+    __shared__ double red[4];
+    double s = 0.0;
+    const float gk = gscale * 2.0f * 255.0f * 255.0f / (float)count;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        const float d = a[i] - b[i];
+        const float e = 255.0f * d;
+        s += (double)e * (double)e;
+        if (grad_a) grad_a[i] = accumulate ? grad_a[i] + gk * d : gk * d;
+    }
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void mse255_final_kernel(const double* __restrict__ partial, int nblocks, long count, float* loss) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int k = 0; k < nblocks; ++k) s += partial[k];
+        loss[0] = (float)(s / (double)count);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// FAN head.  gap[n][c] = mean_p act[n][p][c]
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ act, float* __restrict__ gap, int hw,
+                                                      int c) {
+    const int n = blockIdx.x;
+    for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+        float s = 0.f;
+        const float* p = act + (long)n * hw * c + ch;
+        for (int q = 0; q < hw; ++q) s += p[(long)q * c];
+        gap[(long)n * c + ch] = s / (float)hw;
+    }
+}
+
+// one thread per image: logits = gap W + b, softmax, Keras sparse CE on probabilities (clip 1e-7, renormalise),
+// per-image loss and d loss / d logits (already scaled by loss_scale = 1 / batch)
+__global__ void dense_softmax_ce_kernel(const float* __restrict__ gap, const float* __restrict__ w,
+                                        const float* __restrict__ b, const int* __restrict__ labels,
+                                        float* __restrict__ probs, float* __restrict__ loss_per,
+                                        float* __restrict__ dlogits, int n, int c, int k, float loss_scale) {
+    const int im = blockIdx.x * blockDim.x + threadIdx.x;
+    if (im >= n) return;
+    float z[16], pr[16];
+    for (int j = 0; j < k; ++j) z[j] = b[j];
+    for (int ch = 0; ch < c; ++ch) {
+        const float g = gap[(long)im * c + ch];
+        for (int j = 0; j < k; ++j) z[j] = fmaf(g, w[ch * k + j], z[j]);
+    }
+    float m = z[0];
+    for (int j = 1; j < k; ++j) m = fmaxf(m, z[j]);
+    float s = 0.f;
+    for (int j = 0; j < k; ++j) { pr[j] = expf(z[j] - m); s += pr[j]; }
+    for (int j = 0; j < k; ++j) { pr[j] /= s; probs[(long)im * k + j] = pr[j]; }
+    if (!labels) return;
+    // keras backend sparse_categorical_crossentropy(from_logits=False), eager path: clip, log, softmax-CE of log p
+    const float eps = 1e-7f;
+    const int lab = labels[im];
+    float pc[16], S = 0.f;
+    for (int j = 0; j < k; ++j) { pc[j] = fminf(fmaxf(pr[j], eps), 1.0f - eps); S += pc[j]; }
+    loss_per[im] = -logf(pc[lab]) + logf(S);
+    // dL/dp_j = [p_j inside clip range] * (1/S - delta_jl / pc_l);   dL/dz = p * (g - sum_j g_j p_j)
+    float g[16], dot = 0.f;
+    for (int j = 0; j < k; ++j) {
+        const bool inside = pr[j] >= eps && pr[j] <= 1.0f - eps;
+        g[j] = inside ? (1.0f / S - (j == lab ? 1.0f / pc[lab] : 0.f)) : 0.f;
+        dot += g[j] * pr[j];
+    }
+    for (int j = 0; j < k; ++j) dlogits[(long)im * k + j] = loss_scale * pr[j] * (g[j] - dot);
+}
+
+// dW[c][j] = sum_n gap[n][c] dlogits[n][j];  db[j] = sum_n dlogits[n][j];  loss = scale * sum loss_per
+__global__ void dense_bwd_params_kernel(const float* __restrict__ gap, const float* __restrict__ dlogits,
+                                        const float* __restrict__ loss_per, float* __restrict__ dw,
+                                        float* __restrict__ db, float* __restrict__ loss, int n, int c, int k,
+                                        float loss_scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < c * k) {
+        const int ch = i / k, j = i % k;
+        float s = 0.f;
+        for (int im = 0; im < n; ++im) s = fmaf(gap[(long)im * c + ch], dlogits[(long)im * k + j], s);
+        dw[i] = s;
+    } else if (i < c * k + k) {
+        const int j = i - c * k;
+        float s = 0.f;
+        for (int im = 0; im < n; ++im) s += dlogits[(long)im * k + j];
+        db[j] = s;
+    } else if (i == c * k + k) {
+        double s = 0.0;
+        for (int im = 0; im < n; ++im) s += (double)loss_per[im];
+        loss[0] = (float)(s * (double)loss_scale);
+    }
+}
+
+// d act[n][p][ch] = (sum_j dlogits[n][j] W[ch][j]) / hw * lrelu'(act)
+__global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ w,
+                                                      const float* __restrict__ act, float* __restrict__ dact,
+                                                      int hw, int c, int k, float alpha) {
+    const int n = blockIdx.x;
+    for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+        float g = 0.f;
+        for (int j = 0; j < k; ++j) g = fmaf(dlogits[(long)n * k + j], w[ch * k + j], g);
+        g /= (float)hw;
+        const long base = (long)n * hw * c + ch;
+        for (int q = 0; q < hw; ++q) dact[base + (long)q * c] = g * (act[base + (long)q * c] > 0.f ? 1.0f : alpha);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Keras Adam: theta -= lr_t * m / (sqrt(v) + eps), lr_t = lr * sqrt(1-b2^t)/(1-b1^t); optional grad pre-scale
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long count, float lr_t, float b1, float b2, float eps,
+                            float gscale, const int* __restrict__ skip_flag) {
+    if (skip_flag && skip_flag[0]) return;      // NaN gradients: leave the model untouched (reference raises first)
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        const float gi = gscale * g[i];
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+// flag[0] = 1 if any element is NaN (workflows/manipulation_classification.py:281-282, kept on device)
+__global__ void nan_flag_kernel(const float* __restrict__ g, long count, int* flag) {
+    bool bad = false;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+        bad |= (g[i] != g[i]);
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+}  // namespace
+
+extern "C" {
+
+int nimg_maxpool2_fwd(const float* x, float* y, int n, int h, int w, int c, void* stream) {
+    if (!x || !y || n < 0 || h <= 0 || w <= 0 || c <= 0 || (h & 1) || (w & 1)) return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (c % 4 == 0)
+        hipLaunchKernelGGL(maxpool2_fwd_kernel<4>, dim3(grid_for((long)n * (h / 2) * (w / 2) * (c / 4))), dim3(256),
+                           0, s, x, y, n, h, w, c);
+    else
+        hipLaunchKernelGGL(maxpool2_fwd_kernel<1>, dim3(grid_for((long)n * (h / 2) * (w / 2) * c)), dim3(256), 0, s,
+                           x, y, n, h, w, c);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_maxpool2_bwd(const float* dp, const float* yact, const float* add, float* dz, int n, int h, int w, int c,
+                      int apply_lrelu_mask, float alpha, void* stream) {
+    if (!dp || !yact || !dz || n < 0 || h <= 0 || w <= 0 || c <= 0 || (h & 1) || (w & 1)) return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (c % 4 == 0)
+        hipLaunchKernelGGL(maxpool2_bwd_kernel<4>, dim3(grid_for((long)n * (h / 2) * (w / 2) * (c / 4))), dim3(256),
+                           0, s, dp, yact, add, dz, n, h, w, c, apply_lrelu_mask, alpha);
+    else
+        hipLaunchKernelGGL(maxpool2_bwd_kernel<1>, dim3(grid_for((long)n * (h / 2) * (w / 2) * c)), dim3(256), 0, s,
+                           dp, yact, add, dz, n, h, w, c, apply_lrelu_mask, alpha);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_convt2x2_fwd(const float* x, const float* w, const float* bias, float* y, int n, int h, int wd, int cin,
+                      int cout, void* stream) {
+    if (!x || !w || !y || n < 0 || h <= 0 || wd <= 0 || cin <= 0 || cout <= 0) return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    const long npix = (long)n * h * wd;
+    const long blocks = ((npix + 15) / 16) * ((cout + 63) / 64);
+    hipLaunchKernelGGL(convt2x2_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias, y,
+                       npix, h, wd, cin, cout);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_d2s_clip_fwd(const float* x, float* y, int n, int h, int w, int cout, float scale, float shift, int clip,
+                      void* stream) {
+    if (!x || !y || n < 0 || h <= 0 || w <= 0 || cout <= 0) return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    hipLaunchKernelGGL(d2s_clip_fwd_kernel, dim3(grid_for((long)n * h * w * 4 * cout)), dim3(256), 0,
+                       (hipStream_t)stream, x, y, n, h, w, cout, scale, shift, clip);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_d2s_clip_bwd(const float* dy, float* dx, int n, int h, int w, int cout, float scale, void* stream) {
+    if (!dy || !dx || n < 0 || h <= 0 || w <= 0 || cout <= 0) return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    hipLaunchKernelGGL(d2s_clip_bwd_kernel, dim3(grid_for((long)n * h * w * 4 * cout)), dim3(256), 0,
+                       (hipStream_t)stream, dy, dx, n, h, w, cout, scale);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_lrelu_bwd(const float* dy, const float* yact, float* dz, long count, float alpha, void* stream) {
+    if (!dy || !yact || !dz || count < 0) return NIMG_ERR_ARG;
+    if (count == 0) return NIMG_OK;
+    hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, dy, yact, dz,
+                       count, alpha);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_add(const float* a, const float* b, float* out, long count, void* stream) {
+    if (!a || !b || !out || count < 0) return NIMG_ERR_ARG;
+    if (count == 0) return NIMG_OK;
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, a, b, out, count);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+size_t nimg_mse255_workspace_bytes(void) { return 2048 * sizeof(double); }
+
+int nimg_mse255(const float* a, const float* b, float* loss, float* grad_a, long count, float grad_scale,
+                int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!a || !b || !loss || count <= 0 || !workspace) return NIMG_ERR_ARG;
+    if (workspace_bytes < nimg_mse255_workspace_bytes()) return NIMG_ERR_WORKSPACE;
+    const int grid = grid_for(count);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(mse255_kernel, dim3(grid), dim3(256), 0, s, a, b, grad_a, (double*)workspace, count,
+                       grad_scale, accumulate);
+    NIMG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(mse255_final_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, grid, count, loss);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_fan_head_fwd(const float* act, const float* w, const float* b, const int* labels, float* gap, float* probs,
+                      float* loss_per, float* dlogits, int n, int hw, int c, int k, float loss_scale, void* stream) {
+    if (!act || !w || !b || !gap || !probs || n < 0 || hw <= 0 || c <= 0 || k <= 0 || k > 16) return NIMG_ERR_ARG;
+    if (labels && (!loss_per || !dlogits)) return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gap_fwd_kernel, dim3(n), dim3(256), 0, s, act, gap, hw, c);
+    NIMG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dense_softmax_ce_kernel, dim3((n + 63) / 64), dim3(64), 0, s, gap, w, b, labels, probs,
+                       loss_per, dlogits, n, c, k, loss_scale);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_fan_head_bwd(const float* act, const float* gap, const float* w, const float* dlogits,
+                      const float* loss_per, float* dact, float* dw, float* db, float* loss, int n, int hw, int c,
+                      int k, float loss_scale, float alpha, void* stream) {
+    if (!act || !gap || !w || !dlogits || !loss_per || !dact || !dw || !db || !loss) return NIMG_ERR_ARG;
+    if (n <= 0 || hw <= 0 || c <= 0 || k <= 0 || k > 16) return NIMG_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int items = c * k + k + 1;
+    hipLaunchKernelGGL(dense_bwd_params_kernel, dim3((items + 63) / 64), dim3(64), 0, s, gap, dlogits, loss_per, dw,
+                       db, loss, n, c, k, loss_scale);
+    NIMG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gap_bwd_kernel, dim3(n), dim3(256), 0, s, dlogits, w, act, dact, hw, c, k, alpha);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_adam_step(float* params, const float* grads, float* m, float* v, long count, float lr, float beta1,
+                   float beta2, float eps, int step, float grad_scale, const int* skip_flag, void* stream) {
+    if (!params || !grads || !m || !v || count < 0 || step < 1) return NIMG_ERR_ARG;
+    if (count == 0) return NIMG_OK;
+    const double lr_t = (double)lr * __builtin_sqrt(1.0 - __builtin_pow((double)beta2, (double)step)) /
+                        (1.0 - __builtin_pow((double)beta1, (double)step));
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v,
+                       count, (float)lr_t, beta1, beta2, eps, grad_scale, skip_flag);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_nan_flag(const float* g, long count, int* flag, void* stream) {
+    if (!g || !flag || count < 0) return NIMG_ERR_ARG;
+    if (count == 0) return NIMG_OK;
+    hipLaunchKernelGGL(nan_flag_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, g, count, flag);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,136 @@
+"""
+Photo manipulations and image losses of the channel on the HIP kernels.  Same function names and argument meaning as
+the reference's helpers/tf_helpers.py (manipulation_* :68-184, mse :31-32); each manipulation also exists as an object
+with forward(x, strength, out) / backward(ctx, dy), which is what the workflow's training step uses.
+
+Implemented: sharpen (hsv=True, incl. the S-channel corner-tap quirk), resample (bilinear down+up, any factor),
+gaussian (5x5, any std).  awgn / gamma / median (tf_helpers.py:79-110) are not in the default manipulation set
+(train_manipulation.py:115) and raise NotImplementedError until built.
+"""
+import numpy as np
+import torch
+
+from .. import ops
+from ..device import DeviceArray, to_device, default_device
+from . import kernels as hk
+
+
+class Sharpen(object):
+    """manipulation_sharpen(x, strength, hsv=True)  (tf_helpers.py:156-184)"""
+
+    def __init__(self):
+        self._cache = {}
+
+    def taps(self, strength, device):
+        key = (float(strength), str(device))
+        if key not in self._cache:
+            gk = hk.sharpen_kernel(float(strength)).astype(np.float32)      # tf.constant(gfilter, tf.float32)
+            self._cache[key] = torch.from_numpy(gk.reshape(-1)).to(device)
+        return self._cache[key]
+
+    def forward(self, x, strength=1, out=None, training=False):
+        gk = self.taps(strength, x.device)
+        y, aux, mask = ops.sharpen_fwd(x, gk, out=out, want_aux=training)
+        return y, ({'x': x, 'aux': aux, 'mask': mask, 'gk': gk} if training else None)
+
+    def backward(self, ctx, dy):
+        return ops.sharpen_bwd(ctx['x'], dy, ctx['aux'], ctx['mask'], ctx['gk'])
+
+
+class Gaussian(object):
+    """manipulation_gaussian(x, 5, std)  (tf_helpers.py:113-125)"""
+
+    def __init__(self, kernel=5):
+        if kernel != 5:
+            raise NotImplementedError('only the 5x5 gaussian used by the workflow is built')
+        self._cache = {}
+
+    def taps(self, std, device):
+        key = (float(std), str(device))
+        if key not in self._cache:
+            gk = hk.gkern(5, float(std)).astype(np.float32)
+            self._cache[key] = torch.from_numpy(gk.reshape(-1)).to(device)
+        return self._cache[key]
+
+    def forward(self, x, std=0.83, out=None, training=False, skip_clip=False):
+        gk = self.taps(std, x.device)
+        y, mask = ops.gaussian_fwd(x, gk, out=out, clip=not skip_clip, want_mask=training)
+        return y, ({'mask': mask, 'gk': gk} if training else None)
+
+    def backward(self, ctx, dy):
+        return ops.gaussian_bwd(dy, ctx['mask'], ctx['gk'])
+
+
+class Resample(object):
+    """manipulation_resample(x, factor) (tf_helpers.py:68-76): bilinear down to floor(H*factor/100) and back up, both
+    dims sized from shape[1].  The composition is one banded linear operator M per axis: y = M x M^T, dx = M^T dy M."""
+
+    def __init__(self):
+        self._cache = {}
+
+    def operator(self, size, factor, device):
+        if 0 < factor <= 1:
+            factor = 100 * factor
+        small = size * int(factor) // 100
+        key = (size, small, str(device))
+        if key not in self._cache:
+            m = hk.bilinear_axis_matrix(small, size) @ hk.bilinear_axis_matrix(size, small)
+            self._cache[key] = ops.AxisOperator(m, device)
+        return self._cache[key]
+
+    def forward(self, x, factor=50, out=None, training=False):
+        if x.shape[1] != x.shape[2]:
+            raise ValueError('manipulation_resample assumes square patches (tf_helpers.py:73-76)')
+        op = self.operator(x.shape[1], factor, x.device)
+        tmp = ops.sparse_axis_apply(x, op.fwd, 0, op.out_size)
+        y = ops.sparse_axis_apply(tmp, op.fwd, 1, op.out_size, out=out)
+        return y, ({'op': op} if training else None)
+
+    def backward(self, ctx, dy):
+        op = ctx['op']
+        tmp = ops.sparse_axis_apply(dy, op.bwd, 0, op.in_size)
+        return ops.sparse_axis_apply(tmp, op.bwd, 1, op.in_size)
+
+
+_sharpen, _gaussian, _resample = Sharpen(), Gaussian(), Resample()
+
+
+def _dev(x):
+    x = x.t if isinstance(x, DeviceArray) else x
+    return x.device if isinstance(x, torch.Tensor) and x.is_cuda else default_device()
+
+
+def manipulation_sharpen(x, strength=1, hsv=True):
+    if not hsv:
+        raise NotImplementedError('the workflow always uses hsv=True (workflows/manipulation_classification.py:107)')
+    return DeviceArray(_sharpen.forward(to_device(x, _dev(x)), strength)[0])
+
+
+def manipulation_resample(x, factor=50, method='bilinear'):
+    if method != 'bilinear':
+        raise NotImplementedError(method)
+    return DeviceArray(_resample.forward(to_device(x, _dev(x)), factor)[0])
+
+
+def manipulation_gaussian(x, kernel, std, skip_clip=False):
+    if int(kernel) != 5:
+        raise NotImplementedError('only the 5x5 gaussian used by the workflow is built')
+    return DeviceArray(_gaussian.forward(to_device(x, _dev(x)), std, skip_clip=skip_clip)[0])
+
+
+def manipulation_awgn(x, strength=0.025):
+    raise NotImplementedError('awgn is not in the default manipulation set; not built yet')
+
+
+def manipulation_gamma(x, strength=2.0):
+    raise NotImplementedError('gamma is not in the default manipulation set; not built yet')
+
+
+def manipulation_median(x, kernel=3):
+    raise NotImplementedError('median is not in the default manipulation set; not built yet')
+
+
+def mse(a, b):
+    """mean((255a - 255b)^2)  (tf_helpers.py:31-32)"""
+    d = _dev(a)
+    return DeviceArray(ops.mse255(to_device(a, d), to_device(b, d))[0])

@@ -1,0 +1,155 @@
+"""
+FAN - forensic analysis network on the HIP kernels.  Mirrors the reference's models/forensics.py:29-133.
+
+Graph as built by the workflow's defaults (forensics.py:62-90; ctor values override the ParamSpec defaults, SURVEY 8a
+quirk 6): ConstrainedConv2D -> 4 x [Conv5x5 SAME (32,64,128,256) + LeakyReLU(0.2) -> MaxPool2] -> Conv1x1 256 + LReLU
+-> GAP -> Dense(n_classes, softmax); loss = SparseCategoricalCrossentropy on probabilities (forensics.py:94).
+Only use_gap=True / n_dense=0 / dropout=0 (the configuration every caller in the reference uses) is built.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..device import DeviceArray, to_device
+from ..helpers import paramspec
+from .layers import ConstrainedConv2D, Conv2D
+from .tfmodel import ParamStore, TFModel, glorot_uniform_
+
+
+class FAN(TFModel):
+
+    def __init__(self, n_classes, patch_size=None, n_filters=32, n_fscale=2, n_convolutions=4, kernel=5, dropout=0.0,
+                 use_gap=True, n_dense=0, activation='leaky_relu', device=None, seed=4321):
+        super().__init__(device=device)
+        self._h = paramspec.ParamSpec({
+            'n_classes': (7, int, (2, 256)),
+            'n_filters': (32, int, (4, 128)),
+            'n_fscale': (2, float, (0.25, 4)),
+            'n_convolutions': (4, int, (1, 32)),
+            'kernel': (5, int, (3, 11)),
+            'dropout': (0, float, (0, 1)),
+            'use_gap': (False, bool, None),
+            'n_dense': (2, int, (0, 16)),
+            'activation': ('leaky_relu', str, {'leaky_relu'}),
+        })
+        params = locals()
+        self._h.update(**{k: params[k] for k in self._h.keys()})
+        if not use_gap or n_dense != 0 or dropout != 0:
+            raise NotImplementedError('only the use_gap=True, n_dense=0, dropout=0 head is built')
+        if self._h.kernel not in (3, 5) or self._h.n_classes > 16:
+            raise NotImplementedError('kernel size {} / {} classes not built'.format(self._h.kernel, self._h.n_classes))
+        self.patch_size = patch_size
+        self.x = _Shape((None, patch_size, patch_size, 3))
+        self.y = _Shape((None, n_classes))
+
+        self._constrained = ConstrainedConv2D('constrained')
+        self._convs = []
+        cin, nf = 3, n_filters
+        for i in range(self._h.n_convolutions):
+            self._convs.append(Conv2D('conv{}'.format(i + 1), self._h.kernel, cin, nf, 'leaky_relu'))
+            cin, nf = nf, int(nf * self._h.n_fscale)
+        nf = int(nf // self._h.n_fscale)
+        self._conv1x1 = Conv2D('conv1x1', 1, cin, nf, 'leaky_relu')
+        self._n_features = nf
+        specs = self._constrained.specs()
+        for c in self._convs:
+            specs += c.specs()
+        specs += self._conv1x1.specs()
+        specs += [('dense/kernel', (nf, n_classes)), ('dense/bias', (n_classes,))]
+        self._model = ParamStore(specs, self.device)
+        gen = torch.Generator().manual_seed(seed)
+        self._constrained.init(self._model)
+        for c in self._convs:
+            c.init(self._model, gen)
+        self._conv1x1.init(self._model, gen)
+        k = torch.empty((nf, n_classes), dtype=torch.float32)
+        glorot_uniform_(k, nf, n_classes, gen)
+        self._model.p['dense/kernel'].copy_(k)
+        self.learning_rate = 1e-3
+        self.loss = self._loss
+
+    def reset_performance_stats(self):
+        self.performance = {'loss': {'training': [], 'validation': []}, 'accuracy': {'validation': []},
+                            'confusion': []}
+
+    # ------------------------------------------------------------------------------------------------------------
+    def forward(self, x, labels=None, training=False, loss_scale=None):
+        """x (N,H,W,3) device tensor. labels: int32 device tensor or None. Returns (probs, ctx)."""
+        P = self._model
+        t = OrderedDict()
+        t['x'] = x
+        net, nf = self._constrained.forward(P, x)
+        t['constrained'], t['nf'] = net, nf
+        for i, c in enumerate(self._convs):
+            a = c.forward(P, net)
+            t['conv{}'.format(i + 1)] = a
+            net = ops.maxpool2(a)
+            t['pool{}'.format(i + 1)] = net
+        a = self._conv1x1.forward(P, net)
+        t['conv1x1'] = a
+        n = x.shape[0]
+        ls = (1.0 / n) if loss_scale is None else loss_scale
+        gap, probs, loss_per, dlogits = ops.fan_head_fwd(a, P.p['dense/kernel'], P.p['dense/bias'], labels, ls)
+        t['gap'], t['probs'], t['loss_per'], t['dlogits'], t['loss_scale'] = gap, probs, loss_per, dlogits, ls
+        return probs, (t if training else None)
+
+    def backward(self, t, need_input_grad=False):
+        """Fills the gradient buffer; returns (loss[1], d loss / d x or None)."""
+        P = self._model
+        hw = lambda a: (a.shape[1], a.shape[2])
+        a = t['conv1x1']
+        dz, loss = ops.fan_head_bwd(a, t['gap'], P.p['dense/kernel'], t['dlogits'], t['loss_per'], t['loss_scale'],
+                                    P.g['dense/kernel'], P.g['dense/bias'])
+        nconv = len(self._convs)
+        pool = t['pool{}'.format(nconv)]
+        self._conv1x1.backward_params(P, pool, dz)
+        d_pool = self._conv1x1.backward_input(P, dz, hw(pool))
+        for i in range(nconv, 0, -1):
+            act = t['conv{}'.format(i)]
+            inp = t['pool{}'.format(i - 1)] if i > 1 else t['constrained']
+            dz = ops.maxpool2_bwd(d_pool, act, None, apply_mask=True)
+            self._convs[i - 1].backward_params(P, inp, dz)
+            d_pool = self._convs[i - 1].backward_input(P, dz, hw(inp))
+        self._constrained.backward_params(P, t['x'], d_pool)
+        dx = self._constrained.backward_input(t['nf'], d_pool) if need_input_grad else None
+        return loss, dx
+
+    # -- reference surface ---------------------------------------------------------------------------------------
+    def _loss(self, labels, probs):
+        """SparseCategoricalCrossentropy()(labels, probabilities) (forensics.py:94), host-side convenience."""
+        p = np.clip(np.asarray(probs, np.float64), 1e-7, 1 - 1e-7)
+        lab = np.asarray(labels).astype(np.int64)
+        return float(np.mean(np.log(p.sum(axis=1)) - np.log(p[np.arange(len(lab)), lab])))
+
+    def process(self, batch_x, training=False):
+        """Class probabilities for an image batch (NHWC rgb)."""
+        return DeviceArray(self.forward(to_device(batch_x, self.device))[0])
+
+    def process_and_decide(self, batch_x, with_confidence=False):
+        probs = self.process(batch_x).numpy()
+        if with_confidence:
+            return probs.argmax(axis=1), probs.max(axis=1)
+        return probs.argmax(axis=1)
+
+    def training_step(self, batch_x, target_labels, learning_rate=None):
+        """One optimisation step (forensics.py:116-125); returns the loss."""
+        x = to_device(batch_x, self.device)
+        labels = torch.as_tensor(np.asarray(target_labels), dtype=torch.int32).to(self.device)
+        _, ctx = self.forward(x, labels, training=True)
+        loss, _ = self.backward(ctx, need_input_grad=False)
+        if learning_rate is not None:
+            self.learning_rate = learning_rate
+        self._model.adam(self.learning_rate)
+        return DeviceArray(loss)
+
+    def summary(self):
+        return '{kernel}x{kernel} CNN: 1+{conv}+1 conv layers {gap}+ {fc} fc layers [{params:,} parameters]'.format(
+            kernel=self._h.kernel, conv=self._h.n_convolutions, fc=self._h.n_dense,
+            gap='+ (GAP) ' if self._h.use_gap else '', params=self.count_parameters())
+
+
+class _Shape(object):
+    def __init__(self, shape):
+        self.shape = tuple(shape)

@@ -1,0 +1,104 @@
+"""
+Layer building blocks with explicit forward / backward passes over the HIP kernels (no autograd tape):
+the counterpart of the Keras layers the reference composes (tf.keras.layers.Conv2D / Conv2DTranspose / MaxPool2D) and
+of its custom layers in models/layers.py (ConstrainedConv2D :12-57, Quantization :60-172).
+
+Convention: a layer's backward receives dz = gradient w.r.t. its PRE-activation output (the LeakyReLU derivative has
+already been applied by whoever produced dz - it is fused into the producing kernel's epilogue) and
+  * writes its parameter gradients into the model's flat gradient buffer,
+  * returns the gradient w.r.t. its input, optionally already multiplied by the previous layer's LeakyReLU'.
+"""
+import numpy as np
+import torch
+
+from .. import ops
+from ..helpers import kernels as hk
+
+
+class Conv2D(object):
+    """Conv2D(cout, ks, stride, 'SAME', activation) with (kh,kw,Cin,Cout) kernel + bias."""
+
+    def __init__(self, name, ks, cin, cout, activation=None, stride=1, cin2=0):
+        self.name, self.ks, self.cin, self.cin2, self.cout = name, ks, cin, cin2, cout
+        self.activation, self.stride = activation, stride
+
+    def specs(self):
+        return [(self.name + '/kernel', (self.ks, self.ks, self.cin + self.cin2, self.cout)),
+                (self.name + '/bias', (self.cout,))]
+
+    def init(self, store, gen):
+        from .tfmodel import glorot_uniform_
+        rf = self.ks * self.ks
+        k = torch.empty(store.p[self.name + '/kernel'].shape, dtype=torch.float32)
+        glorot_uniform_(k, (self.cin + self.cin2) * rf, self.cout * rf, gen)
+        store.p[self.name + '/kernel'].copy_(k)
+        store.p[self.name + '/bias'].zero_()
+
+    def forward(self, store, x, x2=None):
+        return ops.conv2d(x, store.p[self.name + '/kernel'], store.p[self.name + '/bias'], x2=x2,
+                          stride=self.stride, act=self.activation)
+
+    def backward_params(self, store, x, dz, x2=None):
+        ops.conv2d_wgrad(x, dz, self.ks, x2=x2, stride=self.stride, dw=store.g[self.name + '/kernel'])
+        ops.bias_grad(dz, db=store.g[self.name + '/bias'])
+
+    def backward_input(self, store, dz, in_hw, act_mask=None, out=None, out2=None):
+        return ops.conv2d_dgrad(dz, store.p[self.name + '/kernel'], in_hw, stride=self.stride, act_mask=act_mask,
+                                out=out, out2=out2)
+
+
+class Conv2DTranspose2x2(object):
+    """Conv2DTranspose(cout, [2,2], [2,2], 'SAME'), kernel (2,2,Cout,Cin) + bias, no activation (pipelines.py:205)."""
+
+    def __init__(self, name, cin, cout):
+        self.name, self.cin, self.cout = name, cin, cout
+
+    def specs(self):
+        return [(self.name + '/kernel', (2, 2, self.cout, self.cin)), (self.name + '/bias', (self.cout,))]
+
+    def init(self, store, gen):
+        from .tfmodel import glorot_uniform_
+        k = torch.empty((2, 2, self.cout, self.cin), dtype=torch.float32)
+        glorot_uniform_(k, self.cin * 4, self.cout * 4, gen)
+        store.p[self.name + '/kernel'].copy_(k)
+        store.p[self.name + '/bias'].zero_()
+
+    def forward(self, store, x):
+        return ops.convt2x2(x, store.p[self.name + '/kernel'], store.p[self.name + '/bias'])
+
+    def backward_params(self, store, x, dy):
+        ops.convt2x2_wgrad(x, dy, dw=store.g[self.name + '/kernel'])
+        ops.bias_grad(dy, db=store.g[self.name + '/bias'])
+
+    def backward_input(self, store, dy, act_mask=None):
+        return ops.convt2x2_dgrad(dy, store.p[self.name + '/kernel'], act_mask=act_mask)
+
+
+class ConstrainedConv2D(object):
+    """Trainable constrained residual filter (models/layers.py:12-57): the (5,5,3,3) kernel is re-normalised on every
+    call (centre taps fixed to -strength, every output channel sums to 0), input padded SYMMETRIC, VALID conv."""
+
+    def __init__(self, name='constrained', filter_strength=100.0):
+        self.name, self.strength = name, float(filter_strength)
+
+    def specs(self):
+        return [(self.name + '/kernel', (5, 5, 3, 3))]
+
+    def init(self, store, gen=None):
+        store.p[self.name + '/kernel'].copy_(torch.from_numpy(hk.residual_init_filter().astype(np.float32)))
+
+    def forward(self, store, x):
+        nf = ops.constrained_kernel(store.p[self.name + '/kernel'], self.strength)
+        y = ops.conv2d(x, nf, None, pads=(2, 2), out_hw=(x.shape[1], x.shape[2]), pad_mode=1)
+        return y, nf
+
+    def backward_params(self, store, x, dy):
+        dnf = ops.conv2d_wgrad(x, dy, 5, pads=(2, 2), pad_mode=1)
+        ops.constrained_kernel_bwd(store.p[self.name + '/kernel'], dnf, store.g[self.name + '/kernel'], self.strength)
+
+    def backward_input(self, nf, dy):
+        # gradient on the padded domain (full correlation with the flipped filter), then fold the SYMMETRIC pad
+        n, h, w, _ = dy.shape
+        wt = ops.flip_weights(nf)
+        dpad = ops.conv2d(dy, wt, None, pads=(4, 4), out_hw=(h + 4, w + 4))
+        return ops.fold_pad(dpad, 2, 1)

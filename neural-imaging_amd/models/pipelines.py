@@ -1,0 +1,213 @@
+"""
+Neural imaging pipelines (camera ISPs) on the HIP kernels.  Mirrors the reference's models/pipelines.py:
+NIPModel (:27-166) - loss selection, training_step, process - and UNet (:169-230); ONet (:353-362) is the identity ISP.
+INet / DNet / ClassicISP reuse the same kernels with other graphs and are SURVEY 8(f) "next".
+
+UNet graph (pipelines.py:190-223): encoder n=1..5: 2 x [Conv3x3 SAME, 32*2^(n-1), LeakyReLU(0.2)] + MaxPool2 (not after
+n=5); decoder n=1..4: ConvT 2x2 s2 -> concat(up, skip) [never materialised: the conv reads two tensors] -> 2 x
+Conv3x3+LReLU; Conv3x3 -> 12 (linear) -> depth_to_space(2) -> straight-through clip.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..device import DeviceArray, to_device
+from ..helpers import paramspec, utils
+from .layers import Conv2D, Conv2DTranspose2x2
+from .tfmodel import ParamStore, TFModel
+
+
+class NIPModel(TFModel):
+    """Abstract neural imaging pipeline: RAW (N,h,w,4) -> RGB (N,2h,2w,3)."""
+
+    def __init__(self, loss_metric='L2', patch_size=None, in_channels=4, device=None, seed=1234, **kwargs):
+        super().__init__(device=device)
+        self.in_channels = in_channels
+        self.patch_size = patch_size
+        self.x = _Placeholder((None, patch_size, patch_size, in_channels))
+        self._seed = seed
+        self.construct_model(**kwargs)
+        self._has_attributes(['y', '_model'])
+        self.loss_metric = loss_metric
+        self.construct_loss(loss_metric)
+
+    def construct_loss(self, loss_metric):
+        if loss_metric == 'L2':
+            self.loss = lambda a, b: DeviceArray(ops.mse255(to_device(a, self.device), to_device(b, self.device))[0])
+        elif loss_metric in ('L1', 'SSIM', 'MS-SSIM'):
+            raise NotImplementedError('loss metric {} is not built yet (SURVEY 8f)'.format(loss_metric))
+        else:
+            raise ValueError('Unsupported loss metric!')
+
+    def construct_model(self):
+        raise NotImplementedError()
+
+    # forward/backward used by the workflow ----------------------------------------------------------------------
+    def forward(self, x, training=False):
+        raise NotImplementedError()
+
+    def backward(self, ctx, dy):
+        raise NotImplementedError()
+
+    def training_step(self, batch_x, batch_y, learning_rate=None):
+        """One step on mse(255 Y, 255 y) (pipelines.py:77-90). Returns the loss."""
+        x = to_device(batch_x, self.device)
+        t = to_device(batch_y, self.device)
+        y, ctx = self.forward(x, training=True)
+        loss, dy = ops.mse255(y, t, grad_scale=1.0)
+        self.backward(ctx, dy)
+        if learning_rate is not None:
+            self.learning_rate = learning_rate
+        self._model.adam(self.learning_rate)
+        return DeviceArray(loss)
+
+    learning_rate = 1e-3      # tf.keras.optimizers.Adam() default
+
+    def process(self, batch_x, training=False):
+        x = to_device(batch_x, self.device)
+        if x.dim() == 3:
+            x = x.unsqueeze(0).contiguous()
+        return DeviceArray(self.forward(x, training=False)[0])
+
+    def reset_performance_stats(self):
+        self.performance = {'loss': {'training': [], 'validation': []}, 'psnr': {'validation': []},
+                            'ssim': {'validation': []}}
+
+    def get_hyperparameters(self):
+        p = {'in_channels': self.in_channels}
+        if hasattr(self, '_h'):
+            p.update(self._h.to_json())
+        return p
+
+    @property
+    def patch_size_raw(self):
+        return self.x.shape[1:]
+
+    @property
+    def patch_size_rgb(self):
+        return self.y.shape[1:]
+
+    def summary(self):
+        return '{:s} : {} -> {}'.format(super().summary(), utils.format_patch_shape(self.patch_size_raw),
+                                        utils.format_patch_shape(self.patch_size_rgb))
+
+
+class _Placeholder(object):
+    """Stands in for the tf.keras.Input / output tensors callers only query for .shape."""
+
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+
+
+class UNet(NIPModel):
+
+    def construct_model(self, **kwargs):
+        self._h = paramspec.ParamSpec({
+            'n_steps': (5, int, (2, 6)),
+            'activation': ('leaky_relu', str, {'leaky_relu'}),
+        })
+        self._h.update(**kwargs)
+        ns = self._h.n_steps
+        self._layers = OrderedDict()
+        cin = self.in_channels
+        for n in range(1, ns + 1):
+            c = 32 * 2 ** (n - 1)
+            self._layers['ec{}1'.format(n)] = Conv2D('ec{}1'.format(n), 3, cin, c, 'leaky_relu')
+            self._layers['ec{}2'.format(n)] = Conv2D('ec{}2'.format(n), 3, c, c, 'leaky_relu')
+            cin = c
+        for n in range(1, ns):
+            c = 32 * 2 ** (ns - n - 1)
+            self._layers['dct{}'.format(n)] = Conv2DTranspose2x2('dct{}'.format(n), cin, c)
+            self._layers['dc{}1'.format(n)] = Conv2D('dc{}1'.format(n), 3, c, c, 'leaky_relu', cin2=c)
+            self._layers['dc{}2'.format(n)] = Conv2D('dc{}2'.format(n), 3, c, c, 'leaky_relu')
+            cin = c
+        self._layers['dc{}'.format(ns)] = Conv2D('dc{}'.format(ns), 3, cin, 12, None)
+        specs = [s for l in self._layers.values() for s in l.specs()]
+        self._model = ParamStore(specs, self.device)
+        gen = torch.Generator().manual_seed(self._seed)
+        for l in self._layers.values():
+            l.init(self._model, gen)
+        ps = self.patch_size
+        self.y = _Placeholder((None, None if ps is None else 2 * ps, None if ps is None else 2 * ps, 3))
+
+    @property
+    def model_code(self):
+        return '{}_{}'.format(self.class_name, self._h.n_steps)
+
+    def forward(self, x, training=False):
+        L, P, ns = self._layers, self._model, self._h.n_steps
+        t = OrderedDict()
+        t['ep0'] = x
+        for n in range(1, ns + 1):
+            t['ec{}1'.format(n)] = L['ec{}1'.format(n)].forward(P, t['ep{}'.format(n - 1)])
+            t['ec{}2'.format(n)] = L['ec{}2'.format(n)].forward(P, t['ec{}1'.format(n)])
+            if n < ns:
+                t['ep{}'.format(n)] = ops.maxpool2(t['ec{}2'.format(n)])
+        t['dc02'] = t['ec{}2'.format(ns)]
+        for n in range(1, ns):
+            t['dct{}'.format(n)] = L['dct{}'.format(n)].forward(P, t['dc{}2'.format(n - 1)])
+            t['dc{}1'.format(n)] = L['dc{}1'.format(n)].forward(P, t['dct{}'.format(n)], t['ec{}2'.format(ns - n)])
+            t['dc{}2'.format(n)] = L['dc{}2'.format(n)].forward(P, t['dc{}1'.format(n)])
+        t['dc{}'.format(ns)] = L['dc{}'.format(ns)].forward(P, t['dc{}2'.format(ns - 1)])
+        y = ops.d2s_clip(t['dc{}'.format(ns)], 1.0, 0.0, True)
+        return y, (t if training else None)
+
+    def backward(self, t, dy):
+        """dy = d loss / d y (N,2h,2w,3).  Fills the gradient buffer; the RAW input needs no gradient."""
+        L, P, ns = self._layers, self._model, self._h.n_steps
+        hw = lambda a: (a.shape[1], a.shape[2])
+        # head: d2s + clip are straight-through
+        dz = ops.d2s_clip_bwd(dy, 1.0)
+        last = 'dc{}2'.format(ns - 1)
+        L['dc{}'.format(ns)].backward_params(P, t[last], dz)
+        dz = L['dc{}'.format(ns)].backward_input(P, dz, hw(t[last]), act_mask=t[last])       # dZ of dc{ns-1}2
+        d_skip = {}
+        for n in range(ns - 1, 0, -1):
+            a1, up, skip = t['dc{}1'.format(n)], t['dct{}'.format(n)], t['ec{}2'.format(ns - n)]
+            L['dc{}2'.format(n)].backward_params(P, a1, dz)
+            dz1 = L['dc{}2'.format(n)].backward_input(P, dz, hw(a1), act_mask=a1)           # dZ of dc{n}1
+            L['dc{}1'.format(n)].backward_params(P, up, dz1, x2=skip)
+            d_up = torch.empty_like(up)
+            d_sk = torch.empty_like(skip)
+            L['dc{}1'.format(n)].backward_input(P, dz1, hw(up), out=d_up, out2=d_sk)
+            d_skip[ns - n] = d_sk
+            prev = t['dc{}2'.format(n - 1)]
+            L['dct{}'.format(n)].backward_params(P, prev, d_up)
+            dz = L['dct{}'.format(n)].backward_input(P, d_up, act_mask=prev)                # dZ of dc{n-1}2 / ec{ns}2
+        for n in range(ns, 0, -1):
+            a1, inp = t['ec{}1'.format(n)], t['ep{}'.format(n - 1)]
+            L['ec{}2'.format(n)].backward_params(P, a1, dz)
+            dz1 = L['ec{}2'.format(n)].backward_input(P, dz, hw(a1), act_mask=a1)
+            L['ec{}1'.format(n)].backward_params(P, inp, dz1)
+            if n > 1:
+                d_pool = L['ec{}1'.format(n)].backward_input(P, dz1, hw(inp))
+                prev = t['ec{}2'.format(n - 1)]
+                dz = ops.maxpool2_bwd(d_pool, prev, add=d_skip[n - 1], apply_mask=True, out=d_skip[n - 1])
+        return None
+
+
+class ONet(NIPModel):
+    """Dummy pipeline for RGB training (pipelines.py:353-362): identity, no parameters."""
+
+    def __init__(self, loss_metric='L2', patch_size=None, in_channels=3, device=None, **kwargs):
+        super().__init__(loss_metric=loss_metric, patch_size=patch_size, in_channels=in_channels, device=device)
+
+    def construct_model(self, **kwargs):
+        self._model = ParamStore([], self.device)
+        ps = self.patch_size
+        self.y = _Placeholder((None, ps, ps, 3))
+
+    def forward(self, x, training=False):
+        return x, ({} if training else None)
+
+    def backward(self, ctx, dy):
+        return None
+
+    @property
+    def model_code(self):
+        return self.class_name
+
+
+supported_models = ['UNet', 'ONet']

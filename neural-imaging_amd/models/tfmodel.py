@@ -1,0 +1,195 @@
+"""
+TFModel - the operator surface shared by all components, mirrored from the reference's models/tfmodel.py:86-294:
+performance log, parameter access/count, save/load, restore, process.  Parameters live in ONE flat float32 device
+buffer per model (`flat_params`), each named parameter being a view in the Keras layout; gradients use a twin buffer
+(`flat_grads`) - that buffer is also the RCCL all-reduce unit and the fused-Adam unit.
+
+Checkpoints: <dir>/<scoped_name>/<classname>.npz (+ optional <classname>.json {'model', 'args'}), same directory layout
+and JSON contract as tfmodel.py:150-182; the Keras .h5 container itself is SURVEY 8(f) "next" (no h5py in this image).
+"""
+import json
+import os
+from collections import OrderedDict
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from ..device import DeviceArray, default_device
+from ..helpers import utils
+from .. import ops
+
+
+class ParamStore(object):
+    """Named views into one flat parameter buffer and one flat gradient buffer."""
+
+    def __init__(self, specs, device):
+        self.specs = OrderedDict(specs)              # name -> shape
+        self.device = device
+        total = int(sum(int(np.prod(s)) if len(s) else 1 for s in self.specs.values()))
+        self.flat = torch.zeros(total, dtype=torch.float32, device=device)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=device)
+        self.p, self.g = OrderedDict(), OrderedDict()
+        off = 0
+        for name, shape in self.specs.items():
+            n = int(np.prod(shape)) if len(shape) else 1
+            self.p[name] = self.flat[off:off + n].view(shape)
+            self.g[name] = self.flat_grad[off:off + n].view(shape)
+            off += n
+        self.m = self.v = None
+        self.step = 0
+
+    def ensure_adam(self):
+        if self.m is None:
+            self.m = torch.zeros_like(self.flat)
+            self.v = torch.zeros_like(self.flat)
+
+    def adam(self, lr, step=None, grad_scale=1.0, skip_flag=None):
+        """One Keras-Adam update over the whole buffer (beta1 .9, beta2 .999, eps 1e-7)."""
+        self.ensure_adam()
+        if step is None:
+            self.step += 1
+            step = self.step
+        ops.adam_step(self.flat, self.flat_grad, self.m, self.v, lr, step, grad_scale=grad_scale, skip_flag=skip_flag)
+
+
+def glorot_uniform_(t, fan_in, fan_out, gen):
+    """Keras default kernel initialiser; generated on the host so runs are reproducible across devices."""
+    limit = float(np.sqrt(6.0 / (fan_in + fan_out)))
+    vals = (torch.rand(t.shape, generator=gen, dtype=torch.float64) * 2 - 1) * limit
+    t.copy_(vals.to(torch.float32))
+
+
+class TFModel(object):
+
+    def __init__(self, device=None, **kwargs):
+        self.device = torch.device(device) if device is not None else default_device()
+        self._model = None           # ParamStore once constructed (name kept from the reference)
+        self.reset_performance_stats()
+
+    # -- performance log (tfmodel.py:111-131) ------------------------------------------------------------------
+    @staticmethod
+    def _reset_performance(metrics):
+        return {k: {'training': [], 'validation': []} for k in metrics}
+
+    def reset_performance_stats(self):
+        self.performance = self._reset_performance(['loss'])
+
+    def log_metric(self, metric, scope, value, raw=False):
+        if not raw:
+            if isinstance(value, DeviceArray):
+                value = float(np.mean(value.numpy()))
+            elif utils.is_number(value):
+                value = float(value)
+            else:
+                value = float(np.mean([float(v) for v in value]))
+        self.performance[metric][scope].append(value)
+
+    def pop_metric(self, metric, scope):
+        return self.performance[metric][scope][-1]
+
+    # -- parameters ----------------------------------------------------------------------------------------------
+    @property
+    def parameters(self):
+        return [] if self._model is None else list(self._model.p.values())
+
+    @property
+    def variables(self):
+        return self.parameters
+
+    @property
+    def parameter_names(self):
+        return [] if self._model is None else list(self._model.p.keys())
+
+    def count_parameters(self):
+        return int(sum(int(p.numel()) for p in self.parameters))
+
+    def state_dict(self):
+        return OrderedDict((k, v.detach().cpu().numpy()) for k, v in self._model.p.items())
+
+    def load_state_dict(self, state):
+        for k, v in self._model.p.items():
+            if k not in state:
+                raise KeyError('missing parameter {} in checkpoint'.format(k))
+            a = np.asarray(state[k], np.float32)
+            if tuple(a.shape) != tuple(v.shape):
+                raise ValueError('shape mismatch for {}: {} vs {}'.format(k, a.shape, tuple(v.shape)))
+            v.copy_(torch.from_numpy(a))
+
+    # -- checkpoints (tfmodel.py:150-182) ------------------------------------------------------------------------
+    def save_model(self, dirname, epoch=0, save_args=False, quiet=False):
+        if not dirname.endswith(self.scoped_name):
+            dirname = os.path.join(dirname, self.scoped_name)
+        os.makedirs(dirname, exist_ok=True)
+        np.savez(os.path.join(dirname, '{}.npz'.format(self.class_name.lower())), **self.state_dict())
+        if save_args:
+            with open(os.path.join(dirname, '{}.json'.format(self.class_name.lower())), 'w') as f:
+                json.dump({'model': self.class_name, 'args': self.get_hyperparameters()}, f, indent=4)
+
+    def load_model(self, dirname, quiet=False):
+        if not dirname.endswith(self.scoped_name):
+            dirname = os.path.join(dirname, self.scoped_name)
+        filename = os.path.join(dirname, '{}.npz'.format(self.class_name.lower()))
+        if not os.path.isfile(filename):
+            raise FileNotFoundError(filename)
+        with np.load(filename) as data:
+            self.load_state_dict({k: data[k] for k in data.files})
+        self.reset_performance_stats()
+
+    @classmethod
+    def restore(cls, dir_name, *, key=None, patch_size=None, **kwargs):
+        candidates = list(Path(dir_name).glob('**/*.json'))
+        training_log_path = str(candidates[0]) if candidates else None
+        if training_log_path is None or not os.path.isfile(training_log_path):
+            raise FileNotFoundError('Could not find a training log (JSON file) in {}'.format(dir_name))
+        with open(training_log_path) as f:
+            training_log = json.load(f)
+        if key is not None:
+            training_log = training_log[key]
+        parameters = training_log['args']
+        if patch_size is not None:
+            parameters['patch_size'] = patch_size
+        for k, value in parameters.items():
+            if isinstance(value, str) and value and value[0] == '(' and value[-1] == ')':
+                parameters[k] = tuple(int(v) for v in value[1:-1].split(',') if v.strip())
+        parameters.update(kwargs)
+        instance = cls(**parameters)
+        instance.load_model(dir_name)
+        return instance
+
+    # -- strings -------------------------------------------------------------------------------------------------
+    @property
+    def class_name(self):
+        return type(self).__name__
+
+    def summary(self):
+        return '{} model [{:,.0f} parameters]'.format(self.class_name, self.count_parameters())
+
+    def summary_compact(self):
+        return '{}'.format(self.class_name)
+
+    @property
+    def model_code(self):
+        raise NotImplementedError()
+
+    @property
+    def scoped_name(self):
+        return '{}'.format(type(self).__name__.lower())
+
+    def get_hyperparameters(self):
+        return self._h.to_json() if hasattr(self, '_h') else None
+
+    def __repr__(self):
+        try:
+            extra_params = utils.join_args(self._h.changed_params())
+        except Exception:
+            extra_params = ''
+        return '{}({})'.format(self.class_name, extra_params)
+
+    def _has_attributes(self, attrs, message='Expected attributes not found: {}'):
+        missing = [key for key in attrs if not hasattr(self, key)]
+        if missing:
+            raise NotImplementedError(message.format(missing))
+
+    def process(self, x, training=False):
+        raise NotImplementedError()

@@ -1,0 +1,434 @@
+"""
+Tensor-level wrappers over the C ABI (include/nimg.h).  torch is used ONLY for device memory (torch.empty / views)
+and the current HIP stream; all arithmetic happens inside libnimg.so.  Every function requires contiguous float32
+CUDA(HIP) tensors in NHWC and raises otherwise - there is no CPU path.
+
+TF padding semantics live here (same_pads): SAME is asymmetric for strided convolutions (extra sample after).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+LRELU_ALPHA = 0.2          # tf.keras.layers.LeakyReLU(alpha=0.2), helpers/tf_helpers.py:23
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not (t.is_cuda and t.is_contiguous()):
+            raise RuntimeError('nimg ops need contiguous device tensors (got device={}, contiguous={})'.format(
+                t.device, t.is_contiguous()))
+
+
+def _f32(*ts):
+    for t in ts:
+        if t is not None and t.dtype != torch.float32:
+            raise RuntimeError('nimg ops need float32 tensors, got {}'.format(t.dtype))
+    _chk(*ts)
+
+
+def same_pads(size, k, s):
+    """TF SAME padding: total = max((ceil(in/s)-1)*s + k - in, 0); before = total // 2 (rest after)."""
+    out = -(-size // s)
+    total = max((out - 1) * s + k - size, 0)
+    return out, total // 2
+
+
+class Workspace(object):
+    """A grow-only scratch buffer (split-K slabs, reduction partials)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        nbytes = max(int(nbytes), 256)
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self.buf
+
+
+_ws = Workspace()
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# differentiable JPEG
+def qtable(quality, channel):
+    out = np.zeros(64, np.float32)
+    _lib.call('nimg_jpeg_qtable', int(quality), int(channel), out.ctypes.data)
+    return out.reshape(8, 8)
+
+
+def qtables_device(quality, device):
+    q = np.stack([qtable(quality, 0), qtable(quality, 1), qtable(quality, 1)]) if quality is not None \
+        else np.ones((3, 8, 8), np.float32)
+    return torch.from_numpy(q).to(device)
+
+
+ROUNDING = {'round': 0, 'soft': 1, 'sin': 2, 'harmonic': 3, 'identity': 4}
+
+
+def djpeg_fwd(x, qtab, rounding='soft', want_mask=True, want_idx=False, want_xdq=False, out=None):
+    _f32(x, qtab, out)
+    n, h, w, c = x.shape
+    if c != 3:
+        raise ValueError('dJPEG expects NHW3 images')
+    y = torch.empty_like(x) if out is None else out
+    mask = torch.empty((n, h, w), dtype=torch.uint8, device=x.device) if want_mask else None
+    idx = torch.empty((n, 3, h // 8, w // 8, 8, 8), dtype=torch.int16, device=x.device) if want_idx else None
+    xdq = torch.empty((n, 3, h // 8, w // 8, 8, 8), dtype=torch.float32, device=x.device) if want_xdq else None
+    _lib.call('nimg_djpeg_fwd', _p(x), _p(y), _p(qtab), _p(mask), _p(idx), _p(xdq), n, h, w, ROUNDING[rounding],
+              _stream())
+    return y, mask, idx, xdq
+
+
+def djpeg_bwd(x, gy, mask, qtab, rounding='soft', out=None):
+    _f32(x, gy, qtab)
+    _chk(mask)
+    n, h, w, _ = x.shape
+    gx = torch.empty_like(x) if out is None else out
+    _lib.call('nimg_djpeg_bwd', _p(x), _p(gy), _p(mask), _p(qtab), _p(gx), n, h, w, ROUNDING[rounding], _stream())
+    return gx
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# convolutions
+def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mode=0, out=None, out2=None,
+           act_mask=None, pads=None, out_hw=None):
+    """x (N,H,W,C1) [+ x2 (N,H,W,C2)], w (k,k,C1+C2,Cout) HWIO.  padding 'SAME' (TF) | 'VALID' | explicit pads/out_hw.
+    out/out2: optional pre-allocated outputs (out2 splits the output channels: Cout = out.C + out2.C)."""
+    _f32(x, w, bias, x2, out, out2, act_mask)
+    n, h, wd, c1 = x.shape
+    c2 = 0 if x2 is None else x2.shape[3]
+    ks = w.shape[0]
+    cout = w.shape[3]
+    if w.shape[2] != c1 + c2 or w.shape[1] != ks:
+        raise ValueError('weight shape {} does not match input channels {}+{}'.format(tuple(w.shape), c1, c2))
+    if pads is not None:
+        pt, pl = pads
+        ho, wo = out_hw
+    elif padding == 'SAME':
+        ho, pt = same_pads(h, ks, stride)
+        wo, pl = same_pads(wd, ks, stride)
+    elif padding == 'VALID':
+        pt = pl = 0
+        ho, wo = (h - ks) // stride + 1, (wd - ks) // stride + 1
+    else:
+        raise ValueError(padding)
+    if out is None:
+        out = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
+    o1 = out.shape[3]
+    o2 = 0 if out2 is None else out2.shape[3]
+    if o1 + o2 != cout or tuple(out.shape[:3]) != (n, ho, wo):
+        raise ValueError('output shape mismatch')
+    _lib.call('nimg_conv2d_fwd', _p(x), c1, _p(x2), c2, _p(w), _p(bias), _p(out), o1, _p(out2), o2, _p(act_mask),
+              n, h, wd, ks, stride, pt, pl, pad_mode, ho, wo, 1 if act == 'leaky_relu' else 0, LRELU_ALPHA, _stream())
+    return out if out2 is None else (out, out2)
+
+
+def flip_weights(w, out=None):
+    """(k,k,Cin,Cout) -> spatially flipped (k,k,Cout,Cin) for the input-gradient pass."""
+    _f32(w, out)
+    kh, kw, cin, cout = w.shape
+    wt = torch.empty((kh, kw, cout, cin), dtype=torch.float32, device=w.device) if out is None else out
+    _lib.call('nimg_conv_flip_weights', _p(w), _p(wt), kh, kw, cin, cout, _stream())
+    return wt
+
+
+def conv2d_dgrad(dz, w, in_hw, stride=1, padding='SAME', act_mask=None, out=None, out2=None):
+    """Input gradient of conv2d (stride 1, odd kernel): correlation of dz with the flipped kernel."""
+    if stride != 1:
+        raise NotImplementedError('strided dgrad is expressed by the caller (see models/compression.py)')
+    ks = w.shape[0]
+    h, wd = in_hw
+    if padding == 'SAME':
+        _, pt = same_pads(h, ks, 1)
+        _, pl = same_pads(wd, ks, 1)
+    else:
+        pt = pl = 0
+    wt = flip_weights(w)
+    # forward used pad (pt, pl); the gradient correlation needs ks-1-pt / ks-1-pl
+    return conv2d(dz, wt, None, pads=(ks - 1 - pt, ks - 1 - pl), out_hw=(h, wd), act_mask=act_mask, out=out,
+                  out2=out2)
+
+
+def conv2d_wgrad(x, dz, ks, x2=None, stride=1, padding='SAME', pad_mode=0, pads=None, dw=None, accumulate=False):
+    """dw (k,k,C1+C2,Cout) = sum over pixels of x (x) dz."""
+    _f32(x, dz, x2, dw)
+    n, h, wd, c1 = x.shape
+    c2 = 0 if x2 is None else x2.shape[3]
+    _, ho, wo, cout = dz.shape
+    if pads is not None:
+        pt, pl = pads
+    elif padding == 'SAME':
+        _, pt = same_pads(h, ks, stride)
+        _, pl = same_pads(wd, ks, stride)
+    else:
+        pt = pl = 0
+    if dw is None:
+        dw = torch.empty((ks, ks, c1 + c2, cout), dtype=torch.float32, device=x.device)
+    need = _lib.load().nimg_conv2d_wgrad_workspace_bytes(c1 + c2, cout, ks, ks, n, ho, wo)
+    ws = _ws.get(need, x.device)
+    _lib.call('nimg_conv2d_wgrad', _p(x), c1, _p(x2), c2, _p(dz), cout, _p(dw), n, h, wd, ks, stride, pt, pl,
+              pad_mode, ho, wo, 1 if accumulate else 0, _p(ws), ws.numel(), _stream())
+    return dw
+
+
+def bias_grad(dz, db=None, accumulate=False):
+    _f32(dz, db)
+    cout = dz.shape[-1]
+    npix = dz.numel() // cout
+    if db is None:
+        db = torch.empty((cout,), dtype=torch.float32, device=dz.device)
+    need = _lib.load().nimg_bias_grad_workspace_bytes(npix, cout)
+    ws = _ws.get(need, dz.device)
+    _lib.call('nimg_bias_grad', _p(dz), _p(db), npix, cout, 1 if accumulate else 0, _p(ws), ws.numel(), _stream())
+    return db
+
+
+def convt2x2(x, w, bias):
+    """Conv2DTranspose(k=2,s=2); w (2,2,Cout,Cin)."""
+    _f32(x, w, bias)
+    n, h, wd, cin = x.shape
+    cout = w.shape[2]
+    y = torch.empty((n, 2 * h, 2 * wd, cout), dtype=torch.float32, device=x.device)
+    _lib.call('nimg_convt2x2_fwd', _p(x), _p(w), _p(bias), _p(y), n, h, wd, cin, cout, _stream())
+    return y
+
+
+def convt2x2_dgrad(dy, w, act_mask=None):
+    """d input of Conv2DTranspose = strided 2x2 conv of dy with the same kernel viewed as (2,2,Cin'=Cout,Cout'=Cin)."""
+    n, h2, w2, _ = dy.shape
+    return conv2d(dy, w, None, stride=2, pads=(0, 0), out_hw=(h2 // 2, w2 // 2), act_mask=act_mask)
+
+
+def convt2x2_wgrad(x, dy, dw=None):
+    """dw (2,2,Cout,Cin) = wgrad with the roles swapped: 'input' = dy (stride 2), 'output gradient' = x."""
+    return conv2d_wgrad(dy, x, 2, stride=2, pads=(0, 0), dw=dw)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# pooling / layout / element-wise
+def maxpool2(x):
+    _f32(x)
+    n, h, w, c = x.shape
+    y = torch.empty((n, h // 2, w // 2, c), dtype=torch.float32, device=x.device)
+    _lib.call('nimg_maxpool2_fwd', _p(x), _p(y), n, h, w, c, _stream())
+    return y
+
+
+def maxpool2_bwd(dp, yact, add=None, apply_mask=True, out=None):
+    _f32(dp, yact, add, out)
+    n, h, w, c = yact.shape
+    dz = torch.empty_like(yact) if out is None else out
+    _lib.call('nimg_maxpool2_bwd', _p(dp), _p(yact), _p(add), _p(dz), n, h, w, c, 1 if apply_mask else 0,
+              LRELU_ALPHA, _stream())
+    return dz
+
+
+def d2s_clip(x, scale=1.0, shift=0.0, clip=True):
+    _f32(x)
+    n, h, w, c4 = x.shape
+    y = torch.empty((n, 2 * h, 2 * w, c4 // 4), dtype=torch.float32, device=x.device)
+    _lib.call('nimg_d2s_clip_fwd', _p(x), _p(y), n, h, w, c4 // 4, float(scale), float(shift), 1 if clip else 0,
+              _stream())
+    return y
+
+
+def d2s_clip_bwd(dy, scale=1.0):
+    _f32(dy)
+    n, h2, w2, c = dy.shape
+    dx = torch.empty((n, h2 // 2, w2 // 2, 4 * c), dtype=torch.float32, device=dy.device)
+    _lib.call('nimg_d2s_clip_bwd', _p(dy), _p(dx), n, h2 // 2, w2 // 2, c, float(scale), _stream())
+    return dx
+
+
+def lrelu_bwd(dy, yact, out=None):
+    _f32(dy, yact, out)
+    dz = torch.empty_like(dy) if out is None else out
+    _lib.call('nimg_lrelu_bwd', _p(dy), _p(yact), _p(dz), dy.numel(), LRELU_ALPHA, _stream())
+    return dz
+
+
+def add(a, b, out=None):
+    _f32(a, b, out)
+    o = torch.empty_like(a) if out is None else out
+    _lib.call('nimg_add', _p(a), _p(b), _p(o), a.numel(), _stream())
+    return o
+
+
+def avgpool(x, f):
+    _f32(x)
+    n, h, w, c = x.shape
+    y = torch.empty((n, h // f, w // f, c), dtype=torch.float32, device=x.device)
+    _lib.call('nimg_avgpool_fwd', _p(x), _p(y), n, h, w, c, f, _stream())
+    return y
+
+
+def avgpool_bwd(dy, f):
+    _f32(dy)
+    n, ho, wo, c = dy.shape
+    dx = torch.empty((n, ho * f, wo * f, c), dtype=torch.float32, device=dy.device)
+    _lib.call('nimg_avgpool_bwd', _p(dy), _p(dx), n, ho * f, wo * f, c, f, _stream())
+    return dx
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# losses / head / optimiser
+def mse255(a, b, grad_scale=None, grad_out=None, accumulate=False):
+    """Returns (loss[1], grad wrt a or None).  grad = grad_scale * d mse255 / d a."""
+    _f32(a, b, grad_out)
+    loss = torch.empty((1,), dtype=torch.float32, device=a.device)
+    g = None
+    if grad_scale is not None:
+        g = torch.empty_like(a) if grad_out is None else grad_out
+    need = _lib.load().nimg_mse255_workspace_bytes()
+    ws = _ws.get(need, a.device)
+    _lib.call('nimg_mse255', _p(a), _p(b), _p(loss), _p(g), a.numel(), float(grad_scale or 0.0),
+              1 if accumulate else 0, _p(ws), ws.numel(), _stream())
+    return loss, g
+
+
+def fan_head_fwd(act, w, b, labels=None, loss_scale=1.0):
+    _f32(act, w, b)
+    n, h, wd, c = act.shape
+    k = w.shape[1]
+    dev = act.device
+    gap = torch.empty((n, c), dtype=torch.float32, device=dev)
+    probs = torch.empty((n, k), dtype=torch.float32, device=dev)
+    loss_per = dlogits = None
+    if labels is not None:
+        _chk(labels)
+        if labels.dtype != torch.int32:
+            raise RuntimeError('labels must be int32')
+        loss_per = torch.empty((n,), dtype=torch.float32, device=dev)
+        dlogits = torch.empty((n, k), dtype=torch.float32, device=dev)
+    _lib.call('nimg_fan_head_fwd', _p(act), _p(w), _p(b), _p(labels), _p(gap), _p(probs), _p(loss_per), _p(dlogits),
+              n, h * wd, c, k, float(loss_scale), _stream())
+    return gap, probs, loss_per, dlogits
+
+
+def fan_head_bwd(act, gap, w, dlogits, loss_per, loss_scale, dw, db):
+    _f32(act, gap, w, dlogits, loss_per, dw, db)
+    n, h, wd, c = act.shape
+    k = w.shape[1]
+    dact = torch.empty_like(act)
+    loss = torch.empty((1,), dtype=torch.float32, device=act.device)
+    _lib.call('nimg_fan_head_bwd', _p(act), _p(gap), _p(w), _p(dlogits), _p(loss_per), _p(dact), _p(dw), _p(db),
+              _p(loss), n, h * wd, c, k, float(loss_scale), LRELU_ALPHA, _stream())
+    return dact, loss
+
+
+def adam_step(params, grads, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0, skip_flag=None):
+    _f32(params, grads, m, v)
+    _lib.call('nimg_adam_step', _p(params), _p(grads), _p(m), _p(v), params.numel(), float(lr), float(beta1),
+              float(beta2), float(eps), int(step), float(grad_scale), _p(skip_flag), _stream())
+
+
+def nan_flag(g, flag):
+    _f32(g)
+    _lib.call('nimg_nan_flag', _p(g), g.numel(), _p(flag), _stream())
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# constrained conv pieces, manipulations
+def constrained_kernel(kernel, strength=100.0):
+    _f32(kernel)
+    nf = torch.empty_like(kernel)
+    _lib.call('nimg_constrained_kernel_fwd', _p(kernel), _p(nf), kernel.shape[0], kernel.shape[2], float(strength),
+              _stream())
+    return nf
+
+
+def constrained_kernel_bwd(kernel, dnf, dk, strength=100.0):
+    _f32(kernel, dnf, dk)
+    _lib.call('nimg_constrained_kernel_bwd', _p(kernel), _p(dnf), _p(dk), kernel.shape[0], kernel.shape[2],
+              float(strength), _stream())
+    return dk
+
+
+def fold_pad(dpad, pad, pad_mode):
+    _f32(dpad)
+    n, hp, wp, c = dpad.shape
+    dx = torch.empty((n, hp - 2 * pad, wp - 2 * pad, c), dtype=torch.float32, device=dpad.device)
+    _lib.call('nimg_fold_pad', _p(dpad), _p(dx), n, hp - 2 * pad, wp - 2 * pad, c, pad, pad_mode, _stream())
+    return dx
+
+
+def gaussian_fwd(x, gk25, out=None, clip=True, want_mask=True):
+    _f32(x, gk25, out)
+    n, h, w, _ = x.shape
+    y = torch.empty_like(x) if out is None else out
+    mask = torch.empty((n, h, w), dtype=torch.uint8, device=x.device) if want_mask else None
+    _lib.call('nimg_gaussian_fwd', _p(x), _p(y), _p(mask), _p(gk25), n, h, w, 1 if clip else 0, _stream())
+    return y, mask
+
+
+def gaussian_bwd(dy, mask, gk25):
+    _f32(dy, gk25)
+    n, h, w, _ = dy.shape
+    dx = torch.empty_like(dy)
+    _lib.call('nimg_gaussian_bwd', _p(dy), _p(mask), _p(dx), _p(gk25), n, h, w, _stream())
+    return dx
+
+
+def sharpen_fwd(x, gk9, out=None, want_aux=True):
+    _f32(x, gk9, out)
+    n, h, w, _ = x.shape
+    y = torch.empty_like(x) if out is None else out
+    aux = torch.empty_like(x) if want_aux else None
+    mask = torch.empty((n, h, w), dtype=torch.uint8, device=x.device) if want_aux else None
+    _lib.call('nimg_sharpen_fwd', _p(x), _p(y), _p(aux), _p(mask), _p(gk9), n, h, w, _stream())
+    return y, aux, mask
+
+
+def sharpen_bwd(x, dy, aux, mask, gk9):
+    _f32(x, dy, aux, gk9)
+    n, h, w, _ = x.shape
+    dx = torch.empty_like(x)
+    _lib.call('nimg_sharpen_bwd', _p(x), _p(dy), _p(aux), _p(mask), _p(dx), _p(gk9), n, h, w, _stream())
+    return dx
+
+
+class AxisOperator(object):
+    """A banded linear operator along a spatial axis, stored as CSR (+ its transpose) on the device."""
+
+    def __init__(self, dense, device):
+        dense = np.asarray(dense, np.float64)
+        self.out_size, self.in_size = dense.shape
+        self.fwd = self._csr(dense, device)
+        self.bwd = self._csr(dense.T, device)
+
+    @staticmethod
+    def _csr(m, device):
+        rowptr, col, val = [0], [], []
+        for r in range(m.shape[0]):
+            nz = np.nonzero(m[r])[0]
+            col.extend(nz.tolist())
+            val.extend(m[r, nz].tolist())
+            rowptr.append(len(col))
+        return (torch.tensor(rowptr, dtype=torch.int32, device=device),
+                torch.tensor(col, dtype=torch.int32, device=device),
+                torch.tensor(np.asarray(val, np.float32), dtype=torch.float32, device=device))
+
+
+def sparse_axis_apply(x, csr, axis, out_size, out=None):
+    _f32(x, out)
+    rowptr, col, val = csr
+    n, h, w, c = x.shape
+    shape = (n, out_size, w, c) if axis == 0 else (n, h, out_size, c)
+    y = torch.empty(shape, dtype=torch.float32, device=x.device) if out is None else out
+    _lib.call('nimg_sparse_axis_apply', _p(x), _p(y), _p(rowptr), _p(col), _p(val), n, h, w, c, axis, out_size,
+              _stream())
+    return y

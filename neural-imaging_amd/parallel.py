@@ -1,0 +1,67 @@
+"""
+Data-parallel plumbing: one process per GPU, torch.distributed (backend "nccl" == RCCL on ROCm) over xGMI.
+
+The reference is single-process / single-device; data parallelism is build-side.  The channel shards over
+raw patches with ONE exchange step: a sum all-reduce of each model's flat float32 gradient buffer (FAN 4.6 MB first -
+its gradients are complete first in the backward pass - then UNet 31 MB), followed by the same fused Adam on every
+rank with grad_scale = 1 / world_size (CE and MSE are means over the batch).  No other collective touches the data path.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_distributed():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def world_size():
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def rank():
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
+def init_from_env(backend=None):
+    """Initialise the process group from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun contract)."""
+    ws = int(os.environ.get('WORLD_SIZE', '1'))
+    if ws <= 1 or (dist.is_available() and dist.is_initialized()):
+        return ws
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    if backend == 'nccl':
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group(backend=backend)
+    return ws
+
+
+class GradientBucket(object):
+    """Asynchronous sum all-reduce of one flat gradient buffer; wait() before the optimiser touches it."""
+
+    def __init__(self):
+        self._work = []
+
+    def launch(self, flat_grad):
+        if is_distributed() and flat_grad.numel() > 0:
+            self._work.append(dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, async_op=True))
+
+    def wait(self):
+        for w in self._work:
+            w.wait()
+        self._work = []
+
+
+def all_reduce_flag(flag):
+    """OR-reduce the NaN flag over ranks (SURVEY 8e caveat 4)."""
+    if is_distributed():
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+
+
+def shard_batch(batch, rank_, world):
+    """Contiguous shard of the global batch for this rank (labels are positional per rank, workflows/...:257-258)."""
+    n = batch.shape[0]
+    per = n // world
+    return batch[rank_ * per:(rank_ + 1) * per]

@@ -11,7 +11,7 @@
  * (neural-imaging_amd/csrc/djpeg.hip) reproduces bit-for-bit, so that the integer index tensor
  * rint(X/Q) - the bit-exact sub-contract of BASELINE.json - can be compared with == :
  *   colour  : acc = bias; acc = fmaf(255*r, c1, acc); fmaf(255*g, c2, acc); fmaf(255*b, c3, acc); minus 127
- *   DCT     : T = F*b (fmaf chain over i ascending, acc0 = 0), X = T*F^T (fmaf chain over j ascending)
+ *   DCT     : row pass T = b*F^T (fmaf chain over j ascending, acc0 = 0), column pass X = F*T (chain over i)
  *   quant   : u = X / Q (IEEE division), r = rintf(u), Xd = r * Q
  *   IDCT    : S = F^T*Xd (chain over u ascending), xi = S*F (chain over v ascending)
  *   colour^-1: q = xi + 127 ; acc = bias; fmaf(q0,c1); fmaf(q1,c2); fmaf(q2,c3); / 255 ; clamp [0,1]
@@ -70,16 +70,16 @@ int djpeg_ref_forward(const float *x, float *y, const float *q, int16_t *idx, fl
                     }
                 for (int c = 0; c < 3; ++c) {
                     float t[8][8], X[8][8], s[8][8];
-                    for (int u = 0; u < 8; ++u)
-                        for (int j = 0; j < 8; ++j) {
-                            float acc = 0.0f;
-                            for (int i = 0; i < 8; ++i) acc = fmaf(DCT_F[u][i], blk[c][i][j], acc);
-                            t[u][j] = acc;
-                        }
-                    for (int u = 0; u < 8; ++u)
+                    for (int i = 0; i < 8; ++i)            /* row pass: T = b * F^T */
                         for (int v = 0; v < 8; ++v) {
                             float acc = 0.0f;
-                            for (int j = 0; j < 8; ++j) acc = fmaf(t[u][j], DCT_F[v][j], acc);
+                            for (int j = 0; j < 8; ++j) acc = fmaf(blk[c][i][j], DCT_F[v][j], acc);
+                            t[i][v] = acc;
+                        }
+                    for (int u = 0; u < 8; ++u)            /* column pass: X = F * T */
+                        for (int v = 0; v < 8; ++v) {
+                            float acc = 0.0f;
+                            for (int i = 0; i < 8; ++i) acc = fmaf(t[i][v], DCT_F[u][i], acc);
                             const float qq = q[c * 64 + u * 8 + v];
                             const float r = rintf(acc / qq);       /* half-to-even in the default rounding mode */
                             X[u][v] = r * qq;

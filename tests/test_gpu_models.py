@@ -1,0 +1,175 @@
+"""
+Model- and workflow-level parity on the GPU: UNet, FAN and the whole ManipulationClassification training step
+(forward, loss, every parameter gradient, two Keras-Adam steps) against the CPU float64 oracle on the same seeded
+inputs and the same initial weights (copied from the product model into the oracle).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets as onets
+from oracle import tfops as T
+from oracle import workflow as owf
+
+from util import assert_close, bayer_from_rgb, natural_images, to64
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from neural_imaging_amd import _lib
+    _lib.load()
+    return torch.device('cuda', 0)
+
+
+def oracle_params(model):
+    return {k: to64(v) for k, v in model.state_dict().items()}
+
+
+def grads_of(model):
+    return {k: v.detach().cpu().numpy() for k, v in model._model.g.items()}
+
+
+def check_grads(got, ref, names, tol=2e-4):
+    worst = []
+    for k in names:
+        a, b = got[k], ref[k].numpy()
+        scale = max(np.abs(b).max(), 1e-12)
+        e = np.abs(a - b).max() / scale
+        worst.append((e, k))
+    worst.sort(reverse=True)
+    assert worst[0][0] < tol, 'parameter gradients off (rel-to-max): {}'.format(worst[:5])
+    return worst[0]
+
+
+def test_unet_forward_backward(dev):
+    from neural_imaging_amd.models import pipelines
+    from neural_imaging_amd import ops
+    net = pipelines.UNet(patch_size=32, device=dev)
+    assert net.count_parameters() == 7763820
+    rgb = natural_images(2, 64, 64, seed=21)
+    raw = bayer_from_rgb(rgb)
+    p = oracle_params(net)
+    for v in p.values():
+        v.requires_grad_(True)
+    y_ref, t_ref = onets.unet_forward(p, to64(raw), return_tensors=True)
+    loss_ref = T.mse255(y_ref, to64(rgb))
+    g_ref = dict(zip(p.keys(), torch.autograd.grad(loss_ref, list(p.values()))))
+
+    x = torch.from_numpy(raw).to(dev)
+    y, ctx = net.forward(x, training=True)
+    assert_close(y.cpu().numpy(), y_ref.detach().numpy(), 1e-4, what='UNet output')
+    for name in ('ec11', 'ec32', 'ec52', 'dct1', 'dc11', 'dc42'):
+        assert_close(ctx[name].cpu().numpy(), t_ref[name].detach().numpy(), 1e-4, 1e-4, what='UNet ' + name)
+    loss, dy = ops.mse255(y, torch.from_numpy(rgb).to(dev), grad_scale=1.0)
+    assert abs(float(loss.item()) - float(loss_ref)) / float(loss_ref) < 1e-4
+    net.backward(ctx, dy)
+    check_grads(grads_of(net), g_ref, list(p.keys()))
+    # reference surface: process() accepts numpy (also a single 3-D image) and answers .numpy()
+    out = net.process(raw[0])
+    assert out.shape == (1, 64, 64, 3) and np.abs(out.numpy()[0] - y_ref.detach().numpy()[0]).max() < 1e-4
+
+
+def test_unet_training_steps_follow_oracle(dev):
+    from neural_imaging_amd.models import pipelines
+    net = pipelines.UNet(patch_size=16, device=dev)
+    rgb = natural_images(4, 32, 32, seed=5)
+    raw = bayer_from_rgb(rgb)
+    p = oracle_params(net)
+    names = list(p.keys())
+    m = [torch.zeros_like(v) for v in p.values()]
+    v2 = [torch.zeros_like(v) for v in p.values()]
+    for step in range(1, 4):
+        for t in p.values():
+            t.requires_grad_(True)
+        loss_ref = T.mse255(onets.unet_forward(p, to64(raw)), to64(rgb))
+        gr = torch.autograd.grad(loss_ref, list(p.values()))
+        for t in p.values():
+            t.requires_grad_(False)
+        with torch.no_grad():
+            T.adam_step(list(p.values()), list(gr), m, v2, step, 1e-4)
+        loss = net.training_step(raw, rgb, learning_rate=1e-4)
+        assert abs(float(loss) - float(loss_ref)) / float(loss_ref) < 2e-4, (step, float(loss), float(loss_ref))
+    sd = net.state_dict()
+    worst = max(np.abs(sd[k] - p[k].numpy()).max() for k in names)
+    assert worst < 5e-5, worst           # 3 steps x lr 1e-4: parameters move by <= 3e-4
+
+
+def test_fan_forward_backward(dev):
+    from neural_imaging_amd.models import forensics
+    fan = forensics.FAN(n_classes=5, patch_size=64, device=dev)
+    assert fan.count_parameters() == 1145382
+    x = natural_images(5, 64, 64, seed=33)
+    labels = np.array([0, 1, 2, 3, 4], np.int32)
+    p = oracle_params(fan)
+    for v in p.values():
+        v.requires_grad_(True)
+    xt = to64(x).requires_grad_(True)
+    probs_ref, t_ref = onets.fan_forward(p, xt, return_tensors=True)
+    loss_ref = T.sparse_ce_from_probs(probs_ref, labels)
+    gr = torch.autograd.grad(loss_ref, list(p.values()) + [xt])
+    g_ref = dict(zip(p.keys(), gr[:-1]))
+
+    probs, ctx = fan.forward(torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev), training=True)
+    assert_close(ctx['constrained'].cpu().numpy(), t_ref['constrained'].detach().numpy(), 2e-3, 1e-5, what='residual')
+    assert_close(ctx['conv2'].cpu().numpy(), t_ref['conv2'].detach().numpy(), 1e-3, 1e-4, what='FAN conv2')
+    assert_close(probs.cpu().numpy(), probs_ref.detach().numpy(), 1e-4, what='FAN probabilities')
+    loss, dx = fan.backward(ctx, need_input_grad=True)
+    assert abs(float(loss.item()) - float(loss_ref)) < 1e-4
+    check_grads(grads_of(fan), g_ref, list(p.keys()), tol=3e-4)
+    assert_close(dx.cpu().numpy(), gr[-1].numpy(), 1e-7, 3e-4, what='FAN input gradient')
+    # reference surface
+    dec = fan.process_and_decide(x)
+    assert dec.shape == (5,) and (dec == probs_ref.detach().numpy().argmax(axis=1)).all()
+
+
+@pytest.mark.parametrize('trainable', [('nip',), ()])
+def test_workflow_training_step(dev, trainable):
+    from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
+    dist = {'downsampling': 'none', 'compression': 'jpeg', 'compression_params': {'quality': 80, 'codec': 'soft'}}
+    wf = ManipulationClassification('UNet', distribution=dist, trainable=set(trainable), raw_patch_size=32,
+                                    device=dev)
+    ref = owf.Workflow(trainable=trainable, jpeg_quality=80)
+    ref.nip = onets.OrderedDict((k, to64(v)) for k, v in wf.nip.state_dict().items())
+    ref.fan = onets.OrderedDict((k, to64(v)) for k, v in wf.fan.state_dict().items())
+    rgb = natural_images(2, 64, 64, seed=8)
+    raw = bayer_from_rgb(rgb)
+    lam = 0.1
+
+    # forward parity of the whole channel
+    Y, c, C, ent, probs = wf.run_workflow(raw)
+    Yr, cr, Cr, _, pr = ref.run_workflow(to64(raw))
+    assert_close(Y.numpy(), Yr.numpy(), 1e-4, what='workflow Y')
+    assert_close(c.numpy(), cr.numpy(), 2e-4, what='workflow manipulated batch')
+    # the codec output can differ by one quantisation step where |X/Q - k| ~ 0.5 (float32 vs float64 ties)
+    dC = np.abs(C.numpy() - Cr.numpy())
+    assert np.mean(dC > 1e-3) < 2e-3, 'too many codec output mismatches: {}'.format(np.mean(dC > 1e-3))
+    assert c.shape == (10, 64, 64, 3) and probs.shape == (10, 5)
+
+    for step in range(2):
+        loss_ref, parts_ref, params, grads, _ = ref.loss_and_grads(to64(raw), to64(rgb), lam)
+        loss, parts = wf.training_step(raw, rgb, lambda_nip=lam, learning_rate=1e-4)
+        assert abs(float(parts['ce']) - parts_ref['ce']) < 2e-3, (float(parts['ce']), parts_ref['ce'])
+        assert abs(float(parts['nip']) - parts_ref['nip']) / parts_ref['nip'] < 1e-3
+        if step == 0:
+            names = list(ref.fan.keys()) + (list(ref.nip.keys()) if 'nip' in trainable else [])
+            gref = dict(zip(names, grads))
+            got = grads_of(wf.fan)
+            if 'nip' in trainable:
+                got.update(grads_of(wf.nip))
+            check_grads(got, gref, names, tol=5e-3)       # a handful of flipped quantisation ties are tolerated
+        # keep the oracle in lock-step (apply its own Adam)
+        if ref._m is None:
+            ref._m = [torch.zeros_like(p) for p in params]
+            ref._v = [torch.zeros_like(p) for p in params]
+        ref._t += 1
+        with torch.no_grad():
+            T.adam_step(params, grads, ref._m, ref._v, ref._t, 1e-4)
+    sd = wf.fan.state_dict()
+    worst = max(np.abs(sd[k] - ref.fan[k].numpy()).max() for k in sd)
+    assert worst < 1e-4, worst
+    assert float(loss) == pytest.approx(float(parts['ce']) + (lam * float(parts['nip']) if 'nip' in trainable else 0),
+                                        rel=1e-5)

@@ -1,0 +1,337 @@
+"""
+Parity tests proper: every HIP entry point (called through the C ABI via neural_imaging_amd.ops) against the CPU oracle
+on identical seeded inputs.  float tolerance: 1e-4 absolute on [0,1]-scaled activations (north_star), and for gradient
+tensors max-abs-error <= 1e-4 x max|reference| ; the JPEG quantisation index tensor is compared with ==.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import djpeg as odj
+from oracle import manip as om
+from oracle import tables as ot
+from oracle import tfops as T
+
+from util import assert_close, natural_images, to64
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-4
+GRTOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from neural_imaging_amd import _lib
+    _lib.load()           # fail loudly if the HIP library is missing
+    return torch.device('cuda', 0)
+
+
+def g(a, dev):
+    return torch.as_tensor(np.asarray(a, dtype=np.float32)).to(dev).contiguous()
+
+
+def rnd(shape, seed, lo=-1.0, hi=1.0):
+    return np.random.default_rng(seed).uniform(lo, hi, size=shape).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# dJPEG
+@pytest.mark.parametrize('shape,q', [((2, 64, 64), 50), ((1, 8, 8), 80), ((3, 40, 72), 10), ((2, 128, 256), 95),
+                                      ((1, 512, 512), 50)])
+def test_djpeg_fwd_bit_exact_index_path(dev, shape, q):
+    from neural_imaging_amd import ops
+    from test_oracle import c_djpeg
+    n, h, w = shape
+    x = natural_images(n, h, w, seed=q + h)
+    if h == 40:
+        x = np.random.default_rng(5).random((n, h, w, 3)).astype(np.float32)     # pure noise: worst case for ties
+    yc, idxc, xdc = c_djpeg(x, q)
+    y, mask, idx, xdq = ops.djpeg_fwd(g(x, dev), ops.qtables_device(q, dev), 'soft', want_idx=True, want_xdq=True)
+    assert torch.equal(idx.cpu(), torch.from_numpy(idxc)), 'quantisation indices differ from the canonical-order oracle'
+    assert np.array_equal(xdq.cpu().numpy(), xdc)
+    assert np.abs(y.cpu().numpy() - yc).max() <= 1e-6
+    y64, _, idx64 = odj.djpeg_torch(to64(x), q, 'soft')
+    assert_close(y.cpu().numpy(), y64.numpy(), ATOL, what='djpeg y vs float64')
+    assert (idx.cpu().numpy() != idx64.numpy()).mean() < 1e-3
+    # mask = "not clipped"
+    ypre_in = (y64.numpy() > 0) & (y64.numpy() < 1)
+    m = mask.cpu().numpy()
+    bits = np.stack([(m >> c) & 1 for c in range(3)], axis=-1).astype(bool)
+    assert (bits[ypre_in]).mean() > 0.999
+
+
+@pytest.mark.parametrize('mode', ['soft', 'sin', 'harmonic', 'identity'])
+def test_djpeg_modes_fwd_bwd(dev, mode):
+    from neural_imaging_amd import ops
+    x = natural_images(2, 32, 48, seed=11)
+    gy = rnd(x.shape, 12)
+    qn = np.stack([ot.jpeg_qtable(50, 0), ot.jpeg_qtable(50, 1), ot.jpeg_qtable(50, 1)]).astype(np.float64)
+    yn, cache = odj.djpeg_numpy_fwd(x, qn, mode)
+    gn = odj.djpeg_numpy_bwd(gy.astype(np.float64), cache)
+    q = ops.qtables_device(50, dev)
+    y, mask, _, _ = ops.djpeg_fwd(g(x, dev), q, mode)
+    assert_close(y.cpu().numpy(), yn, ATOL, what='djpeg fwd ' + mode)
+    gx = ops.djpeg_bwd(g(x, dev), g(gy, dev), mask, q, mode)
+    assert_close(gx.cpu().numpy(), gn, 1e-5, GRTOL * 3, what='djpeg bwd ' + mode)
+
+
+def test_djpeg_properties_full_size(dev):
+    """BASELINE size (batch of 256x256): size-independent properties instead of the (slow) oracle."""
+    from neural_imaging_amd import ops
+    x = g(natural_images(8, 256, 256, seed=2), dev)
+    q = ops.qtables_device(80, dev)
+    y, mask, idx, xdq = ops.djpeg_fwd(x, q, 'soft', want_idx=True, want_xdq=True)
+    assert float(y.min()) >= 0 and float(y.max()) <= 1
+    # dequantised coefficients are exact multiples of the table; indices are what the table divides them into
+    qb = q.reshape(1, 3, 1, 1, 8, 8)
+    assert torch.equal(idx.float() * qb, xdq)
+    # idempotence of the index path under a translation by whole blocks
+    y2, _, idx2, _ = ops.djpeg_fwd(torch.roll(x, shifts=(8, 16), dims=(1, 2)).contiguous(), q, 'soft', want_idx=True)
+    assert torch.equal(torch.roll(idx, shifts=(1, 2), dims=(2, 3)), idx2)
+    # PSNR sanity vs input
+    psnr = 10 * torch.log10(1.0 / ((y - x) ** 2).mean())
+    assert 28 < float(psnr) < 50
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# convolutions
+CONV_CASES = [
+    # n, h, w, c1, c2, cout, ks, stride, act
+    (2, 16, 16, 4, 0, 32, 3, 1, 'leaky_relu'),
+    (2, 16, 16, 32, 0, 32, 3, 1, 'leaky_relu'),
+    (2, 32, 32, 16, 16, 32, 3, 1, 'leaky_relu'),
+    (2, 20, 24, 8, 0, 12, 3, 1, None),
+    (2, 32, 32, 3, 0, 32, 5, 1, 'leaky_relu'),
+    (2, 32, 32, 32, 0, 64, 5, 1, 'leaky_relu'),
+    (5, 8, 8, 64, 0, 64, 1, 1, 'leaky_relu'),
+    (6, 8, 8, 64, 0, 128, 3, 1, 'leaky_relu'),
+    (3, 16, 16, 48, 0, 96, 3, 1, None),
+    (2, 32, 32, 3, 0, 64, 5, 2, 'leaky_relu'),
+    (2, 32, 32, 64, 0, 128, 5, 2, None),
+    (1, 64, 64, 40, 0, 72, 5, 1, 'leaky_relu'),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv2d_fwd(dev, case):
+    from neural_imaging_amd import ops
+    n, h, w, c1, c2, cout, ks, stride, act = case
+    x1, x2 = rnd((n, h, w, c1), 1), (rnd((n, h, w, c2), 2) if c2 else None)
+    wt = rnd((ks, ks, c1 + c2, cout), 3, -0.2, 0.2)
+    b = rnd((cout,), 4)
+    xin = to64(x1) if x2 is None else torch.cat([to64(x1), to64(x2)], dim=-1)
+    ref = T.conv2d(xin, to64(wt), to64(b), stride, 'SAME')
+    if act:
+        ref = T.leaky_relu(ref)
+    out = ops.conv2d(g(x1, dev), g(wt, dev), g(b, dev), x2=None if x2 is None else g(x2, dev), stride=stride, act=act)
+    assert tuple(out.shape) == tuple(ref.shape)
+    assert_close(out.cpu().numpy(), ref.numpy(), ATOL, GRTOL, what='conv fwd {}'.format(case))
+
+
+@pytest.mark.parametrize('case', [c for c in CONV_CASES if c[7] == 1])
+def test_conv2d_dgrad_wgrad(dev, case):
+    from neural_imaging_amd import ops
+    n, h, w, c1, c2, cout, ks, stride, act = case
+    x = to64(rnd((n, h, w, c1 + c2), 1)).requires_grad_(True)
+    wt = to64(rnd((ks, ks, c1 + c2, cout), 3, -0.2, 0.2)).requires_grad_(True)
+    b = to64(rnd((cout,), 4)).requires_grad_(True)
+    dz = rnd((n, h, w, cout), 5)
+    prev_act = rnd((n, h, w, c1 + c2), 6)           # saved activation of the previous layer (for the fused lrelu')
+    z = T.conv2d(x, wt, b, 1, 'SAME')
+    (z * to64(dz)).sum().backward()
+    # weight / bias gradients
+    xg = g(x.detach().numpy(), dev)
+    if c2:
+        dw = ops.conv2d_wgrad(xg[..., :c1].contiguous(), g(dz, dev), ks, x2=xg[..., c1:].contiguous())
+    else:
+        dw = ops.conv2d_wgrad(xg, g(dz, dev), ks)
+    assert_close(dw.cpu().numpy(), wt.grad.numpy(), 1e-5, GRTOL, what='wgrad {}'.format(case))
+    db = ops.bias_grad(g(dz, dev))
+    assert_close(db.cpu().numpy(), b.grad.numpy(), 1e-5, GRTOL, what='bias grad {}'.format(case))
+    # input gradient, with the previous layer's LeakyReLU derivative fused
+    mask = np.where(prev_act > 0, 1.0, 0.2)
+    if c2:
+        o1 = torch.empty((n, h, w, c1), device=dev)
+        o2 = torch.empty((n, h, w, c2), device=dev)
+        ops.conv2d_dgrad(g(dz, dev), g(wt.detach().numpy(), dev), (h, w), out=o1, out2=o2)
+        dx = torch.cat([o1, o2], dim=-1)
+        assert_close(dx.cpu().numpy(), x.grad.numpy(), 1e-5, GRTOL, what='dgrad(2 outputs) {}'.format(case))
+    else:
+        dx = ops.conv2d_dgrad(g(dz, dev), g(wt.detach().numpy(), dev), (h, w), act_mask=g(prev_act, dev))
+        assert_close(dx.cpu().numpy(), x.grad.numpy() * mask, 1e-5, GRTOL, what='dgrad {}'.format(case))
+
+
+def test_conv2d_strided_wgrad(dev):
+    from neural_imaging_amd import ops
+    n, h, w, cin, cout, ks = 2, 32, 32, 16, 32, 5
+    x = to64(rnd((n, h, w, cin), 1))
+    wt = to64(rnd((ks, ks, cin, cout), 3, -0.2, 0.2)).requires_grad_(True)
+    z = T.conv2d(x, wt, None, 2, 'SAME')
+    dz = rnd(tuple(z.shape), 5)
+    (z * to64(dz)).sum().backward()
+    dw = ops.conv2d_wgrad(g(x.numpy(), dev), g(dz, dev), ks, stride=2)
+    assert_close(dw.cpu().numpy(), wt.grad.numpy(), 1e-5, GRTOL, what='strided wgrad')
+
+
+def test_convt2x2_fwd_bwd(dev):
+    from neural_imaging_amd import ops
+    n, h, w, cin, cout = 2, 8, 12, 64, 32
+    x = to64(rnd((n, h, w, cin), 1)).requires_grad_(True)
+    wt = to64(rnd((2, 2, cout, cin), 2, -0.3, 0.3)).requires_grad_(True)
+    b = to64(rnd((cout,), 3)).requires_grad_(True)
+    y = T.conv2d_transpose_2x2(x, wt, b)
+    dy = rnd(tuple(y.shape), 4)
+    (y * to64(dy)).sum().backward()
+    yo = ops.convt2x2(g(x.detach().numpy(), dev), g(wt.detach().numpy(), dev), g(b.detach().numpy(), dev))
+    assert_close(yo.cpu().numpy(), y.detach().numpy(), ATOL, GRTOL, what='convT fwd')
+    prev = rnd((n, h, w, cin), 9)
+    dx = ops.convt2x2_dgrad(g(dy, dev), g(wt.detach().numpy(), dev), act_mask=g(prev, dev))
+    assert_close(dx.cpu().numpy(), x.grad.numpy() * np.where(prev > 0, 1.0, 0.2), 1e-5, GRTOL, what='convT dgrad')
+    dw = ops.convt2x2_wgrad(g(x.detach().numpy(), dev), g(dy, dev))
+    assert_close(dw.cpu().numpy(), wt.grad.numpy(), 1e-5, GRTOL, what='convT wgrad')
+    db = ops.bias_grad(g(dy, dev))
+    assert_close(db.cpu().numpy(), b.grad.numpy(), 1e-5, GRTOL, what='convT bias grad')
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# pooling / layout / element-wise
+@pytest.mark.parametrize('c', [3, 32])
+def test_maxpool_fwd_bwd_with_ties(dev, c):
+    from neural_imaging_amd import ops
+    n, h, w = 2, 8, 12
+    x = np.round(rnd((n, h, w, c), 1) * 4) / 4            # coarse values => many exact ties
+    xt = to64(x).requires_grad_(True)
+    y = T.max_pool2(xt)
+    dp = rnd(tuple(y.shape), 2)
+    (y * to64(dp)).sum().backward()
+    yo = ops.maxpool2(g(x, dev))
+    assert np.array_equal(yo.cpu().numpy(), y.detach().numpy().astype(np.float32))
+    add = rnd((n, h, w, c), 3)
+    dz = ops.maxpool2_bwd(g(dp, dev), g(x, dev), add=g(add, dev), apply_mask=True)
+    ref = (xt.grad.numpy() + add) * np.where(x > 0, 1.0, 0.2)
+    assert_close(dz.cpu().numpy(), ref, 1e-6, what='maxpool bwd (first-max tie rule)')
+
+
+def test_d2s_clip_and_small_ops(dev):
+    from neural_imaging_amd import ops
+    x = rnd((2, 6, 5, 12), 1, -0.5, 1.5)
+    ref = torch.clamp(T.depth_to_space(to64(x), 2), 0, 1)
+    y = ops.d2s_clip(g(x, dev))
+    assert np.array_equal(y.cpu().numpy(), ref.numpy().astype(np.float32))
+    dy = rnd(tuple(ref.shape), 2)
+    dx = ops.d2s_clip_bwd(g(dy, dev))
+    assert np.array_equal(dx.cpu().numpy(), T.space_to_depth(to64(dy), 2).numpy().astype(np.float32))
+    a, b = rnd((1000,), 3), rnd((1000,), 4)
+    assert np.allclose(ops.add(g(a, dev), g(b, dev)).cpu().numpy(), a + b)
+    assert np.allclose(ops.lrelu_bwd(g(a, dev), g(b, dev)).cpu().numpy(), a * np.where(b > 0, 1.0, 0.2))
+    xx = rnd((2, 8, 8, 3), 5)
+    assert_close(ops.avgpool(g(xx, dev), 2).cpu().numpy(), T.avg_pool(to64(xx), 2).numpy(), 1e-6, what='avgpool')
+    dyy = rnd((2, 4, 4, 3), 6)
+    assert_close(ops.avgpool_bwd(g(dyy, dev), 2).cpu().numpy(), np.repeat(np.repeat(dyy, 2, 1), 2, 2) / 4, 1e-6,
+                 what='avgpool bwd')
+
+
+def test_mse255_and_adam_and_nanflag(dev):
+    from neural_imaging_amd import ops
+    a, b = rnd((3, 16, 16, 3), 1, 0, 1), rnd((3, 16, 16, 3), 2, 0, 1)
+    at = to64(a).requires_grad_(True)
+    loss = T.mse255(at, to64(b))
+    (0.1 * loss).backward()
+    lo, gr = ops.mse255(g(a, dev), g(b, dev), grad_scale=0.1)
+    assert abs(float(lo.item()) - float(loss)) / float(loss) < 1e-5
+    assert_close(gr.cpu().numpy(), at.grad.numpy(), 1e-6, GRTOL, what='mse255 grad')
+    # Keras Adam, 3 steps
+    p0, grads = rnd((1000,), 3), [rnd((1000,), 10 + k) for k in range(3)]
+    p = [to64(p0).clone()]
+    m, v = [torch.zeros(1000, dtype=torch.float64)], [torch.zeros(1000, dtype=torch.float64)]
+    pg, mg, vg = g(p0, dev), torch.zeros(1000, device=dev), torch.zeros(1000, device=dev)
+    for k in range(3):
+        T.adam_step(p, [to64(grads[k])], m, v, k + 1, 1e-3)
+        ops.adam_step(pg, g(grads[k], dev), mg, vg, 1e-3, k + 1)
+    assert_close(pg.cpu().numpy(), p[0].numpy(), 1e-6, what='adam params')
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.nan_flag(pg, flag)
+    assert int(flag.item()) == 0
+    pg[17] = float('nan')
+    ops.nan_flag(pg, flag)
+    assert int(flag.item()) == 1
+    before = pg.clone()
+    ops.adam_step(pg, g(grads[0], dev), mg, vg, 1e-3, 4, skip_flag=flag)      # skipped
+    assert torch.equal(torch.nan_to_num(pg), torch.nan_to_num(before))
+
+
+def test_fan_head(dev):
+    from neural_imaging_amd import ops
+    n, h, w, c, k = 6, 4, 4, 32, 5
+    act = to64(rnd((n, h, w, c), 1)).requires_grad_(True)
+    wt = to64(rnd((c, k), 2)).requires_grad_(True)
+    b = to64(rnd((k,), 3)).requires_grad_(True)
+    labels = np.array([0, 1, 2, 3, 4, 1], np.int32)
+    a = T.leaky_relu(act)
+    probs = torch.softmax(a.mean(dim=(1, 2)) @ wt + b, dim=1)
+    loss = T.sparse_ce_from_probs(probs, labels)
+    loss.backward()
+    a_np = a.detach().numpy()
+    gap, pr, lp, dl = ops.fan_head_fwd(g(a_np, dev), g(wt.detach().numpy(), dev), g(b.detach().numpy(), dev),
+                                       torch.from_numpy(labels).to(dev), 1.0 / n)
+    assert_close(pr.cpu().numpy(), probs.detach().numpy(), 1e-6, what='probs')
+    dw, db = torch.empty((c, k), device=dev), torch.empty((k,), device=dev)
+    dact, lo = ops.fan_head_bwd(g(a_np, dev), gap, g(wt.detach().numpy(), dev), dl, lp, 1.0 / n, dw, db)
+    assert abs(float(lo.item()) - float(loss)) < 1e-5
+    assert_close(dw.cpu().numpy(), wt.grad.numpy(), 1e-6, GRTOL, what='dense dW')
+    assert_close(db.cpu().numpy(), b.grad.numpy(), 1e-6, GRTOL, what='dense db')
+    assert_close(dact.cpu().numpy(), act.grad.numpy(), 1e-7, GRTOL, what='d pre-activation of conv1x1')
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# constrained conv + manipulations
+def test_constrained_conv(dev):
+    from neural_imaging_amd import ops
+    k = to64(ot.fan_residual_init() + 0.05 * rnd((5, 5, 3, 3), 1)).requires_grad_(True)
+    m = to64(ot.center_mask_2dfilter(5, 3))
+    x = to64(natural_images(2, 24, 32, seed=4)).requires_grad_(True)
+    y = T.constrained_conv(x, k, m)
+    dy = rnd(tuple(y.shape), 2)
+    (y * to64(dy)).sum().backward()
+    kg = g(k.detach().numpy(), dev)
+    nf = ops.constrained_kernel(kg)
+    assert_close(nf.cpu().numpy(), T.constrained_kernel(k.detach(), m).numpy(), 1e-4, 1e-6, what='normalised filter')
+    yo = ops.conv2d(g(x.detach().numpy(), dev), nf, None, pads=(2, 2), out_hw=(24, 32), pad_mode=1)
+    assert_close(yo.cpu().numpy(), y.detach().numpy(), 1e-3, 1e-5, what='constrained conv fwd')
+    dnf = ops.conv2d_wgrad(g(x.detach().numpy(), dev), g(dy, dev), 5, pads=(2, 2), pad_mode=1)
+    dk = torch.empty_like(kg)
+    ops.constrained_kernel_bwd(kg, dnf, dk)
+    assert_close(dk.cpu().numpy(), k.grad.numpy(), 1e-4, GRTOL, what='constrained kernel grad')
+    dpad = ops.conv2d(g(dy, dev), ops.flip_weights(nf), None, pads=(4, 4), out_hw=(28, 36))
+    dx = ops.fold_pad(dpad, 2, 1)
+    assert_close(dx.cpu().numpy(), x.grad.numpy(), 1e-3, GRTOL, what='constrained conv input grad')
+
+
+@pytest.mark.parametrize('name', ['gaussian', 'gaussian3', 'sharpen', 'sharpen_strong', 'resample50', 'resample73'])
+def test_manipulations_fwd_bwd(dev, name):
+    from neural_imaging_amd.helpers import tf_helpers as th
+    x_np = natural_images(2, 32, 32, seed=7)
+    if name.startswith('sharpen'):
+        x_np = np.clip(x_np * 1.3 - 0.1, 0, 1).astype(np.float32)       # exercise the hard clip too
+    x = to64(x_np).requires_grad_(True)
+    if name == 'gaussian':
+        op, s, ref = th.Gaussian(), 0.83, om.manipulation_gaussian(x, 5, 0.83)
+    elif name == 'gaussian3':
+        op, s, ref = th.Gaussian(), 3.0, om.manipulation_gaussian(x, 5, 3.0)
+    elif name == 'sharpen':
+        op, s, ref = th.Sharpen(), 1.0, om.manipulation_sharpen(x, 1.0)
+    elif name == 'sharpen_strong':
+        op, s, ref = th.Sharpen(), 1.5, om.manipulation_sharpen(x, 1.5)
+    elif name == 'resample50':
+        op, s, ref = th.Resample(), 50, om.manipulation_resample(x, 50)
+    else:
+        op, s, ref = th.Resample(), 73, om.manipulation_resample(x, 73)
+    dy = rnd(tuple(ref.shape), 3)
+    (ref * to64(dy)).sum().backward()
+    y, ctx = op.forward(g(x_np, dev), s, training=True)
+    assert_close(y.cpu().numpy(), ref.detach().numpy(), ATOL, what=name + ' fwd')
+    dx = op.backward(ctx, g(dy, dev))
+    assert_close(dx.cpu().numpy(), x.grad.numpy(), 2e-4, 3e-4, what=name + ' bwd')

@@ -1,0 +1,169 @@
+"""
+Oracle self-consistency (CPU, seconds): two independent restatements must agree, analytic known answers hold
+(SURVEY 8c "Analytic KATs"), and the C float32 dJPEG agrees with the float64 one except at rounding ties.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import djpeg as odj
+from oracle import manip as om
+from oracle import nets as onets
+from oracle import tables as ot
+from oracle import tfops as T
+from oracle import workflow as owf
+
+from util import natural_images, to64
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _clib():
+    path = os.path.join(ROOT, 'oracle', 'libdjpeg_ref.so')
+    if not os.path.isfile(path):
+        pytest.skip('oracle/libdjpeg_ref.so not built (make -C oracle)')
+    return ctypes.CDLL(path)
+
+
+def _q3(q):
+    return np.stack([ot.jpeg_qtable(q, 0), ot.jpeg_qtable(q, 1), ot.jpeg_qtable(q, 1)]).astype(np.float32)
+
+
+def c_djpeg(x, q):
+    lib = _clib()
+    x = np.ascontiguousarray(x, np.float32)
+    n, h, w, _ = x.shape
+    y = np.zeros_like(x)
+    idx = np.zeros((n, 3, h // 8, w // 8, 8, 8), np.int16)
+    xd = np.zeros((n, 3, h // 8, w // 8, 8, 8), np.float32)
+    qq = _q3(q)
+    rc = lib.djpeg_ref_forward(x.ctypes.data_as(ctypes.c_void_p), y.ctypes.data_as(ctypes.c_void_p),
+                               qq.ctypes.data_as(ctypes.c_void_p), idx.ctypes.data_as(ctypes.c_void_p),
+                               xd.ctypes.data_as(ctypes.c_void_p), n, h, w)
+    assert rc == 0
+    return y, idx, xd
+
+
+@pytest.mark.parametrize('q', [10, 50, 95])
+def test_c_djpeg_matches_float64(q):
+    x = natural_images(2, 64, 64, seed=q)
+    y, idx, _ = c_djpeg(x, q)
+    y64, _, idx64 = odj.djpeg_torch(to64(x), q, 'soft')
+    assert np.abs(y - y64.numpy()).max() < 2e-6
+    mism = (idx != idx64.numpy()).mean()
+    assert mism < 1e-3, 'index mismatches vs float64 should only happen at rounding ties: {}'.format(mism)
+
+
+def test_djpeg_numpy_vs_torch_forward_backward():
+    x = torch.rand(1, 16, 24, 3, dtype=torch.float64, requires_grad=True)
+    for mode in ('soft', 'sin', 'harmonic', 'identity'):
+        x.grad = None
+        y, _, _ = odj.djpeg_torch(x, 50, mode)
+        gy = torch.rand_like(y)
+        (y * gy).sum().backward()
+        yn, cache = odj.djpeg_numpy_fwd(x.detach().numpy(), _q3(50).astype(np.float64), mode)
+        gn = odj.djpeg_numpy_bwd(gy.numpy(), cache)
+        assert np.abs(yn - y.detach().numpy()).max() < 1e-12
+        assert np.abs(gn - x.grad.numpy()).max() < 1e-9
+
+
+def test_djpeg_analytic_kats():
+    x = torch.rand(1, 32, 32, 3, dtype=torch.float64)
+    # Q == 1 and identity rounding is NOT an identity: the 4-decimal DCT matrix is not orthonormal
+    y, _, _ = odj.djpeg_torch(x, None, 'identity')
+    d = (y - x).abs().max().item()
+    assert 1e-5 < d < 1e-3
+    # soft forward == round forward
+    ys, _, i1 = odj.djpeg_torch(x, 50, 'soft')
+    yr, _, i2 = odj.djpeg_torch(x, 50, 'round')
+    assert torch.equal(ys, yr) and torch.equal(i1, i2)
+    assert float((i1 - i1.round()).abs().max()) == 0.0
+    F = ot.DCT_F.astype(np.float64)
+    assert 1e-4 < np.abs(F @ F.T - np.eye(8)).max() < 5e-4
+
+
+def test_depth_to_space_is_dcr():
+    x = torch.arange(2 * 3 * 4 * 8, dtype=torch.float64).reshape(2, 3, 4, 8)
+    y = T.depth_to_space(x, 2)
+    for (n, yy, xx, i, j, c) in [(0, 1, 2, 0, 1, 1), (1, 2, 3, 1, 0, 0), (1, 0, 0, 1, 1, 1)]:
+        assert y[n, yy * 2 + i, xx * 2 + j, c] == x[n, yy, xx, (i * 2 + j) * 2 + c]
+    assert torch.equal(T.space_to_depth(y, 2), x)
+
+
+def test_tf_same_padding_and_resize_tables():
+    assert T.same_pads(256, 5, 2) == (1, 2) and T.same_pads(128, 3, 1) == (1, 1) and T.same_pads(7, 5, 2) == (2, 2)
+    lo, hi, t = T.resize_axis_table(256, 128)
+    assert (lo == 2 * np.arange(128)).all() and (hi == lo + 1).all() and np.allclose(t, 0.5)
+    lo, hi, t = T.resize_axis_table(128, 256)
+    assert lo[0] == 0 and hi[0] == 0 and np.isclose(t[1], 0.25) and np.isclose(t[2], 0.75)
+    x = torch.rand(1, 8, 8, 3, dtype=torch.float64)
+    ref = torch.nn.functional.interpolate(x.permute(0, 3, 1, 2), size=(5, 5), mode='bilinear', align_corners=False)
+    assert (T.resize_bilinear(x, 5, 5) - ref.permute(0, 2, 3, 1)).abs().max() < 1e-12
+
+
+def test_constrained_kernel_kats():
+    k = torch.tensor(ot.fan_residual_init()) + 0.01 * torch.rand(5, 5, 3, 3, dtype=torch.float64)
+    m = torch.tensor(ot.center_mask_2dfilter(5, 3))
+    nf = T.constrained_kernel(k, m)
+    assert torch.allclose(nf.sum(dim=(0, 1, 2)), torch.zeros(3, dtype=torch.float64), atol=1e-9)
+    for i in range(3):
+        assert nf[2, 2, i, i] == -100
+    out = T.constrained_conv(torch.full((1, 16, 16, 3), 0.37, dtype=torch.float64), k, m)
+    assert out.abs().max() < 1e-10
+
+
+def test_ce_entropy_kats():
+    p = torch.full((4, 5), 0.2, dtype=torch.float64)
+    assert abs(float(T.sparse_ce_from_probs(p, [0, 1, 2, 3])) - np.log(5)) < 1e-12
+    cb = torch.tensor(ot.codebook(5))
+    assert float(T.entropy(torch.zeros(1000), cb)[0]) < 1e-5
+    vals = cb.repeat(100)
+    assert abs(float(T.entropy(vals, cb)[0]) - 5.0) < 1e-3
+
+
+def test_hsv_roundtrip_and_sharpen_quirk():
+    x = torch.rand(2, 12, 12, 3, dtype=torch.float64)
+    assert (T.hsv_to_rgb(T.rgb_to_hsv(x)) - x).abs().max() < 1e-12
+    import colorsys
+    v = x[0, 3, 4].tolist()
+    ref = colorsys.rgb_to_hsv(*v)
+    assert np.allclose(T.rgb_to_hsv(x)[0, 3, 4].numpy(), ref, atol=1e-12)
+    # strength 0 => H,V untouched, S shifted by (+1,+1) with SYMMETRIC edge handling
+    y0 = om.manipulation_sharpen(x, 0.0)
+    hsv = T.rgb_to_hsv(T.pad2d(x, 1, 'SYMMETRIC'))
+    shifted = torch.stack([hsv[:, 1:-1, 1:-1, 0], hsv[:, 2:, 2:, 1], hsv[:, 1:-1, 1:-1, 2]], dim=-1)
+    assert (y0 - torch.clamp(T.hsv_to_rgb(shifted), 0, 1)).abs().max() < 1e-12
+
+
+def test_keras_adam_first_step():
+    p = [torch.ones(3, dtype=torch.float64)]
+    g = [torch.tensor([0.5, -2.0, 0.0], dtype=torch.float64)]
+    m, v = [torch.zeros(3, dtype=torch.float64)], [torch.zeros(3, dtype=torch.float64)]
+    T.adam_step(p, g, m, v, 1, 1e-3)
+    # first step: m_hat/sqrt(v_hat) = sign(g) up to epsilon placement
+    assert torch.allclose(p[0], torch.tensor([1 - 1e-3, 1 + 1e-3, 1.0], dtype=torch.float64), atol=1e-8)
+
+
+def test_param_counts_and_workflow_step():
+    assert onets.count_params(onets.unet_init()) == 7763820
+    assert onets.count_params(onets.fan_init(5)) == 1145382
+    assert onets.count_params(onets.dcn_init()) == 2533293
+    wf = owf.Workflow()
+    rgb = natural_images(2, 64, 64, seed=1)
+    from util import bayer_from_rgb
+    bx, by = to64(bayer_from_rgb(rgb)), to64(rgb)
+    l0, parts = wf.training_step(bx, by, lambda_nip=0.1, learning_rate=1e-4)
+    l1, _ = wf.training_step(bx, by, lambda_nip=0.1, learning_rate=1e-4)
+    assert np.isfinite(l0) and l1 < l0 and abs(parts['ce'] - np.log(5)) < 0.5
+
+
+def test_gradcheck_manipulations():
+    """Finite-difference check of the oracle's own backward (it is the reference for the HIP backward kernels)."""
+    torch.manual_seed(0)
+    x = (0.2 + 0.6 * torch.rand(1, 8, 8, 3, dtype=torch.float64)).requires_grad_(True)
+    for fn in (lambda t: om.manipulation_gaussian(t, 5, 0.83), lambda t: om.manipulation_resample(t, 50),
+               lambda t: om.manipulation_sharpen(t, 1.0)):
+        assert torch.autograd.gradcheck(fn, (x,), eps=1e-6, atol=1e-5, nondet_tol=0.0)

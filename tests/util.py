@@ -1,0 +1,41 @@
+"""Shared helpers for the parity tests (oracle on CPU float64 vs HIP kernels on the GPU)."""
+import numpy as np
+import torch
+
+
+def natural_images(n, h, w, seed=0):
+    """Natural-image-like synthetic RGB in [0,1]: low-pass blocks + ramp + noise, quantised to k/255."""
+    rng = np.random.default_rng(seed)
+    base = rng.random((n, h // 8 + 1, w // 8 + 1, 3))
+    img = np.kron(base, np.ones((1, 8, 8, 1)))[:, :h, :w, :]
+    ramp = np.linspace(0, 1, w)[None, None, :, None]
+    img = 0.7 * img + 0.3 * ramp + rng.normal(0, 0.03, size=(n, h, w, 3))
+    return (np.round(np.clip(img, 0, 1) * 255) / 255).astype(np.float32)
+
+
+def bayer_from_rgb(rgb):
+    """GBRG Bayer stack (N,h/2,w/2,4) of an RGB batch - a synthetic RAW input for the UNet."""
+    g1 = rgb[:, 0::2, 0::2, 1]
+    b = rgb[:, 0::2, 1::2, 2]
+    r = rgb[:, 1::2, 0::2, 0]
+    g2 = rgb[:, 1::2, 1::2, 1]
+    return np.stack([g1, b, r, g2], axis=-1).astype(np.float32)
+
+
+def to64(a):
+    return torch.tensor(np.asarray(a), dtype=torch.float64)
+
+
+def err(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    d = np.abs(a - b)
+    return float(d.max()), float(d.max() / (np.abs(b).max() + 1e-30))
+
+
+def assert_close(a, b, atol, rtol_max=None, what=''):
+    """|a-b| <= atol  OR  (optionally) max|a-b| <= rtol_max * max|b| (gradient tensors have arbitrary scale)."""
+    mx, rel = err(a, b)
+    ok = mx <= atol or (rtol_max is not None and rel <= rtol_max)
+    assert ok, '{}: max abs err {:.3e}, rel-to-max {:.3e} (atol {}, rtol_max {})'.format(what, mx, rel, atol, rtol_max)
+    return mx, rel
