@@ -63,10 +63,18 @@ def time_dominant_kernel(dev, b_images, reps=5):
             'flops_per_launch': flops, 'ms_per_launch': ms, 'tflops': flops / (ms * 1e-3) / 1e12}
 
 
-def cpu_baseline(raw_patch, budget_s=20.0):
+def _usable_cores():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 32))          # more threads than this only adds barrier overhead for these layer sizes
+
+
+def cpu_baseline_worker(raw_patch, budget_s):
     """Oracle port on the host cores: torch float32 CPU, same step, B=2 raw patches, bounded to ~budget_s."""
     from oracle import workflow as owf
-    cores = os.cpu_count() or 1
+    cores = _usable_cores()
     torch.set_num_threads(cores)
     b = 2
     wf = owf.Workflow(trainable=('nip',), jpeg_quality=80, dtype=torch.float32)
@@ -74,13 +82,30 @@ def cpu_baseline(raw_patch, budget_s=20.0):
     bx, by = torch.from_numpy(raw), torch.from_numpy(rgb)
     wf.training_step(bx, by, lambda_nip=0.1, learning_rate=1e-4)       # warm-up
     t0, steps = time.time(), 0
-    while steps < 3 and (time.time() - t0) < budget_s:
+    while steps < 5 and (time.time() - t0) < budget_s:
         wf.training_step(bx, by, lambda_nip=0.1, learning_rate=1e-4)
         steps += 1
     dt = (time.time() - t0) / max(steps, 1)
     return {'value': b / dt, 'unit': 'patches/s', 'cores': cores, 'kind': 'port',
-            'sample': '{} step(s) of B={} raw patches {}x{}x4, torch-CPU float32 restatement (TF2 unavailable)'.format(
-                steps, b, raw_patch, raw_patch)}
+            'sample': '{} step(s) of B={} raw patches {}x{}x4, torch-CPU float32 restatement of the same step '
+                      '(TF2 unavailable)'.format(steps, b, raw_patch, raw_patch)}
+
+
+def cpu_baseline(raw_patch, budget_s=15.0, hard_timeout_s=120):
+    """Run the CPU leg in a child process so a badly provisioned host can never stall the GPU measurement."""
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', '--raw-patch',
+                              str(raw_patch), '--cpu-budget', str(budget_s)], capture_output=True, text=True,
+                             timeout=hard_timeout_s, env=dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES=''))
+        for ln in reversed(out.stdout.strip().splitlines()):
+            if ln.startswith('{'):
+                return json.loads(ln)
+        return {'value': None, 'unit': 'patches/s', 'cores': _usable_cores(), 'kind': 'port',
+                'sample': 'cpu worker failed: ' + out.stderr[-200:]}
+    except subprocess.TimeoutExpired:
+        return {'value': None, 'unit': 'patches/s', 'cores': _usable_cores(), 'kind': 'port',
+                'sample': 'cpu worker exceeded {} s'.format(hard_timeout_s)}
 
 
 def main():
@@ -91,7 +116,12 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='raw patches per GPU per step')
     ap.add_argument('--raw-patch', type=int, default=128)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-budget', type=float, default=15.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_worker:
+        print(json.dumps(cpu_baseline_worker(args.raw_patch, args.cpu_budget)))
+        return
 
     importlib.import_module('neural-imaging_amd')
     from neural_imaging_amd import _lib, parallel

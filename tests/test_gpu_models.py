@@ -126,42 +126,43 @@ def test_fan_forward_backward(dev):
     assert dec.shape == (5,) and (dec == probs_ref.detach().numpy().argmax(axis=1)).all()
 
 
-@pytest.mark.parametrize('trainable', [('nip',), ()])
-def test_workflow_training_step(dev, trainable):
-    from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
-    dist = {'downsampling': 'none', 'compression': 'jpeg', 'compression_params': {'quality': 80, 'codec': 'soft'}}
-    wf = ManipulationClassification('UNet', distribution=dist, trainable=set(trainable), raw_patch_size=32,
-                                    device=dev)
-    ref = owf.Workflow(trainable=trainable, jpeg_quality=80)
+def _sync_oracle(wf, ref):
     ref.nip = onets.OrderedDict((k, to64(v)) for k, v in wf.nip.state_dict().items())
     ref.fan = onets.OrderedDict((k, to64(v)) for k, v in wf.fan.state_dict().items())
+
+
+@pytest.mark.parametrize('trainable', [('nip',), ()])
+def test_workflow_training_step_smooth_channel(dev, trainable):
+    """Whole-channel parity with a codec whose rounding approximation is continuous ('sin', models/layers.py:125) and
+    without the hard-rounding 'jpeg' manipulation: every gradient must match the float64 oracle tightly, for two
+    consecutive Keras-Adam steps."""
+    from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
+    manips = ['sharpen:1', 'resample:50', 'gaussian:0.83']
+    dist = {'downsampling': 'none', 'compression': 'jpeg', 'compression_params': {'quality': 80, 'codec': 'sin'}}
+    wf = ManipulationClassification('UNet', manipulations=manips, distribution=dist, trainable=set(trainable),
+                                    raw_patch_size=32, device=dev)
+    ref = owf.Workflow(manipulations=manips, trainable=trainable, jpeg_quality=80, jpeg_codec='sin')
+    _sync_oracle(wf, ref)
     rgb = natural_images(2, 64, 64, seed=8)
     raw = bayer_from_rgb(rgb)
     lam = 0.1
-
-    # forward parity of the whole channel
     Y, c, C, ent, probs = wf.run_workflow(raw)
     Yr, cr, Cr, _, pr = ref.run_workflow(to64(raw))
     assert_close(Y.numpy(), Yr.numpy(), 1e-4, what='workflow Y')
     assert_close(c.numpy(), cr.numpy(), 2e-4, what='workflow manipulated batch')
-    # the codec output can differ by one quantisation step where |X/Q - k| ~ 0.5 (float32 vs float64 ties)
-    dC = np.abs(C.numpy() - Cr.numpy())
-    assert np.mean(dC > 1e-3) < 2e-3, 'too many codec output mismatches: {}'.format(np.mean(dC > 1e-3))
-    assert c.shape == (10, 64, 64, 3) and probs.shape == (10, 5)
-
+    assert_close(C.numpy(), Cr.numpy(), 3e-4, what='workflow codec output')
+    assert_close(probs.numpy(), pr.numpy(), 1e-3, what='workflow probabilities')
+    assert c.shape == (8, 64, 64, 3) and probs.shape == (8, 4)
     for step in range(2):
         loss_ref, parts_ref, params, grads, _ = ref.loss_and_grads(to64(raw), to64(rgb), lam)
         loss, parts = wf.training_step(raw, rgb, lambda_nip=lam, learning_rate=1e-4)
-        assert abs(float(parts['ce']) - parts_ref['ce']) < 2e-3, (float(parts['ce']), parts_ref['ce'])
-        assert abs(float(parts['nip']) - parts_ref['nip']) / parts_ref['nip'] < 1e-3
-        if step == 0:
-            names = list(ref.fan.keys()) + (list(ref.nip.keys()) if 'nip' in trainable else [])
-            gref = dict(zip(names, grads))
-            got = grads_of(wf.fan)
-            if 'nip' in trainable:
-                got.update(grads_of(wf.nip))
-            check_grads(got, gref, names, tol=5e-3)       # a handful of flipped quantisation ties are tolerated
-        # keep the oracle in lock-step (apply its own Adam)
+        assert abs(float(parts['ce']) - parts_ref['ce']) < 1e-3, (float(parts['ce']), parts_ref['ce'])
+        assert abs(float(parts['nip']) - parts_ref['nip']) / parts_ref['nip'] < 1e-4
+        names = list(ref.fan.keys()) + (list(ref.nip.keys()) if 'nip' in trainable else [])
+        got = grads_of(wf.fan)
+        if 'nip' in trainable:
+            got.update(grads_of(wf.nip))
+        check_grads(got, dict(zip(names, grads)), names, tol=1e-3)
         if ref._m is None:
             ref._m = [torch.zeros_like(p) for p in params]
             ref._v = [torch.zeros_like(p) for p in params]
@@ -169,7 +170,43 @@ def test_workflow_training_step(dev, trainable):
         with torch.no_grad():
             T.adam_step(params, grads, ref._m, ref._v, ref._t, 1e-4)
     sd = wf.fan.state_dict()
-    worst = max(np.abs(sd[k] - ref.fan[k].numpy()).max() for k in sd)
-    assert worst < 1e-4, worst
-    assert float(loss) == pytest.approx(float(parts['ce']) + (lam * float(parts['nip']) if 'nip' in trainable else 0),
-                                        rel=1e-5)
+    assert max(np.abs(sd[k] - ref.fan[k].numpy()).max() for k in sd) < 5e-5
+    expect = float(parts['ce']) + (lam * float(parts['nip']) if 'nip' in trainable else 0)
+    assert float(loss) == pytest.approx(expect, rel=1e-5)
+
+
+def test_workflow_training_step_default_channel(dev):
+    """The BASELINE configuration (hard rounding in both JPEG stages).  A rounding tie that flips between float32 and
+    float64 moves a block by a quantisation step, and the x100 high-pass residual filter of the FAN amplifies it, so
+    per-tensor parity is judged by direction (cosine) and the losses; the index path itself is pinned bit-exactly in
+    test_gpu_ops.py."""
+    from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
+    dist = {'downsampling': 'none', 'compression': 'jpeg', 'compression_params': {'quality': 80, 'codec': 'soft'}}
+    wf = ManipulationClassification('UNet', distribution=dist, trainable={'nip'}, raw_patch_size=32, device=dev)
+    ref = owf.Workflow(trainable=('nip',), jpeg_quality=80)
+    _sync_oracle(wf, ref)
+    rgb = natural_images(2, 64, 64, seed=8)
+    raw = bayer_from_rgb(rgb)
+    Y, c, C, ent, probs = wf.run_workflow(raw)
+    Yr, cr, Cr, _, pr = ref.run_workflow(to64(raw))
+    assert_close(Y.numpy(), Yr.numpy(), 1e-4, what='workflow Y')
+    dC = np.abs(C.numpy() - Cr.numpy())
+    assert np.mean(dC > 1e-3) < 5e-3, np.mean(dC > 1e-3)
+    assert c.shape == (10, 64, 64, 3) and probs.shape == (10, 5)
+    loss_ref, parts_ref, params, grads, _ = ref.loss_and_grads(to64(raw), to64(rgb), 0.1)
+    loss, parts = wf.training_step(raw, rgb, lambda_nip=0.1, learning_rate=1e-4)
+    assert abs(float(parts['ce']) - parts_ref['ce']) < 5e-3
+    assert abs(float(parts['nip']) - parts_ref['nip']) / parts_ref['nip'] < 1e-3
+    names = list(ref.fan.keys()) + list(ref.nip.keys())
+    got = grads_of(wf.fan)
+    got.update(grads_of(wf.nip))
+    for k, gr in zip(names, grads):
+        a, b = got[k].ravel().astype(np.float64), gr.numpy().ravel()
+        cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
+        assert cos > 0.98, (k, cos)
+    # the reference's NaN guard (workflows/...:281-282): poison one weight, the step must raise and not update
+    wf.fan._model.p['dense/bias'][0] = float('nan')
+    before = wf.nip.state_dict()['ec11/kernel'].copy()
+    with pytest.raises(RuntimeError):
+        wf.training_step(raw, rgb, lambda_nip=0.1, learning_rate=1e-4)
+    assert np.array_equal(before, wf.nip.state_dict()['ec11/kernel'])

@@ -53,9 +53,14 @@ def test_djpeg_fwd_bit_exact_index_path(dev, shape, q):
     assert torch.equal(idx.cpu(), torch.from_numpy(idxc)), 'quantisation indices differ from the canonical-order oracle'
     assert np.array_equal(xdq.cpu().numpy(), xdc)
     assert np.abs(y.cpu().numpy() - yc).max() <= 1e-6
+    # against float64 the hard rounding can flip where |X/Q - (k + 1/2)| is below float32 resolution: a flipped index
+    # moves a whole block by one quantisation step, so compare statistically there and tightly everywhere else
     y64, _, idx64 = odj.djpeg_torch(to64(x), q, 'soft')
-    assert_close(y.cpu().numpy(), y64.numpy(), ATOL, what='djpeg y vs float64')
-    assert (idx.cpu().numpy() != idx64.numpy()).mean() < 1e-3
+    flips = (idx.cpu().numpy() != idx64.numpy())
+    assert flips.mean() < 1e-4, flips.mean()
+    blk_ok = ~flips.any(axis=(1, 4, 5))                                        # (n, hb, wb) blocks without a flip
+    d = np.abs(y.cpu().numpy() - y64.numpy()).reshape(n, h // 8, 8, w // 8, 8, 3).max(axis=(2, 4, 5))
+    assert d[blk_ok].max() <= ATOL, d[blk_ok].max()
     # mask = "not clipped"
     ypre_in = (y64.numpy() > 0) & (y64.numpy() < 1)
     m = mask.cpu().numpy()
