@@ -75,10 +75,11 @@ int nimg_conv2d_fwd(const float* in1, int c1, const float* in2, int c2, const fl
 /* wt[ks*ks-1-t][co][ci] = w[t][ci][co]: spatially flipped, channel-transposed weights for the input-gradient pass */
 int nimg_conv_flip_weights(const float* w, float* wt, int ks_h, int ks_w, int cin, int cout, void* stream);
 /* dw (ks,ks,c1+c2,cout) (+)= sum over pixels of in (x) dz - the weight half of tape.gradient (pipelines.py:84-88,
- * forensics.py:118-124, workflows/manipulation_classification.py:280).  Deterministic split-K through `workspace`. */
+ * forensics.py:118-124, workflows/manipulation_classification.py:280).  Deterministic split-K through `workspace`.
+ * db (optional, may be NULL): (cout) bias gradient = column sums of dz, fused into the same pass. */
 size_t nimg_conv2d_wgrad_workspace_bytes(int cin, int cout, int ks_h, int ks_w, int n, int hout, int wout);
 int nimg_conv2d_wgrad(const float* in1, int c1, const float* in2, int c2, const float* dz, int cout, float* dw,
-                      int n, int h, int wd, int ks, int stride, int pad_t, int pad_l, int pad_mode, int hout,
+                      float* db, int n, int h, int wd, int ks, int stride, int pad_t, int pad_l, int pad_mode, int hout,
                       int wout, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 /* db (cout) (+)= sum over npix pixels of dz (npix, cout) */
 size_t nimg_bias_grad_workspace_bytes(long npix, int cout);

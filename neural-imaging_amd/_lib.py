@@ -23,7 +23,7 @@ PROTOTYPES = {
                                 c_int, c_int, c_int, c_int, c_int, c_int, c_float, P]),
     'nimg_conv_flip_weights': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'nimg_conv2d_wgrad_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
-    'nimg_conv2d_wgrad': (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+    'nimg_conv2d_wgrad': (c_int, [P, c_int, P, c_int, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'nimg_bias_grad_workspace_bytes': (c_size_t, [c_long, c_int]),
     'nimg_bias_grad': (c_int, [P, P, c_long, c_int, c_int, P, c_size_t, P]),

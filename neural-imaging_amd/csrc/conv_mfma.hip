@@ -18,6 +18,11 @@
 //   the output over two tensors (dgrad of a concat input).
 #include "common.h"
 
+// defined in conv_small.hip
+int nimg_internal_conv_fewout(const float* in, int cin, const float* w, const float* bias, float* out, int cout, int n,
+                              int h, int wd, int ks, int pad_t, int pad_l, int pad_mode, int hout, int wout,
+                              hipStream_t s);
+
 namespace {
 
 using namespace nimg;
@@ -193,6 +198,122 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Few input channels (Cin <= 4: FAN conv1 3->32, UNet ec11 4->32, ConstrainedConv2D input): the reduction index packs
+// (tap, ci) densely, K = KS*KS*Cin, so no MFMA k-slot is wasted on channel padding and the weights (which are
+// contiguous in exactly that order, [tap][ci][co]) are staged ONCE per workgroup; the workgroup then walks
+// TILES_PER_WG spatial tiles.  Stride 1, one input tensor.
+template <int KS, int CINP, int TN>
+__global__ __launch_bounds__(256) void conv_fwd_packed_kernel(const ConvParams p, int tiles_per_wg) {
+    constexpr int TH = 16, TW = 16;
+    constexpr int THH = TH + KS - 1, TWH = TW + KS - 1;
+    constexpr int NPIXH = THH * TWH;
+    constexpr int PS = ((NPIXH + 31) / 32) * 32 + 2;
+    constexpr int KTOT = KS * KS * CINP;
+    constexpr int KPAIRS = (KTOT + 1) / 2;
+    constexpr int NI = TN / 32;
+    constexpr int MI = 2;                              // 8 M fragments over 4 waves
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;                                  // [CINP][PS]
+    float* sB = smem + CINP * PS;                      // [2*KPAIRS][TN]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Cout = p.O1 + p.O2;
+    const int cot = (Cout + TN - 1) / TN;
+    const int co0 = (blockIdx.x % cot) * TN;
+    const int wg = blockIdx.x / cot;
+    const int tiles = p.tiles_y * p.tiles_x;
+    const long total_tiles = (long)tiles * p.N;
+
+    // weights: rows k = tap*CINP + ci are contiguous in memory; pad row (if KTOT is odd) is zero
+    for (int item = tid; item < 2 * KPAIRS * TN; item += 256) {
+        const int j = item % TN, k = item / TN;
+        sB[item] = (k < KTOT && co0 + j < Cout) ? p.w[(long)k * Cout + co0 + j] : 0.f;
+    }
+    int abase[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int P = (wave * MI + mi) * 32 + (lane & 31);
+        abase[mi] = (P / TW) * TWH + (P % TW);
+    }
+    for (int tt = 0; tt < tiles_per_wg; ++tt) {
+        const long gt = (long)wg * tiles_per_wg + tt;
+        if (gt >= total_tiles) break;
+        const int n = (int)(gt / tiles), tile = (int)(gt % tiles);
+        const int ty0 = (tile / p.tiles_x) * TH, tx0 = (tile % p.tiles_x) * TW;
+        __syncthreads();
+        for (int pix = tid; pix < NPIXH; pix += 256) {
+            int gy = ty0 - p.pad_t + pix / TWH, gx = tx0 - p.pad_l + pix % TWH;
+            const bool ok = map_coord(gy, p.H, p.pad_mode) && map_coord(gx, p.W, p.pad_mode);
+            const float* src = p.in1 + (((long)n * p.H + gy) * p.W + gx) * CINP;
+#pragma unroll
+            for (int c = 0; c < CINP; ++c) sA[c * PS + pix] = ok ? src[c] : 0.f;
+        }
+        __syncthreads();
+        f32x16 acc[MI][NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[mi][ni][j] = 0.0f;
+        const float* bL = sB + (lane >> 5) * TN + (lane & 31);
+#pragma unroll 2
+        for (int kp = 0; kp < KPAIRS; ++kp) {
+            int k = 2 * kp + (lane >> 5);
+            k = k < KTOT ? k : KTOT - 1;               // the padded slot multiplies a zero weight row
+            const int tap = k / CINP, ci = k - tap * CINP;
+            const int aoff = ci * PS + (tap / KS) * TWH + (tap % KS);
+            float a[MI], b[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) a[mi] = sA[aoff + abase[mi]];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) b[ni] = bL[(2 * kp) * TN + ni * 32];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int co = co0 + ni * 32 + (lane & 31);
+            if (co >= Cout) continue;
+            const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int P = (wave * MI + mi) * 32 + (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5);
+                    const int oy = ty0 + P / TW, ox = tx0 + P % TW;
+                    if (oy >= p.Hout || ox >= p.Wout) continue;
+                    const long pixoff = ((long)n * p.Hout + oy) * p.Wout + ox;
+                    float v = acc[mi][ni][j] + bv;
+                    if (p.act == 1) v = lrelu(v, p.alpha);
+                    if (p.act1) v *= (p.act1[pixoff * Cout + co] > 0.f ? 1.0f : p.alpha);
+                    p.out1[pixoff * Cout + co] = v;
+                }
+        }
+    }
+}
+
+template <int KS, int CINP, int TN>
+int launch_conv_packed(const ConvParams& p, hipStream_t stream) {
+    constexpr int THH = 16 + KS - 1, NPIXH = THH * THH;
+    constexpr int PS = ((NPIXH + 31) / 32) * 32 + 2;
+    constexpr int KP = (KS * KS * CINP + 1) / 2;
+    constexpr size_t lds = (size_t)(CINP * PS + 2 * KP * TN) * sizeof(float);
+    ConvParams q = p;
+    q.tiles_y = cdiv(p.Hout, 16);
+    q.tiles_x = cdiv(p.Wout, 16);
+    const long total_tiles = (long)q.tiles_y * q.tiles_x * p.N;
+    const int tpw = total_tiles >= 8192 ? 8 : (total_tiles >= 2048 ? 2 : 1);
+    const long blocks = cdiv(total_tiles, tpw) * (long)cdiv(p.O1 + p.O2, TN);
+    hipLaunchKernelGGL((conv_fwd_packed_kernel<KS, CINP, TN>), dim3((unsigned)blocks), dim3(256), lds, stream, q, tpw);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
 template <int KS, int STRIDE, int TH, int TW, int NB, int TN, int CK, bool VEC>
 int launch_conv(const ConvParams& p, hipStream_t stream) {
     constexpr int THH = (TH - 1) * STRIDE + KS, TWH = (TW - 1) * STRIDE + KS;
@@ -261,6 +382,18 @@ int nimg_conv2d_fwd(const float* in1, int c1, const float* in2, int c2, const fl
     p.pad_t = pad_t; p.pad_l = pad_l; p.tiles_y = p.tiles_x = 0; p.act = act; p.alpha = alpha; p.pad_mode = pad_mode;
     const bool vec = (c1 % 4 == 0) && (c2 % 4 == 0) && ((o1 + o2) % 4 == 0);
     hipStream_t s = (hipStream_t)stream;
+    const bool plain = (c2 == 0 && o2 == 0 && stride == 1);
+    // few output channels (<= 4): register-blocked VALU kernel (conv_small.hip)
+    if (plain && o1 == 3 && (ks == 3 || ks == 5) && !act_mask && act == 0)
+        return nimg_internal_conv_fewout(in1, c1, w, bias, out1, o1, n, h, wd, ks, pad_t, pad_l, pad_mode, hout, wout, s);
+    // few input channels (<= 4): (tap, ci)-packed reduction on the matrix core
+    if (plain && (c1 == 3 || c1 == 4) && (ks == 3 || ks == 5) && o1 >= 8) {
+        const bool n64 = o1 > 32;
+#define NIMG_PACKED(KS_, C_) (n64 ? launch_conv_packed<KS_, C_, 64>(p, s) : launch_conv_packed<KS_, C_, 32>(p, s))
+        if (ks == 5) return c1 == 3 ? NIMG_PACKED(5, 3) : NIMG_PACKED(5, 4);
+        return c1 == 3 ? NIMG_PACKED(3, 3) : NIMG_PACKED(3, 4);
+#undef NIMG_PACKED
+    }
     if (stride == 1) {
         if (ks == 1) return dispatch_tiles<1, 1, 16>(p, vec, s);
         if (ks == 3) return dispatch_tiles<3, 1, 16>(p, vec, s);

@@ -1,0 +1,116 @@
+// Convolutions with very few OUTPUT channels (Cout <= 4) on the vector ALU, float32:
+//   ConstrainedConv2D forward 5x5 3->3 with SYMMETRIC padding          (models/layers.py:56-57)
+//   its input gradient on the padded domain 3->3                        (backward of the same)
+//   the input gradient of the FAN's first convolution, 5x5 32->3        (models/forensics.py:69, backward)
+// A 32-wide MFMA N tile would idle >= 90 % of the matrix core here, and in float32 the VALU and MFMA peaks are the same
+// 157 TFLOP/s, so these run as a register-blocked direct convolution: one thread owns PW = 4 horizontally adjacent output
+// pixels x all Cout channels, every input sample fetched from the LDS halo tile feeds up to KS x Cout FMAs, and the
+// weights - indexed only by loop counters - live in SGPRs (scalar loads), so the inner loop is pure v_fmac.
+#include "common.h"
+
+namespace {
+
+using namespace nimg;
+
+struct SmallParams {
+    const float* in;
+    const float* w;       // [KS*KS][Cin][COUT]
+    const float* bias;    // optional
+    float* out;
+    int N, H, W, Cin, Hout, Wout, pad_t, pad_l, pad_mode;
+    int tiles_y, tiles_x;
+};
+
+constexpr int S_TH = 16, S_TWT = 16, S_PW = 4;      // 16 rows x (16 threads x 4 px) = 16 x 64 output tile
+constexpr int S_TW = S_TWT * S_PW;
+
+template <int KS, int COUT, int CK>
+__global__ __launch_bounds__(256) void conv_fewout_kernel(const SmallParams p) {
+    constexpr int THH = S_TH + KS - 1, TWH = S_TW + KS - 1;
+    constexpr int CKP = CK + (CK % 2 == 0 ? 1 : 0);            // odd pixel stride => conflict-free column walks
+    extern __shared__ __attribute__((aligned(16))) float smem[];    // [THH][TWH][CKP]
+    const int tid = threadIdx.x;
+    const int tx = tid % S_TWT, ty = tid / S_TWT;
+    int bid = blockIdx.x;
+    const int tiles = p.tiles_y * p.tiles_x;
+    const int n = bid / tiles, tile = bid % tiles;
+    const int ty0 = (tile / p.tiles_x) * S_TH, tx0 = (tile % p.tiles_x) * S_TW;
+
+    float acc[S_PW][COUT];
+#pragma unroll
+    for (int j = 0; j < S_PW; ++j)
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) acc[j][o] = 0.f;
+
+    for (int c0 = 0; c0 < p.Cin; c0 += CK) {
+        __syncthreads();
+        for (int item = tid; item < THH * TWH * CK; item += 256) {
+            const int k = item % CK, pix = item / CK;
+            int gy = ty0 - p.pad_t + pix / TWH, gx = tx0 - p.pad_l + pix % TWH;
+            float v = 0.f;
+            if (c0 + k < p.Cin && map_coord(gy, p.H, p.pad_mode) && map_coord(gx, p.W, p.pad_mode))
+                v = p.in[(((long)n * p.H + gy) * p.W + gx) * p.Cin + c0 + k];
+            smem[pix * CKP + k] = v;
+        }
+        __syncthreads();
+        const int ck = min(CK, p.Cin - c0);
+        for (int ky = 0; ky < KS; ++ky) {
+            const float* row = smem + ((ty + ky) * TWH + tx * S_PW) * CKP;
+            for (int k = 0; k < ck; ++k) {
+                const float* wk = p.w + ((long)(ky * KS) * p.Cin + c0 + k) * COUT;     // + kx * Cin * COUT
+#pragma unroll
+                for (int c = 0; c < S_PW + KS - 1; ++c) {
+                    const float v = row[c * CKP + k];
+#pragma unroll
+                    for (int j = 0; j < S_PW; ++j) {
+                        const int kx = c - j;
+                        if (kx >= 0 && kx < KS) {
+#pragma unroll
+                            for (int o = 0; o < COUT; ++o)
+                                acc[j][o] = fmaf(v, wk[(long)kx * p.Cin * COUT + o], acc[j][o]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    const int oy = ty0 + ty;
+    if (oy >= p.Hout) return;
+#pragma unroll
+    for (int j = 0; j < S_PW; ++j) {
+        const int ox = tx0 + tx * S_PW + j;
+        if (ox >= p.Wout) continue;
+        float* o = p.out + (((long)n * p.Hout + oy) * p.Wout + ox) * COUT;
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) o[c] = acc[j][c] + (p.bias ? p.bias[c] : 0.f);
+    }
+}
+
+template <int KS, int COUT, int CK>
+int launch_fewout(SmallParams p, hipStream_t s) {
+    constexpr int THH = S_TH + KS - 1, TWH = S_TW + KS - 1;
+    constexpr int CKP = CK + (CK % 2 == 0 ? 1 : 0);
+    constexpr size_t lds = (size_t)THH * TWH * CKP * sizeof(float);
+    p.tiles_y = cdiv(p.Hout, S_TH);
+    p.tiles_x = cdiv(p.Wout, S_TW);
+    const long blocks = (long)p.N * p.tiles_y * p.tiles_x;
+    auto k = conv_fewout_kernel<KS, COUT, CK>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, s, p);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+}  // namespace
+
+// internal entry used by nimg_conv2d_fwd's dispatcher (conv_mfma.hip); not part of the public ABI
+int nimg_internal_conv_fewout(const float* in, int cin, const float* w, const float* bias, float* out, int cout, int n,
+                              int h, int wd, int ks, int pad_t, int pad_l, int pad_mode, int hout, int wout,
+                              hipStream_t s) {
+    SmallParams p;
+    p.in = in; p.w = w; p.bias = bias; p.out = out; p.N = n; p.H = h; p.W = wd; p.Cin = cin; p.Hout = hout; p.Wout = wout;
+    p.pad_t = pad_t; p.pad_l = pad_l; p.pad_mode = pad_mode; p.tiles_y = p.tiles_x = 0;
+    if (cout == 3 && ks == 5) return cin <= 4 ? launch_fewout<5, 3, 3>(p, s) : launch_fewout<5, 3, 8>(p, s);
+    if (cout == 3 && ks == 3) return cin <= 4 ? launch_fewout<3, 3, 3>(p, s) : launch_fewout<3, 3, 8>(p, s);
+    return NIMG_ERR_ARG;
+}

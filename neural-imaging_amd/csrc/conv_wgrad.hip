@@ -24,6 +24,7 @@ struct WgradParams {
     const float* in2;
     const float* dz;
     float* partial;       // [splits][taps][Cin][Cout]
+    float* db_partial;    // optional [splits][Cout]: fused bias gradient (column sums of dz)
     int C1, C2, Cout;
     int N, H, W, Hout, Wout, pad_t, pad_l;
     int tiles_y, tiles_x, splits, work_per_split, pad_mode;
@@ -64,6 +65,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     const long work_total = (long)p.N * tiles;
     const long w_begin = (long)split * p.work_per_split;
     const long w_end = min(work_total, w_begin + p.work_per_split);
+    const bool do_bias = p.db_partial && ci0 == 0;
+    float bsum = 0.f;
 
     for (long wk = w_begin; wk < w_end; ++wk) {
         const int n = (int)(wk / tiles), tile = (int)(wk % tiles);
@@ -112,6 +115,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
             }
         }
         __syncthreads();
+        if (do_bias && tid < CO_T) {                       // fused bias gradient: column sums of the dz tile
+#pragma unroll 8
+            for (int px = 0; px < NPIX; ++px) bsum += sZ[px * CO_T + tid];
+        }
         // ---- K loop over pixel pairs; lane half (lane>>5) selects the pixel of the pair
         const float* zL = sZ + (lane >> 5) * CO_T + (lane & 31);
         const float* iL = sI + (lane >> 5) * STRIDE * CI_T + (lane & 31);
@@ -135,6 +142,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
         }
     }
 
+    if (do_bias && tid < CO_T && co0 + tid < p.Cout) p.db_partial[(long)split * p.Cout + co0 + tid] = bsum;
     // ---- write the partial slab: rows = ci (M), cols = co (N)
     float* slab = p.partial + (long)split * TAPS * Cin * p.Cout;
 #pragma unroll
@@ -152,6 +160,109 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
             }
         }
     }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Few input channels (Cin <= 4): the M dimension packs (tap, ci) - 10 taps x 3 channels or 8 taps x 4 channels per
+// 32-row MFMA tile - instead of padding 3 channels to 32.  Every wave holds ALL the accumulators and the 4 waves
+// split the rows of each pixel tile, so a workgroup produces 4 partial slabs (slab index = split * 4 + wave).
+template <int KS, int CINP, int NI>
+__global__ __launch_bounds__(256) void conv_wgrad_packed_kernel(const WgradParams p) {
+    constexpr int TAPS = KS * KS;
+    constexpr int TPF = 32 / CINP;                       // taps per M fragment
+    constexpr int MF = (TAPS + TPF - 1) / TPF;           // M fragments
+    constexpr int THH = WG_TH + KS - 1, TWH = WG_TW + KS - 1;
+    constexpr int NPIXH = THH * TWH, NPIX = WG_TH * WG_TW;
+    constexpr int COT = 32 * NI;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sI = smem;                    // [NPIXH][CINP]
+    float* sZ = smem + NPIXH * CINP;     // [NPIX][COT]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cob = (p.Cout + COT - 1) / COT;
+    const int co0 = (blockIdx.x % cob) * COT;
+    const int split = blockIdx.x / cob;
+
+    // per-lane (tap, ci) of each M fragment -> offset inside the halo tile, or -1 when the slot is padding
+    int aoff[MF];
+#pragma unroll
+    for (int f = 0; f < MF; ++f) {
+        const int i = lane & 31, tl = i / CINP, ci = i % CINP, tap = f * TPF + tl;
+        aoff[f] = (tl < TPF && tap < TAPS) ? ((tap / KS) * TWH + (tap % KS)) * CINP + ci : -1;
+    }
+    f32x16 acc[MF][NI];
+#pragma unroll
+    for (int f = 0; f < MF; ++f)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[f][ni][j] = 0.0f;
+
+    const int tiles = p.tiles_y * p.tiles_x;
+    const long work_total = (long)p.N * tiles;
+    const long w_begin = (long)split * p.work_per_split;
+    const long w_end = min(work_total, w_begin + p.work_per_split);
+    const bool do_bias = p.db_partial != nullptr;
+    float bsum = 0.f;
+    for (long wk = w_begin; wk < w_end; ++wk) {
+        const int n = (int)(wk / tiles), tile = (int)(wk % tiles);
+        const int ty0 = (tile / p.tiles_x) * WG_TH, tx0 = (tile % p.tiles_x) * WG_TW;
+        __syncthreads();
+        for (int pix = tid; pix < NPIXH; pix += 256) {
+            int gy = ty0 - p.pad_t + pix / TWH, gx = tx0 - p.pad_l + pix % TWH;
+            const bool ok = map_coord(gy, p.H, p.pad_mode) && map_coord(gx, p.W, p.pad_mode);
+            const float* src = p.in1 + (((long)n * p.H + gy) * p.W + gx) * CINP;
+#pragma unroll
+            for (int c = 0; c < CINP; ++c) sI[pix * CINP + c] = ok ? src[c] : 0.f;
+        }
+        for (int item = tid; item < NPIX * COT; item += 256) {
+            const int pix = item / COT, c = co0 + item % COT;
+            const int oy = ty0 + pix / WG_TW, ox = tx0 + pix % WG_TW;
+            float v = 0.f;
+            if (oy < p.Hout && ox < p.Wout && c < p.Cout)
+                v = p.dz[(((long)n * p.Hout + oy) * p.Wout + ox) * p.Cout + c];
+            sZ[item] = v;
+        }
+        __syncthreads();
+        if (do_bias && tid < COT) {
+#pragma unroll 8
+            for (int px = 0; px < NPIX; ++px) bsum += sZ[px * COT + tid];
+        }
+        const float* zL = sZ + (lane >> 5) * COT + (lane & 31);
+        for (int r = wave; r < WG_TH; r += 4) {
+#pragma unroll 2
+            for (int cp = 0; cp < WG_TW / 2; ++cp) {
+                const int pix = r * WG_TW + 2 * cp;
+                float b[NI];
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) b[ni] = zL[pix * COT + ni * 32];
+                const int ibase = (r * TWH + 2 * cp + (lane >> 5)) * CINP;
+#pragma unroll
+                for (int f = 0; f < MF; ++f) {
+                    const float a = aoff[f] >= 0 ? sI[ibase + aoff[f]] : 0.f;
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[f][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[ni], acc[f][ni], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (do_bias && tid < COT && co0 + tid < p.Cout) p.db_partial[(long)split * p.Cout + co0 + tid] = bsum;
+    float* slab = p.partial + ((long)split * 4 + wave) * TAPS * CINP * p.Cout;
+#pragma unroll
+    for (int f = 0; f < MF; ++f)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int co = co0 + ni * 32 + (lane & 31);
+            if (co >= p.Cout) continue;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int i = (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5);
+                const int tl = i / CINP, ci = i % CINP, tap = f * TPF + tl;
+                if (tl < TPF && tap < TAPS) slab[((long)tap * CINP + ci) * p.Cout + co] = acc[f][ni][j];
+            }
+        }
 }
 
 // dw[i] = sum_s partial[s][i]   (fixed order => deterministic)
@@ -204,21 +315,33 @@ static int wgrad_splits(int cin, int cout, int n, int hout, int wout) {
     return (int)((work + wps - 1) / wps);
 }
 
+static int packed_splits(int cout, int n, int hout, int wout) {
+    const long blocks_io = nimg::cdiv(cout, cout <= 32 ? 32 : 64);
+    const long work = (long)n * nimg::cdiv(hout, WG_TH) * nimg::cdiv(wout, WG_TW);
+    long splits = (1024 + blocks_io - 1) / blocks_io;
+    if (splits > work) splits = work;
+    if (splits < 1) splits = 1;
+    const long wps = (work + splits - 1) / splits;
+    return (int)((work + wps - 1) / wps);
+}
+
 size_t nimg_conv2d_wgrad_workspace_bytes(int cin, int cout, int ks_h, int ks_w, int n, int hout, int wout) {
     if (cin <= 0 || cout <= 0 || n <= 0) return 0;
     const size_t slab = (size_t)ks_h * ks_w * cin * cout * sizeof(float);
-    return slab * wgrad_splits(cin, cout, n, hout, wout);
+    const size_t generic = (slab + cout * sizeof(float)) * wgrad_splits(cin, cout, n, hout, wout);
+    const size_t packed = cin <= 4 ? (4 * slab + cout * sizeof(float)) * packed_splits(cout, n, hout, wout) : 0;
+    return generic > packed ? generic : packed;
 }
 
 int nimg_conv2d_wgrad(const float* in1, int c1, const float* in2, int c2, const float* dz, int cout, float* dw,
-                      int n, int h, int wd, int ks, int stride, int pad_t, int pad_l, int pad_mode, int hout,
+                      float* db, int n, int h, int wd, int ks, int stride, int pad_t, int pad_l, int pad_mode, int hout,
                       int wout, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
     if (!in1 || !dz || !dw || c1 <= 0 || c2 < 0 || cout <= 0 || n <= 0 || h <= 0 || wd <= 0) return NIMG_ERR_ARG;
     if ((c2 > 0 && !in2) || hout <= 0 || wout <= 0 || !workspace || pad_mode < 0 || pad_mode > 2) return NIMG_ERR_ARG;
     const int cin = c1 + c2;
     if (workspace_bytes < nimg_conv2d_wgrad_workspace_bytes(cin, cout, ks, ks, n, hout, wout)) return NIMG_ERR_WORKSPACE;
     WgradParams p;
-    p.in1 = in1; p.in2 = in2; p.dz = dz; p.partial = (float*)workspace;
+    p.in1 = in1; p.in2 = in2; p.dz = dz; p.partial = (float*)workspace; p.db_partial = nullptr;
     p.C1 = c1; p.C2 = c2; p.Cout = cout; p.N = n; p.H = h; p.W = wd; p.Hout = hout; p.Wout = wout;
     p.pad_t = pad_t; p.pad_l = pad_l; p.pad_mode = pad_mode;
     p.tiles_y = nimg::cdiv(hout, WG_TH); p.tiles_x = nimg::cdiv(wout, WG_TW);
@@ -226,8 +349,41 @@ int nimg_conv2d_wgrad(const float* in1, int c1, const float* in2, int c2, const 
     const long work = (long)n * p.tiles_y * p.tiles_x;
     p.work_per_split = (int)((work + p.splits - 1) / p.splits);
     const bool vec = (c1 % 4 == 0) && (c2 % 4 == 0) && (cout % 4 == 0);
-    const long blocks = (long)nimg::cdiv(cin, CI_T) * nimg::cdiv(cout, CO_T) * p.splits;
     hipStream_t s = (hipStream_t)stream;
+    const long count = (long)ks * ks * cin * cout;
+    const int rgrid = (int)((count + 255) / 256 > 4096 ? 4096 : (count + 255) / 256);
+
+    // few input channels: (tap, ci)-packed M dimension
+    if (c2 == 0 && (c1 == 3 || c1 == 4) && stride == 1 && (ks == 3 || ks == 5)) {
+        const int ni = cout <= 32 ? 1 : 2;
+        p.splits = packed_splits(cout, n, hout, wout);
+        p.work_per_split = (int)((work + p.splits - 1) / p.splits);
+        if (db) p.db_partial = p.partial + (size_t)4 * p.splits * count;
+        const long pblocks = (long)nimg::cdiv(cout, 32 * ni) * p.splits;
+#define NIMG_WGP(KS_, C_, NI_)                                                                                 \
+        do {                                                                                                  \
+            constexpr size_t lds = (size_t)((WG_TH + KS_ - 1) * (WG_TW + KS_ - 1) * C_ + WG_TH * WG_TW * 32 * NI_) * \
+                                   sizeof(float);                                                             \
+            hipLaunchKernelGGL((conv_wgrad_packed_kernel<KS_, C_, NI_>), dim3((unsigned)pblocks), dim3(256), lds, s, p); \
+        } while (0)
+        if (ks == 5 && c1 == 3) { if (ni == 1) NIMG_WGP(5, 3, 1); else NIMG_WGP(5, 3, 2); }
+        else if (ks == 5) { if (ni == 1) NIMG_WGP(5, 4, 1); else NIMG_WGP(5, 4, 2); }
+        else if (c1 == 3) { if (ni == 1) NIMG_WGP(3, 3, 1); else NIMG_WGP(3, 3, 2); }
+        else { if (ni == 1) NIMG_WGP(3, 4, 1); else NIMG_WGP(3, 4, 2); }
+#undef NIMG_WGP
+        NIMG_CHECK_LAUNCH();
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, s, (const float*)workspace, dw, count,
+                           4 * p.splits, accumulate);
+        NIMG_CHECK_LAUNCH();
+        if (db) {
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(1), dim3(256), 0, s, (const float*)p.db_partial, db,
+                               (long)cout, p.splits, accumulate);
+            NIMG_CHECK_LAUNCH();
+        }
+        return NIMG_OK;
+    }
+    if (db) p.db_partial = p.partial + (size_t)p.splits * count;
+    const long blocks = (long)nimg::cdiv(cin, CI_T) * nimg::cdiv(cout, CO_T) * p.splits;
 
 #define NIMG_WG(KS_, ST_)                                                                                     \
     do {                                                                                                      \
@@ -252,11 +408,14 @@ int nimg_conv2d_wgrad(const float* in1, int c1, const float* in2, int c2, const 
     else return NIMG_ERR_ARG;
 #undef NIMG_WG
     NIMG_CHECK_LAUNCH();
-    const long count = (long)ks * ks * cin * cout;
-    const int grid = (int)((count + 255) / 256 > 4096 ? 4096 : (count + 255) / 256);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, s, (const float*)workspace, dw, count,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, s, (const float*)workspace, dw, count,
                        p.splits, accumulate);
     NIMG_CHECK_LAUNCH();
+    if (db) {
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((cout + 255) / 256), dim3(256), 0, s,
+                           (const float*)p.db_partial, db, (long)cout, p.splits, accumulate);
+        NIMG_CHECK_LAUNCH();
+    }
     return NIMG_OK;
 }
 

@@ -39,8 +39,8 @@ class Conv2D(object):
                           stride=self.stride, act=self.activation)
 
     def backward_params(self, store, x, dz, x2=None):
-        ops.conv2d_wgrad(x, dz, self.ks, x2=x2, stride=self.stride, dw=store.g[self.name + '/kernel'])
-        ops.bias_grad(dz, db=store.g[self.name + '/bias'])
+        ops.conv2d_wgrad(x, dz, self.ks, x2=x2, stride=self.stride, dw=store.g[self.name + '/kernel'],
+                         db=store.g[self.name + '/bias'])
 
     def backward_input(self, store, dz, in_hw, act_mask=None, out=None, out2=None):
         return ops.conv2d_dgrad(dz, store.p[self.name + '/kernel'], in_hw, stride=self.stride, act_mask=act_mask,

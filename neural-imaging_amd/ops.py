@@ -163,9 +163,10 @@ def conv2d_dgrad(dz, w, in_hw, stride=1, padding='SAME', act_mask=None, out=None
                   out2=out2)
 
 
-def conv2d_wgrad(x, dz, ks, x2=None, stride=1, padding='SAME', pad_mode=0, pads=None, dw=None, accumulate=False):
-    """dw (k,k,C1+C2,Cout) = sum over pixels of x (x) dz."""
-    _f32(x, dz, x2, dw)
+def conv2d_wgrad(x, dz, ks, x2=None, stride=1, padding='SAME', pad_mode=0, pads=None, dw=None, accumulate=False,
+                 db=None):
+    """dw (k,k,C1+C2,Cout) = sum over pixels of x (x) dz;  db (optional, Cout) = fused bias gradient."""
+    _f32(x, dz, x2, dw, db)
     n, h, wd, c1 = x.shape
     c2 = 0 if x2 is None else x2.shape[3]
     _, ho, wo, cout = dz.shape
@@ -180,7 +181,7 @@ def conv2d_wgrad(x, dz, ks, x2=None, stride=1, padding='SAME', pad_mode=0, pads=
         dw = torch.empty((ks, ks, c1 + c2, cout), dtype=torch.float32, device=x.device)
     need = _lib.load().nimg_conv2d_wgrad_workspace_bytes(c1 + c2, cout, ks, ks, n, ho, wo)
     ws = _ws.get(need, x.device)
-    _lib.call('nimg_conv2d_wgrad', _p(x), c1, _p(x2), c2, _p(dz), cout, _p(dw), n, h, wd, ks, stride, pt, pl,
+    _lib.call('nimg_conv2d_wgrad', _p(x), c1, _p(x2), c2, _p(dz), cout, _p(dw), _p(db), n, h, wd, ks, stride, pt, pl,
               pad_mode, ho, wo, 1 if accumulate else 0, _p(ws), ws.numel(), _stream())
     return dw
 

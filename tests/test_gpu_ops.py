@@ -117,6 +117,11 @@ CONV_CASES = [
     (2, 32, 32, 3, 0, 64, 5, 2, 'leaky_relu'),
     (2, 32, 32, 64, 0, 128, 5, 2, None),
     (1, 64, 64, 40, 0, 72, 5, 1, 'leaky_relu'),
+    (2, 40, 72, 3, 0, 32, 5, 1, 'leaky_relu'),      # packed (tap,ci) reduction, partial tiles
+    (2, 24, 24, 4, 0, 64, 3, 1, None),
+    (3, 32, 80, 32, 0, 3, 5, 1, None),              # few-output VALU kernel (FAN conv1 dgrad shape)
+    (2, 20, 36, 3, 0, 3, 5, 1, None),
+    (2, 16, 16, 16, 0, 3, 3, 1, None),
 ]
 
 
@@ -149,11 +154,13 @@ def test_conv2d_dgrad_wgrad(dev, case):
     (z * to64(dz)).sum().backward()
     # weight / bias gradients
     xg = g(x.detach().numpy(), dev)
+    dbf = torch.empty((cout,), device=dev)
     if c2:
-        dw = ops.conv2d_wgrad(xg[..., :c1].contiguous(), g(dz, dev), ks, x2=xg[..., c1:].contiguous())
+        dw = ops.conv2d_wgrad(xg[..., :c1].contiguous(), g(dz, dev), ks, x2=xg[..., c1:].contiguous(), db=dbf)
     else:
-        dw = ops.conv2d_wgrad(xg, g(dz, dev), ks)
+        dw = ops.conv2d_wgrad(xg, g(dz, dev), ks, db=dbf)
     assert_close(dw.cpu().numpy(), wt.grad.numpy(), 1e-5, GRTOL, what='wgrad {}'.format(case))
+    assert_close(dbf.cpu().numpy(), b.grad.numpy(), 1e-5, GRTOL, what='fused bias grad {}'.format(case))
     db = ops.bias_grad(g(dz, dev))
     assert_close(db.cpu().numpy(), b.grad.numpy(), 1e-5, GRTOL, what='bias grad {}'.format(case))
     # input gradient, with the previous layer's LeakyReLU derivative fused
