@@ -113,7 +113,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=32, help='raw patches per GPU per step')
+    ap.add_argument('--batch', type=int, default=64, help='raw patches per GPU per step (SURVEY 8d C4: 64)')
     ap.add_argument('--raw-patch', type=int, default=128)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)

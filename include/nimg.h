@@ -160,6 +160,32 @@ int nimg_sharpen_bwd(const float* x, const float* dy, float* aux_hsv, const uint
 int nimg_sparse_axis_apply(const float* in, float* out, const int* rowptr, const int* col, const float* val, int n,
                            int hin, int win, int c, int axis, int out_size, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Learned codec (TwitterDCN, models/compression.py:197-279) specific pieces */
+int nimg_affine(const float* x, float* y, long count, float a, float b, void* stream);     /* y = a*x + b (:219,:268) */
+int nimg_lrelu_fwd(const float* x, float* y, long count, float alpha, void* stream);       /* tf.nn.leaky_relu (:224) */
+/* out (n,2h,2w,c) = in with zeros inserted (stride-2 transposed convolution = zero insertion + stride-1 conv) */
+int nimg_zero_insert2(const float* in, float* out, int n, int h, int w, int c, void* stream);
+/* DiscreteLatent (models/layers.py:183-203): latent = Quantization('soft-codebook' | identity)(scale * z) evaluated in
+ * float64 like the reference (layers.py:141), plus the batch-global differentiable entropy of the latent
+ * (helpers/tf_helpers.py:290-333).  scale: device scalar (may be NULL = 1).  count_global: number of latent values over
+ * ALL ranks (0 = count).  finalize = 0 leaves the K float64 histogram sums at workspace + 1024*K doubles for an
+ * all-reduce; call nimg_latent_entropy_finalize afterwards. The workspace must stay untouched until nimg_latent_bwd. */
+size_t nimg_latent_workspace_bytes(int codebook_size);
+int nimg_latent_fwd(const float* z, const float* scale, const float* codebook, int codebook_size, float v,
+                    float gamma, int soft_codebook, float* latent, float* entropy, long count, long count_global,
+                    void* workspace, size_t workspace_bytes, int finalize, void* stream);
+int nimg_latent_entropy_finalize(int codebook_size, long count_global, float* entropy, void* workspace, void* stream);
+/* dz = d loss / d z given dlatent (may be NULL) and the entropy term's coefficient d loss / d H; dscale (optional) */
+int nimg_latent_bwd(const float* z, const float* scale, const float* latent, const float* dlatent,
+                    float entropy_coef, const float* codebook, int codebook_size, float v, float gamma,
+                    int soft_codebook, float* dz, float* dscale, int accumulate_dscale, long count, void* workspace,
+                    size_t workspace_bytes, void* stream);
+/* tf.nn.l2_loss(target - y) = sum((target-y)^2)/2 and grad_y (+)= grad_scale * (y - target)  (compression.py:92-93) */
+size_t nimg_l2_loss_workspace_bytes(void);
+int nimg_l2_loss(const float* target, const float* y, float* loss, float* grad_y, long count, float grad_scale,
+                 int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

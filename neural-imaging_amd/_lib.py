@@ -49,6 +49,16 @@ PROTOTYPES = {
     'nimg_gaussian_bwd': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     'nimg_sharpen_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
     'nimg_sharpen_bwd': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, P]),
+    'nimg_affine': (c_int, [P, P, c_long, c_float, c_float, P]),
+    'nimg_lrelu_fwd': (c_int, [P, P, c_long, c_float, P]),
+    'nimg_zero_insert2': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'nimg_latent_workspace_bytes': (c_size_t, [c_int]),
+    'nimg_latent_fwd': (c_int, [P, P, P, c_int, c_float, c_float, c_int, P, P, c_long, c_long, P, c_size_t, c_int, P]),
+    'nimg_latent_entropy_finalize': (c_int, [c_int, c_long, P, P, P]),
+    'nimg_latent_bwd': (c_int, [P, P, P, P, c_float, P, c_int, c_float, c_float, c_int, P, P, c_int, c_long, P,
+                                c_size_t, P]),
+    'nimg_l2_loss_workspace_bytes': (c_size_t, []),
+    'nimg_l2_loss': (c_int, [P, P, P, P, c_long, c_float, c_int, P, c_size_t, P]),
     'nimg_sparse_axis_apply': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
 }
 

@@ -1,0 +1,339 @@
+// Learned-codec specific kernels (TwitterDCN, models/compression.py:197-279):
+//   DiscreteLatent  = trainable scale * z -> Quantization('soft-codebook') + differentiable entropy
+//                     models/layers.py:139-170, 183-203 ; helpers/tf_helpers.py:290-333
+//   plus the small element-wise pieces the codec graph needs (affine, LeakyReLU, zero insertion for strided dgrad).
+//
+// The reference evaluates the kernel weights in FLOAT64 (layers.py:141, tf_helpers.py:306); so do these kernels - the
+// t-Student kernel (1 + (gamma d)^2 / v)^(-(v+1)/2) with gamma = 25, v = 50 underflows float32 for |d| > ~4.
+// The entropy is a BATCH-GLOBAL statistic: forward accumulates the soft histogram in per-workgroup float64 partials, a
+// finalise kernel reduces them in a fixed order (deterministic), computes H and dH/dhist; the backward kernel needs only
+// those 2^bpf numbers.  Under data parallelism the partial histograms are what gets all-reduced.
+#include "common.h"
+
+namespace {
+
+using namespace nimg;
+
+constexpr int MAXK = 64;       // up to 6 bits per feature handled in registers; larger codebooks loop in chunks
+
+inline int grid_for(long items) {
+    long g = (items + 255) / 256;
+    return (int)(g > 1024 ? 1024 : (g < 1 ? 1 : g));
+}
+
+__global__ void affine_kernel(const float* __restrict__ x, float* __restrict__ y, long count, float a, float b) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+        y[i] = a * x[i] + b;
+}
+
+__global__ void lrelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long count, float alpha) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+        y[i] = lrelu(x[i], alpha);
+}
+
+// out (n,2h,2w,c): out[2y,2x] = in[y,x], zero elsewhere
+__global__ void zero_insert2_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int h, int w, int c) {
+    const long total = (long)n * 4 * h * w * c;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % c);
+        long r = i / c;
+        const int X = (int)(r % (2 * w));
+        r /= 2 * w;
+        const int Y = (int)(r % (2 * h));
+        const long im = r / (2 * h);
+        out[i] = ((X | Y) & 1) ? 0.f : in[((im * h + (Y >> 1)) * w + (X >> 1)) * c + ch];
+    }
+}
+
+struct KernelW {
+    double w[MAXK];
+    double dw[MAXK];
+    double S, dS;
+};
+
+// kernel weights (+eps) and their derivative w.r.t. u, for all K centres
+__device__ __forceinline__ void eval_weights(double u, const float* __restrict__ cb, int K, double v, double gamma,
+                                             KernelW& o, bool need_grad) {
+    o.S = 0.0;
+    o.dS = 0.0;
+    for (int k = 0; k < K; ++k) {
+        const double t = gamma * (u - (double)cb[k]);
+        double wk, dwk;
+        if (v <= 0.0) {                               // Gaussian kernel: exp(-gamma d^2)
+            const double d = u - (double)cb[k];
+            wk = exp(-gamma * d * d);
+            dwk = wk * (-2.0 * gamma * d);
+        } else {
+            const double base = 1.0 + t * t / v;
+            wk = pow(base, -(v + 1.0) / 2.0);
+            dwk = wk * (-(v + 1.0) / v) * gamma * t / base;
+        }
+        o.w[k] = wk + 1e-72;
+        o.dw[k] = need_grad ? dwk : 0.0;
+        o.S += o.w[k];
+        o.dS += o.dw[k];
+    }
+}
+
+// forward: latent = STE(hard, soft)(scale * z); hist partial (float64) of the normalised weights AT THE LATENT values
+__global__ __launch_bounds__(256) void soft_codebook_fwd_kernel(const float* __restrict__ z,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ cb, int K, double v,
+                                                                double gamma, float* __restrict__ latent,
+                                                                double* __restrict__ hist_partial, long count,
+                                                                int soft_codebook) {
+    __shared__ double sh[MAXK];
+    if (threadIdx.x < MAXK) sh[threadIdx.x] = 0.0;
+    __syncthreads();
+    const float s = scale ? scale[0] : 1.0f;
+    double hacc[MAXK];
+    for (int k = 0; k < K; ++k) hacc[k] = 0.0;
+    KernelW kw;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        const float zs = z[i] * s;                                           // layers.py:197-198 (float32 product)
+        float lat = zs;
+        if (soft_codebook) {
+            eval_weights((double)zs, cb, K, v, gamma, kw, false);
+            double soft = 0.0, best = -1.0;
+            int arg = 0;
+            for (int k = 0; k < K; ++k) {
+                const double wn = kw.w[k] / kw.S;
+                soft += wn * (double)cb[k];
+                if (wn > best) { best = wn; arg = k; }                       // first maximum, like tf.argmax
+            }
+            const float softf = (float)soft, hard = cb[arg];
+            lat = (hard - softf) + softf;                                    // stop_gradient(hard - soft) + soft
+        }
+        latent[i] = lat;
+        eval_weights((double)lat, cb, K, v, gamma, kw, false);               // entropy(latent, codebook), layers.py:201
+        for (int k = 0; k < K; ++k) hacc[k] += kw.w[k] / kw.S;
+    }
+    for (int k = 0; k < K; ++k) {
+        const double t = wave_sum_d(hacc[k]);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&sh[k], t);                   // LDS float64 atomics, 4 waves
+    }
+    __syncthreads();
+    if (threadIdx.x < K) hist_partial[(long)blockIdx.x * K + threadIdx.x] = sh[threadIdx.x];
+}
+
+// hist_sum[k] = sum_blocks partial (fixed order)
+__global__ void hist_reduce_kernel(const double* __restrict__ partial, int nblocks, int K, double* __restrict__ hist_sum) {
+    const int k = threadIdx.x;
+    if (k >= K) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[(long)b * K + k];
+    hist_sum[k] = s;
+}
+
+// entropy (bits) and dH/d(hist_sum) from the global weight sums; tf_helpers.py:326-331
+__global__ void entropy_finalize_kernel(const double* __restrict__ hist_sum, int K, double n_total,
+                                        float* __restrict__ entropy, double* __restrict__ dH_dsum) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double hc[MAXK], T = 0.0;
+    bool clipped[MAXK];
+    for (int k = 0; k < K; ++k) {
+        const double h = hist_sum[k] / n_total;
+        clipped[k] = h < 1e-9;
+        hc[k] = clipped[k] ? 1e-9 : h;
+        T += hc[k];
+    }
+    double H = 0.0;
+    for (int k = 0; k < K; ++k) {
+        const double q = hc[k] / T;
+        H -= q * log(q);
+    }
+    entropy[0] = (float)(H / 0.6931);
+    // dH/dhc_k = -(log q_k + 1)/T + (sum_j q_j (log q_j + 1))/T ;  then through the clip and the 1/n_total mean
+    double mean = 0.0;
+    for (int k = 0; k < K; ++k) { const double q = hc[k] / T; mean += q * (log(q) + 1.0); }
+    for (int k = 0; k < K; ++k) {
+        const double q = hc[k] / T;
+        const double d = (-(log(q) + 1.0) + mean) / T / 0.6931;
+        dH_dsum[k] = clipped[k] ? 0.0 : d / n_total;
+    }
+}
+
+// backward: dz = scale * dsoft/du(zs) * [ dlat + coef * sum_k dH_dsum[k] * dwn_k/du(lat) ];  dscale partial = sum z * (...)
+__global__ __launch_bounds__(256) void soft_codebook_bwd_kernel(const float* __restrict__ z,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ latent,
+                                                                const float* __restrict__ dlat,
+                                                                const double* __restrict__ dH_dsum, float coef,
+                                                                const float* __restrict__ cb, int K, double v,
+                                                                double gamma, float* __restrict__ dz,
+                                                                double* __restrict__ dscale_partial, long count,
+                                                                int soft_codebook) {
+    __shared__ double red[4];
+    const float s = scale ? scale[0] : 1.0f;
+    double dsum = 0.0;
+    KernelW kw;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        double g = dlat ? (double)dlat[i] : 0.0;
+        if (coef != 0.f) {
+            eval_weights((double)latent[i], cb, K, v, gamma, kw, true);
+            double e = 0.0;
+            for (int k = 0; k < K; ++k)
+                e += dH_dsum[k] * (kw.dw[k] * kw.S - kw.w[k] * kw.dS) / (kw.S * kw.S);
+            g += (double)coef * e;
+        }
+        double dsoft = 1.0;
+        const float zs = z[i] * s;
+        if (soft_codebook) {
+            eval_weights((double)zs, cb, K, v, gamma, kw, true);
+            dsoft = 0.0;
+            for (int k = 0; k < K; ++k)
+                dsoft += (double)cb[k] * (kw.dw[k] * kw.S - kw.w[k] * kw.dS) / (kw.S * kw.S);
+        }
+        const double gz = g * dsoft;                 // gradient w.r.t. zs = scale * z
+        dz[i] = (float)(gz * (double)s);
+        dsum += gz * (double)z[i];
+    }
+    dsum = wave_sum_d(dsum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dsum;
+    __syncthreads();
+    if (threadIdx.x == 0) dscale_partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void dscale_final_kernel(const double* __restrict__ partial, int nblocks, float* __restrict__ dscale,
+                                    int accumulate) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int b = 0; b < nblocks; ++b) s += partial[b];
+        dscale[0] = accumulate ? dscale[0] + (float)s : (float)s;
+    }
+}
+
+// l2 loss: sum((a-b)^2)/2 and its gradient (a - b) * gscale (tf.nn.l2_loss, models/compression.py:92-93)
+__global__ __launch_bounds__(256) void l2_loss_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      float* grad_b, double* __restrict__ partial, long count,
+                                                      float gscale, int accumulate) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        const float d = b[i] - a[i];                                  // d/db of (a-b)^2/2 = (b - a)
+        s += 0.5 * (double)d * (double)d;
+        if (grad_b) grad_b[i] = accumulate ? grad_b[i] + gscale * d : gscale * d;
+    }
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void sum_final_kernel(const double* __restrict__ partial, int nblocks, float* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int k = 0; k < nblocks; ++k) s += partial[k];
+        out[0] = (float)s;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int nimg_affine(const float* x, float* y, long count, float a, float b, void* stream) {
+    if (!x || !y || count < 0) return NIMG_ERR_ARG;
+    if (count == 0) return NIMG_OK;
+    hipLaunchKernelGGL(affine_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, x, y, count, a, b);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_lrelu_fwd(const float* x, float* y, long count, float alpha, void* stream) {
+    if (!x || !y || count < 0) return NIMG_ERR_ARG;
+    if (count == 0) return NIMG_OK;
+    hipLaunchKernelGGL(lrelu_fwd_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, x, y, count, alpha);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_zero_insert2(const float* in, float* out, int n, int h, int w, int c, void* stream) {
+    if (!in || !out || n < 0 || h <= 0 || w <= 0 || c <= 0) return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    hipLaunchKernelGGL(zero_insert2_kernel, dim3(grid_for((long)n * 4 * h * w * c)), dim3(256), 0,
+                       (hipStream_t)stream, in, out, n, h, w, c);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+size_t nimg_latent_workspace_bytes(int codebook_size) {
+    // [1024 blocks][K] hist partials + [K] hist sums + [K] dH/dsum + [1024] dscale partials, all float64
+    return (size_t)(1024 * (size_t)codebook_size + 2 * (size_t)codebook_size + 1024) * sizeof(double);
+}
+
+int nimg_latent_fwd(const float* z, const float* scale, const float* codebook, int codebook_size, float v,
+                    float gamma, int soft_codebook, float* latent, float* entropy, long count, long count_global,
+                    void* workspace, size_t workspace_bytes, int finalize, void* stream) {
+    if (!z || !codebook || !latent || !entropy || !workspace || count <= 0 || codebook_size < 2 || codebook_size > MAXK)
+        return NIMG_ERR_ARG;
+    if (workspace_bytes < nimg_latent_workspace_bytes(codebook_size)) return NIMG_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int K = codebook_size, grid = grid_for(count);
+    double* part = (double*)workspace;
+    double* hsum = part + 1024 * (size_t)K;
+    double* dH = hsum + K;
+    hipLaunchKernelGGL(soft_codebook_fwd_kernel, dim3(grid), dim3(256), 0, s, z, scale, codebook, K, (double)v,
+                       (double)gamma, latent, part, count, soft_codebook);
+    NIMG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(hist_reduce_kernel, dim3(1), dim3(64), 0, s, (const double*)part, grid, K, hsum);
+    NIMG_CHECK_LAUNCH();
+    if (finalize) {       // single process: the local histogram is the global one
+        hipLaunchKernelGGL(entropy_finalize_kernel, dim3(1), dim3(64), 0, s, (const double*)hsum, K,
+                           (double)(count_global > 0 ? count_global : count), entropy, dH);
+        NIMG_CHECK_LAUNCH();
+    }
+    return NIMG_OK;
+}
+
+/* after an all-reduce(sum) of the K float64 histogram sums (workspace + 1024*K doubles) under data parallelism */
+int nimg_latent_entropy_finalize(int codebook_size, long count_global, float* entropy, void* workspace, void* stream) {
+    if (!entropy || !workspace || codebook_size < 2 || codebook_size > MAXK || count_global <= 0) return NIMG_ERR_ARG;
+    const int K = codebook_size;
+    double* hsum = (double*)workspace + 1024 * (size_t)K;
+    hipLaunchKernelGGL(entropy_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)hsum, K,
+                       (double)count_global, entropy, hsum + K);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_latent_bwd(const float* z, const float* scale, const float* latent, const float* dlatent,
+                    float entropy_coef, const float* codebook, int codebook_size, float v, float gamma,
+                    int soft_codebook, float* dz, float* dscale, int accumulate_dscale, long count, void* workspace,
+                    size_t workspace_bytes, void* stream) {
+    if (!z || !latent || !codebook || !dz || !workspace || count <= 0 || codebook_size < 2 || codebook_size > MAXK)
+        return NIMG_ERR_ARG;
+    if (workspace_bytes < nimg_latent_workspace_bytes(codebook_size)) return NIMG_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int K = codebook_size, grid = grid_for(count);
+    double* part = (double*)workspace;
+    double* dH = part + 1024 * (size_t)K + K;
+    double* dsp = dH + K;
+    hipLaunchKernelGGL(soft_codebook_bwd_kernel, dim3(grid), dim3(256), 0, s, z, scale, latent, dlatent,
+                       (const double*)dH, entropy_coef, codebook, K, (double)v, (double)gamma, dz, dsp, count,
+                       soft_codebook);
+    NIMG_CHECK_LAUNCH();
+    if (dscale) {
+        hipLaunchKernelGGL(dscale_final_kernel, dim3(1), dim3(64), 0, s, (const double*)dsp, grid, dscale,
+                           accumulate_dscale);
+        NIMG_CHECK_LAUNCH();
+    }
+    return NIMG_OK;
+}
+
+size_t nimg_l2_loss_workspace_bytes(void) { return 1024 * sizeof(double); }
+
+int nimg_l2_loss(const float* target, const float* y, float* loss, float* grad_y, long count, float grad_scale,
+                 int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!target || !y || !loss || !workspace || count <= 0) return NIMG_ERR_ARG;
+    if (workspace_bytes < nimg_l2_loss_workspace_bytes()) return NIMG_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = grid_for(count);
+    hipLaunchKernelGGL(l2_loss_kernel, dim3(grid), dim3(256), 0, s, target, y, grad_y, (double*)workspace, count,
+                       grad_scale, accumulate);
+    NIMG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, grid, loss);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+}  // extern "C"

@@ -31,16 +31,21 @@ __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restri
         const int oy = (int)(r % ho), im = (int)(r / ho);
         const float* p00 = x + (((long)im * h + 2 * oy) * w + 2 * ox) * c + cc;
         const float* p10 = p00 + (long)w * c;
-        float o[V];
-#pragma unroll
-        for (int k = 0; k < V; ++k) o[k] = fmaxf(fmaxf(p00[k], p00[c + k]), fmaxf(p10[k], p10[c + k]));
         float* q = y + (((long)im * ho + oy) * wo + ox) * c + cc;
+        if (V == 4) {
+            const float4 a = *reinterpret_cast<const float4*>(p00), b = *reinterpret_cast<const float4*>(p00 + c);
+            const float4 d = *reinterpret_cast<const float4*>(p10), e = *reinterpret_cast<const float4*>(p10 + c);
+            *reinterpret_cast<float4*>(q) = make_float4(fmaxf(fmaxf(a.x, b.x), fmaxf(d.x, e.x)), fmaxf(fmaxf(a.y, b.y), fmaxf(d.y, e.y)),
+                                                        fmaxf(fmaxf(a.z, b.z), fmaxf(d.z, e.z)), fmaxf(fmaxf(a.w, b.w), fmaxf(d.w, e.w)));
+        } else {
 #pragma unroll
-        for (int k = 0; k < V; ++k) q[k] = o[k];
+            for (int k = 0; k < V; ++k) q[k] = fmaxf(fmaxf(p00[k], p00[c + k]), fmaxf(p10[k], p10[c + k]));
+        }
     }
 }
 
 // dz[n,y,x,c] = (first arg-max of the window ? dp : 0) [+ add] ) * [lrelu'(y)]
+// V channels per thread; V == 4 moves float4s (16 B per lane, coalesced along the NHWC channel axis)
 template <int V>
 __global__ void maxpool2_bwd_kernel(const float* __restrict__ dp, const float* __restrict__ yact,
                                     const float* add, float* dz, int n, int h, int w, int c, int apply_mask,
@@ -55,23 +60,49 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ dp, const float* _
         const int oy = (int)(r % ho), im = (int)(r / ho);
         const long base = (((long)im * h + 2 * oy) * w + 2 * ox) * c + cc;
         const long offs[4] = {0, (long)c, (long)w * c, (long)w * c + c};
-        const float* g = dp + (((long)im * ho + oy) * wo + ox) * c + cc;
-#pragma unroll
-        for (int k = 0; k < V; ++k) {
-            float v[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = yact[base + offs[q] + k];
-            const float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-            int sel = 3;
-            if (v[0] == m) sel = 0; else if (v[1] == m) sel = 1; else if (v[2] == m) sel = 2;
-            const float gv = g[k];
+        float v[4][V], a[4][V], g[V], o[4][V];
+        if (V == 4) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                float o = (q == sel) ? gv : 0.f;
-                if (add) o += add[base + offs[q] + k];
-                if (apply_mask) o *= (v[q] > 0.f ? 1.0f : alpha);
-                dz[base + offs[q] + k] = o;
+                const float4 t = *reinterpret_cast<const float4*>(yact + base + offs[q]);
+                v[q][0] = t.x; v[q][1] = t.y; v[q][2] = t.z; v[q][3] = t.w;
+                if (add) {
+                    const float4 u = *reinterpret_cast<const float4*>(add + base + offs[q]);
+                    a[q][0] = u.x; a[q][1] = u.y; a[q][2] = u.z; a[q][3] = u.w;
+                }
             }
+            const float4 t = *reinterpret_cast<const float4*>(dp + (((long)im * ho + oy) * wo + ox) * c + cc);
+            g[0] = t.x; g[1] = t.y; g[2] = t.z; g[3] = t.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    v[q][k] = yact[base + offs[q] + k];
+                    if (add) a[q][k] = add[base + offs[q] + k];
+                }
+#pragma unroll
+            for (int k = 0; k < V; ++k) g[k] = dp[(((long)im * ho + oy) * wo + ox) * c + cc + k];
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float m = fmaxf(fmaxf(v[0][k], v[1][k]), fmaxf(v[2][k], v[3][k]));
+            int sel = 3;
+            if (v[0][k] == m) sel = 0; else if (v[1][k] == m) sel = 1; else if (v[2][k] == m) sel = 2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float t = (q == sel) ? g[k] : 0.f;
+                if (add) t += a[q][k];
+                if (apply_mask) t *= (v[q][k] > 0.f ? 1.0f : alpha);
+                o[q][k] = t;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (V == 4) *reinterpret_cast<float4*>(dz + base + offs[q]) = make_float4(o[q][0], o[q][1], o[q][2], o[q][3]);
+            else
+#pragma unroll
+                for (int k = 0; k < V; ++k) dz[base + offs[q] + k] = o[q][k];
         }
     }
 }

@@ -1,0 +1,289 @@
+"""
+Learned image compression on the HIP kernels.  Mirrors the reference's models/compression.py: DCN (:28-184) - the
+abstract codec with a soft-codebook latent, entropy-regularised L2 loss and Adam - and TwitterDCN (:187-291).
+
+TwitterDCN graph (compression.py:219-271): 2(x-0.5) -> Conv5x5 s2 64 +LReLU -> Conv5x5 s2 128 -> 3 residual blocks
+(block 1 is fed LeakyReLU(net) but its skip adds the PRE-activation net, :224-227) -> Conv5x5 s2 n_features ->
+DiscreteLatent -> Conv3x3 512 -> d2s -> 3 residual blocks -> Conv3x3 256 +LReLU -> d2s -> Conv3x3 12 -> d2s -> (x+1)/2
+-> straight-through clip.  Strided convolutions use TF's asymmetric SAME padding.
+
+As in the reference the latent scale is always trainable and the codebook never, whatever
+scale_latent / train_codebook say; they are recorded hyper-parameters only.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .. import ops, parallel
+from ..device import DeviceArray, to_device
+from ..helpers import paramspec
+from .layers import Conv2D
+from .tfmodel import ParamStore, TFModel
+
+
+class _Shape(object):
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+
+
+class _DiscreteLatent(object):
+    """Surface callers touch: discrete_latent.scaling_factor, .quantization.codebook (layers.py:183-203)."""
+
+    def __init__(self, model):
+        self._model = model
+
+    @property
+    def scaling_factor(self):
+        return DeviceArray(self._model._model.p['latent_scaling'])
+
+
+class DCN(TFModel):
+
+    def __init__(self, patch_size=128, latent_bpf=5, rounding='soft-codebook', train_codebook=False,
+                 entropy_weight=250, scale_latent=True, use_batchnorm=False, loss_metric='L2', device=None,
+                 seed=777, **kwargs):
+        super().__init__(device=device)
+        self._h = paramspec.ParamSpec({
+            'latent_bpf': (5, int, (1, 8)),
+            'train_codebook': (False, bool, None),
+            'entropy_weight': (250, float, (0, 1e6)),
+            'scale_latent': (True, bool, None),
+            'use_batchnorm': (False, bool, None),
+            'loss_metric': ('L2', str, {'L2'}),
+            'rounding': ('soft', str, {'identity', 'soft', 'soft-codebook', 'sin'}),
+        })
+        params = locals()
+        self._h.update(**{k: params[k] for k in self._h.keys()})
+        if self._h.rounding not in ('soft-codebook', 'identity'):
+            raise NotImplementedError('latent rounding {} is not built (soft-codebook | identity)'.format(
+                self._h.rounding))
+        if self._h.latent_bpf > 6:
+            raise NotImplementedError('codebooks above 6 bits per feature are not built')
+        self.patch_size = patch_size
+        self._seed = seed
+        self.x = _Shape((None, patch_size, patch_size, 3))
+        qmin, qmax = -2 ** (self._h.latent_bpf - 1) + 1, 2 ** (self._h.latent_bpf - 1)      # layers.py:110-116
+        self._codebook = torch.arange(qmin, qmax + 1, dtype=torch.float32).to(self.device)
+        self.discrete_latent = _DiscreteLatent(self)
+        self.construct_model(**kwargs)
+        self._has_attributes(['y', '_model'])
+        if loss_metric != 'L2':
+            raise NotImplementedError('Loss metric {} not supported yet.'.format(loss_metric))
+        self.loss = self._loss
+        self.learning_rate = 1e-3
+        self._lws = None
+
+    def _loss(self, image_target, image_compressed, entropy):
+        """tf.nn.l2_loss(target - compressed) + entropy_weight * entropy  (compression.py:92-93)"""
+        a, b = to_device(image_target, self.device), to_device(image_compressed, self.device)
+        return float(DeviceArray(ops.l2_loss(a, b)[0])) + self._h.entropy_weight * float(entropy)
+
+    def construct_model(self, **kwargs):
+        raise NotImplementedError('Not implemented!')
+
+    def reset_performance_stats(self):
+        self.performance = self._reset_performance(['loss', 'entropy', 'ssim', 'psnr'])
+
+    def get_codebook(self):
+        return self._codebook.cpu().numpy().reshape((-1,))
+
+    # -- reference surface ---------------------------------------------------------------------------------------
+    def compress(self, batch_x):
+        x = to_device(batch_x, self.device)
+        x = x.unsqueeze(0).contiguous() if x.dim() == 3 else x
+        return DeviceArray(self.encode(x)[0])
+
+    def decompress(self, batch_z):
+        z = to_device(batch_z, self.device)
+        z = z.unsqueeze(0).contiguous() if z.dim() == 3 else z
+        return DeviceArray(self.decode(z)[0])
+
+    def process(self, batch_x, return_entropy=False):
+        y, ent, _ = self.forward(to_device(batch_x, self.device))
+        return (DeviceArray(y), DeviceArray(ent)) if return_entropy else DeviceArray(y)
+
+    def training_step(self, batch_x, learning_rate=None):
+        """One optimisation step on l2_loss(x - y) + entropy_weight * H (compression.py:123-138)."""
+        x = to_device(batch_x, self.device)
+        y, ent, ctx = self.forward(x, training=True)
+        l2, dy = ops.l2_loss(x, y, grad_scale=1.0)
+        self.backward(ctx, dy, entropy_coef=self._h.entropy_weight)
+        world = parallel.world_size()
+        if world > 1:
+            bucket = parallel.GradientBucket()
+            bucket.launch(self._model.flat_grad)
+            bucket.wait()
+        if learning_rate is not None:
+            self.learning_rate = learning_rate
+        self._model.adam(self.learning_rate)          # l2_loss is a SUM over the batch: summed gradients, no 1/world
+        loss = float(DeviceArray(l2)) + self._h.entropy_weight * float(DeviceArray(ent))
+        return {'loss': np.sqrt(2 * loss), 'ssim': np.nan, 'entropy': DeviceArray(ent)}
+
+    def compression_stats(self, patch_size=None, n_latent_bytes=None):
+        n_latent_bytes = n_latent_bytes or self._h.latent_bpf / 8
+        ps = patch_size or self.patch_size
+        if ps is None:
+            raise ValueError('Patch size not specified!')
+        n_latent = int(np.prod((ps // 8, ps // 8, self._h.n_features)))
+        bitmap_size = ps * ps * 3
+        return {'rate': bitmap_size / (n_latent_bytes * n_latent), 'bpp': 8 * n_latent * n_latent_bytes / (ps * ps),
+                'bpf': 8 * n_latent_bytes, 'bytes': n_latent * n_latent_bytes}
+
+    def summary(self):
+        l_shape = 'x'.join(str(x) for x in self.latent_shape if x is not None)
+        return '{} : {}-D latent space @ {}-bpf [{:,.0f} params]'.format(self.class_name, l_shape, self._h.latent_bpf,
+                                                                         self.count_parameters())
+
+    def summary_compact(self):
+        return '{} {}-D'.format(self.class_name, self.latent_shape[-1])
+
+    @property
+    def model_code(self):
+        return '{}-{}C'.format(type(self).__name__, self._h.n_features)
+
+
+class TwitterDCN(DCN):
+
+    def construct_model(self, n_features=32, activation='leaky_relu'):
+        self._h.add({'n_features': (32, int, (4, 128)), 'activation': ('leaky_relu', str, {'leaky_relu'})})
+        self._h.update(n_features=n_features, activation=activation)
+        nf = self._h.n_features
+        if self.patch_size is None:
+            self.latent_shape, self.n_latent = (None, None, nf), None
+        else:
+            self.latent_shape = (self.patch_size // 8, self.patch_size // 8, nf)
+            self.n_latent = int(np.prod(self.latent_shape))
+        L = OrderedDict()
+        L['e1'] = Conv2D('e1', 5, 3, 64, 'leaky_relu', stride=2)
+        L['e2'] = Conv2D('e2', 5, 64, 128, None, stride=2)
+        for b in (1, 2, 3):
+            L['er{}a'.format(b)] = Conv2D('er{}a'.format(b), 3, 128, 128, 'leaky_relu')
+            L['er{}b'.format(b)] = Conv2D('er{}b'.format(b), 3, 128, 128, None)
+        L['elat'] = Conv2D('elat', 5, 128, nf, None, stride=2)
+        L['d512'] = Conv2D('d512', 3, nf, 512, None)
+        for b in (1, 2, 3):
+            L['dr{}a'.format(b)] = Conv2D('dr{}a'.format(b), 3, 128, 128, 'leaky_relu')
+            L['dr{}b'.format(b)] = Conv2D('dr{}b'.format(b), 3, 128, 128, None)
+        L['d256'] = Conv2D('d256', 3, 128, 256, 'leaky_relu')
+        L['d12'] = Conv2D('d12', 3, 64, 12, None)
+        self._layers = L
+        specs = []
+        for name in ('e1', 'e2', 'er1a', 'er1b', 'er2a', 'er2b', 'er3a', 'er3b', 'elat'):
+            specs += L[name].specs()
+        specs += [('latent_scaling', ())]
+        for name in ('d512', 'dr1a', 'dr1b', 'dr2a', 'dr2b', 'dr3a', 'dr3b', 'd256', 'd12'):
+            specs += L[name].specs()
+        self._model = ParamStore(specs, self.device)
+        gen = torch.Generator().manual_seed(self._seed)
+        for l in L.values():
+            l.init(self._model, gen)
+        self._model.p['latent_scaling'].fill_(1.0)
+        ps = self.patch_size
+        self.y = _Shape((None, ps, ps, 3))
+
+    @property
+    def model_code(self):
+        s = [self._h.rounding, 'Q+{}bpf'.format(self._h.latent_bpf) if self._h.train_codebook else
+             'Q-{}bpf'.format(self._h.latent_bpf), 'S+' if self._h.scale_latent else 'S-']
+        if self._h.entropy_weight is not None:
+            s.append('H+{:.2f}'.format(self._h.entropy_weight))
+        return '{}/{}'.format(super().model_code, '_'.join(s))
+
+    # ------------------------------------------------------------------------------------------------------------
+    def encode(self, x, training=False):
+        L, P = self._layers, self._model
+        t = OrderedDict()
+        t['x0'] = ops.affine(x, 2.0, -1.0)
+        t['e1'] = L['e1'].forward(P, t['x0'])
+        t['e2'] = L['e2'].forward(P, t['e1'])
+        net = t['e2']
+        t['n0'] = net
+        for b in (1, 2, 3):
+            inp = ops.lrelu(net) if b == 1 else net
+            t['er{}in'.format(b)] = inp
+            a = L['er{}a'.format(b)].forward(P, inp)
+            t['er{}a'.format(b)] = a
+            r = L['er{}b'.format(b)].forward(P, a)
+            net = ops.add(net, r)
+            t['n{}'.format(b)] = net
+        t['zl'] = L['elat'].forward(P, net)
+        if self._lws is None or self._lws.buf.device != x.device:
+            self._lws = ops.LatentWorkspace(self._codebook.numel(), x.device)
+        world = parallel.world_size()
+        count = t['zl'].numel()
+        soft = self._h.rounding == 'soft-codebook'
+        lat, ent = ops.latent_fwd(t['zl'], P.p['latent_scaling'], self._codebook, self._lws, soft_codebook=soft,
+                                  count_global=count * world, finalize=(world == 1))
+        if world > 1:       # batch-global soft histogram: 2^bpf float64 sums are all-reduced (SURVEY 8e caveat 1)
+            torch.distributed.all_reduce(self._lws.hist_sums())
+            ops.latent_entropy_finalize(self._lws, count * world, ent)
+        t['latent'] = lat
+        return lat, ent, (t if training else None)
+
+    def decode(self, lat, training=False):
+        L, P = self._layers, self._model
+        t = OrderedDict()
+        t['latent'] = lat
+        t['d512'] = L['d512'].forward(P, lat)
+        net = ops.d2s_clip(t['d512'], 1.0, 0.0, False)
+        t['i0'] = net
+        for b in (1, 2, 3):
+            a = L['dr{}a'.format(b)].forward(P, net)
+            t['dr{}a'.format(b)] = a
+            r = L['dr{}b'.format(b)].forward(P, a)
+            net = ops.add(net, r)
+            t['i{}'.format(b)] = net
+        t['d256'] = L['d256'].forward(P, net)
+        t['i4'] = ops.d2s_clip(t['d256'], 1.0, 0.0, False)
+        t['d12'] = L['d12'].forward(P, t['i4'])
+        y = ops.d2s_clip(t['d12'], 0.5, 0.5, True)               # (x + 1) / 2 then straight-through clip
+        return y, (t if training else None)
+
+    def forward(self, x, training=False):
+        lat, ent, et = self.encode(x, training)
+        y, dt = self.decode(lat, training)
+        return y, ent, ((et, dt) if training else None)
+
+    def backward(self, ctx, dy, entropy_coef=0.0, need_input_grad=False):
+        """dy = d loss / d y; entropy_coef = d loss / d entropy.  Fills the gradient buffer."""
+        et, dt = ctx
+        L, P = self._layers, self._model
+        hw = lambda a: (a.shape[1], a.shape[2])
+        # ---- decoder
+        dz = ops.d2s_clip_bwd(dy, 0.5)
+        L['d12'].backward_params(P, dt['i4'], dz)
+        d_i4 = L['d12'].backward_input(P, dz, hw(dt['i4']))
+        dz = ops.lrelu_bwd(ops.d2s_clip_bwd(d_i4, 1.0), dt['d256'])
+        L['d256'].backward_params(P, dt['i3'], dz)
+        d_net = L['d256'].backward_input(P, dz, hw(dt['i3']))
+        for b in (3, 2, 1):
+            a, inp = dt['dr{}a'.format(b)], dt['i{}'.format(b - 1)]
+            L['dr{}b'.format(b)].backward_params(P, a, d_net)
+            dza = L['dr{}b'.format(b)].backward_input(P, d_net, hw(a), act_mask=a)
+            L['dr{}a'.format(b)].backward_params(P, inp, dza)
+            d_net = ops.add(d_net, L['dr{}a'.format(b)].backward_input(P, dza, hw(inp)))
+        dz = ops.d2s_clip_bwd(d_net, 1.0)
+        L['d512'].backward_params(P, dt['latent'], dz)
+        d_lat = L['d512'].backward_input(P, dz, hw(dt['latent']))
+        # ---- latent
+        soft = self._h.rounding == 'soft-codebook'
+        dzl = ops.latent_bwd(et['zl'], P.p['latent_scaling'], et['latent'], d_lat, entropy_coef, self._codebook,
+                             self._lws, dscale=P.g['latent_scaling'].view(1), soft_codebook=soft)
+        # ---- encoder
+        L['elat'].backward_params(P, et['n3'], dzl)
+        d_net = L['elat'].backward_input(P, dzl, hw(et['n3']))
+        for b in (3, 2, 1):
+            a, inp = et['er{}a'.format(b)], et['er{}in'.format(b)]
+            L['er{}b'.format(b)].backward_params(P, a, d_net)
+            dza = L['er{}b'.format(b)].backward_input(P, d_net, hw(a), act_mask=a)
+            L['er{}a'.format(b)].backward_params(P, inp, dza)
+            # block 1 was fed LeakyReLU(e2): its input gradient goes through that activation (mask by sign of e2)
+            d_in = L['er{}a'.format(b)].backward_input(P, dza, hw(inp), act_mask=et['e2'] if b == 1 else None)
+            d_net = ops.add(d_net, d_in)
+        L['e2'].backward_params(P, et['e1'], d_net)
+        dz1 = L['e2'].backward_input(P, d_net, hw(et['e1']), act_mask=et['e1'])
+        L['e1'].backward_params(P, et['x0'], dz1)
+        if need_input_grad:
+            return ops.affine(L['e1'].backward_input(P, dz1, hw(et['x0'])), 2.0, 0.0)
+        return None

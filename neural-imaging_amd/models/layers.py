@@ -43,6 +43,9 @@ class Conv2D(object):
                          db=store.g[self.name + '/bias'])
 
     def backward_input(self, store, dz, in_hw, act_mask=None, out=None, out2=None):
+        if self.stride == 2:
+            d = ops.conv2d_dgrad_strided2(dz, store.p[self.name + '/kernel'], in_hw)
+            return d if act_mask is None else ops.lrelu_bwd(d, act_mask, out=d)
         return ops.conv2d_dgrad(dz, store.p[self.name + '/kernel'], in_hw, stride=self.stride, act_mask=act_mask,
                                 out=out, out2=out2)
 

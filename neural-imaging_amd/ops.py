@@ -433,3 +433,88 @@ def sparse_axis_apply(x, csr, axis, out_size, out=None):
     _lib.call('nimg_sparse_axis_apply', _p(x), _p(y), _p(rowptr), _p(col), _p(val), n, h, w, c, axis, out_size,
               _stream())
     return y
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# learned codec pieces
+def affine(x, a, b, out=None):
+    _f32(x, out)
+    y = torch.empty_like(x) if out is None else out
+    _lib.call('nimg_affine', _p(x), _p(y), x.numel(), float(a), float(b), _stream())
+    return y
+
+
+def lrelu(x):
+    _f32(x)
+    y = torch.empty_like(x)
+    _lib.call('nimg_lrelu_fwd', _p(x), _p(y), x.numel(), LRELU_ALPHA, _stream())
+    return y
+
+
+def zero_insert2(x):
+    _f32(x)
+    n, h, w, c = x.shape
+    y = torch.empty((n, 2 * h, 2 * w, c), dtype=torch.float32, device=x.device)
+    _lib.call('nimg_zero_insert2', _p(x), _p(y), n, h, w, c, _stream())
+    return y
+
+
+def conv2d_dgrad_strided2(dz, w, in_hw):
+    """Input gradient of a stride-2 TF-SAME convolution: zero insertion + stride-1 correlation with the flipped
+    kernel (pad = ks-1-pad_before)."""
+    ks = w.shape[0]
+    h, wd = in_hw
+    _, pt = same_pads(h, ks, 2)
+    _, pl = same_pads(wd, ks, 2)
+    up = zero_insert2(dz)
+    if up.shape[1] != h or up.shape[2] != wd:
+        raise NotImplementedError('strided dgrad is built for even input sizes')
+    return conv2d(up, flip_weights(w), None, pads=(ks - 1 - pt, ks - 1 - pl), out_hw=(h, wd))
+
+
+class LatentWorkspace(object):
+    """float64 scratch of the DiscreteLatent kernels; must survive from forward to backward."""
+
+    def __init__(self, k, device):
+        self.k = k
+        self.buf = torch.empty(int(_lib.load().nimg_latent_workspace_bytes(k)), dtype=torch.uint8, device=device)
+
+    def hist_sums(self):
+        """view of the K float64 histogram sums (the unit to all-reduce under data parallelism)"""
+        return self.buf.view(torch.float64)[1024 * self.k:1024 * self.k + self.k]
+
+
+def latent_fwd(z, scale, codebook, ws, v=50.0, gamma=25.0, soft_codebook=True, count_global=0, finalize=True):
+    _f32(z, scale, codebook)
+    latent = torch.empty_like(z)
+    entropy = torch.empty((1,), dtype=torch.float32, device=z.device)
+    _lib.call('nimg_latent_fwd', _p(z), _p(scale), _p(codebook), codebook.numel(), float(v), float(gamma),
+              1 if soft_codebook else 0, _p(latent), _p(entropy), z.numel(), int(count_global), _p(ws.buf),
+              ws.buf.numel(), 1 if finalize else 0, _stream())
+    return latent, entropy
+
+
+def latent_entropy_finalize(ws, count_global, entropy):
+    _lib.call('nimg_latent_entropy_finalize', ws.k, int(count_global), _p(entropy), _p(ws.buf), _stream())
+
+
+def latent_bwd(z, scale, latent, dlatent, entropy_coef, codebook, ws, dscale=None, v=50.0, gamma=25.0,
+               soft_codebook=True, accumulate_dscale=False):
+    _f32(z, scale, latent, dlatent, codebook, dscale)
+    dz = torch.empty_like(z)
+    _lib.call('nimg_latent_bwd', _p(z), _p(scale), _p(latent), _p(dlatent), float(entropy_coef), _p(codebook),
+              codebook.numel(), float(v), float(gamma), 1 if soft_codebook else 0, _p(dz), _p(dscale),
+              1 if accumulate_dscale else 0, z.numel(), _p(ws.buf), ws.buf.numel(), _stream())
+    return dz
+
+
+def l2_loss(target, y, grad_scale=None, grad_out=None, accumulate=False):
+    _f32(target, y, grad_out)
+    loss = torch.empty((1,), dtype=torch.float32, device=y.device)
+    g = None
+    if grad_scale is not None:
+        g = torch.empty_like(y) if grad_out is None else grad_out
+    ws = _ws.get(_lib.load().nimg_l2_loss_workspace_bytes(), y.device)
+    _lib.call('nimg_l2_loss', _p(target), _p(y), _p(loss), _p(g), y.numel(), float(grad_scale or 0.0),
+              1 if accumulate else 0, _p(ws), ws.numel(), _stream())
+    return loss, g

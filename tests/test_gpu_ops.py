@@ -347,3 +347,53 @@ def test_manipulations_fwd_bwd(dev, name):
     assert_close(y.cpu().numpy(), ref.detach().numpy(), ATOL, what=name + ' fwd')
     dx = op.backward(ctx, g(dy, dev))
     assert_close(dx.cpu().numpy(), x.grad.numpy(), 2e-4, 3e-4, what=name + ' bwd')
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# learned-codec pieces
+def test_latent_soft_codebook_and_entropy(dev):
+    """DiscreteLatent (models/layers.py:183-203): latent values, batch-global entropy and their gradients."""
+    from neural_imaging_amd import ops
+    cb = ot.codebook(5)
+    z_np = (rnd((2, 4, 4, 32), 1) * 6).astype(np.float32)
+    z = to64(z_np).requires_grad_(True)
+    s = torch.tensor(1.3, dtype=torch.float64, requires_grad=True)
+    lat = T.soft_codebook(z.to(torch.float32).to(torch.float64) * s, to64(cb))
+    ent, _ = T.entropy(lat, to64(cb))
+    dl = rnd(z_np.shape, 2)
+    loss = (lat * to64(dl)).sum() + 250.0 * ent
+    loss.backward()
+    ws = ops.LatentWorkspace(32, dev)
+    sc = torch.tensor([1.3], dtype=torch.float32, device=dev)
+    lg, eg = ops.latent_fwd(g(z_np, dev), sc, g(cb, dev), ws)
+    assert np.array_equal(np.round(lg.cpu().numpy()), np.round(lat.detach().numpy())), 'hard codebook indices differ'
+    assert_close(lg.cpu().numpy(), lat.detach().numpy(), 1e-5, what='latent')
+    assert abs(float(eg.item()) - float(ent)) < 1e-5
+    dscale = torch.zeros(1, device=dev)
+    dz = ops.latent_bwd(g(z_np, dev), sc, lg, g(dl, dev), 250.0, g(cb, dev), ws, dscale=dscale)
+    assert_close(dz.cpu().numpy(), z.grad.numpy(), 1e-6, 2e-4, what='latent dz')
+    assert abs(float(dscale.item()) - float(s.grad)) / (abs(float(s.grad)) + 1e-9) < 2e-4
+    # entropy KATs on the device: constant latent -> ~0 bits, uniform over the 32 centres -> ~5 bits
+    one = torch.ones(1, device=dev)
+    _, e0 = ops.latent_fwd(torch.zeros(4096, device=dev), one, g(cb, dev), ws)
+    _, e5 = ops.latent_fwd(g(np.tile(cb, 128), dev), one, g(cb, dev), ws)
+    assert float(e0.item()) < 1e-4 and abs(float(e5.item()) - 5.0) < 1e-3
+
+
+def test_strided_dgrad_and_codec_small_ops(dev):
+    from neural_imaging_amd import ops
+    n, h, w, cin, cout, ks = 2, 16, 24, 8, 16, 5
+    x = to64(rnd((n, h, w, cin), 1)).requires_grad_(True)
+    wt = to64(rnd((ks, ks, cin, cout), 2, -0.2, 0.2))
+    zc = T.conv2d(x, wt, None, 2, 'SAME')
+    dz = rnd(tuple(zc.shape), 3)
+    (zc * to64(dz)).sum().backward()
+    dx = ops.conv2d_dgrad_strided2(g(dz, dev), g(wt.numpy(), dev), (h, w))
+    assert_close(dx.cpu().numpy(), x.grad.numpy(), 1e-5, GRTOL, what='stride-2 dgrad (zero insertion)')
+    a = rnd((1000,), 4)
+    assert np.allclose(ops.affine(g(a, dev), 2.0, -1.0).cpu().numpy(), 2 * a - 1)
+    assert np.allclose(ops.lrelu(g(a, dev)).cpu().numpy(), np.where(a > 0, a, 0.2 * a))
+    t, y = rnd((2, 8, 8, 3), 5, 0, 1), rnd((2, 8, 8, 3), 6, 0, 1)
+    lo, gr = ops.l2_loss(g(t, dev), g(y, dev), grad_scale=1.0)
+    assert abs(float(lo.item()) - 0.5 * float(((t - y) ** 2).sum())) < 1e-4
+    assert np.allclose(gr.cpu().numpy(), y - t, atol=1e-7)
