@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 F32_MFMA_PEAK_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # same guide: bf16 MFMA dense (the 5 PF headline includes 2:1 sparsity)
 GMAC_FWD_PER_PATCH = 3.079 + 5 * 2.705          # UNet + 5 x FAN, forward
 GFLOP_PER_PATCH = 2 * 3 * GMAC_FWD_PER_PATCH    # fwd + dgrad + wgrad
 
@@ -59,7 +60,9 @@ def time_dominant_kernel(dev, b_images, reps=5):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     flops = 2.0 * 25 * 64 * 128 * 64 * 64 * n
-    return {'kernel': 'conv_fwd_kernel<5,1,16,16,1,64,8> (FAN conv3 fwd, {}x64x64x64->128)'.format(n),
+    from neural_imaging_amd import ops as _o
+    kname = 'conv_fwd_kernel<5,1,16,16,1,64,8>' if _o.COMPUTE == 'f32' else 'conv_fwd_bf16_kernel<5,1,16,16,1,64>'
+    return {'kernel': kname + ' (FAN conv3 fwd, {}x64x64x64->128)'.format(n),
             'flops_per_launch': flops, 'ms_per_launch': ms, 'tflops': flops / (ms * 1e-3) / 1e12}
 
 
@@ -116,6 +119,8 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='raw patches per GPU per step (SURVEY 8d C4: 64)')
     ap.add_argument('--raw-patch', type=int, default=128)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
+                    help='arithmetic type of the convolution GEMMs (f32 = parity mode; bf16 = MFMA throughput mode)')
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--cpu-budget', type=float, default=15.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -135,6 +140,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     _lib.load()
+    from neural_imaging_amd import ops as _ops
+    _ops.set_compute(args.dtype)
     if world != args.gpus and rank == 0:
         print('warning: --gpus {} but WORLD_SIZE {}'.format(args.gpus, world), file=sys.stderr)
 
@@ -168,18 +175,19 @@ def main():
         ms = 1e3 * dt / args.steps
         value = world * args.batch * args.steps / dt
         dom = time_dominant_kernel(dev, 5 * args.batch)
+        peak = F32_MFMA_PEAK_TFLOPS if args.dtype == 'f32' else BF16_MFMA_PEAK_TFLOPS
         line = {
             'metric': 'patches/s (fwd+bwd) ISP->JPEG->FAN @256^2', 'value': value, 'unit': 'patches/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
             'data': 'synthetic (natural-image-like RAW/RGB pairs, random-init weights)',
             'config': {'workload': 'train_manipulation UNet->[native,sharpen:1,resample:50,gaussian:0.83,jpeg:80]->'
                                    'dJPEG(QF80,soft)->FAN, ds none, trainable nip+fan, lambda_nip 0.1',
                        'raw_patch': args.raw_patch, 'rgb_patch': 2 * args.raw_patch,
                        'batch_per_gpu': args.batch, 'global_batch': world * args.batch, 'parallelism': 'dp%d' % world,
                        'loss': float(loss), 'achieved_tflops_whole_step': value * GFLOP_PER_PATCH / 1e3},
-            'roofline': {'bound': 'mfma', 'achieved': dom['tflops'], 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': dom['tflops'] / F32_MFMA_PEAK_TFLOPS, 'traffic': None, 'kernel': dom['kernel'],
+            'roofline': {'bound': 'mfma', 'achieved': dom['tflops'], 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': dom['tflops'] / peak, 'traffic': None, 'kernel': dom['kernel'],
                          'ms_per_launch': dom['ms_per_launch']},
         }
         if not args.no_cpu_baseline and world == 1:

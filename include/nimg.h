@@ -186,6 +186,24 @@ size_t nimg_l2_loss_workspace_bytes(void);
 int nimg_l2_loss(const float* target, const float* y, float* loss, float* grad_y, long count, float grad_scale,
                  int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Throughput mode of the convolutions: bf16 operands on the matrix cores (v_mfma_f32_32x32x16_bf16), float32
+ * accumulation, float32 tensors in HBM.  Same semantics / arguments as nimg_conv2d_fwd / nimg_conv2d_wgrad; channel
+ * counts must be multiples of 8 (forward) / 4 (weight gradient).  Judged on PSNR / accuracy parity (BASELINE.json),
+ * not on the 1e-4 contract.  Weights are laid out once per step by nimg_conv_weights_bf16:
+ *   mode 0 (forward)        wb[tap][co][ci_pad16]        = w[tap][ci][co]
+ *   mode 1 (input gradient) wb[taps-1-tap][ci][co_pad16] = w[tap][ci][co]   (then call with cin/cout swapped) */
+size_t nimg_conv_weights_bf16_bytes(int ks_h, int ks_w, int cin, int cout, int mode);
+int nimg_conv_weights_bf16(const float* w, void* wb, int ks_h, int ks_w, int cin, int cout, int mode, void* stream);
+int nimg_conv2d_fwd_bf16(const float* in1, int c1, const float* in2, int c2, const void* wb, const float* bias,
+                         float* out1, int o1, float* out2, int o2, const float* act_mask, int n, int h, int wd,
+                         int ks, int stride, int pad_t, int pad_l, int pad_mode, int hout, int wout, int act,
+                         float alpha, void* stream);
+size_t nimg_conv2d_wgrad_bf16_workspace_bytes(int cin, int cout, int ks_h, int ks_w, int n, int hout, int wout);
+int nimg_conv2d_wgrad_bf16(const float* in1, int c1, const float* in2, int c2, const float* dz, int cout, float* dw,
+                           float* db, int n, int h, int wd, int ks, int stride, int pad_t, int pad_l, int pad_mode,
+                           int hout, int wout, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,6 +59,13 @@ PROTOTYPES = {
                                 c_size_t, P]),
     'nimg_l2_loss_workspace_bytes': (c_size_t, []),
     'nimg_l2_loss': (c_int, [P, P, P, P, c_long, c_float, c_int, P, c_size_t, P]),
+    'nimg_conv_weights_bf16_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    'nimg_conv_weights_bf16': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'nimg_conv2d_fwd_bf16': (c_int, [P, c_int, P, c_int, P, P, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int,
+                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P]),
+    'nimg_conv2d_wgrad_bf16_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    'nimg_conv2d_wgrad_bf16': (c_int, [P, c_int, P, c_int, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
+                                       c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'nimg_sparse_axis_apply': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
 }
 

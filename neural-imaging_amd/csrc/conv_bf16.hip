@@ -1,0 +1,436 @@
+// Throughput mode of the convolutions: bf16 operands on the CDNA4 matrix cores (v_mfma_f32_32x32x16_bf16, 16x the f32
+// MFMA rate), float32 accumulation, float32 master weights and float32 activations in HBM (converted to bf16 while the
+// tiles are staged into LDS).  Same im2col-free implicit GEMM as conv_mfma.hip / conv_wgrad.hip; judged on PSNR /
+// accuracy parity, not on the 1e-4 contract (that is the f32 mode).
+//
+//   forward / input gradient: A tile [pixel][16 ci] bf16 (32 B per pixel, one ds_read_b128 per fragment, 1-bit XOR
+//       swizzle of the two 16-byte halves => conflict-free), B tile [tap][co][16 ci] bf16 read the same way from weights
+//       that nimg_conv_weights_bf16 lays out once per step as [tap][co][ci_pad].
+//   weight gradient: K = 16 output pixels per MFMA; the f32 NHWC tiles of conv_wgrad.hip are kept and each lane gathers
+//       its 8 pixels with ds_read_b32 (conflict-free) and packs them to bf16 in registers (v_cvt_pk_bf16_f32).
+#include "common.h"
+
+namespace {
+
+using namespace nimg;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8 pack8(const float (&f)[8]) {
+    bf16x8 r;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = (__bf16)f[k];
+    return r;
+}
+
+// wb[tap'][co][ci_pad] (mode 0, forward) = w[tap][ci][co];  mode 1 (input gradient): roles of ci/co swap and the taps
+// are flipped: wb[taps-1-tap][ci][co_pad] = w[tap][ci][co].  Padding columns are zero.
+__global__ void weights_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wb, int taps, int cin, int cout,
+                                    int mode) {
+    const int rows = mode == 0 ? cout : cin, cols = mode == 0 ? cin : cout;
+    const int cpad = (cols + 15) / 16 * 16;
+    const long total = (long)taps * rows * cpad;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cpad), r = (int)((i / cpad) % rows), t = (int)(i / ((long)cpad * rows));
+        float v = 0.f;
+        if (c < cols) v = mode == 0 ? w[((long)t * cin + c) * cout + r] : w[((long)(taps - 1 - t) * cin + r) * cout + c];
+        wb[i] = (__bf16)v;
+    }
+}
+
+struct ConvParamsB {
+    const float* in1;
+    const float* in2;
+    const __bf16* wb;     // [KS*KS][Cout][CinP]
+    const float* bias;
+    float* out1;
+    float* out2;
+    const float* act1;
+    int C1, C2, O1, O2, CinP;
+    int N, H, W, Hout, Wout, pad_t, pad_l;
+    int tiles_y, tiles_x, act, pad_mode;
+    float alpha;
+};
+
+template <int KS, int STRIDE, int TH, int TW, int NB, int TN>
+__global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p) {
+    constexpr int CK = 16;
+    constexpr int THH = (TH - 1) * STRIDE + KS, TWH = (TW - 1) * STRIDE + KS;
+    constexpr int NPIXH = NB * THH * TWH;
+    constexpr int MFRAGS = NB * TH * TW / 32, NFRAGS = TN / 32;
+    constexpr int WAVES_M = MFRAGS >= 4 ? 4 : MFRAGS, WAVES_N = 4 / WAVES_M;
+    constexpr int MI = MFRAGS / WAVES_M, NI = NFRAGS / WAVES_N;
+    constexpr int TAPS = KS * KS;
+    static_assert(NI >= 1 && MFRAGS % WAVES_M == 0, "bad tile configuration");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint4* sA = reinterpret_cast<uint4*>(smem_raw);                       // [NPIXH][2] 16-byte halves
+    uint4* sB = sA + NPIXH * 2;                                           // [TAPS*TN][2]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+    const int Cin = p.C1 + p.C2, Cout = p.O1 + p.O2;
+    const int cot = (Cout + TN - 1) / TN;
+    int bid = blockIdx.x;
+    const int co0 = (bid % cot) * TN;
+    bid /= cot;
+    const int tiles = p.tiles_y * p.tiles_x;
+    const int tile = bid % tiles, grp = bid / tiles;
+    const int ty0 = (tile / p.tiles_x) * TH, tx0 = (tile % p.tiles_x) * TW;
+    const int iy0 = ty0 * STRIDE - p.pad_t, ix0 = tx0 * STRIDE - p.pad_l;
+    const int half = lane >> 5;
+
+    int abase[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int P = (wm * MI + mi) * 32 + (lane & 31);
+        const int img = P / (TH * TW), rem = P % (TH * TW);
+        abase[mi] = img * (THH * TWH) + (rem / TW) * STRIDE * TWH + (rem % TW) * STRIDE;
+    }
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[mi][ni][j] = 0.0f;
+
+    for (int ci0 = 0; ci0 < Cin; ci0 += CK) {
+        __syncthreads();
+        // ---- A: f32 NHWC -> bf16 [pixel][16 ci], 8 channels (two float4) per item
+        for (int item = tid; item < NPIXH * 2; item += 256) {
+            const int pix = item >> 1, h8 = item & 1, c = ci0 + h8 * 8;
+            const int img = pix / (THH * TWH), rem = pix % (THH * TWH);
+            int gy = iy0 + rem / TWH, gx = ix0 + rem % TWH;
+            const int n = grp * NB + img;
+            float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (n < p.N && c < Cin && map_coord(gy, p.H, p.pad_mode) && map_coord(gx, p.W, p.pad_mode)) {
+                const long pixoff = ((long)n * p.H + gy) * p.W + gx;
+                const float* src = c < p.C1 ? p.in1 + pixoff * p.C1 + c : p.in2 + pixoff * p.C2 + (c - p.C1);
+                const float4 v0 = *reinterpret_cast<const float4*>(src);
+                const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
+                f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = v0.w; f[4] = v1.x; f[5] = v1.y; f[6] = v1.z; f[7] = v1.w;
+            }
+            const bf16x8 b = pack8(f);
+            sA[pix * 2 + (h8 ^ ((pix >> 3) & 1))] = *reinterpret_cast<const uint4*>(&b);
+        }
+        // ---- B: bf16 weights [tap][co][ci_pad] -> [tap][co_local][16 ci]
+        for (int item = tid; item < TAPS * TN * 2; item += 256) {
+            const int h8 = item & 1, row = item >> 1, j = row % TN, tap = row / TN;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (co0 + j < Cout)
+                v = *reinterpret_cast<const uint4*>(p.wb + ((long)tap * Cout + co0 + j) * p.CinP + ci0 + h8 * 8);
+            sB[row * 2 + (h8 ^ ((row >> 3) & 1))] = v;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int toff = (tap / KS) * TWH + (tap % KS);
+            bf16x8 a[MI], b[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int pix = abase[mi] + toff;
+                const uint4 v = sA[pix * 2 + (half ^ ((pix >> 3) & 1))];
+                a[mi] = *reinterpret_cast<const bf16x8*>(&v);
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int row = tap * TN + (wn * NI + ni) * 32 + (lane & 31);
+                const uint4 v = sB[row * 2 + (half ^ ((row >> 3) & 1))];
+                b[ni] = *reinterpret_cast<const bf16x8*>(&v);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int co = co0 + (wn * NI + ni) * 32 + (lane & 31);
+        if (co >= Cout) continue;
+        const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int row = (j & 3) + 8 * (j >> 2) + 4 * half;
+                const int P = (wm * MI + mi) * 32 + row;
+                const int img = P / (TH * TW), rem = P % (TH * TW);
+                const int oy = ty0 + rem / TW, ox = tx0 + rem % TW, n = grp * NB + img;
+                if (n >= p.N || oy >= p.Hout || ox >= p.Wout) continue;
+                const long pixoff = ((long)n * p.Hout + oy) * p.Wout + ox;
+                float v = acc[mi][ni][j] + bv;
+                if (p.act == 1) v = lrelu(v, p.alpha);
+                if (co < p.O1) {
+                    if (p.act1) v *= (p.act1[pixoff * p.O1 + co] > 0.f ? 1.0f : p.alpha);
+                    p.out1[pixoff * p.O1 + co] = v;
+                } else {
+                    p.out2[pixoff * p.O2 + (co - p.O1)] = v;
+                }
+            }
+    }
+}
+
+template <int KS, int STRIDE, int TH, int TW, int NB, int TN>
+int launch_conv_b(const ConvParamsB& p, hipStream_t stream) {
+    constexpr int THH = (TH - 1) * STRIDE + KS, TWH = (TW - 1) * STRIDE + KS;
+    constexpr size_t lds = (size_t)(NB * THH * TWH + KS * KS * TN) * 2 * sizeof(uint4);
+    ConvParamsB q = p;
+    q.tiles_y = cdiv(p.Hout, TH);
+    q.tiles_x = cdiv(p.Wout, TW);
+    const long blocks = (long)cdiv(p.O1 + p.O2, TN) * q.tiles_y * q.tiles_x * cdiv(p.N, NB);
+    auto kern = conv_fwd_bf16_kernel<KS, STRIDE, TH, TW, NB, TN>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, q);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+template <int KS, int STRIDE>
+int dispatch_b(const ConvParamsB& p, hipStream_t s) {
+    const int Cout = p.O1 + p.O2;
+    const bool small = (p.Hout <= 8 && p.Wout <= 8);
+    const long blocks64 = (long)cdiv(Cout, 64) * cdiv(p.Hout, small ? 8 : 16) * cdiv(p.Wout, small ? 8 : 16) *
+                          cdiv(p.N, small ? 4 : 1);
+    const bool tn32 = (Cout <= 32) || (blocks64 < 512 && Cout % 64 != 0) || (blocks64 < 384);
+    if (small) return tn32 ? launch_conv_b<KS, STRIDE, 8, 8, 4, 32>(p, s) : launch_conv_b<KS, STRIDE, 8, 8, 4, 64>(p, s);
+    return tn32 ? launch_conv_b<KS, STRIDE, 16, 16, 1, 32>(p, s) : launch_conv_b<KS, STRIDE, 16, 16, 1, 64>(p, s);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+struct WgradParamsB {
+    const float* in1;
+    const float* in2;
+    const float* dz;
+    float* partial;
+    float* db_partial;
+    int C1, C2, Cout;
+    int N, H, W, Hout, Wout, pad_t, pad_l;
+    int tiles_y, tiles_x, splits, work_per_split, pad_mode;
+};
+
+constexpr int B_TH = 8, B_TW = 16, B_CI = 32, B_CO = 64;
+
+template <int KS, int STRIDE>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParamsB p) {
+    constexpr int TAPS = KS * KS, NT = (TAPS + 3) / 4;
+    constexpr int THH = (B_TH - 1) * STRIDE + KS, TWH = (B_TW - 1) * STRIDE + KS;
+    constexpr int NPIXH = THH * TWH, NPIX = B_TH * B_TW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sI = smem;                  // [NPIXH][B_CI] f32
+    float* sZ = smem + NPIXH * B_CI;   // [NPIX][B_CO] f32
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Cin = p.C1 + p.C2;
+    const int cib = (Cin + B_CI - 1) / B_CI, cob = (p.Cout + B_CO - 1) / B_CO;
+    int bid = blockIdx.x;
+    const int ci0 = (bid % cib) * B_CI;
+    bid /= cib;
+    const int co0 = (bid % cob) * B_CO;
+    const int split = bid / cob;
+    const int half = lane >> 5;
+
+    f32x16 acc[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[t][ni][j] = 0.0f;
+    const int tiles = p.tiles_y * p.tiles_x;
+    const long work_total = (long)p.N * tiles;
+    const long w_begin = (long)split * p.work_per_split;
+    const long w_end = min(work_total, w_begin + p.work_per_split);
+    const bool do_bias = p.db_partial && ci0 == 0;
+    float bsum = 0.f;
+    for (long wk = w_begin; wk < w_end; ++wk) {
+        const int n = (int)(wk / tiles), tile = (int)(wk % tiles);
+        const int ty0 = (tile / p.tiles_x) * B_TH, tx0 = (tile % p.tiles_x) * B_TW;
+        const int iy0 = ty0 * STRIDE - p.pad_t, ix0 = tx0 * STRIDE - p.pad_l;
+        __syncthreads();
+        for (int item = tid; item < NPIXH * (B_CI / 4); item += 256) {
+            const int pix = item / (B_CI / 4), c = ci0 + (item % (B_CI / 4)) * 4;
+            int gy = iy0 + pix / TWH, gx = ix0 + pix % TWH;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < Cin && map_coord(gy, p.H, p.pad_mode) && map_coord(gx, p.W, p.pad_mode)) {
+                const long pixoff = ((long)n * p.H + gy) * p.W + gx;
+                v = c < p.C1 ? *reinterpret_cast<const float4*>(p.in1 + pixoff * p.C1 + c)
+                             : *reinterpret_cast<const float4*>(p.in2 + pixoff * p.C2 + (c - p.C1));
+            }
+            *reinterpret_cast<float4*>(sI + pix * B_CI + (item % (B_CI / 4)) * 4) = v;
+        }
+        for (int item = tid; item < NPIX * (B_CO / 4); item += 256) {
+            const int pix = item / (B_CO / 4), c = co0 + (item % (B_CO / 4)) * 4;
+            const int oy = ty0 + pix / B_TW, ox = tx0 + pix % B_TW;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (oy < p.Hout && ox < p.Wout && c < p.Cout)
+                v = *reinterpret_cast<const float4*>(p.dz + (((long)n * p.Hout + oy) * p.Wout + ox) * p.Cout + c);
+            *reinterpret_cast<float4*>(sZ + pix * B_CO + (item % (B_CO / 4)) * 4) = v;
+        }
+        __syncthreads();
+        if (do_bias && tid < B_CO) {
+#pragma unroll 8
+            for (int px = 0; px < NPIX; ++px) bsum += sZ[px * B_CO + tid];
+        }
+        // one MFMA k-step = one tile row of 16 output pixels; lane half h covers pixels h*8 .. h*8+7 of the row
+        const float* zL = sZ + (half * 8) * B_CO + (lane & 31);
+        const float* iL = sI + (half * 8) * STRIDE * B_CI + (lane & 31);
+#pragma unroll 1
+        for (int r = 0; r < B_TH; ++r) {
+            float f[8];
+            bf16x8 b0, b1;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] = zL[(r * B_TW + k) * B_CO];
+            b0 = pack8(f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] = zL[(r * B_TW + k) * B_CO + 32];
+            b1 = pack8(f);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int tap = wave + 4 * t;
+                if (tap < TAPS) {
+                    const float* src = iL + ((r * STRIDE + tap / KS) * TWH + (tap % KS)) * B_CI;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) f[k] = src[k * STRIDE * B_CI];
+                    const bf16x8 a = pack8(f);
+                    acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[t][0], 0, 0, 0);
+                    acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[t][1], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (do_bias && tid < B_CO && co0 + tid < p.Cout) p.db_partial[(long)split * p.Cout + co0 + tid] = bsum;
+    float* slab = p.partial + (long)split * TAPS * Cin * p.Cout;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tap = wave + 4 * t;
+        if (tap >= TAPS) continue;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int co = co0 + ni * 32 + (lane & 31);
+            if (co >= p.Cout) continue;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int ci = ci0 + (j & 3) + 8 * (j >> 2) + 4 * half;
+                if (ci < Cin) slab[((long)tap * Cin + ci) * p.Cout + co] = acc[t][ni][j];
+            }
+        }
+    }
+}
+
+__global__ void reduce_slabs_kernel(const float* __restrict__ partial, float* __restrict__ dw, long count, int splits,
+                                    int accumulate) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += partial[(long)k * count + i];
+        dw[i] = accumulate ? dw[i] + s : s;
+    }
+}
+
+int splits_for(int cin, int cout, int n, int hout, int wout) {
+    const long blocks_io = (long)cdiv(cin, B_CI) * cdiv(cout, B_CO);
+    const long work = (long)n * cdiv(hout, B_TH) * cdiv(wout, B_TW);
+    long splits = (1024 + blocks_io - 1) / blocks_io;
+    if (splits > work) splits = work;
+    if (splits < 1) splits = 1;
+    const long wps = (work + splits - 1) / splits;
+    return (int)((work + wps - 1) / wps);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t nimg_conv_weights_bf16_bytes(int ks_h, int ks_w, int cin, int cout, int mode) {
+    const long rows = mode == 0 ? cout : cin, cols = mode == 0 ? cin : cout;
+    return (size_t)ks_h * ks_w * rows * ((cols + 15) / 16 * 16) * 2;
+}
+
+int nimg_conv_weights_bf16(const float* w, void* wb, int ks_h, int ks_w, int cin, int cout, int mode, void* stream) {
+    if (!w || !wb || ks_h <= 0 || ks_w <= 0 || cin <= 0 || cout <= 0 || mode < 0 || mode > 1) return NIMG_ERR_ARG;
+    const long total = (long)nimg_conv_weights_bf16_bytes(ks_h, ks_w, cin, cout, mode) / 2;
+    const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    hipLaunchKernelGGL(weights_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)wb,
+                       ks_h * ks_w, cin, cout, mode);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_conv2d_fwd_bf16(const float* in1, int c1, const float* in2, int c2, const void* wb, const float* bias,
+                         float* out1, int o1, float* out2, int o2, const float* act_mask, int n, int h, int wd,
+                         int ks, int stride, int pad_t, int pad_l, int pad_mode, int hout, int wout, int act,
+                         float alpha, void* stream) {
+    if (!in1 || !wb || !out1 || c1 <= 0 || c2 < 0 || o1 <= 0 || o2 < 0 || n < 0 || h <= 0 || wd <= 0) return NIMG_ERR_ARG;
+    if ((c2 > 0 && !in2) || (o2 > 0 && !out2) || hout <= 0 || wout <= 0 || pad_t < 0 || pad_l < 0) return NIMG_ERR_ARG;
+    if (act < 0 || act > 1 || pad_mode < 0 || pad_mode > 2) return NIMG_ERR_ARG;
+    if ((c1 % 8) || (c2 % 8)) return NIMG_ERR_ARG;      // 8-channel (two float4) staging granules
+    if (n == 0) return NIMG_OK;
+    ConvParamsB p;
+    p.in1 = in1; p.in2 = in2; p.wb = (const __bf16*)wb; p.bias = bias; p.out1 = out1; p.out2 = out2; p.act1 = act_mask;
+    p.C1 = c1; p.C2 = c2; p.O1 = o1; p.O2 = o2; p.CinP = (c1 + c2 + 15) / 16 * 16;
+    p.N = n; p.H = h; p.W = wd; p.Hout = hout; p.Wout = wout; p.pad_t = pad_t; p.pad_l = pad_l;
+    p.tiles_y = p.tiles_x = 0; p.act = act; p.pad_mode = pad_mode; p.alpha = alpha;
+    hipStream_t s = (hipStream_t)stream;
+    if (stride == 1 && ks == 1) return dispatch_b<1, 1>(p, s);
+    if (stride == 1 && ks == 3) return dispatch_b<3, 1>(p, s);
+    if (stride == 1 && ks == 5) return dispatch_b<5, 1>(p, s);
+    if (stride == 2 && ks == 2) return dispatch_b<2, 2>(p, s);
+    if (stride == 2 && ks == 5) return dispatch_b<5, 2>(p, s);
+    return NIMG_ERR_ARG;
+}
+
+size_t nimg_conv2d_wgrad_bf16_workspace_bytes(int cin, int cout, int ks_h, int ks_w, int n, int hout, int wout) {
+    if (cin <= 0 || cout <= 0 || n <= 0) return 0;
+    return ((size_t)ks_h * ks_w * cin * cout + cout) * sizeof(float) * splits_for(cin, cout, n, hout, wout);
+}
+
+int nimg_conv2d_wgrad_bf16(const float* in1, int c1, const float* in2, int c2, const float* dz, int cout, float* dw,
+                           float* db, int n, int h, int wd, int ks, int stride, int pad_t, int pad_l, int pad_mode,
+                           int hout, int wout, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!in1 || !dz || !dw || c1 <= 0 || c2 < 0 || cout <= 0 || n <= 0 || h <= 0 || wd <= 0) return NIMG_ERR_ARG;
+    if ((c2 > 0 && !in2) || hout <= 0 || wout <= 0 || !workspace || pad_mode < 0 || pad_mode > 2) return NIMG_ERR_ARG;
+    if ((c1 % 4) || (c2 % 4) || (cout % 4)) return NIMG_ERR_ARG;
+    const int cin = c1 + c2;
+    if (workspace_bytes < nimg_conv2d_wgrad_bf16_workspace_bytes(cin, cout, ks, ks, n, hout, wout)) return NIMG_ERR_WORKSPACE;
+    WgradParamsB p;
+    p.in1 = in1; p.in2 = in2; p.dz = dz; p.partial = (float*)workspace; p.db_partial = nullptr;
+    p.C1 = c1; p.C2 = c2; p.Cout = cout; p.N = n; p.H = h; p.W = wd; p.Hout = hout; p.Wout = wout;
+    p.pad_t = pad_t; p.pad_l = pad_l; p.pad_mode = pad_mode;
+    p.tiles_y = cdiv(hout, B_TH); p.tiles_x = cdiv(wout, B_TW);
+    p.splits = splits_for(cin, cout, n, hout, wout);
+    const long work = (long)n * p.tiles_y * p.tiles_x;
+    p.work_per_split = (int)((work + p.splits - 1) / p.splits);
+    const long count = (long)ks * ks * cin * cout;
+    if (db) p.db_partial = p.partial + (size_t)p.splits * count;
+    const long blocks = (long)cdiv(cin, B_CI) * cdiv(cout, B_CO) * p.splits;
+    hipStream_t s = (hipStream_t)stream;
+#define NIMG_WGB(KS_, ST_)                                                                                     \
+    do {                                                                                                      \
+        constexpr int THH = (B_TH - 1) * ST_ + KS_, TWH = (B_TW - 1) * ST_ + KS_;                             \
+        constexpr size_t lds = (size_t)(THH * TWH * B_CI + B_TH * B_TW * B_CO) * sizeof(float);               \
+        auto k = conv_wgrad_bf16_kernel<KS_, ST_>;                                                            \
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, s, p);                                  \
+    } while (0)
+    if (stride == 1 && ks == 1) NIMG_WGB(1, 1);
+    else if (stride == 1 && ks == 3) NIMG_WGB(3, 1);
+    else if (stride == 1 && ks == 5) NIMG_WGB(5, 1);
+    else if (stride == 2 && ks == 2) NIMG_WGB(2, 2);
+    else if (stride == 2 && ks == 5) NIMG_WGB(5, 2);
+    else return NIMG_ERR_ARG;
+#undef NIMG_WGB
+    NIMG_CHECK_LAUNCH();
+    const int rgrid = (int)((count + 255) / 256 > 4096 ? 4096 : (count + 255) / 256);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(rgrid), dim3(256), 0, s, (const float*)workspace, dw, count, p.splits,
+                       accumulate);
+    NIMG_CHECK_LAUNCH();
+    if (db) {
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((cout + 255) / 256), dim3(256), 0, s, (const float*)p.db_partial,
+                           db, (long)cout, p.splits, accumulate);
+        NIMG_CHECK_LAUNCH();
+    }
+    return NIMG_OK;
+}
+
+}  // extern "C"

@@ -14,6 +14,26 @@ from . import _lib
 
 LRELU_ALPHA = 0.2          # tf.keras.layers.LeakyReLU(alpha=0.2), helpers/tf_helpers.py:23
 
+# Arithmetic type of the convolution GEMMs: 'f32' = exact float32 MFMA (parity mode, default) | 'bf16' = bf16 operands
+# with float32 accumulation on the matrix cores (throughput mode; tensors in HBM stay float32).
+COMPUTE = 'f32'
+
+
+def set_compute(mode):
+    global COMPUTE
+    if mode not in ('f32', 'bf16'):
+        raise ValueError('compute mode must be f32 or bf16')
+    COMPUTE = mode
+
+
+def weights_bf16(w, mode):
+    """bf16 weight image for the throughput-mode kernels (re-made every step from the float32 master weights)."""
+    kh, kw, cin, cout = w.shape
+    nbytes = int(_lib.load().nimg_conv_weights_bf16_bytes(kh, kw, cin, cout, mode))
+    wb = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    _lib.call('nimg_conv_weights_bf16', _p(w), _p(wb), kh, kw, cin, cout, mode, _stream())
+    return wb
+
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
@@ -105,15 +125,15 @@ def djpeg_bwd(x, gy, mask, qtab, rounding='soft', out=None):
 # ----------------------------------------------------------------------------------------------------------------
 # convolutions
 def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mode=0, out=None, out2=None,
-           act_mask=None, pads=None, out_hw=None):
+           act_mask=None, pads=None, out_hw=None, _wmode=0, _f32_only=False):
     """x (N,H,W,C1) [+ x2 (N,H,W,C2)], w (k,k,C1+C2,Cout) HWIO.  padding 'SAME' (TF) | 'VALID' | explicit pads/out_hw.
     out/out2: optional pre-allocated outputs (out2 splits the output channels: Cout = out.C + out2.C)."""
     _f32(x, w, bias, x2, out, out2, act_mask)
     n, h, wd, c1 = x.shape
     c2 = 0 if x2 is None else x2.shape[3]
     ks = w.shape[0]
-    cout = w.shape[3]
-    if w.shape[2] != c1 + c2 or w.shape[1] != ks:
+    cout = w.shape[3] if _wmode == 0 else w.shape[2]         # _wmode 1 = input gradient: (k,k,Cin,Cout) read backwards
+    if (w.shape[2] if _wmode == 0 else w.shape[3]) != c1 + c2 or w.shape[1] != ks:
         raise ValueError('weight shape {} does not match input channels {}+{}'.format(tuple(w.shape), c1, c2))
     if pads is not None:
         pt, pl = pads
@@ -132,6 +152,14 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
     o2 = 0 if out2 is None else out2.shape[3]
     if o1 + o2 != cout or tuple(out.shape[:3]) != (n, ho, wo):
         raise ValueError('output shape mismatch')
+    if COMPUTE == 'bf16' and not _f32_only and c1 % 8 == 0 and c2 % 8 == 0 and cout >= 8:
+        wb = weights_bf16(w, _wmode)
+        _lib.call('nimg_conv2d_fwd_bf16', _p(x), c1, _p(x2), c2, _p(wb), _p(bias), _p(out), o1, _p(out2), o2,
+                  _p(act_mask), n, h, wd, ks, stride, pt, pl, pad_mode, ho, wo, 1 if act == 'leaky_relu' else 0,
+                  LRELU_ALPHA, _stream())
+        return out if out2 is None else (out, out2)
+    if _wmode == 1:
+        w = flip_weights(w)
     _lib.call('nimg_conv2d_fwd', _p(x), c1, _p(x2), c2, _p(w), _p(bias), _p(out), o1, _p(out2), o2, _p(act_mask),
               n, h, wd, ks, stride, pt, pl, pad_mode, ho, wo, 1 if act == 'leaky_relu' else 0, LRELU_ALPHA, _stream())
     return out if out2 is None else (out, out2)
@@ -157,10 +185,9 @@ def conv2d_dgrad(dz, w, in_hw, stride=1, padding='SAME', act_mask=None, out=None
         _, pl = same_pads(wd, ks, 1)
     else:
         pt = pl = 0
-    wt = flip_weights(w)
-    # forward used pad (pt, pl); the gradient correlation needs ks-1-pt / ks-1-pl
-    return conv2d(dz, wt, None, pads=(ks - 1 - pt, ks - 1 - pl), out_hw=(h, wd), act_mask=act_mask, out=out,
-                  out2=out2)
+    # forward used pad (pt, pl); the gradient correlation needs ks-1-pt / ks-1-pl; the kernel is read flipped/transposed
+    return conv2d(dz, w, None, pads=(ks - 1 - pt, ks - 1 - pl), out_hw=(h, wd), act_mask=act_mask, out=out,
+                  out2=out2, _wmode=1)
 
 
 def conv2d_wgrad(x, dz, ks, x2=None, stride=1, padding='SAME', pad_mode=0, pads=None, dw=None, accumulate=False,
@@ -179,6 +206,12 @@ def conv2d_wgrad(x, dz, ks, x2=None, stride=1, padding='SAME', pad_mode=0, pads=
         pt = pl = 0
     if dw is None:
         dw = torch.empty((ks, ks, c1 + c2, cout), dtype=torch.float32, device=x.device)
+    if COMPUTE == 'bf16' and c1 % 4 == 0 and c2 % 4 == 0 and cout % 4 == 0 and c1 + c2 >= 8:
+        need = _lib.load().nimg_conv2d_wgrad_bf16_workspace_bytes(c1 + c2, cout, ks, ks, n, ho, wo)
+        ws = _ws.get(need, x.device)
+        _lib.call('nimg_conv2d_wgrad_bf16', _p(x), c1, _p(x2), c2, _p(dz), cout, _p(dw), _p(db), n, h, wd, ks, stride,
+                  pt, pl, pad_mode, ho, wo, 1 if accumulate else 0, _p(ws), ws.numel(), _stream())
+        return dw
     need = _lib.load().nimg_conv2d_wgrad_workspace_bytes(c1 + c2, cout, ks, ks, n, ho, wo)
     ws = _ws.get(need, x.device)
     _lib.call('nimg_conv2d_wgrad', _p(x), c1, _p(x2), c2, _p(dz), cout, _p(dw), _p(db), n, h, wd, ks, stride, pt, pl,
@@ -469,7 +502,7 @@ def conv2d_dgrad_strided2(dz, w, in_hw):
     up = zero_insert2(dz)
     if up.shape[1] != h or up.shape[2] != wd:
         raise NotImplementedError('strided dgrad is built for even input sizes')
-    return conv2d(up, flip_weights(w), None, pads=(ks - 1 - pt, ks - 1 - pl), out_hw=(h, wd))
+    return conv2d(up, w, None, pads=(ks - 1 - pt, ks - 1 - pl), out_hw=(h, wd), _wmode=1)
 
 
 class LatentWorkspace(object):

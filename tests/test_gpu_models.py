@@ -249,3 +249,32 @@ def test_twitter_dcn_forward_backward(dev):
     assert set(out.keys()) == {'loss', 'ssim', 'entropy'} and abs(out['loss'] - np.sqrt(2 * float(loss_ref))) < 1e-2
     yy, ee = dcn.process(x, return_entropy=True)
     assert yy.shape == (2, 32, 32, 3) and np.isfinite(float(ee))
+
+
+def test_workflow_bf16_throughput_mode(dev):
+    """bf16 MFMA mode of the convolutions: judged like BASELINE.json asks - PSNR of the ISP output against the f32
+    path, loss agreement, gradient direction - not on the 1e-4 contract."""
+    from neural_imaging_amd import ops
+    from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
+    dist = {'downsampling': 'none', 'compression': 'jpeg', 'compression_params': {'quality': 80, 'codec': 'soft'}}
+    rgb = natural_images(2, 64, 64, seed=8)
+    raw = bayer_from_rgb(rgb)
+    res = {}
+    for mode in ('f32', 'bf16'):
+        ops.set_compute(mode)
+        try:
+            wf = ManipulationClassification('UNet', distribution=dist, trainable={'nip'}, raw_patch_size=32, device=dev)
+            Y = wf.run_workflow(raw)[0].numpy()
+            loss, parts = wf.training_step(raw, rgb, lambda_nip=0.1, learning_rate=1e-4)
+            res[mode] = (Y, float(parts['ce']), float(parts['nip']), grads_of(wf.nip), grads_of(wf.fan))
+        finally:
+            ops.set_compute('f32')
+    psnr = 10 * np.log10(1.0 / np.mean((res['f32'][0] - res['bf16'][0]) ** 2))
+    assert psnr > 45, psnr
+    assert abs(res['f32'][1] - res['bf16'][1]) < 2e-2 and abs(res['f32'][2] - res['bf16'][2]) / res['f32'][2] < 1e-2
+    for k in ('ec11/kernel', 'ec32/kernel', 'dc11/kernel', 'dc42/kernel'):
+        a, b = res['f32'][3][k].ravel(), res['bf16'][3][k].ravel()
+        assert float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b))) > 0.98, k
+    for k in ('conv2/kernel', 'conv4/kernel', 'dense/kernel'):
+        a, b = res['f32'][4][k].ravel(), res['bf16'][4][k].ravel()
+        assert float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b))) > 0.95, k

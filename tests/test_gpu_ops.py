@@ -397,3 +397,40 @@ def test_strided_dgrad_and_codec_small_ops(dev):
     lo, gr = ops.l2_loss(g(t, dev), g(y, dev), grad_scale=1.0)
     assert abs(float(lo.item()) - 0.5 * float(((t - y) ** 2).sum())) < 1e-4
     assert np.allclose(gr.cpu().numpy(), y - t, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# throughput mode: bf16 operands / float32 accumulation (PSNR-level parity, not the 1e-4 contract)
+@pytest.fixture()
+def bf16_mode():
+    from neural_imaging_amd import ops
+    ops.set_compute('bf16')
+    yield
+    ops.set_compute('f32')
+
+
+BF16_CASES = [(2, 32, 32, 32, 0, 64, 5, 1), (2, 16, 16, 16, 16, 32, 3, 1), (5, 8, 8, 64, 0, 128, 3, 1),
+              (2, 20, 24, 8, 0, 24, 3, 1), (3, 16, 16, 64, 0, 64, 1, 1), (2, 32, 32, 64, 0, 128, 5, 2)]
+
+
+@pytest.mark.parametrize('case', BF16_CASES)
+def test_conv2d_bf16_mode(dev, bf16_mode, case):
+    from neural_imaging_amd import ops
+    n, h, w, c1, c2, cout, ks, stride = case
+    x = to64(rnd((n, h, w, c1 + c2), 1)).requires_grad_(True)
+    wt = to64(rnd((ks, ks, c1 + c2, cout), 3, -0.2, 0.2)).requires_grad_(True)
+    b = to64(rnd((cout,), 4)).requires_grad_(True)
+    z = T.conv2d(x, wt, b, stride, 'SAME')
+    dz = rnd(tuple(z.shape), 5)
+    (z * to64(dz)).sum().backward()
+    xg = g(x.detach().numpy(), dev)
+    x1, x2 = (xg[..., :c1].contiguous(), xg[..., c1:].contiguous()) if c2 else (xg, None)
+    out = ops.conv2d(x1, g(wt.detach().numpy(), dev), g(b.detach().numpy(), dev), x2=x2, stride=stride)
+    assert_close(out.cpu().numpy(), z.detach().numpy(), 0.0, 1.5e-2, what='bf16 conv fwd {}'.format(case))
+    dbf = torch.empty((cout,), device=dev)
+    dw = ops.conv2d_wgrad(x1, g(dz, dev), ks, x2=x2, stride=stride, db=dbf)
+    assert_close(dw.cpu().numpy(), wt.grad.numpy(), 0.0, 1.5e-2, what='bf16 wgrad {}'.format(case))
+    assert_close(dbf.cpu().numpy(), b.grad.numpy(), 0.0, 1e-4, what='bias grad (f32 sums) {}'.format(case))
+    if stride == 1:
+        dx = ops.conv2d_dgrad(g(dz, dev), g(wt.detach().numpy(), dev), (h, w))
+        assert_close(dx.cpu().numpy(), x.grad.numpy(), 0.0, 1.5e-2, what='bf16 dgrad {}'.format(case))
