@@ -268,6 +268,33 @@ __global__ __launch_bounds__(256) void conv_wgrad_packed_kernel(const WgradParam
 // dw[i] = sum_s partial[s][i]   (fixed order => deterministic)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, long count,
                                     int splits, int accumulate) {
+    // fixed summation order => deterministic; 4 independent accumulators keep 4 loads in flight per thread
+    if ((count & 3) == 0) {
+        const long c4 = count >> 2;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < c4; i += (long)gridDim.x * blockDim.x) {
+            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+            const float4* src = reinterpret_cast<const float4*>(partial) + i;
+            int k = 0;
+            for (; k + 3 < splits; k += 4) {
+                const float4 v0 = src[(long)k * c4], v1 = src[(long)(k + 1) * c4], v2 = src[(long)(k + 2) * c4],
+                             v3 = src[(long)(k + 3) * c4];
+                a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+                a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+                a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+                a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+            }
+            for (; k < splits; ++k) {
+                const float4 v = src[(long)k * c4];
+                a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w;
+            }
+            float4 r = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y),
+                                   (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
+            float4* d = reinterpret_cast<float4*>(dw) + i;
+            if (accumulate) { const float4 o = *d; r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
+            *d = r;
+        }
+        return;
+    }
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
         float s = 0.f;
         for (int k = 0; k < splits; ++k) s += partial[(long)k * count + i];
@@ -308,7 +335,7 @@ extern "C" {
 static int wgrad_splits(int cin, int cout, int n, int hout, int wout) {
     const long blocks_io = (long)nimg::cdiv(cin, CI_T) * nimg::cdiv(cout, CO_T);
     const long work = (long)n * nimg::cdiv(hout, WG_TH) * nimg::cdiv(wout, WG_TW);
-    long splits = (1024 + blocks_io - 1) / blocks_io;
+    long splits = (512 + blocks_io - 1) / blocks_io;
     if (splits > work) splits = work;
     if (splits < 1) splits = 1;
     const long wps = (work + splits - 1) / splits;
@@ -318,7 +345,7 @@ static int wgrad_splits(int cin, int cout, int n, int hout, int wout) {
 static int packed_splits(int cout, int n, int hout, int wout) {
     const long blocks_io = nimg::cdiv(cout, cout <= 32 ? 32 : 64);
     const long work = (long)n * nimg::cdiv(hout, WG_TH) * nimg::cdiv(wout, WG_TW);
-    long splits = (1024 + blocks_io - 1) / blocks_io;
+    long splits = (512 + blocks_io - 1) / blocks_io;
     if (splits > work) splits = work;
     if (splits < 1) splits = 1;
     const long wps = (work + splits - 1) / splits;

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Launch only the dominant kernel (FAN conv3 forward, 5x5 64->128 @64x64, 320 images = B 64) a few times - the target
+of the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs) that feed bench.py's roofline.traffic."""
+import argparse
+import importlib
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--dtype', default='f32')
+ap.add_argument('--images', type=int, default=320)
+ap.add_argument('--reps', type=int, default=3)
+args = ap.parse_args()
+importlib.import_module('neural-imaging_amd')
+from neural_imaging_amd import ops
+ops.set_compute(args.dtype)
+dev = torch.device('cuda', 0)
+x = torch.randn((args.images, 64, 64, 64), device=dev)
+w = torch.randn((5, 5, 64, 128), device=dev) * 0.05
+b = torch.zeros((128,), device=dev)
+out = torch.empty((args.images, 64, 64, 128), device=dev)
+for _ in range(args.reps):
+    ops.conv2d(x, w, b, act='leaky_relu', out=out)
+torch.cuda.synchronize()
+print('algorithmic bytes per launch: in {:.1f} MB + out {:.1f} MB + weights {:.2f} MB'.format(
+    x.numel() * 4 / 1e6, out.numel() * 4 / 1e6, w.numel() * 4 / 1e6))

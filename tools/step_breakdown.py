@@ -18,9 +18,11 @@ def main():
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--raw-patch', type=int, default=128)
     ap.add_argument('--reps', type=int, default=2)
+    ap.add_argument('--dtype', default='f32')
     args = ap.parse_args()
     importlib.import_module('neural-imaging_amd')
     from neural_imaging_amd import ops
+    ops.set_compute(args.dtype)
     from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
     from util import bayer_from_rgb, natural_images
     dev = torch.device('cuda', 0)
