@@ -8,6 +8,8 @@
 //       that nimg_conv_weights_bf16 lays out once per step as [tap][co][ci_pad].
 //   weight gradient: K = 16 output pixels per MFMA; the f32 NHWC tiles of conv_wgrad.hip are kept and each lane gathers
 //       its 8 pixels with ds_read_b32 (conflict-free) and packs them to bf16 in registers (v_cvt_pk_bf16_f32).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -123,8 +125,11 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
         }
         __syncthreads();
 #pragma unroll 1
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int toff = (tap / KS) * TWH + (tap % KS);
+        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {            // one kernel row unrolled: the next taps' ds_reads overlap the MFMAs
+            const int tap = ky * KS + kx;
+            const int toff = ky * TWH + kx;
             bf16x8 a[MI], b[NI];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
@@ -195,6 +200,10 @@ int dispatch_b(const ConvParamsB& p, hipStream_t s) {
                           cdiv(p.N, small ? 4 : 1);
     const bool tn32 = (Cout <= 32) || (blocks64 < 512 && Cout % 64 != 0) || (blocks64 < 384);
     if (small) return tn32 ? launch_conv_b<KS, STRIDE, 8, 8, 4, 32>(p, s) : launch_conv_b<KS, STRIDE, 8, 8, 4, 64>(p, s);
+    // plenty of workgroups: 32x16-pixel tiles (4 M fragments per wave) halve the weight-tile traffic per MFMA
+    static const bool big_ok = getenv("NIMG_BIGTILE") != nullptr;   // measured slower (1 WG/CU): opt-in for A/B only
+    if (big_ok && !tn32 && STRIDE == 1 && blocks64 >= 4096 && p.Hout % 32 == 0)
+        return launch_conv_b<KS, STRIDE, 32, 16, 1, 64>(p, s);
     return tn32 ? launch_conv_b<KS, STRIDE, 16, 16, 1, 32>(p, s) : launch_conv_b<KS, STRIDE, 16, 16, 1, 64>(p, s);
 }
 
@@ -212,14 +221,33 @@ struct WgradParamsB {
 
 constexpr int B_TH = 8, B_TW = 16, B_CI = 32, B_CO = 64;
 
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// ds_read_b64_tr_b16 (gfx950 LDS transpose read).  Measured semantics (tools/probe/tr_probe.hip): inside each 16-lane
+// group lane g supplies the 8-byte-aligned address of 4 contiguous bf16; the 16 addresses are read as a 4 x 16 block
+// (row = g >> 2, 4-column group = g & 3) and lane g receives COLUMN g of that block: element j = block[j][g].
+// With a pixel-major [pixel][channel] tile this hands every lane 4 consecutive PIXELS of its own channel - the K-major
+// fragment the weight-gradient GEMM needs - without any transposed copy in LDS.
+__device__ __forceinline__ bf16x8 tr_read8(const unsigned char* p0, const unsigned char* p1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p1);
+    s16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return *reinterpret_cast<bf16x8*>(&r);
+}
+
+constexpr int B_ZS = 192;      // dz tile row stride in bytes (64 co bf16 = 128 B, padded so 4 rows hit 4 bank quarters)
+
 template <int KS, int STRIDE>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParamsB p) {
     constexpr int TAPS = KS * KS, NT = (TAPS + 3) / 4;
     constexpr int THH = (B_TH - 1) * STRIDE + KS, TWH = (B_TW - 1) * STRIDE + KS;
     constexpr int NPIXH = THH * TWH, NPIX = B_TH * B_TW;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sI = smem;                  // [NPIXH][B_CI] f32
-    float* sZ = smem + NPIXH * B_CI;   // [NPIX][B_CO] f32
+    static_assert(STRIDE == 1 || STRIDE == 2, "stride");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned char* sI = smem_raw;                   // [NPIXH][32 ci] bf16, 64 B per pixel
+    unsigned char* sZ = smem_raw + NPIXH * 64;      // [NPIX][64 co] bf16, B_ZS bytes per pixel
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Cin = p.C1 + p.C2;
@@ -229,7 +257,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParamsB
     bid /= cib;
     const int co0 = (bid % cob) * B_CO;
     const int split = bid / cob;
-    const int half = lane >> 5;
+    const int half = lane >> 5, g = lane & 15, sub = (lane >> 4) & 1;
 
     f32x16 acc[NT][2];
 #pragma unroll
@@ -243,64 +271,82 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParamsB
     const long w_begin = (long)split * p.work_per_split;
     const long w_end = min(work_total, w_begin + p.work_per_split);
     const bool do_bias = p.db_partial && ci0 == 0;
-    float bsum = 0.f;
+    float bacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // per-lane constant parts of the transpose-read addresses
+    const int a_lane = ((half * 8 + (g >> 2)) * STRIDE) * 64 + (sub * 16 + (g & 3) * 4) * 2;   // + pixel terms
+    const int z_lane = (half * 8 + (g >> 2)) * B_ZS + (sub * 16 + (g & 3) * 4) * 2;
     for (long wk = w_begin; wk < w_end; ++wk) {
         const int n = (int)(wk / tiles), tile = (int)(wk % tiles);
         const int ty0 = (tile / p.tiles_x) * B_TH, tx0 = (tile % p.tiles_x) * B_TW;
         const int iy0 = ty0 * STRIDE - p.pad_t, ix0 = tx0 * STRIDE - p.pad_l;
         __syncthreads();
-        for (int item = tid; item < NPIXH * (B_CI / 4); item += 256) {
-            const int pix = item / (B_CI / 4), c = ci0 + (item % (B_CI / 4)) * 4;
+        for (int item = tid; item < NPIXH * 4; item += 256) {          // 8 channels (16 B of bf16) per item
+            const int pix = item >> 2, q = item & 3, c = ci0 + q * 8;
             int gy = iy0 + pix / TWH, gx = ix0 + pix % TWH;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (c < Cin && map_coord(gy, p.H, p.pad_mode) && map_coord(gx, p.W, p.pad_mode)) {
                 const long pixoff = ((long)n * p.H + gy) * p.W + gx;
-                v = c < p.C1 ? *reinterpret_cast<const float4*>(p.in1 + pixoff * p.C1 + c)
-                             : *reinterpret_cast<const float4*>(p.in2 + pixoff * p.C2 + (c - p.C1));
+                const float* src = c < p.C1 ? p.in1 + pixoff * p.C1 + c : p.in2 + pixoff * p.C2 + (c - p.C1);
+                const float4 v0 = *reinterpret_cast<const float4*>(src);
+                f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = v0.w;
+                if (c + 4 < Cin) {
+                    const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
+                    f[4] = v1.x; f[5] = v1.y; f[6] = v1.z; f[7] = v1.w;
+                }
             }
-            *reinterpret_cast<float4*>(sI + pix * B_CI + (item % (B_CI / 4)) * 4) = v;
+            const bf16x8 b = pack8(f);
+            *reinterpret_cast<uint4*>(sI + pix * 64 + q * 16) = *reinterpret_cast<const uint4*>(&b);
         }
-        for (int item = tid; item < NPIX * (B_CO / 4); item += 256) {
-            const int pix = item / (B_CO / 4), c = co0 + (item % (B_CO / 4)) * 4;
+        for (int item = tid; item < NPIX * 8; item += 256) {
+            const int pix = item >> 3, q = item & 7, c = co0 + q * 8;
             const int oy = ty0 + pix / B_TW, ox = tx0 + pix % B_TW;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (oy < p.Hout && ox < p.Wout && c < p.Cout)
-                v = *reinterpret_cast<const float4*>(p.dz + (((long)n * p.Hout + oy) * p.Wout + ox) * p.Cout + c);
-            *reinterpret_cast<float4*>(sZ + pix * B_CO + (item % (B_CO / 4)) * 4) = v;
+            float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (oy < p.Hout && ox < p.Wout && c < p.Cout) {
+                const float* src = p.dz + (((long)n * p.Hout + oy) * p.Wout + ox) * p.Cout + c;
+                const float4 v0 = *reinterpret_cast<const float4*>(src);
+                f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = v0.w;
+                if (c + 4 < p.Cout) {
+                    const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
+                    f[4] = v1.x; f[5] = v1.y; f[6] = v1.z; f[7] = v1.w;
+                }
+            }
+            if (do_bias) {                      // fused bias gradient in float32: this thread always owns channels q*8..
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bacc[e] += f[e];
+            }
+            const bf16x8 b = pack8(f);
+            *reinterpret_cast<uint4*>(sZ + pix * B_ZS + q * 16) = *reinterpret_cast<const uint4*>(&b);
         }
         __syncthreads();
-        if (do_bias && tid < B_CO) {
-#pragma unroll 8
-            for (int px = 0; px < NPIX; ++px) bsum += sZ[px * B_CO + tid];
-        }
-        // one MFMA k-step = one tile row of 16 output pixels; lane half h covers pixels h*8 .. h*8+7 of the row
-        const float* zL = sZ + (half * 8) * B_CO + (lane & 31);
-        const float* iL = sI + (half * 8) * STRIDE * B_CI + (lane & 31);
 #pragma unroll 1
         for (int r = 0; r < B_TH; ++r) {
-            float f[8];
-            bf16x8 b0, b1;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) f[k] = zL[(r * B_TW + k) * B_CO];
-            b0 = pack8(f);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) f[k] = zL[(r * B_TW + k) * B_CO + 32];
-            b1 = pack8(f);
+            const unsigned char* zr = sZ + (r * B_TW) * B_ZS + z_lane;
+            const bf16x8 b0 = tr_read8(zr, zr + 4 * B_ZS);
+            const bf16x8 b1 = tr_read8(zr + 64, zr + 4 * B_ZS + 64);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int tap = wave + 4 * t;
                 if (tap < TAPS) {
-                    const float* src = iL + ((r * STRIDE + tap / KS) * TWH + (tap % KS)) * B_CI;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) f[k] = src[k * STRIDE * B_CI];
-                    const bf16x8 a = pack8(f);
+                    const unsigned char* ir = sI + ((r * STRIDE + tap / KS) * TWH + (tap % KS)) * 64 + a_lane;
+                    const bf16x8 a = tr_read8(ir, ir + 4 * STRIDE * 64);
                     acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[t][0], 0, 0, 0);
                     acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[t][1], 0, 0, 0);
                 }
             }
         }
     }
-    if (do_bias && tid < B_CO && co0 + tid < p.Cout) p.db_partial[(long)split * p.Cout + co0 + tid] = bsum;
+    if (do_bias) {                              // thread t holds channels (t & 7) * 8 .. + 7: reduce the 32 owners
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem_raw);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[tid * 8 + e] = bacc[e];
+        __syncthreads();
+        if (tid < B_CO && co0 + tid < p.Cout) {
+            float sum = 0.f;
+            for (int o = 0; o < 32; ++o) sum += red[(o * 8 + (tid >> 3)) * 8 + (tid & 7)];
+            p.db_partial[(long)split * p.Cout + co0 + tid] = sum;
+        }
+    }
     float* slab = p.partial + (long)split * TAPS * Cin * p.Cout;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -417,7 +463,7 @@ int nimg_conv2d_wgrad_bf16(const float* in1, int c1, const float* in2, int c2, c
                            int hout, int wout, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
     if (!in1 || !dz || !dw || c1 <= 0 || c2 < 0 || cout <= 0 || n <= 0 || h <= 0 || wd <= 0) return NIMG_ERR_ARG;
     if ((c2 > 0 && !in2) || hout <= 0 || wout <= 0 || !workspace || pad_mode < 0 || pad_mode > 2) return NIMG_ERR_ARG;
-    if ((c1 % 4) || (c2 % 4) || (cout % 4)) return NIMG_ERR_ARG;
+    if ((c1 % 4) || (c2 % 4) || (cout % 4) || (c2 > 0 && (c1 % 8))) return NIMG_ERR_ARG;
     const int cin = c1 + c2;
     if (workspace_bytes < nimg_conv2d_wgrad_bf16_workspace_bytes(cin, cout, ks, ks, n, hout, wout)) return NIMG_ERR_WORKSPACE;
     WgradParamsB p;
@@ -435,7 +481,7 @@ int nimg_conv2d_wgrad_bf16(const float* in1, int c1, const float* in2, int c2, c
 #define NIMG_WGB(KS_, ST_)                                                                                     \
     do {                                                                                                      \
         constexpr int THH = (B_TH - 1) * ST_ + KS_, TWH = (B_TW - 1) * ST_ + KS_;                             \
-        constexpr size_t lds = (size_t)(THH * TWH * B_CI + B_TH * B_TW * B_CO) * sizeof(float);               \
+        constexpr size_t lds = (size_t)THH * TWH * 64 + (size_t)B_TH * B_TW * B_ZS;                         \
         auto k = conv_wgrad_bf16_kernel<KS_, ST_>;                                                            \
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
         hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, s, p);                                  \

@@ -206,7 +206,8 @@ def conv2d_wgrad(x, dz, ks, x2=None, stride=1, padding='SAME', pad_mode=0, pads=
         pt = pl = 0
     if dw is None:
         dw = torch.empty((ks, ks, c1 + c2, cout), dtype=torch.float32, device=x.device)
-    if COMPUTE == 'bf16' and c1 % 4 == 0 and c2 % 4 == 0 and cout % 4 == 0 and c1 + c2 >= 8:
+    if COMPUTE == 'bf16' and c1 % 4 == 0 and c2 % 4 == 0 and cout % 4 == 0 and c1 + c2 >= 8 and \
+            (c2 == 0 or c1 % 8 == 0):
         need = _lib.load().nimg_conv2d_wgrad_bf16_workspace_bytes(c1 + c2, cout, ks, ks, n, ho, wo)
         ws = _ws.get(need, x.device)
         _lib.call('nimg_conv2d_wgrad_bf16', _p(x), c1, _p(x2), c2, _p(dz), cout, _p(dw), _p(db), n, h, wd, ks, stride,
