@@ -204,6 +204,15 @@ int nimg_conv2d_wgrad_bf16(const float* in1, int c1, const float* in2, int c2, c
                            float* db, int n, int h, int wd, int ks, int stride, int pad_t, int pad_l, int pad_mode,
                            int hout, int wout, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
+/* FAN front end in throughput mode (models/forensics.py:69, the 3-channel side of the first convolution):
+ * few INPUT channels (cin 3 or 4; float32 HWIO weights are converted in-kernel), K = (tap, ci) packed; and the input
+ * gradient of a (ks,ks,3,32) SAME stride-1 convolution with the kx loop folded into the MFMA N dimension (w = the
+ * FORWARD kernel as stored).  nimg_conv2d_wgrad_bf16 picks the (tap, ci)-packed weight-gradient kernel by itself. */
+int nimg_conv2d_fwd_smallc_bf16(const float* in, int cin, const float* w, const float* bias, float* out, int cout,
+                                int n, int h, int wd, int ks, int pad_mode, int act, float alpha, void* stream);
+int nimg_conv2d_dgrad_fewin_bf16(const float* dz, const float* w, float* out, int ci, int cz, int n, int h, int wd,
+                                 int ks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,40 @@ __device__ __forceinline__ bool map_coord(int& g, int size, int pad_mode) {
     return g >= 0 && g < size;
 }
 
+typedef float nimg_f32x16 __attribute__((ext_vector_type(16)));
+
+// Epilogue of the MFMA convolution kernels.  A 32x32 accumulator tile leaves every lane with 16 values of ONE output
+// channel (4 B per lane per store instruction = store-issue bound, ~1.3 TB/s measured).  The tile is therefore turned
+// around through LDS - written channel-contiguous per pixel (conflict-free ds_write_b32), read back as float4 along the
+// NHWC channel axis - so every lane stores 16 B and 16 lanes cover one pixel's 64 channels contiguously.
+//   acc:  NI accumulators of M-fragment `mi` (32 pixels x NI*32 channels);  lds: this wave's scratch, 32*(NI*32+4) floats
+//   emit(row, c, float4 v): row = pixel index inside the fragment (0..31), c = first of 4 channels inside the wave's
+//                           NI*32-channel strip; applies bias/activation/mask and stores.
+// Every wave of the workgroup must call this the same number of times (it contains workgroup barriers).
+constexpr int EPI_PAD = 4;
+// BLOCK_SYNC = true: the scratch aliases tiles other waves may still be reading -> workgroup barriers.
+// BLOCK_SYNC = false: private per-wave scratch; a wave's LDS operations complete in order, so only the compiler has to
+// be kept from reordering (wave_barrier) - no workgroup barrier in a latency-bound tile loop.
+template <int NI, bool BLOCK_SYNC = true, typename Emit>
+__device__ __forceinline__ void epilogue_via_lds(const nimg_f32x16 (&acc)[NI], float* lds, int lane, Emit emit) {
+    constexpr int RS = NI * 32 + EPI_PAD;
+    const int half = lane >> 5, n = lane & 31;
+    if (BLOCK_SYNC) __syncthreads();                   // LDS region free (previous user done)
+    else __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) lds[((j & 3) + 8 * (j >> 2) + 4 * half) * RS + ni * 32 + n] = acc[ni][j];
+    if (BLOCK_SYNC) __syncthreads();
+    else __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < (32 * NI * 8) / 64; ++it) {
+        const int idx = it * 64 + lane, row = idx / (NI * 8), c4 = idx % (NI * 8);
+        const float4 v = *reinterpret_cast<const float4*>(lds + row * RS + c4 * 4);
+        emit(row, c4 * 4, v);
+    }
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace nimg

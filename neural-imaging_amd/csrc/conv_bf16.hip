@@ -12,6 +12,12 @@
 
 #include "common.h"
 
+// defined in conv_small.hip
+size_t nimg_internal_wgrad_tiny_bytes(int ks, int cin, int cout);
+int nimg_internal_conv_wgrad_tiny(const float* in, const float* dz, float* dw, int cin, int cout, int n, int h, int wd,
+                                  int ks, int pad, int pad_mode, int accumulate, void* workspace, hipStream_t s);
+
+
 namespace {
 
 using namespace nimg;
@@ -150,6 +156,40 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
         }
     }
+    // ---- epilogue, vector form: accumulators turned around through LDS so each lane stores 16 B along the channels
+    if ((p.O1 & 3) == 0 && (p.O2 & 3) == 0) {
+        float* elds = reinterpret_cast<float*>(smem_raw) + wave * (32 * (NI * 32 + EPI_PAD));
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            epilogue_via_lds<NI>(acc[mi], elds, lane, [&](int row, int c, float4 v) {
+                const int co = co0 + wn * NI * 32 + c;
+                if (co >= Cout) return;
+                const int P = (wm * MI + mi) * 32 + row;
+                const int img = P / (TH * TW), rem = P % (TH * TW);
+                const int oy = ty0 + rem / TW, ox = tx0 + rem % TW, n = grp * NB + img;
+                if (n >= p.N || oy >= p.Hout || ox >= p.Wout) return;
+                const long pixoff = ((long)n * p.Hout + oy) * p.Wout + ox;
+                if (p.bias) {
+                    const float4 b = *reinterpret_cast<const float4*>(p.bias + co);
+                    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                }
+                if (p.act == 1) {
+                    v.x = lrelu(v.x, p.alpha); v.y = lrelu(v.y, p.alpha); v.z = lrelu(v.z, p.alpha); v.w = lrelu(v.w, p.alpha);
+                }
+                if (co < p.O1) {
+                    if (p.act1) {
+                        const float4 m = *reinterpret_cast<const float4*>(p.act1 + pixoff * p.O1 + co);
+                        v.x *= m.x > 0.f ? 1.0f : p.alpha; v.y *= m.y > 0.f ? 1.0f : p.alpha;
+                        v.z *= m.z > 0.f ? 1.0f : p.alpha; v.w *= m.w > 0.f ? 1.0f : p.alpha;
+                    }
+                    *reinterpret_cast<float4*>(p.out1 + pixoff * p.O1 + co) = v;
+                } else {
+                    *reinterpret_cast<float4*>(p.out2 + pixoff * p.O2 + (co - p.O1)) = v;
+                }
+            });
+        }
+        return;
+    }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
         const int co = co0 + (wn * NI + ni) * 32 + (lane & 31);
@@ -180,7 +220,9 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
 template <int KS, int STRIDE, int TH, int TW, int NB, int TN>
 int launch_conv_b(const ConvParamsB& p, hipStream_t stream) {
     constexpr int THH = (TH - 1) * STRIDE + KS, TWH = (TW - 1) * STRIDE + KS;
-    constexpr size_t lds = (size_t)(NB * THH * TWH + KS * KS * TN) * 2 * sizeof(uint4);
+    constexpr size_t lds_tiles = (size_t)(NB * THH * TWH + KS * KS * TN) * 2 * sizeof(uint4);
+    constexpr size_t lds_epi = (size_t)4 * 32 * (TN + EPI_PAD) * sizeof(float);
+    constexpr size_t lds = lds_tiles > lds_epi ? lds_tiles : lds_epi;
     ConvParamsB q = p;
     q.tiles_y = cdiv(p.Hout, TH);
     q.tiles_x = cdiv(p.Wout, TW);
@@ -220,6 +262,9 @@ struct WgradParamsB {
 };
 
 constexpr int B_TH = 8, B_TW = 16, B_CI = 32, B_CO = 64;
+
+template <int KS, int CINP, int NI>
+__global__ void conv_wgrad_packed_bf16_kernel(const WgradParamsB p);      // defined with the FAN front-end kernels below
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -453,9 +498,24 @@ int nimg_conv2d_fwd_bf16(const float* in1, int c1, const float* in2, int c2, con
     return NIMG_ERR_ARG;
 }
 
+static int packed_splits_b(int cout, int n, int hout, int wout) {
+    const long blocks_io = cdiv(cout, cout <= 32 ? 32 : 64);
+    const long work = (long)n * cdiv(hout, B_TH) * cdiv(wout, B_TW);
+    long splits = (512 + blocks_io - 1) / blocks_io;
+    if (splits > work) splits = work;
+    if (splits < 1) splits = 1;
+    const long wps = (work + splits - 1) / splits;
+    return (int)((work + wps - 1) / wps);
+}
+
 size_t nimg_conv2d_wgrad_bf16_workspace_bytes(int cin, int cout, int ks_h, int ks_w, int n, int hout, int wout) {
     if (cin <= 0 || cout <= 0 || n <= 0) return 0;
-    return ((size_t)ks_h * ks_w * cin * cout + cout) * sizeof(float) * splits_for(cin, cout, n, hout, wout);
+    const size_t slab = (size_t)ks_h * ks_w * cin * cout * sizeof(float);
+    const size_t generic = (slab + cout * sizeof(float)) * splits_for(cin, cout, n, hout, wout);
+    const size_t packed = cin <= 4 ? (4 * slab + cout * sizeof(float)) * packed_splits_b(cout, n, hout, wout) : 0;
+    const size_t tiny = (cin <= 4 && cout <= 4) ? nimg_internal_wgrad_tiny_bytes(ks_h, cin, cout) : 0;
+    const size_t m = generic > packed ? generic : packed;
+    return m > tiny ? m : tiny;
 }
 
 int nimg_conv2d_wgrad_bf16(const float* in1, int c1, const float* in2, int c2, const float* dz, int cout, float* dw,
@@ -463,9 +523,51 @@ int nimg_conv2d_wgrad_bf16(const float* in1, int c1, const float* in2, int c2, c
                            int hout, int wout, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
     if (!in1 || !dz || !dw || c1 <= 0 || c2 < 0 || cout <= 0 || n <= 0 || h <= 0 || wd <= 0) return NIMG_ERR_ARG;
     if ((c2 > 0 && !in2) || hout <= 0 || wout <= 0 || !workspace || pad_mode < 0 || pad_mode > 2) return NIMG_ERR_ARG;
-    if ((c1 % 4) || (c2 % 4) || (cout % 4) || (c2 > 0 && (c1 % 8))) return NIMG_ERR_ARG;
     const int cin = c1 + c2;
     if (workspace_bytes < nimg_conv2d_wgrad_bf16_workspace_bytes(cin, cout, ks, ks, n, hout, wout)) return NIMG_ERR_WORKSPACE;
+    if (c2 == 0 && c1 == 3 && cout == 3 && stride == 1 && (ks == 3 || ks == 5) && hout == h && wout == wd &&
+        pad_t == (ks - 1) / 2 && pad_l == pad_t && !db)              // tiny filter: exact f32 VALU kernel in both modes
+        return nimg_internal_conv_wgrad_tiny(in1, dz, dw, c1, cout, n, h, wd, ks, pad_t, pad_mode, accumulate, workspace,
+                                             (hipStream_t)stream);
+    if (c2 == 0 && (c1 == 3 || c1 == 4) && stride == 1 && (ks == 3 || ks == 5)) {      // (tap, ci)-packed M dimension
+        WgradParamsB q;
+        q.in1 = in1; q.in2 = nullptr; q.dz = dz; q.partial = (float*)workspace; q.db_partial = nullptr;
+        q.C1 = c1; q.C2 = 0; q.Cout = cout; q.N = n; q.H = h; q.W = wd; q.Hout = hout; q.Wout = wout;
+        q.pad_t = pad_t; q.pad_l = pad_l; q.pad_mode = pad_mode;
+        q.tiles_y = cdiv(hout, B_TH); q.tiles_x = cdiv(wout, B_TW);
+        q.splits = packed_splits_b(cout, n, hout, wout);
+        const long work_ = (long)n * q.tiles_y * q.tiles_x;
+        q.work_per_split = (int)((work_ + q.splits - 1) / q.splits);
+        const long cnt = (long)ks * ks * cin * cout;
+        if (db) q.db_partial = q.partial + (size_t)4 * q.splits * cnt;
+        const int ni = cout <= 32 ? 1 : 2;
+        const long pblocks = (long)cdiv(cout, 32 * ni) * q.splits;
+        hipStream_t s_ = (hipStream_t)stream;
+#define NIMG_WGPB(KS_, C_, NI_)                                                                                 \
+        do {                                                                                                  \
+            constexpr size_t lds = (size_t)((B_TH + KS_ - 1) * (B_TW + KS_ - 1) * C_ + B_TH * B_TW * 32 * NI_) * \
+                                   sizeof(float);                                                             \
+            hipLaunchKernelGGL((conv_wgrad_packed_bf16_kernel<KS_, C_, NI_>), dim3((unsigned)pblocks), dim3(256), \
+                               lds, s_, q);                                                                   \
+        } while (0)
+        if (ks == 5 && c1 == 3) { if (ni == 1) NIMG_WGPB(5, 3, 1); else NIMG_WGPB(5, 3, 2); }
+        else if (ks == 5) { if (ni == 1) NIMG_WGPB(5, 4, 1); else NIMG_WGPB(5, 4, 2); }
+        else if (c1 == 3) { if (ni == 1) NIMG_WGPB(3, 3, 1); else NIMG_WGPB(3, 3, 2); }
+        else { if (ni == 1) NIMG_WGPB(3, 4, 1); else NIMG_WGPB(3, 4, 2); }
+#undef NIMG_WGPB
+        NIMG_CHECK_LAUNCH();
+        const int rg = (int)((cnt + 255) / 256 > 4096 ? 4096 : (cnt + 255) / 256);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(rg), dim3(256), 0, s_, (const float*)workspace, dw, cnt,
+                           4 * q.splits, accumulate);
+        NIMG_CHECK_LAUNCH();
+        if (db) {
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(256), 0, s_, (const float*)q.db_partial, db,
+                               (long)cout, q.splits, accumulate);
+            NIMG_CHECK_LAUNCH();
+        }
+        return NIMG_OK;
+    }
+    if ((c1 % 4) || (c2 % 4) || (cout % 4) || (c2 > 0 && (c1 % 8))) return NIMG_ERR_ARG;
     WgradParamsB p;
     p.in1 = in1; p.in2 = in2; p.dz = dz; p.partial = (float*)workspace; p.db_partial = nullptr;
     p.C1 = c1; p.C2 = c2; p.Cout = cout; p.N = n; p.H = h; p.W = wd; p.Hout = hout; p.Wout = wout;
@@ -503,6 +605,422 @@ int nimg_conv2d_wgrad_bf16(const float* in1, int c1, const float* in2, int c2, c
                            db, (long)cout, p.splits, accumulate);
         NIMG_CHECK_LAUNCH();
     }
+    return NIMG_OK;
+}
+
+}  // extern "C"
+
+// ==================================================================================================================
+// FAN front end in throughput mode (the 3-channel side of the first convolution, models/forensics.py:69): the three
+// passes that touch the 256x256x32 tensor are HBM-bound (2.7 GB per 320-image batch each), so they must not waste the
+// matrix core on channel padding nor the LDS on re-reads.
+namespace {
+
+// ---- forward, Cin <= 4: K = (tap, ci) packed (75 -> 80), A gathered from f32 channel planes, B = [co][k] bf16 ---------
+template <int KS, int CINP, int TN>
+__global__ __launch_bounds__(256) void conv_fwd_packed_bf16_kernel(const float* __restrict__ in,
+                                                                   const float* __restrict__ w,
+                                                                   const float* __restrict__ bias,
+                                                                   float* __restrict__ out, int N, int H, int W,
+                                                                   int Cout, int pad_mode, int act, float alpha,
+                                                                   int tiles_y, int tiles_x, int tiles_per_wg) {
+    constexpr int TH = 16, TW = 16, THH = TH + KS - 1, TWH = TW + KS - 1, P = (KS - 1) / 2;
+    constexpr int NPIXH = THH * TWH, PS = ((NPIXH + 31) / 32) * 32 + 2;
+    constexpr int KTOT = KS * KS * CINP, KSTEPS = (KTOT + 15) / 16, KP = KSTEPS * 16;
+    constexpr int NI = TN / 32, MI = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* sA = reinterpret_cast<float*>(smem_raw);                           // [CINP][PS] f32
+    constexpr int A_BYTES = (CINP * PS * 4 + 15) / 16 * 16;
+    __bf16* sB = reinterpret_cast<__bf16*>(smem_raw + A_BYTES);               // [TN][KP] bf16, 16-byte aligned
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cot = (Cout + TN - 1) / TN;
+    const int co0 = (blockIdx.x % cot) * TN, wg = blockIdx.x / cot;
+    const int tiles = tiles_y * tiles_x;
+    const long total_tiles = (long)tiles * N;
+    for (int item = tid; item < TN * KP; item += 256) {
+        const int k = item % KP, j = item / KP;
+        sB[item] = (__bf16)((k < KTOT && co0 + j < Cout) ? w[(long)k * Cout + co0 + j] : 0.f);
+    }
+    int koff[KSTEPS][8];
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int k = s * 16 + half * 8 + j;
+            k = k < KTOT ? k : 0;                                  // padded slots meet zero weights
+            const int tap = k / CINP, ci = k - tap * CINP;
+            koff[s][j] = ci * PS + (tap / KS) * TWH + (tap % KS);
+        }
+    int abase[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int Pp = (wave * MI + mi) * 32 + (lane & 31);
+        abase[mi] = (Pp / TW) * TWH + (Pp % TW);
+    }
+    // the halo of tile t+1 is fetched into registers while tile t is computed and stored (the tiles are tiny, so the
+    // loop is otherwise a chain of exposed HBM latencies)
+    constexpr int PPT = (NPIXH + 255) / 256;
+    float pre[PPT][CINP];
+    auto fetch = [&](long gt) {
+        const int n_ = (int)(gt / tiles), tile_ = (int)(gt % tiles);
+        const int ty_ = (tile_ / tiles_x) * TH, tx_ = (tile_ % tiles_x) * TW;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int pix = tid + q * 256;
+            int gy = ty_ - P + pix / TWH, gx = tx_ - P + pix % TWH;
+            const bool ok = pix < NPIXH && map_coord(gy, H, pad_mode) && map_coord(gx, W, pad_mode);
+            const float* src = in + (((long)n_ * H + gy) * W + gx) * CINP;
+#pragma unroll
+            for (int c = 0; c < CINP; ++c) pre[q][c] = ok ? src[c] : 0.f;
+        }
+    };
+    const long gt0 = (long)wg * tiles_per_wg;
+    if (gt0 < total_tiles) fetch(gt0);
+    for (int tt = 0; tt < tiles_per_wg; ++tt) {
+        const long gt = gt0 + tt;
+        if (gt >= total_tiles) break;
+        const int n = (int)(gt / tiles), tile = (int)(gt % tiles);
+        const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int pix = tid + q * 256;
+            if (pix < NPIXH) {
+#pragma unroll
+                for (int c = 0; c < CINP; ++c) sA[c * PS + pix] = pre[q][c];
+            }
+        }
+        __syncthreads();
+        if (tt + 1 < tiles_per_wg && gt + 1 < total_tiles) fetch(gt + 1);
+        f32x16 acc[MI][NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[mi][ni][j] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            bf16x8 b[NI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                b[ni] = *reinterpret_cast<const bf16x8*>(sB + (ni * 32 + (lane & 31)) * KP + s * 16 + half * 8);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                float f[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = sA[koff[s][j] + abase[mi]];
+                const bf16x8 a = pack8(f);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[ni], acc[mi][ni], 0, 0, 0);
+            }
+        }
+        if ((Cout & 3) == 0) {          // vector epilogue: 16 B per lane along the channels (common.h)
+            float* elds = reinterpret_cast<float*>(smem_raw + A_BYTES + TN * KP * 2) + wave * (32 * (NI * 32 + EPI_PAD));
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                epilogue_via_lds<NI, false>(acc[mi], elds, lane, [&](int row, int c, float4 v) {
+                    const int co = co0 + c;
+                    if (co >= Cout) return;
+                    const int Pp = (wave * MI + mi) * 32 + row;
+                    const int oy = ty0 + Pp / TW, ox = tx0 + Pp % TW;
+                    if (oy >= H || ox >= W) return;
+                    if (bias) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(bias + co);
+                        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+                    }
+                    if (act == 1) {
+                        v.x = lrelu(v.x, alpha); v.y = lrelu(v.y, alpha); v.z = lrelu(v.z, alpha); v.w = lrelu(v.w, alpha);
+                    }
+                    *reinterpret_cast<float4*>(out + (((long)n * H + oy) * W + ox) * Cout + co) = v;
+                });
+            }
+            continue;
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int co = co0 + ni * 32 + (lane & 31);
+            if (co >= Cout) continue;
+            const float bv = bias ? bias[co] : 0.f;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int Pp = (wave * MI + mi) * 32 + (j & 3) + 8 * (j >> 2) + 4 * half;
+                    const int oy = ty0 + Pp / TW, ox = tx0 + Pp % TW;
+                    if (oy >= H || ox >= W) continue;
+                    float v = acc[mi][ni][j] + bv;
+                    if (act == 1) v = lrelu(v, alpha);
+                    out[(((long)n * H + oy) * W + ox) * Cout + co] = v;
+                }
+        }
+    }
+}
+
+// ---- weight gradient, Cin <= 4: M = (tap, ci) packed, K = 16 pixels per MFMA, operands gathered from f32 tiles --------
+template <int KS, int CINP, int NI>
+__global__ __launch_bounds__(256) void conv_wgrad_packed_bf16_kernel(const WgradParamsB p) {
+    constexpr int TAPS = KS * KS, TPF = 32 / CINP, MF = (TAPS + TPF - 1) / TPF;
+    constexpr int THH = B_TH + KS - 1, TWH = B_TW + KS - 1, NPIXH = THH * TWH, NPIX = B_TH * B_TW, COT = 32 * NI;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sI = smem;                    // [NPIXH][CINP]
+    float* sZ = smem + NPIXH * CINP;     // [NPIX][COT]
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cob = (p.Cout + COT - 1) / COT;
+    const int co0 = (blockIdx.x % cob) * COT, split = blockIdx.x / cob;
+    int aoff[MF];
+#pragma unroll
+    for (int f = 0; f < MF; ++f) {
+        const int i = lane & 31, tl = i / CINP, ci = i % CINP, tap = f * TPF + tl;
+        aoff[f] = (tl < TPF && tap < TAPS) ? ((tap / KS) * TWH + (tap % KS)) * CINP + ci : -1;
+    }
+    f32x16 acc[MF][NI];
+#pragma unroll
+    for (int f = 0; f < MF; ++f)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[f][ni][j] = 0.0f;
+    const int tiles = p.tiles_y * p.tiles_x;
+    const long work_total = (long)p.N * tiles;
+    const long w_begin = (long)split * p.work_per_split, w_end = min(work_total, w_begin + p.work_per_split);
+    const bool do_bias = p.db_partial != nullptr;
+    float bsum = 0.f;
+    // register prefetch of the next tile (both operands) while the current one is multiplied
+    constexpr int IPT = (NPIXH + 255) / 256, ZPT = NPIX * (COT / 4) / 256;
+    float prei[IPT][CINP];
+    float4 prez[ZPT];
+    const bool vec_z = (p.Cout % 4 == 0);
+    auto fetch = [&](long wk_) {
+        const int n_ = (int)(wk_ / tiles), tile_ = (int)(wk_ % tiles);
+        const int ty_ = (tile_ / p.tiles_x) * B_TH, tx_ = (tile_ % p.tiles_x) * B_TW;
+#pragma unroll
+        for (int q = 0; q < IPT; ++q) {
+            const int pix = tid + q * 256;
+            int gy = ty_ - p.pad_t + pix / TWH, gx = tx_ - p.pad_l + pix % TWH;
+            const bool ok = pix < NPIXH && map_coord(gy, p.H, p.pad_mode) && map_coord(gx, p.W, p.pad_mode);
+            const float* src = p.in1 + (((long)n_ * p.H + gy) * p.W + gx) * CINP;
+#pragma unroll
+            for (int c = 0; c < CINP; ++c) prei[q][c] = ok ? src[c] : 0.f;
+        }
+        if (vec_z) {
+#pragma unroll
+            for (int q = 0; q < ZPT; ++q) {
+                const int item = tid + q * 256;
+                const int pix = item / (COT / 4), c = co0 + (item % (COT / 4)) * 4;
+                const int oy = ty_ + pix / B_TW, ox = tx_ + pix % B_TW;
+                prez[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (oy < p.Hout && ox < p.Wout && c < p.Cout)
+                    prez[q] = *reinterpret_cast<const float4*>(p.dz + (((long)n_ * p.Hout + oy) * p.Wout + ox) * p.Cout + c);
+            }
+        }
+    };
+    if (w_begin < w_end) fetch(w_begin);
+    for (long wk = w_begin; wk < w_end; ++wk) {
+        const int n = (int)(wk / tiles), tile = (int)(wk % tiles);
+        const int ty0 = (tile / p.tiles_x) * B_TH, tx0 = (tile % p.tiles_x) * B_TW;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < IPT; ++q) {
+            const int pix = tid + q * 256;
+            if (pix < NPIXH) {
+#pragma unroll
+                for (int c = 0; c < CINP; ++c) sI[pix * CINP + c] = prei[q][c];
+            }
+        }
+        if (vec_z) {
+#pragma unroll
+            for (int q = 0; q < ZPT; ++q) {
+                const int item = tid + q * 256;
+                *reinterpret_cast<float4*>(sZ + (item / (COT / 4)) * COT + (item % (COT / 4)) * 4) = prez[q];
+            }
+        } else {
+            for (int item = tid; item < NPIX * COT; item += 256) {
+                const int pix = item / COT, c = co0 + item % COT;
+                const int oy = ty0 + pix / B_TW, ox = tx0 + pix % B_TW;
+                sZ[item] = (oy < p.Hout && ox < p.Wout && c < p.Cout)
+                               ? p.dz[(((long)n * p.Hout + oy) * p.Wout + ox) * p.Cout + c] : 0.f;
+            }
+        }
+        __syncthreads();
+        if (wk + 1 < w_end) fetch(wk + 1);
+        if (do_bias && tid < COT) {
+#pragma unroll 8
+            for (int px = 0; px < NPIX; ++px) bsum += sZ[px * COT + tid];
+        }
+        for (int r = wave; r < B_TH; r += 4) {
+            float f8[8];
+            bf16x8 b[NI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) f8[k] = sZ[(r * B_TW + half * 8 + k) * COT + ni * 32 + (lane & 31)];
+                b[ni] = pack8(f8);
+            }
+#pragma unroll
+            for (int f = 0; f < MF; ++f) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    f8[k] = aoff[f] >= 0 ? sI[(r * TWH + half * 8 + k) * CINP + aoff[f]] : 0.f;
+                const bf16x8 a = pack8(f8);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[f][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[ni], acc[f][ni], 0, 0, 0);
+            }
+        }
+    }
+    if (do_bias && tid < COT && co0 + tid < p.Cout) p.db_partial[(long)split * p.Cout + co0 + tid] = bsum;
+    float* slab = p.partial + ((long)split * 4 + wave) * TAPS * CINP * p.Cout;
+#pragma unroll
+    for (int f = 0; f < MF; ++f)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int co = co0 + ni * 32 + (lane & 31);
+            if (co >= p.Cout) continue;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int i = (j & 3) + 8 * (j >> 2) + 4 * half;
+                const int tl = i / CINP, ci = i % CINP, tap = f * TPF + tl;
+                if (tl < TPF && tap < TAPS) slab[((long)tap * CINP + ci) * p.Cout + co] = acc[f][ni][j];
+            }
+        }
+}
+
+// ---- input gradient towards FEW channels (CI <= 6 with KS*CI <= 32), from CZ = 32 gradient channels -----------------
+//   out[u][v][ci] = sum_{ky,kx,co} dz[u+P-ky][v+P-kx][co] * w[ky][kx][ci][co]
+// The kx loop is folded into the MFMA N dimension: T[u][x'][(kx,ci)] = sum_{ky,co} dz[u+P-ky][x'][co] * w[ky][kx][ci][co]
+// is one 32 x 32 x (KS*CZ) GEMM per output row (32 positions x', KS*CI <= 32 columns, no padded channels), and
+// out[u][v][ci] = sum_kx T[u][v+P-kx][(kx,ci)] is a shift-add through a 2 KB LDS tile.  w is the forward kernel
+// (kh,kw,CI,CZ) as stored - its [ky][(kx,ci)][co] order is exactly the B operand.
+template <int KS, int CI>
+__global__ __launch_bounds__(256) void conv_dgrad_fewin_bf16_kernel(const float* __restrict__ dz,
+                                                                    const float* __restrict__ w,
+                                                                    float* __restrict__ out, int N, int H, int W,
+                                                                    int tiles_y, int tiles_x) {
+    constexpr int CZ = 32, P = (KS - 1) / 2, TH = 16, TWO = 32 - (KS - 1);      // TWO output columns per tile
+    constexpr int ROWS = TH + KS - 1, NJ = KS * CI;
+    static_assert(NJ <= 32, "KS * CI must fit one MFMA N tile");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint4* sD = reinterpret_cast<uint4*>(smem_raw);                           // [ROWS*32 px][4 chunks of 8 co]
+    uint4* sW = sD + ROWS * 32 * 4;                                           // [KS*32 rows][4]
+    float* sT = reinterpret_cast<float*>(sW + KS * 32 * 4);                   // [4 waves][32 x'][16]
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles = tiles_y * tiles_x;
+    const int n = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int u0 = (tile / tiles_x) * TH, v0 = (tile % tiles_x) * TWO;
+    // weights: row (ky, j) = w[(ky*NJ + j)*CZ + co], j < NJ; zero rows above
+    for (int item = tid; item < KS * 32 * 4; item += 256) {
+        const int q = item & 3, row = item >> 2, j = row & 31, ky = row >> 5;
+        float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (j < NJ) {
+            const float* src = w + ((long)(ky * NJ + j)) * CZ + q * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = src[e];
+        }
+        const bf16x8 b = pack8(f);
+        sW[row * 4 + (q ^ ((row >> 2) & 3))] = *reinterpret_cast<const uint4*>(&b);
+    }
+    // dz tile: rows u0-P .. u0+TH+P-1... (row index rr <-> image row u0 + rr - (KS-1-P)), columns v0-P+... 32 positions
+    for (int item = tid; item < ROWS * 32 * 4; item += 256) {
+        const int q = item & 3, pix = item >> 2, xx = pix & 31, rr = pix >> 5;
+        const int gy = u0 + rr - (KS - 1 - P), gx = v0 - (KS - 1 - P) + xx;
+        float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            const float* src = dz + (((long)n * H + gy) * W + gx) * CZ + q * 8;
+            const float4 v0_ = *reinterpret_cast<const float4*>(src), v1_ = *reinterpret_cast<const float4*>(src + 4);
+            f[0] = v0_.x; f[1] = v0_.y; f[2] = v0_.z; f[3] = v0_.w; f[4] = v1_.x; f[5] = v1_.y; f[6] = v1_.z; f[7] = v1_.w;
+        }
+        const bf16x8 b = pack8(f);
+        sD[pix * 4 + (q ^ ((pix >> 2) & 3))] = *reinterpret_cast<const uint4*>(&b);
+    }
+    __syncthreads();
+    float* myT = sT + wave * 32 * 16;
+    for (int ur = wave; ur < TH; ur += 4) {
+        f32x16 acc;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+        // dz row needed for (output row u0+ur, tap ky): image row u0+ur+P-ky  ->  tile row rr = ur + (KS-1) - ky
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+            const int pix = (ur + (KS - 1) - ky) * 32 + (lane & 31);
+            const int row = ky * 32 + (lane & 31);
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int c = h2 * 2 + half;
+                const uint4 av = sD[pix * 4 + (c ^ ((pix >> 2) & 3))];
+                const uint4 bv = sW[row * 4 + (c ^ ((row >> 2) & 3))];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&av),
+                                                              *reinterpret_cast<const bf16x8*>(&bv), acc, 0, 0, 0);
+            }
+        }
+        // T[x'][j] -> LDS (only the NJ real columns), then the kx shift-add
+        if ((lane & 31) < 16) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) myT[((j & 3) + 8 * (j >> 2) + 4 * half) * 16 + (lane & 31)] = acc[j];
+        }
+        __syncthreads();                             // TH % 4 == 0: every wave runs the same trip count
+        const int u = u0 + ur;
+        for (int o = lane; o < TWO * CI; o += 64) {
+            const int vi = o / CI, ci = o % CI, v = v0 + vi;
+            float s = 0.f;
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) s += myT[(vi + (KS - 1) - kx) * 16 + kx * CI + ci];
+            if (u < H && v < W) out[(((long)n * H + u) * W + v) * CI + ci] = s;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+/* FAN front end in throughput mode.  Few INPUT channels (cin 3|4, float32 HWIO weights, converted in-kernel). */
+int nimg_conv2d_fwd_smallc_bf16(const float* in, int cin, const float* w, const float* bias, float* out, int cout,
+                                int n, int h, int wd, int ks, int pad_mode, int act, float alpha, void* stream) {
+    if (!in || !w || !out || n < 0 || h <= 0 || wd <= 0 || cout <= 0 || pad_mode < 0 || pad_mode > 2) return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int ty = cdiv(h, 16), tx = cdiv(wd, 16);
+    const long total_tiles = (long)ty * tx * n;
+    const int tpw = total_tiles >= 8192 ? 8 : (total_tiles >= 2048 ? 2 : 1);
+#define NIMG_FP(KS_, C_, TN_)                                                                                     \
+    do {                                                                                                          \
+        constexpr int THH = 16 + KS_ - 1, NPIXH = THH * THH, PS = ((NPIXH + 31) / 32) * 32 + 2;                    \
+        constexpr int KP = (KS_ * KS_ * C_ + 15) / 16 * 16;                                                       \
+        constexpr size_t lds = (size_t)((C_ * PS * 4 + 15) / 16 * 16) + (size_t)TN_ * KP * 2 +                    \
+                               (size_t)4 * 32 * (TN_ + EPI_PAD) * sizeof(float);                                  \
+        const long blocks = cdiv(total_tiles, tpw) * (long)cdiv(cout, TN_);                                       \
+        hipLaunchKernelGGL((conv_fwd_packed_bf16_kernel<KS_, C_, TN_>), dim3((unsigned)blocks), dim3(256), lds, s, \
+                           in, w, bias, out, n, h, wd, cout, pad_mode, act, alpha, ty, tx, tpw);                  \
+    } while (0)
+    if (ks == 5 && cin == 3) { if (cout > 32) NIMG_FP(5, 3, 64); else NIMG_FP(5, 3, 32); }
+    else if (ks == 5 && cin == 4) { if (cout > 32) NIMG_FP(5, 4, 64); else NIMG_FP(5, 4, 32); }
+    else if (ks == 3 && cin == 3) { if (cout > 32) NIMG_FP(3, 3, 64); else NIMG_FP(3, 3, 32); }
+    else if (ks == 3 && cin == 4) { if (cout > 32) NIMG_FP(3, 4, 64); else NIMG_FP(3, 4, 32); }
+    else return NIMG_ERR_ARG;
+#undef NIMG_FP
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+/* input gradient of a (ks,ks,ci,32) SAME stride-1 convolution towards its ci (= 3) input channels; w = the FORWARD
+ * kernel as stored (not flipped) */
+int nimg_conv2d_dgrad_fewin_bf16(const float* dz, const float* w, float* out, int ci, int cz, int n, int h, int wd,
+                                 int ks, void* stream) {
+    if (!dz || !w || !out || n < 0 || h <= 0 || wd <= 0) return NIMG_ERR_ARG;
+    if (cz != 32 || ci != 3 || ks != 5) return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    constexpr int KS = 5, TH = 16, TWO = 32 - (KS - 1), ROWS = TH + KS - 1;
+    const int ty = cdiv(h, TH), tx = cdiv(wd, TWO);
+    constexpr size_t lds = (size_t)(ROWS * 32 * 4 + KS * 32 * 4) * sizeof(uint4) + 4 * 32 * 16 * sizeof(float);
+    hipLaunchKernelGGL((conv_dgrad_fewin_bf16_kernel<5, 3>), dim3((unsigned)((long)n * ty * tx)), dim3(256), lds,
+                       (hipStream_t)stream, dz, w, out, n, h, wd, ty, tx);
+    NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }
 

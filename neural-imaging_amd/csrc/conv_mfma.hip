@@ -169,6 +169,40 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
         }
     }
 
+    // ---- epilogue, vector form: accumulators turned around through LDS so each lane stores 16 B along the channels
+    if ((p.O1 & 3) == 0 && (p.O2 & 3) == 0) {
+        float* elds = reinterpret_cast<float*>(smem) + wave * (32 * (NI * 32 + EPI_PAD));
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            epilogue_via_lds<NI>(acc[mi], elds, lane, [&](int row, int c, float4 v) {
+                const int co = co0 + wn * NI * 32 + c;
+                if (co >= Cout) return;
+                const int P = (wm * MI + mi) * 32 + row;
+                const int img = P / (TH * TW), rem = P % (TH * TW);
+                const int oy = ty0 + rem / TW, ox = tx0 + rem % TW, n = grp * NB + img;
+                if (n >= p.N || oy >= p.Hout || ox >= p.Wout) return;
+                const long pixoff = ((long)n * p.Hout + oy) * p.Wout + ox;
+                if (p.bias) {
+                    const float4 b = *reinterpret_cast<const float4*>(p.bias + co);
+                    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                }
+                if (p.act == 1) {
+                    v.x = lrelu(v.x, p.alpha); v.y = lrelu(v.y, p.alpha); v.z = lrelu(v.z, p.alpha); v.w = lrelu(v.w, p.alpha);
+                }
+                if (co < p.O1) {
+                    if (p.act1) {
+                        const float4 m = *reinterpret_cast<const float4*>(p.act1 + pixoff * p.O1 + co);
+                        v.x *= m.x > 0.f ? 1.0f : p.alpha; v.y *= m.y > 0.f ? 1.0f : p.alpha;
+                        v.z *= m.z > 0.f ? 1.0f : p.alpha; v.w *= m.w > 0.f ? 1.0f : p.alpha;
+                    }
+                    *reinterpret_cast<float4*>(p.out1 + pixoff * p.O1 + co) = v;
+                } else {
+                    *reinterpret_cast<float4*>(p.out2 + pixoff * p.O2 + (co - p.O1)) = v;
+                }
+            });
+        }
+        return;
+    }
     // ---- epilogue: bias, activation, optional lrelu' mask of the previous layer, NHWC store (128 B per half-wave)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
@@ -319,7 +353,9 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
     constexpr int THH = (TH - 1) * STRIDE + KS, TWH = (TW - 1) * STRIDE + KS;
     constexpr int NPIXH = NB * THH * TWH;
     constexpr int PS = ((NPIXH + 31) / 32) * 32 + 2;
-    constexpr size_t lds = (size_t)(CK * PS + KS * KS * CK * TN) * sizeof(float);
+    constexpr size_t lds_tiles = (size_t)(CK * PS + KS * KS * CK * TN) * sizeof(float);
+    constexpr size_t lds_epi = (size_t)4 * 32 * (TN + EPI_PAD) * sizeof(float);
+    constexpr size_t lds = lds_tiles > lds_epi ? lds_tiles : lds_epi;
     ConvParams q = p;
     q.tiles_y = cdiv(p.Hout, TH);
     q.tiles_x = cdiv(p.Wout, TW);

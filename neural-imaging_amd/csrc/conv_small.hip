@@ -114,3 +114,93 @@ int nimg_internal_conv_fewout(const float* in, int cin, const float* w, const fl
     if (cout == 3 && ks == 3) return cin <= 4 ? launch_fewout<3, 3, 3>(p, s) : launch_fewout<3, 3, 8>(p, s);
     return NIMG_ERR_ARG;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradient of a tiny convolution (Cin <= 4 AND Cout <= 4: the ConstrainedConv2D 5x5x3x3 filter, 225 numbers):
+// one thread per (tap, ci, co) walks the pixels of a 32x32 tile held in LDS (both operands are broadcast / conflict-free
+// reads), persistent workgroups loop over tiles and write one partial per workgroup; a fixed-order reduction follows.
+// HBM-bound on paper (reads x and dz once, 2 x 0.25 GB for 320 images), exact float32 in both compute modes.
+namespace {
+
+struct TinyWParams {
+    const float* in;
+    const float* dz;
+    float* partial;      // [gridDim.x][taps*cin*cout]
+    int N, H, W, pad, pad_mode, tiles_y, tiles_x;
+};
+
+template <int KS, int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv_wgrad_tiny_kernel(const TinyWParams p) {
+    constexpr int T = 32, TH = T + KS - 1, NOUT = KS * KS * CIN * COUT;
+    static_assert(NOUT <= 256, "one thread per weight");
+    __shared__ float sx[TH * TH * CIN];
+    __shared__ float sd[T * T * COUT];
+    const int tid = threadIdx.x;
+    const int co = tid % COUT, ci = (tid / COUT) % CIN, tap = tid / (COUT * CIN);
+    const int ky = tap / KS, kx = tap % KS;
+    const long total = (long)p.N * p.tiles_y * p.tiles_x;
+    float acc = 0.f;
+    for (long t = blockIdx.x; t < total; t += gridDim.x) {
+        const int n = (int)(t / (p.tiles_y * p.tiles_x)), tile = (int)(t % (p.tiles_y * p.tiles_x));
+        const int y0 = (tile / p.tiles_x) * T, x0 = (tile % p.tiles_x) * T;
+        __syncthreads();
+        for (int i = tid; i < TH * TH; i += 256) {
+            int gy = y0 - p.pad + i / TH, gx = x0 - p.pad + i % TH;
+            const bool ok = map_coord(gy, p.H, p.pad_mode) && map_coord(gx, p.W, p.pad_mode);
+            const float* src = p.in + (((long)n * p.H + gy) * p.W + gx) * CIN;
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) sx[i * CIN + c] = ok ? src[c] : 0.f;
+        }
+        for (int i = tid; i < T * T; i += 256) {
+            const int gy = y0 + i / T, gx = x0 + i % T;
+            const bool ok = gy < p.H && gx < p.W;
+            const float* src = p.dz + (((long)n * p.H + gy) * p.W + gx) * COUT;
+#pragma unroll
+            for (int c = 0; c < COUT; ++c) sd[i * COUT + c] = ok ? src[c] : 0.f;
+        }
+        __syncthreads();
+        if (tid < NOUT) {
+            for (int y = 0; y < T; ++y) {
+                const float* xr = sx + ((y + ky) * TH + kx) * CIN + ci;
+                const float* dr = sd + y * T * COUT + co;
+#pragma unroll 8
+                for (int x = 0; x < T; ++x) acc = fmaf(xr[x * CIN], dr[x * COUT], acc);
+            }
+        }
+    }
+    if (tid < NOUT) p.partial[(long)blockIdx.x * NOUT + tid] = acc;
+}
+
+__global__ void tiny_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int count, int blocks,
+                                   int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float s = 0.f;
+    for (int b = 0; b < blocks; ++b) s += partial[(long)b * count + i];
+    dw[i] = accumulate ? dw[i] + s : s;
+}
+
+}  // namespace
+
+constexpr int TINY_BLOCKS = 1024;
+
+size_t nimg_internal_wgrad_tiny_bytes(int ks, int cin, int cout) { return (size_t)TINY_BLOCKS * ks * ks * cin * cout * sizeof(float); }
+
+// internal entry used by the weight-gradient dispatchers; same-size output (stride 1, pad = (ks-1)/2), any pad mode
+int nimg_internal_conv_wgrad_tiny(const float* in, const float* dz, float* dw, int cin, int cout, int n, int h, int wd,
+                                  int ks, int pad, int pad_mode, int accumulate, void* workspace, hipStream_t s) {
+    TinyWParams p;
+    p.in = in; p.dz = dz; p.partial = (float*)workspace; p.N = n; p.H = h; p.W = wd; p.pad = pad; p.pad_mode = pad_mode;
+    p.tiles_y = cdiv(h, 32); p.tiles_x = cdiv(wd, 32);
+    const long total = (long)n * p.tiles_y * p.tiles_x;
+    const int blocks = (int)(total < TINY_BLOCKS ? total : TINY_BLOCKS);
+    if (ks == 5 && cin == 3 && cout == 3) hipLaunchKernelGGL((conv_wgrad_tiny_kernel<5, 3, 3>), dim3(blocks), dim3(256), 0, s, p);
+    else if (ks == 3 && cin == 3 && cout == 3) hipLaunchKernelGGL((conv_wgrad_tiny_kernel<3, 3, 3>), dim3(blocks), dim3(256), 0, s, p);
+    else return NIMG_ERR_ARG;
+    NIMG_CHECK_LAUNCH();
+    const int count = ks * ks * cin * cout;
+    hipLaunchKernelGGL(tiny_reduce_kernel, dim3((count + 255) / 256), dim3(256), 0, s, (const float*)workspace, dw, count,
+                       blocks, accumulate);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}

@@ -14,6 +14,12 @@
 // reduces the slabs in a fixed order (deterministic; no float atomics) and also produces the bias gradient.
 #include "common.h"
 
+// defined in conv_small.hip
+size_t nimg_internal_wgrad_tiny_bytes(int ks, int cin, int cout);
+int nimg_internal_conv_wgrad_tiny(const float* in, const float* dz, float* dw, int cin, int cout, int n, int h, int wd,
+                                  int ks, int pad, int pad_mode, int accumulate, void* workspace, hipStream_t s);
+
+
 namespace {
 
 using namespace nimg;
@@ -357,7 +363,9 @@ size_t nimg_conv2d_wgrad_workspace_bytes(int cin, int cout, int ks_h, int ks_w, 
     const size_t slab = (size_t)ks_h * ks_w * cin * cout * sizeof(float);
     const size_t generic = (slab + cout * sizeof(float)) * wgrad_splits(cin, cout, n, hout, wout);
     const size_t packed = cin <= 4 ? (4 * slab + cout * sizeof(float)) * packed_splits(cout, n, hout, wout) : 0;
-    return generic > packed ? generic : packed;
+    const size_t tiny = (cin <= 4 && cout <= 4) ? nimg_internal_wgrad_tiny_bytes(ks_h, cin, cout) : 0;
+    const size_t m = generic > packed ? generic : packed;
+    return m > tiny ? m : tiny;
 }
 
 int nimg_conv2d_wgrad(const float* in1, int c1, const float* in2, int c2, const float* dz, int cout, float* dw,
@@ -380,6 +388,10 @@ int nimg_conv2d_wgrad(const float* in1, int c1, const float* in2, int c2, const 
     const long count = (long)ks * ks * cin * cout;
     const int rgrid = (int)((count + 255) / 256 > 4096 ? 4096 : (count + 255) / 256);
 
+    // tiny filters (Cin, Cout <= 4): one thread per weight, exact f32 (conv_small.hip)
+    if (c2 == 0 && c1 == 3 && cout == 3 && stride == 1 && (ks == 3 || ks == 5) && hout == h && wout == wd &&
+        pad_t == (ks - 1) / 2 && pad_l == pad_t && !db)
+        return nimg_internal_conv_wgrad_tiny(in1, dz, dw, c1, cout, n, h, wd, ks, pad_t, pad_mode, accumulate, workspace, s);
     // few input channels: (tap, ci)-packed M dimension
     if (c2 == 0 && (c1 == 3 || c1 == 4) && stride == 1 && (ks == 3 || ks == 5)) {
         const int ni = cout <= 32 ? 1 : 2;

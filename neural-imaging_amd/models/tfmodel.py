@@ -26,16 +26,19 @@ class ParamStore(object):
     def __init__(self, specs, device):
         self.specs = OrderedDict(specs)              # name -> shape
         self.device = device
-        total = int(sum(int(np.prod(s)) if len(s) else 1 for s in self.specs.values()))
+        # every parameter starts on a 256-byte boundary of the flat buffer (float4 / uint4 loads in the kernels stay
+        # aligned whatever the element counts are - e.g. the 225-element constrained filter); the gaps stay zero
+        align = 64
+        sizes = [int(np.prod(s)) if len(s) else 1 for s in self.specs.values()]
+        total = int(sum(-(-n // align) * align for n in sizes))
         self.flat = torch.zeros(total, dtype=torch.float32, device=device)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=device)
         self.p, self.g = OrderedDict(), OrderedDict()
         off = 0
-        for name, shape in self.specs.items():
-            n = int(np.prod(shape)) if len(shape) else 1
+        for (name, shape), n in zip(self.specs.items(), sizes):
             self.p[name] = self.flat[off:off + n].view(shape)
             self.g[name] = self.flat_grad[off:off + n].view(shape)
-            off += n
+            off += -(-n // align) * align
         self.m = self.v = None
         self.step = 0
 

@@ -152,6 +152,17 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
     o2 = 0 if out2 is None else out2.shape[3]
     if o1 + o2 != cout or tuple(out.shape[:3]) != (n, ho, wo):
         raise ValueError('output shape mismatch')
+    if COMPUTE == 'bf16' and not _f32_only and _wmode == 0 and c2 == 0 and out2 is None and act_mask is None and \
+            c1 in (3, 4) and ks in (3, 5) and stride == 1 and cout >= 8 and (ho, wo) == (h, wd) and \
+            (pt, pl) == ((ks - 1) // 2, (ks - 1) // 2):
+        _lib.call('nimg_conv2d_fwd_smallc_bf16', _p(x), c1, _p(w), _p(bias), _p(out), cout, n, h, wd, ks, pad_mode,
+                  1 if act == 'leaky_relu' else 0, LRELU_ALPHA, _stream())
+        return out
+    if COMPUTE == 'bf16' and not _f32_only and _wmode == 1 and c2 == 0 and out2 is None and act_mask is None and \
+            c1 == 32 and cout == 3 and ks == 5 and stride == 1 and (ho, wo) == (h, wd) and (pt, pl) == (2, 2) and \
+            pad_mode == 0 and bias is None and act is None:
+        _lib.call('nimg_conv2d_dgrad_fewin_bf16', _p(x), _p(w), _p(out), 3, 32, n, h, wd, 5, _stream())
+        return out
     if COMPUTE == 'bf16' and not _f32_only and c1 % 8 == 0 and c2 % 8 == 0 and cout >= 8:
         wb = weights_bf16(w, _wmode)
         _lib.call('nimg_conv2d_fwd_bf16', _p(x), c1, _p(x2), c2, _p(wb), _p(bias), _p(out), o1, _p(out2), o2,
@@ -206,8 +217,9 @@ def conv2d_wgrad(x, dz, ks, x2=None, stride=1, padding='SAME', pad_mode=0, pads=
         pt = pl = 0
     if dw is None:
         dw = torch.empty((ks, ks, c1 + c2, cout), dtype=torch.float32, device=x.device)
-    if COMPUTE == 'bf16' and c1 % 4 == 0 and c2 % 4 == 0 and cout % 4 == 0 and c1 + c2 >= 8 and \
-            (c2 == 0 or c1 % 8 == 0):
+    packed_ok = c2 == 0 and c1 in (3, 4) and stride == 1 and ks in (3, 5)
+    if COMPUTE == 'bf16' and (packed_ok or (c1 % 4 == 0 and c2 % 4 == 0 and cout % 4 == 0 and c1 + c2 >= 8 and
+                                            (c2 == 0 or c1 % 8 == 0))):
         need = _lib.load().nimg_conv2d_wgrad_bf16_workspace_bytes(c1 + c2, cout, ks, ks, n, ho, wo)
         ws = _ws.get(need, x.device)
         _lib.call('nimg_conv2d_wgrad_bf16', _p(x), c1, _p(x2), c2, _p(dz), cout, _p(dw), _p(db), n, h, wd, ks, stride,

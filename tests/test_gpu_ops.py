@@ -409,7 +409,7 @@ def bf16_mode():
     ops.set_compute('f32')
 
 
-BF16_CASES = [(2, 32, 32, 32, 0, 64, 5, 1), (2, 16, 16, 16, 16, 32, 3, 1), (5, 8, 8, 64, 0, 128, 3, 1),
+BF16_CASES = [(2, 40, 72, 3, 0, 32, 5, 1), (2, 24, 24, 4, 0, 64, 3, 1), (2, 32, 32, 32, 0, 64, 5, 1), (2, 16, 16, 16, 16, 32, 3, 1), (5, 8, 8, 64, 0, 128, 3, 1),
               (2, 20, 24, 8, 0, 24, 3, 1), (3, 16, 16, 64, 0, 64, 1, 1), (2, 32, 32, 64, 0, 128, 5, 2)]
 
 
@@ -434,3 +434,16 @@ def test_conv2d_bf16_mode(dev, bf16_mode, case):
     if stride == 1:
         dx = ops.conv2d_dgrad(g(dz, dev), g(wt.detach().numpy(), dev), (h, w))
         assert_close(dx.cpu().numpy(), x.grad.numpy(), 0.0, 1.5e-2, what='bf16 dgrad {}'.format(case))
+
+
+def test_fan_conv1_input_gradient_bf16(dev, bf16_mode):
+    """kx-folded MFMA input gradient of the FAN's first convolution (5x5, 3 <- 32), incl. partial tiles."""
+    from neural_imaging_amd import ops
+    for (n, h, w) in [(2, 32, 56), (1, 48, 40), (3, 16, 16)]:
+        x = to64(rnd((n, h, w, 3), 1)).requires_grad_(True)
+        wt = to64(rnd((5, 5, 3, 32), 3, -0.2, 0.2))
+        z = T.conv2d(x, wt, None, 1, 'SAME')
+        dz = rnd(tuple(z.shape), 5)
+        (z * to64(dz)).sum().backward()
+        dx = ops.conv2d_dgrad(g(dz, dev), g(wt.numpy(), dev), (h, w))
+        assert_close(dx.cpu().numpy(), x.grad.numpy(), 0.0, 1.5e-2, what='fewin dgrad {}'.format((n, h, w)))
