@@ -213,6 +213,19 @@ int nimg_conv2d_fwd_smallc_bf16(const float* in, int cin, const float* w, const 
 int nimg_conv2d_dgrad_fewin_bf16(const float* dz, const float* w, float* out, int ci, int cz, int n, int h, int wd,
                                  int ks, void* stream);
 
+/* manipulation_awgn / _gamma / _median, helpers/tf_helpers.py:79-110.  awgn takes the noise tensor from the caller
+ * (tf.random.normal is not reproducible); its mask is one byte per ELEMENT.  median: kernel odd <= 9,
+ * REFLECT pad, sel (n,h,w,3) uint8 = window index of the selected element; nimg_median_bwd scatters with atomic adds into
+ * a ZEROED dx. */
+int nimg_awgn_fwd(const float* x, const float* noise, float* y, uint8_t* mask, long count, float strength,
+                  void* stream);
+int nimg_awgn_bwd(const float* x, const float* noise, const float* dy, const uint8_t* mask, float* dx, long count,
+                  float strength, void* stream);
+int nimg_gamma_fwd(const float* x, float* y, long count, float gamma, void* stream);
+int nimg_gamma_bwd(const float* x, const float* dy, float* dx, long count, float gamma, void* stream);
+int nimg_median_fwd(const float* x, float* y, uint8_t* sel, int n, int h, int w, int kernel, void* stream);
+int nimg_median_bwd(const float* dy, const uint8_t* sel, float* dx, int n, int h, int w, int kernel, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,12 @@ PROTOTYPES = {
     'nimg_conv2d_fwd_smallc_bf16': (c_int, [P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                             c_float, P]),
     'nimg_conv2d_dgrad_fewin_bf16': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    'nimg_awgn_fwd': (c_int, [P, P, P, P, c_long, c_float, P]),
+    'nimg_awgn_bwd': (c_int, [P, P, P, P, P, c_long, c_float, P]),
+    'nimg_gamma_fwd': (c_int, [P, P, c_long, c_float, P]),
+    'nimg_gamma_bwd': (c_int, [P, P, P, c_long, c_float, P]),
+    'nimg_median_fwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    'nimg_median_bwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     'nimg_sparse_axis_apply': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
 }
 

@@ -422,3 +422,160 @@ int nimg_avgpool_bwd(const float* dy, float* dx, int n, int h, int w, int c, int
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------
+// awgn / gamma / median manipulations (helpers/tf_helpers.py:79-110); soft_quantization = round in the forward pass,
+// 1 - cos(2 pi x) in the backward pass (tf_helpers.py:271-277).
+namespace {
+
+// y = clip(softq(x + s * noise), 0, 1);   element-wise, mask byte per ELEMENT (1 = gradient passes the clip)
+__global__ void awgn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ noise, float* __restrict__ y,
+                                uint8_t* __restrict__ mask, long count, float strength) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        const float q = rintf(255.0f * (x[i] + strength * noise[i])) / 255.0f;
+        y[i] = fminf(fmaxf(q, 0.f), 1.f);
+        if (mask) mask[i] = (q >= 0.f && q <= 1.f) ? 1 : 0;
+    }
+}
+__global__ void awgn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ noise,
+                                const float* __restrict__ dy, const uint8_t* __restrict__ mask,
+                                float* __restrict__ dx, long count, float strength) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        const float v = 255.0f * (x[i] + strength * noise[i]);
+        const float d = 1.0f - __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(v));      // cos(2 pi v)
+        dx[i] = mask[i] ? dy[i] * d : 0.f;
+    }
+}
+
+// y = pow(clip(softq(pow(x, g)), 1/255, 1), 1/g)
+__global__ void gamma_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long count, float g) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        const float p = powf(x[i], g);
+        const float q = rintf(255.0f * p) / 255.0f;
+        y[i] = powf(fminf(fmaxf(q, 1.0f / 255.0f), 1.f), 1.0f / g);
+    }
+}
+__global__ void gamma_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                 long count, float g) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        const float xv = x[i];
+        const float p = powf(xv, g);
+        const float q = rintf(255.0f * p) / 255.0f;
+        const float c = fminf(fmaxf(q, 1.0f / 255.0f), 1.f);
+        float grad = dy[i] * (1.0f / g) * powf(c, 1.0f / g - 1.0f);                    // d pow(c, 1/g)
+        grad = (q >= 1.0f / 255.0f && q <= 1.f) ? grad : 0.f;                          // clip
+        grad *= 1.0f - __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(255.0f * p));     // soft quantisation
+        dx[i] = grad * g * powf(xv, g - 1.0f);                                         // d pow(x, g)
+    }
+}
+
+// k x k median (k odd <= 9), REFLECT pad; sel (optional) = index (0..k*k-1, row-major in the window) of the element that
+// was selected, so that the backward can route the gradient to it like tf.nn.top_k's gradient does.
+__global__ void median_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ sel, int n,
+                                  int h, int w, int k) {
+    const long total = (long)n * h * w * 3;
+    const int area = k * k, r = k / 2, rank = (area + 1) / 2 - 1;          // descending order, index floor-1
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % 3);
+        long t = i / 3;
+        const int px = (int)(t % w);
+        t /= w;
+        const int py = (int)(t % h);
+        const long im = t / h;
+        float v[81];
+        for (int a = 0; a < k; ++a) {
+            int yy = py + a - r;
+            map_coord(yy, h, 2);
+            for (int b = 0; b < k; ++b) {
+                int xx = px + b - r;
+                map_coord(xx, w, 2);
+                v[a * k + b] = x[((im * h + yy) * w + xx) * 3 + ch];
+            }
+        }
+        // the element with exactly `rank` strictly-greater-or-earlier-equal elements (stable descending order)
+        int pick = 0;
+        for (int a = 0; a < area; ++a) {
+            int before = 0;
+            for (int b = 0; b < area; ++b) before += (v[b] > v[a]) || (v[b] == v[a] && b < a);
+            if (before == rank) pick = a;
+        }
+        y[i] = v[pick];
+        if (sel) sel[i] = (uint8_t)pick;
+    }
+}
+__global__ void median_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ sel,
+                                  float* __restrict__ dx, int n, int h, int w, int k) {
+    const long total = (long)n * h * w * 3;
+    const int r = k / 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % 3);
+        long t = i / 3;
+        const int px = (int)(t % w);
+        t /= w;
+        const int py = (int)(t % h);
+        const long im = t / h;
+        const int s = sel[i];
+        int yy = py + s / k - r, xx = px + s % k - r;
+        map_coord(yy, h, 2);
+        map_coord(xx, w, 2);
+        atomicAdd(dx + ((im * h + yy) * w + xx) * 3 + ch, dy[i]);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int nimg_awgn_fwd(const float* x, const float* noise, float* y, uint8_t* mask, long count, float strength,
+                  void* stream) {
+    if (!x || !noise || !y || count < 0) return NIMG_ERR_ARG;
+    if (count == 0) return NIMG_OK;
+    hipLaunchKernelGGL(awgn_fwd_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, x, noise, y, mask,
+                       count, strength);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+int nimg_awgn_bwd(const float* x, const float* noise, const float* dy, const uint8_t* mask, float* dx, long count,
+                  float strength, void* stream) {
+    if (!x || !noise || !dy || !mask || !dx || count < 0) return NIMG_ERR_ARG;
+    if (count == 0) return NIMG_OK;
+    hipLaunchKernelGGL(awgn_bwd_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, x, noise, dy, mask,
+                       dx, count, strength);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+int nimg_gamma_fwd(const float* x, float* y, long count, float gamma, void* stream) {
+    if (!x || !y || count < 0 || gamma <= 0.f) return NIMG_ERR_ARG;
+    if (count == 0) return NIMG_OK;
+    hipLaunchKernelGGL(gamma_fwd_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, x, y, count, gamma);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+int nimg_gamma_bwd(const float* x, const float* dy, float* dx, long count, float gamma, void* stream) {
+    if (!x || !dy || !dx || count < 0 || gamma <= 0.f) return NIMG_ERR_ARG;
+    if (count == 0) return NIMG_OK;
+    hipLaunchKernelGGL(gamma_bwd_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, count,
+                       gamma);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+int nimg_median_fwd(const float* x, float* y, uint8_t* sel, int n, int h, int w, int kernel, void* stream) {
+    if (!x || !y || n < 0 || kernel < 1 || kernel > 9 || !(kernel & 1) || h <= kernel / 2 || w <= kernel / 2)
+        return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    hipLaunchKernelGGL(median_fwd_kernel, dim3(grid_for((long)n * h * w * 3)), dim3(256), 0, (hipStream_t)stream, x, y,
+                       sel, n, h, w, kernel);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+/* dx must be zero-initialised by the caller (gradients are scattered with atomic adds) */
+int nimg_median_bwd(const float* dy, const uint8_t* sel, float* dx, int n, int h, int w, int kernel, void* stream) {
+    if (!dy || !sel || !dx || n < 0 || kernel < 1 || kernel > 9 || !(kernel & 1)) return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    hipLaunchKernelGGL(median_bwd_kernel, dim3(grid_for((long)n * h * w * 3)), dim3(256), 0, (hipStream_t)stream, dy,
+                       sel, dx, n, h, w, kernel);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+}  // extern "C"

@@ -4,8 +4,7 @@ the reference's helpers/tf_helpers.py (manipulation_* :68-184, mse :31-32); each
 with forward(x, strength, out) / backward(ctx, dy), which is what the workflow's training step uses.
 
 Implemented: sharpen (hsv=True, incl. the S-channel corner-tap quirk), resample (bilinear down+up, any factor),
-gaussian (5x5, any std).  awgn / gamma / median (tf_helpers.py:79-110) are not in the default manipulation set
-(train_manipulation.py:115) and raise NotImplementedError until built.
+gaussian (5x5, any std), awgn (device-side noise), gamma, median (odd kernels up to 9).
 """
 import numpy as np
 import torch
@@ -118,16 +117,60 @@ def manipulation_gaussian(x, kernel, std, skip_clip=False):
     return DeviceArray(_gaussian.forward(to_device(x, _dev(x)), std, skip_clip=skip_clip)[0])
 
 
+class Awgn(object):
+    """manipulation_awgn(x, strength / 255) (tf_helpers.py:79-82; the workflow passes strength/255, workflows/...:122).
+    The noise is drawn on the device per call (per-rank generator under data parallelism) and kept for the backward."""
+
+    def forward(self, x, strength=5.1, out=None, training=False, noise=None):
+        s = float(strength) / 255.0
+        noise = torch.randn_like(x) if noise is None else noise
+        y, mask = ops.awgn_fwd(x, noise, s, out=out, want_mask=training)
+        return y, ({'x': x, 'noise': noise, 'mask': mask, 's': s} if training else None)
+
+    def backward(self, ctx, dy):
+        return ops.awgn_bwd(ctx['x'], ctx['noise'], dy, ctx['mask'], ctx['s'])
+
+
+class Gamma(object):
+    """manipulation_gamma(x, strength) (tf_helpers.py:85-88)"""
+
+    def forward(self, x, strength=3, out=None, training=False):
+        y = ops.gamma_fwd(x, strength, out=out)
+        return y, ({'x': x, 'g': float(strength)} if training else None)
+
+    def backward(self, ctx, dy):
+        return ops.gamma_bwd(ctx['x'], dy, ctx['g'])
+
+
+class Median(object):
+    """manipulation_median(x, kernel) (tf_helpers.py:91-110): even kernels are bumped to the next odd size."""
+
+    @staticmethod
+    def _k(kernel):
+        kernel = int(kernel)
+        if kernel % 2 == 0:
+            kernel += 1
+        return max(kernel, 1)
+
+    def forward(self, x, kernel=3, out=None, training=False):
+        k = self._k(kernel)
+        y, sel = ops.median_fwd(x, k, out=out, want_sel=training)
+        return y, ({'sel': sel, 'k': k} if training else None)
+
+    def backward(self, ctx, dy):
+        return ops.median_bwd(dy, ctx['sel'], ctx['k'])
+
+
 def manipulation_awgn(x, strength=0.025):
-    raise NotImplementedError('awgn is not in the default manipulation set; not built yet')
+    return DeviceArray(Awgn().forward(to_device(x, _dev(x)), 255.0 * strength)[0])
 
 
 def manipulation_gamma(x, strength=2.0):
-    raise NotImplementedError('gamma is not in the default manipulation set; not built yet')
+    return DeviceArray(Gamma().forward(to_device(x, _dev(x)), strength)[0])
 
 
 def manipulation_median(x, kernel=3):
-    raise NotImplementedError('median is not in the default manipulation set; not built yet')
+    return DeviceArray(Median().forward(to_device(x, _dev(x)), kernel)[0])
 
 
 def mse(a, b):

@@ -564,3 +564,51 @@ def l2_loss(target, y, grad_scale=None, grad_out=None, accumulate=False):
     _lib.call('nimg_l2_loss', _p(target), _p(y), _p(loss), _p(g), y.numel(), float(grad_scale or 0.0),
               1 if accumulate else 0, _p(ws), ws.numel(), _stream())
     return loss, g
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# awgn / gamma / median manipulations
+def awgn_fwd(x, noise, strength, out=None, want_mask=True):
+    _f32(x, noise, out)
+    y = torch.empty_like(x) if out is None else out
+    mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_mask else None
+    _lib.call('nimg_awgn_fwd', _p(x), _p(noise), _p(y), _p(mask), x.numel(), float(strength), _stream())
+    return y, mask
+
+
+def awgn_bwd(x, noise, dy, mask, strength):
+    _f32(x, noise, dy)
+    dx = torch.empty_like(x)
+    _lib.call('nimg_awgn_bwd', _p(x), _p(noise), _p(dy), _p(mask), _p(dx), x.numel(), float(strength), _stream())
+    return dx
+
+
+def gamma_fwd(x, g, out=None):
+    _f32(x, out)
+    y = torch.empty_like(x) if out is None else out
+    _lib.call('nimg_gamma_fwd', _p(x), _p(y), x.numel(), float(g), _stream())
+    return y
+
+
+def gamma_bwd(x, dy, g):
+    _f32(x, dy)
+    dx = torch.empty_like(x)
+    _lib.call('nimg_gamma_bwd', _p(x), _p(dy), _p(dx), x.numel(), float(g), _stream())
+    return dx
+
+
+def median_fwd(x, kernel, out=None, want_sel=True):
+    _f32(x, out)
+    n, h, w, _ = x.shape
+    y = torch.empty_like(x) if out is None else out
+    sel = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_sel else None
+    _lib.call('nimg_median_fwd', _p(x), _p(y), _p(sel), n, h, w, int(kernel), _stream())
+    return y, sel
+
+
+def median_bwd(dy, sel, kernel):
+    _f32(dy)
+    n, h, w, _ = dy.shape
+    dx = torch.zeros_like(dy)
+    _lib.call('nimg_median_bwd', _p(dy), _p(sel), _p(dx), n, h, w, int(kernel), _stream())
+    return dx

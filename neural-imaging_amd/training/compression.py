@@ -1,0 +1,56 @@
+"""
+DCN pre-training loop - counterpart of the reference's training/compression.py:123-309: per batch
+host-side flips (:195-197), dcn.training_step(batch, lr), lr x0.5 every 1000 epochs by default (train_dcn.py:105-107),
+validation every `validation_schedule` epochs, progress.json + checkpoint; NaN loss aborts like the reference's
+SSIM-collapse guard (:292-294).
+"""
+import json
+import os
+from collections import OrderedDict
+
+import numpy as np
+
+from . import validation
+
+
+def train_dcn(dcn, training, data, directory='./data/models/dcn/playground/', overwrite=False):
+    spec = {'n_epochs': 1500, 'batch_size': 50, 'patch_size': dcn.patch_size, 'learning_rate': 1e-4,
+            'learning_rate_reduction_schedule': 1000, 'learning_rate_reduction_factor': 0.5,
+            'validation_schedule': 100, 'augmentation_probs': {'flip_h': 0.5, 'flip_v': 0.5}, 'seed': 1234}
+    spec.update(training or {})
+    out = os.path.join(directory, dcn.model_code.split('/')[0], dcn.scoped_name)
+    if os.path.exists(out) and not overwrite:
+        return out
+    rng = np.random.RandomState(spec['seed'])
+    n_batches = data.count_training // spec['batch_size']
+    lr = spec['learning_rate']
+    summary = OrderedDict([('model', dcn.summary()), ('epochs', spec['n_epochs']), ('batch', spec['batch_size']),
+                           ('lr', spec['learning_rate'])])
+    for epoch in range(spec['n_epochs']):
+        stats = {'loss': [], 'entropy': []}
+        for batch_id in range(n_batches):
+            bx = data.next_training_batch(batch_id, spec['batch_size'], spec['patch_size'])
+            bx = bx[1] if isinstance(bx, tuple) else bx
+            if rng.uniform() < spec['augmentation_probs']['flip_h']:
+                bx = bx[:, :, ::-1, :]
+            if rng.uniform() < spec['augmentation_probs']['flip_v']:
+                bx = bx[:, ::-1, :, :]
+            res = dcn.training_step(np.ascontiguousarray(bx), lr)
+            if not np.isfinite(res['loss']):
+                raise RuntimeError('DCN training diverged (non-finite loss)')
+            stats['loss'].append(res['loss'])
+            stats['entropy'].append(float(res['entropy']))
+        dcn.log_metric('loss', 'training', stats['loss'])
+        dcn.log_metric('entropy', 'training', stats['entropy'])
+        if epoch % spec['validation_schedule'] == 0:
+            vals = validation.validate_dcn(dcn, data, out, epoch=epoch)
+            for k, v in vals.items():
+                dcn.log_metric(k, 'validation', v)
+            os.makedirs(out, exist_ok=True)
+            with open(os.path.join(out, 'progress.json'), 'w') as f:
+                json.dump({'performance': dcn.performance, 'summary': summary, 'args': dcn.get_hyperparameters()}, f,
+                          indent=4, default=lambda o: float(o))
+            dcn.save_model(out, epoch, save_args=True, quiet=True)
+        if epoch > 0 and epoch % spec['learning_rate_reduction_schedule'] == 0:
+            lr *= spec['learning_rate_reduction_factor']
+    return out

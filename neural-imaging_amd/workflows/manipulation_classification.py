@@ -69,8 +69,8 @@ class ManipulationClassification(object):
         self._operations = OrderedDict()
         self._forensics_classes = ['native']
         builders = OrderedDict([('sharpen', tf_helpers.Sharpen), ('resample', tf_helpers.Resample),
-                                ('gaussian', tf_helpers.Gaussian), ('jpeg', None), ('awgn', None), ('gamma', None),
-                                ('median', None)])
+                                ('gaussian', tf_helpers.Gaussian), ('jpeg', None), ('awgn', tf_helpers.Awgn),
+                                ('gamma', tf_helpers.Gamma), ('median', tf_helpers.Median)])
         for name, cls in builders.items():
             if name not in manipulations_set:
                 continue
@@ -87,8 +87,11 @@ class ManipulationClassification(object):
             self.codec = jpeg.JPEG(device=self.device, **self._distribution['compression_params'])
         elif self._distribution['compression'] == 'dcn':
             from ..models import compression
-            self.codec = compression.TwitterDCN.restore(self._distribution['compression_params']['dirname'],
-                                                        device=self.device)
+            params = self._distribution['compression_params']
+            self.codec = params['model'] if 'model' in params else compression.TwitterDCN.restore(
+                params['dirname'], device=self.device)
+            self._distribution = dict(self._distribution, compression_params={
+                k: v for k, v in params.items() if k != 'model'})
         elif self._distribution['compression'] == 'none':
             self.codec = None
         else:
@@ -97,6 +100,7 @@ class ManipulationClassification(object):
             raise ValueError('The current codec does not appear to be trainable: {}!'.format(
                 None if self.codec is None else self.codec.class_name))
 
+        self._is_dcn = self._distribution['compression'] == 'dcn'
         fan_input_patch = 2 * raw_patch_size // self.downsampling_factor
         self.fan = forensics.FAN(n_classes=self.n_classes, patch_size=fan_input_patch, device=self.device,
                                  **(fan_args or {}))
@@ -167,10 +171,8 @@ class ManipulationClassification(object):
         Y = self.nip.forward(x)[0]
         m, _ = self._manipulations(Y, augment)
         c = self._downsampling(m)
-        if self.codec is None:
-            C, entropy = c, np.nan
-        else:
-            C, entropy = self.codec.forward(c)[0], np.nan
+        C, ent, _ = self._codec_forward(c)
+        entropy = np.nan if ent is None else DeviceArray(ent)
         probs = self.fan.forward(C)[0]
         return DeviceArray(Y), DeviceArray(c), DeviceArray(C), entropy, DeviceArray(probs)
 
@@ -185,46 +187,77 @@ class ManipulationClassification(object):
 
     def run_compression(self, batch_y, return_entropy=False):
         y = to_device(batch_y, self.device)
-        out = DeviceArray(y if self.codec is None else self.codec.forward(y)[0])
-        return (out, np.nan) if return_entropy else out
+        C, ent, _ = self._codec_forward(y)
+        return (DeviceArray(C), np.nan if ent is None else DeviceArray(ent)) if return_entropy else DeviceArray(C)
 
     def run_rgb_to_fan(self, batch_Y):
         m = self._manipulations(to_device(batch_Y, self.device))[0]
         c = self._downsampling(m)
-        return (c if self.codec is None else self.codec.forward(c)[0]).cpu().numpy()
+        return self._codec_forward(c)[0].cpu().numpy()
 
     def run_rgb_to_probabilities(self, batch_Y):
         C = torch.from_numpy(self.run_rgb_to_fan(batch_Y)).to(self.device)
         return self.fan.forward(C)[0].cpu().numpy()
 
     # -- training ------------------------------------------------------------------------------------------------
+    def _codec_forward(self, c, training=False):
+        """-> (C, entropy or None, ctx); the learned codec returns its entropy, JPEG has none (jpeg.py:245-249)."""
+        if self.codec is None:
+            return c, None, None
+        if self._is_dcn:
+            return self.codec.forward(c, training=training)
+        C, ctx = self.codec.forward(c, training=training)
+        return C, None, ctx
+
     def training_step(self, batch_x, batch_y, lambda_nip=0, lambda_dcn=0, augment=False, learning_rate=1e-4):
         """One joint optimisation step (workflows/...:260-285).  Returns (loss, {'ce','nip','dcn'})."""
         x = to_device(batch_x, self.device)
         target = to_device(batch_y, self.device)
         b = x.shape[0]
         train_nip = 'nip' in self._trainable and self.nip.count_parameters() > 0
-        if 'dcn' in self._trainable:
-            raise NotImplementedError('joint training of the learned codec is not built yet')
+        train_dcn = 'dcn' in self._trainable
+        need_upstream = train_nip or train_dcn
         world = parallel.world_size()
 
         # ---- forward
         Y, nctx = self.nip.forward(x, training=train_nip)
         m, mctxs = self._manipulations(Y, augment, training=train_nip)
         c = self._downsampling(m)
-        if self.codec is None:
-            C, cctx = c, None
-        else:
-            C, cctx = self.codec.forward(c, training=train_nip)
+        C, entropy, cctx = self._codec_forward(c, training=need_upstream)
         _, fctx = self.fan.forward(C, self._device_labels(b), training=True)
 
         # ---- backward
         self._nan_flag.zero_()
-        loss_ce, dC = self.fan.backward(fctx, need_input_grad=train_nip)
+        loss_ce, dC = self.fan.backward(fctx, need_input_grad=need_upstream)
         ops.nan_flag(self.fan._model.flat_grad, self._nan_flag)
         self._bucket.launch(self.fan._model.flat_grad)              # overlaps with the rest of the backward pass
+        loss_dcn = None
+        dc = None
+        if need_upstream:
+            if self.codec is None:
+                dc = dC
+            elif self._is_dcn:
+                # codec.loss(batch_c, batch_C, entropy) = l2_loss(c - C) + w_H * H (compression.py:92-93) joins the
+                # objective only when the codec is trained (workflows/...:275-277).  l2_loss is a SUM over the batch, so
+                # under data parallelism its gradient must not be averaged: pre-multiply by the world size.
+                lam = float(lambda_dcn) * world if train_dcn else 0.0
+                dc_direct = None
+                if train_dcn:
+                    l2, _ = ops.l2_loss(c, C, grad_scale=lam, grad_out=dC, accumulate=True)       # d/dC: lam * (C - c)
+                    if train_nip:
+                        dc_direct = torch.empty_like(c)
+                        ops.l2_loss(C, c, grad_scale=lam, grad_out=dc_direct, accumulate=False)   # d/dc: lam * (c - C)
+                    loss_dcn = (l2, entropy)
+                dc = self.codec.backward(cctx, dC, entropy_coef=lam * self.codec._h.entropy_weight,
+                                         need_input_grad=train_nip)
+                if train_nip and dc_direct is not None:
+                    ops.add(dc, dc_direct, out=dc)
+                if train_dcn:
+                    ops.nan_flag(self.codec._model.flat_grad, self._nan_flag)
+                    self._bucket.launch(self.codec._model.flat_grad)
+            else:
+                dc = self.codec.backward(cctx, dC) if train_nip else None
         if train_nip:
-            dc = dC if self.codec is None else self.codec.backward(cctx, dC)
             dm = self._downsampling_bwd(dc)
             dY = dm[:b].clone() if len(self._operations) else dm[:b]
             for k, (name, op) in enumerate(self._operations.items()):
@@ -247,9 +280,16 @@ class ManipulationClassification(object):
         self.fan._model.adam(learning_rate, self._step, gscale, skip_flag=self._nan_flag)
         if train_nip:
             self.nip._model.adam(learning_rate, self._step, gscale, skip_flag=self._nan_flag)
+        if train_dcn:
+            self.codec._model.adam(learning_rate, self._step, gscale, skip_flag=self._nan_flag)
 
-        loss = _LazyLoss(loss_ce, loss_nip, float(lambda_nip) if 'nip' in self._trainable else 0.0)
-        return loss, {'ce': DeviceArray(loss_ce), 'nip': DeviceArray(loss_nip), 'dcn': np.nan}
+        dcn_value = np.nan
+        extra = 0.0
+        if loss_dcn is not None:
+            dcn_value = float(DeviceArray(loss_dcn[0])) + self.codec._h.entropy_weight * float(DeviceArray(loss_dcn[1]))
+            extra = float(lambda_dcn) * dcn_value
+        loss = _LazyLoss(loss_ce, loss_nip, float(lambda_nip) if 'nip' in self._trainable else 0.0, extra)
+        return loss, {'ce': DeviceArray(loss_ce), 'nip': DeviceArray(loss_nip), 'dcn': dcn_value}
 
     def check_nan(self):
         """Deferred NaN guard (nan_check='deferred'): raises if any step since the last check produced NaN grads."""
@@ -311,15 +351,15 @@ class _JpegManipulation(object):
 
 class _LazyLoss(DeviceArray):
     """loss = ce + lambda_nip * nip, evaluated on the host only when somebody reads it (keeps the step asynchronous)."""
-    __slots__ = ('ce', 'nip', 'lam')
+    __slots__ = ('ce', 'nip', 'lam', 'extra')
 
-    def __init__(self, ce, nip, lam):
+    def __init__(self, ce, nip, lam, extra=0.0):
         self.t = ce
-        self.ce, self.nip, self.lam = ce, nip, lam
+        self.ce, self.nip, self.lam, self.extra = ce, nip, lam, extra
 
     def numpy(self):
         v = self.ce.detach().cpu().numpy().reshape(()) + np.float32(self.lam) * self.nip.detach().cpu().numpy().reshape(())
-        return np.asarray(v, dtype=np.float32)
+        return np.asarray(v + np.float32(self.extra), dtype=np.float32)
 
     def __float__(self):
         return float(self.numpy())

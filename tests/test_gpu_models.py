@@ -278,3 +278,68 @@ def test_workflow_bf16_throughput_mode(dev):
     for k in ('conv2/kernel', 'conv4/kernel', 'dense/kernel'):
         a, b = res['f32'][4][k].ravel(), res['bf16'][4][k].ravel()
         assert float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b))) > 0.95, k
+
+
+def test_workflow_with_learned_codec_joint_training(dev):
+    """Config 5 shape of the channel: UNet -> manipulations -> TwitterDCN -> FAN with trainable = {nip, dcn}
+    (workflows/manipulation_classification.py:267-277: loss = CE + ln * nip + lc * (l2 + 250 H))."""
+    from neural_imaging_amd.models import compression
+    from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
+    manips = ['sharpen:1', 'resample:50', 'gaussian:0.83']
+    dcn = compression.TwitterDCN(patch_size=64, device=dev)
+    dist = {'downsampling': 'none', 'compression': 'dcn', 'compression_params': {'model': dcn}}
+    wf = ManipulationClassification('UNet', manipulations=manips, distribution=dist, trainable={'nip', 'dcn'},
+                                    raw_patch_size=32, device=dev)
+    ref = owf.Workflow(manipulations=manips, codec='dcn', trainable=('nip', 'dcn'))
+    _sync_oracle(wf, ref)
+    ref.dcn = onets.OrderedDict((k, to64(v)) for k, v in dcn.state_dict().items())
+    rgb = natural_images(2, 64, 64, seed=8)
+    raw = bayer_from_rgb(rgb)
+    loss_ref, parts_ref, params, grads, _ = ref.loss_and_grads(to64(raw), to64(rgb), 0.1, 0.01)
+    loss, parts = wf.training_step(raw, rgb, lambda_nip=0.1, lambda_dcn=0.01, learning_rate=1e-4)
+    assert abs(float(parts['ce']) - parts_ref['ce']) < 2e-3
+    assert abs(float(parts['nip']) - parts_ref['nip']) / parts_ref['nip'] < 1e-3
+    assert abs(parts['dcn'] - parts_ref['dcn']) / parts_ref['dcn'] < 1e-3
+    assert abs(float(loss) - float(loss_ref)) / float(loss_ref) < 1e-3
+    names = list(ref.fan.keys()) + list(ref.nip.keys()) + list(ref.dcn.keys())
+    got = grads_of(wf.fan)
+    got.update(grads_of(wf.nip))
+    got.update(grads_of(dcn))
+    worst = 1.0
+    for k, gr in zip(names, grads):
+        a, b = got[k].ravel().astype(np.float64), gr.numpy().ravel()
+        cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
+        worst = min(worst, cos)
+        assert cos > 0.99, (k, cos)
+    assert wf.is_trainable('dcn') and 'TwitterDCN' in wf.summary()
+
+
+def test_training_harness_outputs(dev, tmp_path):
+    """H1 (training/manipulation.py:36-335): epoch loop, lr decay, validation cadence, training.json keys, checkpoints
+    and the 'directory exists => skip' idempotence, on a synthetic dataset."""
+    import json
+    import os
+    from neural_imaging_amd.training import manipulation as tm
+    from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
+    dist = {'downsampling': 'pool:2', 'compression': 'jpeg', 'compression_params': {'quality': 80, 'codec': 'soft'}}
+    wf = ManipulationClassification('UNet', manipulations=['sharpen:1', 'gaussian:1'], distribution=dist,
+                                    trainable={'nip'}, raw_patch_size=16, device=dev)
+    data = tm.SyntheticDataset(8, 4, patch_size=16)
+    spec = {'camera_name': 'synthetic', 'use_pretrained_nip': False, 'patch_size': 16, 'batch_size': 4,
+            'n_epochs': 3, 'validation_schedule': 2, 'lambda_nip': 0.1, 'lambda_dcn': 0, 'run_number': 0,
+            'learning_rate': 1e-4, 'augment': False}
+    mdir = tm.train_manipulation_nip(wf, spec, data, {'root': str(tmp_path)})
+    run_dir = os.path.dirname(mdir)
+    assert run_dir.endswith(os.path.join('synthetic', 'UNet', 'ln-0.1000', 'fixed-codec', '000'))
+    prog = json.load(open(os.path.join(run_dir, 'training.json')))
+    assert set(prog.keys()) >= {'summary', 'distribution', 'manipulations', 'nip', 'forensics', 'codec'}
+    assert prog['manipulations'] == ['native', 'sharpen:1.0', 'gaussian:1.0']
+    assert len(prog['forensics']['performance']['accuracy']['validation']) == 2        # epochs 0 and 2
+    assert len(prog['nip']['performance']['loss']['training']) == 3
+    assert len(prog['nip']['performance']['psnr']['validation']) >= 1
+    assert os.path.isfile(os.path.join(mdir, 'fan', 'fan.npz')) and os.path.isfile(os.path.join(mdir, 'unet', 'unet.npz'))
+    before = os.path.getmtime(os.path.join(run_dir, 'training.json'))
+    assert tm.train_manipulation_nip(wf, spec, data, {'root': str(tmp_path)}) == mdir   # exists => skipped
+    assert os.path.getmtime(os.path.join(run_dir, 'training.json')) == before
+    with pytest.raises(RuntimeError):
+        tm.train_manipulation_nip(wf, {'n_epochs': 1}, data, {'root': str(tmp_path)})   # missing camera_name

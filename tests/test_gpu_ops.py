@@ -447,3 +447,31 @@ def test_fan_conv1_input_gradient_bf16(dev, bf16_mode):
         (z * to64(dz)).sum().backward()
         dx = ops.conv2d_dgrad(g(dz, dev), g(wt.numpy(), dev), (h, w))
         assert_close(dx.cpu().numpy(), x.grad.numpy(), 0.0, 1.5e-2, what='fewin dgrad {}'.format((n, h, w)))
+
+
+@pytest.mark.parametrize('name', ['awgn', 'gamma', 'median3', 'median5'])
+def test_more_manipulations_fwd_bwd(dev, name):
+    """awgn / gamma / median (helpers/tf_helpers.py:79-110); awgn with injected noise (tf.random.normal is not
+    reproducible)."""
+    from neural_imaging_amd.helpers import tf_helpers as th
+    x_np = (0.05 + 0.9 * np.random.default_rng(3).random((2, 20, 24, 3))).astype(np.float32)   # no ties, inside (0,1)
+    x = to64(x_np).requires_grad_(True)
+    noise = rnd(x_np.shape, 9)
+    if name == 'awgn':
+        op, ref = th.Awgn(), om.manipulation_awgn(x, 5.1 / 255, to64(noise))
+        y, ctx = op.forward(g(x_np, dev), 5.1, training=True, noise=g(noise, dev))
+    elif name == 'gamma':
+        op, ref = th.Gamma(), om.manipulation_gamma(x, 3.0)
+        y, ctx = op.forward(g(x_np, dev), 3.0, training=True)
+    else:
+        k = int(name[-1])
+        op, ref = th.Median(), om.manipulation_median(x, k)
+        y, ctx = op.forward(g(x_np, dev), k, training=True)
+    dy = rnd(tuple(ref.shape), 4)
+    (ref * to64(dy)).sum().backward()
+    # hard rounding inside awgn/gamma: a float32/float64 tie may flip a value by 1/255 at isolated elements
+    d = np.abs(y.cpu().numpy() - ref.detach().numpy())
+    assert np.mean(d > 1e-4) < 2e-3 and d.max() < 0.02, (np.mean(d > 1e-4), d.max())
+    dx = op.backward(ctx, g(dy, dev)).cpu().numpy()
+    e = np.abs(dx - x.grad.numpy())
+    assert np.mean(e > 2e-3 * np.abs(x.grad.numpy()).max()) < 5e-3, np.mean(e > 2e-3 * np.abs(x.grad.numpy()).max())
