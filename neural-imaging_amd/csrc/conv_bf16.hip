@@ -102,34 +102,61 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[mi][ni][j] = 0.0f;
 
-    for (int ci0 = 0; ci0 < Cin; ci0 += CK) {
-        __syncthreads();
-        // ---- A: f32 NHWC -> bf16 [pixel][16 ci], 8 channels (two float4) per item
-        for (int item = tid; item < NPIXH * 2; item += 256) {
-            const int pix = item >> 1, h8 = item & 1, c = ci0 + h8 * 8;
+    // Async-stage split (issue early / write late): the global loads of chunk c+1 are issued into registers before the
+    // MFMA loop of chunk c and committed to LDS after it, so HBM/L2 latency hides under the matrix work.
+    constexpr int AP = (NPIXH * 2 + 255) / 256, BP = (TAPS * TN * 2 + 255) / 256;
+    float4 preA[AP][2];
+    uint4 preB[BP];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int q = 0; q < AP; ++q) {
+            const int item = tid + q * 256;
+            const int pix = item >> 1, h8 = item & 1, c = c0 + h8 * 8;
             const int img = pix / (THH * TWH), rem = pix % (THH * TWH);
             int gy = iy0 + rem / TWH, gx = ix0 + rem % TWH;
             const int n = grp * NB + img;
-            float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (n < p.N && c < Cin && map_coord(gy, p.H, p.pad_mode) && map_coord(gx, p.W, p.pad_mode)) {
+            preA[q][0] = preA[q][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (item < NPIXH * 2 && n < p.N && c < Cin && map_coord(gy, p.H, p.pad_mode) &&
+                map_coord(gx, p.W, p.pad_mode)) {
                 const long pixoff = ((long)n * p.H + gy) * p.W + gx;
                 const float* src = c < p.C1 ? p.in1 + pixoff * p.C1 + c : p.in2 + pixoff * p.C2 + (c - p.C1);
-                const float4 v0 = *reinterpret_cast<const float4*>(src);
-                const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
-                f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = v0.w; f[4] = v1.x; f[5] = v1.y; f[6] = v1.z; f[7] = v1.w;
+                preA[q][0] = *reinterpret_cast<const float4*>(src);
+                preA[q][1] = *reinterpret_cast<const float4*>(src + 4);
             }
-            const bf16x8 b = pack8(f);
-            sA[pix * 2 + (h8 ^ ((pix >> 3) & 1))] = *reinterpret_cast<const uint4*>(&b);
         }
-        // ---- B: bf16 weights [tap][co][ci_pad] -> [tap][co_local][16 ci]
-        for (int item = tid; item < TAPS * TN * 2; item += 256) {
+#pragma unroll
+        for (int q = 0; q < BP; ++q) {
+            const int item = tid + q * 256;
             const int h8 = item & 1, row = item >> 1, j = row % TN, tap = row / TN;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (co0 + j < Cout)
-                v = *reinterpret_cast<const uint4*>(p.wb + ((long)tap * Cout + co0 + j) * p.CinP + ci0 + h8 * 8);
-            sB[row * 2 + (h8 ^ ((row >> 3) & 1))] = v;
+            preB[q] = make_uint4(0u, 0u, 0u, 0u);
+            if (item < TAPS * TN * 2 && co0 + j < Cout)
+                preB[q] = *reinterpret_cast<const uint4*>(p.wb + ((long)tap * Cout + co0 + j) * p.CinP + c0 + h8 * 8);
+        }
+    };
+    fetch(0);
+    for (int ci0 = 0; ci0 < Cin; ci0 += CK) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < AP; ++q) {
+            const int item = tid + q * 256;
+            if (item < NPIXH * 2) {
+                const int pix = item >> 1, h8 = item & 1;
+                const float f[8] = {preA[q][0].x, preA[q][0].y, preA[q][0].z, preA[q][0].w,
+                                    preA[q][1].x, preA[q][1].y, preA[q][1].z, preA[q][1].w};
+                const bf16x8 b = pack8(f);
+                sA[pix * 2 + (h8 ^ ((pix >> 3) & 1))] = *reinterpret_cast<const uint4*>(&b);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < BP; ++q) {
+            const int item = tid + q * 256;
+            if (item < TAPS * TN * 2) {
+                const int h8 = item & 1, row = item >> 1;
+                sB[row * 2 + (h8 ^ ((row >> 3) & 1))] = preB[q];
+            }
         }
         __syncthreads();
+        if (ci0 + CK < Cin) fetch(ci0 + CK);
 #pragma unroll 1
         for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
@@ -320,49 +347,66 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParamsB
     // per-lane constant parts of the transpose-read addresses
     const int a_lane = ((half * 8 + (g >> 2)) * STRIDE) * 64 + (sub * 16 + (g & 3) * 4) * 2;   // + pixel terms
     const int z_lane = (half * 8 + (g >> 2)) * B_ZS + (sub * 16 + (g & 3) * 4) * 2;
-    for (long wk = w_begin; wk < w_end; ++wk) {
-        const int n = (int)(wk / tiles), tile = (int)(wk % tiles);
-        const int ty0 = (tile / p.tiles_x) * B_TH, tx0 = (tile % p.tiles_x) * B_TW;
-        const int iy0 = ty0 * STRIDE - p.pad_t, ix0 = tx0 * STRIDE - p.pad_l;
-        __syncthreads();
-        for (int item = tid; item < NPIXH * 4; item += 256) {          // 8 channels (16 B of bf16) per item
-            const int pix = item >> 2, q = item & 3, c = ci0 + q * 8;
-            int gy = iy0 + pix / TWH, gx = ix0 + pix % TWH;
-            float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (c < Cin && map_coord(gy, p.H, p.pad_mode) && map_coord(gx, p.W, p.pad_mode)) {
-                const long pixoff = ((long)n * p.H + gy) * p.W + gx;
+    // async-stage split: tile t+1 travels HBM -> registers while tile t is multiplied
+    constexpr int IP = (NPIXH * 4 + 255) / 256, ZP = (NPIX * 8) / 256;
+    float4 preI[IP][2], preZ[ZP][2];
+    auto fetch = [&](long wk_) {
+        const int n_ = (int)(wk_ / tiles), tile_ = (int)(wk_ % tiles);
+        const int ty_ = (tile_ / p.tiles_x) * B_TH, tx_ = (tile_ % p.tiles_x) * B_TW;
+        const int iy_ = ty_ * STRIDE - p.pad_t, ix_ = tx_ * STRIDE - p.pad_l;
+#pragma unroll
+        for (int q = 0; q < IP; ++q) {
+            const int item = tid + q * 256;
+            const int pix = item >> 2, c = ci0 + (item & 3) * 8;
+            int gy = iy_ + pix / TWH, gx = ix_ + pix % TWH;
+            preI[q][0] = preI[q][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (item < NPIXH * 4 && c < Cin && map_coord(gy, p.H, p.pad_mode) && map_coord(gx, p.W, p.pad_mode)) {
+                const long pixoff = ((long)n_ * p.H + gy) * p.W + gx;
                 const float* src = c < p.C1 ? p.in1 + pixoff * p.C1 + c : p.in2 + pixoff * p.C2 + (c - p.C1);
-                const float4 v0 = *reinterpret_cast<const float4*>(src);
-                f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = v0.w;
-                if (c + 4 < Cin) {
-                    const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
-                    f[4] = v1.x; f[5] = v1.y; f[6] = v1.z; f[7] = v1.w;
-                }
+                preI[q][0] = *reinterpret_cast<const float4*>(src);
+                if (c + 4 < Cin) preI[q][1] = *reinterpret_cast<const float4*>(src + 4);
             }
-            const bf16x8 b = pack8(f);
-            *reinterpret_cast<uint4*>(sI + pix * 64 + q * 16) = *reinterpret_cast<const uint4*>(&b);
         }
-        for (int item = tid; item < NPIX * 8; item += 256) {
-            const int pix = item >> 3, q = item & 7, c = co0 + q * 8;
-            const int oy = ty0 + pix / B_TW, ox = tx0 + pix % B_TW;
-            float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < ZP; ++q) {
+            const int item = tid + q * 256;
+            const int pix = item >> 3, c = co0 + (item & 7) * 8;
+            const int oy = ty_ + pix / B_TW, ox = tx_ + pix % B_TW;
+            preZ[q][0] = preZ[q][1] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (oy < p.Hout && ox < p.Wout && c < p.Cout) {
-                const float* src = p.dz + (((long)n * p.Hout + oy) * p.Wout + ox) * p.Cout + c;
-                const float4 v0 = *reinterpret_cast<const float4*>(src);
-                f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = v0.w;
-                if (c + 4 < p.Cout) {
-                    const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
-                    f[4] = v1.x; f[5] = v1.y; f[6] = v1.z; f[7] = v1.w;
-                }
+                const float* src = p.dz + (((long)n_ * p.Hout + oy) * p.Wout + ox) * p.Cout + c;
+                preZ[q][0] = *reinterpret_cast<const float4*>(src);
+                if (c + 4 < p.Cout) preZ[q][1] = *reinterpret_cast<const float4*>(src + 4);
             }
+        }
+    };
+    if (w_begin < w_end) fetch(w_begin);
+    for (long wk = w_begin; wk < w_end; ++wk) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < IP; ++q) {
+            const int item = tid + q * 256;
+            if (item < NPIXH * 4) {
+                const float f[8] = {preI[q][0].x, preI[q][0].y, preI[q][0].z, preI[q][0].w,
+                                    preI[q][1].x, preI[q][1].y, preI[q][1].z, preI[q][1].w};
+                const bf16x8 b = pack8(f);
+                *reinterpret_cast<uint4*>(sI + (item >> 2) * 64 + (item & 3) * 16) = *reinterpret_cast<const uint4*>(&b);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < ZP; ++q) {
+            const int item = tid + q * 256;
+            const float f[8] = {preZ[q][0].x, preZ[q][0].y, preZ[q][0].z, preZ[q][0].w,
+                                preZ[q][1].x, preZ[q][1].y, preZ[q][1].z, preZ[q][1].w};
             if (do_bias) {                      // fused bias gradient in float32: this thread always owns channels q*8..
 #pragma unroll
                 for (int e = 0; e < 8; ++e) bacc[e] += f[e];
             }
             const bf16x8 b = pack8(f);
-            *reinterpret_cast<uint4*>(sZ + pix * B_ZS + q * 16) = *reinterpret_cast<const uint4*>(&b);
+            *reinterpret_cast<uint4*>(sZ + (item >> 3) * B_ZS + (item & 7) * 16) = *reinterpret_cast<const uint4*>(&b);
         }
         __syncthreads();
+        if (wk + 1 < w_end) fetch(wk + 1);
 #pragma unroll 1
         for (int r = 0; r < B_TH; ++r) {
             const unsigned char* zr = sZ + (r * B_TW) * B_ZS + z_lane;
