@@ -98,6 +98,22 @@ int nimg_maxpool2_fwd(const float* x, float* y, int n, int h, int w, int c, void
 /* dz = (route dp to the FIRST arg-max of each window) [+ add] [* LeakyReLU'(yact)]; add may alias dz */
 int nimg_maxpool2_bwd(const float* dp, const float* yact, const float* add, float* dz, int n, int h, int w, int c,
                       int apply_lrelu_mask, float alpha, void* stream);
+/* Fused Conv2D(SAME, stride 1) -> [LeakyReLU] -> MaxPool2D(2) of the FAN feature extractor (models/forensics.py:69-77:
+ * every conv{i} is followed by its pool; the full-resolution activation is consumed by nothing else), float32 MFMA.
+ * pool_out (n,h/2,w/2,cout) receives the pooled activation, pool_idx (same shape, bytes; may be NULL for inference)
+ * the position 0..3 of the first maximum inside each window (row-major).  h, w even; cout % 4 == 0; ks 3|5. */
+int nimg_conv2d_pool_fwd(const float* in, int cin, const float* w, const float* bias, float* pool_out,
+                         unsigned char* pool_idx, int cout, int n, int h, int wd, int ks, int act, float alpha,
+                         void* stream);
+/* The same pass with bf16 MFMA operands (throughput mode): w = the f32 kernel (read when cin <= 4), wb = its
+ * nimg_conv_weights_bf16(mode 0) image (read otherwise; cin % 8 == 0). */
+int nimg_conv2d_pool_fwd_bf16(const float* in, int cin, const float* w, const void* wb, const float* bias,
+                              float* pool_out, unsigned char* pool_idx, int cout, int n, int h, int wd, int ks, int act,
+                              float alpha, void* stream);
+/* Backward of that epilogue: dz (n,2ho,2wo,c) = dp routed to the stored arg-max [* LeakyReLU'(pooled)], zero elsewhere
+ * (sign(window max) == sign(pooled), so the un-stored activation is not needed).  c % 4 == 0. */
+int nimg_maxpool2_unpool(const float* dp, const unsigned char* idx, const float* pooled, float* dz, int n, int ho, int wo,
+                         int c, int apply_lrelu_mask, float alpha, void* stream);
 /* y = [clip01](scale * depth_to_space_DCR(x, 2) + shift); x (n,h,w,4*cout) -> y (n,2h,2w,cout).
  * pipelines.py:218-223 (scale 1, shift 0, clip 1), compression.py:248,263,266-271.  The clip is straight-through:
  * the backward is dx = scale * space_to_depth(dy). */

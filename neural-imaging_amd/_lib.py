@@ -30,6 +30,10 @@ PROTOTYPES = {
     'nimg_convt2x2_fwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'nimg_maxpool2_fwd': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'nimg_maxpool2_bwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, P]),
+    'nimg_conv2d_pool_fwd': (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P]),
+    'nimg_conv2d_pool_fwd_bf16': (c_int, [P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                                          P]),
+    'nimg_maxpool2_unpool': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, P]),
     'nimg_d2s_clip_fwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, P]),
     'nimg_d2s_clip_bwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, P]),
     'nimg_lrelu_bwd': (c_int, [P, P, P, c_long, c_float, P]),

@@ -72,6 +72,43 @@ __device__ __forceinline__ void epilogue_via_lds(const nimg_f32x16 (&acc)[NI], f
     }
 }
 
+// Fused bias + LeakyReLU + 2x2/2 max-pool epilogue (FAN: conv -> lrelu -> MaxPool2D, models/forensics.py:69-77) for a
+// fragment whose 32 rows are two adjacent 16-pixel tile rows (TW == 16): the window of pooled column pc is rows
+// {2pc, 2pc+1, 16+2pc, 17+2pc}.  Same LDS turn-around as above; one lane finishes 4 channels of one pooled pixel.
+//   emit(pc, c, float4 pooled, uchar4 argmax): argmax = position in the window, row-major, first maximum wins
+//   (the tie rule of nimg_maxpool2_fwd); bias4(c) returns the 4 biases of strip-local channel c.
+template <int NI, bool BLOCK_SYNC = true, typename Bias, typename Emit>
+__device__ __forceinline__ void pool_via_lds(const nimg_f32x16 (&acc)[NI], float* lds, int lane, float alpha, Bias bias4,
+                                             Emit emit) {
+    constexpr int RS = NI * 32 + EPI_PAD;
+    const int half = lane >> 5, n = lane & 31;
+    if (BLOCK_SYNC) __syncthreads();
+    else __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) lds[((j & 3) + 8 * (j >> 2) + 4 * half) * RS + ni * 32 + n] = acc[ni][j];
+    if (BLOCK_SYNC) __syncthreads();
+    else __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        const int idx = it * 64 + lane, pc = idx / (NI * 8), c = (idx % (NI * 8)) * 4;
+        const float4 b = bias4(c);
+        float m[4];
+        unsigned char k[4];
+#pragma unroll
+        for (int pos = 0; pos < 4; ++pos) {
+            const float4 r = *reinterpret_cast<const float4*>(lds + (2 * pc + (pos & 1) + 16 * (pos >> 1)) * RS + c);
+            const float v[4] = {lrelu(r.x + b.x, alpha), lrelu(r.y + b.y, alpha), lrelu(r.z + b.z, alpha),
+                                lrelu(r.w + b.w, alpha)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (pos == 0 || v[e] > m[e]) { m[e] = v[e]; k[e] = (unsigned char)pos; }
+        }
+        emit(pc, c, make_float4(m[0], m[1], m[2], m[3]), make_uchar4(k[0], k[1], k[2], k[3]));
+    }
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace nimg

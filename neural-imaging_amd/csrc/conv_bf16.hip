@@ -54,6 +54,8 @@ struct ConvParamsB {
     float* out1;
     float* out2;
     const float* act1;
+    float* pool_out;            // optional fused activation + 2x2 max-pool output (replaces out1), see common.h
+    unsigned char* pool_idx;
     int C1, C2, O1, O2, CinP;
     int N, H, W, Hout, Wout, pad_t, pad_l;
     int tiles_y, tiles_x, act, pad_mode;
@@ -181,6 +183,32 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+    // ---- epilogue, fused activation + 2x2 max-pool (16x16 tiles; the entry point guarantees even Hout/Wout, Cout % 4 == 0)
+    if constexpr (TW == 16 && NB == 1 && STRIDE == 1) {
+        if (p.pool_out) {
+            float* elds = reinterpret_cast<float*>(smem_raw) + wave * (32 * (NI * 32 + EPI_PAD));
+            const int Hp = p.Hout >> 1, Wp = p.Wout >> 1;
+            const float al = p.act == 1 ? p.alpha : 1.0f;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int py = (ty0 >> 1) + wm * MI + mi;
+                pool_via_lds<NI>(acc[mi], elds, lane, al,
+                    [&](int c) {
+                        const int co = co0 + wn * NI * 32 + c;
+                        return (p.bias && co < Cout) ? *reinterpret_cast<const float4*>(p.bias + co)
+                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+                    },
+                    [&](int pc, int c, float4 v, uchar4 k) {
+                        const int co = co0 + wn * NI * 32 + c, px = (tx0 >> 1) + pc;
+                        if (co >= Cout || grp >= p.N || py >= Hp || px >= Wp) return;
+                        const long o = (((long)grp * Hp + py) * Wp + px) * Cout + co;
+                        *reinterpret_cast<float4*>(p.pool_out + o) = v;
+                        if (p.pool_idx) *reinterpret_cast<uchar4*>(p.pool_idx + o) = k;
+                    });
+            }
+            return;
         }
     }
     // ---- epilogue, vector form: accumulators turned around through LDS so each lane stores 16 B along the channels
@@ -530,6 +558,7 @@ int nimg_conv2d_fwd_bf16(const float* in1, int c1, const float* in2, int c2, con
     if (n == 0) return NIMG_OK;
     ConvParamsB p;
     p.in1 = in1; p.in2 = in2; p.wb = (const __bf16*)wb; p.bias = bias; p.out1 = out1; p.out2 = out2; p.act1 = act_mask;
+    p.pool_out = nullptr; p.pool_idx = nullptr;
     p.C1 = c1; p.C2 = c2; p.O1 = o1; p.O2 = o2; p.CinP = (c1 + c2 + 15) / 16 * 16;
     p.N = n; p.H = h; p.W = wd; p.Hout = hout; p.Wout = wout; p.pad_t = pad_t; p.pad_l = pad_l;
     p.tiles_y = p.tiles_x = 0; p.act = act; p.pad_mode = pad_mode; p.alpha = alpha;
@@ -665,8 +694,10 @@ template <int KS, int CINP, int TN>
 __global__ __launch_bounds__(256) void conv_fwd_packed_bf16_kernel(const float* __restrict__ in,
                                                                    const float* __restrict__ w,
                                                                    const float* __restrict__ bias,
-                                                                   float* __restrict__ out, int N, int H, int W,
-                                                                   int Cout, int pad_mode, int act, float alpha,
+                                                                   float* __restrict__ out,
+                                                                   float* __restrict__ pool_out,
+                                                                   unsigned char* __restrict__ pool_idx, int N, int H,
+                                                                   int W, int Cout, int pad_mode, int act, float alpha,
                                                                    int tiles_y, int tiles_x, int tiles_per_wg) {
     constexpr int TH = 16, TW = 16, THH = TH + KS - 1, TWH = TW + KS - 1, P = (KS - 1) / 2;
     constexpr int NPIXH = THH * TWH, PS = ((NPIXH + 31) / 32) * 32 + 2;
@@ -760,6 +791,28 @@ __global__ __launch_bounds__(256) void conv_fwd_packed_bf16_kernel(const float* 
                 for (int ni = 0; ni < NI; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[ni], acc[mi][ni], 0, 0, 0);
             }
+        }
+        if (pool_out) {                 // fused activation + 2x2 max-pool (common.h); private per-wave scratch
+            float* elds = reinterpret_cast<float*>(smem_raw + A_BYTES + TN * KP * 2) + wave * (32 * (NI * 32 + EPI_PAD));
+            const int Hp = H >> 1, Wp = W >> 1;
+            const float al = act == 1 ? alpha : 1.0f;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int py = (ty0 >> 1) + wave * MI + mi;
+                pool_via_lds<NI, false>(acc[mi], elds, lane, al,
+                    [&](int c) {
+                        return (bias && co0 + c < Cout) ? *reinterpret_cast<const float4*>(bias + co0 + c)
+                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+                    },
+                    [&](int pc, int c, float4 v, uchar4 k) {
+                        const int co = co0 + c, px = (tx0 >> 1) + pc;
+                        if (co >= Cout || py >= Hp || px >= Wp) return;
+                        const long o = (((long)n * Hp + py) * Wp + px) * Cout + co;
+                        *reinterpret_cast<float4*>(pool_out + o) = v;
+                        if (pool_idx) *reinterpret_cast<uchar4*>(pool_idx + o) = k;
+                    });
+            }
+            continue;
         }
         if ((Cout & 3) == 0) {          // vector epilogue: 16 B per lane along the channels (common.h)
             float* elds = reinterpret_cast<float*>(smem_raw + A_BYTES + TN * KP * 2) + wave * (32 * (NI * 32 + EPI_PAD));
@@ -1024,11 +1077,9 @@ __global__ __launch_bounds__(256) void conv_dgrad_fewin_bf16_kernel(const float*
 extern "C" {
 
 /* FAN front end in throughput mode.  Few INPUT channels (cin 3|4, float32 HWIO weights, converted in-kernel). */
-int nimg_conv2d_fwd_smallc_bf16(const float* in, int cin, const float* w, const float* bias, float* out, int cout,
-                                int n, int h, int wd, int ks, int pad_mode, int act, float alpha, void* stream) {
-    if (!in || !w || !out || n < 0 || h <= 0 || wd <= 0 || cout <= 0 || pad_mode < 0 || pad_mode > 2) return NIMG_ERR_ARG;
-    if (n == 0) return NIMG_OK;
-    hipStream_t s = (hipStream_t)stream;
+static int launch_packed_bf16(const float* in, int cin, const float* w, const float* bias, float* out, float* pool_out,
+                              unsigned char* pool_idx, int cout, int n, int h, int wd, int ks, int pad_mode, int act,
+                              float alpha, hipStream_t s) {
     const int ty = cdiv(h, 16), tx = cdiv(wd, 16);
     const long total_tiles = (long)ty * tx * n;
     const int tpw = total_tiles >= 8192 ? 8 : (total_tiles >= 2048 ? 2 : 1);
@@ -1040,7 +1091,7 @@ int nimg_conv2d_fwd_smallc_bf16(const float* in, int cin, const float* w, const 
                                (size_t)4 * 32 * (TN_ + EPI_PAD) * sizeof(float);                                  \
         const long blocks = cdiv(total_tiles, tpw) * (long)cdiv(cout, TN_);                                       \
         hipLaunchKernelGGL((conv_fwd_packed_bf16_kernel<KS_, C_, TN_>), dim3((unsigned)blocks), dim3(256), lds, s, \
-                           in, w, bias, out, n, h, wd, cout, pad_mode, act, alpha, ty, tx, tpw);                  \
+                           in, w, bias, out, pool_out, pool_idx, n, h, wd, cout, pad_mode, act, alpha, ty, tx, tpw); \
     } while (0)
     if (ks == 5 && cin == 3) { if (cout > 32) NIMG_FP(5, 3, 64); else NIMG_FP(5, 3, 32); }
     else if (ks == 5 && cin == 4) { if (cout > 32) NIMG_FP(5, 4, 64); else NIMG_FP(5, 4, 32); }
@@ -1050,6 +1101,39 @@ int nimg_conv2d_fwd_smallc_bf16(const float* in, int cin, const float* w, const 
 #undef NIMG_FP
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
+}
+
+int nimg_conv2d_fwd_smallc_bf16(const float* in, int cin, const float* w, const float* bias, float* out, int cout,
+                                int n, int h, int wd, int ks, int pad_mode, int act, float alpha, void* stream) {
+    if (!in || !w || !out || n < 0 || h <= 0 || wd <= 0 || cout <= 0 || pad_mode < 0 || pad_mode > 2) return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    return launch_packed_bf16(in, cin, w, bias, out, nullptr, nullptr, cout, n, h, wd, ks, pad_mode, act, alpha,
+                              (hipStream_t)stream);
+}
+
+/* conv (SAME, stride 1) + optional LeakyReLU + 2x2/2 max-pool in one pass, bf16 operands: w = f32 kernel (used when
+ * cin <= 4), wb = nimg_conv_weights_bf16(mode 0) image of it (used otherwise) */
+int nimg_conv2d_pool_fwd_bf16(const float* in, int cin, const float* w, const void* wb, const float* bias,
+                              float* pool_out, unsigned char* pool_idx, int cout, int n, int h, int wd, int ks, int act,
+                              float alpha, void* stream) {
+    if (!in || !pool_out || cin <= 0 || cout <= 0 || (cout & 3) || n < 0 || h <= 0 || wd <= 0) return NIMG_ERR_ARG;
+    if ((h & 1) || (wd & 1) || (ks != 3 && ks != 5) || act < 0 || act > 1) return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (cin == 3 || cin == 4) {
+        if (!w) return NIMG_ERR_ARG;
+        return launch_packed_bf16(in, cin, w, bias, nullptr, pool_out, pool_idx, cout, n, h, wd, ks, 0, act, alpha, s);
+    }
+    if (!wb || (cin % 8)) return NIMG_ERR_ARG;
+    ConvParamsB p;
+    p.in1 = in; p.in2 = nullptr; p.wb = (const __bf16*)wb; p.bias = bias; p.out1 = nullptr; p.out2 = nullptr;
+    p.act1 = nullptr; p.pool_out = pool_out; p.pool_idx = pool_idx;
+    p.C1 = cin; p.C2 = 0; p.O1 = cout; p.O2 = 0; p.CinP = (cin + 15) / 16 * 16;
+    p.N = n; p.H = h; p.W = wd; p.Hout = h; p.Wout = wd; p.pad_t = p.pad_l = (ks - 1) / 2;
+    p.tiles_y = p.tiles_x = 0; p.act = act; p.pad_mode = 0; p.alpha = alpha;
+    const bool tn32 = cout <= 32 || (long)cdiv(cout, 64) * cdiv(h, 16) * cdiv(wd, 16) * n < 384;
+    if (ks == 3) return tn32 ? launch_conv_b<3, 1, 16, 16, 1, 32>(p, s) : launch_conv_b<3, 1, 16, 16, 1, 64>(p, s);
+    return tn32 ? launch_conv_b<5, 1, 16, 16, 1, 32>(p, s) : launch_conv_b<5, 1, 16, 16, 1, 64>(p, s);
 }
 
 /* input gradient of a (ks,ks,ci,32) SAME stride-1 convolution towards its ci (= 3) input channels; w = the FORWARD

@@ -36,6 +36,8 @@ struct ConvParams {
     float* out1;
     float* out2;
     const float* act1;    // optional saved activation, same shape as out1: out1 *= lrelu'(act1)
+    float* pool_out;      // optional: fused activation + 2x2 max-pool output [N][Hout/2][Wout/2][Cout] (replaces out1)
+    unsigned char* pool_idx;   // optional argmax (0..3) per pooled element
     int C1, C2, O1, O2;   // Cin = C1 + C2, Cout = O1 + O2
     int N, H, W, Hout, Wout, pad_t, pad_l;
     int tiles_y, tiles_x;
@@ -169,6 +171,32 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
         }
     }
 
+    // ---- epilogue, fused activation + 2x2 max-pool (16x16 tiles only; the entry point guarantees even Hout/Wout, Cout % 4 == 0)
+    if constexpr (TW == 16 && NB == 1 && STRIDE == 1) {
+        if (p.pool_out) {
+            float* elds = reinterpret_cast<float*>(smem) + wave * (32 * (NI * 32 + EPI_PAD));
+            const int Hp = p.Hout >> 1, Wp = p.Wout >> 1;
+            const float al = p.act == 1 ? p.alpha : 1.0f;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int py = (ty0 >> 1) + wm * MI + mi;
+                pool_via_lds<NI>(acc[mi], elds, lane, al,
+                    [&](int c) {
+                        const int co = co0 + wn * NI * 32 + c;
+                        return (p.bias && co < Cout) ? *reinterpret_cast<const float4*>(p.bias + co)
+                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+                    },
+                    [&](int pc, int c, float4 v, uchar4 k) {
+                        const int co = co0 + wn * NI * 32 + c, px = (tx0 >> 1) + pc;
+                        if (co >= Cout || grp >= p.N || py >= Hp || px >= Wp) return;
+                        const long o = (((long)grp * Hp + py) * Wp + px) * Cout + co;
+                        *reinterpret_cast<float4*>(p.pool_out + o) = v;
+                        if (p.pool_idx) *reinterpret_cast<uchar4*>(p.pool_idx + o) = k;
+                    });
+            }
+            return;
+        }
+    }
     // ---- epilogue, vector form: accumulators turned around through LDS so each lane stores 16 B along the channels
     if ((p.O1 & 3) == 0 && (p.O2 & 3) == 0) {
         float* elds = reinterpret_cast<float*>(smem) + wave * (32 * (NI * 32 + EPI_PAD));
@@ -309,6 +337,28 @@ __global__ __launch_bounds__(256) void conv_fwd_packed_kernel(const ConvParams p
                 for (int ni = 0; ni < NI; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
         }
+        if (p.pool_out) {                  // fused activation + 2x2 max-pool (see common.h); private per-wave scratch
+            float* elds = smem + CINP * PS + 2 * KPAIRS * TN + wave * (32 * (NI * 32 + EPI_PAD));
+            const int Hp = p.Hout >> 1, Wp = p.Wout >> 1;
+            const float al = p.act == 1 ? p.alpha : 1.0f;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int py = (ty0 >> 1) + wave * MI + mi;
+                pool_via_lds<NI, false>(acc[mi], elds, lane, al,
+                    [&](int c) {
+                        return (p.bias && co0 + c < Cout) ? *reinterpret_cast<const float4*>(p.bias + co0 + c)
+                                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+                    },
+                    [&](int pc, int c, float4 v, uchar4 k) {
+                        const int co = co0 + c, px = (tx0 >> 1) + pc;
+                        if (co >= Cout || py >= Hp || px >= Wp) return;
+                        const long o = (((long)n * Hp + py) * Wp + px) * Cout + co;
+                        *reinterpret_cast<float4*>(p.pool_out + o) = v;
+                        if (p.pool_idx) *reinterpret_cast<uchar4*>(p.pool_idx + o) = k;
+                    });
+            }
+            continue;
+        }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int co = co0 + ni * 32 + (lane & 31);
@@ -336,7 +386,7 @@ int launch_conv_packed(const ConvParams& p, hipStream_t stream) {
     constexpr int THH = 16 + KS - 1, NPIXH = THH * THH;
     constexpr int PS = ((NPIXH + 31) / 32) * 32 + 2;
     constexpr int KP = (KS * KS * CINP + 1) / 2;
-    constexpr size_t lds = (size_t)(CINP * PS + 2 * KP * TN) * sizeof(float);
+    constexpr size_t lds = (size_t)(CINP * PS + 2 * KP * TN + 4 * 32 * (TN + EPI_PAD)) * sizeof(float);
     ConvParams q = p;
     q.tiles_y = cdiv(p.Hout, 16);
     q.tiles_x = cdiv(p.Wout, 16);
@@ -414,6 +464,7 @@ int nimg_conv2d_fwd(const float* in1, int c1, const float* in2, int c2, const fl
     if (n == 0) return NIMG_OK;
     ConvParams p;
     p.in1 = in1; p.in2 = in2; p.w = w; p.bias = bias; p.out1 = out1; p.out2 = out2; p.act1 = act_mask;
+    p.pool_out = nullptr; p.pool_idx = nullptr;
     p.C1 = c1; p.C2 = c2; p.O1 = o1; p.O2 = o2; p.N = n; p.H = h; p.W = wd; p.Hout = hout; p.Wout = wout;
     p.pad_t = pad_t; p.pad_l = pad_l; p.tiles_y = p.tiles_x = 0; p.act = act; p.alpha = alpha; p.pad_mode = pad_mode;
     const bool vec = (c1 % 4 == 0) && (c2 % 4 == 0) && ((o1 + o2) % 4 == 0);
@@ -439,6 +490,34 @@ int nimg_conv2d_fwd(const float* in1, int c1, const float* in2, int c2, const fl
         if (ks == 5) return dispatch_tiles<5, 2, 8>(p, vec, s);
     }
     return NIMG_ERR_ARG;
+}
+
+int nimg_conv2d_pool_fwd(const float* in, int cin, const float* w, const float* bias, float* pool_out,
+                         unsigned char* pool_idx, int cout, int n, int h, int wd, int ks, int act, float alpha,
+                         void* stream) {
+    if (!in || !w || !pool_out || cin <= 0 || cout <= 0 || (cout & 3) || n < 0 || h <= 0 || wd <= 0) return NIMG_ERR_ARG;
+    if ((h & 1) || (wd & 1) || (ks != 3 && ks != 5) || act < 0 || act > 1) return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    ConvParams p;
+    p.in1 = in; p.in2 = nullptr; p.w = w; p.bias = bias; p.out1 = nullptr; p.out2 = nullptr; p.act1 = nullptr;
+    p.pool_out = pool_out; p.pool_idx = pool_idx;
+    p.C1 = cin; p.C2 = 0; p.O1 = cout; p.O2 = 0; p.N = n; p.H = h; p.W = wd; p.Hout = h; p.Wout = wd;
+    p.pad_t = p.pad_l = (ks - 1) / 2; p.tiles_y = p.tiles_x = 0; p.act = act; p.alpha = alpha; p.pad_mode = 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (cin == 3 || cin == 4) {
+        const bool n64 = cout > 32;
+#define NIMG_PACKED(KS_, C_) (n64 ? launch_conv_packed<KS_, C_, 64>(p, s) : launch_conv_packed<KS_, C_, 32>(p, s))
+        if (ks == 5) return cin == 3 ? NIMG_PACKED(5, 3) : NIMG_PACKED(5, 4);
+        return cin == 3 ? NIMG_PACKED(3, 3) : NIMG_PACKED(3, 4);
+#undef NIMG_PACKED
+    }
+    const bool vec = cin % 4 == 0;
+    const bool tn32 = cout <= 32 || (long)cdiv(cout, 64) * cdiv(h, 16) * cdiv(wd, 16) * n < 384;
+#define NIMG_POOL(KS_, CK_)                                                                                   \
+    (vec ? (tn32 ? launch_conv<KS_, 1, 16, 16, 1, 32, CK_, true>(p, s) : launch_conv<KS_, 1, 16, 16, 1, 64, CK_, true>(p, s)) \
+         : (tn32 ? launch_conv<KS_, 1, 16, 16, 1, 32, CK_, false>(p, s) : launch_conv<KS_, 1, 16, 16, 1, 64, CK_, false>(p, s)))
+    return ks == 3 ? NIMG_POOL(3, 16) : NIMG_POOL(5, 8);
+#undef NIMG_POOL
 }
 
 int nimg_conv_flip_weights(const float* w, float* wt, int ks_h, int ks_w, int cin, int cout, void* stream) {

@@ -45,6 +45,39 @@ __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restri
 }
 
 // dz[n,y,x,c] = (first arg-max of the window ? dp : 0) [+ add] ) * [lrelu'(y)]
+// Backward of the fused conv -> LeakyReLU -> MaxPool2D epilogue (nimg_conv2d_pool_fwd): the full-resolution activation
+// was never stored, so the pre-activation gradient is rebuilt from the pooled tensor, its argmax byte and the
+// upstream gradient: dz[window position] = (position == argmax) ? dp * lrelu'(pooled) : 0.  (The sign of the window
+// maximum is the sign of the pooled value, which is all lrelu' needs.)
+__global__ void maxpool2_unpool_kernel(const float* __restrict__ dp, const unsigned char* __restrict__ idx,
+                                       const float* __restrict__ pooled, float* __restrict__ dz, int n, int ho, int wo,
+                                       int c, int apply_mask, float alpha) {
+    const int cv = c / 4, w = 2 * wo;
+    const long total = (long)n * ho * wo * cv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % cv) * 4;
+        long r = i / cv;
+        const int ox = (int)(r % wo);
+        r /= wo;
+        const int oy = (int)(r % ho), im = (int)(r / ho);
+        const long po = (((long)im * ho + oy) * wo + ox) * c + cc;
+        float4 g = *reinterpret_cast<const float4*>(dp + po);
+        const uchar4 k = *reinterpret_cast<const uchar4*>(idx + po);
+        if (apply_mask) {
+            const float4 pv = *reinterpret_cast<const float4*>(pooled + po);
+            g.x *= pv.x > 0.f ? 1.0f : alpha; g.y *= pv.y > 0.f ? 1.0f : alpha;
+            g.z *= pv.z > 0.f ? 1.0f : alpha; g.w *= pv.w > 0.f ? 1.0f : alpha;
+        }
+        const long base = (((long)im * 2 * ho + 2 * oy) * w + 2 * ox) * c + cc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 o = make_float4(k.x == q ? g.x : 0.f, k.y == q ? g.y : 0.f, k.z == q ? g.z : 0.f,
+                                         k.w == q ? g.w : 0.f);
+            *reinterpret_cast<float4*>(dz + base + (long)(q >> 1) * w * c + (long)(q & 1) * c) = o;
+        }
+    }
+}
+
 // V channels per thread; V == 4 moves float4s (16 B per lane, coalesced along the NHWC channel axis)
 template <int V>
 __global__ void maxpool2_bwd_kernel(const float* __restrict__ dp, const float* __restrict__ yact,
@@ -376,6 +409,17 @@ int nimg_maxpool2_bwd(const float* dp, const float* yact, const float* add, floa
     else
         hipLaunchKernelGGL(maxpool2_bwd_kernel<1>, dim3(grid_for((long)n * (h / 2) * (w / 2) * c)), dim3(256), 0, s,
                            dp, yact, add, dz, n, h, w, c, apply_lrelu_mask, alpha);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_maxpool2_unpool(const float* dp, const unsigned char* idx, const float* pooled, float* dz, int n, int ho, int wo,
+                         int c, int apply_lrelu_mask, float alpha, void* stream) {
+    if (!dp || !idx || !dz || n < 0 || ho <= 0 || wo <= 0 || c <= 0 || (c & 3)) return NIMG_ERR_ARG;
+    if (apply_lrelu_mask && !pooled) return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    hipLaunchKernelGGL(maxpool2_unpool_kernel, dim3(grid_for((long)n * ho * wo * (c / 4))), dim3(256), 0,
+                       (hipStream_t)stream, dp, idx, pooled, dz, n, ho, wo, c, apply_lrelu_mask, alpha);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }

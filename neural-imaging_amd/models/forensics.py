@@ -83,9 +83,13 @@ class FAN(TFModel):
         net, nf = self._constrained.forward(P, x)
         t['constrained'], t['nf'] = net, nf
         for i, c in enumerate(self._convs):
-            a = c.forward(P, net)
-            t['conv{}'.format(i + 1)] = a
-            net = ops.maxpool2(a)
+            if c.can_pool(net):          # conv + LeakyReLU + pool in one pass; the full-resolution tensor is not stored
+                net, idx = c.forward_pool(P, net, want_idx=training)
+                t['idx{}'.format(i + 1)] = idx
+            else:
+                a = c.forward(P, net)
+                t['conv{}'.format(i + 1)] = a
+                net = ops.maxpool2(a)
             t['pool{}'.format(i + 1)] = net
         a = self._conv1x1.forward(P, net)
         t['conv1x1'] = a
@@ -107,9 +111,11 @@ class FAN(TFModel):
         self._conv1x1.backward_params(P, pool, dz)
         d_pool = self._conv1x1.backward_input(P, dz, hw(pool))
         for i in range(nconv, 0, -1):
-            act = t['conv{}'.format(i)]
             inp = t['pool{}'.format(i - 1)] if i > 1 else t['constrained']
-            dz = ops.maxpool2_bwd(d_pool, act, None, apply_mask=True)
+            if 'idx{}'.format(i) in t:
+                dz = ops.maxpool2_unpool(d_pool, t['idx{}'.format(i)], t['pool{}'.format(i)], apply_mask=True)
+            else:
+                dz = ops.maxpool2_bwd(d_pool, t['conv{}'.format(i)], None, apply_mask=True)
             self._convs[i - 1].backward_params(P, inp, dz)
             d_pool = self._convs[i - 1].backward_input(P, dz, hw(inp))
         self._constrained.backward_params(P, t['x'], d_pool)

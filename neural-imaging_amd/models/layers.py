@@ -38,6 +38,15 @@ class Conv2D(object):
         return ops.conv2d(x, store.p[self.name + '/kernel'], store.p[self.name + '/bias'], x2=x2,
                           stride=self.stride, act=self.activation)
 
+    def can_pool(self, x):
+        return self.stride == 1 and self.cin2 == 0 and self.ks in (3, 5) and self.cout % 4 == 0 and \
+            x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0
+
+    def forward_pool(self, store, x, want_idx=True):
+        """conv -> activation -> MaxPool2D(2) in one pass; returns (pooled, argmax bytes)."""
+        return ops.conv2d_pool(x, store.p[self.name + '/kernel'], store.p[self.name + '/bias'], act=self.activation,
+                               want_idx=want_idx)
+
     def backward_params(self, store, x, dz, x2=None):
         ops.conv2d_wgrad(x, dz, self.ks, x2=x2, stride=self.stride, dw=store.g[self.name + '/kernel'],
                          db=store.g[self.name + '/bias'])

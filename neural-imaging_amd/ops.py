@@ -284,6 +284,38 @@ def maxpool2_bwd(dp, yact, add=None, apply_mask=True, out=None):
     return dz
 
 
+def conv2d_pool(x, w, bias=None, act='leaky_relu', want_idx=True):
+    """Conv2D(SAME, stride 1) -> [LeakyReLU] -> MaxPool2D(2) in one pass (the FAN feature extractor): returns the pooled
+    activation and the arg-max bytes; the full-resolution activation is never written."""
+    _f32(x, w, bias)
+    n, h, wd, cin = x.shape
+    ks, cout = w.shape[0], w.shape[3]
+    if w.shape[2] != cin or (h & 1) or (wd & 1) or (cout & 3) or ks not in (3, 5):
+        raise ValueError('conv2d_pool: unsupported shape')
+    pooled = torch.empty((n, h // 2, wd // 2, cout), dtype=torch.float32, device=x.device)
+    idx = torch.empty((n, h // 2, wd // 2, cout), dtype=torch.uint8, device=x.device) if want_idx else None
+    a = 1 if act == 'leaky_relu' else 0
+    if COMPUTE == 'bf16' and (cin in (3, 4) or cin % 8 == 0):
+        wb = None if cin in (3, 4) else weights_bf16(w, 0)
+        _lib.call('nimg_conv2d_pool_fwd_bf16', _p(x), cin, _p(w), _p(wb), _p(bias), _p(pooled), _p(idx), cout, n, h, wd,
+                  ks, a, LRELU_ALPHA, _stream())
+    else:
+        _lib.call('nimg_conv2d_pool_fwd', _p(x), cin, _p(w), _p(bias), _p(pooled), _p(idx), cout, n, h, wd, ks, a,
+                  LRELU_ALPHA, _stream())
+    return pooled, idx
+
+
+def maxpool2_unpool(dp, idx, pooled, apply_mask=True, out=None):
+    """Backward of conv2d_pool's epilogue: the pre-activation gradient at full resolution."""
+    _f32(dp, pooled, out)
+    _chk(idx)
+    n, ho, wo, c = dp.shape
+    dz = torch.empty((n, 2 * ho, 2 * wo, c), dtype=torch.float32, device=dp.device) if out is None else out
+    _lib.call('nimg_maxpool2_unpool', _p(dp), _p(idx), _p(pooled), _p(dz), n, ho, wo, c, 1 if apply_mask else 0,
+              LRELU_ALPHA, _stream())
+    return dz
+
+
 def d2s_clip(x, scale=1.0, shift=0.0, clip=True):
     _f32(x)
     n, h, w, c4 = x.shape

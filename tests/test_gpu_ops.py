@@ -227,6 +227,32 @@ def test_maxpool_fwd_bwd_with_ties(dev, c):
     assert_close(dz.cpu().numpy(), ref, 1e-6, what='maxpool bwd (first-max tie rule)')
 
 
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('cin,cout,ks,h,w', [(3, 32, 5, 32, 48), (32, 64, 5, 32, 32), (16, 24, 3, 16, 16),
+                                              (64, 128, 5, 20, 28), (4, 64, 3, 18, 34), (8, 256, 5, 6, 10)])
+def test_conv_pool_fused_epilogue(dev, mode, cin, cout, ks, h, w):
+    """conv -> LeakyReLU -> MaxPool2D fused in the convolution epilogue == the three separate passes, bit for bit
+    (same accumulation, same first-maximum tie rule), and its arg-max bytes reproduce the un-fused backward."""
+    from neural_imaging_amd import ops
+    n = 3
+    x, wt, b = rnd((n, h, w, cin), 1), rnd((ks, ks, cin, cout), 2, -0.2, 0.2), rnd((cout,), 3, -0.1, 0.1)
+    ops.set_compute(mode)
+    try:
+        for wv in (wt, np.zeros_like(wt)):                      # zero weights: every window is a 4-way tie
+            xd, wd, bd = g(x, dev), g(wv, dev), g(b, dev)
+            full = ops.conv2d(xd, wd, bd, act='leaky_relu')
+            pooled_ref = ops.maxpool2(full)
+            pooled, idx = ops.conv2d_pool(xd, wd, bd, act='leaky_relu')
+            assert np.array_equal(pooled.cpu().numpy(), pooled_ref.cpu().numpy())
+            assert int(idx.max()) <= 3
+            dp = g(rnd(tuple(pooled.shape), 4), dev)
+            dz_ref = ops.maxpool2_bwd(dp, full, None, apply_mask=True)
+            dz = ops.maxpool2_unpool(dp, idx, pooled, apply_mask=True)
+            assert np.array_equal(dz.cpu().numpy(), dz_ref.cpu().numpy())
+    finally:
+        ops.set_compute('f32')
+
+
 def test_d2s_clip_and_small_ops(dev):
     from neural_imaging_amd import ops
     x = rnd((2, 6, 5, 12), 1, -0.5, 1.5)
