@@ -12,7 +12,13 @@ every rank processes its own B patches.  Prints ONE JSON line (rank 0).
 
 Extra objects on the line:
   roofline     - dominant kernel (the FAN 5x5 convolution family) timed live with HIP events on the launch stream:
-                 algorithmic FLOPs of one launch / average launch time, against the f32 MFMA peak
+                 algorithmic FLOPs of one launch / average launch time, against the dense MFMA peak of the compute
+                 dtype; traffic = HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_dominant_kernel.json:
+                 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc runs), scaled to this launch's image count
+
+--dtype bf16 (default) = throughput mode: bf16 MFMA operands, float32 accumulation, float32 tensors / master weights /
+optimizer.  --dtype f32 = parity mode (exact float32 MFMA; the mode the 1e-4 parity tests run in); at N=1 the default run
+also times a few parity-mode steps and reports them under config.f32_parity_mode.
   cpu_baseline - the oracle's CPU port (torch float32, all host cores) of the SAME step on a bounded sample
 """
 import argparse
@@ -41,7 +47,7 @@ def synthetic_batch(b, raw_patch, seed):
     return bayer_from_rgb(rgb), rgb
 
 
-def time_dominant_kernel(dev, b_images, reps=5):
+def time_dominant_kernel(dev, b_images, reps=20):
     """FAN conv3 forward (5x5, 64 -> 128 @ 64x64, the 839 MMAC/image layer) - one launch, HIP events on the
     stream it runs on (the kernels are launched on torch's current stream, so torch.cuda.Event brackets them)."""
     from neural_imaging_amd import ops
@@ -62,7 +68,14 @@ def time_dominant_kernel(dev, b_images, reps=5):
     flops = 2.0 * 25 * 64 * 128 * 64 * 64 * n
     from neural_imaging_amd import ops as _o
     kname = 'conv_fwd_kernel<5,1,16,16,1,64,8>' if _o.COMPUTE == 'f32' else 'conv_fwd_bf16_kernel<5,1,16,16,1,64>'
-    return {'kernel': kname + ' (FAN conv3 fwd, {}x64x64x64->128)'.format(n),
+    traffic = None
+    try:                                                   # measured once with rocprofv3 --pmc, see profiles/README.md
+        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_dominant_kernel.json')) as f:
+            pmc = json.load(f)[_o.COMPUTE]
+        traffic = pmc['traffic_bytes_per_launch'] * n / pmc['images']
+    except (OSError, KeyError, ValueError):
+        pass
+    return {'kernel': kname + ' (FAN conv3 fwd, {}x64x64x64->128)'.format(n), 'traffic': traffic,
             'flops_per_launch': flops, 'ms_per_launch': ms, 'tflops': flops / (ms * 1e-3) / 1e12}
 
 
@@ -119,8 +132,10 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='raw patches per GPU per step (SURVEY 8d C4: 64)')
     ap.add_argument('--raw-patch', type=int, default=128)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
-                    help='arithmetic type of the convolution GEMMs (f32 = parity mode; bf16 = MFMA throughput mode)')
+    ap.add_argument('--dtype', choices=['f32', 'bf16'], default='bf16',
+                    help='arithmetic type of the convolution GEMMs (bf16 = MFMA throughput mode, f32 accumulate; '
+                         'f32 = parity mode)')
+    ap.add_argument('--no-parity-mode', action='store_true', help='skip the extra float32 parity-mode timing at N=1')
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--cpu-budget', type=float, default=15.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -187,9 +202,24 @@ def main():
                        'batch_per_gpu': args.batch, 'global_batch': world * args.batch, 'parallelism': 'dp%d' % world,
                        'loss': float(loss), 'achieved_tflops_whole_step': value * GFLOP_PER_PATCH / 1e3},
             'roofline': {'bound': 'mfma', 'achieved': dom['tflops'], 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': dom['tflops'] / peak, 'traffic': None, 'kernel': dom['kernel'],
-                         'ms_per_launch': dom['ms_per_launch']},
+                         'frac': dom['tflops'] / peak, 'traffic': dom['traffic'], 'kernel': dom['kernel'],
+                         'ms_per_launch': dom['ms_per_launch'], 'flops_per_launch': dom['flops_per_launch']},
         }
+        if world == 1 and args.dtype == 'bf16' and not args.no_parity_mode:
+            _ops.set_compute('f32')                           # same step, exact float32 MFMA (the parity-test mode)
+            wf.training_step(bx, by, lambda_nip=0.1, learning_rate=1e-4)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                wf.training_step(bx, by, lambda_nip=0.1, learning_rate=1e-4)
+            torch.cuda.synchronize()
+            dt32 = (time.perf_counter() - t1) / 3
+            dom32 = time_dominant_kernel(dev, 5 * args.batch)
+            line['config']['f32_parity_mode'] = {
+                'patches_per_s': args.batch / dt32, 'ms_per_step': 1e3 * dt32,
+                'dominant_kernel_tflops': dom32['tflops'], 'dominant_kernel_frac_of_f32_mfma_peak':
+                    dom32['tflops'] / F32_MFMA_PEAK_TFLOPS}
+            _ops.set_compute(args.dtype)
         if not args.no_cpu_baseline and world == 1:
             line['cpu_baseline'] = cpu_baseline(args.raw_patch)
         print(json.dumps(line))
