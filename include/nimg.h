@@ -207,8 +207,8 @@ int nimg_l2_loss(const float* target, const float* y, float* loss, float* grad_y
  * accumulation, float32 tensors in HBM.  Same semantics / arguments as nimg_conv2d_fwd / nimg_conv2d_wgrad; channel
  * counts must be multiples of 8 (forward) / 4 (weight gradient).  Judged on PSNR / accuracy parity (BASELINE.json),
  * not on the 1e-4 contract.  Weights are laid out once per step by nimg_conv_weights_bf16:
- *   mode 0 (forward)        wb[tap][co][ci_pad16]        = w[tap][ci][co]
- *   mode 1 (input gradient) wb[taps-1-tap][ci][co_pad16] = w[tap][ci][co]   (then call with cin/cout swapped) */
+ *   mode 0 (forward)        wb[ci/16][tap][co][ci%16]        = w[tap][ci][co]   (16-channel chunk major, zero padded)
+ *   mode 1 (input gradient) wb[co/16][taps-1-tap][ci][co%16] = w[tap][ci][co]   (then call with cin/cout swapped) */
 size_t nimg_conv_weights_bf16_bytes(int ks_h, int ks_w, int cin, int cout, int mode);
 int nimg_conv_weights_bf16(const float* w, void* wb, int ks_h, int ks_w, int cin, int cout, int mode, void* stream);
 int nimg_conv2d_fwd_bf16(const float* in1, int c1, const float* in2, int c2, const void* wb, const float* bias,

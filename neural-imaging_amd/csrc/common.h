@@ -109,6 +109,66 @@ __device__ __forceinline__ void pool_via_lds(const nimg_f32x16 (&acc)[NI], float
     }
 }
 
+// dst[i] = sum_k partial[k][i] over `splits` slabs, fixed order => deterministic (split-K weight gradients, fused bias
+// sums); 4 independent accumulators keep 4 loads in flight per thread.  `block` of `nblocks` workgroups of 256.
+__device__ __forceinline__ void reduce_slabs(const float* __restrict__ partial, float* __restrict__ dst, long count,
+                                             int splits, int accumulate, long block, long nblocks) {
+    if ((count & 3) == 0) {
+        const long c4 = count >> 2;
+        for (long i = block * 256 + threadIdx.x; i < c4; i += nblocks * 256) {
+            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+            const float4* src = reinterpret_cast<const float4*>(partial) + i;
+            int k = 0;
+            for (; k + 3 < splits; k += 4) {
+                const float4 v0 = src[(long)k * c4], v1 = src[(long)(k + 1) * c4], v2 = src[(long)(k + 2) * c4],
+                             v3 = src[(long)(k + 3) * c4];
+                a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+                a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+                a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+                a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+            }
+            for (; k < splits; ++k) {
+                const float4 v = src[(long)k * c4];
+                a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w;
+            }
+            float4 r = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y),
+                                   (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
+            float4* d = reinterpret_cast<float4*>(dst) + i;
+            if (accumulate) { const float4 o = *d; r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
+            *d = r;
+        }
+        return;
+    }
+    for (long i = block * 256 + threadIdx.x; i < count; i += nblocks * 256) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += partial[(long)k * count + i];
+        dst[i] = accumulate ? dst[i] + s : s;
+    }
+}
+
+// one launch, two reductions: workgroups [0, blocks1) reduce the weight slabs, the rest the bias partials
+// (internal linkage: every translation unit that includes this header gets its own copy)
+static __global__ __launch_bounds__(256) void reduce_slabs2_kernel(const float* __restrict__ p1, float* __restrict__ d1, long n1,
+                                                            int splits1, int blocks1, const float* __restrict__ p2,
+                                                            float* __restrict__ d2, long n2, int splits2,
+                                                            int accumulate) {
+    if ((int)blockIdx.x < blocks1) reduce_slabs(p1, d1, n1, splits1, accumulate, blockIdx.x, blocks1);
+    else reduce_slabs(p2, d2, n2, splits2, accumulate, blockIdx.x - blocks1, gridDim.x - blocks1);
+}
+
+static inline int reduce_grid(long count) {
+    const long g = (count / 4 + 255) / 256;
+    return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+// launch helper: dw slabs (+ optional db partials) in one kernel
+static inline void launch_reduce2(const float* p1, float* d1, long n1, int splits1, const float* p2, float* d2, long n2,
+                                  int splits2, int accumulate, hipStream_t s) {
+    const int b1 = reduce_grid(n1), b2 = (p2 && d2) ? reduce_grid(n2) : 0;
+    hipLaunchKernelGGL(reduce_slabs2_kernel, dim3(b1 + b2), dim3(256), 0, s, p1, d1, n1, splits1, b1, p2, d2, n2, splits2,
+                       accumulate);
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace nimg

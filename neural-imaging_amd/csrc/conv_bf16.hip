@@ -5,7 +5,7 @@
 //
 //   forward / input gradient: A tile [pixel][16 ci] bf16 (32 B per pixel, one ds_read_b128 per fragment, 1-bit XOR
 //       swizzle of the two 16-byte halves => conflict-free), B tile [tap][co][16 ci] bf16 read the same way from weights
-//       that nimg_conv_weights_bf16 lays out once per step as [tap][co][ci_pad].
+//       that nimg_conv_weights_bf16 lays out once per step as [ci chunk][tap][co][16].
 //   weight gradient: K = 16 output pixels per MFMA; the f32 NHWC tiles of conv_wgrad.hip are kept and each lane gathers
 //       its 8 pixels with ds_read_b32 (conflict-free) and packs them to bf16 in registers (v_cvt_pk_bf16_f32).
 #include <stdlib.h>
@@ -31,15 +31,17 @@ __device__ __forceinline__ bf16x8 pack8(const float (&f)[8]) {
     return r;
 }
 
-// wb[tap'][co][ci_pad] (mode 0, forward) = w[tap][ci][co];  mode 1 (input gradient): roles of ci/co swap and the taps
-// are flipped: wb[taps-1-tap][ci][co_pad] = w[tap][ci][co].  Padding columns are zero.
+// wb[chunk][tap'][co][16] (mode 0, forward) = w[tap][ci = 16*chunk + k][co];  mode 1 (input gradient): roles of ci/co
+// swap and the taps are flipped.  Chunk-major, so the weight tile a workgroup stages per 16-channel K chunk is one
+// contiguous 2 KiB run per tap (fully coalesced 16-byte loads).  Padding channels are zero.
 __global__ void weights_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wb, int taps, int cin, int cout,
                                     int mode) {
     const int rows = mode == 0 ? cout : cin, cols = mode == 0 ? cin : cout;
     const int cpad = (cols + 15) / 16 * 16;
     const long total = (long)taps * rows * cpad;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % cpad), r = (int)((i / cpad) % rows), t = (int)(i / ((long)cpad * rows));
+        const int c = (int)(i % 16) + 16 * (int)(i / (16L * rows * taps)), r = (int)((i / 16) % rows);
+        const int t = (int)((i / (16L * rows)) % taps);
         float v = 0.f;
         if (c < cols) v = mode == 0 ? w[((long)t * cin + c) * cout + r] : w[((long)(taps - 1 - t) * cin + r) * cout + c];
         wb[i] = (__bf16)v;
@@ -49,7 +51,7 @@ __global__ void weights_bf16_kernel(const float* __restrict__ w, __bf16* __restr
 struct ConvParamsB {
     const float* in1;
     const float* in2;
-    const __bf16* wb;     // [KS*KS][Cout][CinP]
+    const __bf16* wb;     // [CinP/16][KS*KS][Cout][16]
     const float* bias;
     float* out1;
     float* out2;
@@ -126,13 +128,14 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
                 preA[q][1] = *reinterpret_cast<const float4*>(src + 4);
             }
         }
+        const __bf16* wchunk = p.wb + (long)(c0 >> 4) * (TAPS * 16) * Cout;      // wave-uniform base of this K chunk
 #pragma unroll
         for (int q = 0; q < BP; ++q) {
             const int item = tid + q * 256;
             const int h8 = item & 1, row = item >> 1, j = row % TN, tap = row / TN;
             preB[q] = make_uint4(0u, 0u, 0u, 0u);
             if (item < TAPS * TN * 2 && co0 + j < Cout)
-                preB[q] = *reinterpret_cast<const uint4*>(p.wb + ((long)tap * Cout + co0 + j) * p.CinP + c0 + h8 * 8);
+                preB[q] = *reinterpret_cast<const uint4*>(wchunk + (unsigned)((tap * Cout + co0 + j) * 16 + h8 * 8));
         }
     };
     fetch(0);
@@ -482,42 +485,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParamsB
     }
 }
 
-__global__ void reduce_slabs_kernel(const float* __restrict__ partial, float* __restrict__ dw, long count,
-                                    int splits, int accumulate) {
-    // fixed summation order => deterministic; 4 independent accumulators keep 4 loads in flight per thread
-    if ((count & 3) == 0) {
-        const long c4 = count >> 2;
-        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < c4; i += (long)gridDim.x * blockDim.x) {
-            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
-            const float4* src = reinterpret_cast<const float4*>(partial) + i;
-            int k = 0;
-            for (; k + 3 < splits; k += 4) {
-                const float4 v0 = src[(long)k * c4], v1 = src[(long)(k + 1) * c4], v2 = src[(long)(k + 2) * c4],
-                             v3 = src[(long)(k + 3) * c4];
-                a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
-                a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
-                a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
-                a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
-            }
-            for (; k < splits; ++k) {
-                const float4 v = src[(long)k * c4];
-                a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w;
-            }
-            float4 r = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y),
-                                   (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
-            float4* d = reinterpret_cast<float4*>(dw) + i;
-            if (accumulate) { const float4 o = *d; r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
-            *d = r;
-        }
-        return;
-    }
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += partial[(long)k * count + i];
-        dw[i] = accumulate ? dw[i] + s : s;
-    }
-}
-
 int splits_for(int cin, int cout, int n, int hout, int wout) {
     const long blocks_io = (long)cdiv(cin, B_CI) * cdiv(cout, B_CO);
     const long work = (long)n * cdiv(hout, B_TH) * cdiv(wout, B_TW);
@@ -629,15 +596,9 @@ int nimg_conv2d_wgrad_bf16(const float* in1, int c1, const float* in2, int c2, c
         else { if (ni == 1) NIMG_WGPB(3, 4, 1); else NIMG_WGPB(3, 4, 2); }
 #undef NIMG_WGPB
         NIMG_CHECK_LAUNCH();
-        const int rg = (int)((cnt + 255) / 256 > 4096 ? 4096 : (cnt + 255) / 256);
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(rg), dim3(256), 0, s_, (const float*)workspace, dw, cnt,
-                           4 * q.splits, accumulate);
+        launch_reduce2((const float*)workspace, dw, cnt, 4 * q.splits, db ? (const float*)q.db_partial : nullptr, db,
+                       (long)cout, q.splits, accumulate, s_);
         NIMG_CHECK_LAUNCH();
-        if (db) {
-            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(256), 0, s_, (const float*)q.db_partial, db,
-                               (long)cout, q.splits, accumulate);
-            NIMG_CHECK_LAUNCH();
-        }
         return NIMG_OK;
     }
     if ((c1 % 4) || (c2 % 4) || (cout % 4) || (c2 > 0 && (c1 % 8))) return NIMG_ERR_ARG;
@@ -669,15 +630,9 @@ int nimg_conv2d_wgrad_bf16(const float* in1, int c1, const float* in2, int c2, c
     else return NIMG_ERR_ARG;
 #undef NIMG_WGB
     NIMG_CHECK_LAUNCH();
-    const int rgrid = (int)((count + 255) / 256 > 4096 ? 4096 : (count + 255) / 256);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(rgrid), dim3(256), 0, s, (const float*)workspace, dw, count, p.splits,
-                       accumulate);
+    launch_reduce2((const float*)workspace, dw, count, p.splits, db ? (const float*)p.db_partial : nullptr, db, (long)cout,
+                   p.splits, accumulate, s);
     NIMG_CHECK_LAUNCH();
-    if (db) {
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((cout + 255) / 256), dim3(256), 0, s, (const float*)p.db_partial,
-                           db, (long)cout, p.splits, accumulate);
-        NIMG_CHECK_LAUNCH();
-    }
     return NIMG_OK;
 }
 

@@ -271,43 +271,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_packed_kernel(const WgradParam
         }
 }
 
-// dw[i] = sum_s partial[s][i]   (fixed order => deterministic)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, long count,
-                                    int splits, int accumulate) {
-    // fixed summation order => deterministic; 4 independent accumulators keep 4 loads in flight per thread
-    if ((count & 3) == 0) {
-        const long c4 = count >> 2;
-        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < c4; i += (long)gridDim.x * blockDim.x) {
-            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
-            const float4* src = reinterpret_cast<const float4*>(partial) + i;
-            int k = 0;
-            for (; k + 3 < splits; k += 4) {
-                const float4 v0 = src[(long)k * c4], v1 = src[(long)(k + 1) * c4], v2 = src[(long)(k + 2) * c4],
-                             v3 = src[(long)(k + 3) * c4];
-                a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
-                a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
-                a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
-                a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
-            }
-            for (; k < splits; ++k) {
-                const float4 v = src[(long)k * c4];
-                a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w;
-            }
-            float4 r = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y),
-                                   (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
-            float4* d = reinterpret_cast<float4*>(dw) + i;
-            if (accumulate) { const float4 o = *d; r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
-            *d = r;
-        }
-        return;
-    }
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += partial[(long)k * count + i];
-        dw[i] = accumulate ? dw[i] + s : s;
-    }
-}
-
 // db[co] = sum_pixels dz[pixel][co]: one workgroup per slice of pixels, two-stage (partials then fixed-order reduce)
 __global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __restrict__ dz,
                                                                 float* __restrict__ partial, long npix, int cout,
@@ -386,7 +349,6 @@ int nimg_conv2d_wgrad(const float* in1, int c1, const float* in2, int c2, const 
     const bool vec = (c1 % 4 == 0) && (c2 % 4 == 0) && (cout % 4 == 0);
     hipStream_t s = (hipStream_t)stream;
     const long count = (long)ks * ks * cin * cout;
-    const int rgrid = (int)((count + 255) / 256 > 4096 ? 4096 : (count + 255) / 256);
 
     // tiny filters (Cin, Cout <= 4): one thread per weight, exact f32 (conv_small.hip)
     if (c2 == 0 && c1 == 3 && cout == 3 && stride == 1 && (ks == 3 || ks == 5) && hout == h && wout == wd &&
@@ -411,14 +373,9 @@ int nimg_conv2d_wgrad(const float* in1, int c1, const float* in2, int c2, const 
         else { if (ni == 1) NIMG_WGP(3, 4, 1); else NIMG_WGP(3, 4, 2); }
 #undef NIMG_WGP
         NIMG_CHECK_LAUNCH();
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, s, (const float*)workspace, dw, count,
-                           4 * p.splits, accumulate);
+        nimg::launch_reduce2((const float*)workspace, dw, count, 4 * p.splits, db ? (const float*)p.db_partial : nullptr,
+                             db, (long)cout, p.splits, accumulate, s);
         NIMG_CHECK_LAUNCH();
-        if (db) {
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(1), dim3(256), 0, s, (const float*)p.db_partial, db,
-                               (long)cout, p.splits, accumulate);
-            NIMG_CHECK_LAUNCH();
-        }
         return NIMG_OK;
     }
     if (db) p.db_partial = p.partial + (size_t)p.splits * count;
@@ -447,14 +404,9 @@ int nimg_conv2d_wgrad(const float* in1, int c1, const float* in2, int c2, const 
     else return NIMG_ERR_ARG;
 #undef NIMG_WG
     NIMG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, s, (const float*)workspace, dw, count,
-                       p.splits, accumulate);
+    nimg::launch_reduce2((const float*)workspace, dw, count, p.splits, db ? (const float*)p.db_partial : nullptr, db,
+                         (long)cout, p.splits, accumulate, s);
     NIMG_CHECK_LAUNCH();
-    if (db) {
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((cout + 255) / 256), dim3(256), 0, s,
-                           (const float*)p.db_partial, db, (long)cout, p.splits, accumulate);
-        NIMG_CHECK_LAUNCH();
-    }
     return NIMG_OK;
 }
 
@@ -473,9 +425,7 @@ int nimg_bias_grad(const float* dz, float* db, long npix, int cout, int accumula
     hipLaunchKernelGGL(bias_grad_partial_kernel, dim3((unsigned)blocks), dim3(256), 256 * sizeof(float), s, dz,
                        (float*)workspace, npix, cout, ppb);
     NIMG_CHECK_LAUNCH();
-    const int grid = (cout + 255) / 256;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, s, (const float*)workspace, db, (long)cout,
-                       (int)blocks, accumulate);
+    nimg::launch_reduce2((const float*)workspace, db, (long)cout, (int)blocks, nullptr, nullptr, 0, 0, accumulate, s);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }
