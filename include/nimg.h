@@ -211,6 +211,11 @@ int nimg_l2_loss(const float* target, const float* y, float* loss, float* grad_y
  *   mode 1 (input gradient) wb[co/16][taps-1-tap][ci][co%16] = w[tap][ci][co]   (then call with cin/cout swapped) */
 size_t nimg_conv_weights_bf16_bytes(int ks_h, int ks_w, int cin, int cout, int mode);
 int nimg_conv_weights_bf16(const float* w, void* wb, int ks_h, int ks_w, int cin, int cout, int mode, void* stream);
+/* Conv2DTranspose(cout, [2,2], [2,2]) forward (pipelines.py:205) in throughput mode: four 1x1 products (one per output
+ * phase) on the matrix core in one launch.  wb = nimg_conv_weights_bf16(w, 2, 2, cout, cin, mode 1) of the Keras
+ * (2,2,Cout,Cin) kernel; x (n,h,wd,cin) -> y (n,2h,2wd,cout); cin % 8 == 0. */
+int nimg_convt2x2_fwd_bf16(const float* x, const void* wb, const float* bias, float* y, int n, int h, int wd, int cin,
+                           int cout, void* stream);
 int nimg_conv2d_fwd_bf16(const float* in1, int c1, const float* in2, int c2, const void* wb, const float* bias,
                          float* out1, int o1, float* out2, int o2, const float* act_mask, int n, int h, int wd,
                          int ks, int stride, int pad_t, int pad_l, int pad_mode, int hout, int wout, int act,

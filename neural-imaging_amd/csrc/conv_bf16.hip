@@ -62,6 +62,7 @@ struct ConvParamsB {
     int N, H, W, Hout, Wout, pad_t, pad_l;
     int tiles_y, tiles_x, act, pad_mode;
     float alpha;
+    int convt;            // 1: Conv2DTranspose(2x2, stride 2) as four 1x1 products; workgroup id & 3 = output phase (dy, dx)
 };
 
 template <int KS, int STRIDE, int TH, int TW, int NB, int TN>
@@ -83,6 +84,8 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
     const int Cin = p.C1 + p.C2, Cout = p.O1 + p.O2;
     const int cot = (Cout + TN - 1) / TN;
     int bid = blockIdx.x;
+    int phase = 0;                                       // Conv2DTranspose: which of the 2x2 output phases
+    if (KS == 1 && p.convt) { phase = bid & 3; bid >>= 2; }
     const int co0 = (bid % cot) * TN;
     bid /= cot;
     const int tiles = p.tiles_y * p.tiles_x;
@@ -128,7 +131,9 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
                 preA[q][1] = *reinterpret_cast<const float4*>(src + 4);
             }
         }
-        const __bf16* wchunk = p.wb + (long)(c0 >> 4) * (TAPS * 16) * Cout;      // wave-uniform base of this K chunk
+        // wave-uniform base of this K chunk (the transposed convolution reads tap slot 3 - phase of a 4-tap image)
+        const __bf16* wchunk = (KS == 1 && p.convt) ? p.wb + ((long)(c0 >> 4) * 4 + (3 - phase)) * 16 * Cout
+                                                    : p.wb + (long)(c0 >> 4) * (TAPS * 16) * Cout;
 #pragma unroll
         for (int q = 0; q < BP; ++q) {
             const int item = tid + q * 256;
@@ -226,7 +231,9 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
                 const int img = P / (TH * TW), rem = P % (TH * TW);
                 const int oy = ty0 + rem / TW, ox = tx0 + rem % TW, n = grp * NB + img;
                 if (n >= p.N || oy >= p.Hout || ox >= p.Wout) return;
-                const long pixoff = ((long)n * p.Hout + oy) * p.Wout + ox;
+                const long pixoff = (KS == 1 && p.convt)
+                    ? ((long)n * 2 * p.Hout + 2 * oy + (phase >> 1)) * (2 * p.Wout) + 2 * ox + (phase & 1)
+                    : ((long)n * p.Hout + oy) * p.Wout + ox;
                 if (p.bias) {
                     const float4 b = *reinterpret_cast<const float4*>(p.bias + co);
                     v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
@@ -262,7 +269,9 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
                 const int img = P / (TH * TW), rem = P % (TH * TW);
                 const int oy = ty0 + rem / TW, ox = tx0 + rem % TW, n = grp * NB + img;
                 if (n >= p.N || oy >= p.Hout || ox >= p.Wout) continue;
-                const long pixoff = ((long)n * p.Hout + oy) * p.Wout + ox;
+                const long pixoff = (KS == 1 && p.convt)
+                    ? ((long)n * 2 * p.Hout + 2 * oy + (phase >> 1)) * (2 * p.Wout) + 2 * ox + (phase & 1)
+                    : ((long)n * p.Hout + oy) * p.Wout + ox;
                 float v = acc[mi][ni][j] + bv;
                 if (p.act == 1) v = lrelu(v, p.alpha);
                 if (co < p.O1) {
@@ -284,7 +293,7 @@ int launch_conv_b(const ConvParamsB& p, hipStream_t stream) {
     ConvParamsB q = p;
     q.tiles_y = cdiv(p.Hout, TH);
     q.tiles_x = cdiv(p.Wout, TW);
-    const long blocks = (long)cdiv(p.O1 + p.O2, TN) * q.tiles_y * q.tiles_x * cdiv(p.N, NB);
+    const long blocks = (long)cdiv(p.O1 + p.O2, TN) * q.tiles_y * q.tiles_x * cdiv(p.N, NB) * (p.convt ? 4 : 1);
     auto kern = conv_fwd_bf16_kernel<KS, STRIDE, TH, TW, NB, TN>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, q);
@@ -525,7 +534,7 @@ int nimg_conv2d_fwd_bf16(const float* in1, int c1, const float* in2, int c2, con
     if (n == 0) return NIMG_OK;
     ConvParamsB p;
     p.in1 = in1; p.in2 = in2; p.wb = (const __bf16*)wb; p.bias = bias; p.out1 = out1; p.out2 = out2; p.act1 = act_mask;
-    p.pool_out = nullptr; p.pool_idx = nullptr;
+    p.pool_out = nullptr; p.pool_idx = nullptr; p.convt = 0;
     p.C1 = c1; p.C2 = c2; p.O1 = o1; p.O2 = o2; p.CinP = (c1 + c2 + 15) / 16 * 16;
     p.N = n; p.H = h; p.W = wd; p.Hout = hout; p.Wout = wout; p.pad_t = pad_t; p.pad_l = pad_l;
     p.tiles_y = p.tiles_x = 0; p.act = act; p.pad_mode = pad_mode; p.alpha = alpha;
@@ -536,6 +545,22 @@ int nimg_conv2d_fwd_bf16(const float* in1, int c1, const float* in2, int c2, con
     if (stride == 2 && ks == 2) return dispatch_b<2, 2>(p, s);
     if (stride == 2 && ks == 5) return dispatch_b<5, 2>(p, s);
     return NIMG_ERR_ARG;
+}
+
+/* Conv2DTranspose(cout, 2x2, stride 2) forward (pipelines.py:205) on the matrix core: four 1x1 products, one per output
+ * phase (dy, dx), in a single launch.  wb = nimg_conv_weights_bf16(w, 2, 2, cin'=cout, cout'=cin, mode 1) of the Keras
+ * kernel (2,2,Cout,Cin).  x (n,h,wd,cin) -> y (n,2h,2wd,cout). */
+int nimg_convt2x2_fwd_bf16(const float* x, const void* wb, const float* bias, float* y, int n, int h, int wd, int cin,
+                           int cout, void* stream) {
+    if (!x || !wb || !y || n < 0 || h <= 0 || wd <= 0 || cin <= 0 || cout <= 0 || (cin % 8)) return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    ConvParamsB p;
+    p.in1 = x; p.in2 = nullptr; p.wb = (const __bf16*)wb; p.bias = bias; p.out1 = y; p.out2 = nullptr; p.act1 = nullptr;
+    p.pool_out = nullptr; p.pool_idx = nullptr; p.convt = 1;
+    p.C1 = cin; p.C2 = 0; p.O1 = cout; p.O2 = 0; p.CinP = (cin + 15) / 16 * 16;
+    p.N = n; p.H = h; p.W = wd; p.Hout = h; p.Wout = wd; p.pad_t = 0; p.pad_l = 0;
+    p.tiles_y = p.tiles_x = 0; p.act = 0; p.pad_mode = 0; p.alpha = 0.f;
+    return dispatch_b<1, 1>(p, (hipStream_t)stream);
 }
 
 static int packed_splits_b(int cout, int n, int hout, int wout) {
@@ -1082,7 +1107,7 @@ int nimg_conv2d_pool_fwd_bf16(const float* in, int cin, const float* w, const vo
     if (!wb || (cin % 8)) return NIMG_ERR_ARG;
     ConvParamsB p;
     p.in1 = in; p.in2 = nullptr; p.wb = (const __bf16*)wb; p.bias = bias; p.out1 = nullptr; p.out2 = nullptr;
-    p.act1 = nullptr; p.pool_out = pool_out; p.pool_idx = pool_idx;
+    p.act1 = nullptr; p.pool_out = pool_out; p.pool_idx = pool_idx; p.convt = 0;
     p.C1 = cin; p.C2 = 0; p.O1 = cout; p.O2 = 0; p.CinP = (cin + 15) / 16 * 16;
     p.N = n; p.H = h; p.W = wd; p.Hout = h; p.Wout = wd; p.pad_t = p.pad_l = (ks - 1) / 2;
     p.tiles_y = p.tiles_x = 0; p.act = act; p.pad_mode = 0; p.alpha = alpha;

@@ -171,13 +171,124 @@ __global__ __launch_bounds__(256) void conv_wgrad_tiny_kernel(const TinyWParams 
     if (tid < NOUT) p.partial[(long)blockIdx.x * NOUT + tid] = acc;
 }
 
-__global__ void tiny_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int count, int blocks,
-                                   int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
+// The ConstrainedConv2D filter itself (5x5, 3 -> 3, same-size output): the one-thread-per-weight walk above issues two
+// LDS reads per FMA.  Here a thread owns one kernel ROW ky and one output row of a 48 x 32-pixel tile and slides along
+// it: each step loads ONE new input pixel and ONE dz pixel (16-byte LDS reads, row strides padded to 37 / 33 float4 so
+// that 16 lanes hit 64 distinct banks) and feeds 5 taps x 3 x 3 = 45 FMAs from registers.  240 of 256 threads are
+// busy; the next tile is fetched into registers while the current one is processed; the 48 row-partials of every
+// weight are summed through LDS once per workgroup, in a fixed order.
+__global__ __launch_bounds__(256, 2) void conv_wgrad_c3k5_kernel(const TinyWParams p) {
+    constexpr int KS = 5, TR = 48, TC = 32, XR = TR + KS - 1, XC = TC + KS - 1, XS = 37, DS = 33, NOUT = 225;
+    constexpr int NXP = (XR * XC + 255) / 256, NDP = (TR * TC + 255) / 256;
+    constexpr int SX = XR * XS, SD = TR * DS;                  // float4 entries
+    static_assert((SX + SD) * 4 >= 240 * 45, "reduction scratch must fit the tiles");
+    __shared__ float4 smem4[SX + SD];
+    float4* sx = smem4;
+    float4* sd = smem4 + SX;
+    const int tid = threadIdx.x;
+    const int ky = tid / TR, row = tid % TR;
+    const bool active = tid < KS * TR;
+    const long total = (long)p.N * p.tiles_y * p.tiles_x;
+    float acc[KS][3][3];
+#pragma unroll
+    for (int a = 0; a < KS; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[a][b][c] = 0.f;
+    float px[NXP][3], pd[NDP][3];
+    auto fetch = [&](long t) {
+        const int n = (int)(t / (p.tiles_y * p.tiles_x)), tile = (int)(t % (p.tiles_y * p.tiles_x));
+        const int y0 = (tile / p.tiles_x) * TR, x0 = (tile % p.tiles_x) * TC;
+#pragma unroll
+        for (int q = 0; q < NXP; ++q) {
+            const int i = tid + q * 256;
+            int gy = y0 - p.pad + i / XC, gx = x0 - p.pad + i % XC;
+            const bool ok = i < XR * XC && map_coord(gy, p.H, p.pad_mode) && map_coord(gx, p.W, p.pad_mode);
+            const float* src = p.in + (((long)n * p.H + (ok ? gy : 0)) * p.W + (ok ? gx : 0)) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) px[q][c] = ok ? src[c] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < NDP; ++q) {
+            const int i = tid + q * 256;
+            const int gy = y0 + i / TC, gx = x0 + i % TC;
+            const bool ok = i < TR * TC && gy < p.H && gx < p.W;
+            const float* src = p.dz + (((long)n * p.H + (ok ? gy : 0)) * p.W + (ok ? gx : 0)) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pd[q][c] = ok ? src[c] : 0.f;
+        }
+    };
+    if ((long)blockIdx.x < total) fetch(blockIdx.x);
+    for (long t = blockIdx.x; t < total; t += gridDim.x) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NXP; ++q) {
+            const int i = tid + q * 256;
+            if (i < XR * XC) sx[(i / XC) * XS + i % XC] = make_float4(px[q][0], px[q][1], px[q][2], 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < NDP; ++q) {
+            const int i = tid + q * 256;
+            if (i < TR * TC) sd[(i / TC) * DS + i % TC] = make_float4(pd[q][0], pd[q][1], pd[q][2], 0.f);
+        }
+        __syncthreads();
+        if (t + gridDim.x < total) fetch(t + gridDim.x);
+        if (active) {
+            const float4* xr = sx + (row + ky) * XS;
+            const float4* dr = sd + row * DS;
+            float4 w[KS];
+#pragma unroll
+            for (int k = 0; k < KS - 1; ++k) w[k + 1] = xr[k];
+#pragma unroll 4
+            for (int c = 0; c < TC; ++c) {
+#pragma unroll
+                for (int k = 0; k < KS - 1; ++k) w[k] = w[k + 1];
+                w[KS - 1] = xr[c + KS - 1];
+                const float4 d = dr[c];
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+                    acc[kx][0][0] = fmaf(w[kx].x, d.x, acc[kx][0][0]);
+                    acc[kx][0][1] = fmaf(w[kx].x, d.y, acc[kx][0][1]);
+                    acc[kx][0][2] = fmaf(w[kx].x, d.z, acc[kx][0][2]);
+                    acc[kx][1][0] = fmaf(w[kx].y, d.x, acc[kx][1][0]);
+                    acc[kx][1][1] = fmaf(w[kx].y, d.y, acc[kx][1][1]);
+                    acc[kx][1][2] = fmaf(w[kx].y, d.z, acc[kx][1][2]);
+                    acc[kx][2][0] = fmaf(w[kx].z, d.x, acc[kx][2][0]);
+                    acc[kx][2][1] = fmaf(w[kx].z, d.y, acc[kx][2][1]);
+                    acc[kx][2][2] = fmaf(w[kx].z, d.z, acc[kx][2][2]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem4);              // [45][240]
+    if (active) {
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+                for (int co = 0; co < 3; ++co) red[((kx * 3 + ci) * 3 + co) * (KS * TR) + tid] = acc[kx][ci][co];
+    }
+    __syncthreads();
+    if (tid < NOUT) {
+        const int kyo = tid / 45, rest = tid % 45;               // dw index = ((ky*5 + kx)*3 + ci)*3 + co = ky*45 + rest
+        const float* src = red + rest * (KS * TR) + kyo * TR;
+        float s = 0.f;
+        for (int r = 0; r < TR; ++r) s += src[r];
+        p.partial[(long)blockIdx.x * NOUT + tid] = s;
+    }
+}
+
+// one wave per weight: lane l adds the partials l, l+64, ... in order, then a fixed-shape butterfly => deterministic
+__global__ __launch_bounds__(64) void tiny_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                         int count, int blocks, int accumulate) {
+    const int i = blockIdx.x, lane = threadIdx.x;
     float s = 0.f;
-    for (int b = 0; b < blocks; ++b) s += partial[(long)b * count + i];
-    dw[i] = accumulate ? dw[i] + s : s;
+    for (int b = lane; b < blocks; b += 64) s += partial[(long)b * count + i];
+    s = wave_sum(s);
+    if (lane == 0) dw[i] = accumulate ? dw[i] + s : s;
 }
 
 }  // namespace
@@ -191,16 +302,17 @@ int nimg_internal_conv_wgrad_tiny(const float* in, const float* dz, float* dw, i
                                   int ks, int pad, int pad_mode, int accumulate, void* workspace, hipStream_t s) {
     TinyWParams p;
     p.in = in; p.dz = dz; p.partial = (float*)workspace; p.N = n; p.H = h; p.W = wd; p.pad = pad; p.pad_mode = pad_mode;
-    p.tiles_y = cdiv(h, 32); p.tiles_x = cdiv(wd, 32);
+    const bool c3k5 = ks == 5 && cin == 3 && cout == 3;
+    p.tiles_y = cdiv(h, c3k5 ? 48 : 32); p.tiles_x = cdiv(wd, 32);
     const long total = (long)n * p.tiles_y * p.tiles_x;
     const int blocks = (int)(total < TINY_BLOCKS ? total : TINY_BLOCKS);
-    if (ks == 5 && cin == 3 && cout == 3) hipLaunchKernelGGL((conv_wgrad_tiny_kernel<5, 3, 3>), dim3(blocks), dim3(256), 0, s, p);
+    if (c3k5) hipLaunchKernelGGL(conv_wgrad_c3k5_kernel, dim3(blocks), dim3(256), 0, s, p);
     else if (ks == 3 && cin == 3 && cout == 3) hipLaunchKernelGGL((conv_wgrad_tiny_kernel<3, 3, 3>), dim3(blocks), dim3(256), 0, s, p);
     else return NIMG_ERR_ARG;
     NIMG_CHECK_LAUNCH();
     const int count = ks * ks * cin * cout;
-    hipLaunchKernelGGL(tiny_reduce_kernel, dim3((count + 255) / 256), dim3(256), 0, s, (const float*)workspace, dw, count,
-                       blocks, accumulate);
+    hipLaunchKernelGGL(tiny_reduce_kernel, dim3(count), dim3(64), 0, s, (const float*)workspace, dw, count, blocks,
+                       accumulate);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }

@@ -296,6 +296,42 @@ __global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __r
     }
 }
 
+// float4 variant (cout % 4 == 0 and cout/4 divides 256): 16-byte loads, 4 independent accumulators per thread
+__global__ __launch_bounds__(256) void bias_grad_partial4_kernel(const float* __restrict__ dz,
+                                                                 float* __restrict__ partial, long npix, int cout,
+                                                                 long pix_per_block) {
+    __shared__ float4 red4[256];
+    const int tid = threadIdx.x, cq = cout >> 2, phases = 256 / cq;
+    const int c = tid % cq, ph = tid / cq;
+    const long p0 = (long)blockIdx.x * pix_per_block, p1 = min(npix, p0 + pix_per_block);
+    const float4* src = reinterpret_cast<const float4*>(dz) + c;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    long px = p0 + ph;
+    for (; px + 3L * phases < p1; px += 4L * phases) {
+        const float4 v0 = src[px * cq], v1 = src[(px + phases) * cq], v2 = src[(px + 2L * phases) * cq],
+                     v3 = src[(px + 3L * phases) * cq];
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+        a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+        a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+    }
+    for (; px < p1; px += phases) {
+        const float4 v = src[px * cq];
+        a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w;
+    }
+    red4[tid] = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y),
+                            (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
+    __syncthreads();
+    if (ph == 0) {
+        float4 s = red4[c];
+        for (int k = 1; k < phases; ++k) {
+            const float4 v = red4[k * cq + c];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        reinterpret_cast<float4*>(partial + (long)blockIdx.x * cout)[c] = s;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -410,20 +446,25 @@ int nimg_conv2d_wgrad(const float* in1, int c1, const float* in2, int c2, const 
     return NIMG_OK;
 }
 
+static long bias_grad_blocks(long npix) { return npix < 512 ? 1 : (npix / 512 > 2048 ? 2048 : npix / 512); }
+
 size_t nimg_bias_grad_workspace_bytes(long npix, int cout) {
-    const long blocks = npix < 1024 ? 1 : (npix / 1024 > 512 ? 512 : npix / 1024);
-    return (size_t)blocks * cout * sizeof(float);
+    return (size_t)bias_grad_blocks(npix) * cout * sizeof(float);
 }
 
 int nimg_bias_grad(const float* dz, float* db, long npix, int cout, int accumulate, void* workspace,
                    size_t workspace_bytes, void* stream) {
     if (!dz || !db || npix <= 0 || cout <= 0 || !workspace) return NIMG_ERR_ARG;
     if (workspace_bytes < nimg_bias_grad_workspace_bytes(npix, cout)) return NIMG_ERR_WORKSPACE;
-    const long blocks = npix < 1024 ? 1 : (npix / 1024 > 512 ? 512 : npix / 1024);
+    const long blocks = bias_grad_blocks(npix);
     const long ppb = (npix + blocks - 1) / blocks;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bias_grad_partial_kernel, dim3((unsigned)blocks), dim3(256), 256 * sizeof(float), s, dz,
-                       (float*)workspace, npix, cout, ppb);
+    if ((cout & 3) == 0 && (cout >> 2) <= 256 && 256 % (cout >> 2) == 0)
+        hipLaunchKernelGGL(bias_grad_partial4_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dz, (float*)workspace, npix,
+                           cout, ppb);
+    else
+        hipLaunchKernelGGL(bias_grad_partial_kernel, dim3((unsigned)blocks), dim3(256), 256 * sizeof(float), s, dz,
+                           (float*)workspace, npix, cout, ppb);
     NIMG_CHECK_LAUNCH();
     nimg::launch_reduce2((const float*)workspace, db, (long)cout, (int)blocks, nullptr, nullptr, 0, 0, accumulate, s);
     NIMG_CHECK_LAUNCH();

@@ -250,6 +250,10 @@ def convt2x2(x, w, bias):
     n, h, wd, cin = x.shape
     cout = w.shape[2]
     y = torch.empty((n, 2 * h, 2 * wd, cout), dtype=torch.float32, device=x.device)
+    if COMPUTE == 'bf16' and cin % 8 == 0 and cout >= 8:
+        wb = weights_bf16(w, 1)                # (2,2,Cout,Cin) read as HWIO with the channel roles swapped
+        _lib.call('nimg_convt2x2_fwd_bf16', _p(x), _p(wb), _p(bias), _p(y), n, h, wd, cin, cout, _stream())
+        return y
     _lib.call('nimg_convt2x2_fwd', _p(x), _p(w), _p(bias), _p(y), n, h, wd, cin, cout, _stream())
     return y
 

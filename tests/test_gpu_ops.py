@@ -435,6 +435,26 @@ def bf16_mode():
     ops.set_compute('f32')
 
 
+@pytest.mark.parametrize('shape', [(2, 8, 12, 64, 32), (5, 8, 8, 512, 256), (3, 16, 20, 24, 40), (2, 32, 32, 64, 32)])
+def test_convt2x2_bf16_mode(dev, bf16_mode, shape):
+    """Conv2DTranspose forward as four 1x1 MFMA products (bf16 operands): relative error at the bf16 level, and the
+    phase (dy, dx) -> output position / kernel tap mapping must be exactly the float32 kernel's."""
+    from neural_imaging_amd import ops
+    n, h, w, cin, cout = shape
+    x, wt, b = rnd((n, h, w, cin), 1), rnd((2, 2, cout, cin), 2, -0.3, 0.3), rnd((cout,), 3)
+    y = ops.convt2x2(g(x, dev), g(wt, dev), g(b, dev)).cpu().numpy()
+    ops.set_compute('f32')
+    ref = ops.convt2x2(g(x, dev), g(wt, dev), g(b, dev)).cpu().numpy()
+    ops.set_compute('bf16')
+    err = np.abs(y - ref).max() / np.abs(ref).max()
+    assert err < 1.5e-2, err
+    # a one-hot tap: only phase (dy, dx) = (1, 0) may be non-zero (bias excluded)
+    w1 = np.zeros_like(wt)
+    w1[1, 0] = wt[1, 0]
+    y1 = ops.convt2x2(g(x, dev), g(w1, dev), g(np.zeros_like(b), dev)).cpu().numpy()
+    assert np.abs(y1[:, 0::2]).max() == 0 and np.abs(y1[:, 1::2, 1::2]).max() == 0 and np.abs(y1[:, 1::2, 0::2]).max() > 0
+
+
 BF16_CASES = [(2, 40, 72, 3, 0, 32, 5, 1), (2, 24, 24, 4, 0, 64, 3, 1), (2, 32, 32, 32, 0, 64, 5, 1), (2, 16, 16, 16, 16, 32, 3, 1), (5, 8, 8, 64, 0, 128, 3, 1),
               (2, 20, 24, 8, 0, 24, 3, 1), (3, 16, 16, 64, 0, 64, 1, 1), (2, 32, 32, 64, 0, 128, 5, 2)]
 
