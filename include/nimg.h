@@ -211,6 +211,15 @@ int nimg_l2_loss(const float* target, const float* y, float* loss, float* grad_y
  *   mode 1 (input gradient) wb[co/16][taps-1-tap][ci][co%16] = w[tap][ci][co]   (then call with cin/cout swapped) */
 size_t nimg_conv_weights_bf16_bytes(int ks_h, int ks_w, int cin, int cout, int mode);
 int nimg_conv_weights_bf16(const float* w, void* wb, int ks_h, int ks_w, int cin, int cout, int mode, void* stream);
+/* Backward of a fused conv+pool layer with few input channels (FAN conv1, forensics.py:69-70) without materialising
+ * the sparse full-resolution gradient: g (n,h/2,wd/2,cout) = upstream gradient x LeakyReLU'(pooled), idx = arg-max
+ * bytes of nimg_conv2d_pool_fwd[_bf16]; the 2x2 un-pooling happens while the tiles are staged.
+ *   wgrad: cin 3|4, ks 3|5, SAME, stride 1;  dgrad: ci 3, cz 32, ks 5 (w = the forward kernel as stored). */
+int nimg_conv2d_wgrad_pooled_bf16(const float* in, int cin, const float* g, const unsigned char* idx, int cout,
+                                  float* dw, float* db, int n, int h, int wd, int ks, int accumulate, void* workspace,
+                                  size_t workspace_bytes, void* stream);
+int nimg_conv2d_dgrad_fewin_pooled_bf16(const float* g, const unsigned char* idx, const float* w, float* out, int ci,
+                                        int cz, int n, int h, int wd, int ks, void* stream);
 /* Conv2DTranspose(cout, [2,2], [2,2]) forward (pipelines.py:205) in throughput mode: four 1x1 products (one per output
  * phase) on the matrix core in one launch.  wb = nimg_conv_weights_bf16(w, 2, 2, cout, cin, mode 1) of the Keras
  * (2,2,Cout,Cin) kernel; x (n,h,wd,cin) -> y (n,2h,2wd,cout); cin % 8 == 0. */

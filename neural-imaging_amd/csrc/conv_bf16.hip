@@ -321,6 +321,8 @@ struct WgradParamsB {
     const float* in1;
     const float* in2;
     const float* dz;
+    const unsigned char* dz_idx;   // optional (packed kernel): dz is the POOLED gradient (Hout/2 x Wout/2) of a fused
+                                   // conv+pool layer and dz_idx its arg-max bytes - the 2x2 un-pooling happens while staging
     float* partial;
     float* db_partial;
     int C1, C2, Cout;
@@ -583,9 +585,10 @@ size_t nimg_conv2d_wgrad_bf16_workspace_bytes(int cin, int cout, int ks_h, int k
     return m > tiny ? m : tiny;
 }
 
-int nimg_conv2d_wgrad_bf16(const float* in1, int c1, const float* in2, int c2, const float* dz, int cout, float* dw,
-                           float* db, int n, int h, int wd, int ks, int stride, int pad_t, int pad_l, int pad_mode,
-                           int hout, int wout, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, const float* dz,
+                           const unsigned char* dz_idx, int cout, float* dw, float* db, int n, int h, int wd, int ks,
+                           int stride, int pad_t, int pad_l, int pad_mode, int hout, int wout, int accumulate,
+                           void* workspace, size_t workspace_bytes, void* stream) {
     if (!in1 || !dz || !dw || c1 <= 0 || c2 < 0 || cout <= 0 || n <= 0 || h <= 0 || wd <= 0) return NIMG_ERR_ARG;
     if ((c2 > 0 && !in2) || hout <= 0 || wout <= 0 || !workspace || pad_mode < 0 || pad_mode > 2) return NIMG_ERR_ARG;
     const int cin = c1 + c2;
@@ -596,7 +599,7 @@ int nimg_conv2d_wgrad_bf16(const float* in1, int c1, const float* in2, int c2, c
                                              (hipStream_t)stream);
     if (c2 == 0 && (c1 == 3 || c1 == 4) && stride == 1 && (ks == 3 || ks == 5)) {      // (tap, ci)-packed M dimension
         WgradParamsB q;
-        q.in1 = in1; q.in2 = nullptr; q.dz = dz; q.partial = (float*)workspace; q.db_partial = nullptr;
+        q.in1 = in1; q.in2 = nullptr; q.dz = dz; q.dz_idx = dz_idx; q.partial = (float*)workspace; q.db_partial = nullptr;
         q.C1 = c1; q.C2 = 0; q.Cout = cout; q.N = n; q.H = h; q.W = wd; q.Hout = hout; q.Wout = wout;
         q.pad_t = pad_t; q.pad_l = pad_l; q.pad_mode = pad_mode;
         q.tiles_y = cdiv(hout, B_TH); q.tiles_x = cdiv(wout, B_TW);
@@ -628,7 +631,7 @@ int nimg_conv2d_wgrad_bf16(const float* in1, int c1, const float* in2, int c2, c
     }
     if ((c1 % 4) || (c2 % 4) || (cout % 4) || (c2 > 0 && (c1 % 8))) return NIMG_ERR_ARG;
     WgradParamsB p;
-    p.in1 = in1; p.in2 = in2; p.dz = dz; p.partial = (float*)workspace; p.db_partial = nullptr;
+    p.in1 = in1; p.in2 = in2; p.dz = dz; p.dz_idx = nullptr; p.partial = (float*)workspace; p.db_partial = nullptr;
     p.C1 = c1; p.C2 = c2; p.Cout = cout; p.N = n; p.H = h; p.W = wd; p.Hout = hout; p.Wout = wout;
     p.pad_t = pad_t; p.pad_l = pad_l; p.pad_mode = pad_mode;
     p.tiles_y = cdiv(hout, B_TH); p.tiles_x = cdiv(wout, B_TW);
@@ -659,6 +662,24 @@ int nimg_conv2d_wgrad_bf16(const float* in1, int c1, const float* in2, int c2, c
                    p.splits, accumulate, s);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
+}
+
+int nimg_conv2d_wgrad_bf16(const float* in1, int c1, const float* in2, int c2, const float* dz, int cout, float* dw,
+                           float* db, int n, int h, int wd, int ks, int stride, int pad_t, int pad_l, int pad_mode,
+                           int hout, int wout, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    return wgrad_bf16_impl(in1, c1, in2, c2, dz, nullptr, cout, dw, db, n, h, wd, ks, stride, pad_t, pad_l, pad_mode, hout,
+                           wout, accumulate, workspace, workspace_bytes, stream);
+}
+
+/* Weight (+bias) gradient of a fused conv+pool layer (nimg_conv2d_pool_fwd_bf16) with few input channels (cin 3|4):
+ * the output gradient arrives POOLED - g (n,h/2,wd/2,cout), already multiplied by LeakyReLU'(pooled) - with the
+ * arg-max bytes of the forward pass; the sparse full-resolution gradient is never materialised. */
+int nimg_conv2d_wgrad_pooled_bf16(const float* in, int cin, const float* g, const unsigned char* idx, int cout,
+                                  float* dw, float* db, int n, int h, int wd, int ks, int accumulate, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    if (!idx || (cin != 3 && cin != 4) || (ks != 3 && ks != 5) || (h & 1) || (wd & 1) || (cout & 3)) return NIMG_ERR_ARG;
+    return wgrad_bf16_impl(in, cin, nullptr, 0, g, idx, cout, dw, db, n, h, wd, ks, 1, (ks - 1) / 2, (ks - 1) / 2, 0, h, wd,
+                           accumulate, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"
@@ -870,6 +891,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_packed_bf16_kernel(const Wgrad
     constexpr int IPT = (NPIXH + 255) / 256, ZPT = NPIX * (COT / 4) / 256;
     float prei[IPT][CINP];
     float4 prez[ZPT];
+    unsigned int prek[ZPT];
     const bool vec_z = (p.Cout % 4 == 0);
     auto fetch = [&](long wk_) {
         const int n_ = (int)(wk_ / tiles), tile_ = (int)(wk_ % tiles);
@@ -890,8 +912,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_packed_bf16_kernel(const Wgrad
                 const int pix = item / (COT / 4), c = co0 + (item % (COT / 4)) * 4;
                 const int oy = ty_ + pix / B_TW, ox = tx_ + pix % B_TW;
                 prez[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (oy < p.Hout && ox < p.Wout && c < p.Cout)
+                if (p.dz_idx) {              // pooled gradient + arg-max: this pixel receives it iff it was the window maximum
+                    prek[q] = 0xffffffffu;
+                    if (oy < p.Hout && ox < p.Wout && c < p.Cout) {
+                        const long po = (((long)n_ * (p.Hout >> 1) + (oy >> 1)) * (p.Wout >> 1) + (ox >> 1)) * p.Cout + c;
+                        prez[q] = *reinterpret_cast<const float4*>(p.dz + po);
+                        prek[q] = *reinterpret_cast<const unsigned int*>(p.dz_idx + po);
+                    }
+                } else if (oy < p.Hout && ox < p.Wout && c < p.Cout) {
                     prez[q] = *reinterpret_cast<const float4*>(p.dz + (((long)n_ * p.Hout + oy) * p.Wout + ox) * p.Cout + c);
+                }
             }
         }
     };
@@ -912,7 +942,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_packed_bf16_kernel(const Wgrad
 #pragma unroll
             for (int q = 0; q < ZPT; ++q) {
                 const int item = tid + q * 256;
-                *reinterpret_cast<float4*>(sZ + (item / (COT / 4)) * COT + (item % (COT / 4)) * 4) = prez[q];
+                float4 v = prez[q];
+                if (p.dz_idx) {
+                    const int pix = item / (COT / 4);
+                    const unsigned pos = (unsigned)((((ty0 + pix / B_TW) & 1) << 1) | ((tx0 + pix % B_TW) & 1));
+                    const unsigned k = prek[q];
+                    v.x = (k & 0xffu) == pos ? v.x : 0.f;
+                    v.y = ((k >> 8) & 0xffu) == pos ? v.y : 0.f;
+                    v.z = ((k >> 16) & 0xffu) == pos ? v.z : 0.f;
+                    v.w = (k >> 24) == pos ? v.w : 0.f;
+                }
+                *reinterpret_cast<float4*>(sZ + (item / (COT / 4)) * COT + (item % (COT / 4)) * 4) = v;
             }
         } else {
             for (int item = tid; item < NPIX * COT; item += 256) {
@@ -974,6 +1014,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_packed_bf16_kernel(const Wgrad
 // (kh,kw,CI,CZ) as stored - its [ky][(kx,ci)][co] order is exactly the B operand.
 template <int KS, int CI>
 __global__ __launch_bounds__(256) void conv_dgrad_fewin_bf16_kernel(const float* __restrict__ dz,
+                                                                    const unsigned char* __restrict__ dz_idx,
                                                                     const float* __restrict__ w,
                                                                     float* __restrict__ out, int N, int H, int W,
                                                                     int tiles_y, int tiles_x) {
@@ -1007,9 +1048,21 @@ __global__ __launch_bounds__(256) void conv_dgrad_fewin_bf16_kernel(const float*
         const int gy = u0 + rr - (KS - 1 - P), gx = v0 - (KS - 1 - P) + xx;
         float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            const float* src = dz + (((long)n * H + gy) * W + gx) * CZ + q * 8;
+            // dz_idx given: dz is the pooled gradient of the fused conv+pool layer, un-pooled here through its arg-max bytes
+            const long off = dz_idx ? (((long)n * (H >> 1) + (gy >> 1)) * (W >> 1) + (gx >> 1)) * CZ + q * 8
+                                    : (((long)n * H + gy) * W + gx) * CZ + q * 8;
+            const float* src = dz + off;
             const float4 v0_ = *reinterpret_cast<const float4*>(src), v1_ = *reinterpret_cast<const float4*>(src + 4);
             f[0] = v0_.x; f[1] = v0_.y; f[2] = v0_.z; f[3] = v0_.w; f[4] = v1_.x; f[5] = v1_.y; f[6] = v1_.z; f[7] = v1_.w;
+            if (dz_idx) {
+                const uint2 k = *reinterpret_cast<const uint2*>(dz_idx + off);
+                const unsigned pos = (unsigned)(((gy & 1) << 1) | (gx & 1));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    f[e] = ((k.x >> (8 * e)) & 0xffu) == pos ? f[e] : 0.f;
+                    f[4 + e] = ((k.y >> (8 * e)) & 0xffu) == pos ? f[4 + e] : 0.f;
+                }
+            }
         }
         const bf16x8 b = pack8(f);
         sD[pix * 4 + (q ^ ((pix >> 2) & 3))] = *reinterpret_cast<const uint4*>(&b);
@@ -1118,8 +1171,8 @@ int nimg_conv2d_pool_fwd_bf16(const float* in, int cin, const float* w, const vo
 
 /* input gradient of a (ks,ks,ci,32) SAME stride-1 convolution towards its ci (= 3) input channels; w = the FORWARD
  * kernel as stored (not flipped) */
-int nimg_conv2d_dgrad_fewin_bf16(const float* dz, const float* w, float* out, int ci, int cz, int n, int h, int wd,
-                                 int ks, void* stream) {
+static int dgrad_fewin_impl(const float* dz, const unsigned char* dz_idx, const float* w, float* out, int ci, int cz,
+                            int n, int h, int wd, int ks, void* stream) {
     if (!dz || !w || !out || n < 0 || h <= 0 || wd <= 0) return NIMG_ERR_ARG;
     if (cz != 32 || ci != 3 || ks != 5) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
@@ -1127,9 +1180,22 @@ int nimg_conv2d_dgrad_fewin_bf16(const float* dz, const float* w, float* out, in
     const int ty = cdiv(h, TH), tx = cdiv(wd, TWO);
     constexpr size_t lds = (size_t)(ROWS * 32 * 4 + KS * 32 * 4) * sizeof(uint4) + 4 * 32 * 16 * sizeof(float);
     hipLaunchKernelGGL((conv_dgrad_fewin_bf16_kernel<5, 3>), dim3((unsigned)((long)n * ty * tx)), dim3(256), lds,
-                       (hipStream_t)stream, dz, w, out, n, h, wd, ty, tx);
+                       (hipStream_t)stream, dz, dz_idx, w, out, n, h, wd, ty, tx);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
+}
+
+int nimg_conv2d_dgrad_fewin_bf16(const float* dz, const float* w, float* out, int ci, int cz, int n, int h, int wd,
+                                 int ks, void* stream) {
+    return dgrad_fewin_impl(dz, nullptr, w, out, ci, cz, n, h, wd, ks, stream);
+}
+
+/* the same input gradient with the output gradient given POOLED (g (n,h/2,wd/2,cz) + arg-max bytes), see
+ * nimg_conv2d_wgrad_pooled_bf16 */
+int nimg_conv2d_dgrad_fewin_pooled_bf16(const float* g, const unsigned char* idx, const float* w, float* out, int ci,
+                                        int cz, int n, int h, int wd, int ks, void* stream) {
+    if (!idx || (h & 1) || (wd & 1)) return NIMG_ERR_ARG;
+    return dgrad_fewin_impl(g, idx, w, out, ci, cz, n, h, wd, ks, stream);
 }
 
 }  // extern "C"

@@ -109,15 +109,25 @@ class FAN(TFModel):
         nconv = len(self._convs)
         pool = t['pool{}'.format(nconv)]
         self._conv1x1.backward_params(P, pool, dz)
-        d_pool = self._conv1x1.backward_input(P, dz, hw(pool))
+        # fused layers: the producer of d_pool applies LeakyReLU'(pooled) in its epilogue (sign(window max) = sign(pooled))
+        fused = lambda i: i >= 1 and t.get('idx{}'.format(i)) is not None
+        d_pool = self._conv1x1.backward_input(P, dz, hw(pool), act_mask=pool if fused(nconv) else None)
         for i in range(nconv, 0, -1):
+            conv = self._convs[i - 1]
             inp = t['pool{}'.format(i - 1)] if i > 1 else t['constrained']
-            if 'idx{}'.format(i) in t:
-                dz = ops.maxpool2_unpool(d_pool, t['idx{}'.format(i)], t['pool{}'.format(i)], apply_mask=True)
+            prev_mask = inp if fused(i - 1) else None
+            if fused(i) and ops.pooled_backward_ok(conv.cin, conv.cout, conv.ks) and prev_mask is None:
+                # the pooled gradient feeds the weight / input gradient kernels directly (un-pooled while staging)
+                ops.conv2d_wgrad_pooled(inp, d_pool, t['idx{}'.format(i)], conv.ks, dw=P.g[conv.name + '/kernel'],
+                                        db=P.g[conv.name + '/bias'])
+                d_pool = ops.conv2d_dgrad_pooled(d_pool, t['idx{}'.format(i)], P.p[conv.name + '/kernel'])
+                continue
+            if fused(i):
+                dz = ops.maxpool2_unpool(d_pool, t['idx{}'.format(i)], None, apply_mask=False)
             else:
                 dz = ops.maxpool2_bwd(d_pool, t['conv{}'.format(i)], None, apply_mask=True)
-            self._convs[i - 1].backward_params(P, inp, dz)
-            d_pool = self._convs[i - 1].backward_input(P, dz, hw(inp))
+            conv.backward_params(P, inp, dz)
+            d_pool = conv.backward_input(P, dz, hw(inp), act_mask=prev_mask)
         self._constrained.backward_params(P, t['x'], d_pool)
         dx = self._constrained.backward_input(t['nf'], d_pool) if need_input_grad else None
         return loss, dx

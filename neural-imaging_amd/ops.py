@@ -320,6 +320,40 @@ def maxpool2_unpool(dp, idx, pooled, apply_mask=True, out=None):
     return dz
 
 
+def pooled_backward_ok(cin, cout, ks):
+    """True when the backward of a fused conv+pool layer can consume the pooled gradient directly (no un-pooling
+    pass): throughput mode, the FAN conv1 shape class."""
+    return COMPUTE == 'bf16' and cin == 3 and cout == 32 and ks == 5
+
+
+def conv2d_wgrad_pooled(x, g, idx, ks, dw=None, db=None):
+    """Weight / bias gradient of conv2d_pool from the pooled gradient g (already x LeakyReLU') and the arg-max bytes."""
+    _f32(x, g, dw, db)
+    _chk(idx)
+    n, h, wd, cin = x.shape
+    cout = g.shape[3]
+    if dw is None:
+        dw = torch.empty((ks, ks, cin, cout), dtype=torch.float32, device=x.device)
+    need = _lib.load().nimg_conv2d_wgrad_bf16_workspace_bytes(cin, cout, ks, ks, n, h, wd)
+    ws = _ws.get(need, x.device)
+    _lib.call('nimg_conv2d_wgrad_pooled_bf16', _p(x), cin, _p(g), _p(idx), cout, _p(dw), _p(db), n, h, wd, ks, 0, _p(ws),
+              ws.numel(), _stream())
+    return dw
+
+
+def conv2d_dgrad_pooled(g, idx, w, out=None):
+    """Input gradient of conv2d_pool (3 <- 32 channels, 5x5) from the pooled gradient and the arg-max bytes."""
+    _f32(g, w, out)
+    _chk(idx)
+    n, hp, wp, cz = g.shape
+    ks, ci = w.shape[0], w.shape[2]
+    if out is None:
+        out = torch.empty((n, 2 * hp, 2 * wp, ci), dtype=torch.float32, device=g.device)
+    _lib.call('nimg_conv2d_dgrad_fewin_pooled_bf16', _p(g), _p(idx), _p(w), _p(out), ci, cz, n, 2 * hp, 2 * wp, ks,
+              _stream())
+    return out
+
+
 def d2s_clip(x, scale=1.0, shift=0.0, clip=True):
     _f32(x)
     n, h, w, c4 = x.shape

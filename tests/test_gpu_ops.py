@@ -455,6 +455,28 @@ def test_convt2x2_bf16_mode(dev, bf16_mode, shape):
     assert np.abs(y1[:, 0::2]).max() == 0 and np.abs(y1[:, 1::2, 1::2]).max() == 0 and np.abs(y1[:, 1::2, 0::2]).max() > 0
 
 
+def test_pooled_gradient_kernels_bf16(dev, bf16_mode):
+    """FAN conv1 backward from the POOLED gradient + arg-max bytes == un-pool pass followed by the ordinary weight /
+    input gradient kernels, bit for bit (the staged bf16 operands are identical)."""
+    from neural_imaging_amd import ops
+    n, h, w = 3, 32, 48
+    x, wt, b = rnd((n, h, w, 3), 1), rnd((5, 5, 3, 32), 2, -0.2, 0.2), rnd((32,), 3, -0.1, 0.1)
+    xd, wd, bd = g(x, dev), g(wt, dev), g(b, dev)
+    pooled, idx = ops.conv2d_pool(xd, wd, bd, act='leaky_relu')
+    gp = g(rnd(tuple(pooled.shape), 4), dev)
+    dz = ops.maxpool2_unpool(gp, idx, None, apply_mask=False)
+    db_ref = torch.zeros(32, device=dev)
+    dw_ref = ops.conv2d_wgrad(xd, dz, 5, db=db_ref)
+    dx_ref = ops.conv2d_dgrad(dz, wd, (h, w))
+    assert ops.pooled_backward_ok(3, 32, 5)
+    db = torch.zeros(32, device=dev)
+    dw = ops.conv2d_wgrad_pooled(xd, gp, idx, 5, db=db)
+    dx = ops.conv2d_dgrad_pooled(gp, idx, wd)
+    assert np.array_equal(dw.cpu().numpy(), dw_ref.cpu().numpy())
+    assert np.array_equal(db.cpu().numpy(), db_ref.cpu().numpy())
+    assert np.array_equal(dx.cpu().numpy(), dx_ref.cpu().numpy())
+
+
 BF16_CASES = [(2, 40, 72, 3, 0, 32, 5, 1), (2, 24, 24, 4, 0, 64, 3, 1), (2, 32, 32, 32, 0, 64, 5, 1), (2, 16, 16, 16, 16, 32, 3, 1), (5, 8, 8, 64, 0, 128, 3, 1),
               (2, 20, 24, 8, 0, 24, 3, 1), (3, 16, 16, 64, 0, 64, 1, 1), (2, 32, 32, 64, 0, 128, 5, 2)]
 
