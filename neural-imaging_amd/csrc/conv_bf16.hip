@@ -568,7 +568,7 @@ int nimg_convt2x2_fwd_bf16(const float* x, const void* wb, const float* bias, fl
 static int packed_splits_b(int cout, int n, int hout, int wout) {
     const long blocks_io = cdiv(cout, cout <= 32 ? 32 : 64);
     const long work = (long)n * cdiv(hout, B_TH) * cdiv(wout, B_TW);
-    long splits = (512 + blocks_io - 1) / blocks_io;
+    long splits = (1024 + blocks_io - 1) / blocks_io;
     if (splits > work) splits = work;
     if (splits < 1) splits = 1;
     const long wps = (work + splits - 1) / splits;
@@ -776,6 +776,14 @@ __global__ __launch_bounds__(256) void conv_fwd_packed_bf16_kernel(const float* 
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int j = 0; j < 16; ++j) acc[mi][ni][j] = 0.0f;
+        // an opaque per-tile copy of the pixel bases: otherwise all KSTEPS*8*MI gather addresses (loop invariant) are
+        // hoisted out of the tile loop and pinned in ~80 VGPRs, which drops the kernel to one wave per SIMD
+        int ab[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            ab[mi] = abase[mi];
+            asm volatile("" : "+v"(ab[mi]));
+        }
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
             bf16x8 b[NI];
@@ -786,12 +794,15 @@ __global__ __launch_bounds__(256) void conv_fwd_packed_bf16_kernel(const float* 
             for (int mi = 0; mi < MI; ++mi) {
                 float f[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) f[j] = sA[koff[s][j] + abase[mi]];
+                for (int j = 0; j < 8; ++j) f[j] = sA[koff[s][j] + ab[mi]];
                 const bf16x8 a = pack8(f);
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[ni], acc[mi][ni], 0, 0, 0);
             }
+            // keep the gathers of later k-steps from being hoisted up here: that costs ~250 VGPRs (one wave per SIMD);
+            // with the fence the kernel fits 3-4 waves per SIMD, which is what hides the LDS gather latency
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (pool_out) {                 // fused activation + 2x2 max-pool (common.h); private per-wave scratch
             float* elds = reinterpret_cast<float*>(smem_raw + A_BYTES + TN * KP * 2) + wave * (32 * (NI * 32 + EPI_PAD));
@@ -1018,7 +1029,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_fewin_bf16_kernel(const float*
                                                                     const float* __restrict__ w,
                                                                     float* __restrict__ out, int N, int H, int W,
                                                                     int tiles_y, int tiles_x) {
-    constexpr int CZ = 32, P = (KS - 1) / 2, TH = 16, TWO = 32 - (KS - 1);      // TWO output columns per tile
+    constexpr int CZ = 32, P = (KS - 1) / 2, TH = 8, TWO = 32 - (KS - 1);      // TWO output columns per tile
     constexpr int ROWS = TH + KS - 1, NJ = KS * CI;
     static_assert(NJ <= 32, "KS * CI must fit one MFMA N tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1092,7 +1103,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_fewin_bf16_kernel(const float*
 #pragma unroll
             for (int j = 0; j < 16; ++j) myT[((j & 3) + 8 * (j >> 2) + 4 * half) * 16 + (lane & 31)] = acc[j];
         }
-        __syncthreads();                             // TH % 4 == 0: every wave runs the same trip count
+        __builtin_amdgcn_wave_barrier();             // myT is private to this wave; its LDS operations complete in order
         const int u = u0 + ur;
         for (int o = lane; o < TWO * CI; o += 64) {
             const int vi = o / CI, ci = o % CI, v = v0 + vi;
@@ -1101,7 +1112,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_fewin_bf16_kernel(const float*
             for (int kx = 0; kx < KS; ++kx) s += myT[(vi + (KS - 1) - kx) * 16 + kx * CI + ci];
             if (u < H && v < W) out[(((long)n * H + u) * W + v) * CI + ci] = s;
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -1176,7 +1187,7 @@ static int dgrad_fewin_impl(const float* dz, const unsigned char* dz_idx, const 
     if (!dz || !w || !out || n < 0 || h <= 0 || wd <= 0) return NIMG_ERR_ARG;
     if (cz != 32 || ci != 3 || ks != 5) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
-    constexpr int KS = 5, TH = 16, TWO = 32 - (KS - 1), ROWS = TH + KS - 1;
+    constexpr int KS = 5, TH = 8, TWO = 32 - (KS - 1), ROWS = TH + KS - 1;
     const int ty = cdiv(h, TH), tx = cdiv(wd, TWO);
     constexpr size_t lds = (size_t)(ROWS * 32 * 4 + KS * 32 * 4) * sizeof(uint4) + 4 * 32 * 16 * sizeof(float);
     hipLaunchKernelGGL((conv_dgrad_fewin_bf16_kernel<5, 3>), dim3((unsigned)((long)n * ty * tx)), dim3(256), lds,
