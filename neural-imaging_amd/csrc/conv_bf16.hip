@@ -353,9 +353,11 @@ __device__ __forceinline__ bf16x8 tr_read8(const unsigned char* p0, const unsign
 
 constexpr int B_ZS = 192;      // dz tile row stride in bytes (64 co bf16 = 128 B, padded so 4 rows hit 4 bank quarters)
 
-template <int KS, int STRIDE>
-__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParamsB p) {
-    constexpr int TAPS = KS * KS, NT = (TAPS + 3) / 4;
+// NW waves share the taps: 4 for small kernels; 8 for 5x5, where 4 waves would each pin 7 taps x 32 = 224 accumulator
+// registers (one wave per SIMD, nothing to hide LDS / barrier latency behind) - with 8 it is 4 taps = 128, two per SIMD.
+template <int KS, int STRIDE, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const WgradParamsB p) {
+    constexpr int TAPS = KS * KS, NT = (TAPS + NW - 1) / NW, NTHR = NW * 64;
     constexpr int THH = (B_TH - 1) * STRIDE + KS, TWH = (B_TW - 1) * STRIDE + KS;
     constexpr int NPIXH = THH * TWH, NPIX = B_TH * B_TW;
     static_assert(STRIDE == 1 || STRIDE == 2, "stride");
@@ -390,7 +392,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParamsB
     const int a_lane = ((half * 8 + (g >> 2)) * STRIDE) * 64 + (sub * 16 + (g & 3) * 4) * 2;   // + pixel terms
     const int z_lane = (half * 8 + (g >> 2)) * B_ZS + (sub * 16 + (g & 3) * 4) * 2;
     // async-stage split: tile t+1 travels HBM -> registers while tile t is multiplied
-    constexpr int IP = (NPIXH * 4 + 255) / 256, ZP = (NPIX * 8) / 256;
+    constexpr int IP = (NPIXH * 4 + NTHR - 1) / NTHR, ZP = (NPIX * 8) / NTHR;
+    static_assert((NPIX * 8) % NTHR == 0, "dz tile must divide over the threads");
     float4 preI[IP][2], preZ[ZP][2];
     auto fetch = [&](long wk_) {
         const int n_ = (int)(wk_ / tiles), tile_ = (int)(wk_ % tiles);
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParamsB
         const int iy_ = ty_ * STRIDE - p.pad_t, ix_ = tx_ * STRIDE - p.pad_l;
 #pragma unroll
         for (int q = 0; q < IP; ++q) {
-            const int item = tid + q * 256;
+            const int item = tid + q * NTHR;
             const int pix = item >> 2, c = ci0 + (item & 3) * 8;
             int gy = iy_ + pix / TWH, gx = ix_ + pix % TWH;
             preI[q][0] = preI[q][1] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParamsB
         }
 #pragma unroll
         for (int q = 0; q < ZP; ++q) {
-            const int item = tid + q * 256;
+            const int item = tid + q * NTHR;
             const int pix = item >> 3, c = co0 + (item & 7) * 8;
             const int oy = ty_ + pix / B_TW, ox = tx_ + pix % B_TW;
             preZ[q][0] = preZ[q][1] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParamsB
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < IP; ++q) {
-            const int item = tid + q * 256;
+            const int item = tid + q * NTHR;
             if (item < NPIXH * 4) {
                 const float f[8] = {preI[q][0].x, preI[q][0].y, preI[q][0].z, preI[q][0].w,
                                     preI[q][1].x, preI[q][1].y, preI[q][1].z, preI[q][1].w};
@@ -437,7 +440,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParamsB
         }
 #pragma unroll
         for (int q = 0; q < ZP; ++q) {
-            const int item = tid + q * 256;
+            const int item = tid + q * NTHR;
             const float f[8] = {preZ[q][0].x, preZ[q][0].y, preZ[q][0].z, preZ[q][0].w,
                                 preZ[q][1].x, preZ[q][1].y, preZ[q][1].z, preZ[q][1].w};
             if (do_bias) {                      // fused bias gradient in float32: this thread always owns channels q*8..
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParamsB
             const bf16x8 b1 = tr_read8(zr + 64, zr + 4 * B_ZS + 64);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const int tap = wave + 4 * t;
+                const int tap = wave + NW * t;
                 if (tap < TAPS) {
                     const unsigned char* ir = sI + ((r * STRIDE + tap / KS) * TWH + (tap % KS)) * 64 + a_lane;
                     const bf16x8 a = tr_read8(ir, ir + 4 * STRIDE * 64);
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParamsB
             }
         }
     }
-    if (do_bias) {                              // thread t holds channels (t & 7) * 8 .. + 7: reduce the 32 owners
+    if (do_bias) {                              // thread t holds channels (t & 7) * 8 .. + 7: reduce the NTHR/8 owners
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem_raw);
 #pragma unroll
@@ -474,14 +477,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParamsB
         __syncthreads();
         if (tid < B_CO && co0 + tid < p.Cout) {
             float sum = 0.f;
-            for (int o = 0; o < 32; ++o) sum += red[(o * 8 + (tid >> 3)) * 8 + (tid & 7)];
+            for (int o = 0; o < NTHR / 8; ++o) sum += red[(o * 8 + (tid >> 3)) * 8 + (tid & 7)];
             p.db_partial[(long)split * p.Cout + co0 + tid] = sum;
         }
     }
     float* slab = p.partial + (long)split * TAPS * Cin * p.Cout;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int tap = wave + 4 * t;
+        const int tap = wave + NW * t;
         if (tap >= TAPS) continue;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
@@ -646,9 +649,10 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
     do {                                                                                                      \
         constexpr int THH = (B_TH - 1) * ST_ + KS_, TWH = (B_TW - 1) * ST_ + KS_;                             \
         constexpr size_t lds = (size_t)THH * TWH * 64 + (size_t)B_TH * B_TW * B_ZS;                         \
-        auto k = conv_wgrad_bf16_kernel<KS_, ST_>;                                                            \
+        constexpr int NW = KS_ == 5 ? 8 : 4;                                                                  \
+        auto k = conv_wgrad_bf16_kernel<KS_, ST_, NW>;                                                        \
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
-        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, s, p);                                  \
+        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NW * 64), lds, s, p);                              \
     } while (0)
     if (stride == 1 && ks == 1) NIMG_WGB(1, 1);
     else if (stride == 1 && ks == 3) NIMG_WGB(3, 1);
