@@ -109,40 +109,53 @@ __device__ __forceinline__ void pool_via_lds(const nimg_f32x16 (&acc)[NI], float
     }
 }
 
-// dst[i] = sum_k partial[k][i] over `splits` slabs, fixed order => deterministic (split-K weight gradients, fused bias
-// sums); 4 independent accumulators keep 4 loads in flight per thread.  `block` of `nblocks` workgroups of 256.
+// dst[i] = sum_k partial[k][i] over `splits` slabs, in a fixed order => deterministic (split-K weight gradients, fused
+// bias sums).  A workgroup of 256 covers 16 float4 columns x 16 slab segments: thread (col, seg) adds slabs seg, seg+16,
+// ... (two independent accumulators), then the 16 segment sums are added in order through LDS - so thousands of slabs
+// of a small filter are reduced with 16-way parallelism per column instead of one serial chain per thread.
 __device__ __forceinline__ void reduce_slabs(const float* __restrict__ partial, float* __restrict__ dst, long count,
                                              int splits, int accumulate, long block, long nblocks) {
+    __shared__ float4 red4[256];
+    const int tid = threadIdx.x, col = tid & 15, seg = tid >> 4;
     if ((count & 3) == 0) {
-        const long c4 = count >> 2;
-        for (long i = block * 256 + threadIdx.x; i < c4; i += nblocks * 256) {
-            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
-            const float4* src = reinterpret_cast<const float4*>(partial) + i;
-            int k = 0;
-            for (; k + 3 < splits; k += 4) {
-                const float4 v0 = src[(long)k * c4], v1 = src[(long)(k + 1) * c4], v2 = src[(long)(k + 2) * c4],
-                             v3 = src[(long)(k + 3) * c4];
-                a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
-                a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
-                a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
-                a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+        const long c4 = count >> 2, ncb = (c4 + 15) >> 4;
+        for (long cb = block; cb < ncb; cb += nblocks) {
+            const long i = cb * 16 + col;
+            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+            if (i < c4) {
+                const float4* src = reinterpret_cast<const float4*>(partial) + i;
+                int k = seg;
+                for (; k + 16 < splits; k += 32) {
+                    const float4 v0 = src[(long)k * c4], v1 = src[(long)(k + 16) * c4];
+                    a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+                    a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+                }
+                if (k < splits) {
+                    const float4 v = src[(long)k * c4];
+                    a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w;
+                }
             }
-            for (; k < splits; ++k) {
-                const float4 v = src[(long)k * c4];
-                a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w;
+            __syncthreads();
+            red4[tid] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+            __syncthreads();
+            if (seg == 0 && i < c4) {
+                float4 r = red4[col];
+#pragma unroll
+                for (int sgm = 1; sgm < 16; ++sgm) {
+                    const float4 v = red4[sgm * 16 + col];
+                    r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
+                }
+                float4* d = reinterpret_cast<float4*>(dst) + i;
+                if (accumulate) { const float4 o = *d; r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
+                *d = r;
             }
-            float4 r = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y),
-                                   (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
-            float4* d = reinterpret_cast<float4*>(dst) + i;
-            if (accumulate) { const float4 o = *d; r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
-            *d = r;
         }
         return;
     }
-    for (long i = block * 256 + threadIdx.x; i < count; i += nblocks * 256) {
-        float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += partial[(long)k * count + i];
-        dst[i] = accumulate ? dst[i] + s : s;
+    for (long i = block * 256 + tid; i < count; i += nblocks * 256) {
+        float sacc = 0.f;
+        for (int k = 0; k < splits; ++k) sacc += partial[(long)k * count + i];
+        dst[i] = accumulate ? dst[i] + sacc : sacc;
     }
 }
 
@@ -157,8 +170,8 @@ static __global__ __launch_bounds__(256) void reduce_slabs2_kernel(const float* 
 }
 
 static inline int reduce_grid(long count) {
-    const long g = (count / 4 + 255) / 256;
-    return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+    const long g = (count & 3) == 0 ? (count / 4 + 15) / 16 : (count + 255) / 256;
+    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
 }
 
 // launch helper: dw slabs (+ optional db partials) in one kernel
