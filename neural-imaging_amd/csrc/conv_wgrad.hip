@@ -39,10 +39,12 @@ struct WgradParams {
 constexpr int WG_TH = 8, WG_TW = 16;     // output-pixel tile per K iteration
 constexpr int CI_T = 32, CO_T = 64;      // dw block per workgroup
 
-template <int KS, int STRIDE, bool VEC>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
-    constexpr int TAPS = KS * KS;
-    constexpr int NT = (TAPS + 3) / 4;                 // taps per wave
+// NW waves share the taps (4, or 8 for 5x5: 4 waves would each hold 7 taps x 32 = 224 accumulator registers and run
+// alone on their SIMD; with 8 it is 128 and two waves per SIMD hide each other's LDS / global latency)
+template <int KS, int STRIDE, bool VEC, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_kernel(const WgradParams p) {
+    constexpr int TAPS = KS * KS, NTHR = NW * 64;
+    constexpr int NT = (TAPS + NW - 1) / NW;           // taps per wave
     constexpr int THH = (WG_TH - 1) * STRIDE + KS, TWH = (WG_TW - 1) * STRIDE + KS;
     constexpr int NPIXH = THH * TWH, NPIX = WG_TH * WG_TW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
         __syncthreads();
         // ---- stage the input halo tile [pixel][ci] and the dz tile [pixel][co]
         if (VEC) {
-            for (int item = tid; item < NPIXH * (CI_T / 4); item += 256) {
+            for (int item = tid; item < NPIXH * (CI_T / 4); item += NTHR) {
                 const int pix = item / (CI_T / 4), c = ci0 + (item % (CI_T / 4)) * 4;
                 int gy = iy0 + pix / TWH, gx = ix0 + pix % TWH;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
                 }
                 *reinterpret_cast<float4*>(sI + pix * CI_T + (item % (CI_T / 4)) * 4) = v;
             }
-            for (int item = tid; item < NPIX * (CO_T / 4); item += 256) {
+            for (int item = tid; item < NPIX * (CO_T / 4); item += NTHR) {
                 const int pix = item / (CO_T / 4), c = co0 + (item % (CO_T / 4)) * 4;
                 const int oy = ty0 + pix / WG_TW, ox = tx0 + pix % WG_TW;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
                 *reinterpret_cast<float4*>(sZ + pix * CO_T + (item % (CO_T / 4)) * 4) = v;
             }
         } else {
-            for (int item = tid; item < NPIXH * CI_T; item += 256) {
+            for (int item = tid; item < NPIXH * CI_T; item += NTHR) {
                 const int pix = item / CI_T, c = ci0 + item % CI_T;
                 int gy = iy0 + pix / TWH, gx = ix0 + pix % TWH;
                 float v = 0.f;
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
                 }
                 sI[item] = v;
             }
-            for (int item = tid; item < NPIX * CO_T; item += 256) {
+            for (int item = tid; item < NPIX * CO_T; item += NTHR) {
                 const int pix = item / CO_T, c = co0 + item % CO_T;
                 const int oy = ty0 + pix / WG_TW, ox = tx0 + pix % WG_TW;
                 float v = 0.f;
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
                 const int ibase = (r * STRIDE * TWH + 2 * cp * STRIDE) * CI_T;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const int tap = wave + 4 * t;
+                    const int tap = wave + NW * t;
                     if (tap < TAPS) {
                         const float a = iL[ibase + ((tap / KS) * TWH + (tap % KS)) * CI_T];
                         acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[t][0], 0, 0, 0);
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     float* slab = p.partial + (long)split * TAPS * Cin * p.Cout;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int tap = wave + 4 * t;
+        const int tap = wave + NW * t;
         if (tap >= TAPS) continue;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
@@ -421,14 +423,15 @@ int nimg_conv2d_wgrad(const float* in1, int c1, const float* in2, int c2, const 
     do {                                                                                                      \
         constexpr int THH = (WG_TH - 1) * ST_ + KS_, TWH = (WG_TW - 1) * ST_ + KS_;                           \
         constexpr size_t lds = (size_t)(THH * TWH * CI_T + WG_TH * WG_TW * CO_T) * sizeof(float);             \
+        constexpr int NW = KS_ == 5 ? 8 : 4;                                                                  \
         if (vec) {                                                                                            \
-            auto k = conv_wgrad_kernel<KS_, ST_, true>;                                                       \
+            auto k = conv_wgrad_kernel<KS_, ST_, true, NW>;                                                   \
             (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-            hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, s, p);                              \
+            hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NW * 64), lds, s, p);                          \
         } else {                                                                                              \
-            auto k = conv_wgrad_kernel<KS_, ST_, false>;                                                      \
+            auto k = conv_wgrad_kernel<KS_, ST_, false, NW>;                                                  \
             (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-            hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, s, p);                              \
+            hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NW * 64), lds, s, p);                          \
         }                                                                                                     \
     } while (0)
 
