@@ -136,6 +136,9 @@ def main():
                     help='arithmetic type of the convolution GEMMs (bf16 = MFMA throughput mode, f32 accumulate; '
                          'f32 = parity mode)')
     ap.add_argument('--no-parity-mode', action='store_true', help='skip the extra float32 parity-mode timing at N=1')
+    ap.add_argument('--backend', default=None, help='torch.distributed backend (default: nccl = RCCL); gloo is for a '
+                                                     'functional check of the N>1 path on a one-GPU box')
+    ap.add_argument('--single-device', action='store_true', help='functional check only: every rank uses cuda:0')
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--cpu-budget', type=float, default=15.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -149,7 +152,9 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU; there is no CPU fallback')
-    world = parallel.init_from_env()
+    if args.single_device:
+        os.environ['LOCAL_RANK'] = '0'
+    world = parallel.init_from_env(args.backend)
     rank = parallel.rank()
     local = int(os.environ.get('LOCAL_RANK', 0))
     torch.cuda.set_device(local)
