@@ -263,40 +263,68 @@ __global__ __launch_bounds__(256) void mse255_kernel(const float* __restrict__ a
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 __global__ void mse255_final_kernel(const double* __restrict__ partial, int nblocks, long count, float* loss) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int k = 0; k < nblocks; ++k) s += partial[k];
-        loss[0] = (float)(s / (double)count);
-    }
+    double s = 0.0;                                      // one wave: strided partials, then a fixed-shape butterfly
+    for (int k = threadIdx.x; k < nblocks; k += 64) s += partial[k];
+    s = wave_sum_d(s);
+    if (threadIdx.x == 0) loss[0] = (float)(s / (double)count);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // FAN head.  gap[n][c] = mean_p act[n][p][c]
 __global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ act, float* __restrict__ gap, int hw,
                                                       int c) {
-    const int n = blockIdx.x;
-    for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
-        float s = 0.f;
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int cq = c >> 2;
+    if ((c & 3) == 0 && cq <= 256 && 256 % cq == 0) {    // float4 columns x pixel phases, fixed-order LDS finish
+        __shared__ float4 red4[256];
+        const int parts = 256 / cq, col = tid % cq, part = tid / cq;
+        const float4* src = reinterpret_cast<const float4*>(act + (long)n * hw * c) + col;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = part; q < hw; q += parts) {
+            const float4 v = src[(long)q * cq];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        red4[tid] = a;
+        __syncthreads();
+        if (part == 0) {
+            for (int k = 1; k < parts; ++k) {
+                const float4 v = red4[k * cq + col];
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            const float inv = 1.0f / (float)hw;
+            reinterpret_cast<float4*>(gap + (long)n * c)[col] = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+        }
+        return;
+    }
+    for (int ch = tid; ch < c; ch += blockDim.x) {
+        float sacc = 0.f;
         const float* p = act + (long)n * hw * c + ch;
-        for (int q = 0; q < hw; ++q) s += p[(long)q * c];
-        gap[(long)n * c + ch] = s / (float)hw;
+        for (int q = 0; q < hw; ++q) sacc += p[(long)q * c];
+        gap[(long)n * c + ch] = sacc / (float)hw;
     }
 }
 
-// one thread per image: logits = gap W + b, softmax, Keras sparse CE on probabilities (clip 1e-7, renormalise),
-// per-image loss and d loss / d logits (already scaled by loss_scale = 1 / batch)
-__global__ void dense_softmax_ce_kernel(const float* __restrict__ gap, const float* __restrict__ w,
+// one wave per image: logits = gap W + b (lanes over the features, butterfly sums), softmax, Keras sparse CE on
+// probabilities (clip 1e-7, renormalise), per-image loss and d loss / d logits (already scaled by loss_scale = 1 / batch)
+__global__ __launch_bounds__(64) void dense_softmax_ce_kernel(const float* __restrict__ gap, const float* __restrict__ w,
                                         const float* __restrict__ b, const int* __restrict__ labels,
                                         float* __restrict__ probs, float* __restrict__ loss_per,
                                         float* __restrict__ dlogits, int n, int c, int k, float loss_scale) {
-    const int im = blockIdx.x * blockDim.x + threadIdx.x;
+    const int im = blockIdx.x, lane = threadIdx.x;
     if (im >= n) return;
     float z[16], pr[16];
-    for (int j = 0; j < k; ++j) z[j] = b[j];
-    for (int ch = 0; ch < c; ++ch) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) z[j] = 0.f;
+    for (int ch = lane; ch < c; ch += 64) {
         const float g = gap[(long)im * c + ch];
-        for (int j = 0; j < k; ++j) z[j] = fmaf(g, w[ch * k + j], z[j]);
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (j < k) z[j] = fmaf(g, w[ch * k + j], z[j]);
     }
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (j < k) z[j] = wave_sum(z[j]) + b[j];
+    if (lane != 0) return;
     float m = z[0];
     for (int j = 1; j < k; ++j) m = fmaxf(m, z[j]);
     float s = 0.f;
@@ -320,39 +348,51 @@ __global__ void dense_softmax_ce_kernel(const float* __restrict__ gap, const flo
 }
 
 // dW[c][j] = sum_n gap[n][c] dlogits[n][j];  db[j] = sum_n dlogits[n][j];  loss = scale * sum loss_per
-__global__ void dense_bwd_params_kernel(const float* __restrict__ gap, const float* __restrict__ dlogits,
+// one wave per feature channel (block c: bias gradient, block c + 1: the loss); lanes over the images
+__global__ __launch_bounds__(64) void dense_bwd_params_kernel(const float* __restrict__ gap,
+                                        const float* __restrict__ dlogits,
                                         const float* __restrict__ loss_per, float* __restrict__ dw,
                                         float* __restrict__ db, float* __restrict__ loss, int n, int c, int k,
                                         float loss_scale) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < c * k) {
-        const int ch = i / k, j = i % k;
-        float s = 0.f;
-        for (int im = 0; im < n; ++im) s = fmaf(gap[(long)im * c + ch], dlogits[(long)im * k + j], s);
-        dw[i] = s;
-    } else if (i < c * k + k) {
-        const int j = i - c * k;
-        float s = 0.f;
-        for (int im = 0; im < n; ++im) s += dlogits[(long)im * k + j];
-        db[j] = s;
-    } else if (i == c * k + k) {
-        double s = 0.0;
-        for (int im = 0; im < n; ++im) s += (double)loss_per[im];
-        loss[0] = (float)(s * (double)loss_scale);
+    const int ch = blockIdx.x, lane = threadIdx.x;
+    if (ch == c + 1) {
+        double sd = 0.0;
+        for (int im = lane; im < n; im += 64) sd += (double)loss_per[im];
+        sd = wave_sum_d(sd);
+        if (lane == 0) loss[0] = (float)(sd * (double)loss_scale);
+        return;
     }
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    for (int im = lane; im < n; im += 64) {
+        const float g = ch < c ? gap[(long)im * c + ch] : 1.0f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (j < k) acc[j] = fmaf(g, dlogits[(long)im * k + j], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (j < k) {
+            const float t = wave_sum(acc[j]);
+            if (lane == 0) {
+                if (ch < c) dw[ch * k + j] = t;
+                else db[j] = t;
+            }
+        }
 }
 
-// d act[n][p][ch] = (sum_j dlogits[n][j] W[ch][j]) / hw * lrelu'(act)
+// d act[n][p][ch] = (sum_j dlogits[n][j] W[ch][j]) / hw * lrelu'(act); one thread per element (k is tiny)
 __global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ w,
                                                       const float* __restrict__ act, float* __restrict__ dact,
-                                                      int hw, int c, int k, float alpha) {
-    const int n = blockIdx.x;
-    for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+                                                      int hw, int c, int k, float alpha, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % c);
+        const long n = i / ((long)hw * c);
         float g = 0.f;
-        for (int j = 0; j < k; ++j) g = fmaf(dlogits[(long)n * k + j], w[ch * k + j], g);
+        for (int j = 0; j < k; ++j) g = fmaf(dlogits[n * k + j], w[ch * k + j], g);
         g /= (float)hw;
-        const long base = (long)n * hw * c + ch;
-        for (int q = 0; q < hw; ++q) dact[base + (long)q * c] = g * (act[base + (long)q * c] > 0.f ? 1.0f : alpha);
+        dact[i] = g * (act[i] > 0.f ? 1.0f : alpha);
     }
 }
 
@@ -496,8 +536,8 @@ int nimg_fan_head_fwd(const float* act, const float* w, const float* b, const in
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(gap_fwd_kernel, dim3(n), dim3(256), 0, s, act, gap, hw, c);
     NIMG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(dense_softmax_ce_kernel, dim3((n + 63) / 64), dim3(64), 0, s, gap, w, b, labels, probs,
-                       loss_per, dlogits, n, c, k, loss_scale);
+    hipLaunchKernelGGL(dense_softmax_ce_kernel, dim3(n), dim3(64), 0, s, gap, w, b, labels, probs, loss_per, dlogits, n, c,
+                       k, loss_scale);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }
@@ -508,11 +548,11 @@ int nimg_fan_head_bwd(const float* act, const float* gap, const float* w, const 
     if (!act || !gap || !w || !dlogits || !loss_per || !dact || !dw || !db || !loss) return NIMG_ERR_ARG;
     if (n <= 0 || hw <= 0 || c <= 0 || k <= 0 || k > 16) return NIMG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    const int items = c * k + k + 1;
-    hipLaunchKernelGGL(dense_bwd_params_kernel, dim3((items + 63) / 64), dim3(64), 0, s, gap, dlogits, loss_per, dw,
-                       db, loss, n, c, k, loss_scale);
+    hipLaunchKernelGGL(dense_bwd_params_kernel, dim3(c + 2), dim3(64), 0, s, gap, dlogits, loss_per, dw, db, loss, n, c, k,
+                       loss_scale);
     NIMG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gap_bwd_kernel, dim3(n), dim3(256), 0, s, dlogits, w, act, dact, hw, c, k, alpha);
+    hipLaunchKernelGGL(gap_bwd_kernel, dim3(grid_for((long)n * hw * c)), dim3(256), 0, s, dlogits, w, act, dact, hw, c, k,
+                       alpha, (long)n * hw * c);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }
