@@ -313,6 +313,12 @@ int dispatch_b(const ConvParamsB& p, hipStream_t s) {
     static const bool big_ok = getenv("NIMG_BIGTILE") != nullptr;   // measured slower (1 WG/CU): opt-in for A/B only
     if (big_ok && !tn32 && STRIDE == 1 && blocks64 >= 4096 && p.Hout % 32 == 0)
         return launch_conv_b<KS, STRIDE, 32, 16, 1, 64>(p, s);
+    // narrow outputs (Cout <= 32) of big images: a 32x16-pixel tile keeps 64 accumulator registers per wave (4 x 1
+    // fragments) and stages a third fewer bytes per pixel than 16x16
+    if constexpr (STRIDE == 1 && KS == 5) {
+        if (Cout <= 32 && !p.pool_out && p.Hout % 32 == 0 && (long)cdiv(p.Hout, 32) * cdiv(p.Wout, 16) * p.N >= 2048)
+            return launch_conv_b<KS, STRIDE, 32, 16, 1, 32>(p, s);
+    }
     return tn32 ? launch_conv_b<KS, STRIDE, 16, 16, 1, 32>(p, s) : launch_conv_b<KS, STRIDE, 16, 16, 1, 64>(p, s);
 }
 

@@ -41,3 +41,19 @@ for (n, hw, cin, cout, ks) in [(320, 128, 32, 64, 5), (320, 64, 64, 128, 5), (32
     ms = e0.elapsed_time(e1) / args.reps
     fl = 2.0 * ks * ks * cin * cout * hw * hw * n
     print('conv %dx%d %d->%d @%d x%d: %.3f ms  %.0f TFLOP/s (incl. weight repack)' % (ks, ks, cin, cout, hw, n, ms, fl / ms / 1e9))
+# conv2 dgrad class: 64 -> 32 channels at 128x128
+for (n, hw, cin, cout, ks) in [(320, 128, 64, 32, 5)]:
+    x = torch.randn((n, hw, hw, cin), device=dev)
+    w = torch.randn((ks, ks, cin, cout), device=dev) * 0.05
+    out = torch.empty((n, hw, hw, cout), device=dev)
+    for _ in range(2):
+        ops.conv2d(x, w, None, out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.reps):
+        ops.conv2d(x, w, None, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / args.reps
+    print('conv %dx%d %d->%d @%d x%d: %.3f ms' % (ks, ks, cin, cout, hw, n, ms))
