@@ -155,14 +155,31 @@ class ManipulationClassification(object):
         if mode.startswith('pool'):
             return ops.avgpool(m, factor)
         elif mode == 'bilinear':
-            raise NotImplementedError('bilinear channel down-sampling is not built yet')
+            # tf.image.resize(bilinear) to shape[1] // factor on BOTH axes (workflows/...:237-238): one banded operator
+            op = self._bilinear_operator(m.shape[1], factor, m.device)
+            tmp = ops.sparse_axis_apply(m, op.fwd, 0, op.out_size)
+            return ops.sparse_axis_apply(tmp, op.fwd, 1, op.out_size)
         elif mode == 'none':
             return m
         raise ValueError('Unsupported channel down-sampling {}'.format(mode))
 
+    def _bilinear_operator(self, size, factor, device):
+        from ..helpers import kernels as hk
+        key = (size, factor, str(device))
+        cache = self.__dict__.setdefault('_bilinear_cache', {})
+        if key not in cache:
+            cache[key] = ops.AxisOperator(hk.bilinear_axis_matrix(size, size // factor), device)
+        return cache[key]
+
     def _downsampling_bwd(self, dc):
         mode = self._distribution['downsampling']
-        return ops.avgpool_bwd(dc, self.downsampling_factor) if mode.startswith('pool') else dc
+        if mode.startswith('pool'):
+            return ops.avgpool_bwd(dc, self.downsampling_factor)
+        if mode == 'bilinear':
+            op = self._bilinear_operator(dc.shape[1] * self.downsampling_factor, self.downsampling_factor, dc.device)
+            tmp = ops.sparse_axis_apply(dc, op.bwd, 0, op.in_size)
+            return ops.sparse_axis_apply(tmp, op.bwd, 1, op.in_size)
+        return dc
 
     # -- reference surface ---------------------------------------------------------------------------------------
     def run_workflow(self, batch_x, augment=False, training=False):
