@@ -132,6 +132,13 @@ int nimg_avgpool_bwd(const float* dy, float* dx, int n, int h, int w, int c, int
 size_t nimg_mse255_workspace_bytes(void);
 int nimg_mse255(const float* a, const float* b, float* loss, float* grad_a, long count, float grad_scale,
                 int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* SSIM per image (mean over channels and VALID window positions), a/b (n,h,w,c) in [0,max_val], out (n).
+ *   mode 0 = skimage.metrics.structural_similarity(multichannel=True, data_range=max_val) as helpers/metrics.py:9-25 uses
+ *            it (7x7 uniform window, sample covariance);   mode 1 = tf.image.ssim(max_val) as models/compression.py:89
+ *            uses it (11x11 Gaussian window sigma 1.5 passed by the caller in gauss_win[121], population moments). */
+size_t nimg_ssim_workspace_bytes(int n);
+int nimg_ssim(const float* a, const float* b, float* out, int n, int h, int w, int c, int mode, float max_val,
+              const float* gauss_win, void* workspace, size_t workspace_bytes, void* stream);
 /* FAN head, models/forensics.py:80-94: GAP -> Dense(k, softmax) -> SparseCategoricalCrossentropy on probabilities
  * (Keras eager semantics: clip to [1e-7, 1-1e-7], renormalise).  act (n,hw,c) is the 1x1-conv output AFTER LeakyReLU.
  * labels may be NULL (inference: only gap/probs are written).  loss_scale = 1/batch (mean reduction). */

@@ -73,6 +73,8 @@ PROTOTYPES = {
     'nimg_conv2d_wgrad_pooled_bf16': (c_int, [P, c_int, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t,
                                               P]),
     'nimg_conv2d_dgrad_fewin_pooled_bf16': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    'nimg_ssim_workspace_bytes': (c_size_t, [c_int]),
+    'nimg_ssim': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, P, P, c_size_t, P]),
     'nimg_convt2x2_fwd_bf16': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'nimg_conv2d_fwd_smallc_bf16': (c_int, [P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                             c_float, P]),

@@ -397,6 +397,54 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// SSIM (Wang et al. 2004), per image = mean over channels and VALID window positions.
+//   mode 0: skimage.metrics.structural_similarity as helpers/metrics.py:9-25 calls it (7x7 uniform window, sample
+//           covariance N/(N-1), K1 .01, K2 .03, interior crop == VALID positions);
+//   mode 1: tf.image.ssim as models/compression.py:89 calls it (11x11 Gaussian sigma 1.5, population moments).
+// One thread per (window position, channel); moments in double; per-workgroup partials, fixed-order finish.
+__global__ __launch_bounds__(256) void ssim_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           double* __restrict__ partial, int h, int w, int c, int win,
+                                                           int mode, float max_val, const float* __restrict__ gk,
+                                                           int blocks_per_image) {
+    __shared__ double red[256];
+    const int n = blockIdx.x / blocks_per_image, blk = blockIdx.x % blocks_per_image;
+    const int ho = h - win + 1, wo = w - win + 1;
+    const long items = (long)ho * wo * c;
+    const double c1 = (0.01 * max_val) * (0.01 * max_val), c2 = (0.03 * max_val) * (0.03 * max_val);
+    const double np_ = (double)win * win, covn = mode == 0 ? np_ / (np_ - 1.0) : 1.0;
+    double sum = 0.0;
+    for (long i = (long)blk * 256 + threadIdx.x; i < items; i += (long)blocks_per_image * 256) {
+        const int ch = (int)(i % c), x0 = (int)((i / c) % wo), y0 = (int)(i / ((long)c * wo));
+        double ux = 0, uy = 0, uxx = 0, uyy = 0, uxy = 0;
+        for (int dy = 0; dy < win; ++dy)
+            for (int dx = 0; dx < win; ++dx) {
+                const long o = (((long)n * h + y0 + dy) * w + x0 + dx) * c + ch;
+                const double wt = mode == 0 ? 1.0 / np_ : (double)gk[dy * win + dx];
+                const double va = a[o], vb = b[o];
+                ux += wt * va; uy += wt * vb; uxx += wt * va * va; uyy += wt * vb * vb; uxy += wt * va * vb;
+            }
+        const double vx = covn * (uxx - ux * ux), vy = covn * (uyy - uy * uy), vxy = covn * (uxy - ux * uy);
+        sum += ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux * ux + uy * uy + c1) * (vx + vy + c2));
+    }
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void ssim_final_kernel(const double* __restrict__ partial, float* __restrict__ out, int blocks_per_image,
+                                  double inv_items) {
+    const int n = blockIdx.x;
+    double s = 0.0;
+    for (int k = threadIdx.x; k < blocks_per_image; k += 64) s += partial[(long)n * blocks_per_image + k];
+    s = wave_sum_d(s);
+    if (threadIdx.x == 0) out[n] = (float)(s * inv_items);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Keras Adam: theta -= lr_t * m / (sqrt(v) + eps), lr_t = lr * sqrt(1-b2^t)/(1-b1^t); optional grad pre-scale
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long count, float lr_t, float b1, float b2, float eps,
@@ -524,6 +572,26 @@ int nimg_mse255(const float* a, const float* b, float* loss, float* grad_a, long
                        grad_scale, accumulate);
     NIMG_CHECK_LAUNCH();
     hipLaunchKernelGGL(mse255_final_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, grid, count, loss);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+size_t nimg_ssim_workspace_bytes(int n) { return (size_t)n * 64 * sizeof(double); }
+
+int nimg_ssim(const float* a, const float* b, float* out, int n, int h, int w, int c, int mode, float max_val,
+              const float* gauss_win, void* workspace, size_t workspace_bytes, void* stream) {
+    const int win = mode == 0 ? 7 : 11;
+    if (!a || !b || !out || !workspace || n < 0 || c <= 0 || h < win || w < win || mode < 0 || mode > 1) return NIMG_ERR_ARG;
+    if (mode == 1 && !gauss_win) return NIMG_ERR_ARG;
+    if (workspace_bytes < nimg_ssim_workspace_bytes(n)) return NIMG_ERR_WORKSPACE;
+    if (n == 0) return NIMG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int bpi = 64;
+    hipLaunchKernelGGL(ssim_partial_kernel, dim3(n * bpi), dim3(256), 0, s, a, b, (double*)workspace, h, w, c, win, mode,
+                       max_val, gauss_win, bpi);
+    NIMG_CHECK_LAUNCH();
+    const double items = (double)(h - win + 1) * (w - win + 1) * c;
+    hipLaunchKernelGGL(ssim_final_kernel, dim3(n), dim3(64), 0, s, (const double*)workspace, out, bpi, 1.0 / items);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }

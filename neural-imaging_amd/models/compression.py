@@ -118,7 +118,9 @@ class DCN(TFModel):
             self.learning_rate = learning_rate
         self._model.adam(self.learning_rate)          # l2_loss is a SUM over the batch: summed gradients, no 1/world
         loss = float(DeviceArray(l2)) + self._h.entropy_weight * float(DeviceArray(ent))
-        return {'loss': np.sqrt(2 * loss), 'ssim': np.nan, 'entropy': DeviceArray(ent)}
+        h, w = x.shape[1], x.shape[2]
+        ssim = DeviceArray(ops.ssim(x, y, mode='tf').mean()) if min(h, w) >= 11 else np.nan     # compression.py:89,129
+        return {'loss': np.sqrt(2 * loss), 'ssim': ssim, 'entropy': DeviceArray(ent)}
 
     def compression_stats(self, patch_size=None, n_latent_bytes=None):
         n_latent_bytes = n_latent_bytes or self._h.latent_bpf / 8

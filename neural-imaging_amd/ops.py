@@ -682,3 +682,29 @@ def median_bwd(dy, sel, kernel):
     dx = torch.zeros_like(dy)
     _lib.call('nimg_median_bwd', _p(dy), _p(sel), _p(dx), n, h, w, int(kernel), _stream())
     return dx
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# image quality metrics
+_SSIM_GAUSS = {}
+
+
+def ssim(a, b, mode='skimage', max_val=1.0):
+    """Per-image SSIM of two (N,H,W,C) batches. mode 'skimage' = helpers/metrics.ssim of the reference (7x7 uniform
+    window), 'tf' = tf.image.ssim (11x11 Gaussian, sigma 1.5)."""
+    _f32(a, b)
+    n, h, w, c = a.shape
+    m = {'skimage': 0, 'tf': 1}[mode]
+    gk = None
+    if m == 1:
+        key = str(a.device)
+        if key not in _SSIM_GAUSS:           # tf _fspecial_gauss: softmax of -(x^2 + y^2) / (2 sigma^2)
+            co = np.arange(11, dtype=np.float64) - 5.0
+            g = -0.5 * (co[:, None] ** 2 + co[None, :] ** 2) / 1.5 ** 2
+            g = np.exp(g - g.max())
+            _SSIM_GAUSS[key] = torch.from_numpy((g / g.sum()).astype(np.float32).ravel()).to(a.device)
+        gk = _SSIM_GAUSS[key]
+    out = torch.empty((n,), dtype=torch.float32, device=a.device)
+    ws = _ws.get(_lib.load().nimg_ssim_workspace_bytes(n), a.device)
+    _lib.call('nimg_ssim', _p(a), _p(b), _p(out), n, h, w, c, m, float(max_val), _p(gk), _p(ws), ws.numel(), _stream())
+    return out

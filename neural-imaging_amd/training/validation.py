@@ -3,13 +3,15 @@ Validation helpers and the training-progress JSON of the reference's training/va
   validate_fan (:163-202)           confusion matrix / accuracy through flow.run_workflow_to_decisions
   validate_nip (:96-160, numbers only)  PSNR + loss of the developed validation patches (no matplotlib dashboards)
   save_training_progress (:301-352) training.json with the same keys
-SSIM is reported as NaN until the device-side SSIM of SURVEY 8f-2 is built.
+SSIM / PSNR come from helpers/metrics.py (device-side SSIM kernel, skimage semantics).
 """
 import json
 import os
 from collections import OrderedDict
 
 import numpy as np
+
+from ..helpers import metrics
 
 
 def psnr(a, b, max_val=1.0):
@@ -48,7 +50,7 @@ def validate_nip(model, data, out_directory=None, savefig=False, epoch=0, show_r
         bx, by = data.next_validation_batch(batch, batch_size)
         developed = model.process(bx).numpy().clip(0, 1)
         psnrs.extend(psnr(developed, by).tolist())
-        ssims.extend([float('nan')] * len(bx))
+        ssims.extend(np.atleast_1d(metrics.ssim(developed, by)).tolist())
         d = 255.0 * (developed - by)
         losses.extend((np.mean(d ** 2, axis=(1, 2, 3)) if loss_type == 'L2' else np.mean(np.abs(d), axis=(1, 2, 3))).tolist())
     return ssims, psnrs, losses
@@ -63,7 +65,7 @@ def validate_dcn(dcn, data, out_directory=None, savefig=False, epoch=0, show_ref
         by = by[1] if isinstance(by, tuple) else by
         y, ent = dcn.process(by, return_entropy=True)
         out['psnr'].extend(psnr(y.numpy(), by).tolist())
-        out['ssim'].extend([float('nan')] * len(by))
+        out['ssim'].extend(np.atleast_1d(metrics.ssim(np.clip(y.numpy(), 0, 1), by)).tolist())
         out['entropy'].append(float(ent))
         out['loss'].append(float(np.sqrt(2 * dcn.loss(by, y, float(ent)))))
     return out

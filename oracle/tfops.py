@@ -289,3 +289,46 @@ def adam_step(params, grads, m, v, t, lr, beta1=0.9, beta2=0.999, eps=1e-7):
         mi.mul_(beta1).add_(g, alpha=1 - beta1)
         vi.mul_(beta2).addcmul_(g, g, value=1 - beta2)
         p.sub_(lr_t * mi / (vi.sqrt() + eps))
+
+
+# --------------------------------------------------------------------------------------------------------------
+# SSIM (Wang, Bovik, Sheikh, Simoncelli 2004) in the two flavours the reference calls
+def ssim_skimage(a, b, data_range=1.0):
+    """skimage.metrics.structural_similarity(a, b, multichannel=True, data_range=1) as helpers/metrics.py:9-25 calls it
+    (scikit-image is not installed here; restated from its documentation): per channel, 7x7 uniform window
+    (scipy.ndimage.uniform_filter), sample covariance N/(N-1), K1 = 0.01, K2 = 0.03, mean over the interior that the
+    window covers completely (crop of (win-1)//2), then the mean over channels.  a, b: (H,W,C) numpy arrays."""
+    from scipy.ndimage import uniform_filter
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    win, pad = 7, 3
+    npix = win * win
+    cov_norm = npix / (npix - 1.0)
+    c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+    vals = []
+    for ch in range(a.shape[-1]):
+        x, y = a[..., ch], b[..., ch]
+        ux, uy = uniform_filter(x, win), uniform_filter(y, win)
+        uxx, uyy, uxy = uniform_filter(x * x, win), uniform_filter(y * y, win), uniform_filter(x * y, win)
+        vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+        s = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux ** 2 + uy ** 2 + c1) * (vx + vy + c2))
+        vals.append(s[pad:-pad, pad:-pad].mean())
+    return float(np.mean(vals))
+
+
+def ssim_tf(a, b, max_val=1.0):
+    """tf.image.ssim(a, b, max_val) as models/compression.py:89 calls it (TF 2.1 image_ops_impl: 11x11 Gaussian window,
+    sigma 1.5, built as a softmax of -(x^2+y^2)/(2 sigma^2); VALID depthwise filtering; luminance x contrast-structure
+    from population moments; mean over positions, then channels).  a, b: (N,H,W,C) torch tensors -> (N,)."""
+    co = torch.arange(11, dtype=a.dtype) - 5.0
+    g = -0.5 * (co[:, None] ** 2 + co[None, :] ** 2) / 1.5 ** 2
+    g = torch.softmax(g.reshape(-1), 0).reshape(1, 1, 11, 11)
+    c = a.shape[-1]
+    k = g.repeat(c, 1, 1, 1)
+    f = lambda t: F.conv2d(t.permute(0, 3, 1, 2), k, groups=c)
+    c1, c2 = (0.01 * max_val) ** 2, (0.03 * max_val) ** 2
+    m0, m1 = f(a), f(b)
+    num0, den0 = m0 * m1 * 2.0, m0 * m0 + m1 * m1
+    lum = (num0 + c1) / (den0 + c1)
+    num1, den1 = f(a * b) * 2.0, f(a * a + b * b)
+    cs = (num1 - num0 + c2) / (den1 - den0 + c2)
+    return (lum * cs).mean(dim=(2, 3)).mean(dim=1)

@@ -253,6 +253,29 @@ def test_conv_pool_fused_epilogue(dev, mode, cin, cout, ks, h, w):
         ops.set_compute('f32')
 
 
+@pytest.mark.parametrize('shape', [(3, 40, 56, 3), (2, 64, 64, 1), (1, 11, 11, 3)])
+def test_ssim_both_flavours(dev, shape):
+    """Device SSIM against the restated skimage (7x7 uniform, sample covariance) and tf.image.ssim (11x11 Gaussian)."""
+    from neural_imaging_amd import ops
+    from neural_imaging_amd.helpers import metrics
+    n, h, w, c = shape
+    a = natural_images(n, h, w, seed=5)[..., :c].copy()
+    b = np.clip(a + rnd(a.shape, 6, -0.08, 0.08), 0, 1).astype(np.float32)
+    got = ops.ssim(g(a, dev), g(b, dev), mode='skimage').cpu().numpy()
+    ref = np.array([T.ssim_skimage(a[i], b[i]) for i in range(n)])
+    assert np.abs(got - ref).max() < 1e-5, (got, ref)
+    got_tf = ops.ssim(g(a, dev), g(b, dev), mode='tf').cpu().numpy()
+    ref_tf = T.ssim_tf(to64(a), to64(b)).numpy()
+    assert np.abs(got_tf - ref_tf).max() < 1e-5, (got_tf, ref_tf)
+    assert np.abs(ops.ssim(g(a, dev), g(a, dev)).cpu().numpy() - 1.0).max() < 1e-6
+    # reference surface (helpers/metrics.py): (H,W,C) -> scalar, (N,H,W,C) -> per image, batch() -> mean
+    assert isinstance(metrics.ssim(a[0], b[0]), float) and abs(metrics.ssim(a[0], b[0]) - ref[0]) < 1e-5
+    assert isinstance(metrics.ssim(a, b), float) if n == 1 else metrics.ssim(a, b).shape == (n,)
+    assert abs(metrics.psnr(a[0], b[0]) - 10 * np.log10(1.0 / np.mean((a[0].astype(np.float64) - b[0]) ** 2))) < 1e-4
+    if n > 1:
+        assert abs(metrics.batch(a, b, metrics.ssim) - ref.mean()) < 1e-5
+
+
 def test_d2s_clip_and_small_ops(dev):
     from neural_imaging_amd import ops
     x = rnd((2, 6, 5, 12), 1, -0.5, 1.5)

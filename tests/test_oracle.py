@@ -167,3 +167,22 @@ def test_gradcheck_manipulations():
     for fn in (lambda t: om.manipulation_gaussian(t, 5, 0.83), lambda t: om.manipulation_resample(t, 50),
                lambda t: om.manipulation_sharpen(t, 1.0)):
         assert torch.autograd.gradcheck(fn, (x,), eps=1e-6, atol=1e-5, nondet_tol=0.0)
+
+
+def test_oracle_ssim_flavours():
+    """The two SSIM restatements agree with a direct evaluation of the definition on one window, are 1 for identical
+    images and decrease with noise."""
+    rng = np.random.RandomState(3)
+    a = rng.rand(7, 7, 1)
+    b = np.clip(a + 0.1 * rng.randn(7, 7, 1), 0, 1)
+    x, y = a[..., 0].ravel(), b[..., 0].ravel()
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    vx, vy, vxy = x.var(ddof=1), y.var(ddof=1), np.cov(x, y, ddof=1)[0, 1]
+    direct = (2 * x.mean() * y.mean() + c1) * (2 * vxy + c2) / ((x.mean() ** 2 + y.mean() ** 2 + c1) * (vx + vy + c2))
+    assert abs(T.ssim_skimage(a, b) - direct) < 1e-12
+    img = rng.rand(2, 24, 24, 3)
+    noisy = np.clip(img + 0.05 * rng.randn(*img.shape), 0, 1)
+    s_same = T.ssim_tf(torch.from_numpy(img), torch.from_numpy(img))
+    s_noisy = T.ssim_tf(torch.from_numpy(img), torch.from_numpy(noisy))
+    assert torch.allclose(s_same, torch.ones(2, dtype=torch.float64)) and bool((s_noisy < 0.99).all())
+    assert abs(T.ssim_skimage(img[0], img[0]) - 1.0) < 1e-12 and T.ssim_skimage(img[0], noisy[0]) < 0.99
