@@ -4,7 +4,8 @@ FAN - forensic analysis network on the HIP kernels.  Mirrors the reference's mod
 Graph as built by the workflow's defaults (forensics.py:62-90; ctor values override the ParamSpec defaults, SURVEY 8a
 quirk 6): ConstrainedConv2D -> 4 x [Conv5x5 SAME (32,64,128,256) + LeakyReLU(0.2) -> MaxPool2] -> Conv1x1 256 + LReLU
 -> GAP -> Dense(n_classes, softmax); loss = SparseCategoricalCrossentropy on probabilities (forensics.py:94).
-Only use_gap=True / n_dense=0 / dropout=0 (the configuration every caller in the reference uses) is built.
+Also built: use_gap=False (Flatten) and n_dense > 0 hidden Dense + LeakyReLU layers (forensics.py:79-87), as 1x1
+convolutions on (N,1,1,F) tensors.  dropout > 0 raises NotImplementedError (its random mask cannot be pinned to TF's).
 """
 from collections import OrderedDict
 
@@ -36,8 +37,10 @@ class FAN(TFModel):
         })
         params = locals()
         self._h.update(**{k: params[k] for k in self._h.keys()})
-        if not use_gap or n_dense != 0 or dropout != 0:
-            raise NotImplementedError('only the use_gap=True, n_dense=0, dropout=0 head is built')
+        if dropout != 0:
+            raise NotImplementedError('dropout > 0 is not built (no parity with the TF random stream)')
+        if not use_gap and patch_size is None:
+            raise ValueError('the Flatten head (use_gap=False) needs a fixed patch_size')
         if self._h.kernel not in (3, 5) or self._h.n_classes > 16:
             raise NotImplementedError('kernel size {} / {} classes not built'.format(self._h.kernel, self._h.n_classes))
         self.patch_size = patch_size
@@ -52,21 +55,35 @@ class FAN(TFModel):
             cin, nf = nf, int(nf * self._h.n_fscale)
         nf = int(nf // self._h.n_fscale)
         self._conv1x1 = Conv2D('conv1x1', 1, cin, nf, 'leaky_relu')
-        self._n_features = nf
+        self._use_gap = bool(use_gap)
+        feat = nf if use_gap else nf * (patch_size // 2 ** self._h.n_convolutions) ** 2
+        # hidden Dense + LeakyReLU layers (Keras names dense, dense_1, ...; the classifier is the last Dense)
+        self._hidden = []
+        for i in range(self._h.n_dense):
+            nf = int(nf // self._h.n_fscale)
+            self._hidden.append(Conv2D('dense' if i == 0 else 'dense_{}'.format(i), 1, feat, nf, 'leaky_relu'))
+            feat = nf
+        self._cls = 'dense' if self._h.n_dense == 0 else 'dense_{}'.format(self._h.n_dense)
+        self._n_features = feat
         specs = self._constrained.specs()
         for c in self._convs:
             specs += c.specs()
         specs += self._conv1x1.specs()
-        specs += [('dense/kernel', (nf, n_classes)), ('dense/bias', (n_classes,))]
+        for d in self._hidden:                 # Dense kernel (in, out) == 1x1 HWIO kernel in memory
+            specs += [(d.name + '/kernel', (d.cin, d.cout)), (d.name + '/bias', (d.cout,))]
+        specs += [(self._cls + '/kernel', (feat, n_classes)), (self._cls + '/bias', (n_classes,))]
         self._model = ParamStore(specs, self.device)
         gen = torch.Generator().manual_seed(seed)
         self._constrained.init(self._model)
         for c in self._convs:
             c.init(self._model, gen)
         self._conv1x1.init(self._model, gen)
-        k = torch.empty((nf, n_classes), dtype=torch.float32)
-        glorot_uniform_(k, nf, n_classes, gen)
-        self._model.p['dense/kernel'].copy_(k)
+        for d in self._hidden + [None]:
+            name, fi, fo = (d.name, d.cin, d.cout) if d is not None else (self._cls, feat, n_classes)
+            k = torch.empty((fi, fo), dtype=torch.float32)
+            glorot_uniform_(k, fi, fo, gen)
+            self._model.p[name + '/kernel'].copy_(k)
+            self._model.p[name + '/bias'].zero_()
         self.learning_rate = 1e-3
         self.loss = self._loss
 
@@ -95,7 +112,23 @@ class FAN(TFModel):
         t['conv1x1'] = a
         n = x.shape[0]
         ls = (1.0 / n) if loss_scale is None else loss_scale
-        gap, probs, loss_per, dlogits = ops.fan_head_fwd(a, P.p['dense/kernel'], P.p['dense/bias'], labels, ls)
+        head_in = a
+        if self._hidden or not self._use_gap:
+            # general head: features as an (N,1,1,F) tensor, hidden Dense layers as 1x1 convolutions
+            if self._use_gap:
+                if a.shape[1] != a.shape[2]:
+                    raise ValueError('the hidden-Dense head pools square feature maps')
+                head_in = ops.avgpool(a, a.shape[1])
+            else:
+                head_in = a.reshape(n, 1, 1, -1)
+            t['feat'] = head_in
+            for d in self._hidden:
+                w4 = P.p[d.name + '/kernel'].view(1, 1, d.cin, d.cout)
+                head_in = ops.conv2d(head_in, w4, P.p[d.name + '/bias'], act='leaky_relu')
+                t[d.name] = head_in
+        gap, probs, loss_per, dlogits = ops.fan_head_fwd(head_in, P.p[self._cls + '/kernel'], P.p[self._cls + '/bias'],
+                                                         labels, ls)
+        t['head_in'] = head_in
         t['gap'], t['probs'], t['loss_per'], t['dlogits'], t['loss_scale'] = gap, probs, loss_per, dlogits, ls
         return probs, (t if training else None)
 
@@ -104,8 +137,26 @@ class FAN(TFModel):
         P = self._model
         hw = lambda a: (a.shape[1], a.shape[2])
         a = t['conv1x1']
-        dz, loss = ops.fan_head_bwd(a, t['gap'], P.p['dense/kernel'], t['dlogits'], t['loss_per'], t['loss_scale'],
-                                    P.g['dense/kernel'], P.g['dense/bias'])
+        # classifier backward; dz = gradient w.r.t. the PRE-activation of whatever fed the head (its LeakyReLU' applied)
+        dz, loss = ops.fan_head_bwd(t['head_in'], t['gap'], P.p[self._cls + '/kernel'], t['dlogits'], t['loss_per'],
+                                    t['loss_scale'], P.g[self._cls + '/kernel'], P.g[self._cls + '/bias'])
+        if 'feat' in t:
+            for i in range(len(self._hidden) - 1, -1, -1):
+                d = self._hidden[i]
+                inp = t[self._hidden[i - 1].name] if i > 0 else t['feat']
+                ops.conv2d_wgrad(inp, dz, 1, dw=P.g[d.name + '/kernel'].view(1, 1, d.cin, d.cout),
+                                 db=P.g[d.name + '/bias'])
+                w4 = P.p[d.name + '/kernel'].view(1, 1, d.cin, d.cout)
+                # hidden activations carry a LeakyReLU; the feature vector itself (GAP / Flatten output) does not
+                dz = ops.conv2d_dgrad(dz, w4, (1, 1), act_mask=inp if i > 0 else None)
+            if self._hidden:
+                # dz is now d loss / d feat (no activation applied yet): route it back into the 1x1-conv activation
+                if self._use_gap:
+                    dz = ops.lrelu_bwd(ops.avgpool_bwd(dz, a.shape[1]), a)
+                else:
+                    dz = ops.lrelu_bwd(dz.reshape(a.shape), a)
+            else:
+                dz = dz.reshape(a.shape)          # Flatten straight into the classifier: the head applied LReLU'(a)
         nconv = len(self._convs)
         pool = t['pool{}'.format(nconv)]
         self._conv1x1.backward_params(P, pool, dz)

@@ -92,7 +92,15 @@ def fan_init(n_classes, seed=4321, n_filters=32, n_fscale=2, n_convolutions=4, k
     return p
 
 
-def fan_forward(p, x, n_convolutions=4, return_tensors=False):
+def _dense_names(p):
+    """Keras names of the Dense layers in creation order: dense, dense_1, ... (the last one is the classifier)."""
+    names = [k[:-len('/kernel')] for k in p if k.startswith('dense') and k.endswith('/kernel')]
+    return sorted(names, key=lambda n: int(n.split('_')[1]) if '_' in n else 0)
+
+
+def fan_forward(p, x, n_convolutions=4, return_tensors=False, use_gap=True):
+    """models/forensics.py:62-90: constrained conv -> n x [conv + LReLU -> pool] -> 1x1 conv + LReLU -> GAP | Flatten ->
+    hidden Dense + LReLU layers (n_dense) -> Dense softmax."""
     t = OrderedDict()
     mask = torch.tensor(tables.center_mask_2dfilter(5, 3), dtype=x.dtype)
     net = T.constrained_conv(x, p['constrained/kernel'], mask)
@@ -104,9 +112,13 @@ def fan_forward(p, x, n_convolutions=4, return_tensors=False):
         t['pool{}'.format(i + 1)] = net
     net = T.leaky_relu(T.conv2d(net, p['conv1x1/kernel'], p['conv1x1/bias']))
     t['conv1x1'] = net
-    gap = net.mean(dim=(1, 2))
-    t['gap'] = gap
-    logits = gap @ p['dense/kernel'] + p['dense/bias']
+    feat = net.mean(dim=(1, 2)) if use_gap else net.reshape(net.shape[0], -1)       # Flatten is NHWC row-major
+    t['gap'] = feat
+    dn = _dense_names(p)
+    for name in dn[:-1]:
+        feat = T.leaky_relu(feat @ p[name + '/kernel'] + p[name + '/bias'])
+        t[name] = feat
+    logits = feat @ p[dn[-1] + '/kernel'] + p[dn[-1] + '/bias']
     t['logits'] = logits
     probs = torch.softmax(logits, dim=1)
     return (probs, t) if return_tensors else probs
