@@ -187,6 +187,13 @@ int nimg_sparse_axis_apply(const float* in, float* out, const int* rowptr, const
  * Learned codec (TwitterDCN, models/compression.py:197-279) specific pieces */
 int nimg_affine(const float* x, float* y, long count, float a, float b, void* stream);     /* y = a*x + b (:219,:268) */
 int nimg_lrelu_fwd(const float* x, float* y, long count, float alpha, void* stream);       /* tf.nn.leaky_relu (:224) */
+/* Element-wise pieces of the INet / DNet pipelines (models/pipelines.py:238-345): tanh of the gamma MLP (:283) and its
+ * derivative through the stored output, the straight-through clip (:287, :341; gradient = identity), and
+ * tf.pad(x, [[0,0],[P,P],[P,P],[0,0]], CONSTANT | SYMMETRIC | REFLECT) (:272, :320, :338; backward = nimg_fold_pad). */
+int nimg_tanh_fwd(const float* x, float* y, long count, void* stream);
+int nimg_tanh_bwd(const float* dy, const float* y, float* dx, long count, void* stream);
+int nimg_clip01(const float* x, float* y, long count, void* stream);
+int nimg_pad2d(const float* x, float* y, int n, int h, int w, int c, int pad, int pad_mode, void* stream);
 /* out (n,2h,2w,c) = in with zeros inserted (stride-2 transposed convolution = zero insertion + stride-1 conv) */
 int nimg_zero_insert2(const float* in, float* out, int n, int h, int w, int c, void* stream);
 /* DiscreteLatent (models/layers.py:183-203): latent = Quantization('soft-codebook' | identity)(scale * z) evaluated in

@@ -75,6 +75,10 @@ PROTOTYPES = {
     'nimg_conv2d_dgrad_fewin_pooled_bf16': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'nimg_ssim_workspace_bytes': (c_size_t, [c_int]),
     'nimg_ssim': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, P, P, c_size_t, P]),
+    'nimg_tanh_fwd': (c_int, [P, P, c_long, P]),
+    'nimg_tanh_bwd': (c_int, [P, P, P, c_long, P]),
+    'nimg_clip01': (c_int, [P, P, c_long, P]),
+    'nimg_pad2d': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'nimg_convt2x2_fwd_bf16': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'nimg_conv2d_fwd_smallc_bf16': (c_int, [P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                             c_float, P]),

@@ -31,6 +31,38 @@ __global__ void lrelu_fwd_kernel(const float* __restrict__ x, float* __restrict_
         y[i] = lrelu(x[i], alpha);
 }
 
+// tanh activation of INet's gamma MLP (models/pipelines.py:283) and its derivative through the stored output
+__global__ void tanh_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long count) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+        y[i] = tanhf(x[i]);
+}
+__global__ void tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx,
+                                long count) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+        dx[i] = dy[i] * (1.0f - y[i] * y[i]);
+}
+// y = clip(x, 0, 1); the gradient is straight-through (pipelines.py:287, :341)
+__global__ void clip01_kernel(const float* __restrict__ x, float* __restrict__ y, long count) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+        y[i] = fminf(fmaxf(x[i], 0.0f), 1.0f);
+}
+// tf.pad(x, [[0,0],[P,P],[P,P],[0,0]], mode) with mode 0 CONSTANT(0) | 1 SYMMETRIC | 2 REFLECT: x (n,h,w,c) -> y (n,h+2P,w+2P,c)
+__global__ void pad2d_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int h, int w, int c, int P,
+                             int mode) {
+    const int hp = h + 2 * P, wp = w + 2 * P;
+    const long total = (long)n * hp * wp * c;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % c);
+        long r = i / c;
+        int gx = (int)(r % wp) - P;
+        r /= wp;
+        int gy = (int)(r % hp) - P;
+        const long im = r / hp;
+        const bool ok = map_coord(gy, h, mode) && map_coord(gx, w, mode);
+        y[i] = ok ? x[((im * h + gy) * w + gx) * c + ch] : 0.f;
+    }
+}
+
 // out (n,2h,2w,c): out[2y,2x] = in[y,x], zero elsewhere
 __global__ void zero_insert2_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int h, int w, int c) {
     const long total = (long)n * 4 * h * w * c;
@@ -243,6 +275,40 @@ int nimg_lrelu_fwd(const float* x, float* y, long count, float alpha, void* stre
     if (!x || !y || count < 0) return NIMG_ERR_ARG;
     if (count == 0) return NIMG_OK;
     hipLaunchKernelGGL(lrelu_fwd_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, x, y, count, alpha);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_tanh_fwd(const float* x, float* y, long count, void* stream) {
+    if (!x || !y || count < 0) return NIMG_ERR_ARG;
+    if (count == 0) return NIMG_OK;
+    hipLaunchKernelGGL(tanh_fwd_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, x, y, count);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_tanh_bwd(const float* dy, const float* y, float* dx, long count, void* stream) {
+    if (!dy || !y || !dx || count < 0) return NIMG_ERR_ARG;
+    if (count == 0) return NIMG_OK;
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, count);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_clip01(const float* x, float* y, long count, void* stream) {
+    if (!x || !y || count < 0) return NIMG_ERR_ARG;
+    if (count == 0) return NIMG_OK;
+    hipLaunchKernelGGL(clip01_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, x, y, count);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_pad2d(const float* x, float* y, int n, int h, int w, int c, int pad, int pad_mode, void* stream) {
+    if (!x || !y || n < 0 || h <= 0 || w <= 0 || c <= 0 || pad < 0 || pad_mode < 0 || pad_mode > 2) return NIMG_ERR_ARG;
+    if ((pad_mode == 1 && (pad > h || pad > w)) || (pad_mode == 2 && (pad >= h || pad >= w))) return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    hipLaunchKernelGGL(pad2d_kernel, dim3(grid_for((long)n * (h + 2 * pad) * (w + 2 * pad) * c)), dim3(256), 0,
+                       (hipStream_t)stream, x, y, n, h, w, c, pad, pad_mode);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }

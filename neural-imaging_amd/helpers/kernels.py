@@ -54,3 +54,51 @@ def bilinear_axis_matrix(in_size, out_size):
         m[o, lo] += 1.0 - t
         m[o, hi] += t
     return m
+
+
+def upsampling_kernel(cfa_pattern='gbrg'):
+    """(4,12) 1x1 kernel that scatters the RAW planes [R, G (first in raster order), G (second), B] of a 2x2 Bayer cell
+    to the (position, colour) slots depth_to_space(2) expects - slot = 2*dy + dx, colour R/G/B = 0/1/2 - for the CFA
+    layouts 'gbrg' | 'rggb' | 'bggr' (helpers/kernels.py:9-46 of the reference)."""
+    cfa = cfa_pattern.lower()
+    if cfa not in ('gbrg', 'rggb', 'bggr'):
+        raise ValueError('Unsupported CFA pattern: {}'.format(cfa_pattern))
+    upk = np.zeros((4, 12))
+    greens = [s for s, ch in enumerate(cfa) if ch == 'g']
+    for plane, (slot, colour) in enumerate([(cfa.index('r'), 0), (greens[0], 1), (greens[1], 1), (cfa.index('b'), 2)]):
+        upk[plane, 3 * slot + colour] = 1
+    return upk
+
+
+def bilin_kernel(kernel=3):
+    """(k,k,3,3) bilinear demosaicing filter on the zero-filled colour planes: the green plane with the 4-neighbour cross,
+    red / blue with the separable [1/2, 1, 1/2] tent; channel-diagonal; zero-padded from 3x3 to k x k."""
+    tent = np.array([0.5, 1.0, 0.5])
+    rb = np.outer(tent, tent)
+    g = np.array([[0, 0.25, 0], [0.25, 1, 0.25], [0, 0.25, 0]])
+    dmf = np.zeros((3, 3, 3, 3), np.float32)
+    dmf[:, :, 0, 0], dmf[:, :, 1, 1], dmf[:, :, 2, 2] = rb, g, rb
+    if kernel > 3:
+        pad = (kernel - 3) // 2
+        dmf = np.pad(dmf, ((pad, pad), (pad, pad), (0, 0), (0, 0)), 'constant')
+    return dmf
+
+
+def gamma_kernels():
+    """Weights of the reference's pre-trained toy gamma MLP (1 -> 4 tanh -> 1 per colour channel; the numbers are model
+    data from helpers/kernels.py:49-71), expanded to block-diagonal (3,12) / (12,3) 1x1 kernels."""
+    d1k = np.array([2.9542332, 17.780445, 0.6280197, 0.40384966])
+    d1b = np.array([0.4047071, 1.1489044, -0.17624384, 0.47826886])
+    d2k = np.array([0.44949612, 0.78081024, 0.97692937, -0.24265033])
+    d2b = -0.4702738
+    k1, b1, k2, b2 = np.zeros((3, 12)), np.zeros(12), np.zeros((12, 3)), np.zeros(3)
+    for ch in range(3):
+        k1[ch, 4 * ch:4 * ch + 4], b1[4 * ch:4 * ch + 4] = d1k, d1b
+        k2[4 * ch:4 * ch + 4, ch], b2[ch] = d2k, d2b
+    return k1, b1, k2, b2
+
+
+# example camera-RGB -> sRGB conversion INet starts from (pipelines.py:262-264 of the reference; model data)
+SRGB_EXAMPLE = np.array([[1.82691061, -0.65497452, -0.17193617],
+                         [-0.00683982, 1.33216381, -0.32532394],
+                         [0.06269717, -0.40055895, 1.33786178]]).T

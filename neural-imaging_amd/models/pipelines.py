@@ -1,7 +1,7 @@
 """
 Neural imaging pipelines (camera ISPs) on the HIP kernels.  Mirrors the reference's models/pipelines.py:
-NIPModel (:27-166) - loss selection, training_step, process - and UNet (:169-230); ONet (:353-362) is the identity ISP.
-INet / DNet / ClassicISP reuse the same kernels with other graphs and are SURVEY 8(f) "next".
+NIPModel (:27-166) - loss selection, training_step, process - UNet (:169-230), INet (:233-295), DNet (:298-349); ONet
+(:353-362) is the identity ISP.  ClassicISP is SURVEY 8(f) "next".
 
 UNet graph (pipelines.py:190-223): encoder n=1..5: 2 x [Conv3x3 SAME, 32*2^(n-1), LeakyReLU(0.2)] + MaxPool2 (not after
 n=5); decoder n=1..4: ConvT 2x2 s2 -> concat(up, skip) [never materialised: the conv reads two tensors] -> 2 x
@@ -14,6 +14,7 @@ import torch
 
 from .. import ops
 from ..device import DeviceArray, to_device
+from ..helpers import kernels as hk
 from ..helpers import paramspec, utils
 from .layers import Conv2D, Conv2DTranspose2x2
 from .tfmodel import ParamStore, TFModel
@@ -188,6 +189,82 @@ class UNet(NIPModel):
         return None
 
 
+class INet(NIPModel):
+    """The standard-ISP-shaped pipeline (pipelines.py:233-295): 1x1 CFA up-sampling (4 -> 12, frozen unless
+    trainable_upsampling) -> depth_to_space(2) -> REFLECT-padded k x k demosaicing (3 -> 3, no bias) -> 1x1 colour
+    conversion (3 -> 3, no bias) -> gamma MLP 1x1 (3 -> 12, tanh) + 1x1 (12 -> 3) -> straight-through clip.
+    Layer names: up, demosaic, srgb, gamma1, gamma2 (Keras auto-names conv2d_<k> depend on creation order in the
+    process and are not reproducible)."""
+
+    def construct_model(self, random_init=False, kernel=5, trainable_upsampling=False, cfa_pattern='gbrg'):
+        self._h = paramspec.ParamSpec({
+            'random_init': (False, bool, None),
+            'kernel': (5, int, (3, 11)),
+            'trainable_upsampling': (False, bool, None),
+            'cfa_pattern': ('gbrg', str, {'gbrg', 'rggb', 'bggr'}),
+        })
+        self._h.update(random_init=random_init, kernel=kernel, trainable_upsampling=trainable_upsampling,
+                       cfa_pattern=cfa_pattern)
+        if self._h.kernel not in (3, 5):
+            raise NotImplementedError('demosaicing kernel {} not built (3 | 5)'.format(self._h.kernel))
+        if self._h.trainable_upsampling:
+            raise NotImplementedError('trainable_upsampling=True is not built (the reference default is False)')
+        if self.in_channels != 4:
+            raise ValueError('INet develops 4-plane RAW input')
+        k = self._h.kernel
+        specs = [('up/kernel', (1, 1, 4, 12)), ('demosaic/kernel', (k, k, 3, 3)), ('srgb/kernel', (1, 1, 3, 3)),
+                 ('gamma1/kernel', (1, 1, 3, 12)), ('gamma1/bias', (12,)), ('gamma2/kernel', (1, 1, 12, 3)),
+                 ('gamma2/bias', (3,))]
+        self._model = ParamStore(specs, self.device)
+        if self._h.random_init:
+            rng = np.random.RandomState(self._seed)
+            dmf = rng.normal(0, 0.1, (k, k, 3, 3))
+            g1k, g1b, g2k, g2b = rng.normal(0, 0.1, (3, 12)), np.zeros(12), rng.normal(0, 0.1, (12, 3)), np.zeros(3)
+            srgbk = np.eye(3)
+        else:
+            dmf = hk.bilin_kernel(k)
+            g1k, g1b, g2k, g2b = hk.gamma_kernels()
+            srgbk = hk.SRGB_EXAMPLE
+        init = {'up/kernel': hk.upsampling_kernel(self._h.cfa_pattern), 'demosaic/kernel': dmf, 'srgb/kernel': srgbk,
+                'gamma1/kernel': g1k, 'gamma1/bias': g1b, 'gamma2/kernel': g2k, 'gamma2/bias': g2b}
+        for name, v in init.items():
+            p = self._model.p[name]
+            p.copy_(torch.from_numpy(np.asarray(v, np.float32).reshape(tuple(p.shape))))
+        ps = self.patch_size
+        self.y = _Placeholder((None, None if ps is None else 2 * ps, None if ps is None else 2 * ps, 3))
+
+    @property
+    def model_code(self):
+        return '{c}_{cfa}{tu}{r}_{k}x{k}'.format(c=self.class_name, cfa=self._h.cfa_pattern, k=self._h.kernel,
+                                                 tu='T' if self._h.trainable_upsampling else '',
+                                                 r='R' if self._h.random_init else '')
+
+    def forward(self, x, training=False):
+        P = self._model.p
+        t = OrderedDict()
+        h12 = ops.conv2d(x, P['up/kernel'])
+        t['bayer'] = ops.d2s_clip(h12, 1.0, 0.0, False)
+        t['rgb'] = ops.conv2d(t['bayer'], P['demosaic/kernel'], pad_mode=ops.PAD_MODES['REFLECT'])
+        t['srgb'] = ops.conv2d(t['rgb'], P['srgb/kernel'])
+        t['g0'] = ops.tanh(ops.conv2d(t['srgb'], P['gamma1/kernel'], P['gamma1/bias']))
+        y0 = ops.conv2d(t['g0'], P['gamma2/kernel'], P['gamma2/bias'])
+        return ops.clip01(y0, out=y0), (t if training else None)
+
+    def backward(self, t, dy):
+        """dy = d loss / d y (the clip is straight-through). The frozen up-sampling kernel keeps a zero gradient."""
+        P, G = self._model.p, self._model.g
+        hw = (dy.shape[1], dy.shape[2])
+        k = self._h.kernel
+        ops.conv2d_wgrad(t['g0'], dy, 1, dw=G['gamma2/kernel'], db=G['gamma2/bias'])
+        dz1 = ops.tanh_bwd(ops.conv2d_dgrad(dy, P['gamma2/kernel'], hw), t['g0'])
+        ops.conv2d_wgrad(t['srgb'], dz1, 1, dw=G['gamma1/kernel'], db=G['gamma1/bias'])
+        d_srgb = ops.conv2d_dgrad(dz1, P['gamma1/kernel'], hw)
+        ops.conv2d_wgrad(t['rgb'], d_srgb, 1, dw=G['srgb/kernel'])
+        d_rgb = ops.conv2d_dgrad(d_srgb, P['srgb/kernel'], hw)
+        ops.conv2d_wgrad(t['bayer'], d_rgb, k, pad_mode=ops.PAD_MODES['REFLECT'], dw=G['demosaic/kernel'])
+        return None
+
+
 class ONet(NIPModel):
     """Dummy pipeline for RGB training (pipelines.py:353-362): identity, no parameters."""
 
@@ -210,4 +287,4 @@ class ONet(NIPModel):
         return self.class_name
 
 
-supported_models = ['UNet', 'ONet']
+supported_models = ['UNet', 'INet', 'ONet']

@@ -125,7 +125,7 @@ def djpeg_bwd(x, gy, mask, qtab, rounding='soft', out=None):
 # ----------------------------------------------------------------------------------------------------------------
 # convolutions
 def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mode=0, out=None, out2=None,
-           act_mask=None, pads=None, out_hw=None, _wmode=0, _f32_only=False):
+           act_mask=None, pads=None, out_hw=None, _wmode=0, _f32_only=False, mask_alpha=None):
     """x (N,H,W,C1) [+ x2 (N,H,W,C2)], w (k,k,C1+C2,Cout) HWIO.  padding 'SAME' (TF) | 'VALID' | explicit pads/out_hw.
     out/out2: optional pre-allocated outputs (out2 splits the output channels: Cout = out.C + out2.C)."""
     _f32(x, w, bias, x2, out, out2, act_mask)
@@ -152,11 +152,17 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
     o2 = 0 if out2 is None else out2.shape[3]
     if o1 + o2 != cout or tuple(out.shape[:3]) != (n, ho, wo):
         raise ValueError('output shape mismatch')
+    # activation: LeakyReLU(0.2) | ReLU (= slope 0); act_mask multiplies by the same-slope derivative (mask_alpha
+    # overrides the slope for an input-gradient pass behind a ReLU layer)
+    if act not in (None, 'leaky_relu', 'relu'):
+        raise ValueError('unsupported activation {}'.format(act))
+    act_id = 0 if act is None else 1
+    alpha = 0.0 if act == 'relu' else (LRELU_ALPHA if mask_alpha is None else float(mask_alpha))
     if COMPUTE == 'bf16' and not _f32_only and _wmode == 0 and c2 == 0 and out2 is None and act_mask is None and \
             c1 in (3, 4) and ks in (3, 5) and stride == 1 and cout >= 8 and (ho, wo) == (h, wd) and \
             (pt, pl) == ((ks - 1) // 2, (ks - 1) // 2):
         _lib.call('nimg_conv2d_fwd_smallc_bf16', _p(x), c1, _p(w), _p(bias), _p(out), cout, n, h, wd, ks, pad_mode,
-                  1 if act == 'leaky_relu' else 0, LRELU_ALPHA, _stream())
+                  act_id, alpha, _stream())
         return out
     if COMPUTE == 'bf16' and not _f32_only and _wmode == 1 and c2 == 0 and out2 is None and act_mask is None and \
             c1 == 32 and cout == 3 and ks == 5 and stride == 1 and (ho, wo) == (h, wd) and (pt, pl) == (2, 2) and \
@@ -166,13 +172,13 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
     if COMPUTE == 'bf16' and not _f32_only and c1 % 8 == 0 and c2 % 8 == 0 and cout >= 8:
         wb = weights_bf16(w, _wmode)
         _lib.call('nimg_conv2d_fwd_bf16', _p(x), c1, _p(x2), c2, _p(wb), _p(bias), _p(out), o1, _p(out2), o2,
-                  _p(act_mask), n, h, wd, ks, stride, pt, pl, pad_mode, ho, wo, 1 if act == 'leaky_relu' else 0,
-                  LRELU_ALPHA, _stream())
+                  _p(act_mask), n, h, wd, ks, stride, pt, pl, pad_mode, ho, wo, act_id,
+                  alpha, _stream())
         return out if out2 is None else (out, out2)
     if _wmode == 1:
         w = flip_weights(w)
     _lib.call('nimg_conv2d_fwd', _p(x), c1, _p(x2), c2, _p(w), _p(bias), _p(out), o1, _p(out2), o2, _p(act_mask),
-              n, h, wd, ks, stride, pt, pl, pad_mode, ho, wo, 1 if act == 'leaky_relu' else 0, LRELU_ALPHA, _stream())
+              n, h, wd, ks, stride, pt, pl, pad_mode, ho, wo, act_id, alpha, _stream())
     return out if out2 is None else (out, out2)
 
 
@@ -185,7 +191,7 @@ def flip_weights(w, out=None):
     return wt
 
 
-def conv2d_dgrad(dz, w, in_hw, stride=1, padding='SAME', act_mask=None, out=None, out2=None):
+def conv2d_dgrad(dz, w, in_hw, stride=1, padding='SAME', act_mask=None, out=None, out2=None, mask_alpha=None):
     """Input gradient of conv2d (stride 1, odd kernel): correlation of dz with the flipped kernel."""
     if stride != 1:
         raise NotImplementedError('strided dgrad is expressed by the caller (see models/compression.py)')
@@ -198,7 +204,7 @@ def conv2d_dgrad(dz, w, in_hw, stride=1, padding='SAME', act_mask=None, out=None
         pt = pl = 0
     # forward used pad (pt, pl); the gradient correlation needs ks-1-pt / ks-1-pl; the kernel is read flipped/transposed
     return conv2d(dz, w, None, pads=(ks - 1 - pt, ks - 1 - pl), out_hw=(h, wd), act_mask=act_mask, out=out,
-                  out2=out2, _wmode=1)
+                  out2=out2, _wmode=1, mask_alpha=mask_alpha)
 
 
 def conv2d_wgrad(x, dz, ks, x2=None, stride=1, padding='SAME', pad_mode=0, pads=None, dw=None, accumulate=False,
@@ -371,10 +377,12 @@ def d2s_clip_bwd(dy, scale=1.0):
     return dx
 
 
-def lrelu_bwd(dy, yact, out=None):
+def lrelu_bwd(dy, yact, out=None, alpha=None):
+    """dz = dy * act'(y) for LeakyReLU(alpha) (default 0.2); alpha = 0 is the ReLU derivative."""
     _f32(dy, yact, out)
     dz = torch.empty_like(dy) if out is None else out
-    _lib.call('nimg_lrelu_bwd', _p(dy), _p(yact), _p(dz), dy.numel(), LRELU_ALPHA, _stream())
+    _lib.call('nimg_lrelu_bwd', _p(dy), _p(yact), _p(dz), dy.numel(), LRELU_ALPHA if alpha is None else float(alpha),
+              _stream())
     return dz
 
 
@@ -708,3 +716,38 @@ def ssim(a, b, mode='skimage', max_val=1.0):
     ws = _ws.get(_lib.load().nimg_ssim_workspace_bytes(n), a.device)
     _lib.call('nimg_ssim', _p(a), _p(b), _p(out), n, h, w, c, m, float(max_val), _p(gk), _p(ws), ws.numel(), _stream())
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# element-wise pieces of the INet / DNet pipelines
+def tanh(x, out=None):
+    _f32(x, out)
+    y = torch.empty_like(x) if out is None else out
+    _lib.call('nimg_tanh_fwd', _p(x), _p(y), x.numel(), _stream())
+    return y
+
+
+def tanh_bwd(dy, y, out=None):
+    _f32(dy, y, out)
+    dx = torch.empty_like(dy) if out is None else out
+    _lib.call('nimg_tanh_bwd', _p(dy), _p(y), _p(dx), dy.numel(), _stream())
+    return dx
+
+
+def clip01(x, out=None):
+    _f32(x, out)
+    y = torch.empty_like(x) if out is None else out
+    _lib.call('nimg_clip01', _p(x), _p(y), x.numel(), _stream())
+    return y
+
+
+PAD_MODES = {'CONSTANT': 0, 'SYMMETRIC': 1, 'REFLECT': 2}
+
+
+def pad2d(x, pad, mode='REFLECT'):
+    """tf.pad on the two spatial axes; the backward pass is fold_pad(d, pad, PAD_MODES[mode])."""
+    _f32(x)
+    n, h, w, c = x.shape
+    y = torch.empty((n, h + 2 * pad, w + 2 * pad, c), dtype=torch.float32, device=x.device)
+    _lib.call('nimg_pad2d', _p(x), _p(y), n, h, w, c, pad, PAD_MODES[mode], _stream())
+    return y

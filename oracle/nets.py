@@ -192,3 +192,20 @@ def dcn_loss(x, y, ent, entropy_weight=250.0):
 
 def count_params(p):
     return int(sum(int(np.prod(v.shape)) for v in p.values()))
+
+
+# ---------------------------------------------------------------------------------------------
+def inet_forward(p, x):
+    """INet (models/pipelines.py:233-295): 1x1 up-sampling -> depth_to_space(2) -> REFLECT pad + VALID k x k demosaicing ->
+    1x1 colour conversion -> 1x1 (3->12) + tanh -> 1x1 (12->3) -> straight-through clip.  p: names up, demosaic, srgb,
+    gamma1, gamma2 (+ '/kernel', '/bias')."""
+    k = p['demosaic/kernel'].shape[0]
+    pad = (k - 1) // 2
+    h12 = T.conv2d(x, p['up/kernel'], None, 1, 'VALID')
+    bayer = T.depth_to_space(h12, 2)
+    bp = torch.nn.functional.pad(bayer.permute(0, 3, 1, 2), (pad, pad, pad, pad), mode='reflect').permute(0, 2, 3, 1)
+    rgb = T.conv2d(bp, p['demosaic/kernel'], None, 1, 'VALID')
+    srgb = T.conv2d(rgb, p['srgb/kernel'], None, 1, 'VALID')
+    g0 = torch.tanh(T.conv2d(srgb, p['gamma1/kernel'], p['gamma1/bias'], 1, 'VALID'))
+    y = T.conv2d(g0, p['gamma2/kernel'], p['gamma2/bias'], 1, 'VALID')
+    return y + (torch.clamp(y, 0, 1) - y).detach()

@@ -182,6 +182,58 @@ def test_fan_head_variants(dev, use_gap, n_dense):
         forensics.FAN(n_classes=4, patch_size=32, dropout=0.5, device=dev)
 
 
+@pytest.mark.parametrize('kernel,cfa', [(5, 'gbrg'), (3, 'rggb')])
+def test_inet_forward_backward_and_training(dev, kernel, cfa):
+    """INet (models/pipelines.py:233-295), the NIP the reference's own framework tests train (config/tests/framework.json):
+    output and every trainable gradient against the float64 oracle, frozen up-sampling, then Keras-Adam steps."""
+    from neural_imaging_amd.models import pipelines
+    net = pipelines.INet(patch_size=24, kernel=kernel, cfa_pattern=cfa, device=dev)
+    assert net.model_code == 'INet_{}_{}x{}'.format(cfa, kernel, kernel) and net.count_parameters() == 48 + 9 * kernel ** 2 + 9 + 48 + 39
+    rgb = natural_images(3, 48, 48, seed=21)
+    raw = bayer_from_rgb(rgb)
+    p = oracle_params(net)
+    train = [k for k in p if not k.startswith('up/')]
+    for k in train:
+        p[k].requires_grad_(True)
+    y_ref = onets.inet_forward(p, to64(raw))
+    loss_ref = T.mse255(y_ref, to64(rgb))
+    g_ref = dict(zip(train, torch.autograd.grad(loss_ref, [p[k] for k in train])))
+    y, ctx = net.forward(torch.from_numpy(raw).to(dev), training=True)
+    assert y.shape == (3, 48, 48, 3)
+    assert_close(y.cpu().numpy(), y_ref.detach().numpy(), 1e-5, what='INet output')
+    from neural_imaging_amd import ops
+    loss, dy = ops.mse255(y, torch.from_numpy(rgb).to(dev), grad_scale=1.0)
+    net.backward(ctx, dy)
+    assert abs(float(loss.item()) - float(loss_ref)) / float(loss_ref) < 1e-5
+    got = grads_of(net)
+    check_grads(got, g_ref, train, tol=2e-4)
+    assert np.abs(got['up/kernel']).max() == 0
+    # training: the loss falls and the frozen kernel does not move
+    up0 = net.state_dict()['up/kernel'].copy()
+    losses = [float(net.training_step(raw, rgb, learning_rate=1e-3)) for _ in range(25)]
+    assert losses[-1] < 0.8 * losses[0], losses
+    assert np.array_equal(net.state_dict()['up/kernel'], up0)
+    assert net.process(raw[0]).shape == (1, 48, 48, 3)
+
+
+def test_workflow_with_inet(dev):
+    """train_manipulation.py --nip INet --train nip (config/tests/framework.json 'train-manipulation')."""
+    from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
+    dist = {'downsampling': 'none', 'compression': 'jpeg', 'compression_params': {'quality': 80, 'codec': 'soft'}}
+    wf = ManipulationClassification('INet', manipulations=['sharpen:1', 'gaussian:1'], distribution=dist,
+                                    trainable={'nip'}, raw_patch_size=32, device=dev)
+    rgb = natural_images(4, 64, 64, seed=3)
+    raw = bayer_from_rgb(rgb)
+    before = wf.nip.state_dict()['demosaic/kernel'].copy()
+    l0 = None
+    for _ in range(6):
+        loss, parts = wf.training_step(raw, rgb, lambda_nip=0.1, learning_rate=1e-3)
+        l0 = float(loss) if l0 is None else l0
+    assert np.isfinite(float(loss)) and float(loss) < l0
+    assert np.abs(wf.nip.state_dict()['demosaic/kernel'] - before).max() > 0
+    assert wf.run_workflow_to_decisions(raw).shape == (12,)
+
+
 def _sync_oracle(wf, ref):
     ref.nip = onets.OrderedDict((k, to64(v)) for k, v in wf.nip.state_dict().items())
     ref.fan = onets.OrderedDict((k, to64(v)) for k, v in wf.fan.state_dict().items())
