@@ -265,6 +265,95 @@ class INet(NIPModel):
         return None
 
 
+class DNet(NIPModel):
+    """Joint demosaicing & denoising pipeline after Gharbi et al. 2016 (pipelines.py:298-349): n_layers x [VALID k x k
+    conv + ReLU -> REFLECT re-pad] on the RAW planes (last layer 12 channels) -> depth_to_space(2) -> concat with the
+    up-sampled Bayer image (never materialised: the projection reads two tensors) -> VALID k x k conv + ReLU (6 -> nf) ->
+    REFLECT re-pad -> 1x1 (nf -> 3, ones, no bias) -> straight-through clip.  Layer names: conv0 .. conv{n-1}, up
+    (frozen), proj, out."""
+
+    def construct_model(self, n_layers=15, kernel=3, n_features=64):
+        self._h = paramspec.ParamSpec({
+            'n_layers': (15, int, (1, 32)),
+            'kernel': (3, int, (3, 11)),
+            'n_features': (64, int, (4, 128)),
+        })
+        self._h.update(n_layers=n_layers, kernel=kernel, n_features=n_features)
+        if self._h.kernel not in (3, 5) or self.in_channels != 4:
+            raise NotImplementedError('DNet is built for 3x3 / 5x5 kernels on 4-plane RAW input')
+        k, nf, nl = self._h.kernel, self._h.n_features, self._h.n_layers
+        self._convs = []
+        cin = 4
+        for r in range(nl):
+            cout = 12 if r == nl - 1 else nf
+            self._convs.append(Conv2D('conv{}'.format(r), k, cin, cout, None))
+            cin = cout
+        self._proj = Conv2D('proj', k, 3, nf, None, cin2=3)
+        specs = [sp for c in self._convs for sp in c.specs()]
+        specs += [('up/kernel', (1, 1, 4, 12))] + self._proj.specs() + [('out/kernel', (1, 1, nf, 3))]
+        self._model = ParamStore(specs, self.device)
+        gen = torch.Generator().manual_seed(self._seed)
+        for c in self._convs + [self._proj]:         # VarianceScaling(1, fan_in, truncated normal), zero bias
+            w = self._model.p[c.name + '/kernel']
+            fan_in = c.ks * c.ks * (c.cin + c.cin2)
+            t = torch.empty(tuple(w.shape), dtype=torch.float32)
+            torch.nn.init.trunc_normal_(t, 0.0, 1.0, -2.0, 2.0, generator=gen)
+            w.copy_(t * (np.sqrt(1.0 / fan_in) / 0.87962566103423978))
+            self._model.p[c.name + '/bias'].zero_()
+        self._model.p['up/kernel'].copy_(torch.from_numpy(hk.upsampling_kernel().astype(np.float32).reshape(1, 1, 4, 12)))
+        self._model.p['out/kernel'].fill_(1.0)
+        ps = self.patch_size
+        self.y = _Placeholder((None, None if ps is None else 2 * ps, None if ps is None else 2 * ps, 3))
+
+    @property
+    def model_code(self):
+        return '{c}_{k}x{k}_{l}x{f}f'.format(c=self.class_name, k=self._h.kernel, f=self._h.n_features,
+                                             l=self._h.n_layers)
+
+    def forward(self, x, training=False):
+        P = self._model.p
+        pad = (self._h.kernel - 1) // 2
+        t = OrderedDict()
+        t['in0'] = x
+        deep = x
+        for r, c in enumerate(self._convs):
+            z = ops.conv2d(deep, P[c.name + '/kernel'], P[c.name + '/bias'], padding='VALID', act='relu')
+            t['z{}'.format(r)] = z
+            deep = ops.pad2d(z, pad, 'REFLECT')
+            t['in{}'.format(r + 1)] = deep
+        bayer = ops.d2s_clip(ops.conv2d(x, P['up/kernel']), 1.0, 0.0, False)
+        feat = ops.d2s_clip(deep, 1.0, 0.0, False)
+        t['feat'], t['bayer'] = feat, bayer
+        pu = ops.conv2d(feat, P['proj/kernel'], P['proj/bias'], x2=bayer, padding='VALID', act='relu')
+        t['pu'] = pu
+        t['pup'] = ops.pad2d(pu, pad, 'REFLECT')
+        y0 = ops.conv2d(t['pup'], P['out/kernel'])
+        return ops.clip01(y0, out=y0), (t if training else None)
+
+    def backward(self, t, dy):
+        P, G = self._model.p, self._model.g
+        k = self._h.kernel
+        pad = (k - 1) // 2
+        refl = ops.PAD_MODES['REFLECT']
+        hw = lambda a: (a.shape[1], a.shape[2])
+        ops.conv2d_wgrad(t['pup'], dy, 1, dw=G['out/kernel'])
+        d_pu = ops.fold_pad(ops.conv2d_dgrad(dy, P['out/kernel'], hw(t['pup'])), pad, refl)
+        dz = ops.lrelu_bwd(d_pu, t['pu'], alpha=0.0)
+        ops.conv2d_wgrad(t['feat'], dz, k, x2=t['bayer'], padding='VALID', dw=G['proj/kernel'], db=G['proj/bias'])
+        d_feat = torch.empty_like(t['feat'])
+        d_bayer = torch.empty_like(t['bayer'])               # gradient of the frozen up-sampling branch: discarded
+        ops.conv2d_dgrad(dz, P['proj/kernel'], hw(t['feat']), padding='VALID', out=d_feat, out2=d_bayer)
+        d_deep = ops.d2s_clip_bwd(d_feat, 1.0)
+        for r in range(len(self._convs) - 1, -1, -1):
+            c = self._convs[r]
+            z, inp = t['z{}'.format(r)], t['in{}'.format(r)]
+            dz = ops.lrelu_bwd(ops.fold_pad(d_deep, pad, refl), z, alpha=0.0)
+            ops.conv2d_wgrad(inp, dz, k, padding='VALID', dw=G[c.name + '/kernel'], db=G[c.name + '/bias'])
+            if r > 0:
+                d_deep = ops.conv2d_dgrad(dz, P[c.name + '/kernel'], hw(inp), padding='VALID')
+        return None
+
+
 class ONet(NIPModel):
     """Dummy pipeline for RGB training (pipelines.py:353-362): identity, no parameters."""
 
@@ -287,4 +376,4 @@ class ONet(NIPModel):
         return self.class_name
 
 
-supported_models = ['UNet', 'INet', 'ONet']
+supported_models = ['UNet', 'INet', 'DNet', 'ONet']

@@ -209,3 +209,18 @@ def inet_forward(p, x):
     g0 = torch.tanh(T.conv2d(srgb, p['gamma1/kernel'], p['gamma1/bias'], 1, 'VALID'))
     y = T.conv2d(g0, p['gamma2/kernel'], p['gamma2/bias'], 1, 'VALID')
     return y + (torch.clamp(y, 0, 1) - y).detach()
+
+
+def dnet_forward(p, x):
+    """DNet (models/pipelines.py:298-349).  p: conv0..conv{n-1}, up, proj, out ('/kernel', '/bias')."""
+    refl = lambda t, pad: torch.nn.functional.pad(t.permute(0, 3, 1, 2), (pad,) * 4, mode='reflect').permute(0, 2, 3, 1)
+    n_layers = len([k for k in p if k.startswith('conv') and k.endswith('/kernel')])
+    pad = (p['conv0/kernel'].shape[0] - 1) // 2
+    deep = x
+    for r in range(n_layers):
+        deep = refl(torch.relu(T.conv2d(deep, p['conv{}/kernel'.format(r)], p['conv{}/bias'.format(r)], 1, 'VALID')), pad)
+    bayer = T.depth_to_space(T.conv2d(x, p['up/kernel'], None, 1, 'VALID'), 2)
+    feat = T.depth_to_space(deep, 2)
+    pu = torch.relu(T.conv2d(torch.cat((feat, bayer), dim=3), p['proj/kernel'], p['proj/bias'], 1, 'VALID'))
+    y = T.conv2d(refl(pu, pad), p['out/kernel'], None, 1, 'VALID')
+    return y + (torch.clamp(y, 0, 1) - y).detach()

@@ -234,6 +234,37 @@ def test_workflow_with_inet(dev):
     assert wf.run_workflow_to_decisions(raw).shape == (12,)
 
 
+@pytest.mark.parametrize('n_layers,nf', [(4, 16), (3, 24)])
+def test_dnet_forward_backward(dev, n_layers, nf):
+    """DNet (models/pipelines.py:298-349): VALID conv + ReLU + REFLECT re-pad chains, two-tensor projection, frozen
+    up-sampling; output and every trainable gradient against the float64 oracle."""
+    from neural_imaging_amd import ops
+    from neural_imaging_amd.models import pipelines
+    net = pipelines.DNet(patch_size=16, n_layers=n_layers, n_features=nf, device=dev)
+    assert net.model_code == 'DNet_3x3_{}x{}f'.format(n_layers, nf)
+    rgb = natural_images(3, 32, 32, seed=23)
+    raw = bayer_from_rgb(rgb)
+    p = oracle_params(net)
+    train = [k for k in p if not k.startswith('up/')]
+    for k in train:
+        p[k].requires_grad_(True)
+    y_ref = onets.dnet_forward(p, to64(raw))
+    loss_ref = T.mse255(y_ref, to64(rgb))
+    g_ref = dict(zip(train, torch.autograd.grad(loss_ref, [p[k] for k in train])))
+    y, ctx = net.forward(torch.from_numpy(raw).to(dev), training=True)
+    assert y.shape == (3, 32, 32, 3)
+    assert_close(y.cpu().numpy(), y_ref.detach().numpy(), 2e-5, what='DNet output')
+    loss, dy = ops.mse255(y, torch.from_numpy(rgb).to(dev), grad_scale=1.0)
+    net.backward(ctx, dy)
+    got = grads_of(net)
+    check_grads(got, g_ref, train, tol=3e-4)
+    assert np.abs(got['up/kernel']).max() == 0
+    l0 = float(net.training_step(raw, rgb, learning_rate=1e-3))
+    for _ in range(10):
+        l1 = float(net.training_step(raw, rgb, learning_rate=1e-3))
+    assert l1 < l0
+
+
 def _sync_oracle(wf, ref):
     ref.nip = onets.OrderedDict((k, to64(v)) for k, v in wf.nip.state_dict().items())
     ref.fan = onets.OrderedDict((k, to64(v)) for k, v in wf.fan.state_dict().items())
