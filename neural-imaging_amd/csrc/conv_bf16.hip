@@ -538,6 +538,7 @@ int nimg_conv2d_fwd_bf16(const float* in1, int c1, const float* in2, int c2, con
                          float* out1, int o1, float* out2, int o2, const float* act_mask, int n, int h, int wd,
                          int ks, int stride, int pad_t, int pad_l, int pad_mode, int hout, int wout, int act,
                          float alpha, void* stream) {
+    if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!in1 || !wb || !out1 || c1 <= 0 || c2 < 0 || o1 <= 0 || o2 < 0 || n < 0 || h <= 0 || wd <= 0) return NIMG_ERR_ARG;
     if ((c2 > 0 && !in2) || (o2 > 0 && !out2) || hout <= 0 || wout <= 0 || pad_t < 0 || pad_l < 0) return NIMG_ERR_ARG;
     if (act < 0 || act > 1 || pad_mode < 0 || pad_mode > 2) return NIMG_ERR_ARG;
@@ -563,6 +564,7 @@ int nimg_conv2d_fwd_bf16(const float* in1, int c1, const float* in2, int c2, con
  * kernel (2,2,Cout,Cin).  x (n,h,wd,cin) -> y (n,2h,2wd,cout). */
 int nimg_convt2x2_fwd_bf16(const float* x, const void* wb, const float* bias, float* y, int n, int h, int wd, int cin,
                            int cout, void* stream) {
+    if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!x || !wb || !y || n < 0 || h <= 0 || wd <= 0 || cin <= 0 || cout <= 0 || (cin % 8)) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
     ConvParamsB p;
@@ -1159,6 +1161,7 @@ static int launch_packed_bf16(const float* in, int cin, const float* w, const fl
 
 int nimg_conv2d_fwd_smallc_bf16(const float* in, int cin, const float* w, const float* bias, float* out, int cout,
                                 int n, int h, int wd, int ks, int pad_mode, int act, float alpha, void* stream) {
+    if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!in || !w || !out || n < 0 || h <= 0 || wd <= 0 || cout <= 0 || pad_mode < 0 || pad_mode > 2) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
     return launch_packed_bf16(in, cin, w, bias, out, nullptr, nullptr, cout, n, h, wd, ks, pad_mode, act, alpha,
@@ -1170,6 +1173,7 @@ int nimg_conv2d_fwd_smallc_bf16(const float* in, int cin, const float* w, const 
 int nimg_conv2d_pool_fwd_bf16(const float* in, int cin, const float* w, const void* wb, const float* bias,
                               float* pool_out, unsigned char* pool_idx, int cout, int n, int h, int wd, int ks, int act,
                               float alpha, void* stream) {
+    if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!in || !pool_out || cin <= 0 || cout <= 0 || (cout & 3) || n < 0 || h <= 0 || wd <= 0) return NIMG_ERR_ARG;
     if ((h & 1) || (wd & 1) || (ks != 3 && ks != 5) || act < 0 || act > 1) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;

@@ -354,6 +354,7 @@ int nimg_abi_version(void) { return 1; }
 
 int nimg_djpeg_fwd(const float* x, float* y, const float* qtab, uint8_t* mask, int16_t* idx, float* xdq, int n,
                    int h, int w, int rounding, void* stream) {
+    if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!x || !y || !qtab || n < 0 || h <= 0 || w <= 0 || (h % 8) || (w % 8)) return NIMG_ERR_ARG;
     if (rounding < NIMG_ROUND_ROUND || rounding > NIMG_ROUND_IDENTITY) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
@@ -368,6 +369,7 @@ int nimg_djpeg_fwd(const float* x, float* y, const float* qtab, uint8_t* mask, i
 
 int nimg_djpeg_bwd(const float* x, const float* gy, const uint8_t* mask, const float* qtab, float* gx, int n, int h,
                    int w, int rounding, void* stream) {
+    if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!x || !gy || !mask || !qtab || !gx || n < 0 || h <= 0 || w <= 0 || (h % 8) || (w % 8)) return NIMG_ERR_ARG;
     if (rounding < NIMG_ROUND_ROUND || rounding > NIMG_ROUND_IDENTITY) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;

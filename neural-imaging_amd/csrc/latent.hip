@@ -304,6 +304,7 @@ int nimg_clip01(const float* x, float* y, long count, void* stream) {
 }
 
 int nimg_pad2d(const float* x, float* y, int n, int h, int w, int c, int pad, int pad_mode, void* stream) {
+    if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!x || !y || n < 0 || h <= 0 || w <= 0 || c <= 0 || pad < 0 || pad_mode < 0 || pad_mode > 2) return NIMG_ERR_ARG;
     if ((pad_mode == 1 && (pad > h || pad > w)) || (pad_mode == 2 && (pad >= h || pad >= w))) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
@@ -314,6 +315,7 @@ int nimg_pad2d(const float* x, float* y, int n, int h, int w, int c, int pad, in
 }
 
 int nimg_zero_insert2(const float* in, float* out, int n, int h, int w, int c, void* stream) {
+    if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!in || !out || n < 0 || h <= 0 || w <= 0 || c <= 0) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
     hipLaunchKernelGGL(zero_insert2_kernel, dim3(grid_for((long)n * 4 * h * w * c)), dim3(256), 0,

@@ -338,6 +338,7 @@ extern "C" {
 
 int nimg_gaussian_fwd(const float* x, float* y, uint8_t* mask, const float* gk25, int n, int h, int w, int clip,
                       void* stream) {
+    if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!x || !y || !gk25 || n < 0 || h < 5 || w < 5) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
     hipLaunchKernelGGL(gaussian_fwd_kernel, dim3(grid_for((long)n * h * w)), dim3(256), 0, (hipStream_t)stream, x, y,
@@ -348,6 +349,7 @@ int nimg_gaussian_fwd(const float* x, float* y, uint8_t* mask, const float* gk25
 
 int nimg_gaussian_bwd(const float* dy, const uint8_t* mask, float* dx, const float* gk25, int n, int h, int w,
                       void* stream) {
+    if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!dy || !dx || !gk25 || n < 0 || h < 5 || w < 5) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
     hipLaunchKernelGGL(gaussian_bwd_kernel, dim3(grid_for((long)n * h * w)), dim3(256), 0, (hipStream_t)stream, dy,
@@ -358,6 +360,7 @@ int nimg_gaussian_bwd(const float* dy, const uint8_t* mask, float* dx, const flo
 
 int nimg_sharpen_fwd(const float* x, float* y, float* aux_hsv, uint8_t* mask, const float* gk9, int n, int h, int w,
                      void* stream) {
+    if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!x || !y || !gk9 || n < 0 || h < 3 || w < 3) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
     hipLaunchKernelGGL(sharpen_fwd_kernel, dim3(grid_for((long)n * h * w)), dim3(256), 0, (hipStream_t)stream, x, y,
@@ -368,6 +371,7 @@ int nimg_sharpen_fwd(const float* x, float* y, float* aux_hsv, uint8_t* mask, co
 
 int nimg_sharpen_bwd(const float* x, const float* dy, float* aux_hsv, const uint8_t* mask, float* dx,
                      const float* gk9, int n, int h, int w, void* stream) {
+    if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!x || !dy || !aux_hsv || !mask || !dx || !gk9 || n < 0 || h < 3 || w < 3) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -382,6 +386,7 @@ int nimg_sharpen_bwd(const float* x, const float* dy, float* aux_hsv, const uint
 
 int nimg_sparse_axis_apply(const float* in, float* out, const int* rowptr, const int* col, const float* val, int n,
                            int hin, int win, int c, int axis, int out_size, void* stream) {
+    if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!in || !out || !rowptr || !col || !val || n < 0 || hin <= 0 || win <= 0 || c <= 0 || out_size <= 0)
         return NIMG_ERR_ARG;
     if (axis != 0 && axis != 1) return NIMG_ERR_ARG;
@@ -394,6 +399,7 @@ int nimg_sparse_axis_apply(const float* in, float* out, const int* rowptr, const
 }
 
 int nimg_fold_pad(const float* dpad, float* dx, int n, int h, int w, int c, int pad, int pad_mode, void* stream) {
+    if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!dpad || !dx || n < 0 || h <= 2 * pad || w <= 2 * pad || c <= 0 || pad < 0 || pad_mode < 1 || pad_mode > 2)
         return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
@@ -404,6 +410,7 @@ int nimg_fold_pad(const float* dpad, float* dx, int n, int h, int w, int c, int 
 }
 
 int nimg_avgpool_fwd(const float* x, float* y, int n, int h, int w, int c, int factor, void* stream) {
+    if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!x || !y || n < 0 || h <= 0 || w <= 0 || c <= 0 || factor < 1 || h % factor || w % factor) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
     hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid_for((long)n * (h / factor) * (w / factor) * c)), dim3(256), 0,
@@ -413,6 +420,7 @@ int nimg_avgpool_fwd(const float* x, float* y, int n, int h, int w, int c, int f
 }
 
 int nimg_avgpool_bwd(const float* dy, float* dx, int n, int h, int w, int c, int factor, void* stream) {
+    if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!dy || !dx || n < 0 || h <= 0 || w <= 0 || c <= 0 || factor < 1 || h % factor || w % factor) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
     hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for((long)n * h * w * c)), dim3(256), 0, (hipStream_t)stream, dy,
@@ -560,6 +568,7 @@ int nimg_gamma_bwd(const float* x, const float* dy, float* dx, long count, float
     return NIMG_OK;
 }
 int nimg_median_fwd(const float* x, float* y, uint8_t* sel, int n, int h, int w, int kernel, void* stream) {
+    if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!x || !y || n < 0 || kernel < 1 || kernel > 9 || !(kernel & 1) || h <= kernel / 2 || w <= kernel / 2)
         return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
@@ -570,6 +579,7 @@ int nimg_median_fwd(const float* x, float* y, uint8_t* sel, int n, int h, int w,
 }
 /* dx must be zero-initialised by the caller (gradients are scattered with atomic adds) */
 int nimg_median_bwd(const float* dy, const uint8_t* sel, float* dx, int n, int h, int w, int kernel, void* stream) {
+    if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!dy || !sel || !dx || n < 0 || kernel < 1 || kernel > 9 || !(kernel & 1)) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
     hipLaunchKernelGGL(median_bwd_kernel, dim3(grid_for((long)n * h * w * 3)), dim3(256), 0, (hipStream_t)stream, dy,

@@ -473,6 +473,7 @@ __global__ void nan_flag_kernel(const float* __restrict__ g, long count, int* fl
 extern "C" {
 
 int nimg_maxpool2_fwd(const float* x, float* y, int n, int h, int w, int c, void* stream) {
+    if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!x || !y || n < 0 || h <= 0 || w <= 0 || c <= 0 || (h & 1) || (w & 1)) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -488,6 +489,7 @@ int nimg_maxpool2_fwd(const float* x, float* y, int n, int h, int w, int c, void
 
 int nimg_maxpool2_bwd(const float* dp, const float* yact, const float* add, float* dz, int n, int h, int w, int c,
                       int apply_lrelu_mask, float alpha, void* stream) {
+    if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!dp || !yact || !dz || n < 0 || h <= 0 || w <= 0 || c <= 0 || (h & 1) || (w & 1)) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -503,6 +505,7 @@ int nimg_maxpool2_bwd(const float* dp, const float* yact, const float* add, floa
 
 int nimg_maxpool2_unpool(const float* dp, const unsigned char* idx, const float* pooled, float* dz, int n, int ho, int wo,
                          int c, int apply_lrelu_mask, float alpha, void* stream) {
+    if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!dp || !idx || !dz || n < 0 || ho <= 0 || wo <= 0 || c <= 0 || (c & 3)) return NIMG_ERR_ARG;
     if (apply_lrelu_mask && !pooled) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
@@ -514,6 +517,7 @@ int nimg_maxpool2_unpool(const float* dp, const unsigned char* idx, const float*
 
 int nimg_convt2x2_fwd(const float* x, const float* w, const float* bias, float* y, int n, int h, int wd, int cin,
                       int cout, void* stream) {
+    if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!x || !w || !y || n < 0 || h <= 0 || wd <= 0 || cin <= 0 || cout <= 0) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
     const long npix = (long)n * h * wd;
@@ -526,6 +530,7 @@ int nimg_convt2x2_fwd(const float* x, const float* w, const float* bias, float* 
 
 int nimg_d2s_clip_fwd(const float* x, float* y, int n, int h, int w, int cout, float scale, float shift, int clip,
                       void* stream) {
+    if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!x || !y || n < 0 || h <= 0 || w <= 0 || cout <= 0) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
     hipLaunchKernelGGL(d2s_clip_fwd_kernel, dim3(grid_for((long)n * h * w * 4 * cout)), dim3(256), 0,
@@ -535,6 +540,7 @@ int nimg_d2s_clip_fwd(const float* x, float* y, int n, int h, int w, int cout, f
 }
 
 int nimg_d2s_clip_bwd(const float* dy, float* dx, int n, int h, int w, int cout, float scale, void* stream) {
+    if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!dy || !dx || n < 0 || h <= 0 || w <= 0 || cout <= 0) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
     hipLaunchKernelGGL(d2s_clip_bwd_kernel, dim3(grid_for((long)n * h * w * 4 * cout)), dim3(256), 0,
@@ -580,6 +586,7 @@ size_t nimg_ssim_workspace_bytes(int n) { return (size_t)n * 64 * sizeof(double)
 
 int nimg_ssim(const float* a, const float* b, float* out, int n, int h, int w, int c, int mode, float max_val,
               const float* gauss_win, void* workspace, size_t workspace_bytes, void* stream) {
+    if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     const int win = mode == 0 ? 7 : 11;
     if (!a || !b || !out || !workspace || n < 0 || c <= 0 || h < win || w < win || mode < 0 || mode > 1) return NIMG_ERR_ARG;
     if (mode == 1 && !gauss_win) return NIMG_ERR_ARG;
@@ -598,6 +605,7 @@ int nimg_ssim(const float* a, const float* b, float* out, int n, int h, int w, i
 
 int nimg_fan_head_fwd(const float* act, const float* w, const float* b, const int* labels, float* gap, float* probs,
                       float* loss_per, float* dlogits, int n, int hw, int c, int k, float loss_scale, void* stream) {
+    if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!act || !w || !b || !gap || !probs || n < 0 || hw <= 0 || c <= 0 || k <= 0 || k > 16) return NIMG_ERR_ARG;
     if (labels && (!loss_per || !dlogits)) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;

@@ -276,6 +276,43 @@ def test_ssim_both_flavours(dev, shape):
         assert abs(metrics.batch(a, b, metrics.ssim) - ref.mean()) < 1e-5
 
 
+def test_edge_cases_empty_ragged_and_error_codes(dev):
+    """Empty batches are no-ops, ragged (non-tile-multiple) sizes are exact, malformed calls come back as negative
+    NIMG_ERR_* codes (surfaced as RuntimeError by the binding) instead of launching."""
+    from neural_imaging_amd import _lib, ops
+    # empty batch through the main entry points
+    x0 = torch.empty((0, 16, 16, 8), device=dev)
+    w = g(rnd((3, 3, 8, 16), 1), dev)
+    assert ops.conv2d(x0, w).shape == (0, 16, 16, 16)
+    assert ops.maxpool2(x0).shape == (0, 8, 8, 8)
+    y0, m0, _, _ = ops.djpeg_fwd(torch.empty((0, 16, 16, 3), device=dev), ops.qtables_device(50, dev))
+    assert y0.shape == (0, 16, 16, 3)
+    # ragged sizes: 1 x 1 pixels, prime sizes, single channel counts around the vector widths
+    for (n, h, wd, cin, cout, ks) in [(1, 1, 1, 8, 8, 3), (2, 7, 13, 5, 9, 3), (1, 17, 3, 12, 20, 5), (3, 9, 9, 1, 1, 5)]:
+        x, wt, b = rnd((n, h, wd, cin), 2), rnd((ks, ks, cin, cout), 3, -0.3, 0.3), rnd((cout,), 4)
+        ref = T.conv2d(to64(x), to64(wt), to64(b)).numpy()
+        out = ops.conv2d(g(x, dev), g(wt, dev), g(b, dev))
+        assert_close(out.cpu().numpy(), ref, 1e-5, GRTOL, what='ragged conv {}'.format((n, h, wd, cin, cout, ks)))
+    # error codes: odd size into the pool, dJPEG on a size that is not a multiple of 8, bad activation id
+    with pytest.raises(RuntimeError):
+        ops.maxpool2(g(rnd((1, 5, 4, 4), 5), dev))
+    with pytest.raises(RuntimeError):
+        ops.djpeg_fwd(g(rnd((1, 12, 16, 3), 6), dev), ops.qtables_device(50, dev))
+    lib = _lib.load()
+    xx = g(rnd((1, 8, 8, 8), 7), dev)
+    out = torch.empty((1, 8, 8, 16), device=dev)
+    rc = lib.nimg_conv2d_fwd(xx.data_ptr(), 8, None, 0, w.data_ptr(), None, out.data_ptr(), 16, None, 0, None, 1, 8, 8, 3, 1, 1,
+                             1, 0, 8, 8, 7, 0.2, None)
+    assert rc < 0
+    assert lib.nimg_conv2d_fwd(None, 8, None, 0, w.data_ptr(), None, out.data_ptr(), 16, None, 0, None, 1, 8, 8, 3, 1, 1, 1, 0,
+                               8, 8, 0, 0.2, None) < 0
+    # host tensors and non-contiguous tensors are refused - there is no CPU path
+    with pytest.raises(RuntimeError):
+        ops.conv2d(torch.zeros((1, 8, 8, 8)), w)
+    with pytest.raises(RuntimeError):
+        ops.conv2d(xx.permute(0, 2, 1, 3), w)
+
+
 def test_d2s_clip_and_small_ops(dev):
     from neural_imaging_amd import ops
     x = rnd((2, 6, 5, 12), 1, -0.5, 1.5)
