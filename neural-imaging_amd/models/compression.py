@@ -286,6 +286,6 @@ class TwitterDCN(DCN):
         L['e2'].backward_params(P, et['e1'], d_net)
         dz1 = L['e2'].backward_input(P, d_net, hw(et['e1']), act_mask=et['e1'])
         L['e1'].backward_params(P, et['x0'], dz1)
-        if need_input_grad:
-            return ops.affine(L['e1'].backward_input(P, dz1, hw(et['x0'])), 2.0, 0.0)
-        return None
+        dx = ops.affine(L['e1'].backward_input(P, dz1, hw(et['x0'])), 2.0, 0.0) if need_input_grad else None
+        ops.join_side_stream()
+        return dx

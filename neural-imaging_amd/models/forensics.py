@@ -170,7 +170,7 @@ class FAN(TFModel):
             if fused(i) and ops.pooled_backward_ok(conv.cin, conv.cout, conv.ks) and prev_mask is None:
                 # the pooled gradient feeds the weight / input gradient kernels directly (un-pooled while staging)
                 ops.conv2d_wgrad_pooled(inp, d_pool, t['idx{}'.format(i)], conv.ks, dw=P.g[conv.name + '/kernel'],
-                                        db=P.g[conv.name + '/bias'])
+                                        db=P.g[conv.name + '/bias'], side=True)
                 d_pool = ops.conv2d_dgrad_pooled(d_pool, t['idx{}'.format(i)], P.p[conv.name + '/kernel'])
                 continue
             if fused(i):
@@ -181,6 +181,7 @@ class FAN(TFModel):
             d_pool = conv.backward_input(P, dz, hw(inp), act_mask=prev_mask)
         self._constrained.backward_params(P, t['x'], d_pool)
         dx = self._constrained.backward_input(t['nf'], d_pool) if need_input_grad else None
+        ops.join_side_stream()
         return loss, dx
 
     # -- reference surface ---------------------------------------------------------------------------------------

@@ -48,8 +48,9 @@ class Conv2D(object):
                                want_idx=want_idx)
 
     def backward_params(self, store, x, dz, x2=None):
+        # on the side stream: it only needs (x, dz), which the input gradient on the launch stream reads as well
         ops.conv2d_wgrad(x, dz, self.ks, x2=x2, stride=self.stride, dw=store.g[self.name + '/kernel'],
-                         db=store.g[self.name + '/bias'])
+                         db=store.g[self.name + '/bias'], side=True)
 
     def backward_input(self, store, dz, in_hw, act_mask=None, out=None, out2=None):
         if self.stride == 2:
@@ -79,8 +80,8 @@ class Conv2DTranspose2x2(object):
         return ops.convt2x2(x, store.p[self.name + '/kernel'], store.p[self.name + '/bias'])
 
     def backward_params(self, store, x, dy):
-        ops.convt2x2_wgrad(x, dy, dw=store.g[self.name + '/kernel'])
-        ops.bias_grad(dy, db=store.g[self.name + '/bias'])
+        ops.convt2x2_wgrad(x, dy, dw=store.g[self.name + '/kernel'], side=True)
+        ops.bias_grad(dy, db=store.g[self.name + '/bias'], side=True)
 
     def backward_input(self, store, dy, act_mask=None):
         return ops.convt2x2_dgrad(dy, store.p[self.name + '/kernel'], act_mask=act_mask)

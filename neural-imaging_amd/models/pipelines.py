@@ -186,6 +186,7 @@ class UNet(NIPModel):
                 d_pool = L['ec{}1'.format(n)].backward_input(P, dz1, hw(inp))
                 prev = t['ec{}2'.format(n - 1)]
                 dz = ops.maxpool2_bwd(d_pool, prev, add=d_skip[n - 1], apply_mask=True, out=d_skip[n - 1])
+        ops.join_side_stream()
         return None
 
 
@@ -262,6 +263,7 @@ class INet(NIPModel):
         ops.conv2d_wgrad(t['rgb'], d_srgb, 1, dw=G['srgb/kernel'])
         d_rgb = ops.conv2d_dgrad(d_srgb, P['srgb/kernel'], hw)
         ops.conv2d_wgrad(t['bayer'], d_rgb, k, pad_mode=ops.PAD_MODES['REFLECT'], dw=G['demosaic/kernel'])
+        ops.join_side_stream()
         return None
 
 
@@ -351,6 +353,7 @@ class DNet(NIPModel):
             ops.conv2d_wgrad(inp, dz, k, padding='VALID', dw=G[c.name + '/kernel'], db=G[c.name + '/bias'])
             if r > 0:
                 d_deep = ops.conv2d_dgrad(dz, P[c.name + '/kernel'], hw(inp), padding='VALID')
+        ops.join_side_stream()
         return None
 
 
@@ -369,6 +372,7 @@ class ONet(NIPModel):
         return x, ({} if training else None)
 
     def backward(self, ctx, dy):
+        ops.join_side_stream()
         return None
 
     @property

@@ -80,6 +80,45 @@ class Workspace(object):
 
 
 _ws = Workspace()
+_ws_side = Workspace()          # split-K scratch of the kernels that run on the side stream
+
+# Weight / bias gradients of a layer and its input gradient depend only on the same dz, and many of them (the UNet
+# levels, 512 workgroups each) cannot fill 256 CUs on their own: layers launch their parameter gradients on a second HIP
+# stream so the two kernels share the machine.  The side stream first waits for everything queued on the launch stream,
+# the tensors it reads are pinned against early reuse by the caching allocator (record_stream), and every consumer of
+# the gradient buffers (optimiser, all-reduce, NaN check, end of each model's backward) joins it.  NIMG_NO_SIDE_STREAM=1
+# keeps everything on one stream.
+import os as _os
+
+_SIDE = {'stream': None, 'enabled': _os.environ.get('NIMG_NO_SIDE_STREAM') is None, 'dirty': False}
+
+
+class _on_side_stream(object):
+    def __init__(self, *tensors):
+        self.tensors = [t for t in tensors if t is not None]
+
+    def __enter__(self):
+        dev = self.tensors[0].device
+        if _SIDE['stream'] is None or _SIDE['stream'].device != dev:
+            _SIDE['stream'] = torch.cuda.Stream(device=dev)
+        side = _SIDE['stream']
+        side.wait_stream(torch.cuda.current_stream(dev))
+        for t in self.tensors:
+            t.record_stream(side)
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        _SIDE['dirty'] = True
+        return side
+
+    def __exit__(self, *exc):
+        return self.ctx.__exit__(*exc)
+
+
+def join_side_stream():
+    """Make the current stream wait for the parameter-gradient kernels launched on the side stream."""
+    if _SIDE['dirty'] and _SIDE['stream'] is not None:
+        torch.cuda.current_stream(_SIDE['stream'].device).wait_stream(_SIDE['stream'])
+        _SIDE['dirty'] = False
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -208,8 +247,13 @@ def conv2d_dgrad(dz, w, in_hw, stride=1, padding='SAME', act_mask=None, out=None
 
 
 def conv2d_wgrad(x, dz, ks, x2=None, stride=1, padding='SAME', pad_mode=0, pads=None, dw=None, accumulate=False,
-                 db=None):
-    """dw (k,k,C1+C2,Cout) = sum over pixels of x (x) dz;  db (optional, Cout) = fused bias gradient."""
+                 db=None, side=False):
+    """dw (k,k,C1+C2,Cout) = sum over pixels of x (x) dz;  db (optional, Cout) = fused bias gradient.
+    side=True: launch on the side stream (see _on_side_stream); dw / db must then be persistent buffers."""
+    if side and _SIDE['enabled'] and dw is not None:
+        with _on_side_stream(x, dz, x2):
+            return conv2d_wgrad(x, dz, ks, x2=x2, stride=stride, padding=padding, pad_mode=pad_mode, pads=pads, dw=dw,
+                                accumulate=accumulate, db=db, side=False)
     _f32(x, dz, x2, dw, db)
     n, h, wd, c1 = x.shape
     c2 = 0 if x2 is None else x2.shape[3]
@@ -227,25 +271,28 @@ def conv2d_wgrad(x, dz, ks, x2=None, stride=1, padding='SAME', pad_mode=0, pads=
     if COMPUTE == 'bf16' and (packed_ok or (c1 % 4 == 0 and c2 % 4 == 0 and cout % 4 == 0 and c1 + c2 >= 8 and
                                             (c2 == 0 or c1 % 8 == 0))):
         need = _lib.load().nimg_conv2d_wgrad_bf16_workspace_bytes(c1 + c2, cout, ks, ks, n, ho, wo)
-        ws = _ws.get(need, x.device)
+        ws = (_ws_side if torch.cuda.current_stream(x.device) == _SIDE['stream'] else _ws).get(need, x.device)
         _lib.call('nimg_conv2d_wgrad_bf16', _p(x), c1, _p(x2), c2, _p(dz), cout, _p(dw), _p(db), n, h, wd, ks, stride,
                   pt, pl, pad_mode, ho, wo, 1 if accumulate else 0, _p(ws), ws.numel(), _stream())
         return dw
     need = _lib.load().nimg_conv2d_wgrad_workspace_bytes(c1 + c2, cout, ks, ks, n, ho, wo)
-    ws = _ws.get(need, x.device)
+    ws = (_ws_side if torch.cuda.current_stream(x.device) == _SIDE['stream'] else _ws).get(need, x.device)
     _lib.call('nimg_conv2d_wgrad', _p(x), c1, _p(x2), c2, _p(dz), cout, _p(dw), _p(db), n, h, wd, ks, stride, pt, pl,
               pad_mode, ho, wo, 1 if accumulate else 0, _p(ws), ws.numel(), _stream())
     return dw
 
 
-def bias_grad(dz, db=None, accumulate=False):
+def bias_grad(dz, db=None, accumulate=False, side=False):
+    if side and _SIDE['enabled'] and db is not None:
+        with _on_side_stream(dz):
+            return bias_grad(dz, db=db, accumulate=accumulate, side=False)
     _f32(dz, db)
     cout = dz.shape[-1]
     npix = dz.numel() // cout
     if db is None:
         db = torch.empty((cout,), dtype=torch.float32, device=dz.device)
     need = _lib.load().nimg_bias_grad_workspace_bytes(npix, cout)
-    ws = _ws.get(need, dz.device)
+    ws = (_ws_side if torch.cuda.current_stream(dz.device) == _SIDE['stream'] else _ws).get(need, dz.device)
     _lib.call('nimg_bias_grad', _p(dz), _p(db), npix, cout, 1 if accumulate else 0, _p(ws), ws.numel(), _stream())
     return db
 
@@ -270,9 +317,9 @@ def convt2x2_dgrad(dy, w, act_mask=None):
     return conv2d(dy, w, None, stride=2, pads=(0, 0), out_hw=(h2 // 2, w2 // 2), act_mask=act_mask)
 
 
-def convt2x2_wgrad(x, dy, dw=None):
+def convt2x2_wgrad(x, dy, dw=None, side=False):
     """dw (2,2,Cout,Cin) = wgrad with the roles swapped: 'input' = dy (stride 2), 'output gradient' = x."""
-    return conv2d_wgrad(dy, x, 2, stride=2, pads=(0, 0), dw=dw)
+    return conv2d_wgrad(dy, x, 2, stride=2, pads=(0, 0), dw=dw, side=side)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -332,8 +379,11 @@ def pooled_backward_ok(cin, cout, ks):
     return COMPUTE == 'bf16' and cin == 3 and cout == 32 and ks == 5
 
 
-def conv2d_wgrad_pooled(x, g, idx, ks, dw=None, db=None):
+def conv2d_wgrad_pooled(x, g, idx, ks, dw=None, db=None, side=False):
     """Weight / bias gradient of conv2d_pool from the pooled gradient g (already x LeakyReLU') and the arg-max bytes."""
+    if side and _SIDE['enabled'] and dw is not None:
+        with _on_side_stream(x, g, idx):
+            return conv2d_wgrad_pooled(x, g, idx, ks, dw=dw, db=db, side=False)
     _f32(x, g, dw, db)
     _chk(idx)
     n, h, wd, cin = x.shape
@@ -341,7 +391,7 @@ def conv2d_wgrad_pooled(x, g, idx, ks, dw=None, db=None):
     if dw is None:
         dw = torch.empty((ks, ks, cin, cout), dtype=torch.float32, device=x.device)
     need = _lib.load().nimg_conv2d_wgrad_bf16_workspace_bytes(cin, cout, ks, ks, n, h, wd)
-    ws = _ws.get(need, x.device)
+    ws = (_ws_side if torch.cuda.current_stream(x.device) == _SIDE['stream'] else _ws).get(need, x.device)
     _lib.call('nimg_conv2d_wgrad_pooled_bf16', _p(x), cin, _p(g), _p(idx), cout, _p(dw), _p(db), n, h, wd, ks, 0, _p(ws),
               ws.numel(), _stream())
     return dw
@@ -456,12 +506,14 @@ def fan_head_bwd(act, gap, w, dlogits, loss_per, loss_scale, dw, db):
 
 
 def adam_step(params, grads, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0, skip_flag=None):
+    join_side_stream()
     _f32(params, grads, m, v)
     _lib.call('nimg_adam_step', _p(params), _p(grads), _p(m), _p(v), params.numel(), float(lr), float(beta1),
               float(beta2), float(eps), int(step), float(grad_scale), _p(skip_flag), _stream())
 
 
 def nan_flag(g, flag):
+    join_side_stream()
     _f32(g)
     _lib.call('nimg_nan_flag', _p(g), g.numel(), _p(flag), _stream())
 

@@ -45,6 +45,8 @@ class GradientBucket(object):
         self._work = []
 
     def launch(self, flat_grad):
+        from . import ops
+        ops.join_side_stream()               # parameter gradients may still be running on the side stream
         if is_distributed() and flat_grad.numel() > 0:
             self._work.append(dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, async_op=True))
 
