@@ -30,6 +30,12 @@ extern "C" {
 #define NIMG_ERR_LAUNCH (-2)  /* HIP launch failure (hipGetLastError) */
 #define NIMG_ERR_WORKSPACE (-3) /* workspace too small */
 
+/* tensor-storage flags of the *_ex throughput-mode entry points: the named tensor holds bf16 instead of float32 */
+#define NIMG_BF16_IN 1    /* in1 (convolutions: requires c2 == 0, c1 % 8 == 0) / dp (un-pool) */
+#define NIMG_BF16_OUT 2   /* out1 / pool_out / dz of the un-pool */
+#define NIMG_BF16_MASK 4  /* act_mask */
+#define NIMG_BF16_DZ 8    /* dz of a weight gradient (cout % 8 == 0) */
+
 /* library / ABI version, bumped on any signature change */
 int nimg_abi_version(void);
 
@@ -234,6 +240,20 @@ int nimg_conv2d_wgrad_pooled_bf16(const float* in, int cin, const float* g, cons
                                   size_t workspace_bytes, void* stream);
 int nimg_conv2d_dgrad_fewin_pooled_bf16(const float* g, const unsigned char* idx, const float* w, float* out, int ci,
                                         int cz, int n, int h, int wd, int ks, void* stream);
+/* bf16 STORAGE of the FAN-internal tensors in throughput mode.  Every consumer of the pooled activations, of the
+ * un-pooled gradients and of the pooled gradients converts them to bf16 MFMA operands anyway, so keeping them in bf16
+ * in HBM changes no result bit - it only halves the bytes the kernels stage.  Same arguments as the entry points
+ * without _ex, plus `flags` (NIMG_BF16_*) saying which tensors hold bf16. */
+int nimg_conv2d_fwd_bf16_ex(const float* in1, int c1, const float* in2, int c2, const void* wb, const float* bias,
+                            float* out1, int o1, float* out2, int o2, const float* act_mask, int n, int h, int wd,
+                            int ks, int stride, int pad_t, int pad_l, int pad_mode, int hout, int wout, int act,
+                            float alpha, int flags, void* stream);
+int nimg_conv2d_wgrad_bf16_ex(const float* in1, int c1, const float* in2, int c2, const float* dz, int cout, float* dw,
+                              float* db, int n, int h, int wd, int ks, int stride, int pad_t, int pad_l, int pad_mode,
+                              int hout, int wout, int accumulate, void* workspace, size_t workspace_bytes, int flags,
+                              void* stream);
+int nimg_maxpool2_unpool_ex(const float* dp, const unsigned char* idx, const float* pooled, float* dz, int n, int ho,
+                            int wo, int c, int apply_lrelu_mask, float alpha, int flags, void* stream);
 /* Conv2DTranspose(cout, [2,2], [2,2]) forward (pipelines.py:205) in throughput mode: four 1x1 products (one per output
  * phase) on the matrix core in one launch.  wb = nimg_conv_weights_bf16(w, 2, 2, cout, cin, mode 1) of the Keras
  * (2,2,Cout,Cin) kernel; x (n,h,wd,cin) -> y (n,2h,2wd,cout); cin % 8 == 0. */

@@ -63,9 +63,12 @@ struct ConvParamsB {
     int tiles_y, tiles_x, act, pad_mode;
     float alpha;
     int convt;            // 1: Conv2DTranspose(2x2, stride 2) as four 1x1 products; workgroup id & 3 = output phase (dy, dx)
+    int flags;            // NIMG_BF16_IN: in1 holds bf16 (C2 == 0); _OUT: out1 / pool_out are bf16; _MASK: act1 is bf16
 };
 
-template <int KS, int STRIDE, int TH, int TW, int NB, int TN>
+// INB: in1 is stored as bf16 (compile-time: a run-time branch around the prefetch loads makes the backend wait for them at
+// the join, which serialises the staging latency the async-stage split hides)
+template <int KS, int STRIDE, int TH, int TW, int NB, int TN, bool INB>
 __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p) {
     constexpr int CK = 16;
     constexpr int THH = (TH - 1) * STRIDE + KS, TWH = (TW - 1) * STRIDE + KS;
@@ -126,9 +129,13 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
             if (item < NPIXH * 2 && n < p.N && c < Cin && map_coord(gy, p.H, p.pad_mode) &&
                 map_coord(gx, p.W, p.pad_mode)) {
                 const long pixoff = ((long)n * p.H + gy) * p.W + gx;
-                const float* src = c < p.C1 ? p.in1 + pixoff * p.C1 + c : p.in2 + pixoff * p.C2 + (c - p.C1);
-                preA[q][0] = *reinterpret_cast<const float4*>(src);
-                preA[q][1] = *reinterpret_cast<const float4*>(src + 4);
+                if constexpr (INB) {                 // the tensor already holds bf16: 16 bytes = this item's 8 channels
+                    preA[q][0] = *reinterpret_cast<const float4*>(reinterpret_cast<const __bf16*>(p.in1) + pixoff * p.C1 + c);
+                } else {
+                    const float* src = c < p.C1 ? p.in1 + pixoff * p.C1 + c : p.in2 + pixoff * p.C2 + (c - p.C1);
+                    preA[q][0] = *reinterpret_cast<const float4*>(src);
+                    preA[q][1] = *reinterpret_cast<const float4*>(src + 4);
+                }
             }
         }
         // wave-uniform base of this K chunk (the transposed convolution reads tap slot 3 - phase of a 4-tap image)
@@ -151,10 +158,16 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
             const int item = tid + q * 256;
             if (item < NPIXH * 2) {
                 const int pix = item >> 1, h8 = item & 1;
-                const float f[8] = {preA[q][0].x, preA[q][0].y, preA[q][0].z, preA[q][0].w,
-                                    preA[q][1].x, preA[q][1].y, preA[q][1].z, preA[q][1].w};
-                const bf16x8 b = pack8(f);
-                sA[pix * 2 + (h8 ^ ((pix >> 3) & 1))] = *reinterpret_cast<const uint4*>(&b);
+                uint4 packed;
+                if constexpr (INB) {
+                    packed = *reinterpret_cast<const uint4*>(&preA[q][0]);
+                } else {
+                    const float f[8] = {preA[q][0].x, preA[q][0].y, preA[q][0].z, preA[q][0].w,
+                                        preA[q][1].x, preA[q][1].y, preA[q][1].z, preA[q][1].w};
+                    const bf16x8 b = pack8(f);
+                    packed = *reinterpret_cast<const uint4*>(&b);
+                }
+                sA[pix * 2 + (h8 ^ ((pix >> 3) & 1))] = packed;
             }
         }
 #pragma unroll
@@ -284,7 +297,7 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
     }
 }
 
-template <int KS, int STRIDE, int TH, int TW, int NB, int TN>
+template <int KS, int STRIDE, int TH, int TW, int NB, int TN, bool INB = false>
 int launch_conv_b(const ConvParamsB& p, hipStream_t stream) {
     constexpr int THH = (TH - 1) * STRIDE + KS, TWH = (TW - 1) * STRIDE + KS;
     constexpr size_t lds_tiles = (size_t)(NB * THH * TWH + KS * KS * TN) * 2 * sizeof(uint4);
@@ -294,32 +307,39 @@ int launch_conv_b(const ConvParamsB& p, hipStream_t stream) {
     q.tiles_y = cdiv(p.Hout, TH);
     q.tiles_x = cdiv(p.Wout, TW);
     const long blocks = (long)cdiv(p.O1 + p.O2, TN) * q.tiles_y * q.tiles_x * cdiv(p.N, NB) * (p.convt ? 4 : 1);
-    auto kern = conv_fwd_bf16_kernel<KS, STRIDE, TH, TW, NB, TN>;
+    auto kern = conv_fwd_bf16_kernel<KS, STRIDE, TH, TW, NB, TN, INB>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, q);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }
 
-template <int KS, int STRIDE>
-int dispatch_b(const ConvParamsB& p, hipStream_t s) {
+template <int KS, int STRIDE, bool INB>
+int dispatch_b_t(const ConvParamsB& p, hipStream_t s) {
     const int Cout = p.O1 + p.O2;
     const bool small = (p.Hout <= 8 && p.Wout <= 8);
     const long blocks64 = (long)cdiv(Cout, 64) * cdiv(p.Hout, small ? 8 : 16) * cdiv(p.Wout, small ? 8 : 16) *
                           cdiv(p.N, small ? 4 : 1);
     const bool tn32 = (Cout <= 32) || (blocks64 < 512 && Cout % 64 != 0) || (blocks64 < 384);
-    if (small) return tn32 ? launch_conv_b<KS, STRIDE, 8, 8, 4, 32>(p, s) : launch_conv_b<KS, STRIDE, 8, 8, 4, 64>(p, s);
-    // plenty of workgroups: 32x16-pixel tiles (4 M fragments per wave) halve the weight-tile traffic per MFMA
-    static const bool big_ok = getenv("NIMG_BIGTILE") != nullptr;   // measured slower (1 WG/CU): opt-in for A/B only
-    if (big_ok && !tn32 && STRIDE == 1 && blocks64 >= 4096 && p.Hout % 32 == 0)
-        return launch_conv_b<KS, STRIDE, 32, 16, 1, 64>(p, s);
+    if (small)
+        return tn32 ? launch_conv_b<KS, STRIDE, 8, 8, 4, 32, INB>(p, s) : launch_conv_b<KS, STRIDE, 8, 8, 4, 64, INB>(p, s);
     // narrow outputs (Cout <= 32) of big images: a 32x16-pixel tile keeps 64 accumulator registers per wave (4 x 1
     // fragments) and stages a third fewer bytes per pixel than 16x16
     if constexpr (STRIDE == 1 && KS == 5) {
         if (Cout <= 32 && !p.pool_out && p.Hout % 32 == 0 && (long)cdiv(p.Hout, 32) * cdiv(p.Wout, 16) * p.N >= 2048)
-            return launch_conv_b<KS, STRIDE, 32, 16, 1, 32>(p, s);
+            return launch_conv_b<KS, STRIDE, 32, 16, 1, 32, INB>(p, s);
     }
-    return tn32 ? launch_conv_b<KS, STRIDE, 16, 16, 1, 32>(p, s) : launch_conv_b<KS, STRIDE, 16, 16, 1, 64>(p, s);
+    return tn32 ? launch_conv_b<KS, STRIDE, 16, 16, 1, 32, INB>(p, s) : launch_conv_b<KS, STRIDE, 16, 16, 1, 64, INB>(p, s);
+}
+
+template <int KS, int STRIDE>
+int dispatch_b(const ConvParamsB& p, hipStream_t s) {
+    if constexpr (STRIDE == 1) {          // bf16-stored inputs exist for the stride-1 layers only (FAN)
+        if (p.flags & NIMG_BF16_IN) return dispatch_b_t<KS, STRIDE, true>(p, s);
+    } else {
+        if (p.flags & NIMG_BF16_IN) return NIMG_ERR_ARG;
+    }
+    return dispatch_b_t<KS, STRIDE, false>(p, s);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -334,6 +354,7 @@ struct WgradParamsB {
     int C1, C2, Cout;
     int N, H, W, Hout, Wout, pad_t, pad_l;
     int tiles_y, tiles_x, splits, work_per_split, pad_mode;
+    int flags;                     // NIMG_BF16_IN: in1 holds bf16 (C2 == 0); NIMG_BF16_DZ: dz holds bf16
 };
 
 constexpr int B_TH = 8, B_TW = 16, B_CI = 32, B_CO = 64;
@@ -361,7 +382,7 @@ constexpr int B_ZS = 192;      // dz tile row stride in bytes (64 co bf16 = 128 
 
 // NW waves share the taps: 4 for small kernels; 8 for 5x5, where 4 waves would each pin 7 taps x 32 = 224 accumulator
 // registers (one wave per SIMD, nothing to hide LDS / barrier latency behind) - with 8 it is 4 taps = 128, two per SIMD.
-template <int KS, int STRIDE, int NW>
+template <int KS, int STRIDE, int NW, bool INB, bool DZB>
 __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const WgradParamsB p) {
     constexpr int TAPS = KS * KS, NT = (TAPS + NW - 1) / NW, NTHR = NW * 64;
     constexpr int THH = (B_TH - 1) * STRIDE + KS, TWH = (B_TW - 1) * STRIDE + KS;
@@ -413,9 +434,13 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const Wgrad
             preI[q][0] = preI[q][1] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (item < NPIXH * 4 && c < Cin && map_coord(gy, p.H, p.pad_mode) && map_coord(gx, p.W, p.pad_mode)) {
                 const long pixoff = ((long)n_ * p.H + gy) * p.W + gx;
-                const float* src = c < p.C1 ? p.in1 + pixoff * p.C1 + c : p.in2 + pixoff * p.C2 + (c - p.C1);
-                preI[q][0] = *reinterpret_cast<const float4*>(src);
-                if (c + 4 < Cin) preI[q][1] = *reinterpret_cast<const float4*>(src + 4);
+                if constexpr (INB) {                 // Cin % 8 == 0 (entry point): the 8 channels are one 16-byte load
+                    preI[q][0] = *reinterpret_cast<const float4*>(reinterpret_cast<const __bf16*>(p.in1) + pixoff * p.C1 + c);
+                } else {
+                    const float* src = c < p.C1 ? p.in1 + pixoff * p.C1 + c : p.in2 + pixoff * p.C2 + (c - p.C1);
+                    preI[q][0] = *reinterpret_cast<const float4*>(src);
+                    if (c + 4 < Cin) preI[q][1] = *reinterpret_cast<const float4*>(src + 4);
+                }
             }
         }
 #pragma unroll
@@ -425,9 +450,13 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const Wgrad
             const int oy = ty_ + pix / B_TW, ox = tx_ + pix % B_TW;
             preZ[q][0] = preZ[q][1] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (oy < p.Hout && ox < p.Wout && c < p.Cout) {
-                const float* src = p.dz + (((long)n_ * p.Hout + oy) * p.Wout + ox) * p.Cout + c;
-                preZ[q][0] = *reinterpret_cast<const float4*>(src);
-                if (c + 4 < p.Cout) preZ[q][1] = *reinterpret_cast<const float4*>(src + 4);
+                const long zo = (((long)n_ * p.Hout + oy) * p.Wout + ox) * p.Cout + c;
+                if constexpr (DZB) {                 // Cout % 8 == 0 (entry point)
+                    preZ[q][0] = *reinterpret_cast<const float4*>(reinterpret_cast<const __bf16*>(p.dz) + zo);
+                } else {
+                    preZ[q][0] = *reinterpret_cast<const float4*>(p.dz + zo);
+                    if (c + 4 < p.Cout) preZ[q][1] = *reinterpret_cast<const float4*>(p.dz + zo + 4);
+                }
             }
         }
     };
@@ -438,22 +467,36 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const Wgrad
         for (int q = 0; q < IP; ++q) {
             const int item = tid + q * NTHR;
             if (item < NPIXH * 4) {
-                const float f[8] = {preI[q][0].x, preI[q][0].y, preI[q][0].z, preI[q][0].w,
-                                    preI[q][1].x, preI[q][1].y, preI[q][1].z, preI[q][1].w};
-                const bf16x8 b = pack8(f);
-                *reinterpret_cast<uint4*>(sI + (item >> 2) * 64 + (item & 3) * 16) = *reinterpret_cast<const uint4*>(&b);
+                uint4 packed;
+                if constexpr (INB) {
+                    packed = *reinterpret_cast<const uint4*>(&preI[q][0]);
+                } else {
+                    const float f[8] = {preI[q][0].x, preI[q][0].y, preI[q][0].z, preI[q][0].w,
+                                        preI[q][1].x, preI[q][1].y, preI[q][1].z, preI[q][1].w};
+                    const bf16x8 b = pack8(f);
+                    packed = *reinterpret_cast<const uint4*>(&b);
+                }
+                *reinterpret_cast<uint4*>(sI + (item >> 2) * 64 + (item & 3) * 16) = packed;
             }
         }
 #pragma unroll
         for (int q = 0; q < ZP; ++q) {
             const int item = tid + q * NTHR;
-            const float f[8] = {preZ[q][0].x, preZ[q][0].y, preZ[q][0].z, preZ[q][0].w,
-                                preZ[q][1].x, preZ[q][1].y, preZ[q][1].z, preZ[q][1].w};
+            float f[8];
+            bf16x8 b;
+            if constexpr (DZB) {
+                b = *reinterpret_cast<const bf16x8*>(&preZ[q][0]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = (float)b[e];
+            } else {
+                f[0] = preZ[q][0].x; f[1] = preZ[q][0].y; f[2] = preZ[q][0].z; f[3] = preZ[q][0].w;
+                f[4] = preZ[q][1].x; f[5] = preZ[q][1].y; f[6] = preZ[q][1].z; f[7] = preZ[q][1].w;
+                b = pack8(f);
+            }
             if (do_bias) {                      // fused bias gradient in float32: this thread always owns channels q*8..
 #pragma unroll
                 for (int e = 0; e < 8; ++e) bacc[e] += f[e];
             }
-            const bf16x8 b = pack8(f);
             *reinterpret_cast<uint4*>(sZ + (item >> 3) * B_ZS + (item & 7) * 16) = *reinterpret_cast<const uint4*>(&b);
         }
         __syncthreads();
@@ -534,10 +577,10 @@ int nimg_conv_weights_bf16(const float* w, void* wb, int ks_h, int ks_w, int cin
     return NIMG_OK;
 }
 
-int nimg_conv2d_fwd_bf16(const float* in1, int c1, const float* in2, int c2, const void* wb, const float* bias,
+static int conv2d_fwd_bf16_impl(const float* in1, int c1, const float* in2, int c2, const void* wb, const float* bias,
                          float* out1, int o1, float* out2, int o2, const float* act_mask, int n, int h, int wd,
                          int ks, int stride, int pad_t, int pad_l, int pad_mode, int hout, int wout, int act,
-                         float alpha, void* stream) {
+                         float alpha, int flags, void* stream) {
     if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!in1 || !wb || !out1 || c1 <= 0 || c2 < 0 || o1 <= 0 || o2 < 0 || n < 0 || h <= 0 || wd <= 0) return NIMG_ERR_ARG;
     if ((c2 > 0 && !in2) || (o2 > 0 && !out2) || hout <= 0 || wout <= 0 || pad_t < 0 || pad_l < 0) return NIMG_ERR_ARG;
@@ -546,7 +589,9 @@ int nimg_conv2d_fwd_bf16(const float* in1, int c1, const float* in2, int c2, con
     if (n == 0) return NIMG_OK;
     ConvParamsB p;
     p.in1 = in1; p.in2 = in2; p.wb = (const __bf16*)wb; p.bias = bias; p.out1 = out1; p.out2 = out2; p.act1 = act_mask;
-    p.pool_out = nullptr; p.pool_idx = nullptr; p.convt = 0;
+    p.pool_out = nullptr; p.pool_idx = nullptr; p.convt = 0; p.flags = flags;
+    if ((flags & NIMG_BF16_IN) && c2 != 0) return NIMG_ERR_ARG;
+    if ((flags & (NIMG_BF16_OUT | NIMG_BF16_MASK)) && (o2 != 0 || (o1 & 3))) return NIMG_ERR_ARG;
     p.C1 = c1; p.C2 = c2; p.O1 = o1; p.O2 = o2; p.CinP = (c1 + c2 + 15) / 16 * 16;
     p.N = n; p.H = h; p.W = wd; p.Hout = hout; p.Wout = wout; p.pad_t = pad_t; p.pad_l = pad_l;
     p.tiles_y = p.tiles_x = 0; p.act = act; p.pad_mode = pad_mode; p.alpha = alpha;
@@ -559,6 +604,22 @@ int nimg_conv2d_fwd_bf16(const float* in1, int c1, const float* in2, int c2, con
     return NIMG_ERR_ARG;
 }
 
+int nimg_conv2d_fwd_bf16(const float* in1, int c1, const float* in2, int c2, const void* wb, const float* bias,
+                         float* out1, int o1, float* out2, int o2, const float* act_mask, int n, int h, int wd,
+                         int ks, int stride, int pad_t, int pad_l, int pad_mode, int hout, int wout, int act,
+                         float alpha, void* stream) {
+    return conv2d_fwd_bf16_impl(in1, c1, in2, c2, wb, bias, out1, o1, out2, o2, act_mask, n, h, wd, ks, stride, pad_t, pad_l,
+                                pad_mode, hout, wout, act, alpha, 0, stream);
+}
+
+int nimg_conv2d_fwd_bf16_ex(const float* in1, int c1, const float* in2, int c2, const void* wb, const float* bias,
+                            float* out1, int o1, float* out2, int o2, const float* act_mask, int n, int h, int wd,
+                            int ks, int stride, int pad_t, int pad_l, int pad_mode, int hout, int wout, int act,
+                            float alpha, int flags, void* stream) {
+    return conv2d_fwd_bf16_impl(in1, c1, in2, c2, wb, bias, out1, o1, out2, o2, act_mask, n, h, wd, ks, stride, pad_t, pad_l,
+                                pad_mode, hout, wout, act, alpha, flags, stream);
+}
+
 /* Conv2DTranspose(cout, 2x2, stride 2) forward (pipelines.py:205) on the matrix core: four 1x1 products, one per output
  * phase (dy, dx), in a single launch.  wb = nimg_conv_weights_bf16(w, 2, 2, cin'=cout, cout'=cin, mode 1) of the Keras
  * kernel (2,2,Cout,Cin).  x (n,h,wd,cin) -> y (n,2h,2wd,cout). */
@@ -569,7 +630,7 @@ int nimg_convt2x2_fwd_bf16(const float* x, const void* wb, const float* bias, fl
     if (n == 0) return NIMG_OK;
     ConvParamsB p;
     p.in1 = x; p.in2 = nullptr; p.wb = (const __bf16*)wb; p.bias = bias; p.out1 = y; p.out2 = nullptr; p.act1 = nullptr;
-    p.pool_out = nullptr; p.pool_idx = nullptr; p.convt = 1;
+    p.pool_out = nullptr; p.pool_idx = nullptr; p.convt = 1; p.flags = 0;
     p.C1 = cin; p.C2 = 0; p.O1 = cout; p.O2 = 0; p.CinP = (cin + 15) / 16 * 16;
     p.N = n; p.H = h; p.W = wd; p.Hout = h; p.Wout = wd; p.pad_t = 0; p.pad_l = 0;
     p.tiles_y = p.tiles_x = 0; p.act = 0; p.pad_mode = 0; p.alpha = 0.f;
@@ -599,7 +660,10 @@ size_t nimg_conv2d_wgrad_bf16_workspace_bytes(int cin, int cout, int ks_h, int k
 static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, const float* dz,
                            const unsigned char* dz_idx, int cout, float* dw, float* db, int n, int h, int wd, int ks,
                            int stride, int pad_t, int pad_l, int pad_mode, int hout, int wout, int accumulate,
-                           void* workspace, size_t workspace_bytes, void* stream) {
+                           void* workspace, size_t workspace_bytes, int flags, void* stream) {
+    if ((flags & NIMG_BF16_IN) && (c2 != 0 || (c1 & 7))) return NIMG_ERR_ARG;
+    if ((flags & NIMG_BF16_DZ) && (cout & 7)) return NIMG_ERR_ARG;
+    if (flags && !dz_idx && c2 == 0 && c1 <= 4) return NIMG_ERR_ARG;        /* the packed / tiny kernels stage float32 */
     if (!in1 || !dz || !dw || c1 <= 0 || c2 < 0 || cout <= 0 || n <= 0 || h <= 0 || wd <= 0) return NIMG_ERR_ARG;
     if ((c2 > 0 && !in2) || hout <= 0 || wout <= 0 || !workspace || pad_mode < 0 || pad_mode > 2) return NIMG_ERR_ARG;
     const int cin = c1 + c2;
@@ -611,6 +675,7 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
     if (c2 == 0 && (c1 == 3 || c1 == 4) && stride == 1 && (ks == 3 || ks == 5)) {      // (tap, ci)-packed M dimension
         WgradParamsB q;
         q.in1 = in1; q.in2 = nullptr; q.dz = dz; q.dz_idx = dz_idx; q.partial = (float*)workspace; q.db_partial = nullptr;
+        q.flags = 0;
         q.C1 = c1; q.C2 = 0; q.Cout = cout; q.N = n; q.H = h; q.W = wd; q.Hout = hout; q.Wout = wout;
         q.pad_t = pad_t; q.pad_l = pad_l; q.pad_mode = pad_mode;
         q.tiles_y = cdiv(hout, B_TH); q.tiles_x = cdiv(wout, B_TW);
@@ -643,6 +708,7 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
     if ((c1 % 4) || (c2 % 4) || (cout % 4) || (c2 > 0 && (c1 % 8))) return NIMG_ERR_ARG;
     WgradParamsB p;
     p.in1 = in1; p.in2 = in2; p.dz = dz; p.dz_idx = nullptr; p.partial = (float*)workspace; p.db_partial = nullptr;
+    p.flags = flags;
     p.C1 = c1; p.C2 = c2; p.Cout = cout; p.N = n; p.H = h; p.W = wd; p.Hout = hout; p.Wout = wout;
     p.pad_t = pad_t; p.pad_l = pad_l; p.pad_mode = pad_mode;
     p.tiles_y = cdiv(hout, B_TH); p.tiles_x = cdiv(wout, B_TW);
@@ -658,9 +724,21 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
         constexpr int THH = (B_TH - 1) * ST_ + KS_, TWH = (B_TW - 1) * ST_ + KS_;                             \
         constexpr size_t lds = (size_t)THH * TWH * 64 + (size_t)B_TH * B_TW * B_ZS;                         \
         constexpr int NW = KS_ == 5 ? 8 : 4;                                                                  \
-        auto k = conv_wgrad_bf16_kernel<KS_, ST_, NW>;                                                        \
-        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
-        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NW * 64), lds, s, p);                              \
+        if (ST_ == 1 && (p.flags & NIMG_BF16_IN) && (p.flags & NIMG_BF16_DZ)) {                               \
+            auto k = conv_wgrad_bf16_kernel<KS_, ST_ == 1 ? ST_ : 1, NW, true, true>;                         \
+            (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+            hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NW * 64), lds, s, p);                          \
+        } else if (ST_ == 1 && (p.flags & NIMG_BF16_DZ)) {                                                    \
+            auto k = conv_wgrad_bf16_kernel<KS_, ST_ == 1 ? ST_ : 1, NW, false, true>;                        \
+            (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+            hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NW * 64), lds, s, p);                          \
+        } else if (p.flags) {                                                                                 \
+            return NIMG_ERR_ARG;                                                                              \
+        } else {                                                                                              \
+            auto k = conv_wgrad_bf16_kernel<KS_, ST_, NW, false, false>;                                      \
+            (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+            hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NW * 64), lds, s, p);                          \
+        }                                                                                                     \
     } while (0)
     if (stride == 1 && ks == 1) NIMG_WGB(1, 1);
     else if (stride == 1 && ks == 3) NIMG_WGB(3, 1);
@@ -680,7 +758,15 @@ int nimg_conv2d_wgrad_bf16(const float* in1, int c1, const float* in2, int c2, c
                            float* db, int n, int h, int wd, int ks, int stride, int pad_t, int pad_l, int pad_mode,
                            int hout, int wout, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
     return wgrad_bf16_impl(in1, c1, in2, c2, dz, nullptr, cout, dw, db, n, h, wd, ks, stride, pad_t, pad_l, pad_mode, hout,
-                           wout, accumulate, workspace, workspace_bytes, stream);
+                           wout, accumulate, workspace, workspace_bytes, 0, stream);
+}
+
+int nimg_conv2d_wgrad_bf16_ex(const float* in1, int c1, const float* in2, int c2, const float* dz, int cout, float* dw,
+                              float* db, int n, int h, int wd, int ks, int stride, int pad_t, int pad_l, int pad_mode,
+                              int hout, int wout, int accumulate, void* workspace, size_t workspace_bytes, int flags,
+                              void* stream) {
+    return wgrad_bf16_impl(in1, c1, in2, c2, dz, nullptr, cout, dw, db, n, h, wd, ks, stride, pad_t, pad_l, pad_mode, hout,
+                           wout, accumulate, workspace, workspace_bytes, flags, stream);
 }
 
 /* Weight (+bias) gradient of a fused conv+pool layer (nimg_conv2d_pool_fwd_bf16) with few input channels (cin 3|4):
@@ -691,7 +777,7 @@ int nimg_conv2d_wgrad_pooled_bf16(const float* in, int cin, const float* g, cons
                                   size_t workspace_bytes, void* stream) {
     if (!idx || (cin != 3 && cin != 4) || (ks != 3 && ks != 5) || (h & 1) || (wd & 1) || (cout & 3)) return NIMG_ERR_ARG;
     return wgrad_bf16_impl(in, cin, nullptr, 0, g, idx, cout, dw, db, n, h, wd, ks, 1, (ks - 1) / 2, (ks - 1) / 2, 0, h, wd,
-                           accumulate, workspace, workspace_bytes, stream);
+                           accumulate, workspace, workspace_bytes, 0, stream);
 }
 
 }  // extern "C"
@@ -1185,7 +1271,7 @@ int nimg_conv2d_pool_fwd_bf16(const float* in, int cin, const float* w, const vo
     if (!wb || (cin % 8)) return NIMG_ERR_ARG;
     ConvParamsB p;
     p.in1 = in; p.in2 = nullptr; p.wb = (const __bf16*)wb; p.bias = bias; p.out1 = nullptr; p.out2 = nullptr;
-    p.act1 = nullptr; p.pool_out = pool_out; p.pool_idx = pool_idx; p.convt = 0;
+    p.act1 = nullptr; p.pool_out = pool_out; p.pool_idx = pool_idx; p.convt = 0; p.flags = 0;
     p.C1 = cin; p.C2 = 0; p.O1 = cout; p.O2 = 0; p.CinP = (cin + 15) / 16 * 16;
     p.N = n; p.H = h; p.W = wd; p.Hout = h; p.Wout = wd; p.pad_t = p.pad_l = (ks - 1) / 2;
     p.tiles_y = p.tiles_x = 0; p.act = act; p.pad_mode = 0; p.alpha = alpha;

@@ -49,6 +49,9 @@ __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restri
 // was never stored, so the pre-activation gradient is rebuilt from the pooled tensor, its argmax byte and the
 // upstream gradient: dz[window position] = (position == argmax) ? dp * lrelu'(pooled) : 0.  (The sign of the window
 // maximum is the sign of the pooled value, which is all lrelu' needs.)
+typedef __bf16 nimg_bf16x4 __attribute__((ext_vector_type(4)));
+
+template <bool IN_BF16, bool OUT_BF16>
 __global__ void maxpool2_unpool_kernel(const float* __restrict__ dp, const unsigned char* __restrict__ idx,
                                        const float* __restrict__ pooled, float* __restrict__ dz, int n, int ho, int wo,
                                        int c, int apply_mask, float alpha) {
@@ -61,7 +64,13 @@ __global__ void maxpool2_unpool_kernel(const float* __restrict__ dp, const unsig
         r /= wo;
         const int oy = (int)(r % ho), im = (int)(r / ho);
         const long po = (((long)im * ho + oy) * wo + ox) * c + cc;
-        float4 g = *reinterpret_cast<const float4*>(dp + po);
+        float4 g;
+        if (IN_BF16) {
+            const nimg_bf16x4 gb = *reinterpret_cast<const nimg_bf16x4*>(reinterpret_cast<const __bf16*>(dp) + po);
+            g = make_float4((float)gb[0], (float)gb[1], (float)gb[2], (float)gb[3]);
+        } else {
+            g = *reinterpret_cast<const float4*>(dp + po);
+        }
         const uchar4 k = *reinterpret_cast<const uchar4*>(idx + po);
         if (apply_mask) {
             const float4 pv = *reinterpret_cast<const float4*>(pooled + po);
@@ -73,7 +82,14 @@ __global__ void maxpool2_unpool_kernel(const float* __restrict__ dp, const unsig
         for (int q = 0; q < 4; ++q) {
             const float4 o = make_float4(k.x == q ? g.x : 0.f, k.y == q ? g.y : 0.f, k.z == q ? g.z : 0.f,
                                          k.w == q ? g.w : 0.f);
-            *reinterpret_cast<float4*>(dz + base + (long)(q >> 1) * w * c + (long)(q & 1) * c) = o;
+            const long off = base + (long)(q >> 1) * w * c + (long)(q & 1) * c;
+            if (OUT_BF16) {
+                nimg_bf16x4 ob;
+                ob[0] = (__bf16)o.x; ob[1] = (__bf16)o.y; ob[2] = (__bf16)o.z; ob[3] = (__bf16)o.w;
+                *reinterpret_cast<nimg_bf16x4*>(reinterpret_cast<__bf16*>(dz) + off) = ob;
+            } else {
+                *reinterpret_cast<float4*>(dz + off) = o;
+            }
         }
     }
 }
@@ -509,8 +525,21 @@ int nimg_maxpool2_unpool(const float* dp, const unsigned char* idx, const float*
     if (!dp || !idx || !dz || n < 0 || ho <= 0 || wo <= 0 || c <= 0 || (c & 3)) return NIMG_ERR_ARG;
     if (apply_lrelu_mask && !pooled) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
-    hipLaunchKernelGGL(maxpool2_unpool_kernel, dim3(grid_for((long)n * ho * wo * (c / 4))), dim3(256), 0,
-                       (hipStream_t)stream, dp, idx, pooled, dz, n, ho, wo, c, apply_lrelu_mask, alpha);
+    return nimg_maxpool2_unpool_ex(dp, idx, pooled, dz, n, ho, wo, c, apply_lrelu_mask, alpha, 0, stream);
+}
+
+int nimg_maxpool2_unpool_ex(const float* dp, const unsigned char* idx, const float* pooled, float* dz, int n, int ho,
+                            int wo, int c, int apply_lrelu_mask, float alpha, int flags, void* stream) {
+    if (n == 0) return NIMG_OK;
+    if (!dp || !idx || !dz || n < 0 || ho <= 0 || wo <= 0 || c <= 0 || (c & 3)) return NIMG_ERR_ARG;
+    if (apply_lrelu_mask && !pooled) return NIMG_ERR_ARG;
+    const dim3 grid(grid_for((long)n * ho * wo * (c / 4)));
+    hipStream_t s = (hipStream_t)stream;
+#define NIMG_UNPOOL(A_, B_) hipLaunchKernelGGL((maxpool2_unpool_kernel<A_, B_>), grid, dim3(256), 0, s, dp, idx, pooled, dz, \
+                                               n, ho, wo, c, apply_lrelu_mask, alpha)
+    if (flags & NIMG_BF16_IN) { if (flags & NIMG_BF16_OUT) NIMG_UNPOOL(true, true); else NIMG_UNPOOL(true, false); }
+    else { if (flags & NIMG_BF16_OUT) NIMG_UNPOOL(false, true); else NIMG_UNPOOL(false, false); }
+#undef NIMG_UNPOOL
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }

@@ -174,7 +174,9 @@ class FAN(TFModel):
                 d_pool = ops.conv2d_dgrad_pooled(d_pool, t['idx{}'.format(i)], P.p[conv.name + '/kernel'])
                 continue
             if fused(i):
-                dz = ops.maxpool2_unpool(d_pool, t['idx{}'.format(i)], None, apply_mask=False)
+                # throughput mode: the un-pooled gradient only feeds bf16 MFMA kernels - store it as bf16 (same bits)
+                as_bf16 = ops.COMPUTE == 'bf16' and conv.cout % 8 == 0 and conv.cin % 8 == 0
+                dz = ops.maxpool2_unpool(d_pool, t['idx{}'.format(i)], None, apply_mask=False, out_bf16=as_bf16)
             else:
                 dz = ops.maxpool2_bwd(d_pool, t['conv{}'.format(i)], None, apply_mask=True)
             conv.backward_params(P, inp, dz)

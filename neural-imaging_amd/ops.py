@@ -59,6 +59,21 @@ def _f32(*ts):
     _chk(*ts)
 
 
+BF16_IN, BF16_OUT, BF16_MASK, BF16_DZ = 1, 2, 4, 8          # include/nimg.h NIMG_BF16_*
+
+
+def _fb(*ts):
+    """float32 or bfloat16 device tensors (bf16 STORAGE of FAN-internal tensors in throughput mode)."""
+    for t in ts:
+        if t is not None and t.dtype not in (torch.float32, torch.bfloat16):
+            raise RuntimeError('nimg ops need float32 / bfloat16 tensors, got {}'.format(t.dtype))
+    _chk(*ts)
+
+
+def _is_bf16(t):
+    return t is not None and t.dtype == torch.bfloat16
+
+
 def same_pads(size, k, s):
     """TF SAME padding: total = max((ceil(in/s)-1)*s + k - in, 0); before = total // 2 (rest after)."""
     out = -(-size // s)
@@ -167,7 +182,8 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
            act_mask=None, pads=None, out_hw=None, _wmode=0, _f32_only=False, mask_alpha=None):
     """x (N,H,W,C1) [+ x2 (N,H,W,C2)], w (k,k,C1+C2,Cout) HWIO.  padding 'SAME' (TF) | 'VALID' | explicit pads/out_hw.
     out/out2: optional pre-allocated outputs (out2 splits the output channels: Cout = out.C + out2.C)."""
-    _f32(x, w, bias, x2, out, out2, act_mask)
+    _f32(w, bias, x2, out, out2, act_mask)
+    _fb(x)
     n, h, wd, c1 = x.shape
     c2 = 0 if x2 is None else x2.shape[3]
     ks = w.shape[0]
@@ -210,10 +226,12 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
         return out
     if COMPUTE == 'bf16' and not _f32_only and c1 % 8 == 0 and c2 % 8 == 0 and cout >= 8:
         wb = weights_bf16(w, _wmode)
-        _lib.call('nimg_conv2d_fwd_bf16', _p(x), c1, _p(x2), c2, _p(wb), _p(bias), _p(out), o1, _p(out2), o2,
-                  _p(act_mask), n, h, wd, ks, stride, pt, pl, pad_mode, ho, wo, act_id,
-                  alpha, _stream())
+        flags = BF16_IN if _is_bf16(x) else 0
+        _lib.call('nimg_conv2d_fwd_bf16_ex', _p(x), c1, _p(x2), c2, _p(wb), _p(bias), _p(out), o1, _p(out2), o2,
+                  _p(act_mask), n, h, wd, ks, stride, pt, pl, pad_mode, ho, wo, act_id, alpha, flags, _stream())
         return out if out2 is None else (out, out2)
+    if _is_bf16(x):
+        raise RuntimeError('bf16-stored input reached a float32 convolution path')
     if _wmode == 1:
         w = flip_weights(w)
     _lib.call('nimg_conv2d_fwd', _p(x), c1, _p(x2), c2, _p(w), _p(bias), _p(out), o1, _p(out2), o2, _p(act_mask),
@@ -254,7 +272,8 @@ def conv2d_wgrad(x, dz, ks, x2=None, stride=1, padding='SAME', pad_mode=0, pads=
         with _on_side_stream(x, dz, x2):
             return conv2d_wgrad(x, dz, ks, x2=x2, stride=stride, padding=padding, pad_mode=pad_mode, pads=pads, dw=dw,
                                 accumulate=accumulate, db=db, side=False)
-    _f32(x, dz, x2, dw, db)
+    _f32(x2, dw, db)
+    _fb(x, dz)
     n, h, wd, c1 = x.shape
     c2 = 0 if x2 is None else x2.shape[3]
     _, ho, wo, cout = dz.shape
@@ -272,9 +291,12 @@ def conv2d_wgrad(x, dz, ks, x2=None, stride=1, padding='SAME', pad_mode=0, pads=
                                             (c2 == 0 or c1 % 8 == 0))):
         need = _lib.load().nimg_conv2d_wgrad_bf16_workspace_bytes(c1 + c2, cout, ks, ks, n, ho, wo)
         ws = (_ws_side if torch.cuda.current_stream(x.device) == _SIDE['stream'] else _ws).get(need, x.device)
-        _lib.call('nimg_conv2d_wgrad_bf16', _p(x), c1, _p(x2), c2, _p(dz), cout, _p(dw), _p(db), n, h, wd, ks, stride,
-                  pt, pl, pad_mode, ho, wo, 1 if accumulate else 0, _p(ws), ws.numel(), _stream())
+        flags = (BF16_IN if _is_bf16(x) else 0) | (BF16_DZ if _is_bf16(dz) else 0)
+        _lib.call('nimg_conv2d_wgrad_bf16_ex', _p(x), c1, _p(x2), c2, _p(dz), cout, _p(dw), _p(db), n, h, wd, ks, stride,
+                  pt, pl, pad_mode, ho, wo, 1 if accumulate else 0, _p(ws), ws.numel(), flags, _stream())
         return dw
+    if _is_bf16(x) or _is_bf16(dz):
+        raise RuntimeError('bf16-stored tensor reached a float32 weight-gradient path')
     need = _lib.load().nimg_conv2d_wgrad_workspace_bytes(c1 + c2, cout, ks, ks, n, ho, wo)
     ws = (_ws_side if torch.cuda.current_stream(x.device) == _SIDE['stream'] else _ws).get(need, x.device)
     _lib.call('nimg_conv2d_wgrad', _p(x), c1, _p(x2), c2, _p(dz), cout, _p(dw), _p(db), n, h, wd, ks, stride, pt, pl,
@@ -362,15 +384,19 @@ def conv2d_pool(x, w, bias=None, act='leaky_relu', want_idx=True):
     return pooled, idx
 
 
-def maxpool2_unpool(dp, idx, pooled, apply_mask=True, out=None):
-    """Backward of conv2d_pool's epilogue: the pre-activation gradient at full resolution."""
-    _f32(dp, pooled, out)
+def maxpool2_unpool(dp, idx, pooled, apply_mask=True, out=None, out_bf16=False):
+    """Backward of conv2d_pool's epilogue: the pre-activation gradient at full resolution (optionally stored as bf16:
+    its consumers - the bf16 weight / input gradient kernels - round it to bf16 anyway)."""
+    _f32(pooled)
+    _fb(dp, out)
     _chk(idx)
     n, ho, wo, c = dp.shape
-    dz = torch.empty((n, 2 * ho, 2 * wo, c), dtype=torch.float32, device=dp.device) if out is None else out
-    _lib.call('nimg_maxpool2_unpool', _p(dp), _p(idx), _p(pooled), _p(dz), n, ho, wo, c, 1 if apply_mask else 0,
-              LRELU_ALPHA, _stream())
-    return dz
+    if out is None:
+        out = torch.empty((n, 2 * ho, 2 * wo, c), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=dp.device)
+    flags = (BF16_IN if _is_bf16(dp) else 0) | (BF16_OUT if _is_bf16(out) else 0)
+    _lib.call('nimg_maxpool2_unpool_ex', _p(dp), _p(idx), _p(pooled), _p(out), n, ho, wo, c, 1 if apply_mask else 0,
+              LRELU_ALPHA, flags, _stream())
+    return out
 
 
 def pooled_backward_ok(cin, cout, ks):

@@ -537,6 +537,30 @@ def test_pooled_gradient_kernels_bf16(dev, bf16_mode):
     assert np.array_equal(dx.cpu().numpy(), dx_ref.cpu().numpy())
 
 
+def test_bf16_storage_is_bit_neutral(dev, bf16_mode):
+    """Storing the un-pooled gradient in bf16 (throughput mode) changes no bit of what its consumers compute: they round
+    their MFMA operands to bf16 anyway."""
+    from neural_imaging_amd import ops
+    n, h, w, cin, cout = 3, 32, 32, 32, 64
+    x, wt = g(rnd((n, h, w, cin), 1), dev), g(rnd((5, 5, cin, cout), 2, -0.2, 0.2), dev)
+    pooled, idx = ops.conv2d_pool(x, wt, g(rnd((cout,), 3), dev))
+    gp = g(rnd(tuple(pooled.shape), 4), dev)
+    dz32 = ops.maxpool2_unpool(gp, idx, None, apply_mask=False)
+    dz16 = ops.maxpool2_unpool(gp, idx, None, apply_mask=False, out_bf16=True)
+    assert dz16.dtype == torch.bfloat16 and torch.equal(dz16.float(), dz32.to(torch.bfloat16).float())
+    db32, db16 = torch.zeros(cout, device=dev), torch.zeros(cout, device=dev)
+    dw32 = ops.conv2d_wgrad(x, dz32, 5, db=db32)
+    dw16 = ops.conv2d_wgrad(x, dz16, 5, db=db16)
+    assert torch.equal(dw32, dw16)
+    dx32 = ops.conv2d_dgrad(dz32, wt, (h, w), act_mask=x)
+    dx16 = ops.conv2d_dgrad(dz16, wt, (h, w), act_mask=x)
+    assert torch.equal(dx32, dx16)
+    # the float32 bias sum sees the rounded values in the bf16 case: equal to rounding first
+    db_ref = torch.zeros(cout, device=dev)
+    ops.conv2d_wgrad(x, dz32.to(torch.bfloat16).float().contiguous(), 5, db=db_ref)
+    assert torch.allclose(db16, db_ref, rtol=0, atol=1e-4 * float(db_ref.abs().max()))
+
+
 BF16_CASES = [(2, 40, 72, 3, 0, 32, 5, 1), (2, 24, 24, 4, 0, 64, 3, 1), (2, 32, 32, 32, 0, 64, 5, 1), (2, 16, 16, 16, 16, 32, 3, 1), (5, 8, 8, 64, 0, 128, 3, 1),
               (2, 20, 24, 8, 0, 24, 3, 1), (3, 16, 16, 64, 0, 64, 1, 1), (2, 32, 32, 64, 0, 128, 5, 2)]
 
