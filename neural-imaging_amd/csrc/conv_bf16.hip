@@ -31,6 +31,17 @@ __device__ __forceinline__ bf16x8 pack8(const float (&f)[8]) {
     return r;
 }
 
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store4_bf16(float* base_as_bf16, long elem, float4 v) {
+    bf16x4 o;
+    o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(base_as_bf16) + elem) = o;
+}
+__device__ __forceinline__ float4 load4_bf16(const float* base_as_bf16, long elem) {
+    const bf16x4 o = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(base_as_bf16) + elem);
+    return make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+}
+
 // wb[chunk][tap'][co][16] (mode 0, forward) = w[tap][ci = 16*chunk + k][co];  mode 1 (input gradient): roles of ci/co
 // swap and the taps are flipped.  Chunk-major, so the weight tile a workgroup stages per 16-channel K chunk is one
 // contiguous 2 KiB run per tap (fully coalesced 16-byte loads).  Padding channels are zero.
@@ -225,7 +236,8 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
                         const int co = co0 + wn * NI * 32 + c, px = (tx0 >> 1) + pc;
                         if (co >= Cout || grp >= p.N || py >= Hp || px >= Wp) return;
                         const long o = (((long)grp * Hp + py) * Wp + px) * Cout + co;
-                        *reinterpret_cast<float4*>(p.pool_out + o) = v;
+                        if (p.flags & NIMG_BF16_OUT) store4_bf16(p.pool_out, o, v);
+                        else *reinterpret_cast<float4*>(p.pool_out + o) = v;
                         if (p.pool_idx) *reinterpret_cast<uchar4*>(p.pool_idx + o) = k;
                     });
             }
@@ -256,11 +268,13 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
                 }
                 if (co < p.O1) {
                     if (p.act1) {
-                        const float4 m = *reinterpret_cast<const float4*>(p.act1 + pixoff * p.O1 + co);
+                        const float4 m = (p.flags & NIMG_BF16_MASK) ? load4_bf16(p.act1, pixoff * p.O1 + co)
+                                                                    : *reinterpret_cast<const float4*>(p.act1 + pixoff * p.O1 + co);
                         v.x *= m.x > 0.f ? 1.0f : p.alpha; v.y *= m.y > 0.f ? 1.0f : p.alpha;
                         v.z *= m.z > 0.f ? 1.0f : p.alpha; v.w *= m.w > 0.f ? 1.0f : p.alpha;
                     }
-                    *reinterpret_cast<float4*>(p.out1 + pixoff * p.O1 + co) = v;
+                    if (p.flags & NIMG_BF16_OUT) store4_bf16(p.out1, pixoff * p.O1 + co, v);
+                    else *reinterpret_cast<float4*>(p.out1 + pixoff * p.O1 + co) = v;
                 } else {
                     *reinterpret_cast<float4*>(p.out2 + pixoff * p.O2 + (co - p.O1)) = v;
                 }
@@ -728,6 +742,10 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
             auto k = conv_wgrad_bf16_kernel<KS_, ST_ == 1 ? ST_ : 1, NW, true, true>;                         \
             (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
             hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NW * 64), lds, s, p);                          \
+        } else if (ST_ == 1 && (p.flags & NIMG_BF16_IN)) {                                                    \
+            auto k = conv_wgrad_bf16_kernel<KS_, ST_ == 1 ? ST_ : 1, NW, true, false>;                        \
+            (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+            hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NW * 64), lds, s, p);                          \
         } else if (ST_ == 1 && (p.flags & NIMG_BF16_DZ)) {                                                    \
             auto k = conv_wgrad_bf16_kernel<KS_, ST_ == 1 ? ST_ : 1, NW, false, true>;                        \
             (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
@@ -797,7 +815,8 @@ __global__ __launch_bounds__(256) void conv_fwd_packed_bf16_kernel(const float* 
                                                                    float* __restrict__ pool_out,
                                                                    unsigned char* __restrict__ pool_idx, int N, int H,
                                                                    int W, int Cout, int pad_mode, int act, float alpha,
-                                                                   int tiles_y, int tiles_x, int tiles_per_wg) {
+                                                                   int tiles_y, int tiles_x, int tiles_per_wg,
+                                                                   int out_bf16) {
     constexpr int TH = 16, TW = 16, THH = TH + KS - 1, TWH = TW + KS - 1, P = (KS - 1) / 2;
     constexpr int NPIXH = THH * TWH, PS = ((NPIXH + 31) / 32) * 32 + 2;
     constexpr int KTOT = KS * KS * CINP, KSTEPS = (KTOT + 15) / 16, KP = KSTEPS * 16;
@@ -918,7 +937,8 @@ __global__ __launch_bounds__(256) void conv_fwd_packed_bf16_kernel(const float* 
                         const int co = co0 + c, px = (tx0 >> 1) + pc;
                         if (co >= Cout || py >= Hp || px >= Wp) return;
                         const long o = (((long)n * Hp + py) * Wp + px) * Cout + co;
-                        *reinterpret_cast<float4*>(pool_out + o) = v;
+                        if (out_bf16) store4_bf16(pool_out, o, v);
+                        else *reinterpret_cast<float4*>(pool_out + o) = v;
                         if (pool_idx) *reinterpret_cast<uchar4*>(pool_idx + o) = k;
                     });
             }
@@ -1221,7 +1241,7 @@ extern "C" {
 /* FAN front end in throughput mode.  Few INPUT channels (cin 3|4, float32 HWIO weights, converted in-kernel). */
 static int launch_packed_bf16(const float* in, int cin, const float* w, const float* bias, float* out, float* pool_out,
                               unsigned char* pool_idx, int cout, int n, int h, int wd, int ks, int pad_mode, int act,
-                              float alpha, hipStream_t s) {
+                              float alpha, hipStream_t s, int out_bf16 = 0) {
     const int ty = cdiv(h, 16), tx = cdiv(wd, 16);
     const long total_tiles = (long)ty * tx * n;
     const int tpw = total_tiles >= 8192 ? 8 : (total_tiles >= 2048 ? 2 : 1);
@@ -1233,7 +1253,8 @@ static int launch_packed_bf16(const float* in, int cin, const float* w, const fl
                                (size_t)4 * 32 * (TN_ + EPI_PAD) * sizeof(float);                                  \
         const long blocks = cdiv(total_tiles, tpw) * (long)cdiv(cout, TN_);                                       \
         hipLaunchKernelGGL((conv_fwd_packed_bf16_kernel<KS_, C_, TN_>), dim3((unsigned)blocks), dim3(256), lds, s, \
-                           in, w, bias, out, pool_out, pool_idx, n, h, wd, cout, pad_mode, act, alpha, ty, tx, tpw); \
+                           in, w, bias, out, pool_out, pool_idx, n, h, wd, cout, pad_mode, act, alpha, ty, tx, tpw,    \
+                           out_bf16);                                                                             \
     } while (0)
     if (ks == 5 && cin == 3) { if (cout > 32) NIMG_FP(5, 3, 64); else NIMG_FP(5, 3, 32); }
     else if (ks == 5 && cin == 4) { if (cout > 32) NIMG_FP(5, 4, 64); else NIMG_FP(5, 4, 32); }
@@ -1259,6 +1280,12 @@ int nimg_conv2d_fwd_smallc_bf16(const float* in, int cin, const float* w, const 
 int nimg_conv2d_pool_fwd_bf16(const float* in, int cin, const float* w, const void* wb, const float* bias,
                               float* pool_out, unsigned char* pool_idx, int cout, int n, int h, int wd, int ks, int act,
                               float alpha, void* stream) {
+    return nimg_conv2d_pool_fwd_bf16_ex(in, cin, w, wb, bias, pool_out, pool_idx, cout, n, h, wd, ks, act, alpha, 0, stream);
+}
+
+int nimg_conv2d_pool_fwd_bf16_ex(const float* in, int cin, const float* w, const void* wb, const float* bias,
+                                 float* pool_out, unsigned char* pool_idx, int cout, int n, int h, int wd, int ks,
+                                 int act, float alpha, int flags, void* stream) {
     if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!in || !pool_out || cin <= 0 || cout <= 0 || (cout & 3) || n < 0 || h <= 0 || wd <= 0) return NIMG_ERR_ARG;
     if ((h & 1) || (wd & 1) || (ks != 3 && ks != 5) || act < 0 || act > 1) return NIMG_ERR_ARG;
@@ -1266,16 +1293,22 @@ int nimg_conv2d_pool_fwd_bf16(const float* in, int cin, const float* w, const vo
     hipStream_t s = (hipStream_t)stream;
     if (cin == 3 || cin == 4) {
         if (!w) return NIMG_ERR_ARG;
-        return launch_packed_bf16(in, cin, w, bias, nullptr, pool_out, pool_idx, cout, n, h, wd, ks, 0, act, alpha, s);
+        if (flags & NIMG_BF16_IN) return NIMG_ERR_ARG;
+        return launch_packed_bf16(in, cin, w, bias, nullptr, pool_out, pool_idx, cout, n, h, wd, ks, 0, act, alpha, s,
+                                  (flags & NIMG_BF16_OUT) ? 1 : 0);
     }
     if (!wb || (cin % 8)) return NIMG_ERR_ARG;
     ConvParamsB p;
     p.in1 = in; p.in2 = nullptr; p.wb = (const __bf16*)wb; p.bias = bias; p.out1 = nullptr; p.out2 = nullptr;
-    p.act1 = nullptr; p.pool_out = pool_out; p.pool_idx = pool_idx; p.convt = 0; p.flags = 0;
+    p.act1 = nullptr; p.pool_out = pool_out; p.pool_idx = pool_idx; p.convt = 0; p.flags = flags;
     p.C1 = cin; p.C2 = 0; p.O1 = cout; p.O2 = 0; p.CinP = (cin + 15) / 16 * 16;
     p.N = n; p.H = h; p.W = wd; p.Hout = h; p.Wout = wd; p.pad_t = p.pad_l = (ks - 1) / 2;
     p.tiles_y = p.tiles_x = 0; p.act = act; p.pad_mode = 0; p.alpha = alpha;
     const bool tn32 = cout <= 32 || (long)cdiv(cout, 64) * cdiv(h, 16) * cdiv(wd, 16) * n < 384;
+    if (flags & NIMG_BF16_IN) {
+        if (ks == 3) return tn32 ? launch_conv_b<3, 1, 16, 16, 1, 32, true>(p, s) : launch_conv_b<3, 1, 16, 16, 1, 64, true>(p, s);
+        return tn32 ? launch_conv_b<5, 1, 16, 16, 1, 32, true>(p, s) : launch_conv_b<5, 1, 16, 16, 1, 64, true>(p, s);
+    }
     if (ks == 3) return tn32 ? launch_conv_b<3, 1, 16, 16, 1, 32>(p, s) : launch_conv_b<3, 1, 16, 16, 1, 64>(p, s);
     return tn32 ? launch_conv_b<5, 1, 16, 16, 1, 32>(p, s) : launch_conv_b<5, 1, 16, 16, 1, 64>(p, s);
 }

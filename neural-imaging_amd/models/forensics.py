@@ -101,7 +101,11 @@ class FAN(TFModel):
         t['constrained'], t['nf'] = net, nf
         for i, c in enumerate(self._convs):
             if c.can_pool(net):          # conv + LeakyReLU + pool in one pass; the full-resolution tensor is not stored
-                net, idx = c.forward_pool(P, net, want_idx=training)
+                # throughput mode: pooled activations live in HBM as bf16 - every consumer (next convolution, its weight
+                # gradient, the LeakyReLU' sign test) rounds to bf16 / reads the sign anyway, so no result bit changes
+                nxt = self._convs[i + 1] if i + 1 < len(self._convs) else self._conv1x1
+                as_bf16 = ops.COMPUTE == 'bf16' and ops.STORE_BF16 and c.cout % 8 == 0 and nxt.cout >= 8
+                net, idx = c.forward_pool(P, net, want_idx=training, out_bf16=as_bf16)
                 t['idx{}'.format(i + 1)] = idx
             else:
                 a = c.forward(P, net)
@@ -175,7 +179,7 @@ class FAN(TFModel):
                 continue
             if fused(i):
                 # throughput mode: the un-pooled gradient only feeds bf16 MFMA kernels - store it as bf16 (same bits)
-                as_bf16 = ops.COMPUTE == 'bf16' and conv.cout % 8 == 0 and conv.cin % 8 == 0
+                as_bf16 = ops.COMPUTE == 'bf16' and ops.STORE_BF16 and conv.cout % 8 == 0 and conv.cin % 8 == 0
                 dz = ops.maxpool2_unpool(d_pool, t['idx{}'.format(i)], None, apply_mask=False, out_bf16=as_bf16)
             else:
                 dz = ops.maxpool2_bwd(d_pool, t['conv{}'.format(i)], None, apply_mask=True)

@@ -42,22 +42,22 @@ class Conv2D(object):
         return self.stride == 1 and self.cin2 == 0 and self.ks in (3, 5) and self.cout % 4 == 0 and \
             x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0
 
-    def forward_pool(self, store, x, want_idx=True):
+    def forward_pool(self, store, x, want_idx=True, out_bf16=False):
         """conv -> activation -> MaxPool2D(2) in one pass; returns (pooled, argmax bytes)."""
         return ops.conv2d_pool(x, store.p[self.name + '/kernel'], store.p[self.name + '/bias'], act=self.activation,
-                               want_idx=want_idx)
+                               want_idx=want_idx, out_bf16=out_bf16)
 
     def backward_params(self, store, x, dz, x2=None):
         # on the side stream: it only needs (x, dz), which the input gradient on the launch stream reads as well
         ops.conv2d_wgrad(x, dz, self.ks, x2=x2, stride=self.stride, dw=store.g[self.name + '/kernel'],
                          db=store.g[self.name + '/bias'], side=True)
 
-    def backward_input(self, store, dz, in_hw, act_mask=None, out=None, out2=None):
+    def backward_input(self, store, dz, in_hw, act_mask=None, out=None, out2=None, out_bf16=False):
         if self.stride == 2:
             d = ops.conv2d_dgrad_strided2(dz, store.p[self.name + '/kernel'], in_hw)
             return d if act_mask is None else ops.lrelu_bwd(d, act_mask, out=d)
         return ops.conv2d_dgrad(dz, store.p[self.name + '/kernel'], in_hw, stride=self.stride, act_mask=act_mask,
-                                out=out, out2=out2)
+                                out=out, out2=out2, out_bf16=out_bf16)
 
 
 class Conv2DTranspose2x2(object):

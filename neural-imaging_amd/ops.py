@@ -19,6 +19,11 @@ LRELU_ALPHA = 0.2          # tf.keras.layers.LeakyReLU(alpha=0.2), helpers/tf_he
 COMPUTE = 'f32'
 
 
+# Throughput mode keeps the FAN-internal tensors (pooled activations, un-pooled / pooled gradients) in HBM as bf16: their
+# consumers round to bf16 anyway, so results are bit-identical (test_fan_bf16_storage_is_bit_neutral); False = float32.
+STORE_BF16 = True
+
+
 def set_compute(mode):
     global COMPUTE
     if mode not in ('f32', 'bf16'):
@@ -179,11 +184,11 @@ def djpeg_bwd(x, gy, mask, qtab, rounding='soft', out=None):
 # ----------------------------------------------------------------------------------------------------------------
 # convolutions
 def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mode=0, out=None, out2=None,
-           act_mask=None, pads=None, out_hw=None, _wmode=0, _f32_only=False, mask_alpha=None):
+           act_mask=None, pads=None, out_hw=None, _wmode=0, _f32_only=False, mask_alpha=None, out_bf16=False):
     """x (N,H,W,C1) [+ x2 (N,H,W,C2)], w (k,k,C1+C2,Cout) HWIO.  padding 'SAME' (TF) | 'VALID' | explicit pads/out_hw.
     out/out2: optional pre-allocated outputs (out2 splits the output channels: Cout = out.C + out2.C)."""
-    _f32(w, bias, x2, out, out2, act_mask)
-    _fb(x)
+    _f32(w, bias, x2, out2)
+    _fb(x, out, act_mask)
     n, h, wd, c1 = x.shape
     c2 = 0 if x2 is None else x2.shape[3]
     ks = w.shape[0]
@@ -202,7 +207,7 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
     else:
         raise ValueError(padding)
     if out is None:
-        out = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
+        out = torch.empty((n, ho, wo, cout), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
     o1 = out.shape[3]
     o2 = 0 if out2 is None else out2.shape[3]
     if o1 + o2 != cout or tuple(out.shape[:3]) != (n, ho, wo):
@@ -226,12 +231,13 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
         return out
     if COMPUTE == 'bf16' and not _f32_only and c1 % 8 == 0 and c2 % 8 == 0 and cout >= 8:
         wb = weights_bf16(w, _wmode)
-        flags = BF16_IN if _is_bf16(x) else 0
+        flags = (BF16_IN if _is_bf16(x) else 0) | (BF16_OUT if _is_bf16(out) else 0) | \
+            (BF16_MASK if _is_bf16(act_mask) else 0)
         _lib.call('nimg_conv2d_fwd_bf16_ex', _p(x), c1, _p(x2), c2, _p(wb), _p(bias), _p(out), o1, _p(out2), o2,
                   _p(act_mask), n, h, wd, ks, stride, pt, pl, pad_mode, ho, wo, act_id, alpha, flags, _stream())
         return out if out2 is None else (out, out2)
-    if _is_bf16(x):
-        raise RuntimeError('bf16-stored input reached a float32 convolution path')
+    if _is_bf16(x) or _is_bf16(out) or _is_bf16(act_mask):
+        raise RuntimeError('bf16-stored tensor reached a float32 convolution path')
     if _wmode == 1:
         w = flip_weights(w)
     _lib.call('nimg_conv2d_fwd', _p(x), c1, _p(x2), c2, _p(w), _p(bias), _p(out), o1, _p(out2), o2, _p(act_mask),
@@ -248,7 +254,8 @@ def flip_weights(w, out=None):
     return wt
 
 
-def conv2d_dgrad(dz, w, in_hw, stride=1, padding='SAME', act_mask=None, out=None, out2=None, mask_alpha=None):
+def conv2d_dgrad(dz, w, in_hw, stride=1, padding='SAME', act_mask=None, out=None, out2=None, mask_alpha=None,
+                 out_bf16=False):
     """Input gradient of conv2d (stride 1, odd kernel): correlation of dz with the flipped kernel."""
     if stride != 1:
         raise NotImplementedError('strided dgrad is expressed by the caller (see models/compression.py)')
@@ -261,7 +268,7 @@ def conv2d_dgrad(dz, w, in_hw, stride=1, padding='SAME', act_mask=None, out=None
         pt = pl = 0
     # forward used pad (pt, pl); the gradient correlation needs ks-1-pt / ks-1-pl; the kernel is read flipped/transposed
     return conv2d(dz, w, None, pads=(ks - 1 - pt, ks - 1 - pl), out_hw=(h, wd), act_mask=act_mask, out=out,
-                  out2=out2, _wmode=1, mask_alpha=mask_alpha)
+                  out2=out2, _wmode=1, mask_alpha=mask_alpha, out_bf16=out_bf16)
 
 
 def conv2d_wgrad(x, dz, ks, x2=None, stride=1, padding='SAME', pad_mode=0, pads=None, dw=None, accumulate=False,
@@ -363,21 +370,27 @@ def maxpool2_bwd(dp, yact, add=None, apply_mask=True, out=None):
     return dz
 
 
-def conv2d_pool(x, w, bias=None, act='leaky_relu', want_idx=True):
+def conv2d_pool(x, w, bias=None, act='leaky_relu', want_idx=True, out_bf16=False):
     """Conv2D(SAME, stride 1) -> [LeakyReLU] -> MaxPool2D(2) in one pass (the FAN feature extractor): returns the pooled
-    activation and the arg-max bytes; the full-resolution activation is never written."""
-    _f32(x, w, bias)
+    activation and the arg-max bytes; the full-resolution activation is never written.  Throughput mode: x may be stored as
+    bf16 and the pooled activation can be (out_bf16) - its consumers round it to bf16 anyway."""
+    _f32(w, bias)
+    _fb(x)
     n, h, wd, cin = x.shape
     ks, cout = w.shape[0], w.shape[3]
     if w.shape[2] != cin or (h & 1) or (wd & 1) or (cout & 3) or ks not in (3, 5):
         raise ValueError('conv2d_pool: unsupported shape')
-    pooled = torch.empty((n, h // 2, wd // 2, cout), dtype=torch.float32, device=x.device)
+    bf16_path = COMPUTE == 'bf16' and (cin in (3, 4) or cin % 8 == 0)
+    if (out_bf16 or _is_bf16(x)) and not bf16_path:
+        raise RuntimeError('bf16 storage needs the throughput-mode convolution path')
+    pooled = torch.empty((n, h // 2, wd // 2, cout), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
     idx = torch.empty((n, h // 2, wd // 2, cout), dtype=torch.uint8, device=x.device) if want_idx else None
     a = 1 if act == 'leaky_relu' else 0
-    if COMPUTE == 'bf16' and (cin in (3, 4) or cin % 8 == 0):
+    if bf16_path:
         wb = None if cin in (3, 4) else weights_bf16(w, 0)
-        _lib.call('nimg_conv2d_pool_fwd_bf16', _p(x), cin, _p(w), _p(wb), _p(bias), _p(pooled), _p(idx), cout, n, h, wd,
-                  ks, a, LRELU_ALPHA, _stream())
+        flags = (BF16_IN if _is_bf16(x) else 0) | (BF16_OUT if out_bf16 else 0)
+        _lib.call('nimg_conv2d_pool_fwd_bf16_ex', _p(x), cin, _p(w), _p(wb), _p(bias), _p(pooled), _p(idx), cout, n, h, wd,
+                  ks, a, LRELU_ALPHA, flags, _stream())
     else:
         _lib.call('nimg_conv2d_pool_fwd', _p(x), cin, _p(w), _p(bias), _p(pooled), _p(idx), cout, n, h, wd, ks, a,
                   LRELU_ALPHA, _stream())

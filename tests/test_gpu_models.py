@@ -265,6 +265,35 @@ def test_dnet_forward_backward(dev, n_layers, nf):
     assert l1 < l0
 
 
+def test_fan_bf16_storage_is_bit_neutral(dev):
+    """Throughput mode: FAN-internal tensors stored as bf16 vs float32 - identical probabilities, loss, input gradient and
+    parameter gradients, bit for bit (the consumers of those tensors round to bf16 either way)."""
+    from neural_imaging_amd import ops
+    from neural_imaging_amd.models import forensics
+    x = torch.from_numpy(natural_images(6, 64, 64, seed=5)).to(dev)
+    labels = torch.from_numpy(np.array([0, 1, 2, 3, 4, 0], np.int32)).to(dev)
+    res = {}
+    ops.set_compute('bf16')
+    try:
+        for store in (True, False):
+            ops.STORE_BF16 = store
+            fan = forensics.FAN(n_classes=5, patch_size=64, device=dev)
+            probs, ctx = fan.forward(x, labels, training=True)
+            assert (ctx['pool2'].dtype == torch.bfloat16) == store
+            loss, dx = fan.backward(ctx, need_input_grad=True)
+            res[store] = (probs.cpu().numpy(), float(loss.item()), dx.cpu().numpy(), grads_of(fan))
+    finally:
+        ops.STORE_BF16 = True
+        ops.set_compute('f32')
+    a, b = res[True], res[False]
+    assert np.array_equal(a[0], b[0]) and a[1] == b[1] and np.array_equal(a[2], b[2])
+    for k in a[3]:
+        if k.endswith('/bias') and k.startswith('conv'):      # float32 column sums of the (rounded vs exact) gradient tile
+            assert np.allclose(a[3][k], b[3][k], rtol=0, atol=2e-3 * np.abs(b[3][k]).max()), k
+        else:
+            assert np.array_equal(a[3][k], b[3][k]), k
+
+
 def _sync_oracle(wf, ref):
     ref.nip = onets.OrderedDict((k, to64(v)) for k, v in wf.nip.state_dict().items())
     ref.fan = onets.OrderedDict((k, to64(v)) for k, v in wf.fan.state_dict().items())
