@@ -166,7 +166,13 @@ class FAN(TFModel):
         self._conv1x1.backward_params(P, pool, dz)
         # fused layers: the producer of d_pool applies LeakyReLU'(pooled) in its epilogue (sign(window max) = sign(pooled))
         fused = lambda i: i >= 1 and t.get('idx{}'.format(i)) is not None
-        d_pool = self._conv1x1.backward_input(P, dz, hw(pool), act_mask=pool if fused(nconv) else None)
+        pooled_path = lambda i: fused(i) and not fused(i - 1) and ops.pooled_backward_ok(
+            self._convs[i - 1].cin, self._convs[i - 1].cout, self._convs[i - 1].ks)
+        # a pooled gradient that is only un-pooled into a bf16 tensor can itself be stored as bf16 (throughput mode)
+        g_bf16 = lambda i: (ops.COMPUTE == 'bf16' and ops.STORE_BF16 and fused(i) and not pooled_path(i) and
+                            self._convs[i - 1].cout % 8 == 0 and self._convs[i - 1].cin % 8 == 0)
+        d_pool = self._conv1x1.backward_input(P, dz, hw(pool), act_mask=pool if fused(nconv) else None,
+                                              out_bf16=g_bf16(nconv))
         for i in range(nconv, 0, -1):
             conv = self._convs[i - 1]
             inp = t['pool{}'.format(i - 1)] if i > 1 else t['constrained']
@@ -184,7 +190,7 @@ class FAN(TFModel):
             else:
                 dz = ops.maxpool2_bwd(d_pool, t['conv{}'.format(i)], None, apply_mask=True)
             conv.backward_params(P, inp, dz)
-            d_pool = conv.backward_input(P, dz, hw(inp), act_mask=prev_mask)
+            d_pool = conv.backward_input(P, dz, hw(inp), act_mask=prev_mask, out_bf16=g_bf16(i - 1))
         self._constrained.backward_params(P, t['x'], d_pool)
         dx = self._constrained.backward_input(t['nf'], d_pool) if need_input_grad else None
         ops.join_side_stream()
