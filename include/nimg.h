@@ -255,6 +255,11 @@ int nimg_conv2d_wgrad_bf16_ex(const float* in1, int c1, const float* in2, int c2
 int nimg_conv2d_pool_fwd_bf16_ex(const float* in, int cin, const float* w, const void* wb, const float* bias,
                                  float* pool_out, unsigned char* pool_idx, int cout, int n, int h, int wd, int ks,
                                  int act, float alpha, int flags, void* stream);
+int nimg_conv2d_wgrad_pooled_bf16_ex(const float* in, int cin, const float* g, const unsigned char* idx, int cout,
+                                     float* dw, float* db, int n, int h, int wd, int ks, int accumulate, void* workspace,
+                                     size_t workspace_bytes, int flags, void* stream);     /* NIMG_BF16_DZ: g is bf16 */
+int nimg_conv2d_dgrad_fewin_pooled_bf16_ex(const float* g, const unsigned char* idx, const float* w, float* out, int ci,
+                                           int cz, int n, int h, int wd, int ks, int flags, void* stream);
 int nimg_maxpool2_unpool_ex(const float* dp, const unsigned char* idx, const float* pooled, float* dz, int n, int ho,
                             int wo, int c, int apply_lrelu_mask, float alpha, int flags, void* stream);
 /* Conv2DTranspose(cout, [2,2], [2,2]) forward (pipelines.py:205) in throughput mode: four 1x1 products (one per output

@@ -373,7 +373,7 @@ struct WgradParamsB {
 
 constexpr int B_TH = 8, B_TW = 16, B_CI = 32, B_CO = 64;
 
-template <int KS, int CINP, int NI>
+template <int KS, int CINP, int NI, int ZMODE>
 __global__ void conv_wgrad_packed_bf16_kernel(const WgradParamsB p);      // defined with the FAN front-end kernels below
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -678,6 +678,7 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
     if ((flags & NIMG_BF16_IN) && (c2 != 0 || (c1 & 7))) return NIMG_ERR_ARG;
     if ((flags & NIMG_BF16_DZ) && (cout & 7)) return NIMG_ERR_ARG;
     if (flags && !dz_idx && c2 == 0 && c1 <= 4) return NIMG_ERR_ARG;        /* the packed / tiny kernels stage float32 */
+    if (dz_idx && (flags & ~NIMG_BF16_DZ)) return NIMG_ERR_ARG;
     if (!in1 || !dz || !dw || c1 <= 0 || c2 < 0 || cout <= 0 || n <= 0 || h <= 0 || wd <= 0) return NIMG_ERR_ARG;
     if ((c2 > 0 && !in2) || hout <= 0 || wout <= 0 || !workspace || pad_mode < 0 || pad_mode > 2) return NIMG_ERR_ARG;
     const int cin = c1 + c2;
@@ -689,7 +690,7 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
     if (c2 == 0 && (c1 == 3 || c1 == 4) && stride == 1 && (ks == 3 || ks == 5)) {      // (tap, ci)-packed M dimension
         WgradParamsB q;
         q.in1 = in1; q.in2 = nullptr; q.dz = dz; q.dz_idx = dz_idx; q.partial = (float*)workspace; q.db_partial = nullptr;
-        q.flags = 0;
+        q.flags = flags;
         q.C1 = c1; q.C2 = 0; q.Cout = cout; q.N = n; q.H = h; q.W = wd; q.Hout = hout; q.Wout = wout;
         q.pad_t = pad_t; q.pad_l = pad_l; q.pad_mode = pad_mode;
         q.tiles_y = cdiv(hout, B_TH); q.tiles_x = cdiv(wout, B_TW);
@@ -705,8 +706,15 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
         do {                                                                                                  \
             constexpr size_t lds = (size_t)((B_TH + KS_ - 1) * (B_TW + KS_ - 1) * C_ + B_TH * B_TW * 32 * NI_) * \
                                    sizeof(float);                                                             \
-            hipLaunchKernelGGL((conv_wgrad_packed_bf16_kernel<KS_, C_, NI_>), dim3((unsigned)pblocks), dim3(256), \
-                               lds, s_, q);                                                                   \
+            if (!q.dz_idx)                                                                                    \
+                hipLaunchKernelGGL((conv_wgrad_packed_bf16_kernel<KS_, C_, NI_, 0>), dim3((unsigned)pblocks),     \
+                                   dim3(256), lds, s_, q);                                                    \
+            else if (q.flags & NIMG_BF16_DZ)                                                                  \
+                hipLaunchKernelGGL((conv_wgrad_packed_bf16_kernel<KS_, C_, NI_, 2>), dim3((unsigned)pblocks),     \
+                                   dim3(256), lds, s_, q);                                                    \
+            else                                                                                              \
+                hipLaunchKernelGGL((conv_wgrad_packed_bf16_kernel<KS_, C_, NI_, 1>), dim3((unsigned)pblocks),     \
+                                   dim3(256), lds, s_, q);                                                    \
         } while (0)
         if (ks == 5 && c1 == 3) { if (ni == 1) NIMG_WGPB(5, 3, 1); else NIMG_WGPB(5, 3, 2); }
         else if (ks == 5) { if (ni == 1) NIMG_WGPB(5, 4, 1); else NIMG_WGPB(5, 4, 2); }
@@ -793,9 +801,17 @@ int nimg_conv2d_wgrad_bf16_ex(const float* in1, int c1, const float* in2, int c2
 int nimg_conv2d_wgrad_pooled_bf16(const float* in, int cin, const float* g, const unsigned char* idx, int cout,
                                   float* dw, float* db, int n, int h, int wd, int ks, int accumulate, void* workspace,
                                   size_t workspace_bytes, void* stream) {
+    return nimg_conv2d_wgrad_pooled_bf16_ex(in, cin, g, idx, cout, dw, db, n, h, wd, ks, accumulate, workspace,
+                                            workspace_bytes, 0, stream);
+}
+
+/* flags: NIMG_BF16_DZ = the pooled gradient g is stored as bf16 */
+int nimg_conv2d_wgrad_pooled_bf16_ex(const float* in, int cin, const float* g, const unsigned char* idx, int cout,
+                                     float* dw, float* db, int n, int h, int wd, int ks, int accumulate, void* workspace,
+                                     size_t workspace_bytes, int flags, void* stream) {
     if (!idx || (cin != 3 && cin != 4) || (ks != 3 && ks != 5) || (h & 1) || (wd & 1) || (cout & 3)) return NIMG_ERR_ARG;
     return wgrad_bf16_impl(in, cin, nullptr, 0, g, idx, cout, dw, db, n, h, wd, ks, 1, (ks - 1) / 2, (ks - 1) / 2, 0, h, wd,
-                           accumulate, workspace, workspace_bytes, 0, stream);
+                           accumulate, workspace, workspace_bytes, flags & NIMG_BF16_DZ, stream);
 }
 
 }  // extern "C"
@@ -987,7 +1003,9 @@ __global__ __launch_bounds__(256) void conv_fwd_packed_bf16_kernel(const float* 
 }
 
 // ---- weight gradient, Cin <= 4: M = (tap, ci) packed, K = 16 pixels per MFMA, operands gathered from f32 tiles --------
-template <int KS, int CINP, int NI>
+// ZMODE 0: dz at full resolution (float32); 1: POOLED gradient (float32) + arg-max bytes, un-pooled while staging;
+// 2: the same with the pooled gradient stored as bf16.  Compile-time, so the prefetch loads sit in straight-line code.
+template <int KS, int CINP, int NI, int ZMODE>
 __global__ __launch_bounds__(256) void conv_wgrad_packed_bf16_kernel(const WgradParamsB p) {
     constexpr int TAPS = KS * KS, TPF = 32 / CINP, MF = (TAPS + TPF - 1) / TPF;
     constexpr int THH = B_TH + KS - 1, TWH = B_TW + KS - 1, NPIXH = THH * TWH, NPIX = B_TH * B_TW, COT = 32 * NI;
@@ -1041,11 +1059,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_packed_bf16_kernel(const Wgrad
                 const int pix = item / (COT / 4), c = co0 + (item % (COT / 4)) * 4;
                 const int oy = ty_ + pix / B_TW, ox = tx_ + pix % B_TW;
                 prez[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.dz_idx) {              // pooled gradient + arg-max: this pixel receives it iff it was the window maximum
+                if constexpr (ZMODE >= 1) {  // pooled gradient + arg-max: this pixel receives it iff it was the window maximum
                     prek[q] = 0xffffffffu;
                     if (oy < p.Hout && ox < p.Wout && c < p.Cout) {
                         const long po = (((long)n_ * (p.Hout >> 1) + (oy >> 1)) * (p.Wout >> 1) + (ox >> 1)) * p.Cout + c;
-                        prez[q] = *reinterpret_cast<const float4*>(p.dz + po);
+                        if constexpr (ZMODE == 2) {
+                            const uint2 raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const __bf16*>(p.dz) + po);
+                            prez[q].x = __uint_as_float(raw.x);          // 4 x bf16, expanded when the tile is committed
+                            prez[q].y = __uint_as_float(raw.y);
+                        } else {
+                            prez[q] = *reinterpret_cast<const float4*>(p.dz + po);
+                        }
                         prek[q] = *reinterpret_cast<const unsigned int*>(p.dz_idx + po);
                     }
                 } else if (oy < p.Hout && ox < p.Wout && c < p.Cout) {
@@ -1072,7 +1096,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_packed_bf16_kernel(const Wgrad
             for (int q = 0; q < ZPT; ++q) {
                 const int item = tid + q * 256;
                 float4 v = prez[q];
-                if (p.dz_idx) {
+                if constexpr (ZMODE == 2) {
+                    const unsigned lo = __float_as_uint(prez[q].x), hi = __float_as_uint(prez[q].y);
+                    v = make_float4(__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u),
+                                    __uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u));
+                }
+                if constexpr (ZMODE >= 1) {
                     const int pix = item / (COT / 4);
                     const unsigned pos = (unsigned)((((ty0 + pix / B_TW) & 1) << 1) | ((tx0 + pix % B_TW) & 1));
                     const unsigned k = prek[q];
@@ -1144,7 +1173,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_packed_bf16_kernel(const Wgrad
 template <int KS, int CI>
 __global__ __launch_bounds__(256) void conv_dgrad_fewin_bf16_kernel(const float* __restrict__ dz,
                                                                     const unsigned char* __restrict__ dz_idx,
-                                                                    const float* __restrict__ w,
+                                                                    int dz_bf16, const float* __restrict__ w,
                                                                     float* __restrict__ out, int N, int H, int W,
                                                                     int tiles_y, int tiles_x) {
     constexpr int CZ = 32, P = (KS - 1) / 2, TH = 8, TWO = 32 - (KS - 1);      // TWO output columns per tile
@@ -1180,9 +1209,15 @@ __global__ __launch_bounds__(256) void conv_dgrad_fewin_bf16_kernel(const float*
             // dz_idx given: dz is the pooled gradient of the fused conv+pool layer, un-pooled here through its arg-max bytes
             const long off = dz_idx ? (((long)n * (H >> 1) + (gy >> 1)) * (W >> 1) + (gx >> 1)) * CZ + q * 8
                                     : (((long)n * H + gy) * W + gx) * CZ + q * 8;
-            const float* src = dz + off;
-            const float4 v0_ = *reinterpret_cast<const float4*>(src), v1_ = *reinterpret_cast<const float4*>(src + 4);
-            f[0] = v0_.x; f[1] = v0_.y; f[2] = v0_.z; f[3] = v0_.w; f[4] = v1_.x; f[5] = v1_.y; f[6] = v1_.z; f[7] = v1_.w;
+            if (dz_bf16) {
+                const bf16x8 gb = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(dz) + off);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = (float)gb[e];
+            } else {
+                const float* src = dz + off;
+                const float4 v0_ = *reinterpret_cast<const float4*>(src), v1_ = *reinterpret_cast<const float4*>(src + 4);
+                f[0] = v0_.x; f[1] = v0_.y; f[2] = v0_.z; f[3] = v0_.w; f[4] = v1_.x; f[5] = v1_.y; f[6] = v1_.z; f[7] = v1_.w;
+            }
             if (dz_idx) {
                 const uint2 k = *reinterpret_cast<const uint2*>(dz_idx + off);
                 const unsigned pos = (unsigned)(((gy & 1) << 1) | (gx & 1));
@@ -1315,8 +1350,8 @@ int nimg_conv2d_pool_fwd_bf16_ex(const float* in, int cin, const float* w, const
 
 /* input gradient of a (ks,ks,ci,32) SAME stride-1 convolution towards its ci (= 3) input channels; w = the FORWARD
  * kernel as stored (not flipped) */
-static int dgrad_fewin_impl(const float* dz, const unsigned char* dz_idx, const float* w, float* out, int ci, int cz,
-                            int n, int h, int wd, int ks, void* stream) {
+static int dgrad_fewin_impl(const float* dz, const unsigned char* dz_idx, int dz_bf16, const float* w, float* out,
+                            int ci, int cz, int n, int h, int wd, int ks, void* stream) {
     if (!dz || !w || !out || n < 0 || h <= 0 || wd <= 0) return NIMG_ERR_ARG;
     if (cz != 32 || ci != 3 || ks != 5) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
@@ -1324,22 +1359,27 @@ static int dgrad_fewin_impl(const float* dz, const unsigned char* dz_idx, const 
     const int ty = cdiv(h, TH), tx = cdiv(wd, TWO);
     constexpr size_t lds = (size_t)(ROWS * 32 * 4 + KS * 32 * 4) * sizeof(uint4) + 4 * 32 * 16 * sizeof(float);
     hipLaunchKernelGGL((conv_dgrad_fewin_bf16_kernel<5, 3>), dim3((unsigned)((long)n * ty * tx)), dim3(256), lds,
-                       (hipStream_t)stream, dz, dz_idx, w, out, n, h, wd, ty, tx);
+                       (hipStream_t)stream, dz, dz_idx, dz_bf16, w, out, n, h, wd, ty, tx);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }
 
 int nimg_conv2d_dgrad_fewin_bf16(const float* dz, const float* w, float* out, int ci, int cz, int n, int h, int wd,
                                  int ks, void* stream) {
-    return dgrad_fewin_impl(dz, nullptr, w, out, ci, cz, n, h, wd, ks, stream);
+    return dgrad_fewin_impl(dz, nullptr, 0, w, out, ci, cz, n, h, wd, ks, stream);
 }
 
 /* the same input gradient with the output gradient given POOLED (g (n,h/2,wd/2,cz) + arg-max bytes), see
  * nimg_conv2d_wgrad_pooled_bf16 */
 int nimg_conv2d_dgrad_fewin_pooled_bf16(const float* g, const unsigned char* idx, const float* w, float* out, int ci,
                                         int cz, int n, int h, int wd, int ks, void* stream) {
+    return nimg_conv2d_dgrad_fewin_pooled_bf16_ex(g, idx, w, out, ci, cz, n, h, wd, ks, 0, stream);
+}
+
+int nimg_conv2d_dgrad_fewin_pooled_bf16_ex(const float* g, const unsigned char* idx, const float* w, float* out, int ci,
+                                           int cz, int n, int h, int wd, int ks, int flags, void* stream) {
     if (!idx || (h & 1) || (wd & 1)) return NIMG_ERR_ARG;
-    return dgrad_fewin_impl(g, idx, w, out, ci, cz, n, h, wd, ks, stream);
+    return dgrad_fewin_impl(g, idx, (flags & NIMG_BF16_DZ) ? 1 : 0, w, out, ci, cz, n, h, wd, ks, stream);
 }
 
 }  // extern "C"

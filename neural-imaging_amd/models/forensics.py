@@ -169,8 +169,8 @@ class FAN(TFModel):
         pooled_path = lambda i: fused(i) and not fused(i - 1) and ops.pooled_backward_ok(
             self._convs[i - 1].cin, self._convs[i - 1].cout, self._convs[i - 1].ks)
         # a pooled gradient that is only un-pooled into a bf16 tensor can itself be stored as bf16 (throughput mode)
-        g_bf16 = lambda i: (ops.COMPUTE == 'bf16' and ops.STORE_BF16 and fused(i) and not pooled_path(i) and
-                            self._convs[i - 1].cout % 8 == 0 and self._convs[i - 1].cin % 8 == 0)
+        g_bf16 = lambda i: (ops.COMPUTE == 'bf16' and ops.STORE_BF16 and fused(i) and self._convs[i - 1].cout % 8 == 0 and
+                            (pooled_path(i) or self._convs[i - 1].cin % 8 == 0))
         d_pool = self._conv1x1.backward_input(P, dz, hw(pool), act_mask=pool if fused(nconv) else None,
                                               out_bf16=g_bf16(nconv))
         for i in range(nconv, 0, -1):

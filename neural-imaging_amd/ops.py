@@ -423,7 +423,8 @@ def conv2d_wgrad_pooled(x, g, idx, ks, dw=None, db=None, side=False):
     if side and _SIDE['enabled'] and dw is not None:
         with _on_side_stream(x, g, idx):
             return conv2d_wgrad_pooled(x, g, idx, ks, dw=dw, db=db, side=False)
-    _f32(x, g, dw, db)
+    _f32(x, dw, db)
+    _fb(g)
     _chk(idx)
     n, h, wd, cin = x.shape
     cout = g.shape[3]
@@ -431,21 +432,22 @@ def conv2d_wgrad_pooled(x, g, idx, ks, dw=None, db=None, side=False):
         dw = torch.empty((ks, ks, cin, cout), dtype=torch.float32, device=x.device)
     need = _lib.load().nimg_conv2d_wgrad_bf16_workspace_bytes(cin, cout, ks, ks, n, h, wd)
     ws = (_ws_side if torch.cuda.current_stream(x.device) == _SIDE['stream'] else _ws).get(need, x.device)
-    _lib.call('nimg_conv2d_wgrad_pooled_bf16', _p(x), cin, _p(g), _p(idx), cout, _p(dw), _p(db), n, h, wd, ks, 0, _p(ws),
-              ws.numel(), _stream())
+    _lib.call('nimg_conv2d_wgrad_pooled_bf16_ex', _p(x), cin, _p(g), _p(idx), cout, _p(dw), _p(db), n, h, wd, ks, 0, _p(ws),
+              ws.numel(), BF16_DZ if _is_bf16(g) else 0, _stream())
     return dw
 
 
 def conv2d_dgrad_pooled(g, idx, w, out=None):
     """Input gradient of conv2d_pool (3 <- 32 channels, 5x5) from the pooled gradient and the arg-max bytes."""
-    _f32(g, w, out)
+    _f32(w, out)
+    _fb(g)
     _chk(idx)
     n, hp, wp, cz = g.shape
     ks, ci = w.shape[0], w.shape[2]
     if out is None:
         out = torch.empty((n, 2 * hp, 2 * wp, ci), dtype=torch.float32, device=g.device)
-    _lib.call('nimg_conv2d_dgrad_fewin_pooled_bf16', _p(g), _p(idx), _p(w), _p(out), ci, cz, n, 2 * hp, 2 * wp, ks,
-              _stream())
+    _lib.call('nimg_conv2d_dgrad_fewin_pooled_bf16_ex', _p(g), _p(idx), _p(w), _p(out), ci, cz, n, 2 * hp, 2 * wp, ks,
+              BF16_DZ if _is_bf16(g) else 0, _stream())
     return out
 
 

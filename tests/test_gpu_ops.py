@@ -535,6 +535,13 @@ def test_pooled_gradient_kernels_bf16(dev, bf16_mode):
     assert np.array_equal(dw.cpu().numpy(), dw_ref.cpu().numpy())
     assert np.array_equal(db.cpu().numpy(), db_ref.cpu().numpy())
     assert np.array_equal(dx.cpu().numpy(), dx_ref.cpu().numpy())
+    # the pooled gradient stored as bf16: same operands after rounding => same weight / input gradients
+    g16 = gp.to(torch.bfloat16)
+    db2 = torch.zeros(32, device=dev)
+    dw2 = ops.conv2d_wgrad_pooled(xd, g16, idx, 5, db=db2)
+    dx2 = ops.conv2d_dgrad_pooled(g16, idx, wd)
+    assert np.array_equal(dw2.cpu().numpy(), dw_ref.cpu().numpy())
+    assert np.array_equal(dx2.cpu().numpy(), dx_ref.cpu().numpy())
 
 
 def test_bf16_storage_is_bit_neutral(dev, bf16_mode):
