@@ -128,18 +128,27 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
     constexpr int AP = (NPIXH * 2 + 255) / 256, BP = (TAPS * TN * 2 + 255) / 256;
     float4 preA[AP][2];
     uint4 preB[BP];
+    // The halo-pixel -> image-pixel map (padding mode, tile clipping, image index) does not depend on the channel chunk:
+    // resolve it ONCE per workgroup.  Left inside fetch() it was ~700 instructions of branchy address arithmetic per
+    // chunk in front of every MFMA loop (in-order issue: as long as the 100 MFMAs themselves).
+    int apix[AP];
+#pragma unroll
+    for (int q = 0; q < AP; ++q) {
+        const int item = tid + q * 256;
+        const int pix = item >> 1;
+        const int img = pix / (THH * TWH), rem = pix % (THH * TWH);
+        int gy = iy0 + rem / TWH, gx = ix0 + rem % TWH;
+        const int n = grp * NB + img;
+        const bool ok = item < NPIXH * 2 && n < p.N && map_coord(gy, p.H, p.pad_mode) && map_coord(gx, p.W, p.pad_mode);
+        apix[q] = ok ? (n * p.H + gy) * p.W + gx : -1;
+    }
     auto fetch = [&](int c0) {
+        const int c = c0 + (tid & 1) * 8;               // item = tid + 256 q: the 8-channel half is the thread's parity
 #pragma unroll
         for (int q = 0; q < AP; ++q) {
-            const int item = tid + q * 256;
-            const int pix = item >> 1, h8 = item & 1, c = c0 + h8 * 8;
-            const int img = pix / (THH * TWH), rem = pix % (THH * TWH);
-            int gy = iy0 + rem / TWH, gx = ix0 + rem % TWH;
-            const int n = grp * NB + img;
             preA[q][0] = preA[q][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (item < NPIXH * 2 && n < p.N && c < Cin && map_coord(gy, p.H, p.pad_mode) &&
-                map_coord(gx, p.W, p.pad_mode)) {
-                const long pixoff = ((long)n * p.H + gy) * p.W + gx;
+            if (apix[q] >= 0 && c < Cin) {
+                const long pixoff = apix[q];
                 if constexpr (INB) {                 // the tensor already holds bf16: 16 bytes = this item's 8 channels
                     preA[q][0] = *reinterpret_cast<const float4*>(reinterpret_cast<const __bf16*>(p.in1) + pixoff * p.C1 + c);
                 } else {
