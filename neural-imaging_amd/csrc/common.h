@@ -31,11 +31,15 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // map a possibly out-of-range coordinate according to the padding mode; returns false if it is a zero-pad sample
 // mode 0 = zeros (CONSTANT), 1 = SYMMETRIC (edge sample repeated), 2 = REFLECT (edge sample not repeated)
 __device__ __forceinline__ bool map_coord(int& g, int size, int pad_mode) {
-    if (g >= 0 && g < size) return true;
-    if (pad_mode == 1) g = g < 0 ? -1 - g : 2 * size - 1 - g;
-    else if (pad_mode == 2) g = g < 0 ? -g : 2 * size - 2 - g;
-    else return false;
-    return g >= 0 && g < size;
+    // branch-free (selects only): this sits in the tile-staging address arithmetic of every convolution kernel, where
+    // a chain of data-dependent branches per coordinate costs more issue slots than the loads it guards
+    const bool inside = (unsigned)g < (unsigned)size;
+    const int sym = g < 0 ? -1 - g : 2 * size - 1 - g;
+    const int ref = g < 0 ? -g : 2 * size - 2 - g;
+    const int m = pad_mode == 1 ? sym : ref;
+    const bool mapped = pad_mode != 0 && (unsigned)m < (unsigned)size;
+    g = inside ? g : (mapped ? m : g);
+    return inside || mapped;
 }
 
 typedef float nimg_f32x16 __attribute__((ext_vector_type(16)));
