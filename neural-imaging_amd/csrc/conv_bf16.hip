@@ -433,9 +433,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const Wgrad
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[t][ni][j] = 0.0f;
     const int tiles = p.tiles_y * p.tiles_x;
-    const long work_total = (long)p.N * tiles;
-    const long w_begin = (long)split * p.work_per_split;
-    const long w_end = min(work_total, w_begin + p.work_per_split);
+    const int work_total = p.N * tiles;                 // < 2^31 (checked by the entry point)
+    const int w_begin = split * p.work_per_split;
+    const int w_end = min(work_total, w_begin + p.work_per_split);
     const bool do_bias = p.db_partial && ci0 == 0;
     float bacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // per-lane constant parts of the transpose-read addresses
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const Wgrad
     constexpr int IP = (NPIXH * 4 + NTHR - 1) / NTHR, ZP = (NPIX * 8) / NTHR;
     static_assert((NPIX * 8) % NTHR == 0, "dz tile must divide over the threads");
     float4 preI[IP][2], preZ[ZP][2];
-    auto fetch = [&](long wk_) {
+    auto fetch = [&](int wk_) {
         const int n_ = (int)(wk_ / tiles), tile_ = (int)(wk_ % tiles);
         const int ty_ = (tile_ / p.tiles_x) * B_TH, tx_ = (tile_ % p.tiles_x) * B_TW;
         const int iy_ = ty_ * STRIDE - p.pad_t, ix_ = tx_ * STRIDE - p.pad_l;
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const Wgrad
         }
     };
     if (w_begin < w_end) fetch(w_begin);
-    for (long wk = w_begin; wk < w_end; ++wk) {
+    for (int wk = w_begin; wk < w_end; ++wk) {
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < IP; ++q) {
@@ -1039,8 +1039,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_packed_bf16_kernel(const Wgrad
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[f][ni][j] = 0.0f;
     const int tiles = p.tiles_y * p.tiles_x;
-    const long work_total = (long)p.N * tiles;
-    const long w_begin = (long)split * p.work_per_split, w_end = min(work_total, w_begin + p.work_per_split);
+    const int work_total = p.N * tiles;                 // < 2^31 (checked by the entry point)
+    const int w_begin = split * p.work_per_split, w_end = min(work_total, w_begin + p.work_per_split);
     const bool do_bias = p.db_partial != nullptr;
     float bsum = 0.f;
     // register prefetch of the next tile (both operands) while the current one is multiplied
@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_packed_bf16_kernel(const Wgrad
     float4 prez[ZPT];
     unsigned int prek[ZPT];
     const bool vec_z = (p.Cout % 4 == 0);
-    auto fetch = [&](long wk_) {
+    auto fetch = [&](int wk_) {
         const int n_ = (int)(wk_ / tiles), tile_ = (int)(wk_ % tiles);
         const int ty_ = (tile_ / p.tiles_x) * B_TH, tx_ = (tile_ % p.tiles_x) * B_TW;
 #pragma unroll
@@ -1088,7 +1088,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_packed_bf16_kernel(const Wgrad
         }
     };
     if (w_begin < w_end) fetch(w_begin);
-    for (long wk = w_begin; wk < w_end; ++wk) {
+    for (int wk = w_begin; wk < w_end; ++wk) {
         const int n = (int)(wk / tiles), tile = (int)(wk % tiles);
         const int ty0 = (tile / p.tiles_x) * B_TH, tx0 = (tile % p.tiles_x) * B_TW;
         __syncthreads();

@@ -70,13 +70,13 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_kernel(const WgradParam
             for (int j = 0; j < 16; ++j) acc[t][ni][j] = 0.0f;
 
     const int tiles = p.tiles_y * p.tiles_x;
-    const long work_total = (long)p.N * tiles;
-    const long w_begin = (long)split * p.work_per_split;
-    const long w_end = min(work_total, w_begin + p.work_per_split);
+    const int work_total = p.N * tiles;                 // < 2^31 (checked by the entry point)
+    const int w_begin = split * p.work_per_split;
+    const int w_end = min(work_total, w_begin + p.work_per_split);
     const bool do_bias = p.db_partial && ci0 == 0;
     float bsum = 0.f;
 
-    for (long wk = w_begin; wk < w_end; ++wk) {
+    for (int wk = w_begin; wk < w_end; ++wk) {
         const int n = (int)(wk / tiles), tile = (int)(wk % tiles);
         const int ty0 = (tile / p.tiles_x) * WG_TH, tx0 = (tile % p.tiles_x) * WG_TW;
         const int iy0 = ty0 * STRIDE - p.pad_t, ix0 = tx0 * STRIDE - p.pad_l;
@@ -208,12 +208,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_packed_kernel(const WgradParam
             for (int j = 0; j < 16; ++j) acc[f][ni][j] = 0.0f;
 
     const int tiles = p.tiles_y * p.tiles_x;
-    const long work_total = (long)p.N * tiles;
-    const long w_begin = (long)split * p.work_per_split;
-    const long w_end = min(work_total, w_begin + p.work_per_split);
+    const int work_total = p.N * tiles;                 // < 2^31 (checked by the entry point)
+    const int w_begin = split * p.work_per_split;
+    const int w_end = min(work_total, w_begin + p.work_per_split);
     const bool do_bias = p.db_partial != nullptr;
     float bsum = 0.f;
-    for (long wk = w_begin; wk < w_end; ++wk) {
+    for (int wk = w_begin; wk < w_end; ++wk) {
         const int n = (int)(wk / tiles), tile = (int)(wk % tiles);
         const int ty0 = (tile / p.tiles_x) * WG_TH, tx0 = (tile % p.tiles_x) * WG_TW;
         __syncthreads();
