@@ -1179,10 +1179,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_packed_bf16_kernel(const Wgrad
 // is one 32 x 32 x (KS*CZ) GEMM per output row (32 positions x', KS*CI <= 32 columns, no padded channels), and
 // out[u][v][ci] = sum_kx T[u][v+P-kx][(kx,ci)] is a shift-add through a 2 KB LDS tile.  w is the forward kernel
 // (kh,kw,CI,CZ) as stored - its [ky][(kx,ci)][co] order is exactly the B operand.
-template <int KS, int CI>
+// ZMODE 0: dz at full resolution (float32); 1: POOLED gradient (float32) + arg-max bytes; 2: pooled gradient as bf16.
+template <int KS, int CI, int ZMODE>
 __global__ __launch_bounds__(256) void conv_dgrad_fewin_bf16_kernel(const float* __restrict__ dz,
                                                                     const unsigned char* __restrict__ dz_idx,
-                                                                    int dz_bf16, const float* __restrict__ w,
+                                                                    const float* __restrict__ w,
                                                                     float* __restrict__ out, int N, int H, int W,
                                                                     int tiles_y, int tiles_x) {
     constexpr int CZ = 32, P = (KS - 1) / 2, TH = 8, TWO = 32 - (KS - 1);      // TWO output columns per tile
@@ -1195,9 +1196,9 @@ __global__ __launch_bounds__(256) void conv_dgrad_fewin_bf16_kernel(const float*
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles = tiles_y * tiles_x;
-    const int n = blockIdx.x / tiles, tile = blockIdx.x % tiles;
-    const int u0 = (tile / tiles_x) * TH, v0 = (tile % tiles_x) * TWO;
-    // weights: row (ky, j) = w[(ky*NJ + j)*CZ + co], j < NJ; zero rows above
+    const int total_tiles = N * tiles;
+    // weights: row (ky, j) = w[(ky*NJ + j)*CZ + co], j < NJ; zero rows above.  Staged ONCE: the workgroup is persistent
+    // over tiles (one workgroup per tile re-staged these 10 KB - 160 scalar loads + converts per thread - 102 400 times)
     for (int item = tid; item < KS * 32 * 4; item += 256) {
         const int q = item & 3, row = item >> 2, j = row & 31, ky = row >> 5;
         float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1209,38 +1210,70 @@ __global__ __launch_bounds__(256) void conv_dgrad_fewin_bf16_kernel(const float*
         const bf16x8 b = pack8(f);
         sW[row * 4 + (q ^ ((row >> 2) & 3))] = *reinterpret_cast<const uint4*>(&b);
     }
-    // dz tile: rows u0-P .. u0+TH+P-1... (row index rr <-> image row u0 + rr - (KS-1-P)), columns v0-P+... 32 positions
-    for (int item = tid; item < ROWS * 32 * 4; item += 256) {
-        const int q = item & 3, pix = item >> 2, xx = pix & 31, rr = pix >> 5;
-        const int gy = u0 + rr - (KS - 1 - P), gx = v0 - (KS - 1 - P) + xx;
-        float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            // dz_idx given: dz is the pooled gradient of the fused conv+pool layer, un-pooled here through its arg-max bytes
-            const long off = dz_idx ? (((long)n * (H >> 1) + (gy >> 1)) * (W >> 1) + (gx >> 1)) * CZ + q * 8
-                                    : (((long)n * H + gy) * W + gx) * CZ + q * 8;
-            if (dz_bf16) {
-                const bf16x8 gb = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(dz) + off);
+    // the next tile travels HBM/L2 -> registers while the current one is multiplied
+    constexpr int NPC = (ROWS * 32 * 4 + 255) / 256;
+    uint4 pd0[NPC], pd1[NPC];
+    uint2 pk[NPC];
+    auto fetch = [&](int gt_) {
+        const int n_ = gt_ / tiles, tile_ = gt_ % tiles;
+        const int u_ = (tile_ / tiles_x) * TH, v_ = (tile_ % tiles_x) * TWO;
+#pragma unroll
+        for (int qq = 0; qq < NPC; ++qq) {
+            const int item = tid + qq * 256;
+            const int q = item & 3, pix = item >> 2, xx = pix & 31, rr = pix >> 5;
+            const int gy = u_ + rr - (KS - 1 - P), gx = v_ - (KS - 1 - P) + xx;
+            pd0[qq] = pd1[qq] = make_uint4(0u, 0u, 0u, 0u);
+            pk[qq] = make_uint2(0xffffffffu, 0xffffffffu);
+            if (item < ROWS * 32 * 4 && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                const long off = ZMODE >= 1 ? (((long)n_ * (H >> 1) + (gy >> 1)) * (W >> 1) + (gx >> 1)) * CZ + q * 8
+                                            : (((long)n_ * H + gy) * W + gx) * CZ + q * 8;
+                if constexpr (ZMODE == 2) {
+                    pd0[qq] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(dz) + off);
+                } else {
+                    pd0[qq] = *reinterpret_cast<const uint4*>(dz + off);
+                    pd1[qq] = *reinterpret_cast<const uint4*>(dz + off + 4);
+                }
+                if constexpr (ZMODE >= 1) pk[qq] = *reinterpret_cast<const uint2*>(dz_idx + off);
+            }
+        }
+    };
+    if ((int)blockIdx.x < total_tiles) fetch(blockIdx.x);
+    for (int gt = blockIdx.x; gt < total_tiles; gt += gridDim.x) {
+    const int n = gt / tiles, tile = gt % tiles;
+    const int u0 = (tile / tiles_x) * TH, v0 = (tile % tiles_x) * TWO;
+    __syncthreads();                                 // previous tile fully consumed (and the weights staged)
+    // dz tile: rows u0-P .. (row index rr <-> image row u0 + rr - (KS-1-P)), 32 column positions from v0-(KS-1-P)
+#pragma unroll
+    for (int qq = 0; qq < NPC; ++qq) {
+        const int item = tid + qq * 256;
+        if (item < ROWS * 32 * 4) {
+            const int q = item & 3, pix = item >> 2, xx = pix & 31, rr = pix >> 5;
+            float f[8];
+            if constexpr (ZMODE == 2) {
+                const bf16x8 gb = *reinterpret_cast<const bf16x8*>(&pd0[qq]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] = (float)gb[e];
             } else {
-                const float* src = dz + off;
-                const float4 v0_ = *reinterpret_cast<const float4*>(src), v1_ = *reinterpret_cast<const float4*>(src + 4);
-                f[0] = v0_.x; f[1] = v0_.y; f[2] = v0_.z; f[3] = v0_.w; f[4] = v1_.x; f[5] = v1_.y; f[6] = v1_.z; f[7] = v1_.w;
+                f[0] = __uint_as_float(pd0[qq].x); f[1] = __uint_as_float(pd0[qq].y);
+                f[2] = __uint_as_float(pd0[qq].z); f[3] = __uint_as_float(pd0[qq].w);
+                f[4] = __uint_as_float(pd1[qq].x); f[5] = __uint_as_float(pd1[qq].y);
+                f[6] = __uint_as_float(pd1[qq].z); f[7] = __uint_as_float(pd1[qq].w);
             }
-            if (dz_idx) {
-                const uint2 k = *reinterpret_cast<const uint2*>(dz_idx + off);
+            if constexpr (ZMODE >= 1) {              // un-pool: this pixel receives the gradient iff it was the window maximum
+                const int gy = u0 + rr - (KS - 1 - P), gx = v0 - (KS - 1 - P) + xx;
                 const unsigned pos = (unsigned)(((gy & 1) << 1) | (gx & 1));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    f[e] = ((k.x >> (8 * e)) & 0xffu) == pos ? f[e] : 0.f;
-                    f[4 + e] = ((k.y >> (8 * e)) & 0xffu) == pos ? f[4 + e] : 0.f;
+                    f[e] = ((pk[qq].x >> (8 * e)) & 0xffu) == pos ? f[e] : 0.f;
+                    f[4 + e] = ((pk[qq].y >> (8 * e)) & 0xffu) == pos ? f[4 + e] : 0.f;
                 }
             }
+            const bf16x8 b = pack8(f);
+            sD[pix * 4 + (q ^ ((pix >> 2) & 3))] = *reinterpret_cast<const uint4*>(&b);
         }
-        const bf16x8 b = pack8(f);
-        sD[pix * 4 + (q ^ ((pix >> 2) & 3))] = *reinterpret_cast<const uint4*>(&b);
     }
     __syncthreads();
+    if (gt + (int)gridDim.x < total_tiles) fetch(gt + gridDim.x);
     float* myT = sT + wave * 32 * 16;
     for (int ur = wave; ur < TH; ur += 4) {
         f32x16 acc;
@@ -1275,6 +1308,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_fewin_bf16_kernel(const float*
             if (u < H && v < W) out[(((long)n * H + u) * W + v) * CI + ci] = s;
         }
         __builtin_amdgcn_wave_barrier();
+    }
     }
 }
 
@@ -1367,8 +1401,19 @@ static int dgrad_fewin_impl(const float* dz, const unsigned char* dz_idx, int dz
     constexpr int KS = 5, TH = 8, TWO = 32 - (KS - 1), ROWS = TH + KS - 1;
     const int ty = cdiv(h, TH), tx = cdiv(wd, TWO);
     constexpr size_t lds = (size_t)(ROWS * 32 * 4 + KS * 32 * 4) * sizeof(uint4) + 4 * 32 * 16 * sizeof(float);
-    hipLaunchKernelGGL((conv_dgrad_fewin_bf16_kernel<5, 3>), dim3((unsigned)((long)n * ty * tx)), dim3(256), lds,
-                       (hipStream_t)stream, dz, dz_idx, dz_bf16, w, out, n, h, wd, ty, tx);
+    const long total = (long)n * ty * tx;
+    if (total >= (1L << 31)) return NIMG_ERR_ARG;
+    const unsigned grid = (unsigned)(total < 4096 ? total : 4096);       // persistent: ~16 workgroups per CU
+    hipStream_t s = (hipStream_t)stream;
+    if (!dz_idx)
+        hipLaunchKernelGGL((conv_dgrad_fewin_bf16_kernel<5, 3, 0>), dim3(grid), dim3(256), lds, s, dz, dz_idx, w, out, n, h, wd,
+                           ty, tx);
+    else if (dz_bf16)
+        hipLaunchKernelGGL((conv_dgrad_fewin_bf16_kernel<5, 3, 2>), dim3(grid), dim3(256), lds, s, dz, dz_idx, w, out, n, h, wd,
+                           ty, tx);
+    else
+        hipLaunchKernelGGL((conv_dgrad_fewin_bf16_kernel<5, 3, 1>), dim3(grid), dim3(256), lds, s, dz, dz_idx, w, out, n, h, wd,
+                           ty, tx);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }
