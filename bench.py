@@ -53,6 +53,9 @@ def time_dominant_kernel(dev, b_images, reps=20):
     from neural_imaging_amd import ops
     n = b_images
     x = torch.randn((n, 64, 64, 64), device=dev)
+    stored_bf16 = ops.COMPUTE == 'bf16' and ops.STORE_BF16
+    if stored_bf16:                   # the FAN's pooled activations live in HBM as bf16 in throughput mode
+        x = x.to(torch.bfloat16)
     w = torch.randn((5, 5, 64, 128), device=dev) * 0.05
     b = torch.zeros((128,), device=dev)
     out = torch.empty((n, 64, 64, 128), device=dev)
@@ -67,11 +70,12 @@ def time_dominant_kernel(dev, b_images, reps=20):
     ms = e0.elapsed_time(e1) / reps
     flops = 2.0 * 25 * 64 * 128 * 64 * 64 * n
     from neural_imaging_amd import ops as _o
-    kname = 'conv_fwd_kernel<5,1,16,16,1,64,8>' if _o.COMPUTE == 'f32' else 'conv_fwd_bf16_kernel<5,1,16,16,1,64>'
+    kname = 'conv_fwd_kernel<5,1,16,16,1,64,8>' if _o.COMPUTE == 'f32' else (
+        'conv_fwd_bf16_kernel<5,1,16,16,1,64,INB=true>' if stored_bf16 else 'conv_fwd_bf16_kernel<5,1,16,16,1,64>')
     traffic = None
     try:                                                   # measured once with rocprofv3 --pmc, see profiles/README.md
         with open(os.path.join(ROOT, 'profiles', 'r01_pmc_dominant_kernel.json')) as f:
-            pmc = json.load(f)[_o.COMPUTE]
+            pmc = json.load(f)['bf16_stored_input' if stored_bf16 else _o.COMPUTE]
         traffic = pmc['traffic_bytes_per_launch'] * n / pmc['images']
     except (OSError, KeyError, ValueError):
         pass

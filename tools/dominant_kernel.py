@@ -15,12 +15,15 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--dtype', default='f32')
 ap.add_argument('--images', type=int, default=320)
 ap.add_argument('--reps', type=int, default=3)
+ap.add_argument('--store-bf16', action='store_true', help='input stored as bf16 (the variant the FAN runs in throughput mode)')
 args = ap.parse_args()
 importlib.import_module('neural-imaging_amd')
 from neural_imaging_amd import ops
 ops.set_compute(args.dtype)
 dev = torch.device('cuda', 0)
 x = torch.randn((args.images, 64, 64, 64), device=dev)
+if args.store_bf16:
+    x = x.to(torch.bfloat16)
 w = torch.randn((5, 5, 64, 128), device=dev) * 0.05
 b = torch.zeros((128,), device=dev)
 out = torch.empty((args.images, 64, 64, 128), device=dev)
@@ -28,4 +31,4 @@ for _ in range(args.reps):
     ops.conv2d(x, w, b, act='leaky_relu', out=out)
 torch.cuda.synchronize()
 print('algorithmic bytes per launch: in {:.1f} MB + out {:.1f} MB + weights {:.2f} MB'.format(
-    x.numel() * 4 / 1e6, out.numel() * 4 / 1e6, w.numel() * 4 / 1e6))
+    x.numel() * x.element_size() / 1e6, out.numel() * 4 / 1e6, w.numel() * 4 / 1e6))
