@@ -405,11 +405,13 @@ constexpr int B_ZS = 192;      // dz tile row stride in bytes (64 co bf16 = 128 
 
 // NW waves share the taps: 4 for small kernels; 8 for 5x5, where 4 waves would each pin 7 taps x 32 = 224 accumulator
 // registers (one wave per SIMD, nothing to hide LDS / barrier latency behind) - with 8 it is 4 taps = 128, two per SIMD.
-template <int KS, int STRIDE, int NW, bool INB, bool DZB>
+// TH = output rows per staged tile (8, or 16 for 5x5: the per-tile staging overhead - ~500 instructions of address
+// arithmetic, converts and LDS writes - is then amortised over twice as many MFMAs)
+template <int KS, int STRIDE, int NW, bool INB, bool DZB, int TH>
 __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const WgradParamsB p) {
     constexpr int TAPS = KS * KS, NT = (TAPS + NW - 1) / NW, NTHR = NW * 64;
-    constexpr int THH = (B_TH - 1) * STRIDE + KS, TWH = (B_TW - 1) * STRIDE + KS;
-    constexpr int NPIXH = THH * TWH, NPIX = B_TH * B_TW;
+    constexpr int THH = (TH - 1) * STRIDE + KS, TWH = (B_TW - 1) * STRIDE + KS;
+    constexpr int NPIXH = THH * TWH, NPIX = TH * B_TW;
     static_assert(STRIDE == 1 || STRIDE == 2, "stride");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned char* sI = smem_raw;                   // [NPIXH][32 ci] bf16, 64 B per pixel
@@ -447,7 +449,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const Wgrad
     float4 preI[IP][2], preZ[ZP][2];
     auto fetch = [&](int wk_) {
         const int n_ = (int)(wk_ / tiles), tile_ = (int)(wk_ % tiles);
-        const int ty_ = (tile_ / p.tiles_x) * B_TH, tx_ = (tile_ % p.tiles_x) * B_TW;
+        const int ty_ = (tile_ / p.tiles_x) * TH, tx_ = (tile_ % p.tiles_x) * B_TW;
         const int iy_ = ty_ * STRIDE - p.pad_t, ix_ = tx_ * STRIDE - p.pad_l;
 #pragma unroll
         for (int q = 0; q < IP; ++q) {
@@ -525,7 +527,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const Wgrad
         __syncthreads();
         if (wk + 1 < w_end) fetch(wk + 1);
 #pragma unroll 1
-        for (int r = 0; r < B_TH; ++r) {
+        for (int r = 0; r < TH; ++r) {
             const unsigned char* zr = sZ + (r * B_TW) * B_ZS + z_lane;
             const bf16x8 b0 = tr_read8(zr, zr + 4 * B_ZS);
             const bf16x8 b1 = tr_read8(zr + 64, zr + 4 * B_ZS + 64);
@@ -571,9 +573,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const Wgrad
     }
 }
 
-int splits_for(int cin, int cout, int n, int hout, int wout) {
+int splits_for(int cin, int cout, int n, int hout, int wout, int th = B_TH) {
     const long blocks_io = (long)cdiv(cin, B_CI) * cdiv(cout, B_CO);
-    const long work = (long)n * cdiv(hout, B_TH) * cdiv(wout, B_TW);
+    const long work = (long)n * cdiv(hout, th) * cdiv(wout, B_TW);
     long splits = (512 + blocks_io - 1) / blocks_io;
     if (splits > work) splits = work;
     if (splits < 1) splits = 1;
@@ -742,38 +744,35 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
     p.flags = flags;
     p.C1 = c1; p.C2 = c2; p.Cout = cout; p.N = n; p.H = h; p.W = wd; p.Hout = hout; p.Wout = wout;
     p.pad_t = pad_t; p.pad_l = pad_l; p.pad_mode = pad_mode;
-    p.tiles_y = cdiv(hout, B_TH); p.tiles_x = cdiv(wout, B_TW);
-    p.splits = splits_for(cin, cout, n, hout, wout);
+    const int th = (stride == 1 && ks == 5) ? 16 : B_TH;
+    p.tiles_y = cdiv(hout, th); p.tiles_x = cdiv(wout, B_TW);
+    p.splits = splits_for(cin, cout, n, hout, wout, th);       // <= splits_for(.., B_TH): the workspace bound holds
     const long work = (long)n * p.tiles_y * p.tiles_x;
     p.work_per_split = (int)((work + p.splits - 1) / p.splits);
     const long count = (long)ks * ks * cin * cout;
     if (db) p.db_partial = p.partial + (size_t)p.splits * count;
     const long blocks = (long)cdiv(cin, B_CI) * cdiv(cout, B_CO) * p.splits;
     hipStream_t s = (hipStream_t)stream;
+#define NIMG_WGB1(KS_, ST_, NW_, INB_, DZB_, TH_)                                                               \
+    do {                                                                                                      \
+        constexpr int THH = (TH_ - 1) * ST_ + KS_, TWH = (B_TW - 1) * ST_ + KS_;                              \
+        constexpr size_t lds_t = (size_t)THH * TWH * 64 + (size_t)TH_ * B_TW * B_ZS;                          \
+        constexpr size_t lds = lds_t > (size_t)NW_ * 64 * 8 * 4 ? lds_t : (size_t)NW_ * 64 * 8 * 4;          \
+        auto k = conv_wgrad_bf16_kernel<KS_, ST_, NW_, INB_, DZB_, TH_>;                                      \
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NW_ * 64), lds, s, p);                             \
+    } while (0)
 #define NIMG_WGB(KS_, ST_)                                                                                     \
     do {                                                                                                      \
-        constexpr int THH = (B_TH - 1) * ST_ + KS_, TWH = (B_TW - 1) * ST_ + KS_;                             \
-        constexpr size_t lds = (size_t)THH * TWH * 64 + (size_t)B_TH * B_TW * B_ZS;                         \
         constexpr int NW = KS_ == 5 ? 8 : 4;                                                                  \
-        if (ST_ == 1 && (p.flags & NIMG_BF16_IN) && (p.flags & NIMG_BF16_DZ)) {                               \
-            auto k = conv_wgrad_bf16_kernel<KS_, ST_ == 1 ? ST_ : 1, NW, true, true>;                         \
-            (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-            hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NW * 64), lds, s, p);                          \
-        } else if (ST_ == 1 && (p.flags & NIMG_BF16_IN)) {                                                    \
-            auto k = conv_wgrad_bf16_kernel<KS_, ST_ == 1 ? ST_ : 1, NW, true, false>;                        \
-            (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-            hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NW * 64), lds, s, p);                          \
-        } else if (ST_ == 1 && (p.flags & NIMG_BF16_DZ)) {                                                    \
-            auto k = conv_wgrad_bf16_kernel<KS_, ST_ == 1 ? ST_ : 1, NW, false, true>;                        \
-            (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-            hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NW * 64), lds, s, p);                          \
-        } else if (p.flags) {                                                                                 \
-            return NIMG_ERR_ARG;                                                                              \
-        } else {                                                                                              \
-            auto k = conv_wgrad_bf16_kernel<KS_, ST_, NW, false, false>;                                      \
-            (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-            hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NW * 64), lds, s, p);                          \
-        }                                                                                                     \
+        constexpr int TH_ = (KS_ == 5 && ST_ == 1) ? 16 : B_TH;                                               \
+        constexpr int S1 = ST_ == 1 ? ST_ : 1;              /* bf16-stored operands exist for stride 1 only */    \
+        constexpr int T1 = ST_ == 1 ? TH_ : B_TH;                                                             \
+        if (ST_ == 1 && (p.flags & NIMG_BF16_IN) && (p.flags & NIMG_BF16_DZ)) NIMG_WGB1(KS_, S1, NW, true, true, T1);    \
+        else if (ST_ == 1 && (p.flags & NIMG_BF16_IN)) NIMG_WGB1(KS_, S1, NW, true, false, T1);               \
+        else if (ST_ == 1 && (p.flags & NIMG_BF16_DZ)) NIMG_WGB1(KS_, S1, NW, false, true, T1);               \
+        else if (p.flags) return NIMG_ERR_ARG;                                                                \
+        else NIMG_WGB1(KS_, ST_, NW, false, false, TH_);                                                      \
     } while (0)
     if (stride == 1 && ks == 1) NIMG_WGB(1, 1);
     else if (stride == 1 && ks == 3) NIMG_WGB(3, 1);
@@ -782,6 +781,7 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
     else if (stride == 2 && ks == 5) NIMG_WGB(5, 2);
     else return NIMG_ERR_ARG;
 #undef NIMG_WGB
+#undef NIMG_WGB1
     NIMG_CHECK_LAUNCH();
     launch_reduce2((const float*)workspace, dw, count, p.splits, db ? (const float*)p.db_partial : nullptr, db, (long)cout,
                    p.splits, accumulate, s);
