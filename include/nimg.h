@@ -267,6 +267,9 @@ int nimg_maxpool2_unpool_ex(const float* dp, const unsigned char* idx, const flo
  * (2,2,Cout,Cin) kernel; x (n,h,wd,cin) -> y (n,2h,2wd,cout); cin % 8 == 0. */
 int nimg_convt2x2_fwd_bf16(const float* x, const void* wb, const float* bias, float* y, int n, int h, int wd, int cin,
                            int cout, void* stream);
+/* every bf16 weight image of a model in one launch: `table` = n_entries x 4 int64 on the device,
+ * {w pointer, wb pointer, (kh*kw << 32) | mode, (cin << 32) | cout}, each entry as nimg_conv_weights_bf16 would build it */
+int nimg_conv_weights_bf16_batch(const void* table, int n_entries, void* stream);
 int nimg_conv2d_fwd_bf16(const float* in1, int c1, const float* in2, int c2, const void* wb, const float* bias,
                          float* out1, int o1, float* out2, int o2, const float* act_mask, int n, int h, int wd,
                          int ks, int stride, int pad_t, int pad_l, int pad_mode, int hout, int wout, int act,

@@ -89,6 +89,7 @@ PROTOTYPES = {
                                                  c_size_t, c_int, P]),
     'nimg_conv2d_dgrad_fewin_pooled_bf16_ex': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'nimg_maxpool2_unpool_ex': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),
+    'nimg_conv_weights_bf16_batch': (c_int, [P, c_int, P]),
     'nimg_convt2x2_fwd_bf16': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'nimg_conv2d_fwd_smallc_bf16': (c_int, [P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                             c_float, P]),

@@ -195,6 +195,7 @@ class TwitterDCN(DCN):
     # ------------------------------------------------------------------------------------------------------------
     def encode(self, x, training=False):
         L, P = self._layers, self._model
+        P.refresh_images()
         t = OrderedDict()
         t['x0'] = ops.affine(x, 2.0, -1.0)
         t['e1'] = L['e1'].forward(P, t['x0'])
@@ -225,6 +226,7 @@ class TwitterDCN(DCN):
 
     def decode(self, lat, training=False):
         L, P = self._layers, self._model
+        P.refresh_images()
         t = OrderedDict()
         t['latent'] = lat
         t['d512'] = L['d512'].forward(P, lat)

@@ -94,6 +94,7 @@ class FAN(TFModel):
     # ------------------------------------------------------------------------------------------------------------
     def forward(self, x, labels=None, training=False, loss_scale=None):
         """x (N,H,W,3) device tensor. labels: int32 device tensor or None. Returns (probs, ctx)."""
+        self._model.refresh_images()
         P = self._model
         t = OrderedDict()
         t['x'] = x

@@ -138,6 +138,7 @@ class UNet(NIPModel):
         return '{}_{}'.format(self.class_name, self._h.n_steps)
 
     def forward(self, x, training=False):
+        self._model.refresh_images()
         L, P, ns = self._layers, self._model, self._h.n_steps
         t = OrderedDict()
         t['ep0'] = x
@@ -241,6 +242,7 @@ class INet(NIPModel):
                                                  r='R' if self._h.random_init else '')
 
     def forward(self, x, training=False):
+        self._model.refresh_images()
         P = self._model.p
         t = OrderedDict()
         h12 = ops.conv2d(x, P['up/kernel'])
@@ -313,6 +315,7 @@ class DNet(NIPModel):
                                              l=self._h.n_layers)
 
     def forward(self, x, training=False):
+        self._model.refresh_images()
         P = self._model.p
         pad = (self._h.kernel - 1) // 2
         t = OrderedDict()

@@ -41,6 +41,14 @@ class ParamStore(object):
             off += -(-n // align) * align
         self.m = self.v = None
         self.step = 0
+        # bf16 images of every 4-D (convolution) kernel, rebuilt by one launch per step in throughput mode
+        self.images = ops.WeightImages([t for t in self.p.values() if t.dim() == 4 and min(t.shape) > 0], device) \
+            if torch.device(device).type == 'cuda' else None
+
+    def refresh_images(self):
+        """Call at the top of a forward pass: the kernels of this step read the images built here."""
+        if self.images is not None:
+            self.images.refresh()
 
     def ensure_adam(self):
         if self.m is None:

@@ -31,8 +31,56 @@ def set_compute(mode):
     COMPUTE = mode
 
 
+_WB_REGISTRY = {}        # data_ptr of a registered 4-D weight -> {'shape': ..., 0: image, 1: image} (see WeightImages)
+
+
+class WeightImages(object):
+    """All bf16 weight images (both layouts) of one model's convolution kernels, rebuilt by ONE launch per step
+    (refresh(), called at the top of the model's forward) instead of one tiny launch per layer and pass."""
+
+    def __init__(self, weights, device):
+        lib = _lib.load()
+        self.entries, sizes = [], []
+        for w in weights:
+            kh, kw, cin, cout = w.shape
+            for mode in (0, 1):
+                sizes.append(int(lib.nimg_conv_weights_bf16_bytes(kh, kw, cin, cout, mode)))
+                self.entries.append((w, mode))
+        offs = np.concatenate([[0], np.cumsum([-(-s // 256) * 256 for s in sizes])]).astype(np.int64)
+        self.buf = torch.empty(int(offs[-1]) or 256, dtype=torch.uint8, device=device)
+        table = np.zeros((len(self.entries), 4), np.int64)
+        for i, (w, mode) in enumerate(self.entries):
+            kh, kw, cin, cout = w.shape
+            view = self.buf[int(offs[i]):int(offs[i]) + sizes[i]]
+            table[i] = (w.data_ptr(), view.data_ptr(), ((kh * kw) << 32) | mode, (cin << 32) | cout)
+            if _WB_REGISTRY.get(w.data_ptr(), {}).get('shape') != tuple(w.shape):
+                _WB_REGISTRY[w.data_ptr()] = {'shape': tuple(w.shape)}
+            _WB_REGISTRY[w.data_ptr()][mode] = view
+        self.table = torch.from_numpy(table).to(device)
+        # addresses are recycled by the caching allocator: drop the registry entries with the model
+        import weakref
+        keys = [(w.data_ptr(), tuple(w.shape)) for w in weights]
+        weakref.finalize(self, WeightImages._forget, keys, self.buf.data_ptr(), self.buf.numel())
+
+    @staticmethod
+    def _forget(keys, base, size):
+        for ptr, shape in keys:
+            reg = _WB_REGISTRY.get(ptr)
+            if reg is not None and reg['shape'] == shape and \
+                    all(base <= reg[m].data_ptr() < base + size for m in (0, 1) if m in reg):
+                del _WB_REGISTRY[ptr]
+
+    def refresh(self):
+        if COMPUTE == 'bf16' and len(self.entries):
+            _lib.call('nimg_conv_weights_bf16_batch', _p(self.table), len(self.entries), _stream())
+
+
 def weights_bf16(w, mode):
-    """bf16 weight image for the throughput-mode kernels (re-made every step from the float32 master weights)."""
+    """bf16 weight image for the throughput-mode kernels (re-made every step from the float32 master weights): the
+    model-wide pre-built image if the weight is registered (WeightImages), else converted here."""
+    reg = _WB_REGISTRY.get(w.data_ptr())
+    if reg is not None and reg['shape'] == tuple(w.shape) and mode in reg:
+        return reg[mode]
     kh, kw, cin, cout = w.shape
     nbytes = int(_lib.load().nimg_conv_weights_bf16_bytes(kh, kw, cin, cout, mode))
     wb = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
