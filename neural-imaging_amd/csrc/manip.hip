@@ -131,6 +131,61 @@ __global__ void gaussian_bwd_kernel(const float* __restrict__ dy, const uint8_t*
     }
 }
 
+// LDS-tiled variant (used when the image holds at least one 16x16 tile): the masked dy of a 16x16 tile + its 2-pixel
+// ring is staged once (20 x 20 x float4) instead of 25 global mask + pixel reads per output pixel; same summation order
+// as gaussian_bwd_kernel (sources, then ky, then kx), so the results are identical.
+__global__ __launch_bounds__(256) void gaussian_bwd_tiled_kernel(const float* __restrict__ dy,
+                                                                 const uint8_t* __restrict__ mask,
+                                                                 float* __restrict__ dx, const float* __restrict__ gk,
+                                                                 int n, int h, int w, int tiles_y, int tiles_x) {
+    __shared__ float4 sd[20 * 21];
+    __shared__ float sg[25];
+    const int tid = threadIdx.x;
+    if (tid < 25) sg[tid] = gk[tid];
+    const int tiles = tiles_y * tiles_x;
+    const long im = blockIdx.x / tiles;
+    const int tile = blockIdx.x % tiles, y0 = (tile / tiles_x) * 16, x0 = (tile % tiles_x) * 16;
+    for (int i = tid; i < 400; i += 256) {
+        const int r = i / 20, c = i % 20, gy = y0 - 2 + r, gx = x0 - 2 + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy >= 0 && gy < h && gx >= 0 && gx < w) {
+            const long o = (im * h + gy) * w + gx;
+            const uint32_t m = mask ? mask[o] : 7u;
+            const float* p = dy + o * 3;
+            v = make_float4((m & 1u) ? p[0] : 0.f, (m & 2u) ? p[1] : 0.f, (m & 4u) ? p[2] : 0.f, 0.f);
+        }
+        sd[r * 21 + c] = v;
+    }
+    __syncthreads();
+    const int py = y0 + (tid >> 4), px = x0 + (tid & 15);
+    if (py >= h || px >= w) return;
+    int ys[2], xs[2];
+    const int ny = pad_sources(py, h, 2, 2, ys), nx = pad_sources(px, w, 2, 2, xs);
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int a = 0; a < ny; ++a)
+        for (int b = 0; b < nx; ++b) {
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky) {
+                const int oy = ys[a] - ky;
+                if (oy < 0 || oy >= h) continue;
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx) {
+                    const int ox = xs[b] - kx;
+                    if (ox < 0 || ox >= w) continue;
+                    const float4 v = sd[(oy - y0 + 2) * 21 + (ox - x0 + 2)];
+                    const float wv = sg[ky * 5 + kx];
+                    acc[0] = fmaf(v.x, wv, acc[0]);
+                    acc[1] = fmaf(v.y, wv, acc[1]);
+                    acc[2] = fmaf(v.z, wv, acc[2]);
+                }
+            }
+        }
+    const long i = (im * h + py) * w + px;
+    dx[i * 3 + 0] = acc[0];
+    dx[i * 3 + 1] = acc[1];
+    dx[i * 3 + 2] = acc[2];
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // sharpen forward: y = clip(hsv2rgb(filter(rgb2hsv(sympad(x))))); aux = filtered hsv (needed by the backward)
 __global__ void sharpen_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ aux,
@@ -352,8 +407,13 @@ int nimg_gaussian_bwd(const float* dy, const uint8_t* mask, float* dx, const flo
     if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!dy || !dx || !gk25 || n < 0 || h < 5 || w < 5) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
-    hipLaunchKernelGGL(gaussian_bwd_kernel, dim3(grid_for((long)n * h * w)), dim3(256), 0, (hipStream_t)stream, dy,
-                       mask, dx, gk25, n, h, w);
+    const int ty = (h + 15) / 16, tx = (w + 15) / 16;
+    if (h >= 16 && w >= 16 && (long)n * ty * tx < (1L << 31))
+        hipLaunchKernelGGL(gaussian_bwd_tiled_kernel, dim3((unsigned)((long)n * ty * tx)), dim3(256), 0,
+                           (hipStream_t)stream, dy, mask, dx, gk25, n, h, w, ty, tx);
+    else
+        hipLaunchKernelGGL(gaussian_bwd_kernel, dim3(grid_for((long)n * h * w)), dim3(256), 0, (hipStream_t)stream, dy,
+                           mask, dx, gk25, n, h, w);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }

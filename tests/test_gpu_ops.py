@@ -435,6 +435,25 @@ def test_manipulations_fwd_bwd(dev, name):
     assert_close(dx.cpu().numpy(), x.grad.numpy(), 2e-4, 3e-4, what=name + ' bwd')
 
 
+@pytest.mark.parametrize('hw', [(24, 40), (16, 16), (50, 18), (8, 12)])
+def test_gaussian_backward_tiled_and_plain(dev, hw):
+    """The LDS-tiled backward (images >= 16x16, partial border tiles) and the plain kernel (smaller images) against autograd
+    through the REFLECT-padded filter."""
+    from neural_imaging_amd.helpers import tf_helpers as th
+    h, w = hw
+    x_np = np.ascontiguousarray(natural_images(2, max(h, w), max(h, w), seed=9)[:, :h, :w])    # no saturated regions:
+    # a float32 blur of an all-ones window can land 1 ulp above 1 and flip the clip mask against the float64 oracle
+    x = to64(x_np).requires_grad_(True)
+    ref = om.manipulation_gaussian(x, 5, 0.83)
+    dy = rnd(tuple(ref.shape), 3)
+    (ref * to64(dy)).sum().backward()
+    op = th.Gaussian()
+    y, ctx = op.forward(g(x_np, dev), 0.83, training=True)
+    assert_close(y.cpu().numpy(), ref.detach().numpy(), ATOL, what='gaussian fwd')
+    dx = op.backward(ctx, g(dy, dev))
+    assert_close(dx.cpu().numpy(), x.grad.numpy(), 2e-4, 3e-4, what='gaussian bwd {}'.format(hw))
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # learned-codec pieces
 def test_latent_soft_codebook_and_entropy(dev):
