@@ -331,6 +331,31 @@ __global__ void sparse_axis_kernel(const float* __restrict__ in, float* __restri
     }
 }
 
+// 3-channel images (every caller on the hot path): one thread per output PIXEL, so the CSR row (pointer, columns,
+// values) and the 32-bit index arithmetic are shared by the channels
+__global__ void sparse_axis3_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                    const int* __restrict__ rowptr, const int* __restrict__ col,
+                                    const float* __restrict__ val, int n, int hin, int win, int hout, int wout,
+                                    int axis) {
+    const int total = n * hout * wout;                      // < 2^31 (checked by the entry point)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int ox = i % wout, r = i / wout, oy = r % hout, im = r / hout;
+        const int o = axis == 0 ? oy : ox;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        const int e1 = rowptr[o + 1];
+        for (int e = rowptr[o]; e < e1; ++e) {
+            const int src = col[e];
+            const float v = val[e];
+            const float* p = in + (axis == 0 ? ((long)(im * hin + src) * win + ox) : ((long)(im * hin + oy) * win + src)) * 3;
+            a0 = fmaf(v, p[0], a0);
+            a1 = fmaf(v, p[1], a1);
+            a2 = fmaf(v, p[2], a2);
+        }
+        float* q = out + (long)i * 3;
+        q[0] = a0; q[1] = a1; q[2] = a2;
+    }
+}
+
 // fold a gradient defined on the padded domain (h+2P, w+2P) back onto the image
 __global__ void fold_pad_kernel(const float* __restrict__ dpad, float* __restrict__ dx, int n, int h, int w, int c,
                                 int P, int mode) {
@@ -349,6 +374,25 @@ __global__ void fold_pad_kernel(const float* __restrict__ dpad, float* __restric
         for (int a = 0; a < ny; ++a)
             for (int b = 0; b < nx; ++b) acc += dpad[((im * hp + ys[a]) * wp + xs[b]) * c + ch];
         dx[i] = acc;
+    }
+}
+
+__global__ void fold_pad3_kernel(const float* __restrict__ dpad, float* __restrict__ dx, int n, int h, int w, int P,
+                                 int mode) {
+    const int total = n * h * w;
+    const int hp = h + 2 * P, wp = w + 2 * P;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int px = i % w, r = i / w, py = r % h, im = r / h;
+        int ys[2], xs[2];
+        const int ny = pad_sources(py, h, P, mode, ys), nx = pad_sources(px, w, P, mode, xs);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int a = 0; a < ny; ++a)
+            for (int b = 0; b < nx; ++b) {
+                const float* p = dpad + ((long)(im * hp + ys[a]) * wp + xs[b]) * 3;
+                a0 += p[0]; a1 += p[1]; a2 += p[2];
+            }
+        float* q = dx + (long)i * 3;
+        q[0] = a0; q[1] = a1; q[2] = a2;
     }
 }
 
@@ -452,8 +496,12 @@ int nimg_sparse_axis_apply(const float* in, float* out, const int* rowptr, const
     if (axis != 0 && axis != 1) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
     const int hout = axis == 0 ? out_size : hin, wout = axis == 1 ? out_size : win;
-    hipLaunchKernelGGL(sparse_axis_kernel, dim3(grid_for((long)n * hout * wout * c)), dim3(256), 0,
-                       (hipStream_t)stream, in, out, rowptr, col, val, n, hin, win, hout, wout, c, axis);
+    if (c == 3 && (long)n * hout * wout < (1L << 31) && (long)n * hin * win < (1L << 31))
+        hipLaunchKernelGGL(sparse_axis3_kernel, dim3(grid_for((long)n * hout * wout)), dim3(256), 0, (hipStream_t)stream,
+                           in, out, rowptr, col, val, n, hin, win, hout, wout, axis);
+    else
+        hipLaunchKernelGGL(sparse_axis_kernel, dim3(grid_for((long)n * hout * wout * c)), dim3(256), 0,
+                           (hipStream_t)stream, in, out, rowptr, col, val, n, hin, win, hout, wout, c, axis);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }
@@ -463,8 +511,12 @@ int nimg_fold_pad(const float* dpad, float* dx, int n, int h, int w, int c, int 
     if (!dpad || !dx || n < 0 || h <= 2 * pad || w <= 2 * pad || c <= 0 || pad < 0 || pad_mode < 1 || pad_mode > 2)
         return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
-    hipLaunchKernelGGL(fold_pad_kernel, dim3(grid_for((long)n * h * w * c)), dim3(256), 0, (hipStream_t)stream, dpad,
-                       dx, n, h, w, c, pad, pad_mode);
+    if (c == 3 && (long)n * (h + 2 * pad) * (w + 2 * pad) < (1L << 31))
+        hipLaunchKernelGGL(fold_pad3_kernel, dim3(grid_for((long)n * h * w)), dim3(256), 0, (hipStream_t)stream, dpad, dx, n,
+                           h, w, pad, pad_mode);
+    else
+        hipLaunchKernelGGL(fold_pad_kernel, dim3(grid_for((long)n * h * w * c)), dim3(256), 0, (hipStream_t)stream, dpad,
+                           dx, n, h, w, c, pad, pad_mode);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }
