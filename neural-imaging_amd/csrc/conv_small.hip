@@ -44,19 +44,28 @@ __global__ __launch_bounds__(256) void conv_fewout_kernel(const SmallParams p) {
 
     for (int c0 = 0; c0 < p.Cin; c0 += CK) {
         __syncthreads();
-        for (int item = tid; item < THH * TWH * CK; item += 256) {
+        // staged in batches of 8 independent loads per thread (a rolled loop would serialise 16 global round trips)
+        constexpr int NITEM = THH * TWH * CK, NIT = (NITEM + 255) / 256;
+#pragma unroll 8
+        for (int it = 0; it < NIT; ++it) {
+            const int item = tid + it * 256;
             const int k = item % CK, pix = item / CK;
             int gy = ty0 - p.pad_t + pix / TWH, gx = tx0 - p.pad_l + pix % TWH;
             float v = 0.f;
-            if (c0 + k < p.Cin && map_coord(gy, p.H, p.pad_mode) && map_coord(gx, p.W, p.pad_mode))
+            if (item < NITEM && c0 + k < p.Cin && map_coord(gy, p.H, p.pad_mode) && map_coord(gx, p.W, p.pad_mode))
                 v = p.in[(((long)n * p.H + gy) * p.W + gx) * p.Cin + c0 + k];
-            smem[pix * CKP + k] = v;
+            if (item < NITEM) smem[pix * CKP + k] = v;
         }
         __syncthreads();
         const int ck = min(CK, p.Cin - c0);
+        // fully unrolled for the 3-channel case: the weights are wave-uniform scalar loads, and only an unrolled body lets
+        // the compiler issue the s_loads of the next (ky, ci) pairs while the current FMAs run
+#pragma unroll
         for (int ky = 0; ky < KS; ++ky) {
             const float* row = smem + ((ty + ky) * TWH + tx * S_PW) * CKP;
-            for (int k = 0; k < ck; ++k) {
+#pragma unroll
+            for (int k = 0; k < CK; ++k) {
+                if (k >= ck) break;
                 const float* wk = p.w + ((long)(ky * KS) * p.Cin + c0 + k) * COUT;     // + kx * Cin * COUT
 #pragma unroll
                 for (int c = 0; c < S_PW + KS - 1; ++c) {
