@@ -9,7 +9,7 @@ import os
 from ctypes import c_float, c_int, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libnimg.so')
+LIB_PATH = os.environ.get('NIMG_LIBPATH') or os.path.join(_HERE, 'libnimg.so')     # override: A/B of kernel builds
 
 P = c_void_p  # every device pointer / stream is passed as an opaque pointer
 

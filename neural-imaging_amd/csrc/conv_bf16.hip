@@ -133,8 +133,14 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
     constexpr int TAPS = KS * KS;
     static_assert(NI >= 1 && MFRAGS % WAVES_M == 0, "bad tile configuration");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    uint4* sA = reinterpret_cast<uint4*>(smem_raw);                       // [NPIXH][2] 16-byte halves
-    uint4* sB = sA + NPIXH * 2;                                           // [TAPS*TN][2]
+    // A tile layouts.  PLANAR (stride 1, 16-wide tiles): [k-half][row][32 columns] - 16 consecutive lanes read 256
+    // contiguous bytes, the row stride is a multiple of 256 bytes so the four 16-lane groups of a ds_read_b128 each cover
+    // all 64 banks exactly once, and a tap is a compile-time offset (ky*32 + kx) on one per-fragment base register.
+    // Otherwise: [pixel][2] 16-byte halves, XOR-swizzled by pixel.
+    constexpr bool PLANAR = (STRIDE == 1 && TW == 16 && NB == 1 && KS == 5);   // 3x3: the extra registers cost a wave per SIMD
+    constexpr int PLSZ = THH * 32, A_ENTRIES = PLANAR ? 2 * PLSZ : NPIXH * 2;
+    uint4* sA = reinterpret_cast<uint4*>(smem_raw);
+    uint4* sB = sA + A_ENTRIES;                                           // [TAPS*TN][2]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
@@ -156,7 +162,8 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
     for (int mi = 0; mi < MI; ++mi) {
         const int P = (wm * MI + mi) * 32 + (lane & 31);
         const int img = P / (TH * TW), rem = P % (TH * TW);
-        abase[mi] = img * (THH * TWH) + (rem / TW) * STRIDE * TWH + (rem % TW) * STRIDE;
+        abase[mi] = PLANAR ? half * PLSZ + (rem / TW) * 32 + (rem % TW)
+                           : img * (THH * TWH) + (rem / TW) * STRIDE * TWH + (rem % TW) * STRIDE;
     }
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -230,7 +237,8 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
                     const bf16x8 b = pack8(f);
                     packed = *reinterpret_cast<const uint4*>(&b);
                 }
-                sA[pix * 2 + (h8 ^ ((pix >> 3) & 1))] = packed;
+                if constexpr (PLANAR) sA[h8 * PLSZ + (pix / TWH) * 32 + pix % TWH] = packed;
+                else sA[pix * 2 + (h8 ^ ((pix >> 3) & 1))] = packed;
             }
         }
 #pragma unroll
@@ -248,12 +256,12 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx) {            // one kernel row unrolled: the next taps' ds_reads overlap the MFMAs
             const int tap = ky * KS + kx;
-            const int toff = ky * TWH + kx;
+            const int toff = PLANAR ? ky * 32 + kx : ky * TWH + kx;
             bf16x8 a[MI], b[NI];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 const int pix = abase[mi] + toff;
-                const uint4 v = sA[pix * 2 + (half ^ ((pix >> 3) & 1))];
+                const uint4 v = PLANAR ? sA[pix] : sA[pix * 2 + (half ^ ((pix >> 3) & 1))];
                 a[mi] = *reinterpret_cast<const bf16x8*>(&v);
             }
 #pragma unroll
@@ -366,7 +374,9 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
 template <int KS, int STRIDE, int TH, int TW, int NB, int TN, bool INB = false>
 int launch_conv_b(const ConvParamsB& p, hipStream_t stream) {
     constexpr int THH = (TH - 1) * STRIDE + KS, TWH = (TW - 1) * STRIDE + KS;
-    constexpr size_t lds_tiles = (size_t)(NB * THH * TWH + KS * KS * TN) * 2 * sizeof(uint4);
+    constexpr bool PLANAR = (STRIDE == 1 && TW == 16 && NB == 1 && KS == 5);   // 3x3: the extra registers cost a wave per SIMD
+    constexpr size_t a_entries = PLANAR ? (size_t)2 * THH * 32 : (size_t)NB * THH * TWH * 2;
+    constexpr size_t lds_tiles = (a_entries + (size_t)KS * KS * TN * 2) * sizeof(uint4);
     constexpr size_t lds_epi = (size_t)4 * 32 * (TN + EPI_PAD) * sizeof(float);
     constexpr size_t lds = lds_tiles > lds_epi ? lds_tiles : lds_epi;
     ConvParamsB q = p;
