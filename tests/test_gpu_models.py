@@ -524,6 +524,44 @@ def test_workflow_with_learned_codec_joint_training(dev):
     assert wf.is_trainable('dcn') and 'TwitterDCN' in wf.summary()
 
 
+def test_channel_learns_and_compute_modes_agree(dev):
+    """The reference's own acceptance test (config/tests/framework.json 'train-manipulation': INet, sharpen + gaussian,
+    --train nip, validation accuracy > 0.50) on synthetic patches, in both compute modes: the classifier reaches the
+    floor within 100 steps, and the bf16 throughput mode follows the float32 loss trajectory (accuracy / PSNR parity)."""
+    from neural_imaging_amd import ops
+    from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
+    dist = {'downsampling': 'none', 'compression': 'jpeg', 'compression_params': {'quality': 80, 'codec': 'soft'}}
+    rgb = natural_images(64, 64, 64, seed=100)
+    raw = bayer_from_rgb(rgb)
+    vrgb = natural_images(24, 64, 64, seed=200)
+    vraw = bayer_from_rgb(vrgb)
+    labels = np.repeat(np.arange(3), 24)
+    traj = {}
+    for mode in ('f32', 'bf16'):
+        ops.set_compute(mode)
+        try:
+            wf = ManipulationClassification('INet', manipulations=['sharpen:1', 'gaussian:1'], distribution=dist,
+                                            trainable={'nip'}, raw_patch_size=32, device=dev)
+            rng = np.random.RandomState(0)
+            losses = []
+            for step in range(100):
+                idx = rng.choice(64, 8, replace=False)
+                loss, parts = wf.training_step(raw[idx], rgb[idx], lambda_nip=0.1, learning_rate=1e-4)
+                losses.append(float(loss))
+            acc = float(np.mean(np.asarray(wf.run_workflow_to_decisions(vraw)) == labels))
+            y = wf.nip.process(vraw).numpy()
+            psnr = float(np.mean(10 * np.log10(1.0 / np.mean((y - vrgb) ** 2, axis=(1, 2, 3)))))
+            traj[mode] = (np.array(losses), acc, psnr)
+        finally:
+            ops.set_compute('f32')
+    for mode in traj:
+        assert traj[mode][1] > 0.5, (mode, traj[mode][1])                   # the reference's floor
+        assert traj[mode][0][-1] < 0.8 * traj[mode][0][0]
+    assert abs(traj['f32'][1] - traj['bf16'][1]) <= 0.05                     # accuracy parity
+    assert abs(traj['f32'][2] - traj['bf16'][2]) < 0.2                       # PSNR parity (dB)
+    assert np.max(np.abs(traj['f32'][0] - traj['bf16'][0]) / traj['f32'][0]) < 2e-2
+
+
 def test_training_harness_outputs(dev, tmp_path):
     """H1 (training/manipulation.py:36-335): epoch loop, lr decay, validation cadence, training.json keys, checkpoints
     and the 'directory exists => skip' idempotence, on a synthetic dataset."""
