@@ -99,7 +99,8 @@ int nimg_convt2x2_fwd(const float* x, const float* w, const float* bias, float* 
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Pooling / layout / element-wise */
-/* MaxPool2D 2x2 (pipelines.py:197 SAME, forensics.py:70 VALID; identical on even sizes) */
+/* MaxPool2D 2x2 (pipelines.py:197 SAME, forensics.py:70 VALID; identical on even sizes).  Odd sizes follow VALID: y is
+ * (n, h/2, w/2, c) with the last row / column dropped, and the backward pass leaves it a zero gradient. */
 int nimg_maxpool2_fwd(const float* x, float* y, int n, int h, int w, int c, void* stream);
 /* dz = (route dp to the FIRST arg-max of each window) [+ add] [* LeakyReLU'(yact)]; add may alias dz */
 int nimg_maxpool2_bwd(const float* dp, const float* yact, const float* add, float* dz, int n, int h, int w, int c,

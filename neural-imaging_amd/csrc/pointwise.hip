@@ -490,7 +490,7 @@ extern "C" {
 
 int nimg_maxpool2_fwd(const float* x, float* y, int n, int h, int w, int c, void* stream) {
     if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
-    if (!x || !y || n < 0 || h <= 0 || w <= 0 || c <= 0 || (h & 1) || (w & 1)) return NIMG_ERR_ARG;
+    if (!x || !y || n < 0 || h < 2 || w < 2 || c <= 0) return NIMG_ERR_ARG;      /* odd sizes: VALID (the last row / column is dropped) */
     if (n == 0) return NIMG_OK;
     hipStream_t s = (hipStream_t)stream;
     if (c % 4 == 0)
@@ -506,9 +506,13 @@ int nimg_maxpool2_fwd(const float* x, float* y, int n, int h, int w, int c, void
 int nimg_maxpool2_bwd(const float* dp, const float* yact, const float* add, float* dz, int n, int h, int w, int c,
                       int apply_lrelu_mask, float alpha, void* stream) {
     if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
-    if (!dp || !yact || !dz || n < 0 || h <= 0 || w <= 0 || c <= 0 || (h & 1) || (w & 1)) return NIMG_ERR_ARG;
+    if (!dp || !yact || !dz || n < 0 || h < 2 || w < 2 || c <= 0) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
     hipStream_t s = (hipStream_t)stream;
+    if ((h & 1) || (w & 1)) {            /* VALID pooling of an odd size: the dropped last row / column gets no gradient */
+        if (add && add != dz) return NIMG_ERR_ARG;
+        if (!add && hipMemsetAsync(dz, 0, (size_t)n * h * w * c * sizeof(float), s) != hipSuccess) return NIMG_ERR_LAUNCH;
+    }
     if (c % 4 == 0)
         hipLaunchKernelGGL(maxpool2_bwd_kernel<4>, dim3(grid_for((long)n * (h / 2) * (w / 2) * (c / 4))), dim3(256),
                            0, s, dp, yact, add, dz, n, h, w, c, apply_lrelu_mask, alpha);

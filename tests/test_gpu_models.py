@@ -294,6 +294,32 @@ def test_fan_bf16_storage_is_bit_neutral(dev):
             assert np.array_equal(a[3][k], b[3][k]), k
 
 
+@pytest.mark.parametrize('patch', [48, 40, 24])
+def test_fan_odd_pyramids_in_throughput_mode(dev, patch):
+    """Throughput mode on feature pyramids that stop being even (48 -> 24 -> 12 -> 6 -> 3, 40 -> .. -> 5 -> 2): fused layers
+    with bf16-stored tensors hand over to the separate conv / pool kernels and back; gradients stay aligned with float32."""
+    from neural_imaging_amd import ops
+    from neural_imaging_amd.models import forensics
+    x = torch.from_numpy(natural_images(6, patch, patch, seed=43)).to(dev)
+    labels = torch.from_numpy(np.array([0, 1, 2, 0, 1, 2], np.int32)).to(dev)
+    res = {}
+    for mode in ('f32', 'bf16'):
+        ops.set_compute(mode)
+        try:
+            fan = forensics.FAN(n_classes=3, patch_size=patch, device=dev)
+            probs, ctx = fan.forward(x, labels, training=True)
+            loss, dx = fan.backward(ctx, need_input_grad=True)
+            res[mode] = (probs.cpu().numpy(), float(loss.item()), grads_of(fan), dx.cpu().numpy())
+        finally:
+            ops.set_compute('f32')
+    assert np.abs(res['f32'][0] - res['bf16'][0]).max() < 2e-2 and abs(res['f32'][1] - res['bf16'][1]) < 2e-2
+    for k in ('conv1/kernel', 'conv3/kernel', 'conv4/kernel', 'conv1x1/kernel', 'dense/kernel'):
+        a, b = res['f32'][2][k].ravel(), res['bf16'][2][k].ravel()
+        assert float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b))) > 0.97, k
+    a, b = res['f32'][3].ravel(), res['bf16'][3].ravel()
+    assert float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b))) > 0.97
+
+
 def _sync_oracle(wf, ref):
     ref.nip = onets.OrderedDict((k, to64(v)) for k, v in wf.nip.state_dict().items())
     ref.fan = onets.OrderedDict((k, to64(v)) for k, v in wf.fan.state_dict().items())

@@ -294,8 +294,15 @@ def test_edge_cases_empty_ragged_and_error_codes(dev):
         out = ops.conv2d(g(x, dev), g(wt, dev), g(b, dev))
         assert_close(out.cpu().numpy(), ref, 1e-5, GRTOL, what='ragged conv {}'.format((n, h, wd, cin, cout, ks)))
     # error codes: odd size into the pool, dJPEG on a size that is not a multiple of 8, bad activation id
-    with pytest.raises(RuntimeError):
-        ops.maxpool2(g(rnd((1, 5, 4, 4), 5), dev))
+    xo = rnd((1, 5, 7, 4), 5)                                 # odd sizes pool VALID: last row / column dropped
+    yo = ops.maxpool2(g(xo, dev))
+    ref_o = T.max_pool2(to64(xo)).numpy()
+    assert yo.shape == (1, 2, 3, 4) and np.array_equal(yo.cpu().numpy(), ref_o.astype(np.float32))
+    xt = to64(xo).requires_grad_(True)
+    dpo = rnd((1, 2, 3, 4), 6)
+    (T.max_pool2(xt) * to64(dpo)).sum().backward()
+    dzo = ops.maxpool2_bwd(g(dpo, dev), g(xo, dev), None, apply_mask=False)
+    assert_close(dzo.cpu().numpy(), xt.grad.numpy(), 1e-6, what='odd-size pool backward')
     with pytest.raises(RuntimeError):
         ops.djpeg_fwd(g(rnd((1, 12, 16, 3), 6), dev), ops.qtables_device(50, dev))
     lib = _lib.load()
