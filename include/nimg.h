@@ -201,6 +201,24 @@ int nimg_tanh_fwd(const float* x, float* y, long count, void* stream);
 int nimg_tanh_bwd(const float* dy, const float* y, float* dx, long count, void* stream);
 int nimg_clip01(const float* x, float* y, long count, void* stream);
 int nimg_pad2d(const float* x, float* y, int n, int h, int w, int c, int pad, int pad_mode, void* stream);
+/* Element-wise pieces of ClassicISP (models/pipelines.py:416-453 `_ClassicISP.call`, models/layers.py:206-258
+ * `DemosaicingLayer`).
+ *  residual: y = [clip01](x - alpha[0] * f)  (layers.py:252-255; f NULL = the c_filters=() case, y = [clip01](x)); the clip
+ *            is straight-through, so the backward pass is df = -alpha dy, dalpha (+)= -sum(dy f) (fixed-order sum;
+ *            workspace = nimg_isp_residual_workspace_bytes() bytes of device scratch), dx = dy.
+ *  sigmoid:  activation of the non-residual head (layers.py:235), backward through the stored output.
+ *  gamma_ste: y = pow(clip(x, lo, hi), exponent) with a straight-through clip (pipelines.py:449-451: lo 1/255, hi 1,
+ *            exponent 1/2.2): dx = dy * exponent * pow(clip(x), exponent - 1). */
+int nimg_isp_residual_fwd(const float* x, const float* f, const float* alpha, float* y, long count, int clip,
+                          void* stream);
+long nimg_isp_residual_workspace_bytes(void);
+int nimg_isp_residual_bwd(const float* dy, const float* f, const float* alpha, float* df, float* dalpha,
+                          float* workspace, long count, int accumulate, void* stream);
+int nimg_sigmoid_fwd(const float* x, float* y, long count, void* stream);
+int nimg_sigmoid_bwd(const float* dy, const float* y, float* dx, long count, void* stream);
+int nimg_gamma_ste_fwd(const float* x, float* y, long count, float lo, float hi, float exponent, void* stream);
+int nimg_gamma_ste_bwd(const float* x, const float* dy, float* dx, long count, float lo, float hi, float exponent,
+                       void* stream);
 /* out (n,2h,2w,c) = in with zeros inserted (stride-2 transposed convolution = zero insertion + stride-1 conv) */
 int nimg_zero_insert2(const float* in, float* out, int n, int h, int w, int c, void* stream);
 /* DiscreteLatent (models/layers.py:183-203): latent = Quantization('soft-codebook' | identity)(scale * z) evaluated in

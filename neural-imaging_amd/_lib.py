@@ -78,6 +78,13 @@ PROTOTYPES = {
     'nimg_tanh_fwd': (c_int, [P, P, c_long, P]),
     'nimg_tanh_bwd': (c_int, [P, P, P, c_long, P]),
     'nimg_clip01': (c_int, [P, P, c_long, P]),
+    'nimg_isp_residual_fwd': (c_int, [P, P, P, P, c_long, c_int, P]),
+    'nimg_isp_residual_workspace_bytes': (c_long, []),
+    'nimg_isp_residual_bwd': (c_int, [P, P, P, P, P, P, c_long, c_int, P]),
+    'nimg_sigmoid_fwd': (c_int, [P, P, c_long, P]),
+    'nimg_sigmoid_bwd': (c_int, [P, P, P, c_long, P]),
+    'nimg_gamma_ste_fwd': (c_int, [P, P, c_long, c_float, c_float, c_float, P]),
+    'nimg_gamma_ste_bwd': (c_int, [P, P, P, c_long, c_float, c_float, c_float, P]),
     'nimg_pad2d': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'nimg_conv2d_fwd_bf16_ex': (c_int, [P, c_int, P, c_int, P, P, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int,
                                         c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),

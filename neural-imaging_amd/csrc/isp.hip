@@ -1,0 +1,165 @@
+// Element-wise pieces of the classic camera ISP (reference models/pipelines.py:416-453 `_ClassicISP`,
+// models/layers.py:206-258 `DemosaicingLayer`): the residual combination y = clip_ste(x - alpha f) with its scalar
+// gradient, the sigmoid of the non-residual head, and the gamma stage pow(clip_ste(x, 1/255, 1), 1/2.2).
+// All HBM-bound streams: float4 grid-stride loops; the alpha gradient is a fixed-order two-stage sum (deterministic).
+#include "common.h"
+
+namespace {
+using namespace nimg;
+
+constexpr int RED_BLOCKS = 1024;
+
+inline int grid_for(long count) {
+    long g = (count + 1023) / 1024;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+__device__ __forceinline__ float clip01f(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
+
+// y = [clip01](x - alpha * f); the clip is straight-through, so no mask is kept
+__global__ void residual_fwd_kernel(const float* __restrict__ x, const float* __restrict__ f,
+                                    const float* __restrict__ alpha, float* __restrict__ y, long count, int clip) {
+    const float a = f ? alpha[0] : 0.f;
+    const long c4 = count >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < c4; i += (long)gridDim.x * blockDim.x) {
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        if (f) {
+            const float4 r = reinterpret_cast<const float4*>(f)[i];
+            v.x -= a * r.x; v.y -= a * r.y; v.z -= a * r.z; v.w -= a * r.w;
+        }
+        if (clip) { v.x = clip01f(v.x); v.y = clip01f(v.y); v.z = clip01f(v.z); v.w = clip01f(v.w); }
+        reinterpret_cast<float4*>(y)[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (count & 3)) {
+        const long i = (c4 << 2) + threadIdx.x;
+        float v = x[i] - (f ? a * f[i] : 0.f);
+        y[i] = clip ? clip01f(v) : v;
+    }
+}
+
+// df = -alpha dy;  partial[block] = sum over the block's elements of dy * f
+__global__ __launch_bounds__(256) void residual_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ f,
+                                                           const float* __restrict__ alpha, float* __restrict__ df,
+                                                           float* __restrict__ partial, long count) {
+    __shared__ float red[4];
+    const float a = alpha[0];
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        const float g = dy[i];
+        acc += g * f[i];
+        df[i] = -a * g;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(64) void residual_final_kernel(const float* __restrict__ partial, int blocks,
+                                                            float* __restrict__ dalpha, int accumulate) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < blocks; i += 64) acc += partial[i];
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) dalpha[0] = (accumulate ? dalpha[0] : 0.f) - acc;
+}
+
+__global__ void sigmoid_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long count) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+        y[i] = 1.0f / (1.0f + expf(-x[i]));
+}
+__global__ void sigmoid_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx,
+                                   long count) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        const float s = y[i];
+        dx[i] = dy[i] * s * (1.0f - s);
+    }
+}
+
+// y = pow(clip(x, lo, hi), e); the clip is straight-through: dx = dy e pow(clip(x), e - 1) everywhere
+__global__ void gamma_ste_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long count, float lo, float hi,
+                                     float e) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+        y[i] = powf(fminf(fmaxf(x[i], lo), hi), e);
+}
+__global__ void gamma_ste_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                     long count, float lo, float hi, float e) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+        dx[i] = dy[i] * e * powf(fminf(fmaxf(x[i], lo), hi), e - 1.0f);
+}
+
+}  // namespace
+
+extern "C" {
+
+int nimg_isp_residual_fwd(const float* x, const float* f, const float* alpha, float* y, long count, int clip,
+                          void* stream) {
+    if (count < 0) return NIMG_ERR_ARG;
+    if (count == 0) return NIMG_OK;
+    if (!x || !y || (f && !alpha)) return NIMG_ERR_ARG;
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)f) & 15) return NIMG_ERR_ARG;
+    hipLaunchKernelGGL(residual_fwd_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, x, f, alpha, y,
+                       count, clip);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+long nimg_isp_residual_workspace_bytes(void) { return (long)RED_BLOCKS * sizeof(float); }
+
+int nimg_isp_residual_bwd(const float* dy, const float* f, const float* alpha, float* df, float* dalpha,
+                          float* workspace, long count, int accumulate, void* stream) {
+    if (count < 0) return NIMG_ERR_ARG;
+    if (!dalpha || !alpha) return NIMG_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (count == 0) {
+        if (!accumulate && hipMemsetAsync(dalpha, 0, sizeof(float), s) != hipSuccess) return NIMG_ERR_LAUNCH;
+        return NIMG_OK;
+    }
+    if (!dy || !f || !df || !workspace) return NIMG_ERR_ARG;
+    const long want = (count + 255) / 256;
+    const int blocks = (int)(want > RED_BLOCKS ? RED_BLOCKS : want);
+    hipLaunchKernelGGL(residual_bwd_kernel, dim3(blocks), dim3(256), 0, s, dy, f, alpha, df, workspace, count);
+    hipLaunchKernelGGL(residual_final_kernel, dim3(1), dim3(64), 0, s, workspace, blocks, dalpha, accumulate);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_sigmoid_fwd(const float* x, float* y, long count, void* stream) {
+    if (count < 0) return NIMG_ERR_ARG;
+    if (count == 0) return NIMG_OK;
+    if (!x || !y) return NIMG_ERR_ARG;
+    hipLaunchKernelGGL(sigmoid_fwd_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, x, y, count);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_sigmoid_bwd(const float* dy, const float* y, float* dx, long count, void* stream) {
+    if (count < 0) return NIMG_ERR_ARG;
+    if (count == 0) return NIMG_OK;
+    if (!dy || !y || !dx) return NIMG_ERR_ARG;
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, count);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_gamma_ste_fwd(const float* x, float* y, long count, float lo, float hi, float exponent, void* stream) {
+    if (count < 0 || !(lo > 0.f) || !(hi >= lo)) return NIMG_ERR_ARG;
+    if (count == 0) return NIMG_OK;
+    if (!x || !y) return NIMG_ERR_ARG;
+    hipLaunchKernelGGL(gamma_ste_fwd_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, x, y, count, lo,
+                       hi, exponent);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_gamma_ste_bwd(const float* x, const float* dy, float* dx, long count, float lo, float hi, float exponent,
+                       void* stream) {
+    if (count < 0 || !(lo > 0.f) || !(hi >= lo)) return NIMG_ERR_ARG;
+    if (count == 0) return NIMG_OK;
+    if (!x || !dy || !dx) return NIMG_ERR_ARG;
+    hipLaunchKernelGGL(gamma_ste_bwd_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, count,
+                       lo, hi, exponent);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+}  // extern "C"

@@ -10,6 +10,14 @@ import numpy as np
 from . import utils
 
 
+def numbers_in_range(dtype, min_value=None, max_value=None):
+    """Validator for tuple-valued parameters (helpers/paramspec.py:20-30 in the reference)."""
+    def check(items):
+        return all(isinstance(i, dtype) and (min_value is None or i >= min_value) and
+                   (max_value is None or i <= max_value) for i in items)
+    return check
+
+
 class ParamSpec(object):
 
     def __init__(self, specs):

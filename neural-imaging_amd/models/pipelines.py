@@ -360,6 +360,155 @@ class DNet(NIPModel):
         return None
 
 
+class ClassicISP(NIPModel):
+    """The classic camera ISP as a differentiable model (pipelines.py:416-514 `_ClassicISP` / `ClassicISP`,
+    models/layers.py:206-258 `DemosaicingLayer`): 1x1 CFA up-sampling (4 -> 12) -> depth_to_space(2) -> demosaicing ->
+    1x1 colour conversion (camera sRGB matrix) -> pow(clip_ste(., 1/255, 1), 1/2.2).
+
+    Demosaicing, residual=True: REFLECT-padded k x k bilinear interpolation x (frozen) minus alpha (trainable scalar,
+    0.1) times a CNN f of the Bayer image: len(c_filters) x [k x k SAME conv + LeakyReLU] -> 1x1 (-> 3) + tanh; with
+    c_filters=() the CNN is skipped (f = 0) and its 1x1 layer is never built.  residual=False: the CNN alone, sigmoid on
+    the 1x1 head.  Both end in a straight-through clip to [0, 1].
+
+    Parameter names: demosaicing/alpha, demosaicing/conv{i}/(kernel|bias), demosaicing/out/(kernel|bias); the constant
+    tensors of the reference (up-sampling, bilinear, sRGB) are held as frozen entries up/kernel, bilinear/kernel,
+    srgb/kernel whose gradients stay zero.  `brightness` never reaches `_ClassicISP` in the reference (it is not a key
+    of the ParamSpec that is forwarded, pipelines.py:472-479), so there is no brightness stage here either."""
+
+    def construct_model(self, srgb_mat=None, kernel=5, c_filters=(), cfa_pattern='gbrg', residual=True, brightness=None):
+        self._h = paramspec.ParamSpec({
+            'kernel': (5, int, (3, 11)),
+            'c_filters': ((), tuple, paramspec.numbers_in_range(int, 1, 1024)),
+            'cfa_pattern': ('gbrg', str, {'gbrg', 'rggb', 'bggr'}),
+            'residual': (True, bool, None),
+        })
+        self._h.update(kernel=kernel, c_filters=tuple(c_filters), cfa_pattern=cfa_pattern, residual=residual)
+        if self._h.kernel not in (3, 5):
+            raise NotImplementedError('demosaicing kernel {} not built (3 | 5)'.format(self._h.kernel))
+        if self.in_channels != 4:
+            raise ValueError('ClassicISP develops 4-plane RAW input')
+        k, res = self._h.kernel, self._h.residual
+        self._convs = []
+        cin = 3
+        for i, nf in enumerate(self._h.c_filters):
+            self._convs.append(Conv2D('demosaicing/conv{}'.format(i), k, cin, int(nf), 'leaky_relu'))
+            cin = int(nf)
+        self._head = Conv2D('demosaicing/out', 1, cin, 3, None) if (self._convs or not res) else None
+        specs = [('demosaicing/alpha', (1,))] if res else []
+        for c in self._convs + ([self._head] if self._head else []):
+            specs += c.specs()
+        specs += [('up/kernel', (1, 1, 4, 12)), ('srgb/kernel', (1, 1, 3, 3))]
+        if res:
+            specs += [('bilinear/kernel', (k, k, 3, 3))]
+        self._model = ParamStore(specs, self.device)
+        gen = torch.Generator().manual_seed(self._seed)
+        for c in self._convs + ([self._head] if self._head else []):
+            c.init(self._model, gen)
+        if res:
+            self._model.p['demosaicing/alpha'].fill_(0.1)
+            self._model.p['bilinear/kernel'].copy_(torch.from_numpy(
+                np.asarray(hk.bilin_kernel(k), np.float32).reshape(k, k, 3, 3)))
+        self._frozen = ('up/kernel', 'srgb/kernel', 'bilinear/kernel')
+        self.set_cfa_pattern(self._h.cfa_pattern)
+        self.set_srgb_conversion(np.eye(3) if srgb_mat is None else srgb_mat)
+        ps = self.patch_size
+        self.y = _Placeholder((None, None if ps is None else 2 * ps, None if ps is None else 2 * ps, 3))
+
+    @property
+    def trainable_names(self):
+        return [k for k in self._model.p if k not in self._frozen]
+
+    def count_parameters(self):
+        """Trainable parameters only - the constants are plain tensors in the reference, not Keras variables."""
+        return int(sum(int(self._model.p[k].numel()) for k in self.trainable_names))
+
+    def set_cfa_pattern(self, cfa_pattern):
+        if cfa_pattern is not None:
+            cfa_pattern = cfa_pattern.lower()
+            up = hk.upsampling_kernel(cfa_pattern).reshape((1, 1, 4, 12)).astype(np.float32)
+            self._model.p['up/kernel'].copy_(torch.from_numpy(up))
+            self._h.update(cfa_pattern=cfa_pattern)
+
+    def set_srgb_conversion(self, srgb_mat):
+        if srgb_mat is not None:
+            srgb = np.ascontiguousarray(np.asarray(srgb_mat, np.float32).T).reshape((1, 1, 3, 3))
+            self._model.p['srgb/kernel'].copy_(torch.from_numpy(srgb))
+
+    def set_camera(self, camera, cameras_json='config/cameras.json'):
+        """Sets both CFA and sRGB from the camera presets (the reference reads config/cameras.json, pipelines.py:499-504)."""
+        import json
+        with open(cameras_json) as f:
+            cameras = json.load(f)
+        self.set_cfa_pattern(cameras[camera]['cfa'])
+        self.set_srgb_conversion(np.array(cameras[camera]['srgb']))
+
+    def process(self, batch_x, training=False, cfa_pattern=None, srgb_mat=None):
+        self.set_cfa_pattern(cfa_pattern)
+        self.set_srgb_conversion(srgb_mat)
+        return super().process(batch_x, training)
+
+    @property
+    def model_code(self):
+        return 'ClassicISP_{cfa}_{k}x{k}_{fs}-{of}{r}'.format(
+            fs='-'.join(['{:d}'.format(x) for x in self._h.c_filters]), of=3, k=self._h.kernel,
+            cfa=self._h.cfa_pattern, r='R' if self._h.residual else '')
+
+    @classmethod
+    def restore(cls, dir_name='data/models/isp/ClassicISP_auto_3x3_32-32-32-32-3R/', *, camera=None, cfa=None, srgb=None,
+                patch_size=128, **kwargs):
+        isp = super().restore(dir_name, patch_size=patch_size, **kwargs)
+        if camera is not None:
+            isp.set_camera(camera)
+        isp.set_cfa_pattern(cfa)
+        isp.set_srgb_conversion(srgb)
+        return isp
+
+    def forward(self, x, training=False):
+        self._model.refresh_images()
+        P, M = self._model.p, self._model
+        t = OrderedDict()
+        bayer = ops.d2s_clip(ops.conv2d(x, P['up/kernel']), 1.0, 0.0, False)
+        t['a0'] = bayer
+        f = None
+        if self._head is not None:
+            f = bayer
+            for i, c in enumerate(self._convs):
+                f = c.forward(M, f)
+                t['a{}'.format(i + 1)] = f
+            z = self._head.forward(M, f)
+            f = ops.tanh(z, out=z) if self._h.residual else ops.sigmoid(z, out=z)
+            t['f'] = f
+        if self._h.residual:
+            xb = ops.conv2d(bayer, P['bilinear/kernel'], pad_mode=ops.PAD_MODES['REFLECT'])
+            rgb = ops.isp_residual(xb, f, P['demosaicing/alpha'], clip=True, out=xb)
+        else:
+            rgb = ops.clip01(f)
+        t['srgb'] = ops.conv2d(rgb, P['srgb/kernel'])
+        return ops.gamma_ste(t['srgb']), (t if training else None)
+
+    def backward(self, t, dy):
+        """dy = d loss / d y.  Only the demosaicing CNN and alpha receive gradients."""
+        P, G, M = self._model.p, self._model.g, self._model
+        hw = (dy.shape[1], dy.shape[2])
+        if self._head is None:
+            return None                                       # f = 0: d y / d alpha = 0, nothing else is trainable
+        d_rgb = ops.conv2d_dgrad(ops.gamma_ste_bwd(t['srgb'], dy), P['srgb/kernel'], hw)
+        if self._h.residual:
+            df = ops.isp_residual_bwd(d_rgb, t['f'], P['demosaicing/alpha'], G['demosaicing/alpha'])
+            dz = ops.tanh_bwd(df, t['f'], out=df)
+        else:
+            dz = ops.sigmoid_bwd(d_rgb, t['f'], out=d_rgb)
+        n = len(self._convs)
+        self._head.backward_params(M, t['a{}'.format(n)], dz)
+        layer = self._head
+        for i in range(n, 0, -1):
+            dz = layer.backward_input(M, dz, hw, act_mask=t['a{}'.format(i)])
+            layer = self._convs[i - 1]
+            layer.backward_params(M, t['a{}'.format(i - 1)], dz)
+        ops.join_side_stream()
+        return None
+
+
 class ONet(NIPModel):
     """Dummy pipeline for RGB training (pipelines.py:353-362): identity, no parameters."""
 
@@ -383,4 +532,4 @@ class ONet(NIPModel):
         return self.class_name
 
 
-supported_models = ['UNet', 'INet', 'DNet', 'ONet']
+supported_models = ['UNet', 'INet', 'DNet', 'ONet', 'ClassicISP']

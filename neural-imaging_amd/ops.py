@@ -882,6 +882,54 @@ def clip01(x, out=None):
     return y
 
 
+# element-wise pieces of ClassicISP (models/pipelines.py:416-453, models/layers.py:206-258)
+def isp_residual(x, f, alpha, clip=True, out=None):
+    """y = [clip01](x - alpha f); f = None -> y = [clip01](x).  alpha: 1-element device tensor."""
+    _f32(x, f, alpha, out)
+    y = torch.empty_like(x) if out is None else out
+    _lib.call('nimg_isp_residual_fwd', _p(x), _p(f), _p(alpha), _p(y), x.numel(), 1 if clip else 0, _stream())
+    return y
+
+
+def isp_residual_bwd(dy, f, alpha, dalpha, accumulate=False):
+    """df = -alpha dy (returned), dalpha (+)= -sum(dy f); the clip of the forward pass is straight-through."""
+    _f32(dy, f, alpha, dalpha)
+    ws = _ws.get(_lib.load().nimg_isp_residual_workspace_bytes(), dy.device)
+    df = torch.empty_like(dy)
+    _lib.call('nimg_isp_residual_bwd', _p(dy), _p(f), _p(alpha), _p(df), _p(dalpha), _p(ws), dy.numel(),
+              1 if accumulate else 0, _stream())
+    return df
+
+
+def sigmoid(x, out=None):
+    _f32(x, out)
+    y = torch.empty_like(x) if out is None else out
+    _lib.call('nimg_sigmoid_fwd', _p(x), _p(y), x.numel(), _stream())
+    return y
+
+
+def sigmoid_bwd(dy, y, out=None):
+    _f32(dy, y, out)
+    dx = torch.empty_like(dy) if out is None else out
+    _lib.call('nimg_sigmoid_bwd', _p(dy), _p(y), _p(dx), dy.numel(), _stream())
+    return dx
+
+
+def gamma_ste(x, lo=1.0 / 255, hi=1.0, exponent=1.0 / 2.2, out=None):
+    """y = pow(clip_ste(x, lo, hi), exponent) - the gamma stage of ClassicISP (pipelines.py:449-451)."""
+    _f32(x, out)
+    y = torch.empty_like(x) if out is None else out
+    _lib.call('nimg_gamma_ste_fwd', _p(x), _p(y), x.numel(), lo, hi, exponent, _stream())
+    return y
+
+
+def gamma_ste_bwd(x, dy, lo=1.0 / 255, hi=1.0, exponent=1.0 / 2.2, out=None):
+    _f32(x, dy, out)
+    dx = torch.empty_like(dy) if out is None else out
+    _lib.call('nimg_gamma_ste_bwd', _p(x), _p(dy), _p(dx), dy.numel(), lo, hi, exponent, _stream())
+    return dx
+
+
 PAD_MODES = {'CONSTANT': 0, 'SYMMETRIC': 1, 'REFLECT': 2}
 
 

@@ -211,6 +211,35 @@ def inet_forward(p, x):
     return y + (torch.clamp(y, 0, 1) - y).detach()
 
 
+def classic_isp_forward(p, x, residual=True):
+    """ClassicISP (models/pipelines.py:416-453 `_ClassicISP.call`; demosaicing = models/layers.py:238-258).  p: up, srgb,
+    [bilinear], demosaicing/alpha, demosaicing/conv{i}, demosaicing/out ('/kernel', '/bias'); the CNN is present iff
+    'demosaicing/out/kernel' is."""
+    ste = lambda t, lo, hi: t + (torch.clamp(t, lo, hi) - t).detach()
+    bayer = T.depth_to_space(T.conv2d(x, p['up/kernel'], None, 1, 'VALID'), 2)
+    f = None
+    if 'demosaicing/out/kernel' in p:
+        f = bayer
+        n = len([k for k in p if k.startswith('demosaicing/conv') and k.endswith('/kernel')])
+        for i in range(n):
+            f = T.leaky_relu(T.conv2d(f, p['demosaicing/conv{}/kernel'.format(i)], p['demosaicing/conv{}/bias'.format(i)],
+                                      1, 'SAME'))
+        f = T.conv2d(f, p['demosaicing/out/kernel'], p['demosaicing/out/bias'], 1, 'VALID')
+        f = torch.tanh(f) if residual else torch.sigmoid(f)
+    if residual:
+        k = p['bilinear/kernel'].shape[0]
+        pad = (k - 1) // 2
+        bp = torch.nn.functional.pad(bayer.permute(0, 3, 1, 2), (pad,) * 4, mode='reflect').permute(0, 2, 3, 1)
+        rgb = T.conv2d(bp, p['bilinear/kernel'], None, 1, 'VALID')
+        if f is not None:
+            rgb = rgb - p['demosaicing/alpha'] * f
+    else:
+        rgb = f
+    rgb = ste(rgb, 0.0, 1.0)
+    srgb = T.conv2d(rgb, p['srgb/kernel'], None, 1, 'VALID')
+    return torch.pow(ste(srgb, 1.0 / 255, 1.0), 1 / 2.2)
+
+
 def dnet_forward(p, x):
     """DNet (models/pipelines.py:298-349).  p: conv0..conv{n-1}, up, proj, out ('/kernel', '/bias')."""
     refl = lambda t, pad: torch.nn.functional.pad(t.permute(0, 3, 1, 2), (pad,) * 4, mode='reflect').permute(0, 2, 3, 1)

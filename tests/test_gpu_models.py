@@ -216,6 +216,66 @@ def test_inet_forward_backward_and_training(dev, kernel, cfa):
     assert net.process(raw[0]).shape == (1, 48, 48, 3)
 
 
+@pytest.mark.parametrize('kernel,c_filters,residual', [(5, (8, 8), True), (3, (16,), True), (5, (), True), (3, (8,), False),
+                                                       (5, (), False)])
+def test_classic_isp_forward_backward_and_training(dev, kernel, c_filters, residual):
+    """ClassicISP (models/pipelines.py:416-514) with its DemosaicingLayer (models/layers.py:206-258): output, the gradient
+    of alpha and of every CNN parameter against the float64 oracle, camera setters, constants stay frozen."""
+    from neural_imaging_amd.models import pipelines
+    from neural_imaging_amd import ops
+    srgb = np.array([[1.6, -0.4, -0.2], [-0.3, 1.5, -0.2], [0.0, -0.5, 1.5]], np.float32)
+    net = pipelines.ClassicISP(patch_size=24, kernel=kernel, c_filters=c_filters, residual=residual, srgb_mat=srgb,
+                               cfa_pattern='rggb', device=dev)
+    fs = '-'.join(str(c) for c in c_filters)
+    assert net.model_code == 'ClassicISP_rggb_{k}x{k}_{fs}-3{r}'.format(k=kernel, fs=fs, r='R' if residual else '')
+    chans = (3,) + tuple(c_filters)
+    n_cnn = sum(kernel * kernel * a * b + b for a, b in zip(chans[:-1], chans[1:])) + chans[-1] * 3 + 3
+    has_cnn = bool(c_filters) or not residual
+    assert net.count_parameters() == (1 if residual else 0) + (n_cnn if has_cnn else 0)
+    rgb = natural_images(3, 48, 48, seed=31)
+    raw = bayer_from_rgb(rgb)
+    if has_cnn:                                                # a larger head so that tanh / sigmoid leave the linear range
+        w = net._model.p['demosaicing/out/kernel']
+        w.mul_(6.0)
+        net._model.p['demosaicing/out/bias'].copy_(torch.tensor([0.3, -0.2, 0.1]))
+    p = oracle_params(net)
+    train = [k for k in net.trainable_names if has_cnn or k != 'demosaicing/alpha']
+    for k in train:
+        p[k].requires_grad_(True)
+    y_ref = onets.classic_isp_forward(p, to64(raw), residual=residual)
+    loss_ref = T.mse255(y_ref, to64(rgb))
+    y, ctx = net.forward(torch.from_numpy(raw).to(dev), training=True)
+    assert y.shape == (3, 48, 48, 3)
+    assert_close(y.cpu().numpy(), y_ref.detach().numpy(), 2e-5, what='ClassicISP output')
+    loss, dy = ops.mse255(y, torch.from_numpy(rgb).to(dev), grad_scale=1.0)
+    assert abs(float(loss.item()) - float(loss_ref)) / float(loss_ref) < 1e-5
+    net.backward(ctx, dy)
+    got = grads_of(net)
+    if train:
+        g_ref = dict(zip(train, torch.autograd.grad(loss_ref, [p[k] for k in train])))
+        check_grads(got, g_ref, train, tol=3e-4)
+    for k in ('up/kernel', 'srgb/kernel') + (('bilinear/kernel',) if residual else ()):
+        assert np.abs(got[k]).max() == 0
+    if not has_cnn:
+        assert np.abs(got['demosaicing/alpha']).max() == 0
+    # training moves the CNN (if any) and leaves the constants alone; the setters replace the constants
+    net = pipelines.ClassicISP(patch_size=24, kernel=kernel, c_filters=c_filters, residual=residual, cfa_pattern='rggb',
+                               device=dev)
+    const0 = {k: net.state_dict()[k].copy() for k in ('up/kernel', 'srgb/kernel')}
+    target = np.power(rgb, 1 / 2.2).astype(np.float32)
+    losses = [float(net.training_step(raw, target, learning_rate=1e-3)) for _ in range(20)]
+    assert np.isfinite(losses).all()
+    if has_cnn:
+        assert losses[-1] < losses[0], losses
+    for k, v in const0.items():
+        assert np.array_equal(net.state_dict()[k], v)
+    out = net.process(raw[0], cfa_pattern='GBRG', srgb_mat=np.eye(3))
+    assert out.shape == (1, 48, 48, 3) and net._h.cfa_pattern == 'gbrg'
+    assert np.array_equal(net.state_dict()['srgb/kernel'].reshape(3, 3), np.eye(3, dtype=np.float32))
+    from neural_imaging_amd.helpers import kernels as hk
+    assert np.array_equal(net.state_dict()['up/kernel'].reshape(4, 12), hk.upsampling_kernel('gbrg').reshape(4, 12))
+
+
 def test_workflow_with_inet(dev):
     """train_manipulation.py --nip INet --train nip (config/tests/framework.json 'train-manipulation')."""
     from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification

@@ -29,6 +29,9 @@ def to64(a):
 def err(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.size == 0:
+        return 0.0, 0.0
     d = np.abs(a - b)
     return float(d.max()), float(d.max() / (np.abs(b).max() + 1e-30))
 
