@@ -139,6 +139,16 @@ int nimg_avgpool_bwd(const float* dy, float* dx, int n, int h, int w, int c, int
 size_t nimg_mse255_workspace_bytes(void);
 int nimg_mse255(const float* a, const float* b, float* loss, float* grad_a, long count, float grad_scale,
                 int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* helpers/tf_helpers.py:35-36  loss = mean |255a - 255b|; grad_a (+)= grad_scale * 255 sign(a - b) / count (NIP --loss L1) */
+size_t nimg_mae255_workspace_bytes(void);
+int nimg_mae255(const float* a, const float* b, float* loss, float* grad_a, long count, float grad_scale,
+                int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* helpers/tf_helpers.py:39-40  loss = mean_n 255 (1 - tf.image.ssim(y, t, max_val)_n)  (NIP --loss SSIM); y, t (n,h,w,c),
+ * h, w >= 11; gauss_win = the 121 window weights (device); grad_y (may be NULL) (+)= grad_scale * dloss/dy. */
+size_t nimg_ssim_loss_workspace_bytes(int n, int h, int w, int c, int with_grad);
+int nimg_ssim_loss(const float* y, const float* t, float* loss, float* grad_y, int n, int h, int w, int c,
+                   float max_val, const float* gauss_win, float grad_scale, int accumulate, void* workspace,
+                   size_t workspace_bytes, void* stream);
 /* SSIM per image (mean over channels and VALID window positions), a/b (n,h,w,c) in [0,max_val], out (n).
  *   mode 0 = skimage.metrics.structural_similarity(multichannel=True, data_range=max_val) as helpers/metrics.py:9-25 uses
  *            it (7x7 uniform window, sample covariance);   mode 1 = tf.image.ssim(max_val) as models/compression.py:89

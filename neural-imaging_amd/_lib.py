@@ -85,6 +85,10 @@ PROTOTYPES = {
     'nimg_sigmoid_bwd': (c_int, [P, P, P, c_long, P]),
     'nimg_gamma_ste_fwd': (c_int, [P, P, c_long, c_float, c_float, c_float, P]),
     'nimg_gamma_ste_bwd': (c_int, [P, P, P, c_long, c_float, c_float, c_float, P]),
+    'nimg_mae255_workspace_bytes': (c_size_t, []),
+    'nimg_mae255': (c_int, [P, P, P, P, c_long, c_float, c_int, P, c_size_t, P]),
+    'nimg_ssim_loss_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    'nimg_ssim_loss': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, P, c_float, c_int, P, c_size_t, P]),
     'nimg_pad2d': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'nimg_conv2d_fwd_bf16_ex': (c_int, [P, c_int, P, c_int, P, P, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int,
                                         c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),

@@ -35,12 +35,18 @@ class NIPModel(TFModel):
         self.construct_loss(loss_metric)
 
     def construct_loss(self, loss_metric):
-        if loss_metric == 'L2':
-            self.loss = lambda a, b: DeviceArray(ops.mse255(to_device(a, self.device), to_device(b, self.device))[0])
-        elif loss_metric in ('L1', 'SSIM', 'MS-SSIM'):
-            raise NotImplementedError('loss metric {} is not built yet (SURVEY 8f)'.format(loss_metric))
+        """L2 | L1 | SSIM on 255-scaled images (pipelines.py:53-63 -> helpers/tf_helpers.py:31-40)."""
+        if loss_metric in ops.IMAGE_LOSSES:
+            self._loss_fn = ops.IMAGE_LOSSES[loss_metric]
+            self.loss = lambda a, b: DeviceArray(self._loss_fn(to_device(a, self.device), to_device(b, self.device))[0])
+        elif loss_metric == 'MS-SSIM':
+            raise NotImplementedError('loss metric MS-SSIM is not built (tf.image.ssim_multiscale, 5 scales)')
         else:
             raise ValueError('Unsupported loss metric!')
+
+    def loss_and_grad(self, y, target, grad_scale=1.0, grad_out=None, accumulate=False):
+        """(loss[1], grad_scale * d loss / d y) of the configured metric; grad_out (+)= when accumulate."""
+        return self._loss_fn(y, target, grad_scale=grad_scale, grad_out=grad_out, accumulate=accumulate)
 
     def construct_model(self):
         raise NotImplementedError()
@@ -53,11 +59,11 @@ class NIPModel(TFModel):
         raise NotImplementedError()
 
     def training_step(self, batch_x, batch_y, learning_rate=None):
-        """One step on mse(255 Y, 255 y) (pipelines.py:77-90). Returns the loss."""
+        """One step on the configured loss of (255 Y, 255 y) (pipelines.py:77-90). Returns the loss."""
         x = to_device(batch_x, self.device)
         t = to_device(batch_y, self.device)
         y, ctx = self.forward(x, training=True)
-        loss, dy = ops.mse255(y, t, grad_scale=1.0)
+        loss, dy = self.loss_and_grad(y, t)
         self.backward(ctx, dy)
         if learning_rate is not None:
             self.learning_rate = learning_rate

@@ -846,17 +846,53 @@ def ssim(a, b, mode='skimage', max_val=1.0):
     m = {'skimage': 0, 'tf': 1}[mode]
     gk = None
     if m == 1:
-        key = str(a.device)
-        if key not in _SSIM_GAUSS:           # tf _fspecial_gauss: softmax of -(x^2 + y^2) / (2 sigma^2)
-            co = np.arange(11, dtype=np.float64) - 5.0
-            g = -0.5 * (co[:, None] ** 2 + co[None, :] ** 2) / 1.5 ** 2
-            g = np.exp(g - g.max())
-            _SSIM_GAUSS[key] = torch.from_numpy((g / g.sum()).astype(np.float32).ravel()).to(a.device)
-        gk = _SSIM_GAUSS[key]
+        gk = _ssim_window(a.device)
     out = torch.empty((n,), dtype=torch.float32, device=a.device)
     ws = _ws.get(_lib.load().nimg_ssim_workspace_bytes(n), a.device)
     _lib.call('nimg_ssim', _p(a), _p(b), _p(out), n, h, w, c, m, float(max_val), _p(gk), _p(ws), ws.numel(), _stream())
     return out
+
+
+def _ssim_window(device):
+    key = str(device)
+    if key not in _SSIM_GAUSS:           # tf _fspecial_gauss: softmax of -(x^2 + y^2) / (2 sigma^2)
+        co = np.arange(11, dtype=np.float64) - 5.0
+        g = -0.5 * (co[:, None] ** 2 + co[None, :] ** 2) / 1.5 ** 2
+        g = np.exp(g - g.max())
+        _SSIM_GAUSS[key] = torch.from_numpy((g / g.sum()).astype(np.float32).ravel()).to(device)
+    return _SSIM_GAUSS[key]
+
+
+def mae255(a, b, grad_scale=None, grad_out=None, accumulate=False):
+    """helpers/tf_helpers.py:35-36 mean |255a - 255b|.  Returns (loss[1], grad wrt a or None), like mse255."""
+    _f32(a, b, grad_out)
+    loss = torch.empty((1,), dtype=torch.float32, device=a.device)
+    g = None
+    if grad_scale is not None:
+        g = torch.empty_like(a) if grad_out is None else grad_out
+    ws = _ws.get(_lib.load().nimg_mae255_workspace_bytes(), a.device)
+    _lib.call('nimg_mae255', _p(a), _p(b), _p(loss), _p(g), a.numel(), float(grad_scale or 0.0),
+              1 if accumulate else 0, _p(ws), ws.numel(), _stream())
+    return loss, g
+
+
+def ssim_loss(y, t, grad_scale=None, grad_out=None, accumulate=False, max_val=1.0):
+    """helpers/tf_helpers.py:39-40 mean 255 (1 - tf.image.ssim(y, t, 1)).  Returns (loss[1], grad wrt y or None)."""
+    _f32(y, t, grad_out)
+    n, h, w, c = y.shape
+    if h < 11 or w < 11:
+        raise ValueError('tf.image.ssim needs images of at least 11 x 11 pixels')
+    loss = torch.empty((1,), dtype=torch.float32, device=y.device)
+    g = None
+    if grad_scale is not None:
+        g = torch.empty_like(y) if grad_out is None else grad_out
+    ws = _ws.get(_lib.load().nimg_ssim_loss_workspace_bytes(n, h, w, c, 0 if g is None else 1), y.device)
+    _lib.call('nimg_ssim_loss', _p(y), _p(t), _p(loss), _p(g), n, h, w, c, float(max_val), _p(_ssim_window(y.device)),
+              float(grad_scale or 0.0), 1 if accumulate else 0, _p(ws), ws.numel(), _stream())
+    return loss, g
+
+
+IMAGE_LOSSES = {'L2': mse255, 'L1': mae255, 'SSIM': ssim_loss}
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -279,12 +279,12 @@ class ManipulationClassification(object):
             dY = dm[:b].clone() if len(self._operations) else dm[:b]
             for k, (name, op) in enumerate(self._operations.items()):
                 ops.add(dY, op.backward(mctxs[k], dm[(k + 1) * b:(k + 2) * b]), out=dY)
-            loss_nip, _ = ops.mse255(Y, target, grad_scale=float(lambda_nip), grad_out=dY, accumulate=True)
+            loss_nip, _ = self.nip.loss_and_grad(Y, target, grad_scale=float(lambda_nip), grad_out=dY, accumulate=True)
             self.nip.backward(nctx, dY)
             ops.nan_flag(self.nip._model.flat_grad, self._nan_flag)
             self._bucket.launch(self.nip._model.flat_grad)
         else:
-            loss_nip, _ = ops.mse255(Y, target)
+            loss_nip, _ = self.nip._loss_fn(Y, target)
         parallel.all_reduce_flag(self._nan_flag)
         if self._nan_check == 'eager' and int(self._nan_flag.item()) != 0:       # host sync, like the reference
             self._bucket.wait()

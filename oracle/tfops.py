@@ -332,3 +332,12 @@ def ssim_tf(a, b, max_val=1.0):
     num1, den1 = f(a * b) * 2.0, f(a * a + b * b)
     cs = (num1 - num0 + c2) / (den1 - den0 + c2)
     return (lum * cs).mean(dim=(2, 3)).mean(dim=1)
+
+
+def ssim_loss255(a, b):
+    """helpers/tf_helpers.py:39-40: mean over the batch of 255 (1 - tf.image.ssim(a, b, 1.0))."""
+    return torch.mean(255 * (1 - ssim_tf(a, b, 1.0)))
+
+
+IMAGE_LOSSES = {'L2': mse255, 'L1': mae255, 'SSIM': ssim_loss255}
+

@@ -276,6 +276,36 @@ def test_classic_isp_forward_backward_and_training(dev, kernel, c_filters, resid
     assert np.array_equal(net.state_dict()['up/kernel'].reshape(4, 12), hk.upsampling_kernel('gbrg').reshape(4, 12))
 
 
+@pytest.mark.parametrize('metric', ['L1', 'SSIM'])
+def test_nip_loss_metrics(dev, metric):
+    """NIPModel(loss_metric=...) (models/pipelines.py:53-63): loss value and every UNet gradient of one training step on
+    the L1 / SSIM loss against autograd through the float64 oracle; MS-SSIM is refused."""
+    from neural_imaging_amd.models import pipelines
+    net = pipelines.UNet(loss_metric=metric, patch_size=16, device=dev)
+    rgb = natural_images(2, 32, 32, seed=11)
+    raw = bayer_from_rgb(rgb)
+    p = oracle_params(net)
+    names = list(p.keys())
+    for k in names:
+        p[k].requires_grad_(True)
+    y_ref = onets.unet_forward(p, to64(raw))
+    y_ref = y_ref[0] if isinstance(y_ref, tuple) else y_ref
+    loss_ref = T.IMAGE_LOSSES[metric](y_ref, to64(rgb))
+    g_ref = dict(zip(names, torch.autograd.grad(loss_ref, [p[k] for k in names])))
+    y, ctx = net.forward(torch.from_numpy(raw).to(dev), training=True)
+    loss, dy = net.loss_and_grad(y, torch.from_numpy(rgb).to(dev))
+    assert abs(float(loss.item()) - float(loss_ref)) / float(loss_ref) < 1e-5
+    assert abs(float(net.loss(y, rgb)) - float(loss_ref)) / float(loss_ref) < 1e-5
+    net.backward(ctx, dy)
+    check_grads(grads_of(net), g_ref, names, tol=3e-4)
+    l0 = float(net.training_step(raw, rgb, learning_rate=1e-3))
+    for _ in range(10):
+        l1 = float(net.training_step(raw, rgb, learning_rate=1e-3))
+    assert l1 < l0
+    with pytest.raises(NotImplementedError):
+        pipelines.UNet(loss_metric='MS-SSIM', patch_size=16, device=dev)
+
+
 def test_workflow_with_inet(dev):
     """train_manipulation.py --nip INet --train nip (config/tests/framework.json 'train-manipulation')."""
     from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification

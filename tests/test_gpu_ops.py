@@ -704,3 +704,31 @@ def test_classic_isp_pointwise(dev, count):
         gg, = torch.autograd.grad((g_ref * to64(dy)).sum(), [vt])
         assert_close(ops.gamma_ste_bwd(g(v, dev), g(dy, dev)).cpu().numpy(), gg.numpy(), 1e-5, what='d gamma')
 
+
+@pytest.mark.parametrize('metric,shape', [('L1', (2, 16, 16, 3)), ('L1', (1, 7, 5, 3)), ('SSIM', (3, 32, 40, 3)),
+                                          ('SSIM', (1, 11, 11, 3)), ('SSIM', (2, 17, 12, 1)), ('L2', (2, 16, 16, 3))])
+def test_image_losses_with_gradient(dev, metric, shape):
+    """The NIP training losses (helpers/tf_helpers.py:31-40 via models/pipelines.py:53-63): value, gradient w.r.t. the
+    developed image, gradient accumulation with a scale (the workflow's lambda_nip term)."""
+    from neural_imaging_amd import ops
+    n, h, w, c = shape
+    t = natural_images(n, h, w, seed=5)[..., :c].copy()
+    y = np.clip(t + 0.08 * rnd(t.shape, 6), 0, 1).astype(np.float32)
+    y[0, 0, 0, 0] = t[0, 0, 0, 0]                            # an exact tie: tf.abs has a zero gradient there
+    yt = to64(y).requires_grad_(True)
+    ref = T.IMAGE_LOSSES[metric](yt, to64(t))
+    gref, = torch.autograd.grad(ref, [yt])
+    fn = ops.IMAGE_LOSSES[metric]
+    loss, grad = fn(g(y, dev), g(t, dev), grad_scale=1.0)
+    assert abs(float(loss.item()) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    assert_close(grad.cpu().numpy(), gref.numpy(), 1e-7, 1e-5, what=metric + ' gradient')
+    base = rnd(t.shape, 7)
+    acc = g(base, dev)
+    loss2, out = fn(g(y, dev), g(t, dev), grad_scale=0.25, grad_out=acc, accumulate=True)
+    assert out is acc and float(loss2.item()) == float(loss.item())
+    assert_close(acc.cpu().numpy(), base + 0.25 * gref.numpy(), 1e-6, 1e-5, what=metric + ' accumulated gradient')
+    assert fn(g(y, dev), g(t, dev))[1] is None
+    if metric == 'SSIM':
+        with pytest.raises(ValueError):
+            ops.ssim_loss(g(y[:, :10], dev), g(t[:, :10], dev))
+
