@@ -415,6 +415,7 @@ class ClassicISP(NIPModel):
             self._model.p['bilinear/kernel'].copy_(torch.from_numpy(
                 np.asarray(hk.bilin_kernel(k), np.float32).reshape(k, k, 3, 3)))
         self._frozen = ('up/kernel', 'srgb/kernel', 'bilinear/kernel')
+        self._h5_skip = ('up/kernel', 'srgb/kernel')     # tf constants in the reference, not Keras variables
         self.set_cfa_pattern(self._h.cfa_pattern)
         self.set_srgb_conversion(np.eye(3) if srgb_mat is None else srgb_mat)
         ps = self.patch_size

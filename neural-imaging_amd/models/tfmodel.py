@@ -4,8 +4,9 @@ performance log, parameter access/count, save/load, restore, process.  Parameter
 buffer per model (`flat_params`), each named parameter being a view in the Keras layout; gradients use a twin buffer
 (`flat_grads`) - that buffer is also the RCCL all-reduce unit and the fused-Adam unit.
 
-Checkpoints: <dir>/<scoped_name>/<classname>.npz (+ optional <classname>.json {'model', 'args'}), same directory layout
-and JSON contract as tfmodel.py:150-182; the Keras .h5 container itself is SURVEY 8(f) "next" (no h5py in this image).
+Checkpoints: <dir>/<scoped_name>/<classname>.h5 in the Keras `save_weights` layout (helpers/keras_h5.py over a pure-Python
+HDF5 codec - no h5py in this image) + optional <classname>.json {'model', 'args'}: directory layout and JSON contract of
+tfmodel.py:150-182.
 """
 import json
 import os
@@ -128,11 +129,52 @@ class TFModel(object):
             v.copy_(torch.from_numpy(a))
 
     # -- checkpoints (tfmodel.py:150-182) ------------------------------------------------------------------------
+    _h5_skip = ()            # parameter names that are constants (not Keras variables) in the reference: never stored
+
+    def keras_layers(self):
+        """[(layer name, [(weight name, ndarray)])] - the parameters grouped the way Keras lists them: consecutive
+        entries that share the prefix before the last '/' form one layer ('/' -> '_' in the layer name)."""
+        layers = []
+        for k, v in self.state_dict().items():
+            if k in self._h5_skip:
+                continue
+            prefix, _, leaf = k.rpartition('/')
+            lname = (prefix or leaf).replace('/', '_')
+            if not layers or layers[-1][0] != lname:
+                layers.append((lname, []))
+            layers[-1][1].append(('{}/{}:0'.format(lname, leaf), v))
+        return layers
+
+    def load_keras_weights(self, filename):
+        """Keras' default h5 loading rule (topological = file order, layers without weights skipped), with the shapes
+        checked one by one; scalars may be stored as () or (1,)."""
+        from ..helpers import keras_h5
+        flat = [(l, w, a) for l, ws in keras_h5.load_weights(filename) for w, a in ws]
+        names = [k for k in self._model.p if k not in self._h5_skip]
+        if len(flat) != len(names):
+            raise ValueError('{} holds {} weight tensors, {} expects {}'.format(filename, len(flat), self.class_name,
+                                                                                len(names)))
+        state = {}
+        for k, (l, w, a) in zip(names, flat):
+            want = tuple(self._model.p[k].shape)
+            if tuple(a.shape) != want and int(a.size) == int(np.prod(want)) and \
+                    tuple(d for d in a.shape if d != 1) == tuple(d for d in want if d != 1):
+                a = a.reshape(want)
+            if tuple(a.shape) != want:
+                raise ValueError('{}: weight {} of layer {} has shape {}, parameter {} expects {}'.format(
+                    filename, w, l, tuple(a.shape), k, want))
+            state[k] = a
+        for k in self._h5_skip:
+            if k in self._model.p:
+                state[k] = self._model.p[k].detach().cpu().numpy()
+        self.load_state_dict(state)
+
     def save_model(self, dirname, epoch=0, save_args=False, quiet=False):
+        from ..helpers import keras_h5
         if not dirname.endswith(self.scoped_name):
             dirname = os.path.join(dirname, self.scoped_name)
         os.makedirs(dirname, exist_ok=True)
-        np.savez(os.path.join(dirname, '{}.npz'.format(self.class_name.lower())), **self.state_dict())
+        keras_h5.save_weights(os.path.join(dirname, '{}.h5'.format(self.class_name.lower())), self.keras_layers())
         if save_args:
             with open(os.path.join(dirname, '{}.json'.format(self.class_name.lower())), 'w') as f:
                 json.dump({'model': self.class_name, 'args': self.get_hyperparameters()}, f, indent=4)
@@ -140,11 +182,15 @@ class TFModel(object):
     def load_model(self, dirname, quiet=False):
         if not dirname.endswith(self.scoped_name):
             dirname = os.path.join(dirname, self.scoped_name)
-        filename = os.path.join(dirname, '{}.npz'.format(self.class_name.lower()))
-        if not os.path.isfile(filename):
-            raise FileNotFoundError(filename)
-        with np.load(filename) as data:
-            self.load_state_dict({k: data[k] for k in data.files})
+        filename = os.path.join(dirname, '{}.h5'.format(self.class_name.lower()))
+        if os.path.isfile(filename):
+            self.load_keras_weights(filename)
+        else:
+            legacy = os.path.join(dirname, '{}.npz'.format(self.class_name.lower()))      # round-1 snapshots
+            if not os.path.isfile(legacy):
+                raise FileNotFoundError(filename)
+            with np.load(legacy) as data:
+                self.load_state_dict({k: data[k] for k in data.files})
         self.reset_performance_stats()
 
     @classmethod

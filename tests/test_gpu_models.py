@@ -701,7 +701,7 @@ def test_training_harness_outputs(dev, tmp_path):
     assert len(prog['forensics']['performance']['accuracy']['validation']) == 2        # epochs 0 and 2
     assert len(prog['nip']['performance']['loss']['training']) == 3
     assert len(prog['nip']['performance']['psnr']['validation']) >= 1
-    assert os.path.isfile(os.path.join(mdir, 'fan', 'fan.npz')) and os.path.isfile(os.path.join(mdir, 'unet', 'unet.npz'))
+    assert os.path.isfile(os.path.join(mdir, 'fan', 'fan.h5')) and os.path.isfile(os.path.join(mdir, 'unet', 'unet.h5'))
     before = os.path.getmtime(os.path.join(run_dir, 'training.json'))
     assert tm.train_manipulation_nip(wf, spec, data, {'root': str(tmp_path)}) == mdir   # exists => skipped
     assert os.path.getmtime(os.path.join(run_dir, 'training.json')) == before
