@@ -201,6 +201,24 @@ int nimg_sparse_axis_apply(const float* in, float* out, const int* rowptr, const
                            int hin, int win, int c, int axis, int out_size, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * GPU-resident training-data feed (helpers/dataset.py:89-131 `Dataset.next_training_batch`, helpers/loading.py:132-211
+ * `sample_patch`).  rgb: (n_images, h, w, 3) uint8, raw: (n_images, h/2, w/2, 4) uint16, both resident in HBM.
+ * image_idx (b) picks the image of every batch entry; cand_xy (b, attempts, 2) are candidate (xx, yy) patch corners (even
+ * numbers, the Bayer alignment of loading.py:160-161); patch = RGB patch size (even).
+ *  stats:  var / mean (b, attempts) of every candidate patch / 255 (np.var, np.mean over all three channels; :166-168).
+ *  select: the discard policy over each image's candidates -> chosen_xy (b, 2); mode 0 none, 1 'flat' (uniforms (b,
+ *          attempts) feed its coin flip, :177-178), 2 'flat-aggressive', 3 'dark-n-textured'; max_attempts = the panic
+ *          counter (:156); attempts_used (b, may be NULL) = candidates consumed.
+ *  gather: x_out (b, patch/2, patch/2, 4) = raw crop / 65535, y_out (b, patch, patch, 3) = rgb crop / 255 (either may be
+ *          NULL), float32 of the float64 quotient like dataset.py:124-126. */
+int nimg_patch_stats(const uint8_t* rgb, int n_images, int h, int w, const int* image_idx, const int* cand_xy, int b,
+                     int attempts, int patch, double* var_out, double* mean_out, void* stream);
+int nimg_patch_select(const int* cand_xy, const float* uniforms, const double* var, const double* mean, int b,
+                      int attempts, int max_attempts, int mode, int* chosen_xy, int* attempts_used, void* stream);
+int nimg_patch_gather(const uint16_t* raw, const uint8_t* rgb, int n_images, int h, int w, const int* image_idx,
+                      const int* xy, int b, int patch, float* x_out, float* y_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Learned codec (TwitterDCN, models/compression.py:197-279) specific pieces */
 int nimg_affine(const float* x, float* y, long count, float a, float b, void* stream);     /* y = a*x + b (:219,:268) */
 int nimg_lrelu_fwd(const float* x, float* y, long count, float alpha, void* stream);       /* tf.nn.leaky_relu (:224) */

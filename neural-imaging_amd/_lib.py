@@ -89,6 +89,9 @@ PROTOTYPES = {
     'nimg_mae255': (c_int, [P, P, P, P, c_long, c_float, c_int, P, c_size_t, P]),
     'nimg_ssim_loss_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     'nimg_ssim_loss': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, P, c_float, c_int, P, c_size_t, P]),
+    'nimg_patch_stats': (c_int, [P, c_int, c_int, c_int, P, P, c_int, c_int, c_int, P, P, P]),
+    'nimg_patch_select': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P, P]),
+    'nimg_patch_gather': (c_int, [P, P, c_int, c_int, c_int, P, P, c_int, c_int, P, P, P]),
     'nimg_pad2d': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'nimg_conv2d_fwd_bf16_ex': (c_int, [P, c_int, P, c_int, P, P, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int,
                                         c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),

@@ -896,6 +896,60 @@ IMAGE_LOSSES = {'L2': mse255, 'L1': mae255, 'SSIM': ssim_loss}
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# GPU-resident data feed (helpers/dataset.py:89-131, helpers/loading.py:132-211)
+DISCARD_MODES = {None: 0, 'flat': 1, 'flat-aggressive': 2, 'dark-n-textured': 3}
+
+
+def _feed_chk(t, dtype, what):
+    if t is None:
+        return
+    if not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+        raise TypeError('{}: contiguous {} tensor on the GPU expected, got {} on {}'.format(what, dtype, t.dtype, t.device))
+
+
+def patch_stats(rgb, image_idx, cand_xy, patch):
+    """rgb (n, H, W, 3) uint8, image_idx (B) int32, cand_xy (B, A, 2) int32 -> (var, mean) float64 (B, A)."""
+    _feed_chk(rgb, torch.uint8, 'rgb'), _feed_chk(image_idx, torch.int32, 'image_idx'), _feed_chk(cand_xy, torch.int32, 'cand_xy')
+    n, h, w, _ = rgb.shape
+    b, a = cand_xy.shape[0], cand_xy.shape[1]
+    var = torch.empty((b, a), dtype=torch.float64, device=rgb.device)
+    mean = torch.empty_like(var)
+    _lib.call('nimg_patch_stats', _p(rgb), n, h, w, _p(image_idx), _p(cand_xy), b, a, int(patch), _p(var), _p(mean), _stream())
+    return var, mean
+
+
+def patch_select(cand_xy, uniforms, var, mean, discard, max_attempts):
+    """The discard policy over (B, A) candidates -> (chosen_xy (B, 2) int32, candidates consumed (B) int32)."""
+    _feed_chk(cand_xy, torch.int32, 'cand_xy'), _feed_chk(uniforms, torch.float32, 'uniforms')
+    _feed_chk(var, torch.float64, 'var'), _feed_chk(mean, torch.float64, 'mean')
+    b, a = cand_xy.shape[0], cand_xy.shape[1]
+    xy = torch.empty((b, 2), dtype=torch.int32, device=cand_xy.device)
+    used = torch.empty((b,), dtype=torch.int32, device=cand_xy.device)
+    _lib.call('nimg_patch_select', _p(cand_xy), _p(uniforms), _p(var), _p(mean), b, a, int(max_attempts),
+              DISCARD_MODES[discard], _p(xy), _p(used), _stream())
+    return xy, used
+
+
+def patch_gather(raw, rgb, image_idx, xy, patch):
+    """raw (n, H/2, W/2, 4) uint16 (stored as int16 bits) | None, rgb (n, H, W, 3) uint8 | None, xy (B, 2) int32 ->
+    (x (B, p/2, p/2, 4) | None, y (B, p, p, 3) | None) float32."""
+    _feed_chk(raw, torch.int16, 'raw'), _feed_chk(rgb, torch.uint8, 'rgb')
+    _feed_chk(image_idx, torch.int32, 'image_idx'), _feed_chk(xy, torch.int32, 'xy')
+    if raw is None and rgb is None:
+        raise ValueError('nothing to gather')
+    if rgb is not None:
+        n, h, w, _ = rgb.shape
+    else:
+        n, h, w = raw.shape[0], 2 * raw.shape[1], 2 * raw.shape[2]
+    b, p = xy.shape[0], int(patch)
+    dev = xy.device
+    x = None if raw is None else torch.empty((b, p // 2, p // 2, 4), dtype=torch.float32, device=dev)
+    y = None if rgb is None else torch.empty((b, p, p, 3), dtype=torch.float32, device=dev)
+    _lib.call('nimg_patch_gather', _p(raw), _p(rgb), n, h, w, _p(image_idx), _p(xy), b, p, _p(x), _p(y), _stream())
+    return x, y
+
+
+# ----------------------------------------------------------------------------------------------------------------
 # element-wise pieces of the INet / DNet pipelines
 def tanh(x, out=None):
     _f32(x, out)

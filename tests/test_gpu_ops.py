@@ -732,3 +732,102 @@ def test_image_losses_with_gradient(dev, metric, shape):
         with pytest.raises(ValueError):
             ops.ssim_loss(g(y[:, :10], dev), g(t[:, :10], dev))
 
+
+def _feed_images(n, h, w, seed):
+    rng = np.random.RandomState(seed)
+    rgb = np.zeros((n, h, w, 3), np.uint8)
+    for i in range(n):
+        base = np.full((h, w, 3), 40.0 + 25 * i)
+        base[h // 4:h // 2, w // 3:] += 80 * rng.uniform(-1, 1, (h // 2 - h // 4, w - w // 3, 3))
+        base[:, :w // 4] += 15 * np.sin(np.arange(w // 4) / 2.0)[None, :, None]
+        rgb[i] = np.clip(base + rng.normal(0, 2, (h, w, 3)), 0, 255)
+    rgb[n - 1] = 77                                           # a perfectly flat image: variance exactly 0
+    raw = rng.randint(0, 65536, (n, h // 2, w // 2, 4)).astype(np.uint16)
+    return raw, rgb
+
+
+@pytest.mark.parametrize('discard', [None, 'flat', 'flat-aggressive', 'dark-n-textured'])
+@pytest.mark.parametrize('patch,attempts,max_attempts', [(32, 12, 5), (64, 30, 25), (96, 4, 4)])
+def test_device_data_feed_kernels(dev, discard, patch, attempts, max_attempts):
+    """nimg_patch_stats / _select / _gather (helpers/dataset.py:89-131, helpers/loading.py:132-211) against the oracle that
+    is pinned on the reference's own sample_patch: patch moments, the discard policy over a given candidate list (same
+    corner, same number of candidates consumed), and the cut batch bit for bit."""
+    from oracle import datafeed as odf
+    from neural_imaging_amd import ops
+    raw, rgb = _feed_images(6, 96, 128, 9)
+    rng = np.random.RandomState(patch + attempts)
+    b = 9
+    image_idx = rng.randint(0, 6, b).astype(np.int32)
+    image_idx[-1] = 5
+    cand = np.stack([2 * (rng.randint(0, max(128 - patch, 1), (b, attempts)) // 2),
+                     2 * (rng.randint(0, max(96 - patch, 1), (b, attempts)) // 2)], axis=2).astype(np.int32)
+    uni = rng.uniform(size=(b, attempts)).astype(np.float32)
+    d_rgb = torch.from_numpy(rgb).to(dev)
+    d_raw = torch.from_numpy(raw.view(np.int16)).to(dev)
+    d_idx, d_cand, d_uni = torch.from_numpy(image_idx).to(dev), torch.from_numpy(cand).to(dev), torch.from_numpy(uni).to(dev)
+    var, mean = ops.patch_stats(d_rgb, d_idx, d_cand, patch)
+    ref = np.array([[odf.patch_stats(rgb[image_idx[i]], cand[i, k, 0], cand[i, k, 1], patch) for k in range(attempts)]
+                    for i in range(b)])
+    assert np.abs(var.cpu().numpy() - ref[..., 0]).max() < 1e-13 and np.abs(mean.cpu().numpy() - ref[..., 1]).max() < 1e-13
+    assert (var.cpu().numpy()[-1] == 0).all()                 # flat image: exactly zero, like np.var
+    xy, used = ops.patch_select(d_cand, d_uni, var if discard else None, mean if discard else None, discard, max_attempts)
+    want = [odf.select(rgb[image_idx[i]], [tuple(c) for c in cand[i]], uni[i], patch, discard, max_attempts)
+            for i in range(b)]
+    assert xy.cpu().numpy().tolist() == [list(w[0]) for w in want]
+    assert used.cpu().numpy().tolist() == [w[1] for w in want]
+    x, y = ops.patch_gather(d_raw, d_rgb, d_idx, xy, patch)
+    xr, yr = odf.cut_batch(raw, rgb, image_idx, [w[0] for w in want], patch)
+    assert x.dtype == torch.float32 and np.array_equal(x.cpu().numpy(), xr) and np.array_equal(y.cpu().numpy(), yr)
+    only_y = ops.patch_gather(None, d_rgb, d_idx, xy, patch)
+    assert only_y[0] is None and np.array_equal(only_y[1].cpu().numpy(), yr)
+    only_x = ops.patch_gather(d_raw, None, d_idx, xy, patch)
+    assert only_x[1] is None and np.array_equal(only_x[0].cpu().numpy(), xr)
+    with pytest.raises(RuntimeError):
+        ops.patch_stats(d_rgb, d_idx, d_cand, 200)
+    with pytest.raises(TypeError):
+        ops.patch_gather(d_raw.to(torch.int32), d_rgb, d_idx, xy, patch)
+
+
+def test_device_dataset(dev):
+    """helpers/dataset.DeviceDataset: the host sampler reproduces Dataset.next_training_batch bit for bit (same numpy RNG
+    stream); the device sampler is deterministic per seed, stays on the Bayer grid inside the image and returns exactly
+    the crop at the corners it chose; validation batches equal the host's; batches feed a pipeline directly."""
+    from neural_imaging_amd.helpers import dataset
+    from neural_imaging_amd.models import pipelines
+    raw, rgb = _feed_images(8, 96, 128, 21)
+    host = dataset.Dataset.from_arrays({'x': raw[:6], 'y': rgb[:6]}, {'x': raw[6:, :16, :16], 'y': rgb[6:, :32, :32]})
+    feed = dataset.DeviceDataset(host, device=dev, sampler='host')
+    for discard in (None, 'flat', 'flat-aggressive', 'dark-n-textured'):
+        np.random.seed(4)
+        xh, yh = host.next_training_batch(1, 3, 48, discard, max_attempts=7)
+        np.random.seed(4)
+        xd, yd = feed.next_training_batch(1, 3, 48, discard, max_attempts=7)
+        assert np.array_equal(xd.numpy(), xh) and np.array_equal(yd.numpy(), yh)
+    xv, yv = feed.next_validation_batch(0, 2)
+    xvh, yvh = host.next_validation_batch(0, 2)
+    assert np.array_equal(xv.numpy(), xvh) and np.array_equal(yv.numpy(), yvh)
+    assert feed.count_training == 6 and feed.rgb_patch_size == 32 and 'raw+rgb' in feed.summary()
+    a, b_ = dataset.DeviceDataset(host, device=dev, seed=5), dataset.DeviceDataset(host, device=dev, seed=5)
+    c = dataset.DeviceDataset(host, device=dev, seed=6)
+    seen = []
+    for discard in (None, 'flat', 'flat-aggressive', 'dark-n-textured'):
+        xa, ya = a.next_training_batch(0, 6, 64, discard)
+        xb, yb = b_.next_training_batch(0, 6, 64, discard)
+        c.next_training_batch(0, 6, 64, discard)
+        xy = a.last_xy.cpu().numpy()
+        assert np.array_equal(xy, b_.last_xy.cpu().numpy()) and np.array_equal(ya.numpy(), yb.numpy())
+        assert (xy % 2 == 0).all() and (xy >= 0).all() and (xy[:, 0] <= 128 - 64).all() and (xy[:, 1] <= 96 - 64).all()
+        for i in range(6):
+            assert np.array_equal(ya.numpy()[i], (rgb[i, xy[i, 1]:xy[i, 1] + 64, xy[i, 0]:xy[i, 0] + 64] / 255.0).astype(np.float32))
+            assert np.array_equal(xa.numpy()[i], (raw[i, xy[i, 1] // 2:xy[i, 1] // 2 + 32, xy[i, 0] // 2:xy[i, 0] // 2 + 32]
+                                                  / 65535.0).astype(np.float32))
+        seen.append((xy, c.last_xy.cpu().numpy()))
+    assert any(not np.array_equal(p, q) for p, q in seen)      # another seed, other corners
+    net = pipelines.INet(patch_size=32, device=dev)
+    xa, ya = a.next_training_batch(0, 6, 64, 'flat')
+    assert np.isfinite(float(net.training_step(xa, ya, learning_rate=1e-3)))
+    with pytest.raises(ValueError):
+        a.next_training_batch(0, 6, 63)
+    with pytest.raises(ValueError):
+        a.next_training_batch(1, 6, 64)
+

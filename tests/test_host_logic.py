@@ -235,6 +235,61 @@ def test_keras_checkpoints_of_every_model(tmp_path):
         fan_b.load_model(str(tmp_path / 'f'))
 
 
+def _feed_images(n, h, w, seed):
+    rng = np.random.RandomState(seed)
+    rgb = np.zeros((n, h, w, 3), np.uint8)
+    for i in range(n):
+        base = np.full((h, w, 3), 40.0 + 25 * i)
+        base[h // 4:h // 2, w // 3:] += 80 * rng.uniform(-1, 1, (h // 2 - h // 4, w - w // 3, 3))
+        base[:, :w // 4] += 15 * np.sin(np.arange(w // 4) / 2.0)[None, :, None]
+        rgb[i] = np.clip(base + rng.normal(0, 2, (h, w, 3)), 0, 255)
+    raw = rng.randint(0, 65536, (n, h // 2, w // 2, 4)).astype(np.uint16)
+    return raw, rgb
+
+
+def test_host_dataset_from_directory_and_arrays(tmp_path):
+    """helpers/dataset.Dataset over *.npy + *.png pairs (reference helpers/dataset.py, helpers/loading.py): the split, the
+    loaded shapes, a training batch equal to the oracle's cut at the coordinates the seeded numpy RNG gives."""
+    from PIL import Image
+    from oracle import datafeed as odf
+    from neural_imaging_amd.helpers import dataset, loading
+    raw, rgb = _feed_images(7, 64, 96, 5)
+    for i in range(7):
+        Image.fromarray(rgb[i]).save(str(tmp_path / 'img_{:02d}.png'.format(i)))
+        np.save(str(tmp_path / 'img_{:02d}.npy'.format(i)), raw[i])
+    data = dataset.Dataset(str(tmp_path), n_images=4, v_images=3, val_rgb_patch_size=32, val_n_patches=2, randomize=11)
+    files = sorted(f for f in os.listdir(str(tmp_path)) if f.endswith('.png'))
+    np.random.seed(11)
+    np.random.shuffle(files)
+    assert data.files['training'] == files[:4] and data.files['validation'] == files[4:7]
+    assert data.count_training == 4 and data.count_validation == 6 and data.rgb_patch_size == 32 and data.is_raw_and_rgb()
+    assert data['training']['x'].shape == (4, 32, 48, 4) and data['training']['y'].dtype == np.uint8
+    assert (data.H, data.W) == (64, 96) and 'raw+rgb' in data.summary()
+    order = [int(f[4:6]) for f in files[:4]]
+    assert np.array_equal(data['training']['y'], rgb[order]) and np.array_equal(data['training']['x'], raw[order])
+    for discard in (None, 'flat', 'flat-aggressive', 'dark-n-textured'):
+        np.random.seed(3)
+        x, y = data.next_training_batch(1, 2, 32, discard, max_attempts=6)
+        np.random.seed(3)
+        xy = [odf.sample_patch(rgb[order[2 + b]], 32, discard, 6) for b in range(2)]
+        xr, yr = odf.cut_batch(raw[order], rgb[order], [2, 3], xy, 32)
+        assert x.dtype == np.float32 and np.array_equal(x, xr) and np.array_equal(y, yr)
+    xv, yv = data.next_validation_batch(1, 3)
+    assert xv.shape == (3, 16, 16, 4) and yv.shape == (3, 32, 32, 3) and float(yv.max()) <= 1.0
+    with pytest.raises(ValueError):
+        data.next_training_batch(2, 2, 32)
+    with pytest.raises(ValueError):
+        dataset.Dataset(str(tmp_path), n_images=6, v_images=3)
+    with pytest.raises(ValueError):
+        dataset.Dataset(str(tmp_path / 'nowhere'))
+    arr = dataset.Dataset.from_arrays({'y': rgb[:4]}, {'y': rgb[4:, :32, :32]})
+    assert arr.loaded_data == 'rgb' and arr.next_training_batch(0, 4, 48, 'flat').shape == (4, 48, 48, 3)
+    with pytest.raises(ValueError):
+        dataset.Dataset.from_arrays({'y': rgb[:4].astype(np.float32)}, {'y': rgb[4:]})
+    with pytest.raises(RuntimeError):
+        dataset.DeviceDataset(arr, device='cpu')
+
+
 def test_data_parallel_plumbing_gloo_world2():
     import torch.multiprocessing as mp
     from dp_worker import dp_worker
