@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
     const int Cin = p.C1 + p.C2, Cout = p.O1 + p.O2;
     const int cot = (Cout + TN - 1) / TN;
-    int bid = blockIdx.x;
+    int bid = xcd_order(blockIdx.x);
     int phase = 0;                                       // Conv2DTranspose: which of the 2x2 output phases
     if (KS == 1 && p.convt) { phase = bid & 3; bid >>= 2; }
     const int co0 = (bid % cot) * TN;
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const Wgrad
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Cin = p.C1 + p.C2;
     const int cib = (Cin + B_CI - 1) / B_CI, cob = (p.Cout + B_CO - 1) / B_CO;
-    int bid = blockIdx.x;
+    int bid = xcd_order(blockIdx.x);
     const int ci0 = (bid % cib) * B_CI;
     bid /= cib;
     const int co0 = (bid % cob) * B_CO;
@@ -915,7 +915,8 @@ __global__ __launch_bounds__(256) void conv_fwd_packed_bf16_kernel(const float* 
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cot = (Cout + TN - 1) / TN;
-    const int co0 = (blockIdx.x % cot) * TN, wg = blockIdx.x / cot;
+    const int xbid = xcd_order(blockIdx.x);
+    const int co0 = (xbid % cot) * TN, wg = xbid / cot;
     const int tiles = tiles_y * tiles_x;
     const long total_tiles = (long)tiles * N;
     for (int item = tid; item < TN * KP; item += 256) {
@@ -1086,7 +1087,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_packed_bf16_kernel(const Wgrad
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cob = (p.Cout + COT - 1) / COT;
-    const int co0 = (blockIdx.x % cob) * COT, split = blockIdx.x / cob;
+    const int xbid = xcd_order(blockIdx.x);
+    const int co0 = (xbid % cob) * COT, split = xbid / cob;
     int aoff[MF];
 #pragma unroll
     for (int f = 0; f < MF; ++f) {

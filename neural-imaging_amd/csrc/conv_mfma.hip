@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
 
     // block -> (co tile, spatial tile, image group); co tile fastest so neighbours reuse the input tile in L2/MALL
     const int cot = (Cout + TN - 1) / TN;
-    int bid = blockIdx.x;
+    int bid = xcd_order(blockIdx.x);
     const int co0 = (bid % cot) * TN;
     bid /= cot;
     const int tiles = p.tiles_y * p.tiles_x;
@@ -282,8 +282,9 @@ __global__ __launch_bounds__(256) void conv_fwd_packed_kernel(const ConvParams p
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Cout = p.O1 + p.O2;
     const int cot = (Cout + TN - 1) / TN;
-    const int co0 = (blockIdx.x % cot) * TN;
-    const int wg = blockIdx.x / cot;
+    const int xbid = xcd_order(blockIdx.x);
+    const int co0 = (xbid % cot) * TN;
+    const int wg = xbid / cot;
     const int tiles = p.tiles_y * p.tiles_x;
     const long total_tiles = (long)tiles * p.N;
 

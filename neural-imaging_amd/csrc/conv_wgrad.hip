@@ -55,7 +55,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_kernel(const WgradParam
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
     const int Cin = p.C1 + p.C2;
     const int cib = (Cin + CI_T - 1) / CI_T, cob = (p.Cout + CO_T - 1) / CO_T;
-    int bid = blockIdx.x;
+    int bid = xcd_order(blockIdx.x);
     const int ci0 = (bid % cib) * CI_T;
     bid /= cib;
     const int co0 = (bid % cob) * CO_T;
@@ -189,8 +189,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_packed_kernel(const WgradParam
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cob = (p.Cout + COT - 1) / COT;
-    const int co0 = (blockIdx.x % cob) * COT;
-    const int split = blockIdx.x / cob;
+    const int xbid = xcd_order(blockIdx.x);
+    const int co0 = (xbid % cob) * COT;
+    const int split = xbid / cob;
 
     // per-lane (tap, ci) of each M fragment -> offset inside the halo tile, or -1 when the slot is padding
     int aoff[MF];
