@@ -1301,8 +1301,9 @@ __global__ __launch_bounds__(256) void conv_dgrad_fewin_bf16_kernel(const float*
             }
         }
     };
-    if ((int)blockIdx.x < total_tiles) fetch(blockIdx.x);
-    for (int gt = blockIdx.x; gt < total_tiles; gt += gridDim.x) {
+    const int first_tile = xcd_order(blockIdx.x);      // every round hands each XCD one contiguous range of tiles
+    if (first_tile < total_tiles) fetch(first_tile);
+    for (int gt = first_tile; gt < total_tiles; gt += gridDim.x) {
     const int n = gt / tiles, tile = gt % tiles;
     const int u0 = (tile / tiles_x) * TH, v0 = (tile % tiles_x) * TWO;
     __syncthreads();                                 // previous tile fully consumed (and the weights staged)

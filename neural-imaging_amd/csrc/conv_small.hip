@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void conv_fewout_kernel(const SmallParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];    // [THH][TWH][CKP]
     const int tid = threadIdx.x;
     const int tx = tid % S_TWT, ty = tid / S_TWT;
-    int bid = blockIdx.x;
+    int bid = xcd_order(blockIdx.x);
     const int tiles = p.tiles_y * p.tiles_x;
     const int n = bid / tiles, tile = bid % tiles;
     const int ty0 = (tile / p.tiles_x) * S_TH, tx0 = (tile % p.tiles_x) * S_TW;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tiny_kernel(const TinyWParams 
     const int ky = tap / KS, kx = tap % KS;
     const long total = (long)p.N * p.tiles_y * p.tiles_x;
     float acc = 0.f;
-    for (long t = blockIdx.x; t < total; t += gridDim.x) {
+    for (long t = xcd_order(blockIdx.x); t < total; t += gridDim.x) {
         const int n = (int)(t / (p.tiles_y * p.tiles_x)), tile = (int)(t % (p.tiles_y * p.tiles_x));
         const int y0 = (tile / p.tiles_x) * T, x0 = (tile % p.tiles_x) * T;
         __syncthreads();
@@ -228,8 +228,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_c3k5_kernel(const TinyWPara
             for (int c = 0; c < 3; ++c) pd[q][c] = ok ? src[c] : 0.f;
         }
     };
-    if ((long)blockIdx.x < total) fetch(blockIdx.x);
-    for (long t = blockIdx.x; t < total; t += gridDim.x) {
+    const long first_tile = xcd_order(blockIdx.x);
+    if (first_tile < total) fetch(first_tile);
+    for (long t = first_tile; t < total; t += gridDim.x) {
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < NXP; ++q) {
