@@ -10,6 +10,7 @@
 //       its 8 pixels with ds_read_b32 (conflict-free) and packs them to bf16 in registers (v_cvt_pk_bf16_f32).
 #include <stdlib.h>
 
+#include <cstdlib>
 #include "common.h"
 
 // defined in conv_small.hip
@@ -122,7 +123,12 @@ struct ConvParamsB {
 
 // INB: in1 is stored as bf16 (compile-time: a run-time branch around the prefetch loads makes the backend wait for them at
 // the join, which serialises the staging latency the async-stage split hides)
-template <int KS, int STRIDE, int TH, int TW, int NB, int TN, bool INB>
+// BUF (with INB, one input tensor, Cin % 16 == 0, Cout % TN == 0, tensors < 2 GB): the prefetch goes through buffer
+// descriptors - per-lane byte offsets resolved once per tile, the channel chunk in the scalar offset, padding pixels as
+// out-of-range offsets that the hardware answers with zeros.  hipcc wraps every predicated flat load in s_and_saveexec /
+// branch / zero-fill / 64-bit address arithmetic (~9 instructions x 17 loads per thread and chunk, issued in front of the
+// MFMA loop); a buffer load is one instruction.
+template <int KS, int STRIDE, int TH, int TW, int NB, int TN, bool INB, bool BUF = false>
 __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p) {
     constexpr int CK = 16;
     constexpr int THH = (TH - 1) * STRIDE + KS, TWH = (TW - 1) * STRIDE + KS;
@@ -192,7 +198,38 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
         const bool ok = item < NPIXH * 2 && n < p.N && map_coord(gy, p.H, p.pad_mode) && map_coord(gx, p.W, p.pad_mode);
         apix[q] = ok ? (n * p.H + gy) * p.W + gx : -1;
     }
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    unsigned aoff[AP];                                   // BUF: byte offset of this thread's 16 B inside the input tensor
+    unsigned boff0 = 0, boff_last = 0;
+    if constexpr (BUF) {
+        static_assert(INB && 128 % TN == 0, "buffer prefetch: bf16-stored input, TN divides 128");
+#pragma unroll
+        for (int q = 0; q < AP; ++q)
+            aoff[q] = apix[q] >= 0 ? (unsigned)((apix[q] * p.C1 + (tid & 1) * 8) * 2) : 0x80000000u;
+        const int row = tid >> 1;
+        boff0 = (unsigned)((((row / TN) * Cout + co0 + row % TN) * 16 + (tid & 1) * 8) * 2);
+        boff_last = (tid + (BP - 1) * 256 < TAPS * TN * 2) ? boff0 : 0x80000000u;
+    }
     auto fetch = [&](int c0) {
+        if constexpr (BUF) {
+            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(p.in1), 0, (int)((long)p.N * p.H * p.W * p.C1 * 2), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<__bf16*>(p.wb), 0, (int)((long)(p.CinP >> 4) * TAPS * 16 * Cout * 2), 0x00020000);
+#pragma unroll
+            for (int q = 0; q < AP; ++q) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, aoff[q], c0 * 2, 0);
+                preA[q][0] = *reinterpret_cast<const float4*>(&v);
+            }
+            const int chunk_base = (c0 >> 4) * (TAPS * 16 * 2) * Cout, qstride = (128 / TN) * Cout * 32;
+#pragma unroll
+            for (int q = 0; q < BP; ++q) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rb, q == BP - 1 ? boff_last : boff0,
+                                                                      chunk_base + q * qstride, 0);
+                preB[q] = *reinterpret_cast<const uint4*>(&v);
+            }
+            return;
+        }
         const int c = c0 + (tid & 1) * 8;               // item = tid + 256 q: the 8-channel half is the thread's parity
 #pragma unroll
         for (int q = 0; q < AP; ++q) {
@@ -371,8 +408,16 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
     }
 }
 
-template <int KS, int STRIDE, int TH, int TW, int NB, int TN, bool INB = false>
+template <int KS, int STRIDE, int TH, int TW, int NB, int TN, bool INB = false, bool BUF = false>
 int launch_conv_b(const ConvParamsB& p, hipStream_t stream) {
+    if constexpr (INB && !BUF && KS == 5 && STRIDE == 1 && 128 % TN == 0) {
+        static const bool no_buf = getenv("NIMG_NO_BUFFER_LOADS") != nullptr;
+        const int Cin = p.C1 + p.C2, Cout = p.O1 + p.O2;
+        const long in_bytes = (long)p.N * p.H * p.W * p.C1 * 2, w_bytes = (long)(p.CinP >> 4) * KS * KS * 16 * Cout * 2;
+        if (!no_buf && p.C2 == 0 && Cin % 16 == 0 && Cout % TN == 0 && !p.convt && in_bytes < (1l << 31) - 65536 &&
+            w_bytes < (1l << 31) - 65536)
+            return launch_conv_b<KS, STRIDE, TH, TW, NB, TN, true, true>(p, stream);
+    }
     constexpr int THH = (TH - 1) * STRIDE + KS, TWH = (TW - 1) * STRIDE + KS;
     constexpr bool PLANAR = (STRIDE == 1 && TW == 16 && NB == 1 && KS == 5);   // 3x3: the extra registers cost a wave per SIMD
     constexpr size_t a_entries = PLANAR ? (size_t)2 * THH * 32 : (size_t)NB * THH * TWH * 2;
@@ -383,7 +428,7 @@ int launch_conv_b(const ConvParamsB& p, hipStream_t stream) {
     q.tiles_y = cdiv(p.Hout, TH);
     q.tiles_x = cdiv(p.Wout, TW);
     const long blocks = (long)cdiv(p.O1 + p.O2, TN) * q.tiles_y * q.tiles_x * cdiv(p.N, NB) * (p.convt ? 4 : 1);
-    auto kern = conv_fwd_bf16_kernel<KS, STRIDE, TH, TW, NB, TN, INB>;
+    auto kern = conv_fwd_bf16_kernel<KS, STRIDE, TH, TW, NB, TN, INB, BUF>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, q);
     NIMG_CHECK_LAUNCH();
