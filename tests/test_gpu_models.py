@@ -678,6 +678,57 @@ def test_channel_learns_and_compute_modes_agree(dev):
     assert np.max(np.abs(traj['f32'][0] - traj['bf16'][0]) / traj['f32'][0]) < 2e-2
 
 
+def test_full_size_step_properties(dev):
+    """BASELINE.json configs[3] at its full size (64 RAW patches of 128 x 128 -> 320 FAN images of 256 x 256, UNet -> five
+    manipulation classes -> dJPEG QF 80 -> FAN), where the float64 oracle would take minutes: size-independent properties.
+      * the analytic FAN gradient of the float32 step equals the directional derivative of the loss measured by central
+        differences along a random direction (the FAN sees a fixed input when only its weights move, so the rounding stages
+        upstream do not enter);
+      * the bf16 throughput mode reproduces the float32 loss and gradients of the same step;
+      * the class order / label layout of run_workflow at this size: B contiguous rows per class."""
+    from neural_imaging_amd import ops
+    from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
+    dist = {'downsampling': 'none', 'compression': 'jpeg', 'compression_params': {'quality': 80, 'codec': 'soft'}}
+    b = 64
+    rgb = natural_images(b, 256, 256, seed=77)
+    raw = bayer_from_rgb(rgb)
+    res = {}
+    for mode in ('f32', 'bf16'):
+        ops.set_compute(mode)
+        try:
+            wf = ManipulationClassification('UNet', distribution=dist, trainable={'nip', 'fan'}, raw_patch_size=128, device=dev,
+                                            manipulations=['sharpen', 'resample', 'gaussian', 'jpeg'])
+            loss, parts = wf.training_step(raw, rgb, lambda_nip=0.1, learning_rate=0.0)     # lr 0: gradients, no update
+            res[mode] = (float(loss), wf.fan._model.flat_grad.clone(), wf.nip._model.flat_grad.clone())
+            if mode == 'f32':
+                assert wf.n_classes == 5
+                Y, c, C, _, probs = wf.run_workflow(raw)
+                assert Y.shape == (b, 256, 256, 3) and C.shape == (5 * b, 256, 256, 3) and probs.shape == (5 * b, 5)
+                assert np.array_equal(c.numpy()[:b], Y.numpy())                         # class 0 = the native images
+                # directional derivative of the loss w.r.t. the FAN parameters
+                gfan = res[mode][1]
+                w0 = wf.fan._model.flat.clone()
+                gen = torch.Generator(device='cpu').manual_seed(5)
+                d = torch.randn(w0.shape, generator=gen).to(dev) * (w0 != 0)              # keep the alignment gaps at zero
+                d = d / d.norm() * 0.02 * w0.norm()
+                fd = []
+                for sgn in (1.0, -1.0):
+                    wf.fan._model.flat.copy_(w0 + sgn * d)
+                    l, _ = wf.training_step(raw, rgb, lambda_nip=0.1, learning_rate=0.0)
+                    fd.append(float(l))
+                wf.fan._model.flat.copy_(w0)
+                num = (fd[0] - fd[1]) / 2.0
+                ana = float((gfan.double() * d.double()).sum())
+                assert abs(num) > 1e-4 and abs(num - ana) <= 0.03 * abs(num), (num, ana, fd, res[mode][0])
+        finally:
+            ops.set_compute('f32')
+    lf, lb = res['f32'][0], res['bf16'][0]
+    assert np.isfinite(lf) and abs(lf - lb) / lf < 1e-2, (lf, lb)
+    cos = lambda a, c: float((a.double() * c.double()).sum() / (a.double().norm() * c.double().norm()))
+    assert cos(res['f32'][1], res['bf16'][1]) > 0.995
+    assert cos(res['f32'][2], res['bf16'][2]) > 0.97
+
+
 def test_training_harness_outputs(dev, tmp_path):
     """H1 (training/manipulation.py:36-335): epoch loop, lr decay, validation cadence, training.json keys, checkpoints
     and the 'directory exists => skip' idempotence, on a synthetic dataset."""
