@@ -242,6 +242,9 @@ int nimg_isp_residual_fwd(const float* x, const float* f, const float* alpha, fl
 long nimg_isp_residual_workspace_bytes(void);
 int nimg_isp_residual_bwd(const float* dy, const float* f, const float* alpha, float* df, float* dalpha,
                           float* workspace, long count, int accumulate, void* stream);
+/* Dropout of the FAN's hidden Dense layers at training time (models/forensics.py:88), forward and backward alike:
+ * y = keep[i] ? x[i] * scale : 0, keep = the Bernoulli(1 - rate) mask bytes, scale = 1 / (1 - rate). */
+int nimg_mask_scale(const float* x, const uint8_t* keep, float* y, long count, float scale, void* stream);
 int nimg_sigmoid_fwd(const float* x, float* y, long count, void* stream);
 int nimg_sigmoid_bwd(const float* dy, const float* y, float* dx, long count, void* stream);
 int nimg_gamma_ste_fwd(const float* x, float* y, long count, float lo, float hi, float exponent, void* stream);

@@ -92,6 +92,7 @@ PROTOTYPES = {
     'nimg_patch_stats': (c_int, [P, c_int, c_int, c_int, P, P, c_int, c_int, c_int, P, P, P]),
     'nimg_patch_select': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P, P]),
     'nimg_patch_gather': (c_int, [P, P, c_int, c_int, c_int, P, P, c_int, c_int, P, P, P]),
+    'nimg_mask_scale': (c_int, [P, P, P, c_long, c_float, P]),
     'nimg_pad2d': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'nimg_conv2d_fwd_bf16_ex': (c_int, [P, c_int, P, c_int, P, P, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int,
                                         c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),

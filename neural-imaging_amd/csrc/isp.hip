@@ -87,9 +87,25 @@ __global__ void gamma_ste_bwd_kernel(const float* __restrict__ x, const float* _
         dx[i] = dy[i] * e * powf(fminf(fmaxf(x[i], lo), hi), e - 1.0f);
 }
 
+// Keras Dropout at training time, forward and backward alike: y = keep[i] ? x * scale : 0 (models/forensics.py:88)
+__global__ void mask_scale_kernel(const float* __restrict__ x, const uint8_t* __restrict__ keep, float* __restrict__ y,
+                                  long count, float scale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+        y[i] = keep[i] ? x[i] * scale : 0.f;
+}
+
 }  // namespace
 
 extern "C" {
+
+int nimg_mask_scale(const float* x, const uint8_t* keep, float* y, long count, float scale, void* stream) {
+    if (count < 0) return NIMG_ERR_ARG;
+    if (count == 0) return NIMG_OK;
+    if (!x || !keep || !y) return NIMG_ERR_ARG;
+    hipLaunchKernelGGL(mask_scale_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, x, keep, y, count, scale);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
 
 int nimg_isp_residual_fwd(const float* x, const float* f, const float* alpha, float* y, long count, int clip,
                           void* stream) {

@@ -5,7 +5,7 @@ Graph as built by the workflow's defaults (forensics.py:62-90; ctor values overr
 quirk 6): ConstrainedConv2D -> 4 x [Conv5x5 SAME (32,64,128,256) + LeakyReLU(0.2) -> MaxPool2] -> Conv1x1 256 + LReLU
 -> GAP -> Dense(n_classes, softmax); loss = SparseCategoricalCrossentropy on probabilities (forensics.py:94).
 Also built: use_gap=False (Flatten) and n_dense > 0 hidden Dense + LeakyReLU layers (forensics.py:79-87), as 1x1
-convolutions on (N,1,1,F) tensors.  dropout > 0 raises NotImplementedError (its random mask cannot be pinned to TF's).
+convolutions on (N,1,1,F) tensors, with Keras Dropout after each of them at training time (masks from a device generator).
 """
 from collections import OrderedDict
 
@@ -37,8 +37,13 @@ class FAN(TFModel):
         })
         params = locals()
         self._h.update(**{k: params[k] for k in self._h.keys()})
-        if dropout != 0:
-            raise NotImplementedError('dropout > 0 is not built (no parity with the TF random stream)')
+        if not 0 <= float(dropout) < 1:
+            raise ValueError('dropout rate must be in [0, 1)')
+        # Dropout (forensics.py:88) follows every hidden Dense layer at training time.  The masks come from a device
+        # generator (seeded per model; TensorFlow's own random stream is not reproducible elsewhere) unless a test injects
+        # them through `dropout_masks` (list of uint8 tensors, one per hidden layer, consumed by the next training forward).
+        self._dropout_gen, self._dropout_seed = None, int(seed) + 17
+        self.dropout_masks = None
         if not use_gap and patch_size is None:
             raise ValueError('the Flatten head (use_gap=False) needs a fixed patch_size')
         if self._h.kernel not in (3, 5) or self._h.n_classes > 16:
@@ -127,10 +132,23 @@ class FAN(TFModel):
             else:
                 head_in = a.reshape(n, 1, 1, -1)
             t['feat'] = head_in
-            for d in self._hidden:
+            rate = float(self._h.dropout)
+            for li, d in enumerate(self._hidden):
                 w4 = P.p[d.name + '/kernel'].view(1, 1, d.cin, d.cout)
                 head_in = ops.conv2d(head_in, w4, P.p[d.name + '/bias'], act='leaky_relu')
-                t[d.name] = head_in
+                t[d.name] = head_in                              # the activation (its sign gates LeakyReLU' backwards)
+                if training and rate > 0:
+                    if self.dropout_masks is not None:
+                        keep = self.dropout_masks[li].to(device=x.device, dtype=torch.uint8).reshape(head_in.shape).contiguous()
+                    else:
+                        if self._dropout_gen is None:
+                            self._dropout_gen = torch.Generator(device=x.device)
+                            self._dropout_gen.manual_seed(self._dropout_seed)
+                        keep = (torch.rand(head_in.shape, device=x.device, generator=self._dropout_gen) >= rate).to(torch.uint8)
+                    head_in = ops.mask_scale(head_in, keep, 1.0 / (1.0 - rate))
+                    t[d.name + '/keep'], t[d.name + '/dropped'] = keep, head_in
+            if training:
+                self.dropout_masks = None
         gap, probs, loss_per, dlogits = ops.fan_head_fwd(head_in, P.p[self._cls + '/kernel'], P.p[self._cls + '/bias'],
                                                          labels, ls)
         t['head_in'] = head_in
@@ -146,14 +164,18 @@ class FAN(TFModel):
         dz, loss = ops.fan_head_bwd(t['head_in'], t['gap'], P.p[self._cls + '/kernel'], t['dlogits'], t['loss_per'],
                                     t['loss_scale'], P.g[self._cls + '/kernel'], P.g[self._cls + '/bias'])
         if 'feat' in t:
+            keep_scale = 1.0 / (1.0 - float(self._h.dropout))
             for i in range(len(self._hidden) - 1, -1, -1):
                 d = self._hidden[i]
-                inp = t[self._hidden[i - 1].name] if i > 0 else t['feat']
+                if d.name + '/keep' in t:          # dz arrived w.r.t. the dropped tensor (x LeakyReLU' of its sign = the
+                    dz = ops.mask_scale(dz.reshape(t[d.name].shape), t[d.name + '/keep'], keep_scale)   # activation's)
+                prev = self._hidden[i - 1].name if i > 0 else None
+                inp = t.get(prev + '/dropped', t[prev]) if i > 0 else t['feat']
                 ops.conv2d_wgrad(inp, dz, 1, dw=P.g[d.name + '/kernel'].view(1, 1, d.cin, d.cout),
                                  db=P.g[d.name + '/bias'])
                 w4 = P.p[d.name + '/kernel'].view(1, 1, d.cin, d.cout)
                 # hidden activations carry a LeakyReLU; the feature vector itself (GAP / Flatten output) does not
-                dz = ops.conv2d_dgrad(dz, w4, (1, 1), act_mask=inp if i > 0 else None)
+                dz = ops.conv2d_dgrad(dz, w4, (1, 1), act_mask=t[prev] if i > 0 else None)
             if self._hidden:
                 # dz is now d loss / d feat (no activation applied yet): route it back into the 1x1-conv activation
                 if self._use_gap:

@@ -991,6 +991,16 @@ def isp_residual_bwd(dy, f, alpha, dalpha, accumulate=False):
     return df
 
 
+def mask_scale(x, keep, scale, out=None):
+    """y = keep ? x * scale : 0 - Keras Dropout with a given uint8 mask (forward and backward)."""
+    _f32(x, out)
+    if keep.dtype != torch.uint8 or keep.numel() != x.numel() or not keep.is_contiguous():
+        raise TypeError('keep: contiguous uint8 mask of the size of x')
+    y = torch.empty_like(x) if out is None else out
+    _lib.call('nimg_mask_scale', _p(x), _p(keep), _p(y), x.numel(), float(scale), _stream())
+    return y
+
+
 def sigmoid(x, out=None):
     _f32(x, out)
     y = torch.empty_like(x) if out is None else out

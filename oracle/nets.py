@@ -98,7 +98,7 @@ def _dense_names(p):
     return sorted(names, key=lambda n: int(n.split('_')[1]) if '_' in n else 0)
 
 
-def fan_forward(p, x, n_convolutions=4, return_tensors=False, use_gap=True):
+def fan_forward(p, x, n_convolutions=4, return_tensors=False, use_gap=True, dropout=0.0, dropout_masks=None):
     """models/forensics.py:62-90: constrained conv -> n x [conv + LReLU -> pool] -> 1x1 conv + LReLU -> GAP | Flatten ->
     hidden Dense + LReLU layers (n_dense) -> Dense softmax."""
     t = OrderedDict()
@@ -115,9 +115,11 @@ def fan_forward(p, x, n_convolutions=4, return_tensors=False, use_gap=True):
     feat = net.mean(dim=(1, 2)) if use_gap else net.reshape(net.shape[0], -1)       # Flatten is NHWC row-major
     t['gap'] = feat
     dn = _dense_names(p)
-    for name in dn[:-1]:
+    for li, name in enumerate(dn[:-1]):
         feat = T.leaky_relu(feat @ p[name + '/kernel'] + p[name + '/bias'])
         t[name] = feat
+        if dropout_masks is not None:                    # Keras Dropout at training time (forensics.py:88), given mask
+            feat = feat * dropout_masks[li].to(feat.dtype) / (1.0 - dropout)
     logits = feat @ p[dn[-1] + '/kernel'] + p[dn[-1] + '/bias']
     t['logits'] = logits
     probs = torch.softmax(logits, dim=1)

@@ -178,8 +178,47 @@ def test_fan_head_variants(dev, use_gap, n_dense):
     assert abs(float(loss.item()) - float(loss_ref)) < 1e-4
     check_grads(grads_of(fan), g_ref, list(p.keys()), tol=3e-4)
     assert_close(dx.cpu().numpy(), gr[-1].numpy(), 1e-7, 3e-4, what='FAN input gradient')
-    with pytest.raises(NotImplementedError):
-        forensics.FAN(n_classes=4, patch_size=32, dropout=0.5, device=dev)
+    with pytest.raises(ValueError):
+        forensics.FAN(n_classes=4, patch_size=32, dropout=1.0, device=dev)
+
+
+@pytest.mark.parametrize('use_gap', [True, False])
+def test_fan_dropout(dev, use_gap):
+    """Keras Dropout after the hidden Dense layers (models/forensics.py:88): with the masks injected, probabilities, loss
+    and every gradient equal the oracle's; inference ignores it; the built-in generator keeps ~(1 - rate) of the units and
+    gives a different mask every step."""
+    from neural_imaging_amd.models import forensics
+    rate = 0.4
+    fan = forensics.FAN(n_classes=4, patch_size=32, use_gap=use_gap, n_dense=2, dropout=rate, device=dev)
+    x = natural_images(6, 32, 32, seed=78)
+    labels = np.array([0, 1, 2, 3, 1, 2], np.int32)
+    rng = np.random.RandomState(3)
+    masks = [(rng.uniform(size=(6, 128)) >= rate).astype(np.uint8), (rng.uniform(size=(6, 64)) >= rate).astype(np.uint8)]
+    p = oracle_params(fan)
+    for v in p.values():
+        v.requires_grad_(True)
+    xt = to64(x).requires_grad_(True)
+    probs_ref = onets.fan_forward(p, xt, use_gap=use_gap, dropout=rate, dropout_masks=[torch.from_numpy(m) for m in masks])
+    loss_ref = T.sparse_ce_from_probs(probs_ref, labels)
+    gr = torch.autograd.grad(loss_ref, list(p.values()) + [xt])
+    g_ref = dict(zip(p.keys(), gr[:-1]))
+    fan.dropout_masks = [torch.from_numpy(m) for m in masks]
+    probs, ctx = fan.forward(torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev), training=True)
+    assert fan.dropout_masks is None
+    assert_close(probs.cpu().numpy(), probs_ref.detach().numpy(), 1e-4, what='FAN probabilities under dropout')
+    loss, dx = fan.backward(ctx, need_input_grad=True)
+    assert abs(float(loss.item()) - float(loss_ref)) < 1e-4
+    check_grads(grads_of(fan), g_ref, list(p.keys()), tol=3e-4)
+    assert_close(dx.cpu().numpy(), gr[-1].numpy(), 1e-7, 3e-4, what='FAN input gradient under dropout')
+    # inference: no dropout
+    probs_inf = fan.process(x).numpy()
+    assert_close(probs_inf, onets.fan_forward(p, to64(x), use_gap=use_gap).detach().numpy(), 1e-4, what='inference')
+    # the built-in generator
+    _, c1 = fan.forward(torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev), training=True)
+    _, c2 = fan.forward(torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev), training=True)
+    k1, k2 = c1['dense/keep'].float(), c2['dense/keep'].float()
+    assert 0.4 < float(k1.mean()) < 0.8 and not torch.equal(k1, k2)
+    assert float(fan.training_step(x, labels, learning_rate=1e-3)) > 0
 
 
 @pytest.mark.parametrize('kernel,cfa', [(5, 'gbrg'), (3, 'rggb')])
