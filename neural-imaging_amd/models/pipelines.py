@@ -215,8 +215,6 @@ class INet(NIPModel):
                        cfa_pattern=cfa_pattern)
         if self._h.kernel not in (3, 5):
             raise NotImplementedError('demosaicing kernel {} not built (3 | 5)'.format(self._h.kernel))
-        if self._h.trainable_upsampling:
-            raise NotImplementedError('trainable_upsampling=True is not built (the reference default is False)')
         if self.in_channels != 4:
             raise ValueError('INet develops 4-plane RAW input')
         k = self._h.kernel
@@ -252,6 +250,7 @@ class INet(NIPModel):
         P = self._model.p
         t = OrderedDict()
         h12 = ops.conv2d(x, P['up/kernel'])
+        t['x'] = x
         t['bayer'] = ops.d2s_clip(h12, 1.0, 0.0, False)
         t['rgb'] = ops.conv2d(t['bayer'], P['demosaic/kernel'], pad_mode=ops.PAD_MODES['REFLECT'])
         t['srgb'] = ops.conv2d(t['rgb'], P['srgb/kernel'])
@@ -260,7 +259,8 @@ class INet(NIPModel):
         return ops.clip01(y0, out=y0), (t if training else None)
 
     def backward(self, t, dy):
-        """dy = d loss / d y (the clip is straight-through). The frozen up-sampling kernel keeps a zero gradient."""
+        """dy = d loss / d y (the clip is straight-through). The up-sampling kernel keeps a zero gradient unless
+        trainable_upsampling is set."""
         P, G = self._model.p, self._model.g
         hw = (dy.shape[1], dy.shape[2])
         k = self._h.kernel
@@ -271,6 +271,13 @@ class INet(NIPModel):
         ops.conv2d_wgrad(t['rgb'], d_srgb, 1, dw=G['srgb/kernel'])
         d_rgb = ops.conv2d_dgrad(d_srgb, P['srgb/kernel'], hw)
         ops.conv2d_wgrad(t['bayer'], d_rgb, k, pad_mode=ops.PAD_MODES['REFLECT'], dw=G['demosaic/kernel'])
+        if self._h.trainable_upsampling:
+            # through the REFLECT-padded demosaicing: full correlation with the flipped filter on the padded domain, the pad
+            # folded back, depth_to_space undone, then the 1x1 filter gradient
+            dpad = ops.conv2d(d_rgb, ops.flip_weights(P['demosaic/kernel']), None, pads=(k - 1, k - 1),
+                              out_hw=(hw[0] + k - 1, hw[1] + k - 1))
+            d_bayer = ops.fold_pad(dpad, (k - 1) // 2, ops.PAD_MODES['REFLECT'])
+            ops.conv2d_wgrad(t['x'], ops.d2s_clip_bwd(d_bayer, 1.0), 1, dw=G['up/kernel'])
         ops.join_side_stream()
         return None
 

@@ -255,6 +255,30 @@ def test_inet_forward_backward_and_training(dev, kernel, cfa):
     assert net.process(raw[0]).shape == (1, 48, 48, 3)
 
 
+def test_inet_trainable_upsampling(dev):
+    """INet(trainable_upsampling=True) (models/pipelines.py:262-266): the 1x1 CFA up-sampling filter receives its gradient
+    through depth_to_space and the REFLECT-padded demosaicing convolution."""
+    from neural_imaging_amd.models import pipelines
+    from neural_imaging_amd import ops
+    net = pipelines.INet(patch_size=24, kernel=5, trainable_upsampling=True, random_init=True, device=dev)
+    assert net.model_code == 'INet_gbrgTR_5x5'
+    rgb = natural_images(2, 48, 48, seed=23)
+    raw = bayer_from_rgb(rgb)
+    p = oracle_params(net)
+    names = list(p.keys())
+    for k in names:
+        p[k].requires_grad_(True)
+    loss_ref = T.mse255(onets.inet_forward(p, to64(raw)), to64(rgb))
+    g_ref = dict(zip(names, torch.autograd.grad(loss_ref, [p[k] for k in names])))
+    y, ctx = net.forward(torch.from_numpy(raw).to(dev), training=True)
+    loss, dy = ops.mse255(y, torch.from_numpy(rgb).to(dev), grad_scale=1.0)
+    net.backward(ctx, dy)
+    check_grads(grads_of(net), g_ref, names, tol=3e-4)
+    up0 = net.state_dict()['up/kernel'].copy()
+    net.training_step(raw, rgb, learning_rate=1e-3)
+    assert np.abs(net.state_dict()['up/kernel'] - up0).max() > 0
+
+
 @pytest.mark.parametrize('kernel,c_filters,residual', [(5, (8, 8), True), (3, (16,), True), (5, (), True), (3, (8,), False),
                                                        (5, (), False)])
 def test_classic_isp_forward_backward_and_training(dev, kernel, c_filters, residual):
