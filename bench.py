@@ -71,7 +71,7 @@ def time_dominant_kernel(dev, b_images, reps=20):
     flops = 2.0 * 25 * 64 * 128 * 64 * 64 * n
     from neural_imaging_amd import ops as _o
     kname = 'conv_fwd_kernel<5,1,16,16,1,64,8>' if _o.COMPUTE == 'f32' else (
-        'conv_fwd_bf16_kernel<5,1,16,16,1,64,INB=true>' if stored_bf16 else 'conv_fwd_bf16_kernel<5,1,16,16,1,64>')
+        'conv_fwd_bf16_kernel<5,1,16,16,1,64,INB=true,BUF=true>' if stored_bf16 else 'conv_fwd_bf16_kernel<5,1,16,16,1,64>')
     traffic = None
     try:                                                   # measured once with rocprofv3 --pmc, see profiles/README.md
         with open(os.path.join(ROOT, 'profiles', 'r01_pmc_dominant_kernel.json')) as f:
