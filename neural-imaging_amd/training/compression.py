@@ -1,8 +1,8 @@
 """
 DCN pre-training loop - counterpart of the reference's training/compression.py:123-309: per batch
 host-side flips (:195-197), dcn.training_step(batch, lr), lr x0.5 every 1000 epochs by default (train_dcn.py:105-107),
-validation every `validation_schedule` epochs, progress.json + checkpoint; NaN loss aborts like the reference's
-SSIM-collapse guard (:292-294).
+validation every `validation_schedule` epochs with progress.json + checkpoint (only then, like the reference), early stop
+on a converged or deteriorating validation SSIM (:282-295); a non-finite loss aborts.
 """
 import json
 import os
@@ -16,7 +16,8 @@ from . import validation
 def train_dcn(dcn, training, data, directory='./data/models/dcn/playground/', overwrite=False):
     spec = {'n_epochs': 1500, 'batch_size': 50, 'patch_size': dcn.patch_size, 'learning_rate': 1e-4,
             'learning_rate_reduction_schedule': 1000, 'learning_rate_reduction_factor': 0.5,
-            'validation_schedule': 100, 'augmentation_probs': {'flip_h': 0.5, 'flip_v': 0.5}, 'seed': 1234}
+            'validation_schedule': 100, 'augmentation_probs': {'flip_h': 0.5, 'flip_v': 0.5}, 'seed': 1234,
+            'convergence_threshold': 1e-5}
     spec.update(training or {})
     out = os.path.join(directory, dcn.model_code.split('/')[0], dcn.scoped_name)
     if os.path.exists(out) and not overwrite:
@@ -31,11 +32,15 @@ def train_dcn(dcn, training, data, directory='./data/models/dcn/playground/', ov
         for batch_id in range(n_batches):
             bx = data.next_training_batch(batch_id, spec['batch_size'], spec['patch_size'])
             bx = bx[1] if isinstance(bx, tuple) else bx
-            if rng.uniform() < spec['augmentation_probs']['flip_h']:
-                bx = bx[:, :, ::-1, :]
-            if rng.uniform() < spec['augmentation_probs']['flip_v']:
-                bx = bx[:, ::-1, :, :]
-            res = dcn.training_step(np.ascontiguousarray(bx), lr)
+            flips = [ax for ax, key in ((2, 'flip_h'), (1, 'flip_v')) if rng.uniform() < spec['augmentation_probs'][key]]
+            if hasattr(bx, 't'):                  # DeviceArray (DeviceDataset): flip on the device
+                import torch
+                bx = torch.flip(bx.t, flips).contiguous() if flips else bx.t
+            else:
+                for ax in flips:
+                    bx = np.flip(bx, ax)
+                bx = np.ascontiguousarray(bx)
+            res = dcn.training_step(bx, lr)
             if not np.isfinite(res['loss']):
                 raise RuntimeError('DCN training diverged (non-finite loss)')
             stats['loss'].append(res['loss'])
@@ -51,6 +56,12 @@ def train_dcn(dcn, training, data, directory='./data/models/dcn/playground/', ov
                 json.dump({'performance': dcn.performance, 'summary': summary, 'args': dcn.get_hyperparameters()}, f,
                           indent=4, default=lambda o: float(o))
             dcn.save_model(out, epoch, save_args=True, quiet=True)
+            # convergence / deterioration of the validation SSIM over the last n_tail samplings (compression.py:282-295)
+            vs, n_tail = dcn.performance['ssim']['validation'], 5
+            if len(vs) > 5:
+                current, previous = np.mean(vs[-n_tail:]), np.mean(vs[-(n_tail + 1):-1])
+                if abs((current - previous) / previous) < spec['convergence_threshold'] or current < 0.9 * previous:
+                    break
         if epoch > 0 and epoch % spec['learning_rate_reduction_schedule'] == 0:
             lr *= spec['learning_rate_reduction_factor']
     return out

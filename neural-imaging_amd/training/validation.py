@@ -48,6 +48,7 @@ def validate_nip(model, data, out_directory=None, savefig=False, epoch=0, show_r
     batch_size = int(np.minimum(10, data.count_validation))
     for batch in range(data.count_validation // batch_size):
         bx, by = data.next_validation_batch(batch, batch_size)
+        by = np.asarray(by)                       # a DeviceDataset answers DeviceArrays
         developed = model.process(bx).numpy().clip(0, 1)
         psnrs.extend(psnr(developed, by).tolist())
         ssims.extend(np.atleast_1d(metrics.ssim(developed, by)).tolist())
@@ -64,6 +65,7 @@ def validate_dcn(dcn, data, out_directory=None, savefig=False, epoch=0, show_ref
         by = data.next_validation_batch(batch, batch_size)
         by = by[1] if isinstance(by, tuple) else by
         y, ent = dcn.process(by, return_entropy=True)
+        by = np.asarray(by)
         out['psnr'].extend(psnr(y.numpy(), by).tolist())
         out['ssim'].extend(np.atleast_1d(metrics.ssim(np.clip(y.numpy(), 0, 1), by)).tolist())
         out['entropy'].append(float(ent))

@@ -821,3 +821,83 @@ def test_training_harness_outputs(dev, tmp_path):
     assert os.path.getmtime(os.path.join(run_dir, 'training.json')) == before
     with pytest.raises(RuntimeError):
         tm.train_manipulation_nip(wf, {'n_epochs': 1}, data, {'root': str(tmp_path)})   # missing camera_name
+
+
+def _tiny_dataset(n_train, n_val, h, w, val_patch, seed):
+    """helpers/dataset.Dataset over synthetic full-resolution images: RGB uint8 + the uint16 RAW stacks of its Bayer mosaic."""
+    from neural_imaging_amd.helpers import dataset
+    rgb = (natural_images(n_train + n_val, h, w, seed=seed) * 255).round().astype(np.uint8)
+    raw = (bayer_from_rgb(rgb.astype(np.float32) / 255) * 65535).round().astype(np.uint16)
+    return dataset.Dataset.from_arrays({'x': raw[:n_train], 'y': rgb[:n_train]},
+                                       {'x': raw[n_train:, :val_patch // 2, :val_patch // 2],
+                                        'y': rgb[n_train:, :val_patch, :val_patch]})
+
+
+@pytest.mark.parametrize('feed', ['host', 'device'])
+def test_nip_pretraining_harness(dev, tmp_path, feed):
+    """H2 (training/pipeline.py:105-256): epoch loop over Dataset batches, validation cadence, progress.json, checkpoint,
+    resume and the 'directory exists => skip' rule - fed from the host Dataset and from the HBM-resident DeviceDataset."""
+    import json
+    import os
+    from neural_imaging_amd.helpers import dataset
+    from neural_imaging_amd.models import pipelines
+    from neural_imaging_amd.training import pipeline as tp
+    data = _tiny_dataset(8, 4, 96, 128, 64, seed=5)
+    if feed == 'device':
+        data = dataset.DeviceDataset(data, device=dev, seed=3)
+    np.random.seed(1)
+    net = pipelines.UNet(patch_size=16, device=dev)
+    out = tp.train_nip_model(net, 'synthetic', n_epochs=6, lr_schedule={0: 1e-3, 3: 5e-4}, validation_schedule=2,
+                             patch_size=32, batch_size=4, data=data, out_directory_root=str(tmp_path), discard=None)
+    assert out.endswith(os.path.join('synthetic', net.model_code, 'unet'))
+    prog = json.load(open(os.path.join(out, 'progress.json')))
+    assert set(prog.keys()) == {'performance', 'summary', 'args'} and prog['summary']['Epoch'] == 5
+    perf = prog['performance']
+    assert len(perf['loss']['training']) == 6 and len(perf['loss']['validation']) == 3      # epochs 0, 2, 4
+    assert len(perf['psnr']['validation']) == 3 and len(perf['ssim']['validation']) == 3
+    assert perf['loss']['training'][-1] < 0.9 * perf['loss']['training'][0], perf['loss']['training']
+    assert perf['psnr']['validation'][-1] > perf['psnr']['validation'][0]
+    assert os.path.isfile(os.path.join(out, 'unet.h5'))
+    assert tp.train_nip_model(net, 'synthetic', n_epochs=6, patch_size=32, batch_size=4, data=data,
+                              out_directory_root=str(tmp_path)) == out                       # exists => skipped
+    net2 = pipelines.UNet(patch_size=16, device=dev, seed=99)
+    tp.train_nip_model(net2, 'synthetic', n_epochs=8, validation_schedule=2, patch_size=32, batch_size=4, data=data,
+                       out_directory_root=str(tmp_path), resume=True, discard=None)
+    prog2 = json.load(open(os.path.join(out, 'progress.json')))
+    assert prog2['summary']['Start epoch'] == 6 and len(prog2['performance']['loss']['training']) == 8
+    assert prog2['performance']['loss']['training'][6] < perf['loss']['training'][0]            # resumed, not restarted
+    with pytest.raises(ValueError):
+        tp.train_nip_model(net, 'synthetic', patch_size=32, batch_size=16, data=data, out_directory_root=str(tmp_path))
+
+
+@pytest.mark.parametrize('feed', ['host', 'device'])
+def test_dcn_pretraining_harness(dev, tmp_path, feed):
+    """H2 (training/compression.py:123-309): flips, training_step per batch, lr reduction schedule, validation metrics,
+    progress.json and checkpoint, from both dataset kinds."""
+    import json
+    import os
+    from neural_imaging_amd.helpers import dataset
+    from neural_imaging_amd.models import compression
+    from neural_imaging_amd.training import compression as tc
+    host = _tiny_dataset(8, 4, 96, 128, 64, seed=6)
+    data = dataset.Dataset.from_arrays({'y': host.data['training']['y']}, {'y': host.data['validation']['y']})
+    if feed == 'device':
+        data = dataset.DeviceDataset(data, device=dev, seed=4)
+    np.random.seed(2)
+    dcn = compression.TwitterDCN(patch_size=64, n_features=8, device=dev)
+    spec = {'n_epochs': 13, 'batch_size': 4, 'patch_size': 64, 'learning_rate': 5e-4, 'validation_schedule': 4,
+            'learning_rate_reduction_schedule': 8}
+    out = tc.train_dcn(dcn, spec, data, directory=str(tmp_path))
+    prog = json.load(open(os.path.join(out, 'progress.json')))
+    perf = prog['performance']
+    assert len(perf['loss']['training']) == 13 and len(perf['entropy']['training']) == 13    # written at epochs 0, 4, 8, 12
+    assert all(len(perf[k]['validation']) == 4 for k in ('ssim', 'psnr', 'entropy', 'loss'))
+    tl = perf['loss']['training']
+    assert np.isfinite(tl).all() and np.mean(tl[-3:]) < np.mean(tl[:3]), tl
+    assert perf['psnr']['validation'][-1] > perf['psnr']['validation'][0]
+    assert os.path.isfile(os.path.join(out, 'twitterdcn.h5'))
+    assert tc.train_dcn(dcn, spec, data, directory=str(tmp_path)) == out                    # exists => skipped
+    restored = compression.TwitterDCN.restore(out, patch_size=64, device=dev)
+    for a, b_ in zip(dcn.parameters, restored.parameters):
+        assert torch.equal(a, b_)
+
