@@ -387,6 +387,34 @@ def test_workflow_with_inet(dev):
     assert wf.run_workflow_to_decisions(raw).shape == (12,)
 
 
+@pytest.mark.parametrize('metric', ['L1', 'SSIM'])
+def test_workflow_nip_loss_metric(dev, metric):
+    """ManipulationClassification(loss_metric=...) (workflows/manipulation_classification.py:14-15,268): the lambda_nip term
+    of the joint step uses the NIP's configured loss; its gradient reaches the NIP on top of the classification gradient
+    (checked against the same step with lambda_nip = 0 plus the stand-alone loss gradient - both passes are linear in it)."""
+    from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
+    dist = {'downsampling': 'none', 'compression': 'jpeg', 'compression_params': {'quality': 80, 'codec': 'soft'}}
+    rgb = natural_images(3, 64, 64, seed=9)
+    raw = bayer_from_rgb(rgb)
+    grads = {}
+    for lam in (0.0, 0.3):
+        wf = ManipulationClassification('INet', manipulations=['sharpen:1', 'gaussian:1'], distribution=dist,
+                                        trainable={'nip'}, raw_patch_size=32, loss_metric=metric, device=dev)
+        loss, parts = wf.training_step(raw, rgb, lambda_nip=lam, learning_rate=0.0)
+        grads[lam] = (wf.nip._model.flat_grad.clone(), float(loss), parts)
+    net = wf.nip
+    y, ctx = net.forward(torch.from_numpy(raw).to(dev), training=True)
+    lval, dy = net.loss_and_grad(y, torch.from_numpy(rgb).to(dev), grad_scale=0.3)
+    net._model.flat_grad.zero_()
+    net.backward(ctx, dy)
+    want = grads[0.0][0] + net._model.flat_grad
+    got = grads[0.3][0]
+    assert float((got - want).abs().max()) <= 2e-4 * float(want.abs().max())
+    assert abs(grads[0.3][1] - (grads[0.0][1] + 0.3 * float(lval.item()))) < 1e-3 * abs(grads[0.3][1])
+    with pytest.raises(ValueError):
+        ManipulationClassification('INet', distribution=dist, loss_metric='L3', device=dev)
+
+
 @pytest.mark.parametrize('n_layers,nf', [(4, 16), (3, 24)])
 def test_dnet_forward_backward(dev, n_layers, nf):
     """DNet (models/pipelines.py:298-349): VALID conv + ReLU + REFLECT re-pad chains, two-tensor projection, frozen
