@@ -666,6 +666,44 @@ def test_twitter_dcn_forward_backward(dev):
     assert yy.shape == (2, 32, 32, 3) and np.isfinite(float(ee))
 
 
+@pytest.mark.parametrize('family', ['INet', 'DNet', 'ClassicISP', 'TwitterDCN'])
+def test_model_families_in_throughput_mode(dev, family):
+    """Every model family besides the UNet / FAN pair of the bench also runs with bf16 MFMA operands (ops.set_compute('bf16')):
+    same weights, same input - the output stays within bf16 rounding of the float32 result and the parameter gradients
+    point the same way."""
+    from neural_imaging_amd import ops
+    from neural_imaging_amd.models import compression, pipelines
+    rgb = natural_images(4, 64, 64, seed=41)
+    raw = bayer_from_rgb(rgb)
+    make = {'INet': lambda: pipelines.INet(patch_size=32, random_init=True, device=dev),
+            'DNet': lambda: pipelines.DNet(patch_size=32, n_layers=4, n_features=16, device=dev),
+            'ClassicISP': lambda: pipelines.ClassicISP(patch_size=32, c_filters=(16, 16), kernel=3, device=dev),
+            'TwitterDCN': lambda: compression.TwitterDCN(patch_size=64, n_features=8, device=dev)}[family]
+    res = {}
+    for mode in ('f32', 'bf16'):
+        ops.set_compute(mode)
+        try:
+            net = make()
+            if family == 'TwitterDCN':
+                x = torch.from_numpy(rgb).to(dev)
+                y, ent, ctx = net.forward(x, training=True)
+                l2, dy = ops.l2_loss(x, y, grad_scale=1.0)
+                net.backward(ctx, dy, entropy_coef=250.0)
+            else:
+                y, ctx = net.forward(torch.from_numpy(raw).to(dev), training=True)
+                _, dy = net.loss_and_grad(y, torch.from_numpy(rgb).to(dev))
+                net.backward(ctx, dy)
+            res[mode] = (y.float().cpu().numpy(), net._model.flat_grad.clone())
+        finally:
+            ops.set_compute('f32')
+    assert np.isfinite(res['bf16'][0]).all()
+    assert np.abs(res['f32'][0] - res['bf16'][0]).max() < 0.06, np.abs(res['f32'][0] - res['bf16'][0]).max()
+    mse = float(np.mean((res['f32'][0] - res['bf16'][0]) ** 2))
+    assert 10 * np.log10(1.0 / max(mse, 1e-12)) > 38                              # PSNR between the two modes' outputs
+    a, b_ = res['f32'][1].double(), res['bf16'][1].double()
+    assert float((a * b_).sum() / (a.norm() * b_.norm())) > 0.97
+
+
 def test_workflow_bf16_throughput_mode(dev):
     """bf16 MFMA mode of the convolutions: judged like BASELINE.json asks - PSNR of the ISP output against the f32
     path, loss agreement, gradient direction - not on the 1e-4 contract."""
