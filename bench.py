@@ -209,7 +209,11 @@ def main():
                                    'dJPEG(QF80,soft)->FAN, ds none, trainable nip+fan, lambda_nip 0.1',
                        'raw_patch': args.raw_patch, 'rgb_patch': 2 * args.raw_patch,
                        'batch_per_gpu': args.batch, 'global_batch': world * args.batch, 'parallelism': 'dp%d' % world,
-                       'loss': float(loss), 'achieved_tflops_whole_step': value * GFLOP_PER_PATCH / 1e3},
+                       'loss': float(loss), 'achieved_tflops_whole_step': value * GFLOP_PER_PATCH / 1e3,
+                       # SURVEY 8d compulsory-traffic model of the whole step against 8 TB/s: one kernel per reference op
+                       # (343.8 MB bf16 / 687.5 MB f32 per raw patch) and the fused figure (141.9 / 283.8 MB)
+                       'hbm_frac_whole_step_op_by_op': value / world * (343.8e6 if args.dtype == 'bf16' else 687.5e6) / 8e12,
+                       'hbm_frac_whole_step_fused': value / world * (141.9e6 if args.dtype == 'bf16' else 283.8e6) / 8e12},
             'roofline': {'bound': 'mfma', 'achieved': dom['tflops'], 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': dom['tflops'] / peak, 'traffic': dom['traffic'], 'kernel': dom['kernel'],
                          'ms_per_launch': dom['ms_per_launch'], 'flops_per_launch': dom['flops_per_launch']},

@@ -62,6 +62,18 @@ def all_reduce_flag(flag):
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
 
 
+def broadcast_floats(values, device=None):
+    """Rank 0's host-side random draws for every rank (SURVEY 8e caveat 2: the augmentation strengths of a step are drawn once,
+    on the host, for the whole global batch - workflows/...:205)."""
+    values = [float(v) for v in values]
+    if not is_distributed() or not values:
+        return values
+    dev = device if dist.get_backend() == 'nccl' else 'cpu'
+    t = torch.tensor(values, dtype=torch.float64, device=dev)
+    dist.broadcast(t, src=0)
+    return t.cpu().tolist()
+
+
 def shard_batch(batch, rank_, world):
     """Contiguous shard of the global batch for this rank (labels are positional per rank, workflows/...:257-258)."""
     n = batch.shape[0]

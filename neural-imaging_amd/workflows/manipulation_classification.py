@@ -143,8 +143,15 @@ class ManipulationClassification(object):
         m = torch.empty((self.n_classes * b,) + tuple(Y.shape[1:]), dtype=torch.float32, device=Y.device)
         m[:b].copy_(Y)
         ctxs = []
+        names = list(self._operations.keys())
+        if randomize:         # one draw per operation and step from the numpy global stream (workflows/...:205); under data
+            # parallelism every rank draws (the streams stay in step) and rank 0's values are used everywhere
+            drawn = parallel.broadcast_floats([np.random.uniform(*self._strengths_range[n]) for n in names], Y.device)
+            strengths = dict(zip(names, drawn))
+        else:
+            strengths = override
         for k, (name, op) in enumerate(self._operations.items()):
-            s = override[name] if not randomize else np.random.uniform(*self._strengths_range[name])
+            s = strengths[name]
             _, ctx = op.forward(Y, s, out=m[(k + 1) * b:(k + 2) * b], training=training)
             ctxs.append(ctx)
         return m, ctxs

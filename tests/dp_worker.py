@@ -23,5 +23,6 @@ def dp_worker(rank, world, port, q):
     par.all_reduce_flag(flag)
     batch = torch.arange(8).reshape(8, 1)
     shard = par.shard_batch(batch, rank, world)
-    q.put((rank, float(flat[0]), int(flag[0]), shard.flatten().tolist()))
+    drawn = par.broadcast_floats([0.25 + rank, 7.0 * (rank + 1)])
+    q.put((rank, float(flat[0]), int(flag[0]), shard.flatten().tolist(), drawn))
     torch.distributed.destroy_process_group()

@@ -415,6 +415,31 @@ def test_workflow_nip_loss_metric(dev, metric):
         ManipulationClassification('INet', distribution=dist, loss_metric='L3', device=dev)
 
 
+def test_workflow_augmentation_strengths(dev):
+    """augment=True (workflows/manipulation_classification.py:199-208): one strength per operation and step from the numpy
+    global stream, inside the reference's ranges; the same seed reproduces the step, another one does not."""
+    from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
+    dist = {'downsampling': 'none', 'compression': 'jpeg', 'compression_params': {'quality': 80, 'codec': 'soft'}}
+    wf = ManipulationClassification('INet', manipulations=['sharpen', 'resample', 'gaussian', 'jpeg', 'awgn', 'gamma', 'median'],
+                                    distribution=dist, trainable={'nip'}, raw_patch_size=32, device=dev)
+    rgb = natural_images(2, 64, 64, seed=19)
+    raw = bayer_from_rgb(rgb)
+    outs = []
+    for seed in (5, 5, 6):
+        np.random.seed(seed)
+        m = wf.run_manipulations(wf.nip.process(raw), randomize=True).numpy()
+        assert m.shape == (8 * 2, 64, 64, 3) and np.isfinite(m).all()
+        probe = np.random.uniform()                      # position of the global stream after the draws
+        outs.append((m, probe))
+    keep = [i for i, n in enumerate(['native'] + list(wf._operations.keys())) if n != 'awgn']    # awgn adds device noise
+    rows = np.concatenate([np.arange(2 * i, 2 * i + 2) for i in keep])
+    assert np.array_equal(outs[0][0][rows], outs[1][0][rows]) and outs[0][1] == outs[1][1]
+    assert not np.array_equal(outs[0][0][rows], outs[2][0][rows])
+    np.random.seed(5)
+    loss, _ = wf.training_step(raw, rgb, lambda_nip=0.1, augment=True, learning_rate=1e-4)
+    assert np.isfinite(float(loss))
+
+
 @pytest.mark.parametrize('n_layers,nf', [(4, 16), (3, 24)])
 def test_dnet_forward_backward(dev, n_layers, nf):
     """DNet (models/pipelines.py:298-349): VALID conv + ReLU + REFLECT re-pad chains, two-tensor projection, frozen

@@ -309,3 +309,4 @@ def test_data_parallel_plumbing_gloo_world2():
     assert res[0][1] == 3.0 and res[1][1] == 3.0                  # sum all-reduce of the flat gradient buffers
     assert res[0][2] == 1 and res[1][2] == 1                      # NaN flag is OR-reduced
     assert res[0][3] == [0, 1, 2, 3] and res[1][3] == [4, 5, 6, 7]
+    assert res[0][4] == [0.25, 7.0] and res[1][4] == [0.25, 7.0]  # rank 0's augmentation draws reach every rank
