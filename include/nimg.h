@@ -200,6 +200,23 @@ int nimg_sharpen_bwd(const float* x, const float* dy, float* aux_hsv, const uint
 int nimg_sparse_axis_apply(const float* in, float* out, const int* rowptr, const int* col, const float* val, int n,
                            int hin, int win, int c, int axis, int out_size, void* stream);
 
+/* Building blocks of the MS-SSIM loss (helpers/tf_helpers.py:43-44 -> tf.image.ssim_multiscale, 5 scales, weights 0.0448,
+ * 0.2856, 0.3001, 0.2363, 0.1333; the 2x2 average pooling between the scales is nimg_avgpool_fwd / _bwd):
+ *  ssim_planes: per (image, channel) means of the SSIM map and of its contrast-structure factor (either may be NULL) over
+ *               the VALID positions of the 11x11 Gaussian window, and - which_maps 1 (SSIM) | 2 (cs) - the unscaled
+ *               derivative maps w.r.t. the window moments, 3 x n x (h-10) x (w-10) x c floats;
+ *  msssim_combine: values (scales, n*c) = cs means of scales 0..S-2 and the SSIM mean of the last one; items (scales) = window
+ *               positions per plane; loss = 255 (1 - mean prod relu(v)^w); coef (scales, n*c) = d loss / d v / items;
+ *  ssim_maps_grad: grad_y (+)= grad_scale * coef[n, c] * (transposed-window gather of the maps). */
+size_t nimg_ssim_planes_workspace_bytes(int n, int c);
+int nimg_ssim_planes(const float* y, const float* t, int n, int h, int w, int c, float max_val, const float* gauss_win,
+                     float* mean_ssim, float* mean_cs, float* maps, int which_maps, void* workspace,
+                     size_t workspace_bytes, void* stream);
+int nimg_msssim_combine(const float* values, const float* items, int scales, int planes, float* loss, float* coef,
+                        void* stream);
+int nimg_ssim_maps_grad(const float* y, const float* t, const float* maps, const float* coef, float* grad_y, int n,
+                        int h, int w, int c, const float* gauss_win, float grad_scale, int accumulate, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * GPU-resident training-data feed (helpers/dataset.py:89-131 `Dataset.next_training_batch`, helpers/loading.py:132-211
  * `sample_patch`).  rgb: (n_images, h, w, 3) uint8, raw: (n_images, h/2, w/2, 4) uint16, both resident in HBM.

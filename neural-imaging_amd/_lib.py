@@ -93,6 +93,10 @@ PROTOTYPES = {
     'nimg_patch_select': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P, P]),
     'nimg_patch_gather': (c_int, [P, P, c_int, c_int, c_int, P, P, c_int, c_int, P, P, P]),
     'nimg_mask_scale': (c_int, [P, P, P, c_long, c_float, P]),
+    'nimg_ssim_planes_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'nimg_ssim_planes': (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, P, P, P, P, c_int, P, c_size_t, P]),
+    'nimg_msssim_combine': (c_int, [P, P, c_int, c_int, P, P, P]),
+    'nimg_ssim_maps_grad': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P, c_float, c_int, P]),
     'nimg_pad2d': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'nimg_conv2d_fwd_bf16_ex': (c_int, [P, c_int, P, c_int, P, P, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int,
                                         c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),

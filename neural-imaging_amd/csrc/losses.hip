@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void ssim_loss_grad_kernel(const float* __rest
                                                              const float* __restrict__ maps, long plane,
                                                              float* grad, int n, int h, int w, int c,
                                                              const float* __restrict__ gk, float gscale,
-                                                             int accumulate) {
+                                                             int accumulate, const float* __restrict__ coef) {
     __shared__ float gs[WIN * WIN];
     if (threadIdx.x < WIN * WIN) gs[threadIdx.x] = gk[threadIdx.x];
     __syncthreads();
@@ -115,9 +115,98 @@ __global__ __launch_bounds__(256) void ssim_loss_grad_kernel(const float* __rest
                 sxy = fmaf(wt, maps[2 * plane + o], sxy);
             }
         }
-        const float g = gscale * (sm + 2.0f * y[i] * sxx + t[i] * sxy);
+        const float cf = coef ? coef[im * c + ch] : 1.0f;          // MS-SSIM: the maps are unscaled, the weight is per (n, c)
+        const float g = gscale * cf * (sm + 2.0f * y[i] * sxx + t[i] * sxy);
         grad[i] = accumulate ? grad[i] + g : g;
     }
+}
+
+// MS-SSIM building block (tf.image.ssim_multiscale -> _ssim_per_channel): per (image, channel) sums of the SSIM map
+// (luminance x contrast-structure) and of the contrast-structure map alone, plus - optionally - the UNSCALED derivative maps of
+// one of them w.r.t. the window moments (which = 1: SSIM, 2: cs).  Workgroups (n, ch, blk): every block stays in one plane.
+constexpr int BPP = 8;           // workgroups per (image, channel) plane
+__global__ __launch_bounds__(256) void ssim_planes_kernel(const float* __restrict__ y, const float* __restrict__ t,
+                                                          double* __restrict__ partial, float* __restrict__ maps,
+                                                          long plane, int h, int w, int c, float max_val,
+                                                          const float* __restrict__ gk, int which) {
+    __shared__ double red[8];
+    __shared__ float gs[WIN * WIN];
+    if (threadIdx.x < WIN * WIN) gs[threadIdx.x] = gk[threadIdx.x];
+    __syncthreads();
+    const int blk = blockIdx.x % BPP, ch = (blockIdx.x / BPP) % c, n = blockIdx.x / (BPP * c);
+    const int ho = h - WIN + 1, wo = w - WIN + 1;
+    const int items = ho * wo;
+    const double c1 = (0.01 * max_val) * (0.01 * max_val), c2 = (0.03 * max_val) * (0.03 * max_val);
+    double s_ssim = 0.0, s_cs = 0.0;
+    for (int i = blk * 256 + threadIdx.x; i < items; i += BPP * 256) {
+        const int x0 = i % wo, y0 = i / wo;
+        double ey = 0, et = 0, eyy = 0, ett = 0, eyt = 0;
+        for (int dy = 0; dy < WIN; ++dy) {
+            const long row = (((long)n * h + y0 + dy) * w + x0) * c + ch;
+#pragma unroll
+            for (int dx = 0; dx < WIN; ++dx) {
+                const double wt = (double)gs[dy * WIN + dx];
+                const double vy = y[row + (long)dx * c], vt = t[row + (long)dx * c];
+                ey += wt * vy; et += wt * vt; eyy += wt * vy * vy; ett += wt * vt * vt; eyt += wt * vy * vt;
+            }
+        }
+        const double a1 = 2 * ey * et + c1, a2 = 2 * (eyt - ey * et) + c2;
+        const double b1 = ey * ey + et * et + c1, b2 = (eyy - ey * ey) + (ett - et * et) + c2;
+        const double cs = a2 / b2, ss = a1 * cs / b1;
+        s_ssim += ss;
+        s_cs += cs;
+        if (maps && which) {
+            const long o = (((long)n * ho + y0) * wo + x0) * c + ch;
+            if (which == 1) {
+                const double inv = 1.0 / (b1 * b2);
+                maps[o] = (float)(2 * et * (a2 - a1) * inv - ss * 2 * ey * (b2 - b1) * inv);
+                maps[plane + o] = (float)(-ss / b2);
+                maps[2 * plane + o] = (float)(2 * a1 * inv);
+            } else {
+                maps[o] = (float)((-2 * et * b2 + 2 * ey * a2) / (b2 * b2));
+                maps[plane + o] = (float)(-a2 / (b2 * b2));
+                maps[2 * plane + o] = (float)(2.0 / b2);
+            }
+        }
+    }
+    s_ssim = wave_sum_d(s_ssim);
+    s_cs = wave_sum_d(s_cs);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s_ssim; red[4 + (threadIdx.x >> 6)] = s_cs; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+        partial[2 * blockIdx.x + 1] = red[4] + red[5] + red[6] + red[7];
+    }
+}
+
+__global__ void ssim_planes_final_kernel(const double* __restrict__ partial, int planes, double inv_items,
+                                         float* __restrict__ mean_ssim, float* __restrict__ mean_cs) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= planes) return;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < BPP; ++k) { a += partial[2 * (p * BPP + k)]; b += partial[2 * (p * BPP + k) + 1]; }
+    if (mean_ssim) mean_ssim[p] = (float)(a * inv_items);
+    if (mean_cs) mean_cs[p] = (float)(b * inv_items);
+}
+
+// ms[n][c] = prod_k relu(v[k][n][c]) ^ w[k];  loss = 255 (1 - mean ms);  coef[k][n][c] = d loss / d v[k][n][c] / items[k]
+__global__ __launch_bounds__(64) void msssim_combine_kernel(const float* __restrict__ v, const float* __restrict__ items,
+                                                            int scales, int planes, float* __restrict__ loss,
+                                                            float* __restrict__ coef) {
+    const float wts[5] = {0.0448f, 0.2856f, 0.3001f, 0.2363f, 0.1333f};
+    double acc = 0.0;
+    for (int p = threadIdx.x; p < planes; p += 64) {
+        double ms = 1.0;
+        for (int k = 0; k < scales; ++k) ms *= pow((double)fmaxf(v[k * planes + p], 0.f), (double)wts[k]);
+        acc += ms;
+        if (coef)
+            for (int k = 0; k < scales; ++k) {
+                const float vk = v[k * planes + p];
+                coef[k * planes + p] = vk > 0.f ? (float)(-255.0 / planes * wts[k] * ms / vk / items[k]) : 0.f;
+            }
+    }
+    acc = wave_sum_d(acc);
+    if (threadIdx.x == 0) loss[0] = (float)(255.0 * (1.0 - acc / planes));
 }
 
 }  // namespace
@@ -167,9 +256,49 @@ int nimg_ssim_loss(const float* y, const float* t, float* loss, float* grad_y, i
     NIMG_CHECK_LAUNCH();
     if (grad_y) {
         hipLaunchKernelGGL(ssim_loss_grad_kernel, dim3(grid_for((long)n * h * w * c)), dim3(256), 0, s, y, t, maps, plane,
-                           grad_y, n, h, w, c, gauss_win, grad_scale, accumulate);
+                           grad_y, n, h, w, c, gauss_win, grad_scale, accumulate, (const float*)nullptr);
         NIMG_CHECK_LAUNCH();
     }
+    return NIMG_OK;
+}
+
+size_t nimg_ssim_planes_workspace_bytes(int n, int c) { return (size_t)2 * n * c * BPP * sizeof(double); }
+
+int nimg_ssim_planes(const float* y, const float* t, int n, int h, int w, int c, float max_val, const float* gauss_win,
+                     float* mean_ssim, float* mean_cs, float* maps, int which_maps, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+    if (!y || !t || !gauss_win || !workspace || n <= 0 || c <= 0 || h < WIN || w < WIN || !(max_val > 0.f) ||
+        which_maps < 0 || which_maps > 2 || (which_maps && !maps) || (long)n * c * BPP > 0x7fffffffL)
+        return NIMG_ERR_ARG;
+    if (workspace_bytes < nimg_ssim_planes_workspace_bytes(n, c)) return NIMG_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const long plane = (long)n * (h - WIN + 1) * (w - WIN + 1) * c;
+    hipLaunchKernelGGL(ssim_planes_kernel, dim3(n * c * BPP), dim3(256), 0, s, y, t, (double*)workspace, maps, plane, h, w,
+                       c, max_val, gauss_win, which_maps);
+    NIMG_CHECK_LAUNCH();
+    const int planes = n * c;
+    hipLaunchKernelGGL(ssim_planes_final_kernel, dim3((planes + 63) / 64), dim3(64), 0, s, (const double*)workspace, planes,
+                       1.0 / ((double)(h - WIN + 1) * (w - WIN + 1)), mean_ssim, mean_cs);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_msssim_combine(const float* values, const float* items, int scales, int planes, float* loss, float* coef,
+                        void* stream) {
+    if (!values || !items || !loss || scales < 1 || scales > 5 || planes <= 0) return NIMG_ERR_ARG;
+    hipLaunchKernelGGL(msssim_combine_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, values, items, scales, planes,
+                       loss, coef);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_ssim_maps_grad(const float* y, const float* t, const float* maps, const float* coef, float* grad_y, int n,
+                        int h, int w, int c, const float* gauss_win, float grad_scale, int accumulate, void* stream) {
+    if (!y || !t || !maps || !grad_y || !gauss_win || n <= 0 || c <= 0 || h < WIN || w < WIN) return NIMG_ERR_ARG;
+    const long plane = (long)n * (h - WIN + 1) * (w - WIN + 1) * c;
+    hipLaunchKernelGGL(ssim_loss_grad_kernel, dim3(grid_for((long)n * h * w * c)), dim3(256), 0, (hipStream_t)stream, y,
+                       t, maps, plane, grad_y, n, h, w, c, gauss_win, grad_scale, accumulate, coef);
+    NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }
 

@@ -35,12 +35,10 @@ class NIPModel(TFModel):
         self.construct_loss(loss_metric)
 
     def construct_loss(self, loss_metric):
-        """L2 | L1 | SSIM on 255-scaled images (pipelines.py:53-63 -> helpers/tf_helpers.py:31-40)."""
+        """L2 | L1 | SSIM | MS-SSIM on 255-scaled images (pipelines.py:53-63 -> helpers/tf_helpers.py:31-44)."""
         if loss_metric in ops.IMAGE_LOSSES:
             self._loss_fn = ops.IMAGE_LOSSES[loss_metric]
             self.loss = lambda a, b: DeviceArray(self._loss_fn(to_device(a, self.device), to_device(b, self.device))[0])
-        elif loss_metric == 'MS-SSIM':
-            raise NotImplementedError('loss metric MS-SSIM is not built (tf.image.ssim_multiscale, 5 scales)')
         else:
             raise ValueError('Unsupported loss metric!')
 

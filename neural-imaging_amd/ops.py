@@ -892,7 +892,61 @@ def ssim_loss(y, t, grad_scale=None, grad_out=None, accumulate=False, max_val=1.
     return loss, g
 
 
-IMAGE_LOSSES = {'L2': mse255, 'L1': mae255, 'SSIM': ssim_loss}
+MSSSIM_SCALES = 5
+
+
+def msssim_loss(y, t, grad_scale=None, grad_out=None, accumulate=False, max_val=1.0):
+    """helpers/tf_helpers.py:43-44 mean 255 (1 - tf.image.ssim_multiscale(y, t, 1)): contrast-structure means of four scales
+    and the SSIM mean of the fifth, each scale a 2x2 average pooling of the previous one, combined by the weighted geometric
+    mean per (image, channel).  Returns (loss[1], grad wrt y or None).  Sizes must be multiples of 16 with H/16, W/16 >= 11
+    (TF pads odd scales symmetrically instead; not built)."""
+    _f32(y, t, grad_out)
+    n, h, w, c = y.shape
+    div = 1 << (MSSSIM_SCALES - 1)
+    if h % div or w % div or h // div < 11 or w // div < 11:
+        raise ValueError('MS-SSIM needs image sizes that are multiples of {} and at least {} pixels'.format(div, 11 * div))
+    dev = y.device
+    gk = _ssim_window(dev)
+    planes = n * c
+    values = torch.empty((MSSSIM_SCALES, planes), dtype=torch.float32, device=dev)
+    items = torch.tensor([float((h // (1 << k) - 10) * (w // (1 << k) - 10)) for k in range(MSSSIM_SCALES)],
+                         dtype=torch.float32, device=dev)
+    want_grad = grad_scale is not None
+    ys, ts, maps = [y], [t], []
+    ws = _ws.get(_lib.load().nimg_ssim_planes_workspace_bytes(n, c), dev)
+    for k in range(MSSSIM_SCALES):
+        if k > 0:
+            ys.append(avgpool(ys[-1], 2))
+            ts.append(avgpool(ts[-1], 2))
+        hk, wk = ys[k].shape[1], ys[k].shape[2]
+        last = k == MSSSIM_SCALES - 1
+        mp = torch.empty((3, n, hk - 10, wk - 10, c), dtype=torch.float32, device=dev) if want_grad else None
+        maps.append(mp)
+        _lib.call('nimg_ssim_planes', _p(ys[k]), _p(ts[k]), n, hk, wk, c, float(max_val), _p(gk),
+                  _p(values[k]) if last else None, None if last else _p(values[k]), _p(mp),
+                  (1 if last else 2) if want_grad else 0, _p(ws), ws.numel(), _stream())
+    loss = torch.empty((1,), dtype=torch.float32, device=dev)
+    coef = torch.empty_like(values) if want_grad else None
+    _lib.call('nimg_msssim_combine', _p(values), _p(items), MSSSIM_SCALES, planes, _p(loss), _p(coef), _stream())
+    if not want_grad:
+        return loss, None
+    acc = None
+    for k in range(MSSSIM_SCALES - 1, -1, -1):           # coarse to fine: g_k + un-pooled gradient of the coarser scales
+        hk, wk = ys[k].shape[1], ys[k].shape[2]
+        if k == 0:
+            g = torch.empty_like(y) if grad_out is None else grad_out
+            acc_flag = accumulate
+        else:
+            g, acc_flag = torch.empty_like(ys[k]), False
+        _lib.call('nimg_ssim_maps_grad', _p(ys[k]), _p(ts[k]), _p(maps[k]), _p(coef[k]), _p(g), n, hk, wk, c, _p(gk),
+                  float(grad_scale), 1 if acc_flag else 0, _stream())
+        if acc is not None:
+            add(g, avgpool_bwd(acc, 2), out=g)
+        acc = g
+    return loss, acc
+
+
+IMAGE_LOSSES = {'L2': mse255, 'L1': mae255, 'SSIM': ssim_loss, 'MS-SSIM': msssim_loss}
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -339,5 +339,47 @@ def ssim_loss255(a, b):
     return torch.mean(255 * (1 - ssim_tf(a, b, 1.0)))
 
 
-IMAGE_LOSSES = {'L2': mse255, 'L1': mae255, 'SSIM': ssim_loss255}
+def _ssim_per_channel(a, b, max_val=1.0):
+    """tf.image _ssim_per_channel: per (image, channel) means of luminance x contrast-structure and of contrast-structure."""
+    co = torch.arange(11, dtype=a.dtype) - 5.0
+    g = -0.5 * (co[:, None] ** 2 + co[None, :] ** 2) / 1.5 ** 2
+    g = torch.softmax(g.reshape(-1), 0).reshape(1, 1, 11, 11)
+    c = a.shape[-1]
+    k = g.repeat(c, 1, 1, 1)
+    f = lambda t: F.conv2d(t.permute(0, 3, 1, 2), k, groups=c)
+    c1, c2 = (0.01 * max_val) ** 2, (0.03 * max_val) ** 2
+    m0, m1 = f(a), f(b)
+    num0, den0 = m0 * m1 * 2.0, m0 * m0 + m1 * m1
+    lum = (num0 + c1) / (den0 + c1)
+    num1, den1 = f(a * b) * 2.0, f(a * a + b * b)
+    cs = (num1 - num0 + c2) / (den1 - den0 + c2)
+    return (lum * cs).mean(dim=(2, 3)), cs.mean(dim=(2, 3))
+
+
+MSSSIM_WEIGHTS = (0.0448, 0.2856, 0.3001, 0.2363, 0.1333)
+
+
+def ssim_multiscale(a, b, max_val=1.0):
+    """tf.image.ssim_multiscale (TF 2.1 image_ops_impl): five scales, each a 2x2 VALID average pooling of the previous one
+    (even sizes assumed - TF pads odd ones symmetrically), relu(cs) of scales 0..3 and relu(ssim) of scale 4 raised to the
+    power factors, product over the scales, mean over the channels.  -> (N,)"""
+    mcs = []
+    for k in range(len(MSSSIM_WEIGHTS)):
+        if k > 0:
+            a = F.avg_pool2d(a.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+            b = F.avg_pool2d(b.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+        ssim_pc, cs = _ssim_per_channel(a, b, max_val)
+        mcs.append(torch.relu(cs))
+    mcs.pop()
+    stack = torch.stack(mcs + [torch.relu(ssim_pc)], dim=-1)
+    w = torch.tensor(MSSSIM_WEIGHTS, dtype=a.dtype)
+    return torch.prod(stack ** w, dim=-1).mean(dim=-1)
+
+
+def msssim_loss255(a, b):
+    """helpers/tf_helpers.py:43-44."""
+    return torch.mean(255 * (1 - ssim_multiscale(a, b, 1.0)))
+
+
+IMAGE_LOSSES = {'L2': mse255, 'L1': mae255, 'SSIM': ssim_loss255, 'MS-SSIM': msssim_loss255}
 

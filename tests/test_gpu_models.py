@@ -339,13 +339,14 @@ def test_classic_isp_forward_backward_and_training(dev, kernel, c_filters, resid
     assert np.array_equal(net.state_dict()['up/kernel'].reshape(4, 12), hk.upsampling_kernel('gbrg').reshape(4, 12))
 
 
-@pytest.mark.parametrize('metric', ['L1', 'SSIM'])
+@pytest.mark.parametrize('metric', ['L1', 'SSIM', 'MS-SSIM'])
 def test_nip_loss_metrics(dev, metric):
     """NIPModel(loss_metric=...) (models/pipelines.py:53-63): loss value and every UNet gradient of one training step on
-    the L1 / SSIM loss against autograd through the float64 oracle; MS-SSIM is refused."""
+    the L1 / SSIM / MS-SSIM loss against autograd through the float64 oracle."""
     from neural_imaging_amd.models import pipelines
-    net = pipelines.UNet(loss_metric=metric, patch_size=16, device=dev)
-    rgb = natural_images(2, 32, 32, seed=11)
+    side = 96 if metric == 'MS-SSIM' else 16                 # five scales need >= 176 output pixels
+    net = pipelines.UNet(loss_metric=metric, patch_size=side, device=dev)
+    rgb = natural_images(2, 2 * side, 2 * side, seed=11)
     raw = bayer_from_rgb(rgb)
     p = oracle_params(net)
     names = list(p.keys())
@@ -360,13 +361,15 @@ def test_nip_loss_metrics(dev, metric):
     assert abs(float(loss.item()) - float(loss_ref)) / float(loss_ref) < 1e-5
     assert abs(float(net.loss(y, rgb)) - float(loss_ref)) / float(loss_ref) < 1e-5
     net.backward(ctx, dy)
-    check_grads(grads_of(net), g_ref, names, tol=3e-4)
+    # 192 x 192: the float32 sums of the UNet's deepest layers alone are off by 4e-4 (L2) .. 1.1e-3 (SSIM) of the layer's
+    # largest gradient at this size (measured); the loss gradient itself matches to 1e-5 (test_image_losses_with_gradient)
+    check_grads(grads_of(net), g_ref, names, tol=3e-4 if side == 16 else 3e-3)
     l0 = float(net.training_step(raw, rgb, learning_rate=1e-3))
     for _ in range(10):
         l1 = float(net.training_step(raw, rgb, learning_rate=1e-3))
     assert l1 < l0
-    with pytest.raises(NotImplementedError):
-        pipelines.UNet(loss_metric='MS-SSIM', patch_size=16, device=dev)
+    with pytest.raises(ValueError):
+        pipelines.UNet(loss_metric='L3', patch_size=16, device=dev)
 
 
 def test_workflow_with_inet(dev):

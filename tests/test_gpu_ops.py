@@ -706,7 +706,8 @@ def test_classic_isp_pointwise(dev, count):
 
 
 @pytest.mark.parametrize('metric,shape', [('L1', (2, 16, 16, 3)), ('L1', (1, 7, 5, 3)), ('SSIM', (3, 32, 40, 3)),
-                                          ('SSIM', (1, 11, 11, 3)), ('SSIM', (2, 17, 12, 1)), ('L2', (2, 16, 16, 3))])
+                                          ('SSIM', (1, 11, 11, 3)), ('SSIM', (2, 17, 12, 1)), ('L2', (2, 16, 16, 3)),
+                                          ('MS-SSIM', (2, 176, 192, 3)), ('MS-SSIM', (1, 256, 256, 1))])
 def test_image_losses_with_gradient(dev, metric, shape):
     """The NIP training losses (helpers/tf_helpers.py:31-40 via models/pipelines.py:53-63): value, gradient w.r.t. the
     developed image, gradient accumulation with a scale (the workflow's lambda_nip term)."""
@@ -731,6 +732,9 @@ def test_image_losses_with_gradient(dev, metric, shape):
     if metric == 'SSIM':
         with pytest.raises(ValueError):
             ops.ssim_loss(g(y[:, :10], dev), g(t[:, :10], dev))
+    if metric == 'MS-SSIM':
+        with pytest.raises(ValueError):
+            ops.msssim_loss(g(y[:, :168], dev), g(t[:, :168], dev))
 
 
 def _feed_images(n, h, w, seed):
