@@ -23,7 +23,7 @@ def default_training_specs():
 
 class SyntheticDataset(object):
     """Stand-in with the interface of helpers/dataset.Dataset (next_training_batch / next_validation_batch /
-    count_* / is_raw_and_rgb / summary): natural-image-like RGB patches and their GBRG Bayer stacks."""
+    count_* / is_raw_and_rgb / summary): natural-image-like RGB patches and their RGGB-ordered Bayer stacks of a GBRG mosaic."""
 
     def __init__(self, n_training=40, n_validation=20, patch_size=64, seed=1234, raw=True):
         rng = np.random.default_rng(seed)
@@ -41,7 +41,8 @@ class SyntheticDataset(object):
 
     @staticmethod
     def _bayer(rgb):
-        return np.stack([rgb[:, 0::2, 0::2, 1], rgb[:, 0::2, 1::2, 2], rgb[:, 1::2, 0::2, 0], rgb[:, 1::2, 1::2, 1]],
+        # RGGB-ordered stack of a GBRG mosaic (helpers/raw.py:204-225 stack_bayer): R (1,0), G1 (0,0), G2 (1,1), B (0,1)
+        return np.stack([rgb[:, 1::2, 0::2, 0], rgb[:, 0::2, 0::2, 1], rgb[:, 1::2, 1::2, 1], rgb[:, 0::2, 1::2, 2]],
                         axis=-1).astype(np.float32)
 
     def is_raw_and_rgb(self):

@@ -372,6 +372,27 @@ def test_nip_loss_metrics(dev, metric):
         pipelines.UNet(loss_metric='L3', patch_size=16, device=dev)
 
 
+def test_classic_isp_develops_a_reference_ordered_raw(dev):
+    """The constants of ClassicISP / INet mean something only for the reference's RAW layout (helpers/raw.py:204-225: an RGGB-
+    ordered stack, the CFA pattern says where the planes sit): with that layout the parameter-free ClassicISP - bilinear
+    demosaicing, identity colour matrix, gamma - reproduces a smooth image, and INet's hand-set constants come close."""
+    from util import stack_bayer
+    from neural_imaging_amd.models import pipelines
+    yy, xx = np.mgrid[0:64, 0:64] / 64.0
+    rgb = np.stack([0.2 + 0.6 * xx, 0.5 + 0.3 * np.sin(3 * yy), 0.7 - 0.5 * xx * yy], axis=-1)[None].astype(np.float32)
+    raw = stack_bayer(rgb)
+    isp = pipelines.ClassicISP(patch_size=32, device=dev)                  # c_filters=(): no CNN, nothing to train
+    y = isp.process(raw).numpy()
+    want = np.power(np.clip(rgb, 1 / 255, 1), 1 / 2.2)
+    psnr = lambda a, b: 10 * np.log10(1.0 / np.mean((a - b) ** 2))
+    assert psnr(y[:, 2:-2, 2:-2], want[:, 2:-2, 2:-2]) > 45
+    swapped = isp.process(bayer_from_rgb(rgb)).numpy()                      # the position-ordered stack is NOT that layout
+    assert psnr(swapped[:, 2:-2, 2:-2], want[:, 2:-2, 2:-2]) < 25
+    right = psnr(y[:, 2:-2, 2:-2], want[:, 2:-2, 2:-2])
+    isp.set_cfa_pattern('rggb')                    # a wrong CFA pattern keeps the colours but shifts the samples by a pixel
+    assert psnr(isp.process(raw).numpy()[:, 2:-2, 2:-2], want[:, 2:-2, 2:-2]) < right - 3
+
+
 def test_workflow_with_inet(dev):
     """train_manipulation.py --nip INet --train nip (config/tests/framework.json 'train-manipulation')."""
     from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification

@@ -186,3 +186,83 @@ def test_oracle_ssim_flavours():
     s_noisy = T.ssim_tf(torch.from_numpy(img), torch.from_numpy(noisy))
     assert torch.allclose(s_same, torch.ones(2, dtype=torch.float64)) and bool((s_noisy < 0.99).all())
     assert abs(T.ssim_skimage(img[0], img[0]) - 1.0) < 1e-12 and T.ssim_skimage(img[0], noisy[0]) < 0.99
+
+
+def test_oracle_msssim_known_answers():
+    """ssim_multiscale: 1 for identical images, symmetric, equal to the hand-combined per-scale statistics (weights 0.0448 ..
+    0.1333, cs of scales 0-3, ssim of scale 4), a single-scale ssim_tf consistent with its per-channel parts."""
+    import torch.nn.functional as F
+    rng = np.random.RandomState(8)
+    a = torch.from_numpy(natural_images(2, 176, 192, seed=3).astype(np.float64))
+    b = (a + 0.06 * torch.from_numpy(rng.randn(*a.shape))).clamp(0, 1)
+    assert torch.allclose(T.ssim_multiscale(a, a), torch.ones(2, dtype=torch.float64))
+    ms = T.ssim_multiscale(a, b)
+    assert torch.allclose(ms, T.ssim_multiscale(b, a)) and bool((ms < 0.999).all()) and bool((ms > 0).all())
+    ssim_pc, cs_pc = T._ssim_per_channel(a, b)
+    assert torch.allclose(ssim_pc.mean(dim=1), T.ssim_tf(a, b))
+    vals, x, y = [], a, b
+    for k in range(5):
+        if k:
+            x = F.avg_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+            y = F.avg_pool2d(y.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+        s_, c_ = T._ssim_per_channel(x, y)
+        vals.append(s_ if k == 4 else c_)
+    want = torch.ones_like(vals[0])
+    for v, w in zip(vals, T.MSSSIM_WEIGHTS):
+        want = want * torch.relu(v) ** w
+    assert torch.allclose(ms, want.mean(dim=1))
+    assert abs(float(T.msssim_loss255(a, b)) - float((255 * (1 - ms)).mean())) < 1e-12
+
+
+def test_oracle_classic_isp_known_answers():
+    """classic_isp_forward: with alpha = 0 (or no CNN) the residual ISP is bilinear demosaicing -> colour matrix -> gamma of
+    the clipped value; the gamma stage keeps a gradient below 1/255 (straight-through clip)."""
+    from oracle import tables as ot2
+    from util import stack_bayer
+    from neural_imaging_amd.helpers import kernels as hk
+    col = np.array([0.8, 0.35, 0.002])                      # a flat colour: bilinear demosaicing must return it everywhere
+    rgb = np.broadcast_to(col, (1, 16, 16, 3)).astype(np.float32)
+    raw = stack_bayer(rgb).astype(np.float64)
+    p = {'up/kernel': to64(hk.upsampling_kernel('gbrg').reshape(1, 1, 4, 12)),
+         'bilinear/kernel': to64(np.asarray(hk.bilin_kernel(5)).reshape(5, 5, 3, 3)),
+         'srgb/kernel': to64(np.eye(3).reshape(1, 1, 3, 3)), 'demosaicing/alpha': to64(np.array([0.1]))}
+    y = onets.classic_isp_forward(p, to64(raw), residual=True)
+    want = np.maximum(col.astype(np.float32).astype(np.float64), 1 / 255) ** (1 / 2.2)
+    assert y.shape == (1, 16, 16, 3) and np.abs(y.numpy()[:, 2:-2, 2:-2] - want).max() < 1e-6      # REFLECT border aside
+    x = torch.tensor([0.0, 1e-3, 0.5, 2.0], dtype=torch.float64, requires_grad=True)
+    g = x + (torch.clamp(x, 1 / 255, 1) - x).detach()
+    out = torch.pow(g, 1 / 2.2)
+    out.sum().backward()
+    assert float(x.grad[0]) > 1.0 and abs(float(x.grad[3]) - 1 / 2.2) < 1e-12       # clipped values keep d/dx of pow
+
+
+def test_oracle_datafeed_policy_consistency():
+    """oracle/datafeed.select over the candidate list that sample_patch itself drew gives sample_patch's answer (the two share
+    the Policy the device kernel is checked against), and cut_batch normalises like dataset.py:124-126."""
+    from oracle import datafeed as odf
+    d = np.load(os.path.join(ROOT, 'tests', 'golden', 'datafeed_sample_patch.npz'))
+    img = d['images'][0]
+
+    class Rec(object):                      # records the draws of one sample_patch call
+        def __init__(self, seed):
+            self.r = np.random.RandomState(seed); self.xy = []; self.u = []; self._pend = []
+        def randint(self, lo, hi):
+            v = self.r.randint(lo, hi); self._pend.append(v)
+            if len(self._pend) == 2:
+                self.xy.append((2 * (self._pend[0] // 2), 2 * (self._pend[1] // 2))); self.u.append(0.75); self._pend = []
+            return v
+        def uniform(self):
+            v = self.r.uniform(); self.u[-1] = v
+            return v
+    for mode in ('flat', 'flat-aggressive', 'dark-n-textured'):
+        for seed in range(6):
+            rec = Rec(seed)
+            want = odf.sample_patch(img, 32, mode, 6, rng=rec)
+            got, used = odf.select(img, rec.xy, rec.u, 32, mode, 6)
+            assert got == tuple(want) and used == len(rec.xy), (mode, seed)
+    raw = np.arange(2 * 8 * 8 * 4, dtype=np.uint16).reshape(2, 8, 8, 4) * 100
+    rgb = (np.arange(2 * 16 * 16 * 3) % 256).astype(np.uint8).reshape(2, 16, 16, 3)
+    x, y = odf.cut_batch(raw, rgb, [1, 0], [(2, 4), (0, 0)], 8)
+    assert x.dtype == np.float32 and np.array_equal(x[0], (raw[1, 2:6, 1:5] / 65535.0).astype(np.float32))
+    assert np.array_equal(y[1], (rgb[0, :8, :8] / 255.0).astype(np.float32))
+

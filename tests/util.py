@@ -14,12 +14,21 @@ def natural_images(n, h, w, seed=0):
 
 
 def bayer_from_rgb(rgb):
-    """GBRG Bayer stack (N,h/2,w/2,4) of an RGB batch - a synthetic RAW input for the UNet."""
+    """Position-ordered Bayer stack (N,h/2,w/2,4) of an RGB batch on a GBRG mosaic: planes taken at (0,0), (0,1), (1,0), (1,1)
+    = G, B, R, G.  A synthetic RAW input for the learned pipelines (which do not care about the plane order); the parity
+    tolerances of the workflow tests were tuned on it.  The reference's own order is stack_bayer() below."""
     g1 = rgb[:, 0::2, 0::2, 1]
     b = rgb[:, 0::2, 1::2, 2]
     r = rgb[:, 1::2, 0::2, 0]
     g2 = rgb[:, 1::2, 1::2, 1]
     return np.stack([g1, b, r, g2], axis=-1).astype(np.float32)
+
+
+def stack_bayer(rgb):
+    """RGGB-ordered stack of a GBRG mosaic like the reference's helpers/raw.py:204-225 `stack_bayer(image, 'GBRG')`: planes
+    (R, G1, G2, B) taken at (1,0), (0,0), (1,1), (0,1) - what upsampling_kernel('gbrg') puts back in place."""
+    return np.stack([rgb[:, 1::2, 0::2, 0], rgb[:, 0::2, 0::2, 1], rgb[:, 1::2, 1::2, 1], rgb[:, 0::2, 1::2, 2]],
+                    axis=-1).astype(np.float32)
 
 
 def to64(a):
