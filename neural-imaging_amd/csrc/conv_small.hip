@@ -42,21 +42,25 @@ __global__ __launch_bounds__(256) void conv_fewout_kernel(const SmallParams p) {
 #pragma unroll
         for (int o = 0; o < COUT; ++o) acc[j][o] = 0.f;
 
-    // 3-channel case (the ConstrainedConv2D filter and its input gradient): the weights sit in LDS and one kernel row of them
-    // at a time in VGPRs (wave-uniform addresses = broadcast reads).  Indexed straight from memory they are wave-uniform scalar loads -
-    // 507 s_load + 120 s_waitcnt in front of 450 v_pk_fma_f32 per thread, i.e. the kernel waited on the scalar cache.
-    constexpr bool WREG = (CK == 3);
-    constexpr int WROW = KS * 3 * COUT, WROWP = (WROW + 3) / 4 * 4;      // weights of one kernel row, padded to float4
-    float* wl = smem + (THH * TWH * CKP + 3) / 4 * 4;                   // [KS][WROWP], behind the halo tile
-    if constexpr (WREG) {
+    // Many-channel case (CK = 8: the FAN conv1 input gradient in float32 mode): the weights of the current channel chunk
+    // sit in LDS and one kernel row of them at a time in VGPRs (wave-uniform addresses = broadcast reads) instead of being
+    // wave-uniform scalar loads in the FMA loop: +1.9 % float32-mode step.  For the 3-channel filter (225 weights) the same
+    // change is neutral stand-alone and costs 1.7 % of the bf16-mode step (more LDS per workgroup next to the kernels it
+    // overlaps with), so that case keeps the scalar loads (three same-box A/B pairs each).
+    constexpr bool WLDS = (CK != 3);
+    constexpr int WROW = KS * CK * COUT, WROWP = (WROW + 3) / 4 * 4;     // weights of one kernel row and channel chunk
+    float* wl = smem + (THH * TWH * CKP + 3) / 4 * 4;                   // [KS][kx][k][o] padded to WROWP, behind the halo tile
+
+    auto stage_weights = [&](int c0) {                      // this chunk's weights: w[(ky*KS + kx)*Cin + c0 + k][o]
         for (int i = tid; i < KS * WROWP; i += 256) {
             const int ky = i / WROWP, r = i % WROWP;
-            wl[i] = (p.Cin == 3 && r < WROW) ? p.w[ky * WROW + r] : 0.f;
+            const int o = r % COUT, k = (r / COUT) % CK, kx = r / (COUT * CK);
+            wl[i] = (r < WROW && c0 + k < p.Cin) ? p.w[((long)(ky * KS + kx) * p.Cin + c0 + k) * COUT + o] : 0.f;
         }
-    }
-
+    };
     for (int c0 = 0; c0 < p.Cin; c0 += CK) {
         __syncthreads();
+        if constexpr (WLDS) stage_weights(c0);
         // staged in batches of 8 independent loads per thread (a rolled loop would serialise 16 global round trips)
         constexpr int NITEM = THH * TWH * CK, NIT = (NITEM + 255) / 256;
 #pragma unroll 8
@@ -76,8 +80,8 @@ __global__ __launch_bounds__(256) void conv_fewout_kernel(const SmallParams p) {
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky) {
             const float* row = smem + ((ty + ky) * TWH + tx * S_PW) * CKP;
-            float wrow[WREG ? WROWP : 4];                   // this kernel row's weights: wave-uniform LDS reads (broadcast)
-            if constexpr (WREG) {
+            float wrow[WLDS ? WROWP : 4];                   // this kernel row's weights: wave-uniform LDS reads (broadcast)
+            if constexpr (WLDS) {
 #pragma unroll
                 for (int i = 0; i < WROWP / 4; ++i) {
                     const float4 w4 = *reinterpret_cast<const float4*>(wl + ky * WROWP + 4 * i);
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(256) void conv_fewout_kernel(const SmallParams p) {
                         if (kx >= 0 && kx < KS) {
 #pragma unroll
                             for (int o = 0; o < COUT; ++o) {
-                                if constexpr (WREG) acc[j][o] = fmaf(v, wrow[(kx * 3 + k) * COUT + o], acc[j][o]);
+                                if constexpr (WLDS) acc[j][o] = fmaf(v, wrow[(kx * CK + k) * COUT + o], acc[j][o]);
                                 else acc[j][o] = fmaf(v, wk[(long)kx * p.Cin * COUT + o], acc[j][o]);
                             }
                         }
@@ -122,7 +126,7 @@ template <int KS, int COUT, int CK>
 int launch_fewout(SmallParams p, hipStream_t s) {
     constexpr int THH = S_TH + KS - 1, TWH = S_TW + KS - 1;
     constexpr int CKP = CK + (CK % 2 == 0 ? 1 : 0);
-    constexpr size_t lds = ((size_t)THH * TWH * CKP + 4 + (CK == 3 ? KS * ((KS * 3 * COUT + 3) / 4 * 4) : 0)) * sizeof(float);
+    constexpr size_t lds = ((size_t)THH * TWH * CKP + 4 + (CK != 3 ? KS * ((KS * CK * COUT + 3) / 4 * 4) : 0)) * sizeof(float);
     p.tiles_y = cdiv(p.Hout, S_TH);
     p.tiles_x = cdiv(p.Wout, S_TW);
     const long blocks = (long)p.N * p.tiles_y * p.tiles_x;
