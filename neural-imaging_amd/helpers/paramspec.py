@@ -1,105 +1,120 @@
 """
-Hyper-parameter specification / validation with the reference's semantics (helpers/paramspec.py:33-178):
-specs are {name: (default, dtype, validator)} with validators range-tuple | enum-set | substring | callable;
-update(**kw) casts, validates and raises ValueError on unknown or invalid values; values cannot be set directly.
-"""
-import types
+Hyper-parameter records of the models: a schema {name: (default, type, rule)} plus the values that differ from it.
 
-import numpy as np
+Same contract as the reference's helpers/paramspec.py:33-178 (callers read attributes, call `update`, `to_dict`,
+`to_json`, `changed_params`, `keys`, `add`, `get_dtype`, `get_default`, `get_value`; assignment is refused; every failure is
+a ValueError).  A rule is None, a (low, high) range with open ends as None, a set of allowed values, a substring a string
+value must contain, or a predicate.  `update` casts each value to the field's type first; None leaves a field as it is.
+"""
+import math
+import numbers
+import types
 
 from . import utils
 
 
 def numbers_in_range(dtype, min_value=None, max_value=None):
-    """Validator for tuple-valued parameters (helpers/paramspec.py:20-30 in the reference)."""
-    def check(items):
-        return all(isinstance(i, dtype) and (min_value is None or i >= min_value) and
-                   (max_value is None or i <= max_value) for i in items)
-    return check
+    """Rule for tuple-valued fields: every item is a `dtype` inside [min_value, max_value] (paramspec.py:20-30)."""
+    def inside(item):
+        if not isinstance(item, dtype):
+            return False
+        return (min_value is None or item >= min_value) and (max_value is None or item <= max_value)
+    return lambda items: all(inside(i) for i in items)
+
+
+class _Field(object):
+    """One schema entry with its rule compiled into a list of (test, message) pairs."""
+    __slots__ = ('default', 'dtype', 'rule', 'tests')
+
+    def __init__(self, name, entry):
+        if not isinstance(entry, tuple) or len(entry) != 3:
+            raise ValueError('Invalid parameter specification for key {} - expected tuple of length 3'.format(name))
+        self.default, self.dtype, self.rule = entry
+        rule, kind = self.rule, type(self.rule)
+        if rule is not None:
+            if self.dtype is str and kind not in (str, set, types.FunctionType):
+                raise ValueError('String data types can be validated by a regex (string), enum (set) or custom function')
+            if utils.is_numeric_type(self.dtype) and kind not in (tuple, set):
+                raise ValueError('Numeric data types can be validated by a range (2-elem tuple), or enum (set)')
+        self.tests = []
+        if kind is tuple and len(rule) == 2:
+            low, high = rule
+            if low is not None:
+                self.tests.append((lambda v: v >= low, 'fails minimum validation check >= {}!'.format(low)))
+            if high is not None:
+                self.tests.append((lambda v: v <= high, 'fails maximum validation check (<= {})!'.format(high)))
+        elif kind is set:
+            self.tests.append((lambda v: v in rule, 'is not an allowed value ({})!'.format(rule)))
+        elif kind is str:
+            if self.dtype is str:
+                self.tests.append((lambda v: rule in v, 'does not match regex ({})!'.format(rule)))
+        elif callable(rule):
+            self.tests.append((rule, 'failed custom validation check!'))
+
+    def accept(self, name, value):
+        if isinstance(value, numbers.Real) and not isinstance(value, bool) and math.isnan(value):
+            raise ValueError('Invalid value {} for attribute {}'.format(value, name))
+        candidate = self.dtype(value) if self.dtype is not None else value
+        for test, message in self.tests:
+            if not test(candidate):
+                raise ValueError('{}: {} {}'.format(name, candidate, message))
+        return candidate
 
 
 class ParamSpec(object):
 
     def __init__(self, specs):
-        self._validate_specs(specs)
-        self.__dict__['_specs'] = dict(specs)
-        self.__dict__['_values'] = {}
+        object.__setattr__(self, '_fields', {name: _Field(name, entry) for name, entry in specs.items()})
+        object.__setattr__(self, '_values', {})
 
-    @staticmethod
-    def _validate_specs(specs):
-        for key, spec in specs.items():
-            if type(spec) is not tuple or len(spec) != 3:
-                raise ValueError('Invalid parameter specification for key {} - expected tuple of length 3'.format(key))
-            if spec[2] is None:
-                continue
-            if spec[1] is str and not any(type(spec[2]) is s for s in [str, set, types.FunctionType]):
-                raise ValueError('String data types can be validated by a regex (string), enum (set) or custom function')
-            if utils.is_numeric_type(spec[1]) and not any(type(spec[2]) is s for s in [tuple, set]):
-                raise ValueError('Numeric data types can be validated by a range (2-elem tuple), or enum (set)')
-
+    # -- schema -------------------------------------------------------------------------------------------------------
     def add(self, specs):
-        self._validate_specs(specs)
-        self._specs.update(specs)
+        fresh = {name: _Field(name, entry) for name, entry in specs.items()}     # validated before anything is touched
+        self._fields.update(fresh)
 
-    def __getattr__(self, name):
-        if name in self.__dict__['_values']:
-            return self.__dict__['_values'][name]
-        if name in self.__dict__['_specs']:
-            return self.__dict__['_specs'][name][0]
-        raise KeyError(name)
+    def keys(self):
+        return list(self._fields)
 
-    def __setattr__(self, key, value):
-        raise ValueError('Values cannot be set directly. Use the `update` method.')
+    def __contains__(self, name):
+        return name in self._fields
 
     def get_dtype(self, name):
-        return self._specs[name][1]
+        return self._fields[name].dtype
 
     def get_default(self, name):
-        return self._specs[name][0]
+        return self._fields[name].default
+
+    # -- values -------------------------------------------------------------------------------------------------------
+    def __getattr__(self, name):
+        state = object.__getattribute__(self, '__dict__')
+        if name in state.get('_values', ()):
+            return state['_values'][name]
+        if name in state.get('_fields', ()):
+            return state['_fields'][name].default
+        raise KeyError(name)
+
+    def __setattr__(self, name, value):
+        raise ValueError('Values cannot be set directly. Use the `update` method.')
 
     def get_value(self, name):
-        return self.__getattr__(name)
+        return getattr(self, name)
+
+    def update(self, **params):
+        for name, value in params.items():
+            field = self._fields.get(name)
+            if field is None:
+                raise ValueError('Unexpected parameter: {}!'.format(name))
+            if value is not None:
+                self._values[name] = field.accept(name, value)
+
+    def to_dict(self):
+        return {name: self._values.get(name, field.default) for name, field in self._fields.items()}
+
+    def to_json(self):
+        return {name: (value if utils.is_number(value) else str(value)) for name, value in self.to_dict().items()}
+
+    def changed_params(self):
+        return {name: value for name, value in self._values.items() if value != self._fields[name].default}
 
     def __repr__(self):
         return '{}({})'.format(type(self).__name__, self.to_dict())
-
-    def to_dict(self):
-        params = {key: spec[0] for key, spec in self._specs.items()}
-        params.update(self._values)
-        return params
-
-    def to_json(self):
-        return {k: v if utils.is_number(v) else str(v) for k, v in self.to_dict().items()}
-
-    def __contains__(self, item):
-        return item in self._specs
-
-    def keys(self):
-        return list(self._specs.keys())
-
-    def changed_params(self):
-        return {key: value for key, value in self._values.items() if self._specs[key][0] != value}
-
-    def update(self, **params):
-        for key, value in params.items():
-            if key not in self._specs:
-                raise ValueError('Unexpected parameter: {}!'.format(key))
-            _, dtype, validation = self._specs[key]
-            if value is None:
-                continue
-            if utils.is_number(value) and np.isnan(value):
-                raise ValueError('Invalid value {} for attribute {}'.format(value, key))
-            candidate = value if dtype is None else dtype(value)
-            if validation is not None:
-                if type(validation) == tuple and len(validation) == 2:
-                    if validation[0] is not None and candidate < validation[0]:
-                        raise ValueError('{}: {} fails minimum validation check >= {}!'.format(key, candidate, validation[0]))
-                    if validation[1] is not None and candidate > validation[1]:
-                        raise ValueError('{}: {} fails maximum validation check (<= {})!'.format(key, candidate, validation[1]))
-                if type(validation) == set and candidate not in validation:
-                    raise ValueError('{}: {} is not an allowed value ({})!'.format(key, candidate, validation))
-                if type(validation) == str and dtype == str and validation not in candidate:
-                    raise ValueError('{}: {} does not match regex ({})!'.format(key, candidate, validation))
-                if callable(validation) and not validation(candidate):
-                    raise ValueError('{}: {} failed custom validation check!'.format(key, candidate))
-            self._values[key] = candidate
