@@ -224,7 +224,18 @@ def main():
                          'ms_per_launch': dom['ms_per_launch'], 'flops_per_launch': dom['flops_per_launch']},
         }
         if world == 1 and args.dtype == 'bf16' and not args.no_parity_mode:
+            # PSNR / decision parity of the two compute modes on the same weights and batch (BASELINE metric: "PSNR/acc
+            # parity"): ISP output and classifier decisions in throughput mode vs float32 mode
+            out_b = wf.run_workflow(bx)
             _ops.set_compute('f32')                           # same step, exact float32 MFMA (the parity-test mode)
+            out_f = wf.run_workflow(bx)
+            yb, yf = out_b[0].t.float(), out_f[0].t.float()
+            mse_modes = float(((yb - yf) ** 2).mean().item())
+            agree = float((out_b[-1].t.argmax(dim=1) == out_f[-1].t.argmax(dim=1)).float().mean().item())
+            mode_parity = {'isp_psnr_bf16_vs_f32_db': 10 * np.log10(1.0 / max(mse_modes, 1e-20)),
+                           'fan_decision_agreement': agree,
+                           'isp_psnr_vs_target_db': {'bf16': 10 * np.log10(1.0 / float(((yb - by) ** 2).mean().item())),
+                                                     'f32': 10 * np.log10(1.0 / float(((yf - by) ** 2).mean().item()))}}
             wf.training_step(bx, by, lambda_nip=0.1, learning_rate=1e-4)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -236,7 +247,7 @@ def main():
             line['config']['f32_parity_mode'] = {
                 'patches_per_s': args.batch / dt32, 'ms_per_step': 1e3 * dt32,
                 'dominant_kernel_tflops': dom32['tflops'], 'dominant_kernel_frac_of_f32_mfma_peak':
-                    dom32['tflops'] / F32_MFMA_PEAK_TFLOPS}
+                    dom32['tflops'] / F32_MFMA_PEAK_TFLOPS, 'parity_of_modes': mode_parity}
             _ops.set_compute(args.dtype)
         if not args.no_cpu_baseline and world == 1:
             line['cpu_baseline'] = cpu_baseline(args.raw_patch)
