@@ -1,30 +1,46 @@
 #!/usr/bin/env python3
 """
-bench.py - raw patches/s (forward + backward + Adam) of the imaging channel  UNet ISP -> manipulations -> dJPEG -> FAN
-at 256x256 RGB (BASELINE.json metric; workload = configs[3] = SURVEY 8d "C4").
+bench.py - raw patches/s (forward + backward + Adam) of the imaging channel  UNet ISP -> manipulations -> codec -> FAN
+at 256x256 RGB (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W [--workload c4|c3|c5]
 
-A "step" = ManipulationClassification.training_step on a synthetic batch already resident in HBM: B raw patches
-(B,128,128,4) -> UNet -> (5B,256,256,3) [native, sharpen:1, resample:50, gaussian:0.83, jpeg:80] -> dJPEG(80) -> FAN ->
-CE + 0.1 * mse255 -> backward to the UNet and FAN weights -> gradient all-reduce (N>1) -> Keras Adam.  Weak scaling:
-every rank processes its own B patches.  Prints ONE JSON line (rank 0).
+N > 1 without a torch.distributed environment: bench.py re-launches itself as
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`
+(one rank per GPU over RCCL); under an existing launcher (RANK / WORLD_SIZE set) it just joins the group.
+
+Workloads (BASELINE.json configs):
+  c4 (default, configs[3], the configuration the metric is quoted on): B = 64 raw patches / GPU -> UNet -> (5B,256,256,3)
+      [native, sharpen:1, resample:50, gaussian:0.83, jpeg:80] -> dJPEG(80, soft) -> FAN -> CE + 0.1 mse255 -> backward to the
+      UNet and FAN weights -> gradient all-reduce (N > 1) -> Keras Adam.  Unit = one raw patch.
+  c3 (configs[2]): TwitterDCN-32C training step on B = 16 RGB patches of 256x256 (l2 + 250 H).  Unit = one RGB patch.
+  c5 (configs[4]): the full channel with the learned codec, UNet -> manipulations -> TwitterDCN-32C -> FAN, B = 16 raw
+      patches / GPU (128 global on 8 GPUs), trainable nip + dcn, lambda_dcn 0.1.  Unit = one raw patch.
+A "step" = one training step on a synthetic batch already resident in HBM.  Weak scaling: every rank processes its own B
+units.  Rank 0 prints ONE JSON line.
+
+Timing: W warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides (max over ranks) -> `value`.
+HIP events recorded between five equal blocks of the same K steps give `config.block_ms_per_step` (their median is reported
+next to the contract figure; no extra host synchronisation inside the timed region).
 
 Extra objects on the line:
-  roofline     - dominant kernel (the FAN 5x5 convolution family) timed live with HIP events on the launch stream:
-                 algorithmic FLOPs of one launch / average launch time, against the dense MFMA peak of the compute
-                 dtype; traffic = HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_dominant_kernel.json:
-                 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc runs), scaled to this launch's image count
-
---dtype bf16 (default) = throughput mode: bf16 MFMA operands, float32 accumulation, float32 tensors / master weights /
-optimizer.  --dtype f32 = parity mode (exact float32 MFMA; the mode the 1e-4 parity tests run in); at N=1 the default run
-also times a few parity-mode steps and reports them under config.f32_parity_mode.
-  cpu_baseline - the oracle's CPU port (torch float32, all host cores) of the SAME step on a bounded sample
+  roofline     - the workload's dominant kernel timed live with HIP events on the launch stream: algorithmic FLOPs of one
+                 launch / average launch time against the dense MFMA peak of the compute dtype; traffic = HBM bytes per launch
+                 from the committed PMC passes (profiles/*pmc_dominant_kernel.json: 2 x FETCH_SIZE + WRITE_SIZE, separate
+                 --pmc runs), scaled to this launch's image count
+  cpu_baseline - the oracle's CPU port (torch float32, all host cores) of the SAME step on a bounded sample: 2 warm-up steps,
+                 median of >= 5 timed steps
+--dtype bf16 (default) = throughput mode: bf16 MFMA operands, float32 accumulation, float32 master weights / optimizer.
+--dtype f32 = parity mode (exact float32 MFMA; the mode the 1e-4 parity tests run in).  At N = 1 the default c4 run also
+times parity-mode steps (top-level f32_mode_* keys) and trains two copies of the channel (same initial weights, same batches)
+for --parity-steps steps, one per mode, to report accuracy / PSNR parity of the throughput mode on held-out patches.
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,8 +53,8 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 F32_MFMA_PEAK_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # same guide: bf16 MFMA dense (the 5 PF headline includes 2:1 sparsity)
-GMAC_FWD_PER_PATCH = 3.079 + 5 * 2.705          # UNet + 5 x FAN, forward
-GFLOP_PER_PATCH = 2 * 3 * GMAC_FWD_PER_PATCH    # fwd + dgrad + wgrad
+GMAC_UNET, GMAC_FAN, GMAC_DCN = 3.079, 2.705, 9.742          # SURVEY appendix A, forward, per image
+MANIPS = ['sharpen:1', 'resample:50', 'gaussian:0.83', 'jpeg:80']
 
 
 def synthetic_batch(b, raw_patch, seed):
@@ -47,11 +63,137 @@ def synthetic_batch(b, raw_patch, seed):
     return bayer_from_rgb(rgb), rgb
 
 
-def time_dominant_kernel(dev, b_images, reps=20):
-    """FAN conv3 forward (5x5, 64 -> 128 @ 64x64, the 839 MMAC/image layer) - one launch, HIP events on the
-    stream it runs on (the kernels are launched on torch's current stream, so torch.cuda.Event brackets them)."""
+# ----------------------------------------------------------------------------------------------------------------------
+# workloads
+class Workload(object):
+    """build(dev, rank) -> step(); units = raw (or RGB) patches per step and rank."""
+    key = name = unit_name = ''
+    default_batch = 64
+    gflop_per_unit = 0.0
+    hbm_bytes_per_unit = None         # (bf16, f32) op-by-op compulsory traffic model, SURVEY 8d (c4 only)
+
+    def __init__(self, args):
+        self.args = args
+        self.batch = args.batch or self.default_batch
+
+    def build(self, dev, rank):
+        raise NotImplementedError
+
+    def finish(self):
+        pass
+
+
+class ChannelJPEG(Workload):
+    key = 'c4'
+    name = ('train_manipulation UNet->[native,sharpen:1,resample:50,gaussian:0.83,jpeg:80]->dJPEG(QF80,soft)->FAN, ds none, '
+            'trainable nip+fan, lambda_nip 0.1')
+    default_batch = 64
+    gflop_per_unit = 2 * 3 * (GMAC_UNET + 5 * GMAC_FAN)
+    hbm_bytes_per_unit = (343.8e6, 687.5e6)
+
+    def make_flow(self, dev, nan_check='deferred'):
+        from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
+        dist_cfg = {'downsampling': 'none', 'compression': 'jpeg', 'compression_params': {'quality': 80, 'codec': 'soft'}}
+        return ManipulationClassification('UNet', manipulations=MANIPS, distribution=dist_cfg, trainable={'nip'},
+                                          raw_patch_size=self.args.raw_patch, device=dev, nan_check=nan_check)
+
+    def step_args(self):
+        return dict(lambda_nip=0.1, learning_rate=1e-4)
+
+    def build(self, dev, rank):
+        self.wf = self.make_flow(dev)
+        raw, rgb = synthetic_batch(self.batch, self.args.raw_patch, seed=1234 + rank)
+        self.bx, self.by = torch.from_numpy(raw).to(dev), torch.from_numpy(rgb).to(dev)
+        kw = self.step_args()
+        if self.args.graph:
+            from neural_imaging_amd import graphs
+            self.runner = graphs.CapturedStep(self.wf, self.bx, self.by, **kw)
+            return self.runner.step
+        return lambda: self.wf.training_step(self.bx, self.by, **kw)
+
+    def finish(self):
+        self.wf.check_nan()
+
+    def dominant(self, dev):
+        return time_conv5_dominant(dev, 5 * self.batch)
+
+
+class ChannelDCN(ChannelJPEG):
+    key = 'c5'
+    name = ('full channel UNet->[native,sharpen:1,resample:50,gaussian:0.83,jpeg:80]->TwitterDCN-32C->FAN, ds none, '
+            'trainable nip+dcn+fan, lambda_nip 0.1, lambda_dcn 0.1')
+    default_batch = 16
+    gflop_per_unit = 2 * 3 * (GMAC_UNET + 5 * GMAC_FAN + 5 * GMAC_DCN)
+    hbm_bytes_per_unit = None
+
+    def make_flow(self, dev, nan_check='deferred'):
+        from neural_imaging_amd.models import compression
+        from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
+        codec = compression.TwitterDCN(patch_size=2 * self.args.raw_patch, n_features=32, device=dev)
+        dist_cfg = {'downsampling': 'none', 'compression': 'dcn', 'compression_params': {'model': codec}}
+        return ManipulationClassification('UNet', manipulations=MANIPS, distribution=dist_cfg, trainable={'nip', 'dcn'},
+                                          raw_patch_size=self.args.raw_patch, device=dev, nan_check=nan_check)
+
+    def step_args(self):
+        return dict(lambda_nip=0.1, lambda_dcn=0.1, learning_rate=1e-4)
+
+    def dominant(self, dev):
+        return time_conv3_dominant(dev, 5 * self.batch)
+
+
+class TrainDCN(Workload):
+    key = 'c3'
+    name = 'train_dcn TwitterDCN-32C on 256x256 RGB patches, l2_loss + 250 H, soft-codebook 5 bpf'
+    default_batch = 16
+    gflop_per_unit = 2 * 3 * GMAC_DCN
+
+    def build(self, dev, rank):
+        from neural_imaging_amd.models import compression
+        from util import natural_images
+        ps = 2 * self.args.raw_patch
+        self.dcn = compression.TwitterDCN(patch_size=ps, n_features=32, device=dev)
+        self.x = torch.from_numpy(natural_images(self.batch, ps, ps, seed=1234 + rank)).to(dev)
+        self.last = None
+
+        def step():
+            self.last = self.dcn.training_step(self.x, learning_rate=1e-4, sync=False)
+            return self.last
+        return step
+
+    def dominant(self, dev):
+        return time_conv3_dominant(dev, self.batch)
+
+
+WORKLOADS = {w.key: w for w in (ChannelJPEG, TrainDCN, ChannelDCN)}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# dominant kernels (roofline)
+def _event_time(run, reps):
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def _pmc_traffic(fname, key, n):
+    try:                                   # measured with rocprofv3 --pmc in separate passes, see profiles/README.md
+        with open(os.path.join(ROOT, 'profiles', fname)) as f:
+            pmc = json.load(f)[key]
+        return pmc['traffic_bytes_per_launch'] * n / pmc['images']
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def time_conv5_dominant(dev, n, reps=20):
+    """FAN conv3 forward (5x5, 64 -> 128 @ 64x64, the 839 MMAC/image layer) - one launch, HIP events on the stream it runs
+    on (the kernels are launched on torch's current stream, so torch.cuda.Event brackets them)."""
     from neural_imaging_amd import ops
-    n = b_images
     x = torch.randn((n, 64, 64, 64), device=dev)
     stored_bf16 = ops.COMPUTE == 'bf16' and ops.STORE_BF16
     if stored_bf16:                   # the FAN's pooled activations live in HBM as bf16 in throughput mode
@@ -63,101 +205,178 @@ def time_dominant_kernel(dev, b_images, reps=20):
     # pooled output + arg-max bytes (same kernel, same FLOPs; only the epilogue's store volume differs from the plain call)
     run = (lambda: ops.conv2d_pool(x, w, b, out_bf16=True)) if stored_bf16 else \
         (lambda: ops.conv2d(x, w, b, act='leaky_relu', out=out))
-    run()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        run()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    ms = _event_time(run, reps)
     flops = 2.0 * 25 * 64 * 128 * 64 * 64 * n
-    from neural_imaging_amd import ops as _o
-    kname = 'conv_fwd_kernel<5,1,16,16,1,64,8>' if _o.COMPUTE == 'f32' else (
+    kname = 'conv_fwd_kernel<5,1,16,16,1,64,8>' if ops.COMPUTE == 'f32' else (
         'conv_fwd_bf16_kernel<5,1,16,16,1,64,INB=true,BUF=true>' if stored_bf16 else 'conv_fwd_bf16_kernel<5,1,16,16,1,64>')
-    traffic = None
-    try:                                                   # measured once with rocprofv3 --pmc, see profiles/README.md
-        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_dominant_kernel.json')) as f:
-            pmc = json.load(f)['bf16_stored_input_pooled' if stored_bf16 else _o.COMPUTE]
-        traffic = pmc['traffic_bytes_per_launch'] * n / pmc['images']
-    except (OSError, KeyError, ValueError):
-        pass
+    traffic = _pmc_traffic('r01_pmc_dominant_kernel.json', 'bf16_stored_input_pooled' if stored_bf16 else ops.COMPUTE, n)
     return {'kernel': kname + ' (FAN conv3 fwd{}, {}x64x64x64->128)'.format(' + LReLU + pool' if stored_bf16 else '', n),
-            'traffic': traffic,
+            'traffic': traffic, 'flops_per_launch': flops, 'ms_per_launch': ms, 'tflops': flops / (ms * 1e-3) / 1e12}
+
+
+def time_conv3_dominant(dev, n, reps=20):
+    """TwitterDCN residual-block convolution (3x3, 128 -> 128 @ 64x64; 12 of them = 7.2 of the 9.74 GMAC per image)."""
+    from neural_imaging_amd import ops
+    x = torch.randn((n, 64, 64, 128), device=dev)
+    w = torch.randn((3, 3, 128, 128), device=dev) * 0.05
+    b = torch.zeros((128,), device=dev)
+    out = torch.empty((n, 64, 64, 128), device=dev)
+    ms = _event_time(lambda: ops.conv2d(x, w, b, act='leaky_relu', out=out), reps)
+    flops = 2.0 * 9 * 128 * 128 * 64 * 64 * n
+    kname = 'conv_fwd_kernel<3,1,...>' if ops.COMPUTE == 'f32' else 'conv_fwd_bf16_kernel<3,1,16,16,1,64>'
+    traffic = _pmc_traffic('r02_pmc_dcn_kernel.json', ops.COMPUTE, n)
+    return {'kernel': kname + ' (TwitterDCN residual conv fwd, {}x64x64x128->128)'.format(n), 'traffic': traffic,
             'flops_per_launch': flops, 'ms_per_launch': ms, 'tflops': flops / (ms * 1e-3) / 1e12}
 
 
-def _usable_cores():
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU baseline (oracle port, child process)
+def _host_cpu():
+    model = None
     try:
-        n = len(os.sched_getaffinity(0))
+        with open('/proc/cpuinfo') as f:
+            for ln in f:
+                if ln.startswith('model name'):
+                    model = ln.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
     except AttributeError:
-        n = os.cpu_count() or 1
-    return max(1, min(n, 32))          # more threads than this only adds barrier overhead for these layer sizes
+        usable = os.cpu_count() or 1
+    return model, os.cpu_count() or usable, usable
 
 
-def cpu_baseline_worker(raw_patch, budget_s):
-    """Oracle port on the host cores: torch float32 CPU, same step, B=2 raw patches, bounded to ~budget_s."""
-    from oracle import workflow as owf
-    cores = _usable_cores()
-    torch.set_num_threads(cores)
+def cpu_baseline_worker(workload, raw_patch, budget_s):
+    """Oracle port on the host cores: torch float32 CPU, the same step, bounded to ~budget_s of timed work."""
+    from oracle import nets as onets, workflow as owf
+    from util import natural_images
+    model, total, usable = _host_cpu()
+    torch.set_num_threads(usable)
     b = 2
-    wf = owf.Workflow(trainable=('nip',), jpeg_quality=80, dtype=torch.float32)
-    raw, rgb = synthetic_batch(b, raw_patch, seed=99)
-    bx, by = torch.from_numpy(raw), torch.from_numpy(rgb)
-    wf.training_step(bx, by, lambda_nip=0.1, learning_rate=1e-4)       # warm-up
-    t0, steps = time.time(), 0
-    while steps < 5 and (time.time() - t0) < budget_s:
-        wf.training_step(bx, by, lambda_nip=0.1, learning_rate=1e-4)
-        steps += 1
-    dt = (time.time() - t0) / max(steps, 1)
-    return {'value': b / dt, 'unit': 'patches/s', 'cores': cores, 'kind': 'port',
-            'sample': '{} step(s) of B={} raw patches {}x{}x4, torch-CPU float32 restatement of the same step '
-                      '(TF2 unavailable)'.format(steps, b, raw_patch, raw_patch)}
+    if workload == 'c3':
+        dcn = onets.dcn_init(777, dtype=torch.float32)
+        x = torch.from_numpy(natural_images(b, 2 * raw_patch, 2 * raw_patch, seed=99))
+        trainer = onets.DCNTrainer(dcn)
+        step = lambda: trainer.training_step(x, learning_rate=1e-4)
+    else:
+        kw = dict(lambda_nip=0.1, learning_rate=1e-4)
+        if workload == 'c5':
+            wf = owf.Workflow(trainable=('nip', 'dcn'), codec='dcn', dtype=torch.float32)
+            kw['lambda_dcn'] = 0.1
+        else:
+            wf = owf.Workflow(trainable=('nip',), jpeg_quality=80, dtype=torch.float32)
+        raw, rgb = synthetic_batch(b, raw_patch, seed=99)
+        bx, by = torch.from_numpy(raw), torch.from_numpy(rgb)
+        step = lambda: wf.training_step(bx, by, **kw)
+    for _ in range(2):                                                      # warm-up (BASELINE.md section 4)
+        step()
+    times, t_all = [], time.time()
+    while len(times) < 5 or (len(times) < 15 and time.time() - t_all < budget_s):
+        t0 = time.time()
+        step()
+        times.append(time.time() - t0)
+    med = float(np.median(times))
+    return {'value': b / med, 'unit': 'patches/s', 'cores': usable, 'kind': 'port', 'host_cores': total, 'cpu_model': model,
+            'sample': 'median of {} step(s) after 2 warm-ups, B={} {} patches, torch-CPU float32 restatement of the same step '
+                      '(restated-reference CPU baseline, TF2 unavailable), {} threads'.format(
+                          len(times), b, 'RGB 256x256' if workload == 'c3' else 'raw {0}x{0}x4'.format(raw_patch), usable)}
 
 
-def cpu_baseline(raw_patch, budget_s=15.0, hard_timeout_s=120):
+def cpu_baseline(workload, raw_patch, budget_s=20.0, hard_timeout_s=240):
     """Run the CPU leg in a child process so a badly provisioned host can never stall the GPU measurement."""
-    import subprocess
+    _, total, usable = _host_cpu()
+    fail = {'value': None, 'unit': 'patches/s', 'cores': usable, 'kind': 'port', 'host_cores': total}
     try:
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', '--raw-patch',
-                              str(raw_patch), '--cpu-budget', str(budget_s)], capture_output=True, text=True,
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', '--workload', workload,
+                              '--raw-patch', str(raw_patch), '--cpu-budget', str(budget_s)], capture_output=True, text=True,
                              timeout=hard_timeout_s, env=dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES=''))
         for ln in reversed(out.stdout.strip().splitlines()):
             if ln.startswith('{'):
                 return json.loads(ln)
-        return {'value': None, 'unit': 'patches/s', 'cores': _usable_cores(), 'kind': 'port',
-                'sample': 'cpu worker failed: ' + out.stderr[-200:]}
+        return dict(fail, sample='cpu worker failed: ' + out.stderr[-200:])
     except subprocess.TimeoutExpired:
-        return {'value': None, 'unit': 'patches/s', 'cores': _usable_cores(), 'kind': 'port',
-                'sample': 'cpu worker exceeded {} s'.format(hard_timeout_s)}
+        return dict(fail, sample='cpu worker exceeded {} s'.format(hard_timeout_s))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    """--gpus N without a launcher environment: start N ranks under torch.distributed.run and relay their output."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    return subprocess.call(cmd, env=env)
+
+
+def accuracy_parity(wl, dev, steps):
+    """Throughput-mode vs float32-mode LEARNING parity at the workload's scale: two copies of the channel with identical
+    initial weights are trained for `steps` steps on the same four batches, one per compute mode, then evaluated on a held-out
+    batch: FAN accuracy, CE, ISP PSNR against the target, ISP outputs of the two runs against each other."""
+    from neural_imaging_amd import ops
+    b, rp = wl.batch, wl.args.raw_patch
+    batches = [synthetic_batch(b, rp, seed=4000 + i) for i in range(4)]
+    batches = [(torch.from_numpy(r).to(dev), torch.from_numpy(g).to(dev)) for r, g in batches]
+    hr, hg = synthetic_batch(b, rp, seed=4999)
+    hx, hy = torch.from_numpy(hr).to(dev), torch.from_numpy(hg).to(dev)
+    out = {'steps': steps, 'batch': b}
+    ys = {}
+    for mode in ('bf16', 'f32'):
+        ops.set_compute(mode)
+        torch.manual_seed(0)
+        wf = wl.make_flow(dev)
+        for i in range(steps):
+            wf.training_step(*batches[i % 4], **wl.step_args())
+        wf.check_nan()
+        res = wf.run_workflow(hx)
+        Y, probs = res[0].t.float(), res[-1].t.float()
+        labels = wf._device_labels(b).long()
+        p_true = probs.gather(1, labels[:, None]).clamp_min(1e-7)
+        ys[mode] = Y
+        out[mode] = {'fan_accuracy': float((probs.argmax(dim=1) == labels).float().mean().item()),
+                     'ce': float((-p_true.log()).mean().item()),
+                     'isp_psnr_vs_target_db': float(10 * np.log10(1.0 / float(((Y - hy) ** 2).mean().item())))}
+        del wf
+    out['isp_psnr_between_modes_db'] = float(10 * np.log10(1.0 / max(float(((ys['bf16'] - ys['f32']) ** 2).mean().item()), 1e-20)))
+    out['fan_accuracy_delta'] = out['bf16']['fan_accuracy'] - out['f32']['fan_accuracy']
+    out['isp_psnr_delta_db'] = out['bf16']['isp_psnr_vs_target_db'] - out['f32']['isp_psnr_vs_target_db']
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=8)
-    ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=64, help='raw patches per GPU per step (SURVEY 8d C4: 64)')
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--workload', choices=sorted(WORKLOADS), default='c4')
+    ap.add_argument('--batch', type=int, default=0, help='units per GPU per step (default: the workload\'s, c4: 64)')
     ap.add_argument('--raw-patch', type=int, default=128)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dtype', choices=['f32', 'bf16'], default='bf16',
                     help='arithmetic type of the convolution GEMMs (bf16 = MFMA throughput mode, f32 accumulate; '
                          'f32 = parity mode)')
-    ap.add_argument('--no-parity-mode', action='store_true', help='skip the extra float32 parity-mode timing at N=1')
+    ap.add_argument('--no-parity-mode', action='store_true', help='skip the float32 parity-mode legs at N=1')
+    ap.add_argument('--parity-steps', type=int, default=60, help='training steps of the accuracy-parity leg (0 = skip)')
+    ap.add_argument('--graph', action='store_true', help='replay the step from a captured HIP graph (c4 / c5)')
     ap.add_argument('--backend', default=None, help='torch.distributed backend (default: nccl = RCCL); gloo is for a '
                                                      'functional check of the N>1 path on a one-GPU box')
     ap.add_argument('--single-device', action='store_true', help='functional check only: every rank uses cuda:0')
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
-    ap.add_argument('--cpu-budget', type=float, default=15.0, help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-budget', type=float, default=20.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
-        print(json.dumps(cpu_baseline_worker(args.raw_patch, args.cpu_budget)))
+        print(json.dumps(cpu_baseline_worker(args.workload, args.raw_patch, args.cpu_budget)))
         return
+    if args.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args))
 
     importlib.import_module('neural-imaging_amd')
     from neural_imaging_amd import _lib, parallel
-    from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
 
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU; there is no CPU fallback')
@@ -171,15 +390,11 @@ def main():
     _lib.load()
     from neural_imaging_amd import ops as _ops
     _ops.set_compute(args.dtype)
-    if world != args.gpus and rank == 0:
-        print('warning: --gpus {} but WORLD_SIZE {}'.format(args.gpus, world), file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit('--gpus {} but the process group has {} rank(s)'.format(args.gpus, world))
 
-    dist_cfg = {'downsampling': 'none', 'compression': 'jpeg', 'compression_params': {'quality': 80, 'codec': 'soft'}}
-    wf = ManipulationClassification('UNet', manipulations=['sharpen:1', 'resample:50', 'gaussian:0.83', 'jpeg:80'],
-                                    distribution=dist_cfg, trainable={'nip'}, raw_patch_size=args.raw_patch,
-                                    device=dev, nan_check='deferred')
-    raw, rgb = synthetic_batch(args.batch, args.raw_patch, seed=1234 + rank)
-    bx, by = torch.from_numpy(raw).to(dev), torch.from_numpy(rgb).to(dev)
+    wl = WORKLOADS[args.workload](args)
+    step = wl.build(dev, rank)
 
     def barrier():
         if world > 1:
@@ -187,14 +402,21 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        wf.training_step(bx, by, lambda_nip=0.1, learning_rate=1e-4)
+        step()
+    nblk = 5 if args.steps >= 5 else 1
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(nblk + 1)]
+    edges = [round(i * args.steps / nblk) for i in range(nblk + 1)]
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, parts = wf.training_step(bx, by, lambda_nip=0.1, learning_rate=1e-4)
+    last = None
+    for i in range(args.steps):
+        if i in edges:
+            marks[edges.index(i)].record()
+        last = step()
+    marks[nblk].record()
     barrier()
     dt = time.perf_counter() - t0
-    wf.check_nan()
+    wl.finish()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -202,55 +424,65 @@ def main():
 
     if rank == 0:
         ms = 1e3 * dt / args.steps
-        value = world * args.batch * args.steps / dt
-        dom = time_dominant_kernel(dev, 5 * args.batch)
+        value = world * wl.batch * args.steps / dt
+        blocks = [marks[i].elapsed_time(marks[i + 1]) / max(edges[i + 1] - edges[i], 1) for i in range(nblk)]
+        dom = wl.dominant(dev)
         peak = F32_MFMA_PEAK_TFLOPS if args.dtype == 'f32' else BF16_MFMA_PEAK_TFLOPS
+        if isinstance(last, tuple):
+            loss = float(last[0])
+        elif isinstance(last, dict):
+            loss = float(last['loss'])
+        else:
+            loss = None
+        cfg = {'workload': '{} = {}'.format(wl.key, wl.name), 'raw_patch': args.raw_patch, 'rgb_patch': 2 * args.raw_patch,
+               'batch_per_gpu': wl.batch, 'global_batch': world * wl.batch, 'parallelism': 'dp%d' % world,
+               'world_size': world, 'backend': torch.distributed.get_backend() if world > 1 else None,
+               'hip_graph': bool(args.graph), 'loss': loss,
+               'achieved_tflops_whole_step': value * wl.gflop_per_unit / 1e3,
+               'block_ms_per_step': [round(v, 4) for v in blocks], 'median_block_ms_per_step': float(np.median(blocks))}
+        if wl.hbm_bytes_per_unit is not None:
+            # SURVEY 8d compulsory-traffic model of the whole step against 8 TB/s: one kernel per reference op
+            # (343.8 MB bf16 / 687.5 MB f32 per raw patch) and the fused figure (141.9 / 283.8 MB)
+            per = wl.hbm_bytes_per_unit[0 if args.dtype == 'bf16' else 1]
+            cfg['hbm_frac_whole_step_op_by_op'] = value / world * per / 8e12
+            cfg['hbm_frac_whole_step_fused'] = value / world * (141.9e6 if args.dtype == 'bf16' else 283.8e6) / 8e12
         line = {
-            'metric': 'patches/s (fwd+bwd) ISP->JPEG->FAN @256^2', 'value': value, 'unit': 'patches/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
-            'data': 'synthetic (natural-image-like RAW/RGB pairs, random-init weights)',
-            'config': {'workload': 'train_manipulation UNet->[native,sharpen:1,resample:50,gaussian:0.83,jpeg:80]->'
-                                   'dJPEG(QF80,soft)->FAN, ds none, trainable nip+fan, lambda_nip 0.1',
-                       'raw_patch': args.raw_patch, 'rgb_patch': 2 * args.raw_patch,
-                       'batch_per_gpu': args.batch, 'global_batch': world * args.batch, 'parallelism': 'dp%d' % world,
-                       'loss': float(loss), 'achieved_tflops_whole_step': value * GFLOP_PER_PATCH / 1e3,
-                       # SURVEY 8d compulsory-traffic model of the whole step against 8 TB/s: one kernel per reference op
-                       # (343.8 MB bf16 / 687.5 MB f32 per raw patch) and the fused figure (141.9 / 283.8 MB)
-                       'hbm_frac_whole_step_op_by_op': value / world * (343.8e6 if args.dtype == 'bf16' else 687.5e6) / 8e12,
-                       'hbm_frac_whole_step_fused': value / world * (141.9e6 if args.dtype == 'bf16' else 283.8e6) / 8e12},
+            'metric': 'patches/s (fwd+bwd) ISP->JPEG->FAN @256^2' if wl.key == 'c4' else
+                      ('patches/s (fwd+bwd) TwitterDCN-32C @256^2' if wl.key == 'c3' else
+                       'patches/s (fwd+bwd) ISP->TwitterDCN->FAN @256^2'),
+            'value': value, 'unit': 'patches/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
+            'data': 'synthetic (natural-image-like RAW/RGB pairs, random-init weights)', 'config': cfg,
             'roofline': {'bound': 'mfma', 'achieved': dom['tflops'], 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': dom['tflops'] / peak, 'traffic': dom['traffic'], 'kernel': dom['kernel'],
                          'ms_per_launch': dom['ms_per_launch'], 'flops_per_launch': dom['flops_per_launch']},
         }
-        if world == 1 and args.dtype == 'bf16' and not args.no_parity_mode:
-            # PSNR / decision parity of the two compute modes on the same weights and batch (BASELINE metric: "PSNR/acc
-            # parity"): ISP output and classifier decisions in throughput mode vs float32 mode
-            out_b = wf.run_workflow(bx)
+        if world == 1 and args.dtype == 'bf16' and not args.no_parity_mode and wl.key in ('c4', 'c5') and not args.graph:
             _ops.set_compute('f32')                           # same step, exact float32 MFMA (the parity-test mode)
-            out_f = wf.run_workflow(bx)
-            yb, yf = out_b[0].t.float(), out_f[0].t.float()
-            mse_modes = float(((yb - yf) ** 2).mean().item())
-            agree = float((out_b[-1].t.argmax(dim=1) == out_f[-1].t.argmax(dim=1)).float().mean().item())
-            mode_parity = {'isp_psnr_bf16_vs_f32_db': 10 * np.log10(1.0 / max(mse_modes, 1e-20)),
-                           'fan_decision_agreement': agree,
-                           'isp_psnr_vs_target_db': {'bf16': 10 * np.log10(1.0 / float(((yb - by) ** 2).mean().item())),
-                                                     'f32': 10 * np.log10(1.0 / float(((yf - by) ** 2).mean().item()))}}
-            wf.training_step(bx, by, lambda_nip=0.1, learning_rate=1e-4)
+            for _ in range(2):
+                step()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(3):
-                wf.training_step(bx, by, lambda_nip=0.1, learning_rate=1e-4)
+            n32 = 5
+            for _ in range(n32):
+                step()
             torch.cuda.synchronize()
-            dt32 = (time.perf_counter() - t1) / 3
-            dom32 = time_dominant_kernel(dev, 5 * args.batch)
-            line['config']['f32_parity_mode'] = {
-                'patches_per_s': args.batch / dt32, 'ms_per_step': 1e3 * dt32,
-                'dominant_kernel_tflops': dom32['tflops'], 'dominant_kernel_frac_of_f32_mfma_peak':
-                    dom32['tflops'] / F32_MFMA_PEAK_TFLOPS, 'parity_of_modes': mode_parity}
+            dt32 = (time.perf_counter() - t1) / n32
+            dom32 = wl.dominant(dev)
+            line['f32_mode_patches_per_s'] = wl.batch / dt32          # top level: the driver's parser keeps flat scalars
+            line['f32_mode_ms_per_step'] = 1e3 * dt32
+            line['f32_mode_dominant_kernel_frac_of_peak'] = dom32['tflops'] / F32_MFMA_PEAK_TFLOPS
             _ops.set_compute(args.dtype)
+            if args.parity_steps > 0 and wl.key == 'c4':
+                par = accuracy_parity(wl, dev, args.parity_steps)
+                line['parity_fan_accuracy_bf16'] = par['bf16']['fan_accuracy']
+                line['parity_fan_accuracy_f32'] = par['f32']['fan_accuracy']
+                line['parity_isp_psnr_db_bf16'] = par['bf16']['isp_psnr_vs_target_db']
+                line['parity_isp_psnr_db_f32'] = par['f32']['isp_psnr_vs_target_db']
+                cfg['mode_parity_after_training'] = par
+                _ops.set_compute(args.dtype)
         if not args.no_cpu_baseline and world == 1:
-            line['cpu_baseline'] = cpu_baseline(args.raw_patch)
+            line['cpu_baseline'] = cpu_baseline(wl.key, args.raw_patch)
         print(json.dumps(line))
     if world > 1:
         torch.distributed.barrier()

@@ -170,6 +170,10 @@ int nimg_fan_head_bwd(const float* act, const float* gap, const float* w, const 
  * device int): when non-zero the update is skipped - the device-side form of the NaN guard at workflows/...:281-283. */
 int nimg_adam_step(float* params, const float* grads, float* m, float* v, long count, float lr, float beta1,
                    float beta2, float eps, int step, float grad_scale, const int* skip_flag, void* stream);
+/* The same update with the bias-corrected rate lr*sqrt(1-b2^t)/(1-b1^t) read from DEVICE memory (one float): the form a
+ * captured hipGraph replays - the host refreshes *lr_t before every replay, the launch itself never changes. */
+int nimg_adam_step_dev(float* params, const float* grads, float* m, float* v, long count, const float* lr_t, float beta1,
+                       float beta2, float eps, float grad_scale, const int* skip_flag, void* stream);
 /* flag[0] |= 1 if any gradient is NaN (device-side version of workflows/manipulation_classification.py:281-282) */
 int nimg_nan_flag(const float* g, long count, int* flag, void* stream);
 
@@ -262,6 +266,13 @@ int nimg_isp_residual_bwd(const float* dy, const float* f, const float* alpha, f
 /* Dropout of the FAN's hidden Dense layers at training time (models/forensics.py:88), forward and backward alike:
  * y = keep[i] ? x[i] * scale : 0, keep = the Bernoulli(1 - rate) mask bytes, scale = 1 / (1 - rate). */
 int nimg_mask_scale(const float* x, const uint8_t* keep, float* y, long count, float scale, void* stream);
+/* Classifier decisions + confusion matrix on the device - replaces the host loop of validate_fan,
+ * training/validation.py:163-202 (np.argmax per batch, conf[c, c_] += sum((y == c) * (pred == c_)), one D2H per batch).
+ * probs (n,k) float32; labels (n) int32 or NULL; pred (n) int32 or NULL: first arg-max of each row (numpy.argmax);
+ * conf (k,k) uint64 or NULL (needs labels): conf[label][pred] += 1, accumulated over calls - the caller zeroes it once per
+ * validation pass and reads it back once. */
+int nimg_confusion_accumulate(const float* probs, const int* labels, int* pred, unsigned long long* conf, int n, int k,
+                              void* stream);
 int nimg_sigmoid_fwd(const float* x, float* y, long count, void* stream);
 int nimg_sigmoid_bwd(const float* dy, const float* y, float* dx, long count, void* stream);
 int nimg_gamma_ste_fwd(const float* x, float* y, long count, float lo, float hi, float exponent, void* stream);

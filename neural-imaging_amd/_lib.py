@@ -45,6 +45,7 @@ PROTOTYPES = {
     'nimg_fan_head_fwd': (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     'nimg_fan_head_bwd': (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P]),
     'nimg_adam_step': (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_int, c_float, P, P]),
+    'nimg_adam_step_dev': (c_int, [P, P, P, P, c_long, P, c_float, c_float, c_float, c_float, P, P]),
     'nimg_nan_flag': (c_int, [P, c_long, P, P]),
     'nimg_constrained_kernel_fwd': (c_int, [P, P, c_int, c_int, c_float, P]),
     'nimg_constrained_kernel_bwd': (c_int, [P, P, P, c_int, c_int, c_float, P]),
@@ -93,6 +94,7 @@ PROTOTYPES = {
     'nimg_patch_select': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P, P]),
     'nimg_patch_gather': (c_int, [P, P, c_int, c_int, c_int, P, P, c_int, c_int, P, P, P]),
     'nimg_mask_scale': (c_int, [P, P, P, c_long, c_float, P]),
+    'nimg_confusion_accumulate': (c_int, [P, P, P, P, c_int, c_int, P]),
     'nimg_ssim_planes_workspace_bytes': (c_size_t, [c_int, c_int]),
     'nimg_ssim_planes': (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, P, P, P, P, c_int, P, c_size_t, P]),
     'nimg_msssim_combine': (c_int, [P, P, c_int, c_int, P, P, P]),

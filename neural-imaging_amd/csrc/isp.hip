@@ -94,9 +94,39 @@ __global__ void mask_scale_kernel(const float* __restrict__ x, const uint8_t* __
         y[i] = keep[i] ? x[i] * scale : 0.f;
 }
 
+// Classifier decisions and their confusion matrix on the device (training/validation.py:163-202 does this on the host,
+// one batch at a time): pred = first arg-max of the probability row (numpy.argmax), conf[label][pred] += 1.
+__global__ void confusion_kernel(const float* __restrict__ probs, const int* __restrict__ labels, int* __restrict__ pred,
+                                 unsigned long long* __restrict__ conf, int n, int k) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float* row = probs + (long)i * k;
+        int best = 0;
+        float bv = row[0];
+        for (int c = 1; c < k; ++c) {
+            const float v = row[c];
+            if (v > bv) { bv = v; best = c; }
+        }
+        if (pred) pred[i] = best;
+        if (conf && labels) {
+            const int l = labels[i];
+            if (l >= 0 && l < k) atomicAdd(conf + (long)l * k + best, 1ull);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int nimg_confusion_accumulate(const float* probs, const int* labels, int* pred, unsigned long long* conf, int n, int k,
+                              void* stream) {
+    if (n < 0 || k < 1) return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    if (!probs || (!pred && !conf) || (conf && !labels)) return NIMG_ERR_ARG;
+    hipLaunchKernelGGL(confusion_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, probs, labels, pred, conf, n, k);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
 
 int nimg_mask_scale(const float* x, const uint8_t* keep, float* y, long count, float scale, void* stream) {
     if (count < 0) return NIMG_ERR_ARG;

@@ -464,8 +464,9 @@ __global__ void ssim_final_kernel(const double* __restrict__ partial, float* __r
 // Keras Adam: theta -= lr_t * m / (sqrt(v) + eps), lr_t = lr * sqrt(1-b2^t)/(1-b1^t); optional grad pre-scale
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long count, float lr_t, float b1, float b2, float eps,
-                            float gscale, const int* __restrict__ skip_flag) {
+                            float gscale, const int* __restrict__ skip_flag, const float* __restrict__ lr_t_dev) {
     if (skip_flag && skip_flag[0]) return;      // NaN gradients: leave the model untouched (reference raises first)
+    if (lr_t_dev) lr_t = lr_t_dev[0];           // captured step: the bias-corrected rate of THIS replay lives on the device
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
         const float gi = gscale * g[i];
         const float mi = b1 * m[i] + (1.0f - b1) * gi;
@@ -673,7 +674,17 @@ int nimg_adam_step(float* params, const float* grads, float* m, float* v, long c
     const double lr_t = (double)lr * __builtin_sqrt(1.0 - __builtin_pow((double)beta2, (double)step)) /
                         (1.0 - __builtin_pow((double)beta1, (double)step));
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v,
-                       count, (float)lr_t, beta1, beta2, eps, grad_scale, skip_flag);
+                       count, (float)lr_t, beta1, beta2, eps, grad_scale, skip_flag, (const float*)nullptr);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_adam_step_dev(float* params, const float* grads, float* m, float* v, long count, const float* lr_t, float beta1,
+                       float beta2, float eps, float grad_scale, const int* skip_flag, void* stream) {
+    if (!params || !grads || !m || !v || !lr_t || count < 0) return NIMG_ERR_ARG;
+    if (count == 0) return NIMG_OK;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v,
+                       count, 0.f, beta1, beta2, eps, grad_scale, skip_flag, lr_t);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }

@@ -50,10 +50,28 @@ class DeviceArray(object):
     def __getitem__(self, item):
         return DeviceArray(self.t[item])
 
+    # scalar results take part in host arithmetic like the EagerTensors they stand for (np.sqrt(2 * loss), a - b, ...)
     def __mul__(self, other):
         return float(self) * other
 
     __rmul__ = __mul__
+
+    def __add__(self, other):
+        return float(self) + other
+
+    __radd__ = __add__
+
+    def __sub__(self, other):
+        return float(self) - other
+
+    def __rsub__(self, other):
+        return other - float(self)
+
+    def __truediv__(self, other):
+        return float(self) / other
+
+    def __rtruediv__(self, other):
+        return other / float(self)
 
     def __repr__(self):
         return 'DeviceArray(shape={}, device={})'.format(self.shape, self.t.device)

@@ -1,0 +1,63 @@
+"""
+hipGraph capture of the channel's training step.
+
+A training step is a fixed sequence of ~240 kernel launches (explicit forward / backward, no tape, no host decisions between
+launches when nan_check='deferred'), issued through Python + ctypes.  CapturedStep records that sequence ONCE into a HIP graph
+(torch.cuda.CUDAGraph drives hipStreamBeginCapture on torch's stream; the library's launches land on that stream, the
+weight-gradient side stream is forked / joined inside the capture) and replays it with one call per step.  The only per-step
+host input is Keras Adam's bias-corrected rate lr * sqrt(1 - b2^t) / (1 - b1^t): it lives in a one-float device buffer that is
+refreshed before every replay (nimg_adam_step_dev reads it), so the captured launches never change.
+
+Restrictions: fixed batch shape and hyper-parameters (lambda_*, manipulation strengths: augment=False), single process (the
+RCCL bucket launches are not captured), nan_check='deferred'.
+"""
+import torch
+
+from . import ops, parallel
+
+
+class CapturedStep(object):
+
+    def __init__(self, flow, batch_x, batch_y, learning_rate=1e-4, warmup=3, **kw):
+        if parallel.world_size() > 1:
+            raise RuntimeError('CapturedStep: the data-parallel step is not captured (RCCL launches stay eager)')
+        if flow._nan_check != 'deferred' or kw.get('augment'):
+            raise ValueError('CapturedStep needs nan_check="deferred" and augment=False (no host decisions inside a step)')
+        self.flow, self.lr, self.kw = flow, float(learning_rate), kw
+        dev = flow.device
+        self.x = batch_x.detach().to(dev).clone().contiguous()          # static inputs: refill with load()
+        self.y = batch_y.detach().to(dev).clone().contiguous()
+        self._rate_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        # warm-up on a side stream (allocator / workspace growth, lazy module state), as torch's capture rules ask
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            for _ in range(max(int(warmup), 1)):
+                flow.training_step(self.x, self.y, learning_rate=self.lr, **kw)
+        torch.cuda.current_stream(dev).wait_stream(s)
+        torch.cuda.synchronize(dev)
+        self.t = flow._step
+        flow._lr_t_dev = self._rate_dev
+        self.graph = torch.cuda.CUDAGraph()
+        try:
+            self._set_rate(self.t + 1)
+            with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
+                self.out = flow.training_step(self.x, self.y, learning_rate=self.lr, **kw)
+        finally:
+            flow._lr_t_dev = None
+        flow._step = self.t                 # the capture itself executed nothing
+
+    def _set_rate(self, t):
+        self._rate_dev.fill_(ops.adam_lr_t(self.lr, t))     # a scalar-argument fill launch, ordered before the replay
+
+    def load(self, batch_x, batch_y):
+        """Next batch into the captured step's input buffers (device-to-device or pinned host-to-device copy)."""
+        self.x.copy_(batch_x, non_blocking=True)
+        self.y.copy_(batch_y, non_blocking=True)
+
+    def step(self):
+        self.t += 1
+        self._set_rate(self.t)
+        self.graph.replay()
+        self.flow._step = self.t
+        return self.out

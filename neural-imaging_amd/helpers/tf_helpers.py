@@ -6,6 +6,8 @@ with forward(x, strength, out) / backward(ctx, dy), which is what the workflow's
 Implemented: sharpen (hsv=True, incl. the S-channel corner-tap quirk), resample (bilinear down+up, any factor),
 gaussian (5x5, any std), awgn (device-side noise), gamma, median (odd kernels up to 9).
 """
+from collections import OrderedDict
+
 import numpy as np
 import torch
 
@@ -14,18 +16,34 @@ from ..device import DeviceArray, to_device, default_device
 from . import kernels as hk
 
 
+class _TapCache(OrderedDict):
+    """Device copies of small filter tables keyed by (strength, device), least recently used dropped beyond `limit` entries:
+    augmentation draws a fresh strength every step, an unbounded cache would grow by one device allocation per step."""
+
+    def __init__(self, limit=8):
+        super().__init__()
+        self.limit = limit
+
+    def fetch(self, key, build):
+        if key in self:
+            self.move_to_end(key)
+            return self[key]
+        self[key] = value = build()
+        while len(self) > self.limit:
+            self.popitem(last=False)
+        return value
+
+
 class Sharpen(object):
     """manipulation_sharpen(x, strength, hsv=True)  (tf_helpers.py:156-184)"""
 
     def __init__(self):
-        self._cache = {}
+        self._cache = _TapCache()
 
     def taps(self, strength, device):
-        key = (float(strength), str(device))
-        if key not in self._cache:
-            gk = hk.sharpen_kernel(float(strength)).astype(np.float32)      # tf.constant(gfilter, tf.float32)
-            self._cache[key] = torch.from_numpy(gk.reshape(-1)).to(device)
-        return self._cache[key]
+        # tf.constant(gfilter, tf.float32)
+        return self._cache.fetch((float(strength), str(device)), lambda: torch.from_numpy(
+            hk.sharpen_kernel(float(strength)).astype(np.float32).reshape(-1)).to(device))
 
     def forward(self, x, strength=1, out=None, training=False):
         gk = self.taps(strength, x.device)
@@ -42,14 +60,11 @@ class Gaussian(object):
     def __init__(self, kernel=5):
         if kernel != 5:
             raise NotImplementedError('only the 5x5 gaussian used by the workflow is built')
-        self._cache = {}
+        self._cache = _TapCache()
 
     def taps(self, std, device):
-        key = (float(std), str(device))
-        if key not in self._cache:
-            gk = hk.gkern(5, float(std)).astype(np.float32)
-            self._cache[key] = torch.from_numpy(gk.reshape(-1)).to(device)
-        return self._cache[key]
+        return self._cache.fetch((float(std), str(device)), lambda: torch.from_numpy(
+            hk.gkern(5, float(std)).astype(np.float32).reshape(-1)).to(device))
 
     def forward(self, x, std=0.83, out=None, training=False, skip_clip=False):
         gk = self.taps(std, x.device)

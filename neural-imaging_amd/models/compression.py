@@ -103,23 +103,22 @@ class DCN(TFModel):
         y, ent, _ = self.forward(to_device(batch_x, self.device))
         return (DeviceArray(y), DeviceArray(ent)) if return_entropy else DeviceArray(y)
 
-    def training_step(self, batch_x, learning_rate=None):
-        """One optimisation step on l2_loss(x - y) + entropy_weight * H (compression.py:123-138)."""
+    def training_step(self, batch_x, learning_rate=None, sync=True):
+        """One optimisation step on l2_loss(x - y) + entropy_weight * H (compression.py:123-138).  sync=False keeps the step
+        asynchronous: 'loss' is then a lazy value that reads the device scalars only when converted (float / numpy)."""
         x = to_device(batch_x, self.device)
         y, ent, ctx = self.forward(x, training=True)
         l2, dy = ops.l2_loss(x, y, grad_scale=1.0)
         self.backward(ctx, dy, entropy_coef=self._h.entropy_weight)
-        world = parallel.world_size()
-        if world > 1:
-            bucket = parallel.GradientBucket()
-            bucket.launch(self._model.flat_grad)
-            bucket.wait()
+        parallel.sync_gradients(self._model.flat_grad)
         if learning_rate is not None:
             self.learning_rate = learning_rate
         self._model.adam(self.learning_rate)          # l2_loss is a SUM over the batch: summed gradients, no 1/world
-        loss = float(DeviceArray(l2)) + self._h.entropy_weight * float(DeviceArray(ent))
         h, w = x.shape[1], x.shape[2]
         ssim = DeviceArray(ops.ssim(x, y, mode='tf').mean()) if min(h, w) >= 11 else np.nan     # compression.py:89,129
+        if not sync:
+            return {'loss': _LazyDcnLoss(l2, ent, self._h.entropy_weight), 'ssim': ssim, 'entropy': DeviceArray(ent)}
+        loss = float(DeviceArray(l2)) + self._h.entropy_weight * float(DeviceArray(ent))
         return {'loss': np.sqrt(2 * loss), 'ssim': ssim, 'entropy': DeviceArray(ent)}
 
     def compression_stats(self, patch_size=None, n_latent_bytes=None):
@@ -143,6 +142,22 @@ class DCN(TFModel):
     @property
     def model_code(self):
         return '{}-{}C'.format(type(self).__name__, self._h.n_features)
+
+
+class _LazyDcnLoss(DeviceArray):
+    """sqrt(2 (l2 + w H)) (compression.py:135), evaluated on the host only when somebody reads it."""
+    __slots__ = ('l2', 'ent', 'w')
+
+    def __init__(self, l2, ent, w):
+        self.t = l2
+        self.l2, self.ent, self.w = l2, ent, float(w)
+
+    def numpy(self):
+        v = float(self.l2.detach().cpu().reshape(())) + self.w * float(self.ent.detach().cpu().reshape(()))
+        return np.asarray(np.sqrt(2 * v), dtype=np.float64)
+
+    def __float__(self):
+        return float(self.numpy())
 
 
 class TwitterDCN(DCN):

@@ -12,7 +12,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-from .. import ops
+from .. import ops, parallel
 from ..device import DeviceArray, to_device
 from ..helpers import paramspec
 from .layers import ConstrainedConv2D, Conv2D
@@ -242,9 +242,10 @@ class FAN(TFModel):
         labels = torch.as_tensor(np.asarray(target_labels), dtype=torch.int32).to(self.device)
         _, ctx = self.forward(x, labels, training=True)
         loss, _ = self.backward(ctx, need_input_grad=False)
+        world = parallel.sync_gradients(self._model.flat_grad)       # data parallel: CE is a mean over the batch
         if learning_rate is not None:
             self.learning_rate = learning_rate
-        self._model.adam(self.learning_rate)
+        self._model.adam(self.learning_rate, grad_scale=1.0 / world)
         return DeviceArray(loss)
 
     def summary(self):

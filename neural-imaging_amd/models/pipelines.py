@@ -12,7 +12,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-from .. import ops
+from .. import ops, parallel
 from ..device import DeviceArray, to_device
 from ..helpers import kernels as hk
 from ..helpers import paramspec, utils
@@ -63,9 +63,10 @@ class NIPModel(TFModel):
         y, ctx = self.forward(x, training=True)
         loss, dy = self.loss_and_grad(y, t)
         self.backward(ctx, dy)
+        world = parallel.sync_gradients(self._model.flat_grad)       # data parallel: the loss is a mean over the batch
         if learning_rate is not None:
             self.learning_rate = learning_rate
-        self._model.adam(self.learning_rate)
+        self._model.adam(self.learning_rate, grad_scale=1.0 / world)
         return DeviceArray(loss)
 
     learning_rate = 1e-3      # tf.keras.optimizers.Adam() default
@@ -160,8 +161,14 @@ class UNet(NIPModel):
         y = ops.d2s_clip(t['dc{}'.format(ns)], 1.0, 0.0, True)
         return y, (t if training else None)
 
-    def backward(self, t, dy):
-        """dy = d loss / d y (N,2h,2w,3).  Fills the gradient buffer; the RAW input needs no gradient."""
+    def decoder_grads(self):
+        """The decoder's slice of the flat gradient buffer (complete when the decoder backward is done), the encoder's."""
+        return self._model.grad_range(first='dct1/kernel'), self._model.grad_range(before='dct1/kernel')
+
+    def backward(self, t, dy, on_decoder_done=None):
+        """dy = d loss / d y (N,2h,2w,3).  Fills the gradient buffer; the RAW input needs no gradient.
+        on_decoder_done(): called once every decoder gradient has been queued (data parallelism all-reduces that slice
+        while the encoder backward runs)."""
         L, P, ns = self._layers, self._model, self._h.n_steps
         hw = lambda a: (a.shape[1], a.shape[2])
         # head: d2s + clip are straight-through
@@ -182,6 +189,8 @@ class UNet(NIPModel):
             prev = t['dc{}2'.format(n - 1)]
             L['dct{}'.format(n)].backward_params(P, prev, d_up)
             dz = L['dct{}'.format(n)].backward_input(P, d_up, act_mask=prev)                # dZ of dc{n-1}2 / ec{ns}2
+        if on_decoder_done is not None:
+            on_decoder_done()
         for n in range(ns, 0, -1):
             a1, inp = t['ec{}1'.format(n)], t['ep{}'.format(n - 1)]
             L['ec{}2'.format(n)].backward_params(P, a1, dz)

@@ -34,17 +34,25 @@ class ParamStore(object):
         total = int(sum(-(-n // align) * align for n in sizes))
         self.flat = torch.zeros(total, dtype=torch.float32, device=device)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=device)
-        self.p, self.g = OrderedDict(), OrderedDict()
+        self.p, self.g, self.offsets = OrderedDict(), OrderedDict(), OrderedDict()
         off = 0
         for (name, shape), n in zip(self.specs.items(), sizes):
             self.p[name] = self.flat[off:off + n].view(shape)
             self.g[name] = self.flat_grad[off:off + n].view(shape)
+            self.offsets[name] = off
             off += -(-n // align) * align
         self.m = self.v = None
         self.step = 0
         # bf16 images of every 4-D (convolution) kernel, rebuilt by one launch per step in throughput mode
         self.images = ops.WeightImages([t for t in self.p.values() if t.dim() == 4 and min(t.shape) > 0], device) \
             if torch.device(device).type == 'cuda' else None
+
+    def grad_range(self, first=None, before=None):
+        """Contiguous view of the flat gradient buffer from parameter `first` (default: the start) up to, not including,
+        parameter `before` (default: the end) - the unit of a partial all-reduce."""
+        lo = 0 if first is None else self.offsets[first]
+        hi = self.flat_grad.numel() if before is None else self.offsets[before]
+        return self.flat_grad[lo:hi]
 
     def refresh_images(self):
         """Call at the top of a forward pass: the kernels of this step read the images built here."""
@@ -56,13 +64,14 @@ class ParamStore(object):
             self.m = torch.zeros_like(self.flat)
             self.v = torch.zeros_like(self.flat)
 
-    def adam(self, lr, step=None, grad_scale=1.0, skip_flag=None):
+    def adam(self, lr, step=None, grad_scale=1.0, skip_flag=None, lr_t_dev=None):
         """One Keras-Adam update over the whole buffer (beta1 .9, beta2 .999, eps 1e-7)."""
         self.ensure_adam()
         if step is None:
             self.step += 1
             step = self.step
-        ops.adam_step(self.flat, self.flat_grad, self.m, self.v, lr, step, grad_scale=grad_scale, skip_flag=skip_flag)
+        ops.adam_step(self.flat, self.flat_grad, self.m, self.v, lr, step, grad_scale=grad_scale, skip_flag=skip_flag,
+                      lr_t_dev=lr_t_dev)
 
 
 def glorot_uniform_(t, fan_in, fan_out, gen):

@@ -594,9 +594,20 @@ def fan_head_bwd(act, gap, w, dlogits, loss_per, loss_scale, dw, db):
     return dact, loss
 
 
-def adam_step(params, grads, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0, skip_flag=None):
+def adam_lr_t(lr, step, beta1=0.9, beta2=0.999):
+    """Keras Adam's bias-corrected rate of iteration `step` (1-based), in double like nimg_adam_step computes it."""
+    return float(lr) * math.sqrt(1.0 - beta2 ** int(step)) / (1.0 - beta1 ** int(step))
+
+
+def adam_step(params, grads, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0, skip_flag=None,
+              lr_t_dev=None):
+    """lr_t_dev: optional 1-element device tensor holding the bias-corrected rate (captured-graph replays refresh it)."""
     join_side_stream()
-    _f32(params, grads, m, v)
+    _f32(params, grads, m, v, lr_t_dev)
+    if lr_t_dev is not None:
+        _lib.call('nimg_adam_step_dev', _p(params), _p(grads), _p(m), _p(v), params.numel(), _p(lr_t_dev), float(beta1),
+                  float(beta2), float(eps), float(grad_scale), _p(skip_flag), _stream())
+        return
     _lib.call('nimg_adam_step', _p(params), _p(grads), _p(m), _p(v), params.numel(), float(lr), float(beta1),
               float(beta2), float(eps), int(step), float(grad_scale), _p(skip_flag), _stream())
 
@@ -1053,6 +1064,20 @@ def mask_scale(x, keep, scale, out=None):
     y = torch.empty_like(x) if out is None else out
     _lib.call('nimg_mask_scale', _p(x), _p(keep), _p(y), x.numel(), float(scale), _stream())
     return y
+
+
+def confusion_accumulate(probs, labels=None, conf=None, want_pred=True):
+    """Decisions (first arg-max per row, int32) of a (n,k) probability batch and, given int32 labels and a (k,k) int64
+    device matrix, conf[label][pred] += 1 - all on the device (training/validation.py:163-202 without the per-batch D2H)."""
+    _f32(probs)
+    n, k = probs.shape
+    if labels is not None and (labels.dtype != torch.int32 or labels.numel() != n or not labels.is_cuda):
+        raise TypeError('labels: int32 device tensor with one entry per row of probs')
+    if conf is not None and (conf.dtype != torch.int64 or tuple(conf.shape) != (k, k) or not conf.is_contiguous()):
+        raise TypeError('conf: contiguous (k,k) int64 device tensor')
+    pred = torch.empty((n,), dtype=torch.int32, device=probs.device) if want_pred else None
+    _lib.call('nimg_confusion_accumulate', _p(probs), _p(labels), _p(pred), _p(conf), n, k, _stream())
+    return pred
 
 
 def sigmoid(x, out=None):

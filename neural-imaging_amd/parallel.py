@@ -56,6 +56,16 @@ class GradientBucket(object):
         self._work = []
 
 
+def sync_gradients(flat_grad):
+    """Blocking sum all-reduce of one model's flat gradient buffer (the stand-alone training_step of a single model).
+    Returns the world size: mean losses scale the Adam step by 1 / world, sum losses (tf.nn.l2_loss) by 1."""
+    from . import ops
+    ops.join_side_stream()
+    if is_distributed() and flat_grad.numel() > 0:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+    return world_size()
+
+
 def all_reduce_flag(flag):
     """OR-reduce the NaN flag over ranks (SURVEY 8e caveat 4)."""
     if is_distributed():
@@ -77,5 +87,7 @@ def broadcast_floats(values, device=None):
 def shard_batch(batch, rank_, world):
     """Contiguous shard of the global batch for this rank (labels are positional per rank, workflows/...:257-258)."""
     n = batch.shape[0]
+    if n % world:
+        raise ValueError('a global batch of {} does not split over {} ranks'.format(n, world))
     per = n // world
     return batch[rank_ * per:(rank_ + 1) * per]

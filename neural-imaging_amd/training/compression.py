@@ -10,6 +10,7 @@ from collections import OrderedDict
 
 import numpy as np
 
+from .. import parallel
 from . import validation
 
 
@@ -23,6 +24,9 @@ def train_dcn(dcn, training, data, directory='./data/models/dcn/playground/', ov
     if os.path.exists(out) and not overwrite:
         return out
     rng = np.random.RandomState(spec['seed'])
+    world, rank = parallel.world_size(), parallel.rank()
+    if spec['batch_size'] % world:
+        raise ValueError('batch_size {} does not split over {} ranks'.format(spec['batch_size'], world))
     n_batches = data.count_training // spec['batch_size']
     lr = spec['learning_rate']
     summary = OrderedDict([('model', dcn.summary()), ('epochs', spec['n_epochs']), ('batch', spec['batch_size']),
@@ -40,22 +44,27 @@ def train_dcn(dcn, training, data, directory='./data/models/dcn/playground/', ov
                 for ax in flips:
                     bx = np.flip(bx, ax)
                 bx = np.ascontiguousarray(bx)
-            res = dcn.training_step(bx, lr)
-            if not np.isfinite(res['loss']):
-                raise RuntimeError('DCN training diverged (non-finite loss)')
+            if world > 1:          # batch_size is the global batch; every rank trains on its contiguous shard
+                bx = parallel.shard_batch(bx, rank, world).contiguous() if hasattr(bx, 'contiguous') else \
+                    np.ascontiguousarray(parallel.shard_batch(bx, rank, world))
+            res = dcn.training_step(bx, lr, sync=False)         # device scalars, read once per epoch
             stats['loss'].append(res['loss'])
-            stats['entropy'].append(float(res['entropy']))
+            stats['entropy'].append(res['entropy'])
+        stats = {k: [float(v) for v in vs] for k, vs in stats.items()}
+        if not np.isfinite(stats['loss']).all():
+            raise RuntimeError('DCN training diverged (non-finite loss)')
         dcn.log_metric('loss', 'training', stats['loss'])
         dcn.log_metric('entropy', 'training', stats['entropy'])
         if epoch % spec['validation_schedule'] == 0:
             vals = validation.validate_dcn(dcn, data, out, epoch=epoch)
             for k, v in vals.items():
                 dcn.log_metric(k, 'validation', v)
-            os.makedirs(out, exist_ok=True)
-            with open(os.path.join(out, 'progress.json'), 'w') as f:
-                json.dump({'performance': dcn.performance, 'summary': summary, 'args': dcn.get_hyperparameters()}, f,
-                          indent=4, default=lambda o: float(o))
-            dcn.save_model(out, epoch, save_args=True, quiet=True)
+            if rank == 0:
+                os.makedirs(out, exist_ok=True)
+                with open(os.path.join(out, 'progress.json'), 'w') as f:
+                    json.dump({'performance': dcn.performance, 'summary': summary, 'args': dcn.get_hyperparameters()}, f,
+                              indent=4, default=lambda o: float(o))
+                dcn.save_model(out, epoch, save_args=True, quiet=True)
             # convergence / deterioration of the validation SSIM over the last n_tail samplings (compression.py:282-295)
             vs, n_tail = dcn.performance['ssim']['validation'], 5
             if len(vs) > 5:

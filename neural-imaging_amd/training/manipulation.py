@@ -8,10 +8,13 @@ root/camera/NIP/{ln-x|fixed-nip}/{lc-x|fixed-codec}/run (:111-123) with "directo
 `data` is any object with the reference Dataset's duck type (helpers/dataset.py) - see SyntheticDataset below.
 """
 import os
+import shutil
 from collections import OrderedDict, deque
 
 import numpy as np
 
+from .. import parallel
+from ..models import compression
 from . import validation
 
 
@@ -130,6 +133,41 @@ def train_manipulation_nip(flow, training, data, directories=None, overwrite=Fal
     summary['Validation schedule'] = training['validation_schedule']
     summary['Augmentation'] = str(training['augment'])
 
+    world, rank = parallel.world_size(), parallel.rank()
+    if training['batch_size'] % world:
+        raise ValueError('batch_size {} does not split over {} ranks'.format(training['batch_size'], world))
+    codec_is_dcn = flow.is_trainable('dcn') and isinstance(flow.codec, compression.DCN)
+
+    def validate_and_save(epoch, final=False):
+        """One validation pass over every trained model, training.json and the checkpoints (training/manipulation.py:224-259
+        inside the loop, :300-334 after it).  Every rank validates (the learned codec's entropy is a collective under data
+        parallelism); rank 0 writes."""
+        accuracy, conf = validation.validate_fan(flow, data)
+        flow.fan.log_metric('accuracy', 'validation', accuracy)
+        flow.fan.performance['confusion'] = conf.tolist()
+        if flow.is_trainable('nip') and data.is_raw_and_rgb():
+            values = validation.validate_nip(flow.nip, data, save_dir, epoch=epoch,
+                                             loss_type='L2' if final else flow.nip.loss_metric)
+            for metric, arr in zip(['ssim', 'psnr', 'loss'], values):
+                flow.nip.log_metric(metric, 'validation', arr)
+        if codec_is_dcn:
+            for metric, value in validation.validate_dcn(flow.codec, data, save_dir, epoch=epoch).items():
+                flow.codec.log_metric(metric, 'validation', value)
+        if rank != 0:
+            return
+        validation.save_training_progress(summary, flow, save_dir, quiet=True)
+        flow.fan.save_model(os.path.join(model_directory, flow.fan.scoped_name), epoch, quiet=True)
+        if flow.is_trainable('nip'):
+            flow.nip.save_model(os.path.join(model_directory, flow.nip.scoped_name), epoch, quiet=True)
+        if codec_is_dcn:
+            codec_dir = os.path.join(model_directory, flow.codec.scoped_name)
+            flow.codec.save_model(codec_dir, epoch, quiet=True)
+            src = flow._distribution.get('compression_params', {}).get('dirname')
+            src = None if src is None else os.path.join(src, flow.codec.scoped_name, 'progress.json')
+            if final and src is not None and os.path.isfile(src):          # the pre-training record travels with the model
+                shutil.copyfile(src, os.path.join(codec_dir, 'progress.json'))
+
+    epoch = 0
     for epoch in range(0, training['n_epochs']):
         for batch_id in range(n_batches):
             if data._loaded_data == 'xy':
@@ -137,24 +175,19 @@ def train_manipulation_nip(flow, training, data, directories=None, overwrite=Fal
             else:
                 batch_x = data.next_training_batch(batch_id, training['batch_size'], 2 * ps)
                 batch_y = batch_x
+            if world > 1:          # the global batch is the reference's batch; every rank trains on its contiguous shard
+                batch_x, batch_y = parallel.shard_batch(batch_x, rank, world), parallel.shard_batch(batch_y, rank, world)
             comb_loss, comp_loss = flow.training_step(batch_x, batch_y, training['lambda_nip'], training['lambda_dcn'],
                                                       training['augment'], learning_rate)
-            loss_epoch['fan'].append(float(comb_loss))
-            loss_epoch['nip'].append(float(comp_loss['nip']))
+            loss_epoch['fan'].append(comb_loss)            # lazy device values: read once per epoch, not once per step
+            loss_epoch['nip'].append(comp_loss['nip'])
+        if getattr(flow, '_nan_check', 'eager') == 'deferred':
+            flow.check_nan()                               # NaN steps of this epoch (their updates were skipped on the device)
         for name, model in (('nip', flow.nip), ('fan', flow.fan)):
-            model.log_metric('loss', 'training', list(loss_epoch[name]))
+            model.log_metric('loss', 'training', [float(v) for v in loss_epoch[name]])
         if epoch % training['validation_schedule'] == 0:
-            accuracy, conf = validation.validate_fan(flow, data)
-            flow.fan.log_metric('accuracy', 'validation', accuracy)
-            flow.fan.performance['confusion'] = conf.tolist()
-            if flow.is_trainable('nip') and data.is_raw_and_rgb():
-                values = validation.validate_nip(flow.nip, data, save_dir, epoch=epoch, loss_type=flow.nip.loss_metric)
-                for metric, arr in zip(['ssim', 'psnr', 'loss'], values):
-                    flow.nip.log_metric(metric, 'validation', arr)
-            validation.save_training_progress(summary, flow, save_dir, quiet=True)
-            flow.fan.save_model(os.path.join(model_directory, flow.fan.scoped_name), epoch, quiet=True)
-            if flow.is_trainable('nip'):
-                flow.nip.save_model(os.path.join(model_directory, flow.nip.scoped_name), epoch, quiet=True)
+            validate_and_save(epoch)
         if epoch % decay_schedule == 0:
             learning_rate *= decay_rate
+    validate_and_save(epoch, final=True)
     return model_directory

@@ -10,6 +10,7 @@ from collections import OrderedDict
 
 import numpy as np
 
+from .. import parallel
 from . import validation
 
 
@@ -57,14 +58,19 @@ def train_nip_model(model, camera_name, n_epochs=10000, lr_schedule=None, valida
                            ('Saved checkpoint', None), ('Output directory', out_directory)])
     learning_rate = 1e-4
     epoch = start_epoch
+    world, rank = parallel.world_size(), parallel.rank()
+    if batch_size % world:
+        raise ValueError('batch_size {} does not split over {} ranks'.format(batch_size, world))
     for epoch in range(start_epoch, n_epochs):
         if epoch in lr_schedule:
             learning_rate = lr_schedule[epoch]
         losses = []
         for batch_id in range(n_batches):
             bx, by = data.next_training_batch(batch_id, batch_size, patch_size, discard=discard)
-            losses.append(float(model.training_step(bx, by, learning_rate)))
-        model.log_metric('loss', 'training', losses)
+            if world > 1:          # batch_size is the global batch; every rank trains on its contiguous shard
+                bx, by = parallel.shard_batch(bx, rank, world), parallel.shard_batch(by, rank, world)
+            losses.append(model.training_step(bx, by, learning_rate))          # device scalars, read once per epoch
+        model.log_metric('loss', 'training', [float(v) for v in losses])
         if epoch % validation_schedule == 0:
             ssims, psnrs, v_losses = validation.validate_nip(model, data, out_directory, epoch=epoch,
                                                              loss_type=model.loss_metric)
@@ -72,11 +78,14 @@ def train_nip_model(model, camera_name, n_epochs=10000, lr_schedule=None, valida
             model.log_metric('psnr', 'validation', psnrs)
             model.log_metric('loss', 'validation', v_losses)
             summary['Epoch'] = epoch
-            save_progress(model, summary, out_directory)
             vl = model.performance['loss']['validation']
-            if not save_best or (len(vl) > 2 and vl[-1] <= min(vl)):
+            keep = not save_best or (len(vl) > 2 and vl[-1] <= min(vl))
+            if keep:
                 summary['Saved checkpoint'] = epoch
-                model.save_model(out_directory, epoch, quiet=True)
+            if rank == 0:
+                save_progress(model, summary, out_directory)
+                if keep:
+                    model.save_model(out_directory, epoch, quiet=True)
             if len(vl) > 5 and vl[-1] > 1.2 * min(vl):
                 learning_rate = max(learning_rate * 0.95, 1e-7)
             if validation_loss_threshold is not None and len(vl) > 10:
@@ -84,6 +93,7 @@ def train_nip_model(model, camera_name, n_epochs=10000, lr_schedule=None, valida
                 if abs((current - previous) / previous) < validation_loss_threshold:
                     break
     summary['Epoch'] = epoch
-    model.save_model(out_directory, epoch, quiet=True)
-    save_progress(model, summary, out_directory)
+    if rank == 0:
+        model.save_model(out_directory, epoch, quiet=True)
+        save_progress(model, summary, out_directory)
     return out_directory

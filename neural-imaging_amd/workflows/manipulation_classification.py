@@ -111,8 +111,12 @@ class ManipulationClassification(object):
             self._parameters.extend(self.codec.parameters)
         self._step = 0
         self._nan_check = nan_check
+        # device-side NaN guard: _nan_flag is this step's flag (it gates the step's Adam updates), _nan_seen keeps every
+        # flag raised since the last check_nan() (nan_check='deferred' reads it once per epoch / bench run, not per step)
         self._nan_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._nan_seen = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._labels_cache = {}
+        self._lr_t_dev = None
         self._bucket = parallel.GradientBucket()
 
     # ------------------------------------------------------------------------------------------------------------
@@ -287,13 +291,26 @@ class ManipulationClassification(object):
             for k, (name, op) in enumerate(self._operations.items()):
                 ops.add(dY, op.backward(mctxs[k], dm[(k + 1) * b:(k + 2) * b]), out=dY)
             loss_nip, _ = self.nip.loss_and_grad(Y, target, grad_scale=float(lambda_nip), grad_out=dY, accumulate=True)
-            self.nip.backward(nctx, dY)
-            ops.nan_flag(self.nip._model.flat_grad, self._nan_flag)
-            self._bucket.launch(self.nip._model.flat_grad)
+            if world > 1 and hasattr(self.nip, 'decoder_grads'):
+                # two buckets: the decoder's gradients (its backward runs first) travel while the encoder backward
+                # computes; only the encoder's slice is exposed at the end of the step
+                dec, enc = self.nip.decoder_grads()
+                def decoder_done():
+                    ops.nan_flag(dec, self._nan_flag)
+                    self._bucket.launch(dec)
+                self.nip.backward(nctx, dY, on_decoder_done=decoder_done)
+                ops.nan_flag(enc, self._nan_flag)
+                self._bucket.launch(enc)
+            else:
+                self.nip.backward(nctx, dY)
+                ops.nan_flag(self.nip._model.flat_grad, self._nan_flag)
+                self._bucket.launch(self.nip._model.flat_grad)
         else:
             loss_nip, _ = self.nip._loss_fn(Y, target)
         parallel.all_reduce_flag(self._nan_flag)
+        torch.maximum(self._nan_seen, self._nan_flag, out=self._nan_seen)
         if self._nan_check == 'eager' and int(self._nan_flag.item()) != 0:       # host sync, like the reference
+            self._nan_seen.zero_()
             self._bucket.wait()
             raise RuntimeError('gradient NaNs in the workflow step')
         self._bucket.wait()
@@ -301,23 +318,26 @@ class ManipulationClassification(object):
         # ---- one shared Adam step (lr assigned every step, workflows/...:279)
         self._step += 1
         gscale = 1.0 / world
-        self.fan._model.adam(learning_rate, self._step, gscale, skip_flag=self._nan_flag)
+        rate = self._lr_t_dev              # None, or the device-resident rate of a captured step (graphs.CapturedStep)
+        self.fan._model.adam(learning_rate, self._step, gscale, skip_flag=self._nan_flag, lr_t_dev=rate)
         if train_nip:
-            self.nip._model.adam(learning_rate, self._step, gscale, skip_flag=self._nan_flag)
+            self.nip._model.adam(learning_rate, self._step, gscale, skip_flag=self._nan_flag, lr_t_dev=rate)
         if train_dcn:
-            self.codec._model.adam(learning_rate, self._step, gscale, skip_flag=self._nan_flag)
+            self.codec._model.adam(learning_rate, self._step, gscale, skip_flag=self._nan_flag, lr_t_dev=rate)
 
         dcn_value = np.nan
-        extra = 0.0
-        if loss_dcn is not None:
-            dcn_value = float(DeviceArray(loss_dcn[0])) + self.codec._h.entropy_weight * float(DeviceArray(loss_dcn[1]))
-            extra = float(lambda_dcn) * dcn_value
-        loss = _LazyLoss(loss_ce, loss_nip, float(lambda_nip) if 'nip' in self._trainable else 0.0, extra)
+        if loss_dcn is not None:           # codec.loss = l2 + w H, read from the device only when somebody looks at it
+            dcn_value = _LazySum(loss_dcn[0], loss_dcn[1], self.codec._h.entropy_weight)
+        loss = _LazyLoss(loss_ce, loss_nip, float(lambda_nip) if 'nip' in self._trainable else 0.0,
+                         dcn_value if loss_dcn is not None else None, float(lambda_dcn))
         return loss, {'ce': DeviceArray(loss_ce), 'nip': DeviceArray(loss_nip), 'dcn': dcn_value}
 
     def check_nan(self):
-        """Deferred NaN guard (nan_check='deferred'): raises if any step since the last check produced NaN grads."""
-        if int(self._nan_flag.item()) != 0:
+        """Deferred NaN guard (nan_check='deferred'): raises if any step since the last check produced NaN grads (those
+        steps' Adam updates were skipped on the device)."""
+        seen = int(self._nan_seen.item())
+        self._nan_seen.zero_()
+        if seen != 0:
             raise RuntimeError('gradient NaNs in the workflow step')
 
     # -- strings -------------------------------------------------------------------------------------------------
@@ -373,17 +393,34 @@ class _JpegManipulation(object):
         return self.codec.backward(ctx, dy)
 
 
-class _LazyLoss(DeviceArray):
-    """loss = ce + lambda_nip * nip, evaluated on the host only when somebody reads it (keeps the step asynchronous)."""
-    __slots__ = ('ce', 'nip', 'lam', 'extra')
+class _LazySum(DeviceArray):
+    """a + w * b of two device scalars, evaluated on the host only when somebody reads it."""
+    __slots__ = ('a', 'b', 'w')
 
-    def __init__(self, ce, nip, lam, extra=0.0):
+    def __init__(self, a, b, w):
+        self.t = a
+        self.a, self.b, self.w = a, b, float(w)
+
+    def numpy(self):
+        return np.asarray(float(self.a.detach().cpu().reshape(())) + self.w * float(self.b.detach().cpu().reshape(())))
+
+    def __float__(self):
+        return float(self.numpy())
+
+
+class _LazyLoss(DeviceArray):
+    """loss = ce + lambda_nip * nip [+ lambda_dcn * dcn], evaluated on the host only when somebody reads it (keeps the step
+    asynchronous and capturable)."""
+    __slots__ = ('ce', 'nip', 'lam', 'dcn', 'lam_dcn')
+
+    def __init__(self, ce, nip, lam, dcn=None, lam_dcn=0.0):
         self.t = ce
-        self.ce, self.nip, self.lam, self.extra = ce, nip, lam, extra
+        self.ce, self.nip, self.lam, self.dcn, self.lam_dcn = ce, nip, lam, dcn, lam_dcn
 
     def numpy(self):
         v = self.ce.detach().cpu().numpy().reshape(()) + np.float32(self.lam) * self.nip.detach().cpu().numpy().reshape(())
-        return np.asarray(v + np.float32(self.extra), dtype=np.float32)
+        extra = 0.0 if self.dcn is None else self.lam_dcn * float(self.dcn)
+        return np.asarray(v + np.float32(extra), dtype=np.float32)
 
     def __float__(self):
         return float(self.numpy())

@@ -192,6 +192,36 @@ def dcn_loss(x, y, ent, entropy_weight=250.0):
     return T.l2_loss(x - y) + entropy_weight * ent
 
 
+class DCNTrainer(object):
+    """DCN.training_step restated (models/compression.py:123-138): tape over l2_loss(x - y) + entropy_weight * H, Keras Adam
+    (default learning rate 1e-3 unless assigned), returns {'loss': sqrt(2 loss), 'ssim', 'entropy'}."""
+
+    def __init__(self, params, entropy_weight=250.0):
+        self.p, self.entropy_weight = params, entropy_weight
+        self._m = self._v = None
+        self._t, self.lr = 0, 1e-3
+
+    def training_step(self, x, learning_rate=None):
+        ps = list(self.p.values())
+        for q in ps:
+            q.requires_grad_(True)
+        y, ent, _ = dcn_forward(self.p, x)
+        loss = dcn_loss(x, y, ent, self.entropy_weight)
+        grads = torch.autograd.grad(loss, ps)
+        for q in ps:
+            q.requires_grad_(False)
+        if learning_rate is not None:
+            self.lr = learning_rate
+        if self._m is None:
+            self._m = [torch.zeros_like(q) for q in ps]
+            self._v = [torch.zeros_like(q) for q in ps]
+        self._t += 1
+        with torch.no_grad():
+            T.adam_step(ps, list(grads), self._m, self._v, self._t, self.lr)
+            ssim = float(T.ssim_tf(x, y.detach()).mean()) if min(x.shape[1], x.shape[2]) >= 11 else float('nan')
+        return {'loss': float(np.sqrt(2 * float(loss.detach()))), 'ssim': ssim, 'entropy': float(ent.detach())}
+
+
 def count_params(p):
     return int(sum(int(np.prod(v.shape)) for v in p.values()))
 

@@ -26,3 +26,48 @@ def dp_worker(rank, world, port, q):
     drawn = par.broadcast_floats([0.25 + rank, 7.0 * (rank + 1)])
     q.put((rank, float(flat[0]), int(flag[0]), shard.flatten().tolist(), drawn))
     torch.distributed.destroy_process_group()
+
+
+def make_channel(codec, dev, nan_check='deferred'):
+    """The channel of the data-parallel step test: UNet -> 3 manipulations -> (dJPEG | TwitterDCN) -> FAN at raw 32x32."""
+    from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
+    manips = ['sharpen:1', 'resample:50', 'gaussian:0.83']
+    if codec == 'dcn':
+        from neural_imaging_amd.models import compression
+        dcn = compression.TwitterDCN(patch_size=64, device=dev)
+        dist = {'downsampling': 'none', 'compression': 'dcn', 'compression_params': {'model': dcn}}
+        return ManipulationClassification('UNet', manipulations=manips, distribution=dist, trainable={'nip', 'dcn'},
+                                          raw_patch_size=32, device=dev, nan_check=nan_check), dict(lambda_nip=0.1, lambda_dcn=0.01)
+    dist = {'downsampling': 'none', 'compression': 'jpeg', 'compression_params': {'quality': 80, 'codec': 'soft'}}
+    return ManipulationClassification('UNet', manipulations=manips, distribution=dist, trainable={'nip'},
+                                      raw_patch_size=32, device=dev, nan_check=nan_check), dict(lambda_nip=0.1)
+
+
+def channel_state(wf):
+    """(flat gradients, flat parameters) of every trainable model, on the host."""
+    models = [wf.fan, wf.nip] + ([wf.codec] if wf.is_trainable('dcn') else [])
+    return ([m._model.flat_grad.detach().cpu().numpy().copy() for m in models],
+            [m._model.flat.detach().cpu().numpy().copy() for m in models])
+
+
+def dp_step_worker(rank, world, port, q, codec, raw, rgb):
+    """One data-parallel training step of the channel on this rank's contiguous shard of the global batch (every rank drives
+    cuda:0; gloo carries the collectives, so the test runs on a one-GPU box)."""
+    import torch
+    os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'RANK': str(rank),
+                       'WORLD_SIZE': str(world), 'LOCAL_RANK': '0'})
+    importlib.import_module('neural-imaging_amd')
+    from neural_imaging_amd import _lib, parallel as par
+    _lib.load()
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    assert par.init_from_env('gloo') == world
+    wf, kw = make_channel(codec, dev)
+    bx = par.shard_batch(torch.from_numpy(raw), rank, world)
+    by = par.shard_batch(torch.from_numpy(rgb), rank, world)
+    loss, parts = wf.training_step(bx, by, learning_rate=1e-4, **kw)
+    wf.check_nan()
+    grads, params = channel_state(wf)
+    q.put((rank, float(parts['ce']), float(parts['nip']), float(parts['dcn']), grads, params))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()

@@ -927,7 +927,9 @@ def test_training_harness_outputs(dev, tmp_path):
     prog = json.load(open(os.path.join(run_dir, 'training.json')))
     assert set(prog.keys()) >= {'summary', 'distribution', 'manipulations', 'nip', 'forensics', 'codec'}
     assert prog['manipulations'] == ['native', 'sharpen:1.0', 'gaussian:1.0']
-    assert len(prog['forensics']['performance']['accuracy']['validation']) == 2        # epochs 0 and 2
+    assert len(prog['forensics']['performance']['accuracy']['validation']) == 3        # epochs 0 and 2 + the final pass
+    conf = np.asarray(prog['forensics']['performance']['confusion'])
+    assert conf.shape == (3, 3) and np.allclose(conf.sum(axis=1), 1.0)                 # rows = true class, normalised
     assert len(prog['nip']['performance']['loss']['training']) == 3
     assert len(prog['nip']['performance']['psnr']['validation']) >= 1
     assert os.path.isfile(os.path.join(mdir, 'fan', 'fan.h5')) and os.path.isfile(os.path.join(mdir, 'unet', 'unet.h5'))
@@ -1016,3 +1018,107 @@ def test_dcn_pretraining_harness(dev, tmp_path, feed):
     for a, b_ in zip(dcn.parameters, restored.parameters):
         assert torch.equal(a, b_)
 
+
+
+@pytest.mark.parametrize('codec', ['jpeg', 'dcn'])
+def test_data_parallel_step_equals_global_batch(dev, codec):
+    """two ranks (gloo, both on cuda:0) each run training_step on one half of a global batch; the all-reduced
+    gradients / world, the losses and the parameters after the shared Adam step equal the single-rank step on the whole
+    batch (float32 mode).  Covers the mean-loss 1/world scaling, the un-divided l2_loss of the learned codec, its batch-global
+    entropy histogram (all-reduced in the forward pass), the decoder / encoder gradient buckets and the NaN flag."""
+    import socket
+    import torch.multiprocessing as mp
+    from dp_worker import channel_state, dp_step_worker, make_channel
+    from neural_imaging_amd import ops
+    ops.set_compute('f32')
+    rgb = natural_images(4, 64, 64, seed=21)
+    raw = bayer_from_rgb(rgb)
+    wf, kw = make_channel(codec, dev)
+    loss, parts = wf.training_step(raw, rgb, learning_rate=1e-4, **kw)
+    wf.check_nan()
+    g_ref, p_ref = channel_state(wf)
+    ref = (float(parts['ce']), float(parts['nip']), float(parts['dcn']))
+    del wf
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=dp_step_worker, args=(r, 2, port, q, codec, raw, rgb)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # CE and the NIP loss are means over the rank's shard: their rank average is the global-batch value
+    assert abs(0.5 * (res[0][1] + res[1][1]) - ref[0]) < 1e-5 * max(1.0, abs(ref[0]))
+    assert abs(0.5 * (res[0][2] + res[1][2]) - ref[1]) < 1e-5 * max(1.0, abs(ref[1]))
+    for k in range(len(g_ref)):
+        scale = np.abs(g_ref[k]).max()
+        for r in res:
+            assert np.abs(r[4][k] / 2.0 - g_ref[k]).max() <= 1e-5 * scale + 1e-12, ('gradients', k, r[0])
+            assert np.abs(r[5][k] - p_ref[k]).max() <= 2e-6, ('parameters after Adam', k, r[0])
+        assert np.array_equal(res[0][4][k], res[1][4][k])          # both ranks hold the same reduced buffer
+
+
+def test_captured_step_replays_the_eager_step(dev):
+    """graphs.CapturedStep: the hipGraph replay of the training step walks the same weights trajectory as eager launches
+    (including Keras Adam's per-step bias correction, which the replay reads from device memory)."""
+    from neural_imaging_amd import graphs, ops
+    from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
+    ops.set_compute('f32')
+    dist = {'downsampling': 'none', 'compression': 'jpeg', 'compression_params': {'quality': 80, 'codec': 'soft'}}
+    rgb = natural_images(2, 64, 64, seed=31)
+    raw = bayer_from_rgb(rgb)
+    bx, by = torch.from_numpy(raw).to(dev), torch.from_numpy(rgb).to(dev)
+    finals = []
+    for captured in (False, True):
+        wf = ManipulationClassification('UNet', distribution=dist, trainable={'nip'}, raw_patch_size=32, device=dev,
+                                        nan_check='deferred')
+        if captured:
+            runner = graphs.CapturedStep(wf, bx, by, learning_rate=1e-3, lambda_nip=0.1, warmup=2)
+            for _ in range(3):
+                loss, parts = runner.step()
+            assert wf._step == 5
+        else:
+            for _ in range(5):
+                loss, parts = wf.training_step(bx, by, lambda_nip=0.1, learning_rate=1e-3)
+        wf.check_nan()
+        finals.append((float(loss), wf.fan._model.flat.cpu().numpy().copy(), wf.nip._model.flat.cpu().numpy().copy()))
+    assert abs(finals[0][0] - finals[1][0]) <= 1e-5 * abs(finals[0][0])
+    assert np.abs(finals[0][1] - finals[1][1]).max() <= 1e-6
+    assert np.abs(finals[0][2] - finals[1][2]).max() <= 1e-6
+
+
+def test_validate_fan_on_device(dev):
+    """validation.validate_fan (device-side decisions + confusion counts, one read-back) against the reference's host loop
+    (training/validation.py:163-202) restated with numpy on the same decisions."""
+    from neural_imaging_amd import ops
+    from neural_imaging_amd.training import manipulation as tm, validation
+    from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
+    ops.set_compute('f32')
+    dist = {'downsampling': 'none', 'compression': 'jpeg', 'compression_params': {'quality': 80, 'codec': 'soft'}}
+    wf = ManipulationClassification('UNet', manipulations=['sharpen:1', 'gaussian:1'], distribution=dist, trainable={'nip'},
+                                    raw_patch_size=16, device=dev)
+    data = tm.SyntheticDataset(4, 23, patch_size=16)
+    acc, conf, labels = validation.validate_fan(wf, data, get_labels=True)
+    size, k = 10, wf.n_classes
+    ref_conf, ref_acc, ref_labels = np.zeros((k, k)), [], []
+    for b in range(23 // size):
+        bx = data.next_validation_batch(b, size)[0]
+        truth = wf._batch_labels(size)
+        pred = wf.run_workflow_to_decisions(bx)
+        ref_labels += list(pred)
+        for c in range(k):
+            for c_ in range(k):
+                ref_conf[c, c_] += np.sum((truth == c) * (pred == c_))
+        ref_acc.append(np.mean(pred == truth))
+    assert labels == [int(v) for v in ref_labels]
+    assert np.array_equal(conf, ref_conf / 20) and abs(acc - np.mean(ref_acc)) < 1e-12
+    probs = torch.tensor([[0.2, 0.5, 0.5], [0.9, 0.05, 0.05], [0.1, 0.1, 0.8]], device=dev)
+    lab = torch.tensor([1, 0, 0], dtype=torch.int32, device=dev)
+    cm = torch.zeros((3, 3), dtype=torch.int64, device=dev)
+    pred = ops.confusion_accumulate(probs, lab, cm)
+    assert pred.tolist() == [1, 0, 2] and cm.tolist() == [[1, 0, 1], [0, 1, 0], [0, 0, 0]]      # first maximum wins
