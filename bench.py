@@ -28,8 +28,9 @@ Extra objects on the line:
                  launch / average launch time against the dense MFMA peak of the compute dtype; traffic = HBM bytes per launch
                  from the committed PMC passes (profiles/*pmc_dominant_kernel.json: 2 x FETCH_SIZE + WRITE_SIZE, separate
                  --pmc runs), scaled to this launch's image count
-  cpu_baseline - the oracle's CPU port (torch float32, all host cores) of the SAME step on a bounded sample: 2 warm-up steps,
-                 median of >= 5 timed steps
+  cpu_baseline - the oracle's CPU port (torch float32, 32 host threads - more only adds barrier overhead at these layer
+                 sizes; the host's thread count is reported) of the SAME step on a bounded sample: 2 warm-up steps, median of
+                 >= 5 timed steps
 --dtype bf16 (default) = throughput mode: bf16 MFMA operands, float32 accumulation, float32 master weights / optimizer.
 --dtype f32 = parity mode (exact float32 MFMA; the mode the 1e-4 parity tests run in).  At N = 1 the default c4 run also
 times parity-mode steps (top-level f32_mode_* keys) and trains two copies of the channel (same initial weights, same batches)
@@ -253,6 +254,9 @@ def cpu_baseline_worker(workload, raw_patch, budget_s):
     from oracle import nets as onets, workflow as owf
     from util import natural_images
     model, total, usable = _host_cpu()
+    # 32 threads: the box offers 256 hardware threads, but the layers of a B = 2 step are far too small for them - with
+    # torch.set_num_threads(256) one step did not finish in 240 s (oneDNN barrier overhead), with 32 it takes ~0.5 s
+    usable = max(1, min(usable, 32))
     torch.set_num_threads(usable)
     b = 2
     if workload == 'c3':
@@ -280,18 +284,19 @@ def cpu_baseline_worker(workload, raw_patch, budget_s):
     med = float(np.median(times))
     return {'value': b / med, 'unit': 'patches/s', 'cores': usable, 'kind': 'port', 'host_cores': total, 'cpu_model': model,
             'sample': 'median of {} step(s) after 2 warm-ups, B={} {} patches, torch-CPU float32 restatement of the same step '
-                      '(restated-reference CPU baseline, TF2 unavailable), {} threads'.format(
-                          len(times), b, 'RGB 256x256' if workload == 'c3' else 'raw {0}x{0}x4'.format(raw_patch), usable)}
+                      '(restated-reference CPU baseline, TF2 unavailable), {} threads of {} host threads'.format(
+                          len(times), b, 'RGB 256x256' if workload == 'c3' else 'raw {0}x{0}x4'.format(raw_patch), usable, total)}
 
 
-def cpu_baseline(workload, raw_patch, budget_s=20.0, hard_timeout_s=240):
+def cpu_baseline(workload, raw_patch, budget_s=20.0, hard_timeout_s=150):
     """Run the CPU leg in a child process so a badly provisioned host can never stall the GPU measurement."""
     _, total, usable = _host_cpu()
-    fail = {'value': None, 'unit': 'patches/s', 'cores': usable, 'kind': 'port', 'host_cores': total}
+    fail = {'value': None, 'unit': 'patches/s', 'cores': min(usable, 32), 'kind': 'port', 'host_cores': total}
     try:
         out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', '--workload', workload,
                               '--raw-patch', str(raw_patch), '--cpu-budget', str(budget_s)], capture_output=True, text=True,
-                             timeout=hard_timeout_s, env=dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES=''))
+                             timeout=hard_timeout_s, env=dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='',
+                                                           OMP_NUM_THREADS=str(min(usable, 32))))
         for ln in reversed(out.stdout.strip().splitlines()):
             if ln.startswith('{'):
                 return json.loads(ln)

@@ -266,6 +266,27 @@ int nimg_isp_residual_bwd(const float* dy, const float* f, const float* alpha, f
 /* Dropout of the FAN's hidden Dense layers at training time (models/forensics.py:88), forward and backward alike:
  * y = keep[i] ? x[i] * scale : 0, keep = the Bernoulli(1 - rate) mask bytes, scale = 1 / (1 - rate). */
 int nimg_mask_scale(const float* x, const uint8_t* keep, float* y, long count, float scale, void* stream);
+/* ------------------------------------------------------------------------------------------------------------------
+ * FAN front end (csrc/frontend.hip): ConstrainedConv2D, models/layers.py:56-57 (tf.pad SYMMETRIC + VALID conv2d) and the
+ * first FAN convolution, models/forensics.py:69-70, as row-band kernels (float32 VALU stencil / bf16 MFMA).
+ *
+ * nimg_cconv3: 5x5 convolution 3 -> 3, same-size output, no bias: out[y][x][o] = sum in_pad[y+ky-2][x+kx-2][i] w[ky][kx][i][o]
+ * with pad_mode 0 (zeros) | 1 (SYMMETRIC).  w = the 225 floats of a (5,5,3,3) HWIO kernel in device memory.
+ *   forward:        w = the normalised filter (nimg_constrained_kernel_fwd), pad_mode 1
+ *   input gradient: w = nimg_conv_flip_weights(normalised filter), pad_mode 0, then nimg_cconv3_dgrad_border adds what the
+ *                   SYMMETRIC pad folds back onto the two outermost rows / columns (needs h, w >= 4).
+ * out_f32 (n,h,w,3) float32 and / or out_c4 (n,h,w,4) bf16 = {o0, o1, o2, 1.0} (the 8-byte pixel of the throughput-mode
+ * conv1 kernels; the constant channel carries the bias gradient through their weight-gradient GEMM); at least one. */
+int nimg_cconv3(const float* in, const float* w, float* out_f32, void* out_c4, int n, int h, int w_, int pad_mode,
+                void* stream);
+int nimg_cconv3_dgrad_border(const float* dc, const float* nf, float* dx, int n, int h, int w_, void* stream);
+/* First FAN convolution in throughput mode, models/forensics.py:69-70: Conv2D(32, 5x5, SAME) + bias + LeakyReLU(alpha) +
+ * MaxPool2D(2) in one pass over the bf16 {c0,c1,c2,1} pixels of nimg_cconv3 (bf16 MFMA operands, float32 accumulation).
+ * c4 (n,h,w,4) bf16; w (5,5,3,32) float32 HWIO; bias (32) or NULL; pooled (n,h/2,w/2,32) bf16 (out_bf16 = 1) or float32;
+ * pool_idx (n,h/2,w/2,32) uint8 arg-max position inside the window (row-major, first maximum wins) or NULL.
+ * h, w even; 0 < alpha <= 1 (1 = no activation). */
+int nimg_conv1_pool_fwd_c4(const void* c4, const float* w, const float* bias, void* pooled, unsigned char* pool_idx, int n,
+                           int h, int w_, float alpha, int out_bf16, void* stream);
 /* Classifier decisions + confusion matrix on the device - replaces the host loop of validate_fan,
  * training/validation.py:163-202 (np.argmax per batch, conf[c, c_] += sum((y == c) * (pred == c_)), one D2H per batch).
  * probs (n,k) float32; labels (n) int32 or NULL; pred (n) int32 or NULL: first arg-max of each row (numpy.argmax);

@@ -94,6 +94,9 @@ PROTOTYPES = {
     'nimg_patch_select': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P, P]),
     'nimg_patch_gather': (c_int, [P, P, c_int, c_int, c_int, P, P, c_int, c_int, P, P, P]),
     'nimg_mask_scale': (c_int, [P, P, P, c_long, c_float, P]),
+    'nimg_cconv3': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    'nimg_cconv3_dgrad_border': (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    'nimg_conv1_pool_fwd_c4': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_float, c_int, P]),
     'nimg_confusion_accumulate': (c_int, [P, P, P, P, c_int, c_int, P]),
     'nimg_ssim_planes_workspace_bytes': (c_size_t, [c_int, c_int]),
     'nimg_ssim_planes': (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, P, P, P, P, c_int, P, c_size_t, P]),

@@ -1,0 +1,524 @@
+// FAN front end (models/forensics.py:62-70): ConstrainedConv2D 5x5 3->3 (models/layers.py:36-57) and the first
+// convolution 5x5 3->32 + LeakyReLU + MaxPool2D, forward and backward.  320 images of 256x256 per training step make these
+// the widest tensors of the whole channel (21 M pixels), while they hold under 3 % of its FLOPs: every pass here is bound by
+// HBM bytes or by plain VALU issue, not by the matrix core.  Decomposition ("front end"):
+//
+//   cconv_kernel         ConstrainedConv2D forward (SYMMETRIC pad) AND its input gradient (zero pad, flipped / transposed
+//                        filter): float32 VALU stencil, 4 px x 3 channels per thread, SGPR weights, LDS row band
+//   cdgrad_border_kernel the terms of the input gradient that the SYMMETRIC pad folds back onto the 2-pixel image border
+//
+// This file is compiled with -fno-slp-vectorize (csrc/Makefile): the stencil wants v_fmac_f32 v, s, v; hipcc's SLP pass
+// otherwise builds v_pk_fma_f32 pairs with a v_mov per operand (gfx950's VALU already retires one f32 FMA per lane and clock,
+// so the packed form buys nothing and the moves cost issue slots).
+#include "common.h"
+
+namespace {
+
+using namespace nimg;
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+struct CConvParams {
+    const float* in;      // (N,H,W,3)
+    const float* w;       // [5][5][3][3] = [ky][kx][ci][co], 225 floats (wave-uniform: read through the scalar cache)
+    float* out_f32;       // optional (N,H,W,3)
+    uint2* out_c4;        // optional (N,H,W) x {bf16 c0, c1, c2, 1.0}: the 8-byte pixel the throughput-mode conv1 kernels read
+    int N, H, W, pad_mode, tiles_y, tiles_x;
+};
+
+// Workgroup = 256 threads = TPR threads along a row x (256 / TPR) thread rows; a thread owns 4 adjacent pixels x RPT rows x 3
+// output channels.  Tile = (256 / TPR * RPT) rows x (4 TPR) columns, staged with its 2-pixel halo as float32 [row][pixel][3];
+// a thread's 8-pixel input window of one tile row is 6 aligned ds_read_b128 (lane stride 48 B: the sixteen lanes of every
+// b128 group cover the 64 banks once), which feed 180 FMAs per kernel row with the row's 45 weights in SGPRs.
+template <int TPR, int RPT>
+__global__ __launch_bounds__(256) void cconv_kernel(const float* __restrict__ p_in, const float* __restrict__ p_w,
+                                                    float* __restrict__ p_out_f32, uint2* __restrict__ p_out_c4,
+                                                    const CConvParams p) {
+    constexpr int TW = 4 * TPR, TROWS = 256 / TPR, TR = TROWS * RPT, HR = TR + 4, HC = TW + 4;
+    constexpr int RS = (HC * 3 + 3) / 4 * 4;                 // floats per tile row, 16-byte multiple
+    constexpr int NPIX = HR * HC, PPT = (NPIX + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) float tile[];      // [HR][RS]
+    const int tid = threadIdx.x, tx = tid % TPR, ty = tid / TPR;
+    const int tiles = p.tiles_y * p.tiles_x;
+    const int total = p.N * tiles;                     // < 2^31 / (12 * 32): the entry point bounds the batch
+
+    // Staging.  Halo pixels travel as ONE 12-byte buffer load each; zero-pad pixels and everything outside the tensor are
+    // offsets beyond num_records, which the hardware answers with zeros (a predicated flat load costs hipcc a saveexec /
+    // branch / zero-fill scaffold per pixel).  A thread owns one tile COLUMN (its x mapping is resolved once per tile) and
+    // walks down the rows (row mapping = a handful of scalar-ish selects), so a pixel costs one add + one load.  The few
+    // columns beyond the thread grid (HC - NCOLT) are one extra pixel for the first threads.  Tensor < 2 GB (entry point).
+    typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int NCOLT = HC <= 128 ? 128 : 256, RG = 256 / NCOLT, RPTS = (HR + RG - 1) / RG;
+    constexpr int EXC = HC > NCOLT ? HC - NCOLT : 0, EXN = EXC * HR;
+    static_assert(EXN <= 256, "extra halo columns: one pixel per thread");
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p_in), 0,
+                                                                         (int)((long)p.N * p.H * p.W * 12), 0x00020000);
+    const int sc = tid % NCOLT, sr = tid / NCOLT;                    // staging column / first row of this thread
+    const int er = EXC ? tid / (EXC ? EXC : 1) : 0, ec = EXC ? NCOLT + tid % (EXC ? EXC : 1) : 0;
+    u32x3 pre[RPTS], pre_x;
+    auto byte_x = [&](int gx) {
+        const bool ok = map_coord(gx, p.W, p.pad_mode);
+        return ok ? (unsigned)(gx * 12) : OOB;
+    };
+    auto fetch = [&](int t) {
+        const int n = t / tiles, tl = t % tiles;
+        const int y0 = (tl / p.tiles_x) * TR, x0 = (tl % p.tiles_x) * TW;
+        const unsigned xb = sc < HC ? byte_x(x0 - 2 + sc) : OOB;
+#pragma unroll
+        for (int q = 0; q < RPTS; ++q) {
+            int gy = y0 - 2 + q * RG + sr;
+            const bool ok = map_coord(gy, p.H, p.pad_mode) & (q * RG + sr < HR);
+            const unsigned rowb = (unsigned)((n * p.H + gy) * p.W * 12);
+            pre[q] = __builtin_amdgcn_raw_buffer_load_b96(rin, (rowb + xb) | (ok ? 0u : OOB), 0, 0);   // rowb < 2^31: an OOB xb stays OOB
+        }
+        if constexpr (EXN > 0) {
+            int gy = y0 - 2 + er;
+            const bool ok = map_coord(gy, p.H, p.pad_mode) & (tid < EXN);
+            const unsigned rowb = (unsigned)((n * p.H + gy) * p.W * 12);
+            pre_x = __builtin_amdgcn_raw_buffer_load_b96(rin, (rowb + byte_x(x0 - 2 + ec)) | (ok ? 0u : OOB), 0, 0);
+        }
+    };
+    const int first = xcd_order(blockIdx.x);
+    if (first < total) fetch(first);
+    for (int t = first; t < total; t += gridDim.x) {
+        const int n = t / tiles, tl = t % tiles;
+        const int y0 = (tl / p.tiles_x) * TR, x0 = (tl % p.tiles_x) * TW;
+        __syncthreads();
+        if (sc < HC) {
+#pragma unroll
+            for (int q = 0; q < RPTS; ++q) {
+                if (q * RG + sr < HR) {
+                    float* d = tile + (q * RG + sr) * RS + sc * 3;
+                    d[0] = __uint_as_float(pre[q][0]); d[1] = __uint_as_float(pre[q][1]); d[2] = __uint_as_float(pre[q][2]);
+                }
+            }
+        }
+        if constexpr (EXN > 0) {
+            if (tid < EXN) {
+                float* d = tile + er * RS + ec * 3;
+                d[0] = __uint_as_float(pre_x[0]); d[1] = __uint_as_float(pre_x[1]); d[2] = __uint_as_float(pre_x[2]);
+            }
+        }
+        __syncthreads();
+        if (t + (int)gridDim.x < total) fetch(t + gridDim.x);
+
+        float acc[RPT][4][3];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[r][j][0] = acc[r][j][1] = acc[r][j][2] = 0.f;
+#pragma unroll 1
+        for (int ky = 0; ky < 5; ++ky) {
+            const float* wk = p_w + ky * 45;                    // [kx][ci][co]: 45 wave-uniform values -> SGPRs
+            float wr[45];
+#pragma unroll
+            for (int i = 0; i < 45; ++i) wr[i] = wk[i];
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                const float4* row = reinterpret_cast<const float4*>(tile + (ty * RPT + r + ky) * RS + tx * 12);
+                float v[24];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const float4 q4 = row[i];
+                    v[4 * i] = q4.x; v[4 * i + 1] = q4.y; v[4 * i + 2] = q4.z; v[4 * i + 3] = q4.w;
+                }
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx)
+#pragma unroll
+                    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float xv = v[(j + kx) * 3 + ci];
+                            acc[r][j][0] = fmaf(xv, wr[(kx * 3 + ci) * 3 + 0], acc[r][j][0]);
+                            acc[r][j][1] = fmaf(xv, wr[(kx * 3 + ci) * 3 + 1], acc[r][j][1]);
+                            acc[r][j][2] = fmaf(xv, wr[(kx * 3 + ci) * 3 + 2], acc[r][j][2]);
+                        }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int oy = y0 + ty * RPT + r, ox = x0 + tx * 4;
+            if (oy >= p.H || ox >= p.W) continue;
+            const long o = ((long)n * p.H + oy) * p.W + ox;
+            if (ox + 3 < p.W && (p.W & 3) == 0) {               // whole group inside the row, 16-byte aligned
+                if (p_out_f32) {
+                    float4* d = reinterpret_cast<float4*>(p_out_f32 + o * 3);
+                    d[0] = make_float4(acc[r][0][0], acc[r][0][1], acc[r][0][2], acc[r][1][0]);
+                    d[1] = make_float4(acc[r][1][1], acc[r][1][2], acc[r][2][0], acc[r][2][1]);
+                    d[2] = make_float4(acc[r][2][2], acc[r][3][0], acc[r][3][1], acc[r][3][2]);
+                }
+                if (p_out_c4) {
+                    bf16x4 c[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        c[j][0] = (__bf16)acc[r][j][0]; c[j][1] = (__bf16)acc[r][j][1]; c[j][2] = (__bf16)acc[r][j][2];
+                        c[j][3] = (__bf16)1.0f;
+                    }
+                    uint4* d = reinterpret_cast<uint4*>(p_out_c4 + o);
+                    const uint2 a0 = *reinterpret_cast<const uint2*>(&c[0]), a1 = *reinterpret_cast<const uint2*>(&c[1]);
+                    const uint2 a2 = *reinterpret_cast<const uint2*>(&c[2]), a3 = *reinterpret_cast<const uint2*>(&c[3]);
+                    d[0] = make_uint4(a0.x, a0.y, a1.x, a1.y);
+                    d[1] = make_uint4(a2.x, a2.y, a3.x, a3.y);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (ox + j >= p.W) break;
+                    if (p_out_f32) {
+                        p_out_f32[(o + j) * 3] = acc[r][j][0];
+                        p_out_f32[(o + j) * 3 + 1] = acc[r][j][1];
+                        p_out_f32[(o + j) * 3 + 2] = acc[r][j][2];
+                    }
+                    if (p_out_c4) {
+                        bf16x4 c;
+                        c[0] = (__bf16)acc[r][j][0]; c[1] = (__bf16)acc[r][j][1]; c[2] = (__bf16)acc[r][j][2];
+                        c[3] = (__bf16)1.0f;
+                        p_out_c4[o + j] = *reinterpret_cast<const uint2*>(&c);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Input gradient of the SYMMETRIC-padded filter, border part.  With xp = pad(x): dxp[u][v][i] = sum_{ky,kx,o}
+// dc[u-ky][v-kx][o] nf[ky][kx][i][o] on the (H+4) x (W+4) padded domain, and dx[y][x] = sum of dxp over every padded position
+// that mirrors onto (y, x): (y+2, x+2) itself - that term is cconv_kernel with the flipped filter and zero padding - plus, on
+// the two outermost rows / columns, the mirror images u in {1-y, 2H+1-y}, v in {1-x, 2W+1-x}.  One thread per border pixel
+// adds those extra terms to dx (4(H+W)-16 pixels per image: the work is negligible, the reads come from L2).
+__global__ void cdgrad_border_kernel(const float* __restrict__ dc, const float* __restrict__ nf, float* __restrict__ dx, int N,
+                                     int H, int W) {
+    const int per = 4 * W + 4 * (H - 4);                        // 2 top + 2 bottom rows, then 2 + 2 columns of the other rows
+    const long total = (long)N * per;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(t / per), b = (int)(t % per);
+        int y, x;
+        if (b < 4 * W) {
+            const int r = b / W;
+            y = r < 2 ? r : H - 4 + r;
+            x = b % W;
+        } else {
+            const int c = (b - 4 * W) & 3;
+            y = 2 + (b - 4 * W) / 4;
+            x = c < 2 ? c : W - 4 + c;
+        }
+        int us[3], vs[3], nu = 0, nv = 0;
+        us[nu++] = y + 2;
+        if (y < 2) us[nu++] = 1 - y;
+        if (y >= H - 2) us[nu++] = 2 * H + 1 - y;
+        vs[nv++] = x + 2;
+        if (x < 2) vs[nv++] = 1 - x;
+        if (x >= W - 2) vs[nv++] = 2 * W + 1 - x;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int iu = 0; iu < nu; ++iu)
+            for (int iv = 0; iv < nv; ++iv) {
+                if (iu == 0 && iv == 0) continue;               // the direct term belongs to the main kernel
+                const int u = us[iu], v = vs[iv];
+                for (int ky = 0; ky < 5; ++ky) {
+                    const int py = u - ky;
+                    if (py < 0 || py >= H) continue;
+                    for (int kx = 0; kx < 5; ++kx) {
+                        const int px = v - kx;
+                        if (px < 0 || px >= W) continue;
+                        const float* g = dc + (((long)n * H + py) * W + px) * 3;
+                        const float* wv = nf + (ky * 5 + kx) * 9;            // [i][o]
+#pragma unroll
+                        for (int o = 0; o < 3; ++o) {
+                            a0 = fmaf(g[o], wv[o], a0);
+                            a1 = fmaf(g[o], wv[3 + o], a1);
+                            a2 = fmaf(g[o], wv[6 + o], a2);
+                        }
+                    }
+                }
+            }
+        float* d = dx + (((long)n * H + y) * W + x) * 3;
+        d[0] += a0; d[1] += a1; d[2] += a2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// First FAN convolution, throughput mode: 5x5, 3 -> 32, SAME (zeros), + bias + LeakyReLU + MaxPool2D(2) in one pass
+// (models/forensics.py:69-70) over the 8-byte bf16 pixels {c0, c1, c2, 1} written by cconv_kernel.
+//
+// GEMM view per output row: D[cout 32][pixel 32] += A[cout][k] B[k][pixel], v_mfma_f32_32x32x16_bf16, K = 7 steps of 16 =
+// 28 (tap, 4 channel) slots for the 25 taps (the 4th channel and the 3 spare slots meet zero weights).  The weights (A) stay
+// in 28 VGPRs for the whole kernel; a pixel's B operand is two 8-byte LDS reads of whole pixels at immediate tap offsets -
+// no gather, no conversion, no packing.  Slot order: k-steps 0..4 = kernel rows (lane half h takes kx = 2h, 2h+1), k-step 5
+// = column kx = 4 of rows 2h, 2h+1, k-step 6 = tap (4,4): inside a k-step the two lane halves differ by ONE constant LDS
+// offset, so three per-lane base addresses serve every read.
+// Output layout D^T (couts along the accumulator registers, pixels along the lanes): the 2x2 pool is one DPP exchange with
+// the neighbouring lane plus the second output row's accumulator - no LDS turn-around; v_permlane32_swap then leaves every even
+// lane with 16 consecutive channels of one pooled pixel = 16-byte stores (pooled bf16 / float32 and the arg-max bytes).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float dpp_swap1(float v) {           // value of lane ^ 1 (quad_perm [1,0,3,2])
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 r;
+    r[0] = (__bf16)a; r[1] = (__bf16)b;
+    return *reinterpret_cast<const unsigned*>(&r);
+}
+
+// tap (ky, kx) of K slot (k-step ks, lane half h, j in {0,1}); ky < 0: spare slot (zero weight)
+__device__ __forceinline__ void conv1_slot(int ks, int h, int j, int& ky, int& kx) {
+    if (ks < 5) { ky = ks; kx = 2 * h + j; }
+    else if (ks == 5) { ky = 2 * h + j; kx = 4; }
+    else { ky = (h == 0 && j == 0) ? 4 : -1; kx = 4; }
+}
+
+template <int TWD, bool OUT_BF16>
+__global__ __launch_bounds__(256) void conv1_pool_fwd_kernel(const void* __restrict__ c4, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, void* __restrict__ pooled,
+                                                             unsigned char* __restrict__ pidx, int N, int H, int W,
+                                                             float alpha, int tiles_y, int tiles_x) {
+    constexpr int TRD = 8, HR = TRD + 4, HC = TWD + 4, NPC = HC / 2;            // tile rows / halo rows / halo cols / pixel pairs
+    constexpr int PT = NPC <= 64 ? 64 : 128, RG = 256 / PT, RPTS = (HR + RG - 1) / RG;
+    constexpr int EXC = NPC > PT ? NPC - PT : 0, EXN = EXC * HR;
+    constexpr int UC = TWD / 32, UNITS = (TRD / 2) * UC;
+    constexpr unsigned OOB = 0x80000000u;
+    static_assert(EXN <= 256 && HC % 2 == 0, "staging layout");
+    __shared__ __attribute__((aligned(16))) uint4 tile[HR * NPC];                 // [row][pixel pair]: 8 B per pixel
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, nl = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles = tiles_y * tiles_x, total = N * tiles;
+
+    // A operand: this lane's cout m = nl, K values of the lane half, for the 7 k-steps
+    bf16x8 wa[7];
+#pragma unroll
+    for (int ks = 0; ks < 7; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int ky, kx;
+            conv1_slot(ks, h, j, ky, kx);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                wa[ks][4 * j + c] = (__bf16)((ky >= 0 && c < 3) ? w[((ky * 5 + kx) * 3 + c) * 32 + nl] : 0.f);
+        }
+    float br[16];                                     // bias of the 16 couts this lane's accumulator registers hold
+#pragma unroll
+    for (int r = 0; r < 16; ++r) br[r] = bias ? bias[(r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
+
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(c4), 0, (int)((long)N * H * W * 8),
+                                                                         0x00020000);
+    const int sp = tid % PT, sr = tid / PT;           // staging: pixel-pair column / first row of this thread
+    const int er = EXC ? tid / (EXC ? EXC : 1) : 0, ep = EXC ? PT + tid % (EXC ? EXC : 1) : 0;
+    u32x4 pre[RPTS], pre_x;
+    auto fetch = [&](int t) {
+        const int n = t / tiles, tl = t % tiles;
+        const int y0 = (tl / tiles_x) * TRD, x0 = (tl % tiles_x) * TWD;
+        const int gx = x0 - 2 + 2 * sp;               // W and x0 are even: a pair is inside or outside as a whole
+        const unsigned xb = (sp < NPC && (unsigned)gx < (unsigned)W) ? (unsigned)(gx * 8) : OOB;
+#pragma unroll
+        for (int q = 0; q < RPTS; ++q) {
+            const int gy = y0 - 2 + q * RG + sr;
+            const bool ok = ((unsigned)gy < (unsigned)H) & (q * RG + sr < HR);
+            pre[q] = __builtin_amdgcn_raw_buffer_load_b128(rin, ((unsigned)((n * H + gy) * W * 8) + xb) | (ok ? 0u : OOB), 0, 0);
+        }
+        if constexpr (EXN > 0) {
+            const int gy = y0 - 2 + er, gx2 = x0 - 2 + 2 * ep;
+            const bool ok = ((unsigned)gy < (unsigned)H) & ((unsigned)gx2 < (unsigned)W) & (tid < EXN);
+            pre_x = __builtin_amdgcn_raw_buffer_load_b128(rin, ok ? (unsigned)(((n * H + gy) * W + gx2) * 8) : OOB, 0, 0);
+        }
+    };
+    const int first = xcd_order(blockIdx.x);
+    if (first < total) fetch(first);
+    const int Hp = H >> 1, Wp = W >> 1;
+    for (int t = first; t < total; t += gridDim.x) {
+        const int n = t / tiles, tl = t % tiles;
+        const int y0 = (tl / tiles_x) * TRD, x0 = (tl % tiles_x) * TWD;
+        __syncthreads();
+        if (sp < NPC) {
+#pragma unroll
+            for (int q = 0; q < RPTS; ++q)
+                if (q * RG + sr < HR) tile[(q * RG + sr) * NPC + sp] = *reinterpret_cast<const uint4*>(&pre[q]);
+        }
+        if constexpr (EXN > 0) {
+            if (tid < EXN) tile[er * NPC + ep] = *reinterpret_cast<const uint4*>(&pre_x);
+        }
+        __syncthreads();
+        if (t + (int)gridDim.x < total) fetch(t + gridDim.x);
+
+        const unsigned char* tb = reinterpret_cast<const unsigned char*>(tile);
+        for (int u = wave; u < UNITS; u += 4) {
+            const int ur = u / UC, uc = u % UC;
+            // pixel (row 2ur [+1], column 32uc + nl) tap (ky, kx) sits at tile[(2ur [+1] + ky)][32uc + nl + kx]
+            const int a0 = ((2 * ur) * HC + 32 * uc + nl) * 8;
+            const int baseA = a0 + h * 16, baseB = a0 + h * (2 * HC * 8);
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = br[r];
+#pragma unroll
+            for (int ks = 0; ks < 7; ++ks) {
+                int o0, o1, base;
+                if (ks < 5) { base = baseA; o0 = (ks * HC) * 8; o1 = o0 + 8; }
+                else if (ks == 5) { base = baseB; o0 = 4 * 8; o1 = (HC + 4) * 8; }
+                else { base = a0; o0 = o1 = (4 * HC + 4) * 8; }
+                u32x4 b0, b1;
+                const u32x2 p00 = *reinterpret_cast<const u32x2*>(tb + base + o0);
+                const u32x2 p01 = *reinterpret_cast<const u32x2*>(tb + base + o1);
+                const u32x2 p10 = *reinterpret_cast<const u32x2*>(tb + base + o0 + HC * 8);
+                const u32x2 p11 = *reinterpret_cast<const u32x2*>(tb + base + o1 + HC * 8);
+                b0[0] = p00[0]; b0[1] = p00[1]; b0[2] = p01[0]; b0[3] = p01[1];
+                b1[0] = p10[0]; b1[1] = p10[1]; b1[2] = p11[0]; b1[3] = p11[1];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks], *reinterpret_cast<const bf16x8*>(&b0), acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks], *reinterpret_cast<const bf16x8*>(&b1), acc1, 0, 0, 0);
+            }
+            // bias is in the accumulator already; LeakyReLU, then the 2x2 window = {own, lane^1} x {row 0, row 1}: the even lane
+            // of a pair sees it in window order (first maximum wins, like nimg_maxpool2_fwd) and keeps the result
+            float mx[16];
+            unsigned kk[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // compare + select throughout (each compare also yields the arg-max bit; fmaxf would add a canonicalising
+                // v_max per accumulator / DPP value under IEEE mode)
+                const float z0 = acc0[r], z1 = acc1[r];
+                const float v0 = z0 > 0.f ? z0 : alpha * z0, v1 = z1 > 0.f ? z1 : alpha * z1;
+                const float q0 = dpp_swap1(v0), q1 = dpp_swap1(v1);
+                const bool rt = q0 > v0, rb = q1 > v1;
+                const float mt = rt ? q0 : v0, mb = rb ? q1 : v1;
+                const unsigned kt = rt ? 1u : 0u, kb = rb ? 3u : 2u;
+                const bool bot = mb > mt;
+                mx[r] = bot ? mb : mt;
+                kk[r] = bot ? kb : kt;
+            }
+            // registers 0..7 = couts {0-3, 8-11} + 4h, 8..15 = {16-19, 24-27} + 4h.  Swapping the upper group of the low lane
+            // half with the lower group of the high half leaves lane half h with the 16 couts 16h .. 16h+15, in memory order
+            unsigned ib[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ib[g] = kk[4 * g] | (kk[4 * g + 1] << 8) | (kk[4 * g + 2] << 16) | (kk[4 * g + 3] << 24);
+            const int py = ((y0 + 2 * ur) >> 1), px = (x0 + 32 * uc + nl) >> 1;
+            const bool st = ((lane & 1) == 0) && py < Hp && px < Wp;
+            const long po = ((long)(n * Hp + py) * Wp + px) * 32 + 16 * h;
+            {
+                u32x2 s0 = __builtin_amdgcn_permlane32_swap(ib[0], ib[2], false, false);
+                u32x2 s1 = __builtin_amdgcn_permlane32_swap(ib[1], ib[3], false, false);
+                // permlane32_swap(L, U): lanes 32-63 of L <-> lanes 0-31 of U.  Low half: L' = own lower group, U' = the high
+                // half's lower group; high half: L' = the low half's upper group, U' = own upper group - memory order L', U'
+                if (st && pidx) *reinterpret_cast<uint4*>(pidx + po) = make_uint4(s0[0], s0[1], s1[0], s1[1]);
+            }
+            if constexpr (OUT_BF16) {
+                unsigned pb[8];
+#pragma unroll
+                for (int g = 0; g < 8; ++g) pb[g] = pk_bf16(mx[2 * g], mx[2 * g + 1]);
+                u32x2 s[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) s[g] = __builtin_amdgcn_permlane32_swap(pb[g], pb[g + 4], false, false);
+                if (st) {
+                    uint4* d = reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(pooled) + po);
+                    d[0] = make_uint4(s[0][0], s[1][0], s[0][1], s[1][1]);
+                    d[1] = make_uint4(s[2][0], s[3][0], s[2][1], s[3][1]);
+                }
+            } else {
+                u32x2 s[8];
+#pragma unroll
+                for (int g = 0; g < 8; ++g)
+                    s[g] = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx[g]), __float_as_uint(mx[g + 8]), false, false);
+                if (st) {
+                    uint4* d = reinterpret_cast<uint4*>(reinterpret_cast<float*>(pooled) + po);
+                    d[0] = make_uint4(s[0][0], s[1][0], s[2][0], s[3][0]);
+                    d[1] = make_uint4(s[0][1], s[1][1], s[2][1], s[3][1]);
+                    d[2] = make_uint4(s[4][0], s[5][0], s[6][0], s[7][0]);
+                    d[3] = make_uint4(s[4][1], s[5][1], s[6][1], s[7][1]);
+                }
+            }
+        }
+    }
+}
+
+template <int TPR, int RPT>
+int launch_cconv(CConvParams p, hipStream_t s) {
+    constexpr int TW = 4 * TPR, TR = (256 / TPR) * RPT, HR = TR + 4, HC = TW + 4, RS = (HC * 3 + 3) / 4 * 4;
+    constexpr size_t lds = (size_t)HR * RS * sizeof(float);
+    p.tiles_y = cdiv(p.H, TR);
+    p.tiles_x = cdiv(p.W, TW);
+    const long total = (long)p.N * p.tiles_y * p.tiles_x;
+    const long cap = 256L * (lds > 40000 ? 3 : 6);              // persistent: a few workgroups per CU
+    auto k = cconv_kernel<TPR, RPT>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3((unsigned)(total < cap ? total : cap)), dim3(256), lds, s, p.in, p.w, p.out_f32, p.out_c4, p);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+template <int TWD>
+int launch_conv1_pool(const void* c4, const float* w, const float* bias, void* pooled, unsigned char* pidx, int n, int h,
+                      int wd, float alpha, int out_bf16, hipStream_t s) {
+    const int tiles_y = cdiv(h, 8), tiles_x = cdiv(wd, TWD);
+    const long total = (long)n * tiles_y * tiles_x;
+    const long cap = 256L * (TWD > 64 ? 4 : 8);
+    const dim3 grid((unsigned)(total < cap ? total : cap));
+    if (out_bf16)
+        hipLaunchKernelGGL((conv1_pool_fwd_kernel<TWD, true>), grid, dim3(256), 0, s, c4, w, bias, pooled, pidx, n, h, wd, alpha,
+                           tiles_y, tiles_x);
+    else
+        hipLaunchKernelGGL((conv1_pool_fwd_kernel<TWD, false>), grid, dim3(256), 0, s, c4, w, bias, pooled, pidx, n, h, wd,
+                           alpha, tiles_y, tiles_x);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nimg_conv1_pool_fwd_c4(const void* c4, const float* w, const float* bias, void* pooled, unsigned char* pool_idx, int n,
+                           int h, int wd, float alpha, int out_bf16, void* stream) {
+    if (n == 0) return NIMG_OK;
+    if (!c4 || !w || !pooled || n < 0 || h < 2 || wd < 2 || (h & 1) || (wd & 1) || !(alpha > 0.f && alpha <= 1.f))
+        return NIMG_ERR_ARG;
+    const long per_image = (long)h * wd * 8;
+    if (per_image > 0x7fffffffL) return NIMG_ERR_ARG;
+    const int chunk = (int)(0x7fffffffL / per_image);           // buffer descriptors address < 2 GB
+    const size_t esz = out_bf16 ? 2 : 4;
+    for (int n0 = 0; n0 < n; n0 += chunk) {
+        const int nn = n - n0 < chunk ? n - n0 : chunk;
+        const long px0 = (long)n0 * h * wd, pp0 = (long)n0 * (h / 2) * (wd / 2) * 32;
+        const void* src = (const char*)c4 + px0 * 8;
+        void* dst = (char*)pooled + pp0 * esz;
+        unsigned char* di = pool_idx ? pool_idx + pp0 : nullptr;
+        const int rc = wd > 96 ? launch_conv1_pool<256>(src, w, bias, dst, di, nn, h, wd, alpha, out_bf16, (hipStream_t)stream)
+                               : launch_conv1_pool<64>(src, w, bias, dst, di, nn, h, wd, alpha, out_bf16, (hipStream_t)stream);
+        if (rc != NIMG_OK) return rc;
+    }
+    return NIMG_OK;
+}
+
+int nimg_cconv3(const float* in, const float* w, float* out_f32, void* out_c4, int n, int h, int wd, int pad_mode,
+                void* stream) {
+    if (n == 0) return NIMG_OK;
+    if (!in || !w || (!out_f32 && !out_c4) || n < 0 || h < 1 || wd < 1 || pad_mode < 0 || pad_mode > 2) return NIMG_ERR_ARG;
+    if (pad_mode != 0 && (h < 2 || wd < 2)) return NIMG_ERR_ARG;
+    const long per_image = (long)h * wd * 12;
+    if (per_image > 0x7fffffffL) return NIMG_ERR_ARG;
+    const int chunk = (int)(0x7fffffffL / per_image);           // buffer descriptors address < 2 GB
+    for (int n0 = 0; n0 < n; n0 += chunk) {
+        CConvParams p;
+        const long px0 = (long)n0 * h * wd;
+        p.in = in + px0 * 3; p.w = w; p.out_f32 = out_f32 ? out_f32 + px0 * 3 : nullptr;
+        p.out_c4 = out_c4 ? (uint2*)out_c4 + px0 : nullptr;
+        p.N = n - n0 < chunk ? n - n0 : chunk; p.H = h; p.W = wd; p.pad_mode = pad_mode; p.tiles_y = p.tiles_x = 0;
+        const int rc = wd > 96 ? launch_cconv<64, 2>(p, (hipStream_t)stream) : launch_cconv<16, 1>(p, (hipStream_t)stream);
+        if (rc != NIMG_OK) return rc;
+    }
+    return NIMG_OK;
+}
+
+int nimg_cconv3_dgrad_border(const float* dc, const float* nf, float* dx, int n, int h, int wd, void* stream) {
+    if (n == 0) return NIMG_OK;
+    if (!dc || !nf || !dx || n < 0 || h < 4 || wd < 4) return NIMG_ERR_ARG;
+    const long total = (long)n * (4 * wd + 4 * (h - 4));
+    const long g = (total + 255) / 256;
+    hipLaunchKernelGGL(cdgrad_border_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, (hipStream_t)stream, dc, nf,
+                       dx, n, h, wd);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+}  // extern "C"

@@ -103,10 +103,21 @@ class FAN(TFModel):
         P = self._model
         t = OrderedDict()
         t['x'] = x
-        net, nf = self._constrained.forward(P, x)
+        c1 = self._convs[0]
+        front = ops.front_end_ok(c1.cin, c1.cout, c1.ks, x.shape[1], x.shape[2]) and c1.activation == 'leaky_relu'
+        if front:       # throughput mode: the filtered image also leaves as 8-byte bf16 pixels for the row-band conv1 kernel
+            net, nf, c4 = self._constrained.forward(P, x, want_c4=True)
+        else:
+            net, nf = self._constrained.forward(P, x)
         t['constrained'], t['nf'] = net, nf
         for i, c in enumerate(self._convs):
-            if c.can_pool(net):          # conv + LeakyReLU + pool in one pass; the full-resolution tensor is not stored
+            if i == 0 and front:
+                nxt = self._convs[1] if len(self._convs) > 1 else self._conv1x1
+                as_bf16 = ops.STORE_BF16 and nxt.cout >= 8
+                net, idx = ops.conv1_pool_c4(c4, P.p[c.name + '/kernel'], P.p[c.name + '/bias'], want_idx=training,
+                                             out_bf16=as_bf16)
+                t['idx1'] = idx
+            elif c.can_pool(net):        # conv + LeakyReLU + pool in one pass; the full-resolution tensor is not stored
                 # throughput mode: pooled activations live in HBM as bf16 - every consumer (next convolution, its weight
                 # gradient, the LeakyReLU' sign test) rounds to bf16 / reads the sign anyway, so no result bit changes
                 nxt = self._convs[i + 1] if i + 1 < len(self._convs) else self._conv1x1

@@ -100,18 +100,20 @@ class ConstrainedConv2D(object):
     def init(self, store, gen=None):
         store.p[self.name + '/kernel'].copy_(torch.from_numpy(hk.residual_init_filter().astype(np.float32)))
 
-    def forward(self, store, x):
+    def forward(self, store, x, want_c4=False):
+        """-> (y float32, normalised filter[, y as bf16 {y0,y1,y2,1} pixels for the throughput-mode conv1 kernels])"""
         nf = ops.constrained_kernel(store.p[self.name + '/kernel'], self.strength)
-        y = ops.conv2d(x, nf, None, pads=(2, 2), out_hw=(x.shape[1], x.shape[2]), pad_mode=1)
-        return y, nf
+        y, c4 = ops.cconv3(x, nf, pad_mode=1, want_c4=want_c4)
+        return (y, nf, c4) if want_c4 else (y, nf)
 
     def backward_params(self, store, x, dy):
         dnf = ops.conv2d_wgrad(x, dy, 5, pads=(2, 2), pad_mode=1)
         ops.constrained_kernel_bwd(store.p[self.name + '/kernel'], dnf, store.g[self.name + '/kernel'], self.strength)
 
     def backward_input(self, nf, dy):
-        # gradient on the padded domain (full correlation with the flipped filter), then fold the SYMMETRIC pad
+        # correlation with the flipped filter + the terms the SYMMETRIC pad folds back onto the image border
         n, h, w, _ = dy.shape
-        wt = ops.flip_weights(nf)
-        dpad = ops.conv2d(dy, wt, None, pads=(4, 4), out_hw=(h + 4, w + 4))
-        return ops.fold_pad(dpad, 2, 1)
+        if h < 4 or w < 4:
+            dpad = ops.conv2d(dy, ops.flip_weights(nf), None, pads=(4, 4), out_hw=(h + 4, w + 4))
+            return ops.fold_pad(dpad, 2, 1)
+        return ops.cconv3_dgrad(dy, nf)

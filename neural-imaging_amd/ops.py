@@ -635,6 +635,54 @@ def constrained_kernel_bwd(kernel, dnf, dk, strength=100.0):
     return dk
 
 
+def cconv3(x, w, pad_mode=1, out=None, want_f32=True, want_c4=False):
+    """5x5 convolution 3 -> 3 on the VALU (the ConstrainedConv2D core): x (N,H,W,3), w (5,5,3,3) HWIO device tensor.
+    Returns (y float32 (N,H,W,3) | None, c4 bf16 (N,H,W,4) = {y0, y1, y2, 1} | None)."""
+    _f32(x, w, out)
+    n, h, wd, c = x.shape
+    if c != 3 or tuple(w.shape) != (5, 5, 3, 3):
+        raise ValueError('cconv3: (N,H,W,3) input and a (5,5,3,3) kernel expected')
+    y = (torch.empty_like(x) if out is None else out) if want_f32 else None
+    c4 = torch.empty((n, h, wd, 4), dtype=torch.bfloat16, device=x.device) if want_c4 else None
+    _lib.call('nimg_cconv3', _p(x), _p(w), _p(y), _p(c4), n, h, wd, int(pad_mode), _stream())
+    return y, c4
+
+
+# The row-band front-end kernels (csrc/frontend.hip) serve the FAN's standard first layer in throughput mode; NIMG_OLD_FRONTEND=1
+# keeps the generic small-channel kernels (A/B runs).
+FRONT_END = _os.environ.get('NIMG_OLD_FRONTEND') is None
+
+
+def front_end_ok(cin, cout, ks, h, w):
+    return FRONT_END and COMPUTE == 'bf16' and cin == 3 and cout == 32 and ks == 5 and h % 2 == 0 and w % 2 == 0 and \
+        h >= 4 and w >= 4
+
+
+def conv1_pool_c4(c4, w, bias, act='leaky_relu', want_idx=True, out_bf16=True):
+    """Conv2D(32, 5x5, SAME) + bias + activation + MaxPool2D(2) over the bf16 {c0,c1,c2,1} pixels written by cconv3 (the FAN's
+    first convolution, throughput mode).  Returns (pooled (N,H/2,W/2,32), arg-max bytes | None)."""
+    _f32(w, bias)
+    _chk(c4)
+    n, h, wd, c = c4.shape
+    if c4.dtype != torch.bfloat16 or c != 4 or tuple(w.shape) != (5, 5, 3, 32) or (h & 1) or (wd & 1):
+        raise ValueError('conv1_pool_c4: (N,H,W,4) bf16 pixels, a (5,5,3,32) kernel and even sizes expected')
+    pooled = torch.empty((n, h // 2, wd // 2, 32), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=c4.device)
+    idx = torch.empty((n, h // 2, wd // 2, 32), dtype=torch.uint8, device=c4.device) if want_idx else None
+    _lib.call('nimg_conv1_pool_fwd_c4', _p(c4), _p(w), _p(bias), _p(pooled), _p(idx), n, h, wd,
+              LRELU_ALPHA if act == 'leaky_relu' else 1.0, 1 if out_bf16 else 0, _stream())
+    return pooled, idx
+
+
+def cconv3_dgrad(dy, nf):
+    """Input gradient of the SYMMETRIC-padded 5x5 3 -> 3 filter nf: zero-padded correlation with the flipped / transposed
+    filter plus the mirror terms of the two outermost rows / columns."""
+    _f32(dy, nf)
+    n, h, wd, _ = dy.shape
+    dx, _ = cconv3(dy, flip_weights(nf), pad_mode=0)
+    _lib.call('nimg_cconv3_dgrad_border', _p(dy), _p(nf), _p(dx), n, h, wd, _stream())
+    return dx
+
+
 def fold_pad(dpad, pad, pad_mode):
     _f32(dpad)
     n, hp, wp, c = dpad.shape

@@ -20,3 +20,12 @@ def pytest_configure(config):
 def golden():
     import numpy as np
     return np.load(os.path.join(ROOT, 'tests', 'golden', 'reference_tables.npz'))
+
+
+@pytest.fixture(autouse=True)
+def _parity_mode_between_tests():
+    """Every test starts in the float32 parity mode, whatever the previous one selected."""
+    yield
+    ops = sys.modules.get('neural_imaging_amd.ops')
+    if ops is not None:
+        ops.set_compute('f32')

@@ -415,6 +415,67 @@ def test_constrained_conv(dev):
     assert_close(dx.cpu().numpy(), x.grad.numpy(), 1e-3, GRTOL, what='constrained conv input grad')
 
 
+@pytest.mark.parametrize('shape', [(2, 24, 32), (1, 40, 272), (3, 8, 8), (1, 5, 100), (2, 256, 256)])
+def test_cconv3_front_end_stencil(dev, shape):
+    """csrc/frontend.hip: the ConstrainedConv2D forward (SYMMETRIC pad) and its input gradient (flipped filter + border
+    fold) against the float64 oracle (models/layers.py:56-57), on both tile shapes (narrow / full-width), ragged sizes and the
+    bench size; the bf16 {y, 1} pixel is the rounded float32 output."""
+    from neural_imaging_amd import ops
+    n, h, w = shape
+    k = to64(ot.fan_residual_init() + 0.05 * rnd((5, 5, 3, 3), 1))
+    m = to64(ot.center_mask_2dfilter(5, 3))
+    x = to64(natural_images(n, h, w, seed=4)).requires_grad_(True)
+    y = T.constrained_conv(x, k, m)
+    dy = rnd(tuple(y.shape), 2)
+    (y * to64(dy)).sum().backward()
+    nf = ops.constrained_kernel(g(k.numpy(), dev))
+    yo, c4 = ops.cconv3(g(x.detach().numpy(), dev), nf, pad_mode=1, want_c4=True)
+    assert_close(yo.cpu().numpy(), y.detach().numpy(), 1e-3, 1e-5, what='constrained conv fwd')
+    c4 = c4.float().cpu().numpy()
+    assert np.array_equal(c4[..., :3], yo.to(torch.bfloat16).float().cpu().numpy()) and (c4[..., 3] == 1.0).all()
+    dx = ops.cconv3_dgrad(g(dy, dev), nf)
+    assert_close(dx.cpu().numpy(), x.grad.numpy(), 1e-3, GRTOL, what='constrained conv input grad')
+    # the previous decomposition (full correlation on the padded domain, then the fold) gives the same numbers
+    dpad = ops.conv2d(g(dy, dev), ops.flip_weights(nf), None, pads=(4, 4), out_hw=(h + 4, w + 4), _f32_only=True)
+    assert_close(dx.cpu().numpy(), ops.fold_pad(dpad, 2, 1).cpu().numpy(), 1e-3, 1e-5, what='vs pad-fold path')
+
+
+def _bf16_round(a):
+    return torch.from_numpy(np.asarray(a, np.float32)).to(torch.bfloat16).double()
+
+
+@pytest.mark.parametrize('shape,out_bf16', [((2, 16, 32), False), ((1, 24, 72), True), ((3, 64, 64), True), ((1, 10, 256), False),
+                                            ((2, 256, 256), True)])
+def test_conv1_pool_front_end(dev, shape, out_bf16):
+    """csrc/frontend.hip conv1_pool_fwd_kernel: Conv2D(32, 5x5, SAME) + bias + LeakyReLU + MaxPool2D over 8-byte bf16 pixels
+    (models/forensics.py:69-70) against the float64 oracle evaluated on the SAME bf16-rounded operands (so only the float32
+    accumulation order differs): pooled values, and the arg-max byte wherever the window maximum is not a near-tie."""
+    from neural_imaging_amd import ops
+    ops.set_compute('bf16')
+    n, h, w = shape
+    c = rnd((n, h, w, 3), 11) * 2.0
+    wk = rnd((5, 5, 3, 32), 12) * 0.2
+    b = rnd((32,), 13) * 0.1
+    c4 = torch.ones((n, h, w, 4), dtype=torch.bfloat16, device=dev)
+    c4[..., :3] = g(c, dev).to(torch.bfloat16)
+    pooled, idx = ops.conv1_pool_c4(c4.contiguous(), g(wk, dev), g(b, dev), out_bf16=out_bf16)
+    act = T.leaky_relu(T.conv2d(_bf16_round(c), _bf16_round(wk), to64(b)))
+    ref = T.max_pool2(act).numpy()
+    got = pooled.float().cpu().numpy()
+    tol = 1e-2 if out_bf16 else 2e-4                         # bf16 storage rounds to 2^-9 relative
+    assert got.shape == ref.shape == (n, h // 2, w // 2, 32)
+    assert np.abs(got - ref).max() <= tol * max(1.0, np.abs(ref).max()), np.abs(got - ref).max()
+    win = act.numpy().reshape(n, h // 2, 2, w // 2, 2, 32).transpose(0, 1, 3, 5, 2, 4).reshape(n, h // 2, w // 2, 32, 4)
+    srt = np.sort(win, axis=-1)
+    clear = (srt[..., 3] - srt[..., 2]) > 1e-4 * (1.0 + np.abs(srt[..., 3]))
+    k = idx.cpu().numpy()
+    assert clear.mean() > 0.99 and np.array_equal(k[clear], win.argmax(axis=-1)[clear]) and k.max() <= 3
+    # same kernel, no activation (alpha = 1) and no bias / no arg-max output
+    p2, i2 = ops.conv1_pool_c4(c4.contiguous(), g(wk, dev), None, act=None, want_idx=False, out_bf16=out_bf16)
+    ref2 = T.max_pool2(T.conv2d(_bf16_round(c), _bf16_round(wk), None)).numpy()
+    assert i2 is None and np.abs(p2.float().cpu().numpy() - ref2).max() <= tol * max(1.0, np.abs(ref2).max())
+
+
 @pytest.mark.parametrize('name', ['gaussian', 'gaussian3', 'sharpen', 'sharpen_strong', 'resample50', 'resample73'])
 def test_manipulations_fwd_bwd(dev, name):
     from neural_imaging_amd.helpers import tf_helpers as th
