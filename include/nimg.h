@@ -287,6 +287,17 @@ int nimg_cconv3_dgrad_border(const float* dc, const float* nf, float* dx, int n,
  * h, w even; 0 < alpha <= 1 (1 = no activation). */
 int nimg_conv1_pool_fwd_c4(const void* c4, const float* w, const float* bias, void* pooled, unsigned char* pool_idx, int n,
                            int h, int w_, float alpha, int out_bf16, void* stream);
+/* Weight and bias gradient of that convolution from the POOLED gradient (backward of nimg_conv1_pool_fwd_c4; the tape of
+ * forensics.py:118-124 for this layer): dw (5,5,3,32) (+)= sum c (x) dz, db (32) (+)= sum dz with dz = the MaxPool2D routing of g
+ * by the arg-max bytes.  c4 as above; g (n,h/2,w/2,32) bf16 (g_bf16 = 1) or float32, already multiplied by LeakyReLU';
+ * db may be NULL.  workspace: nimg_conv1_wgrad_c4_workspace_bytes() bytes (per-wave slabs, reduced in a fixed order). */
+size_t nimg_conv1_wgrad_c4_workspace_bytes(void);
+int nimg_conv1_wgrad_c4(const void* c4, const void* g, const unsigned char* pool_idx, float* dw, float* db, int n, int h, int w_,
+                        int g_bf16, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* Input gradient of that convolution from the pooled gradient: dc (n,h,w,3) float32 = sum_{ky,kx,o} dz[y+2-ky][x+2-kx][o]
+ * w[ky][kx][i][o] (bf16 MFMA operands, float32 accumulation); w = the (5,5,3,32) float32 forward kernel as stored. */
+int nimg_conv1_dgrad_pooled(const void* g, const unsigned char* pool_idx, const float* w, float* dc, int n, int h, int w_,
+                            int g_bf16, void* stream);
 /* Classifier decisions + confusion matrix on the device - replaces the host loop of validate_fan,
  * training/validation.py:163-202 (np.argmax per batch, conf[c, c_] += sum((y == c) * (pred == c_)), one D2H per batch).
  * probs (n,k) float32; labels (n) int32 or NULL; pred (n) int32 or NULL: first arg-max of each row (numpy.argmax);

@@ -97,6 +97,9 @@ PROTOTYPES = {
     'nimg_cconv3': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'nimg_cconv3_dgrad_border': (c_int, [P, P, P, c_int, c_int, c_int, P]),
     'nimg_conv1_pool_fwd_c4': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_float, c_int, P]),
+    'nimg_conv1_wgrad_c4_workspace_bytes': (c_size_t, []),
+    'nimg_conv1_wgrad_c4': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    'nimg_conv1_dgrad_pooled': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'nimg_confusion_accumulate': (c_int, [P, P, P, P, c_int, c_int, P]),
     'nimg_ssim_planes_workspace_bytes': (c_size_t, [c_int, c_int]),
     'nimg_ssim_planes': (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, P, P, P, P, c_int, P, c_size_t, P]),

@@ -447,6 +447,294 @@ int launch_cconv(CConvParams p, hipStream_t s) {
     return NIMG_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight + bias gradient of the first FAN convolution from the POOLED gradient (throughput mode):
+//   dw[ky][kx][ci][o] = sum_{n,y,x} c[n][y+ky-2][x+kx-2][ci] dz[n][y][x][o],   db[o] = sum dz[n][y][x][o],
+//   dz[y][x][o] = g[y/2][x/2][o] if argmax[y/2][x/2][o] == 2 (y & 1) + (x & 1) else 0      (MaxPool2D routing; g carries LReLU')
+// GEMM view: D[(tap, 4 ch) 128][o 32] += A[(tap, ch)][16 pixels] B[16 pixels][o]: 4 M-fragments x v_mfma_f32_32x32x16_bf16 per
+// run of 16 pixels.  Both operands are pixel-major in memory and K(=pixel)-major in the MFMA, which is what
+// ds_read_b64_tr_b16 delivers: A straight from the 8-byte {c0,c1,c2,1} pixels (a 16-lane group reads 4 pixels x 4 taps x 4
+// channels; the tap is a per-lane offset), B from the un-pooled, arg-max-masked gradient tile the staging pass builds in LDS
+// with packed bit operations (no float conversions).  The constant channel of the pixel makes row (tap (2,2), ch 3) of D the
+// bias gradient.  Waves split the pixel runs of a tile; every wave keeps its 64 accumulator registers over all its tiles and
+// writes one slab (final dw layout) at the end; a fixed-order slab reduction follows (deterministic).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// ds_read_b64_tr_b16: in a 16-lane group lane g supplies the 8-byte aligned address of row g >> 2, columns 4 (g & 3) .. + 3 of
+// a 4 x 16 block of 16-bit elements and receives column g (4 elements).  Two reads = the 8 K values of an MFMA operand.
+__device__ __forceinline__ bf16x8 tr_read8(const unsigned char* p0, const unsigned char* p1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p1);
+    s16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return *reinterpret_cast<bf16x8*>(&r);
+}
+
+// 4 arg-max bytes (values 0..3) -> 0xFF in every byte that equals pos
+__device__ __forceinline__ unsigned eq_bytes(unsigned k, unsigned pos) {
+    const unsigned x = k ^ (pos * 0x01010101u);
+    return (((x | (x >> 1)) & 0x01010101u) ^ 0x01010101u) * 0xFFu;
+}
+
+constexpr int F_TR = 8, F_TW = 64, F_HR = F_TR + 4, F_HC = F_TW + 4;          // tile rows / cols, with the 2-pixel halo
+constexpr int F_C4_BYTES = F_HR * F_HC * 8, F_DZ_BYTES = F_TR * F_TW * 64;
+constexpr int F_DW = 25 * 3 * 32;                                             // floats of one dw slab
+
+template <bool GB>      // GB: the pooled gradient is stored as bf16 (else float32)
+__global__ __launch_bounds__(256) void conv1_wgrad_pooled_kernel(const void* __restrict__ c4, const void* __restrict__ gp,
+                                                                 const unsigned char* __restrict__ pidx,
+                                                                 float* __restrict__ dw_slabs, float* __restrict__ db_slabs,
+                                                                 int N, int H, int W, int tiles_y, int tiles_x, int per_wg) {
+    constexpr unsigned OOB = 0x80000000u;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[F_C4_BYTES + F_DZ_BYTES];
+    unsigned char* sC = smem;                       // [F_HR][F_HC] x 8 B
+    unsigned char* sZ = smem + F_C4_BYTES;          // [F_TR][F_TW] x 64 B (32 o, bf16)
+    const int tid = threadIdx.x, lane = tid & 63, kh = lane >> 5, q1 = (lane >> 4) & 1, g16 = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles = tiles_y * tiles_x, total = N * tiles;
+    const int Hp = H >> 1, Wp = W >> 1;
+    const int w_begin = blockIdx.x * per_wg, w_end = min(total, w_begin + per_wg);
+
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(c4), 0, (int)((long)N * H * W * 8),
+                                                                        0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(gp), 0,
+                                                                        (int)((long)N * Hp * Wp * 32 * (GB ? 2 : 4)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(pidx), 0,
+                                                                        (int)((long)N * Hp * Wp * 32), 0x00020000);
+    // per-lane parts of the transpose-read addresses
+    const int tl = 4 * q1 + (g16 & 3);                               // this lane's tap inside an 8-tap M fragment
+    int a_off[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int tap = min(8 * f + tl, 24);                         // spare slots re-read tap 24 (their D rows are dropped)
+        a_off[f] = ((tap / 5) * F_HC + (tap % 5) + 8 * kh + (g16 >> 2)) * 8;
+    }
+    const int z_off = (8 * kh + (g16 >> 2)) * 64 + (16 * q1 + 4 * (g16 & 3)) * 2;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+    constexpr int C_ITEMS = F_HR * (F_HC / 2), C_PT = (C_ITEMS + 255) / 256;      // 16-byte pixel pairs of the c tile
+    constexpr int G_PT = (F_TR / 2) * (F_TW / 2) * 4 / 256;                       // (pooled pixel, 8-channel chunk) items
+    static_assert(G_PT * 256 == (F_TR / 2) * (F_TW / 2) * 4, "gradient tile must divide over the threads");
+    u32x4 pc[C_PT], pg[G_PT][GB ? 1 : 2];
+    u32x2 pk[G_PT];
+    auto fetch = [&](int t) {
+        const int n = t / tiles, tile = t % tiles;
+        const int y0 = (tile / tiles_x) * F_TR, x0 = (tile % tiles_x) * F_TW;
+#pragma unroll
+        for (int q = 0; q < C_PT; ++q) {
+            const int item = tid + q * 256, row = item / (F_HC / 2), pr = item % (F_HC / 2);
+            const int gy = y0 - 2 + row, gx = x0 - 2 + 2 * pr;                    // W, x0 even: a pair is in or out as a whole
+            const bool ok = (item < C_ITEMS) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+            pc[q] = __builtin_amdgcn_raw_buffer_load_b128(rc, ok ? (unsigned)(((n * H + gy) * W + gx) * 8) : OOB, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < G_PT; ++q) {
+            const int item = tid + q * 256, pp = item >> 2, ch = item & 3;
+            const int py = (y0 >> 1) + pp / (F_TW / 2), px = (x0 >> 1) + pp % (F_TW / 2);
+            const bool ok = (py < Hp) & (px < Wp);
+            const unsigned e = (unsigned)(((n * Hp + py) * Wp + px) * 32 + ch * 8);      // element index of the 8-channel chunk
+            if constexpr (GB) {
+                pg[q][0] = __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? e * 2 : OOB, 0, 0);
+            } else {
+                pg[q][0] = __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? e * 4 : OOB, 0, 0);
+                pg[q][1] = __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? e * 4 + 16 : OOB, 0, 0);
+            }
+            pk[q] = __builtin_amdgcn_raw_buffer_load_b64(rk, ok ? e : OOB, 0, 0);
+        }
+    };
+    if (w_begin < w_end) fetch(w_begin);
+    for (int t = w_begin; t < w_end; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < C_PT; ++q) {
+            const int item = tid + q * 256;
+            if (item < C_ITEMS) *reinterpret_cast<uint4*>(sC + item * 16) = *reinterpret_cast<const uint4*>(&pc[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < G_PT; ++q) {
+            const int item = tid + q * 256, pp = item >> 2, ch = item & 3;
+            const int ry = 2 * (pp / (F_TW / 2)), rx = 2 * (pp % (F_TW / 2));
+            unsigned d[4];
+            if constexpr (GB) {
+                d[0] = pg[q][0][0]; d[1] = pg[q][0][1]; d[2] = pg[q][0][2]; d[3] = pg[q][0][3];
+            } else {
+                d[0] = pk_bf16(__uint_as_float(pg[q][0][0]), __uint_as_float(pg[q][0][1]));
+                d[1] = pk_bf16(__uint_as_float(pg[q][0][2]), __uint_as_float(pg[q][0][3]));
+                d[2] = pk_bf16(__uint_as_float(pg[q][1][0]), __uint_as_float(pg[q][1][1]));
+                d[3] = pk_bf16(__uint_as_float(pg[q][1][2]), __uint_as_float(pg[q][1][3]));
+            }
+#pragma unroll
+            for (int pos = 0; pos < 4; ++pos) {
+                const unsigned m0 = eq_bytes(pk[q][0], pos), m1 = eq_bytes(pk[q][1], pos);
+                uint4 v;                                               // byte masks -> one 16-bit mask per bf16
+                v.x = d[0] & __builtin_amdgcn_perm(m0, m0, 0x01010000u);
+                v.y = d[1] & __builtin_amdgcn_perm(m0, m0, 0x03030202u);
+                v.z = d[2] & __builtin_amdgcn_perm(m1, m1, 0x01010000u);
+                v.w = d[3] & __builtin_amdgcn_perm(m1, m1, 0x03030202u);
+                *reinterpret_cast<uint4*>(sZ + ((ry + (pos >> 1)) * F_TW + rx + (pos & 1)) * 64 + ch * 16) = v;
+            }
+        }
+        __syncthreads();
+        if (t + 1 < w_end) fetch(t + 1);
+#pragma unroll 2
+        for (int ks = wave; ks < F_TR * (F_TW / 16); ks += 4) {
+            const int r = ks / (F_TW / 16), xr = ks % (F_TW / 16);
+            const unsigned char* zb = sZ + (r * F_TW + 16 * xr) * 64 + z_off;
+            const bf16x8 b = tr_read8(zb, zb + 4 * 64);
+            const unsigned char* ab = sC + (r * F_HC + 16 * xr) * 8;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const bf16x8 a = tr_read8(ab + a_off[f], ab + a_off[f] + 32);
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[f], 0, 0, 0);
+            }
+        }
+    }
+    // D row m = (reg & 3) + 8 (reg >> 2) + 4 kh = 4 (tap - 8 f) + ch, column o = lane & 31
+    float* dws = dw_slabs + ((long)blockIdx.x * 4 + wave) * F_DW;
+    const int o = lane & 31;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = r & 3, tap = 8 * f + 2 * (r >> 2) + kh;
+            if (ch < 3 && tap < 25) dws[(tap * 3 + ch) * 32 + o] = acc[f][r];
+            if (ch == 3 && tap == 12 && db_slabs) db_slabs[((long)blockIdx.x * 4 + wave) * 32 + o] = acc[f][r];
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Input gradient of the first FAN convolution from the POOLED gradient (throughput mode), 32 -> 3 channels:
+//   dc[y][x][i] = sum_{ky,kx,o} dz[y+2-ky][x+2-kx][o] w[ky][kx][i][o]          (dz = MaxPool2D routing of g, as above)
+// kx is folded into the MFMA M dimension: P[(kx,i) 15 of 16][q] = sum_{ky,o} w[ky][kx][i][o] dz[y+2-ky][q][o] is five
+// v_mfma_f32_16x16x32_bf16 per 16 positions q (K = the 32 channels, contiguous in the [pixel][o] tile: plain 16-byte operand
+// reads, XOR-swizzled so that the sixteen lanes of a b128 group cover the 64 banks), the weights (A) live in 20 VGPRs, and
+// dc[y][x][i] = sum_kx P[(kx,i)][x+2-kx] is a shift-add through a 4 KB per-wave LDS strip.  The gradient tile is un-pooled
+// and arg-max-masked once per tile by the staging pass (packed bit operations), then read five times (once per ky).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int E_TR = 8, E_TW = 64, E_HR = E_TR + 4, E_HC = E_TW + 4;
+constexpr int E_DZ_BYTES = E_HR * E_HC * 64 + 12 * 64;                       // + slack: the last fragment over-reads 12 pixels
+constexpr int E_P_BYTES = E_HC * 64;                                         // per wave: [position][16] float32
+
+template <bool GB>
+__global__ __launch_bounds__(256) void conv1_dgrad_pooled_kernel(const void* __restrict__ gp, const unsigned char* __restrict__ pidx,
+                                                                 const float* __restrict__ w, float* __restrict__ dc, int N, int H,
+                                                                 int W, int tiles_y, int tiles_x) {
+    constexpr unsigned OOB = 0x80000000u;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[E_DZ_BYTES + 4 * E_P_BYTES];
+    unsigned char* sZ = smem;                                  // [E_HR][E_HC] x 4 chunks of 8 channels (bf16), chunk c of
+    const int tid = threadIdx.x, lane = tid & 63;              // tile column q stored at chunk slot c ^ (((q >> 3) & 1) << 1)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* sP = reinterpret_cast<float*>(smem + E_DZ_BYTES + wave * E_P_BYTES);
+    const int nl = lane & 15, kg = lane >> 4;
+    const int tiles = tiles_y * tiles_x, total = N * tiles;
+    const int Hp = H >> 1, Wp = W >> 1;
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(gp), 0,
+                                                                        (int)((long)N * Hp * Wp * 32 * (GB ? 2 : 4)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(pidx), 0,
+                                                                        (int)((long)N * Hp * Wp * 32), 0x00020000);
+    // A operand: row m = (kx, i) = nl (row 15 is empty), K values o = 8 kg .. 8 kg + 7, one fragment per ky
+    bf16x8 wa[5];
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            wa[ky][e] = (__bf16)(nl < 15 ? w[((ky * 5 + nl / 3) * 3 + nl % 3) * 32 + 8 * kg + e] : 0.f);
+
+    constexpr int PR = E_HR / 2, PCOLS = E_HC / 2, G_ITEMS = PR * PCOLS * 4, G_PT = (G_ITEMS + 255) / 256;
+    u32x4 pg[G_PT][GB ? 1 : 2];
+    u32x2 pk[G_PT];
+    auto fetch = [&](int t) {
+        const int n = t / tiles, tile = t % tiles;
+        const int y0 = (tile / tiles_x) * E_TR, x0 = (tile % tiles_x) * E_TW;
+#pragma unroll
+        for (int q = 0; q < G_PT; ++q) {
+            const int item = tid + q * 256, pp = item >> 2, ch = item & 3;
+            const int py = ((y0 - 2) >> 1) + pp / PCOLS, px = ((x0 - 2) >> 1) + pp % PCOLS;     // arithmetic shift: -1 at the border
+            const bool ok = (item < G_ITEMS) & ((unsigned)py < (unsigned)Hp) & ((unsigned)px < (unsigned)Wp);
+            const unsigned e = (unsigned)(((n * Hp + py) * Wp + px) * 32 + ch * 8);
+            if constexpr (GB) {
+                pg[q][0] = __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? e * 2 : OOB, 0, 0);
+            } else {
+                pg[q][0] = __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? e * 4 : OOB, 0, 0);
+                pg[q][1] = __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? e * 4 + 16 : OOB, 0, 0);
+            }
+            pk[q] = __builtin_amdgcn_raw_buffer_load_b64(rk, ok ? e : OOB, 0, 0);
+        }
+    };
+    const int first = xcd_order(blockIdx.x);
+    if (first < total) fetch(first);
+    for (int t = first; t < total; t += gridDim.x) {
+        const int n = t / tiles, tile = t % tiles;
+        const int y0 = (tile / tiles_x) * E_TR, x0 = (tile % tiles_x) * E_TW;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < G_PT; ++q) {
+            const int item = tid + q * 256, pp = item >> 2, ch = item & 3;
+            if (item < G_ITEMS) {
+                const int ry = 2 * (pp / PCOLS), rx = 2 * (pp % PCOLS);
+                unsigned d[4];
+                if constexpr (GB) {
+                    d[0] = pg[q][0][0]; d[1] = pg[q][0][1]; d[2] = pg[q][0][2]; d[3] = pg[q][0][3];
+                } else {
+                    d[0] = pk_bf16(__uint_as_float(pg[q][0][0]), __uint_as_float(pg[q][0][1]));
+                    d[1] = pk_bf16(__uint_as_float(pg[q][0][2]), __uint_as_float(pg[q][0][3]));
+                    d[2] = pk_bf16(__uint_as_float(pg[q][1][0]), __uint_as_float(pg[q][1][1]));
+                    d[3] = pk_bf16(__uint_as_float(pg[q][1][2]), __uint_as_float(pg[q][1][3]));
+                }
+#pragma unroll
+                for (int pos = 0; pos < 4; ++pos) {
+                    const unsigned m0 = eq_bytes(pk[q][0], pos), m1 = eq_bytes(pk[q][1], pos);
+                    uint4 v;
+                    v.x = d[0] & __builtin_amdgcn_perm(m0, m0, 0x01010000u);
+                    v.y = d[1] & __builtin_amdgcn_perm(m0, m0, 0x03030202u);
+                    v.z = d[2] & __builtin_amdgcn_perm(m1, m1, 0x01010000u);
+                    v.w = d[3] & __builtin_amdgcn_perm(m1, m1, 0x03030202u);
+                    const int col = rx + (pos & 1);
+                    *reinterpret_cast<uint4*>(sZ + ((ry + (pos >> 1)) * E_HC + col) * 64 + ((ch ^ (((col >> 3) & 1) << 1)) * 16)) = v;
+                }
+            }
+        }
+        __syncthreads();
+        if (t + (int)gridDim.x < total) fetch(t + gridDim.x);
+
+        for (int r = wave; r < E_TR; r += 4) {
+            // output row y0 + r, tap ky reads gradient row y0 + r + 2 - ky = tile row r + 4 - ky; position q = tile column
+#pragma unroll
+            for (int fq = 0; fq < 5; ++fq) {
+                const int q = 16 * fq + nl;                              // fragment 4 over-reads 12 columns (never gathered)
+                const int slot = (kg ^ (((q >> 3) & 1) << 1)) * 16;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ky = 0; ky < 5; ++ky) {
+                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(sZ + ((r + 4 - ky) * E_HC + q) * 64 + slot);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ky], b, acc, 0, 0, 0);
+                }
+                // D: column = position q (lane & 15), rows m = 4 kg + reg
+                if (q < E_HC) *reinterpret_cast<f32x4*>(sP + q * 16 + 4 * kg) = acc;
+            }
+            __builtin_amdgcn_wave_barrier();                             // sP is private to the wave: LDS ops complete in order
+            const int oy = y0 + r;
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const int o = lane + 64 * it, vi = o / 3, ci = o - 3 * vi;           // output column x0 + vi, channel ci
+                float sacc = 0.f;
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx) sacc += sP[(vi + 4 - kx) * 16 + kx * 3 + ci];     // q = x + 2 - kx, tile col q + 2
+                if (oy < H && x0 + vi < W) dc[((long)(n * H + oy) * W + x0 + vi) * 3 + ci] = sacc;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+constexpr int F1_WGS = 1024;             // persistent workgroups of the conv1 weight gradient (4 slabs each)
+
 template <int TWD>
 int launch_conv1_pool(const void* c4, const float* w, const float* bias, void* pooled, unsigned char* pidx, int n, int h,
                       int wd, float alpha, int out_bf16, hipStream_t s) {
@@ -487,6 +775,50 @@ int nimg_conv1_pool_fwd_c4(const void* c4, const float* w, const float* bias, vo
                                : launch_conv1_pool<64>(src, w, bias, dst, di, nn, h, wd, alpha, out_bf16, (hipStream_t)stream);
         if (rc != NIMG_OK) return rc;
     }
+    return NIMG_OK;
+}
+
+int nimg_conv1_dgrad_pooled(const void* g, const unsigned char* pool_idx, const float* w, float* dc, int n, int h, int wd,
+                            int g_bf16, void* stream) {
+    if (n == 0) return NIMG_OK;
+    if (!g || !pool_idx || !w || !dc || n < 0 || h < 2 || wd < 2 || (h & 1) || (wd & 1)) return NIMG_ERR_ARG;
+    if ((long)n * (h / 2) * (wd / 2) * 32 * (g_bf16 ? 2 : 4) > 0x7fffffffL) return NIMG_ERR_ARG;      // one descriptor, < 2 GB
+    const int tiles_y = cdiv(h, E_TR), tiles_x = cdiv(wd, E_TW);
+    const long total = (long)n * tiles_y * tiles_x;
+    const dim3 grid((unsigned)(total < 512 ? total : 512));              // persistent: two 70 KB workgroups per CU
+    if (g_bf16)
+        hipLaunchKernelGGL((conv1_dgrad_pooled_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, g, pool_idx, w, dc, n, h, wd,
+                           tiles_y, tiles_x);
+    else
+        hipLaunchKernelGGL((conv1_dgrad_pooled_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, g, pool_idx, w, dc, n, h,
+                           wd, tiles_y, tiles_x);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+size_t nimg_conv1_wgrad_c4_workspace_bytes(void) { return (size_t)F1_WGS * 4 * (F_DW + 32) * sizeof(float); }
+
+int nimg_conv1_wgrad_c4(const void* c4, const void* g, const unsigned char* pool_idx, float* dw, float* db, int n, int h, int wd,
+                        int g_bf16, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    if (n == 0) return NIMG_OK;
+    if (!c4 || !g || !pool_idx || !dw || !workspace || n < 0 || h < 2 || wd < 2 || (h & 1) || (wd & 1)) return NIMG_ERR_ARG;
+    if (workspace_bytes < nimg_conv1_wgrad_c4_workspace_bytes()) return NIMG_ERR_WORKSPACE;
+    if ((long)n * h * wd * 8 > 0x7fffffffL) return NIMG_ERR_ARG;          // one buffer descriptor per tensor (< 2 GB)
+    const int tiles_y = cdiv(h, F_TR), tiles_x = cdiv(wd, F_TW);
+    const long total = (long)n * tiles_y * tiles_x;
+    const int wgs = (int)(total < F1_WGS ? total : F1_WGS), per = cdiv(total, wgs);
+    const int used = cdiv(total, per);                                    // workgroups that own at least one tile
+    float* dws = (float*)workspace;
+    float* dbs = dws + (size_t)F1_WGS * 4 * F_DW;
+    if (g_bf16)
+        hipLaunchKernelGGL((conv1_wgrad_pooled_kernel<true>), dim3(used), dim3(256), 0, (hipStream_t)stream, c4, g, pool_idx, dws,
+                           db ? dbs : nullptr, n, h, wd, tiles_y, tiles_x, per);
+    else
+        hipLaunchKernelGGL((conv1_wgrad_pooled_kernel<false>), dim3(used), dim3(256), 0, (hipStream_t)stream, c4, g, pool_idx,
+                           dws, db ? dbs : nullptr, n, h, wd, tiles_y, tiles_x, per);
+    NIMG_CHECK_LAUNCH();
+    launch_reduce2(dws, dw, F_DW, used * 4, db ? dbs : nullptr, db, 32, used * 4, accumulate, (hipStream_t)stream);
+    NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }
 

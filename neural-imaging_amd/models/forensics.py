@@ -105,18 +105,16 @@ class FAN(TFModel):
         t['x'] = x
         c1 = self._convs[0]
         front = ops.front_end_ok(c1.cin, c1.cout, c1.ks, x.shape[1], x.shape[2]) and c1.activation == 'leaky_relu'
-        if front:       # throughput mode: the filtered image also leaves as 8-byte bf16 pixels for the row-band conv1 kernel
-            net, nf, c4 = self._constrained.forward(P, x, want_c4=True)
-        else:
-            net, nf = self._constrained.forward(P, x)
+        # throughput mode: the filtered image leaves as 8-byte bf16 {c, 1} pixels, the form the row-band conv1 kernels read
+        net, nf = self._constrained.forward(P, x, c4_only=front)
         t['constrained'], t['nf'] = net, nf
         for i, c in enumerate(self._convs):
             if i == 0 and front:
                 nxt = self._convs[1] if len(self._convs) > 1 else self._conv1x1
                 as_bf16 = ops.STORE_BF16 and nxt.cout >= 8
-                net, idx = ops.conv1_pool_c4(c4, P.p[c.name + '/kernel'], P.p[c.name + '/bias'], want_idx=training,
+                net, idx = ops.conv1_pool_c4(net, P.p[c.name + '/kernel'], P.p[c.name + '/bias'], want_idx=training,
                                              out_bf16=as_bf16)
-                t['idx1'] = idx
+                t['idx1'], t['front'] = idx, True
             elif c.can_pool(net):        # conv + LeakyReLU + pool in one pass; the full-resolution tensor is not stored
                 # throughput mode: pooled activations live in HBM as bf16 - every consumer (next convolution, its weight
                 # gradient, the LeakyReLU' sign test) rounds to bf16 / reads the sign anyway, so no result bit changes
@@ -213,9 +211,14 @@ class FAN(TFModel):
             prev_mask = inp if fused(i - 1) else None
             if fused(i) and ops.pooled_backward_ok(conv.cin, conv.cout, conv.ks) and prev_mask is None:
                 # the pooled gradient feeds the weight / input gradient kernels directly (un-pooled while staging)
-                ops.conv2d_wgrad_pooled(inp, d_pool, t['idx{}'.format(i)], conv.ks, dw=P.g[conv.name + '/kernel'],
-                                        db=P.g[conv.name + '/bias'], side=True)
-                d_pool = ops.conv2d_dgrad_pooled(d_pool, t['idx{}'.format(i)], P.p[conv.name + '/kernel'])
+                if t.get('front'):     # row-band front end: `inp` is the filtered image as 8-byte bf16 pixels
+                    ops.conv1_wgrad_c4(inp, d_pool, t['idx{}'.format(i)], dw=P.g[conv.name + '/kernel'],
+                                       db=P.g[conv.name + '/bias'], side=True)
+                    d_pool = ops.conv1_dgrad_pooled(d_pool, t['idx{}'.format(i)], P.p[conv.name + '/kernel'])
+                else:
+                    ops.conv2d_wgrad_pooled(inp, d_pool, t['idx{}'.format(i)], conv.ks, dw=P.g[conv.name + '/kernel'],
+                                            db=P.g[conv.name + '/bias'], side=True)
+                    d_pool = ops.conv2d_dgrad_pooled(d_pool, t['idx{}'.format(i)], P.p[conv.name + '/kernel'])
                 continue
             if fused(i):
                 # throughput mode: the un-pooled gradient only feeds bf16 MFMA kernels - store it as bf16 (same bits)

@@ -100,11 +100,12 @@ class ConstrainedConv2D(object):
     def init(self, store, gen=None):
         store.p[self.name + '/kernel'].copy_(torch.from_numpy(hk.residual_init_filter().astype(np.float32)))
 
-    def forward(self, store, x, want_c4=False):
-        """-> (y float32, normalised filter[, y as bf16 {y0,y1,y2,1} pixels for the throughput-mode conv1 kernels])"""
+    def forward(self, store, x, c4_only=False):
+        """-> (y, normalised filter): y float32 (N,H,W,3), or - c4_only, the throughput-mode front end - the same image as
+        bf16 {y0,y1,y2,1} pixels (N,H,W,4), the only form the row-band conv1 kernels read."""
         nf = ops.constrained_kernel(store.p[self.name + '/kernel'], self.strength)
-        y, c4 = ops.cconv3(x, nf, pad_mode=1, want_c4=want_c4)
-        return (y, nf, c4) if want_c4 else (y, nf)
+        y, c4 = ops.cconv3(x, nf, pad_mode=1, want_f32=not c4_only, want_c4=c4_only)
+        return (c4 if c4_only else y), nf
 
     def backward_params(self, store, x, dy):
         dnf = ops.conv2d_wgrad(x, dy, 5, pads=(2, 2), pad_mode=1)

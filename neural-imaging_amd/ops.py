@@ -595,8 +595,10 @@ def fan_head_bwd(act, gap, w, dlogits, loss_per, loss_scale, dw, db):
 
 
 def adam_lr_t(lr, step, beta1=0.9, beta2=0.999):
-    """Keras Adam's bias-corrected rate of iteration `step` (1-based), in double like nimg_adam_step computes it."""
-    return float(lr) * math.sqrt(1.0 - beta2 ** int(step)) / (1.0 - beta1 ** int(step))
+    """Keras Adam's bias-corrected rate of iteration `step` (1-based), exactly as nimg_adam_step computes it: double
+    arithmetic on the float32 values of lr / beta1 / beta2 that cross the C ABI."""
+    lr, beta1, beta2 = (float(np.float32(v)) for v in (lr, beta1, beta2))
+    return lr * math.sqrt(1.0 - math.pow(beta2, float(int(step)))) / (1.0 - math.pow(beta1, float(int(step))))
 
 
 def adam_step(params, grads, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0, skip_flag=None,
@@ -671,6 +673,40 @@ def conv1_pool_c4(c4, w, bias, act='leaky_relu', want_idx=True, out_bf16=True):
     _lib.call('nimg_conv1_pool_fwd_c4', _p(c4), _p(w), _p(bias), _p(pooled), _p(idx), n, h, wd,
               LRELU_ALPHA if act == 'leaky_relu' else 1.0, 1 if out_bf16 else 0, _stream())
     return pooled, idx
+
+
+def conv1_wgrad_c4(c4, g, idx, dw=None, db=None, accumulate=False, side=False):
+    """Weight / bias gradient of conv1_pool_c4 from the pooled gradient g (already x LeakyReLU') and the arg-max bytes."""
+    if side and _SIDE['enabled'] and dw is not None:
+        with _on_side_stream(c4, g, idx):
+            return conv1_wgrad_c4(c4, g, idx, dw=dw, db=db, accumulate=accumulate, side=False)
+    _f32(dw, db)
+    _fb(g)
+    _chk(c4, idx)
+    n, h, wd, _ = c4.shape
+    if c4.dtype != torch.bfloat16 or tuple(g.shape) != (n, h // 2, wd // 2, 32) or tuple(idx.shape) != tuple(g.shape):
+        raise ValueError('conv1_wgrad_c4: (N,H,W,4) bf16 pixels and (N,H/2,W/2,32) gradient / arg-max tensors expected')
+    if dw is None:
+        dw = torch.empty((5, 5, 3, 32), dtype=torch.float32, device=c4.device)
+    need = _lib.load().nimg_conv1_wgrad_c4_workspace_bytes()
+    ws = (_ws_side if torch.cuda.current_stream(c4.device) == _SIDE['stream'] else _ws).get(need, c4.device)
+    _lib.call('nimg_conv1_wgrad_c4', _p(c4), _p(g), _p(idx), _p(dw), _p(db), n, h, wd, 1 if _is_bf16(g) else 0,
+              1 if accumulate else 0, _p(ws), ws.numel(), _stream())
+    return dw
+
+
+def conv1_dgrad_pooled(g, idx, w, out=None):
+    """Input gradient (N,H,W,3) of conv1_pool_c4 from the pooled gradient g (N,H/2,W/2,32) and the arg-max bytes."""
+    _f32(w, out)
+    _fb(g)
+    _chk(idx)
+    n, hp, wp, c = g.shape
+    if c != 32 or tuple(w.shape) != (5, 5, 3, 32) or tuple(idx.shape) != tuple(g.shape):
+        raise ValueError('conv1_dgrad_pooled: (N,H/2,W/2,32) gradient / arg-max tensors and a (5,5,3,32) kernel expected')
+    if out is None:
+        out = torch.empty((n, 2 * hp, 2 * wp, 3), dtype=torch.float32, device=g.device)
+    _lib.call('nimg_conv1_dgrad_pooled', _p(g), _p(idx), _p(w), _p(out), n, 2 * hp, 2 * wp, 1 if _is_bf16(g) else 0, _stream())
+    return out
 
 
 def cconv3_dgrad(dy, nf):

@@ -26,6 +26,7 @@ def golden():
 def _parity_mode_between_tests():
     """Every test starts in the float32 parity mode, whatever the previous one selected."""
     yield
-    ops = sys.modules.get('neural_imaging_amd.ops')
+    pkg = sys.modules.get('neural_imaging_amd')          # submodules are registered under the hyphenated package name
+    ops = getattr(pkg, 'ops', None)
     if ops is not None:
         ops.set_compute('f32')

@@ -476,6 +476,39 @@ def test_conv1_pool_front_end(dev, shape, out_bf16):
     assert i2 is None and np.abs(p2.float().cpu().numpy() - ref2).max() <= tol * max(1.0, np.abs(ref2).max())
 
 
+@pytest.mark.parametrize('shape,g_bf16', [((2, 16, 32), False), ((1, 24, 72), True), ((3, 64, 64), True), ((1, 10, 256), False),
+                                          ((2, 256, 256), True)])
+def test_conv1_wgrad_front_end(dev, shape, g_bf16):
+    """csrc/frontend.hip conv1_wgrad_pooled_kernel: weight + bias gradient of the FAN's first convolution from the pooled
+    gradient and the arg-max bytes, against float64 autograd on the same bf16-rounded operands (MaxPool2D routing restated)."""
+    from neural_imaging_amd import ops
+    n, h, w = shape
+    c = _bf16_round(rnd((n, h, w, 3), 21) * 2.0)
+    gp = _bf16_round(rnd((n, h // 2, w // 2, 32), 22))
+    k = np.random.default_rng(23).integers(0, 4, size=(n, h // 2, w // 2, 32)).astype(np.uint8)
+    dz = np.zeros((n, h, w, 32))
+    for pos in range(4):
+        dz[:, pos >> 1::2, pos & 1::2, :] = np.where(k == pos, gp.numpy(), 0.0)
+    wk = to64(rnd((5, 5, 3, 32), 24)).requires_grad_(True)
+    (T.conv2d(c, wk, None) * to64(dz)).sum().backward()
+    c4 = torch.ones((n, h, w, 4), dtype=torch.bfloat16, device=dev)
+    c4[..., :3] = c.to(torch.bfloat16).to(dev)
+    gd = gp.to(torch.bfloat16 if g_bf16 else torch.float32).to(dev).contiguous()
+    dw = torch.full((5, 5, 3, 32), 7.0, device=dev)
+    db = torch.full((32,), 7.0, device=dev)
+    ops.conv1_wgrad_c4(c4.contiguous(), gd, torch.from_numpy(k).to(dev), dw=dw, db=db)
+    assert_close(dw.cpu().numpy(), wk.grad.numpy(), 1e-6, 2e-5, what='conv1 dw')
+    assert_close(db.cpu().numpy(), dz.sum(axis=(0, 1, 2)), 1e-6, 2e-5, what='conv1 db')
+    ops.conv1_wgrad_c4(c4.contiguous(), gd, torch.from_numpy(k).to(dev), dw=dw, db=db, accumulate=True)
+    assert_close(dw.cpu().numpy(), 2 * wk.grad.numpy(), 1e-6, 4e-5, what='conv1 dw, accumulated')
+    # input gradient from the same pooled gradient (conv1_dgrad_pooled_kernel): autograd w.r.t. the image, bf16-rounded kernel
+    cx = c.clone().requires_grad_(True)
+    wb = _bf16_round(wk.detach().numpy())
+    (T.conv2d(cx, wb, None) * to64(dz)).sum().backward()
+    dc = ops.conv1_dgrad_pooled(gd, torch.from_numpy(k).to(dev), g(wk.detach().numpy(), dev))
+    assert_close(dc.cpu().numpy(), cx.grad.numpy(), 1e-6, 2e-5, what='conv1 input gradient')
+
+
 @pytest.mark.parametrize('name', ['gaussian', 'gaussian3', 'sharpen', 'sharpen_strong', 'resample50', 'resample73'])
 def test_manipulations_fwd_bwd(dev, name):
     from neural_imaging_amd.helpers import tf_helpers as th
