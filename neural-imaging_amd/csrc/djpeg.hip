@@ -26,6 +26,11 @@ constexpr int TILE_F = 3 * 8 * 72;        // transpose tiles: [ch][block][8][9]
 constexpr int WAVE_LDS_F = (STAGE_F > TILE_F ? STAGE_F : TILE_F);
 constexpr int WAVES_PER_BLOCK = 4;
 
+// Every LDS region of these kernels (staging rows, transpose tiles) is PRIVATE to one wave, and a wave's LDS operations
+// complete in issue order: what has to be prevented is only the compiler moving reads above writes.  A workgroup barrier here
+// would make four independent waves wait for each other twice per 8x8 transpose.
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+
 // 4-decimal DCT matrix, literal (models/jpeg.py:78-85)
 __device__ constexpr float kF[8][8] = {
     {0.3536f, 0.3536f, 0.3536f, 0.3536f, 0.3536f, 0.3536f, 0.3536f, 0.3536f},
@@ -134,12 +139,12 @@ __device__ __forceinline__ void transpose24(float* tile, int b, int r, float (&v
     for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int k = 0; k < 8; ++k) tile[((c * 8 + b) * 8 + r) * 9 + k] = v[c][k];
-    __syncthreads();
+    wave_sync();
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[c][k] = tile[((c * 8 + b) * 8 + k) * 9 + r];
-    __syncthreads();
+    wave_sync();
 }
 
 __device__ __forceinline__ float quantise(float u, int rounding) {
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(256) void djpeg_fwd_kernel(const float* __restrict_
     const bool active = t.valid && (t.x0 + b * 8 < w);
 
     load_strip(x, lds, t, h, w, lane);
-    __syncthreads();
+    wave_sync();
     float px[24];
     float v[3][8];
     if (active) {
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(256) void djpeg_fwd_kernel(const float* __restrict_
 #pragma unroll
         for (int c = 0; c < 3; ++c) dct_fwd8(ycc[c], v[c]);          // T[r][k] = sum_j b[r][j] F[k][j]
     }
-    __syncthreads();
+    wave_sync();
     transpose24(lds, b, r, v);                                       // lane now holds T[0..7][col r]
     if (active) {
 #pragma unroll
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(256) void djpeg_fwd_kernel(const float* __restrict_
         if (mask)
             *reinterpret_cast<uint2*>(mask + ((long)t.n * h + t.by * 8 + r) * w + t.x0 + b * 8) = make_uint2(mlo, mhi);
     }
-    __syncthreads();
+    wave_sync();
     store_strip(y, lds, t, h, w, lane);
 }
 
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(256) void djpeg_bwd_kernel(const float* __restrict_
 
     // ---- recompute the forward row pass from x
     load_strip(x, lds, t, h, w, lane);
-    __syncthreads();
+    wave_sync();
     if (active) {
         read_row24(lds, b, r, px);
         float ycc[3][8];
@@ -291,10 +296,10 @@ __global__ __launch_bounds__(256) void djpeg_bwd_kernel(const float* __restrict_
 #pragma unroll
         for (int c = 0; c < 3; ++c) dct_fwd8(ycc[c], tx[c]);
     }
-    __syncthreads();
+    wave_sync();
     // ---- gradient: clip mask, /255, transpose(colour_I), row pass (d xi = F^T dXd F  =>  dXd = F g F^T)
     load_strip(gy, lds, t, h, w, lane);
-    __syncthreads();
+    wave_sync();
     if (active) {
         read_row24(lds, b, r, px);
         const uint2 mm = *reinterpret_cast<const uint2*>(mask + ((long)t.n * h + t.by * 8 + r) * w + t.x0 + b * 8);
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(256) void djpeg_bwd_kernel(const float* __restrict_
 #pragma unroll
         for (int c = 0; c < 3; ++c) dct_fwd8(gq[c], tg[c]);
     }
-    __syncthreads();
+    wave_sync();
     transpose24(lds, b, r, tx);
     transpose24(lds, b, r, tg);
     if (active) {
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(256) void djpeg_bwd_kernel(const float* __restrict_
                     255.0f * (gb[0][j] * kCF[0][1 + c] + gb[1][j] * kCF[1][1 + c] + gb[2][j] * kCF[2][1 + c]);
         write_row24(lds, b, r, px);
     }
-    __syncthreads();
+    wave_sync();
     store_strip(gx, lds, t, h, w, lane);
 }
 
