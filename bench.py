@@ -106,11 +106,14 @@ class ChannelJPEG(Workload):
         raw, rgb = synthetic_batch(self.batch, self.args.raw_patch, seed=1234 + rank)
         self.bx, self.by = torch.from_numpy(raw).to(dev), torch.from_numpy(rgb).to(dev)
         kw = self.step_args()
-        if self.args.graph:
+        self.eager = lambda: self.wf.training_step(self.bx, self.by, **kw)
+        self.graph = False
+        if self.args.graph and world_size() == 1:          # the data-parallel step is not captured (RCCL launches stay eager)
             from neural_imaging_amd import graphs
             self.runner = graphs.CapturedStep(self.wf, self.bx, self.by, **kw)
+            self.graph = True
             return self.runner.step
-        return lambda: self.wf.training_step(self.bx, self.by, **kw)
+        return self.eager
 
     def finish(self):
         self.wf.check_nan()
@@ -154,15 +157,16 @@ class TrainDCN(Workload):
         ps = 2 * self.args.raw_patch
         self.dcn = compression.TwitterDCN(patch_size=ps, n_features=32, device=dev)
         self.x = torch.from_numpy(natural_images(self.batch, ps, ps, seed=1234 + rank)).to(dev)
-        self.last = None
-
-        def step():
-            self.last = self.dcn.training_step(self.x, learning_rate=1e-4, sync=False)
-            return self.last
-        return step
+        self.graph = False
+        self.eager = lambda: self.dcn.training_step(self.x, learning_rate=1e-4, sync=False)
+        return self.eager
 
     def dominant(self, dev):
         return time_conv3_dominant(dev, self.batch)
+
+
+def world_size():
+    return int(os.environ.get('WORLD_SIZE', '1'))
 
 
 WORKLOADS = {w.key: w for w in (ChannelJPEG, TrainDCN, ChannelDCN)}
@@ -367,7 +371,9 @@ def main():
                          'f32 = parity mode)')
     ap.add_argument('--no-parity-mode', action='store_true', help='skip the float32 parity-mode legs at N=1')
     ap.add_argument('--parity-steps', type=int, default=60, help='training steps of the accuracy-parity leg (0 = skip)')
-    ap.add_argument('--graph', action='store_true', help='replay the step from a captured HIP graph (c4 / c5)')
+    ap.add_argument('--no-graph', dest='graph', action='store_false',
+                    help='launch every kernel of the timed steps eagerly (default at N = 1: the step is captured once into a HIP '
+                         'graph and replayed - same kernels, same order, one launch call per step)')
     ap.add_argument('--backend', default=None, help='torch.distributed backend (default: nccl = RCCL); gloo is for a '
                                                      'functional check of the N>1 path on a one-GPU box')
     ap.add_argument('--single-device', action='store_true', help='functional check only: every rank uses cuda:0')
@@ -442,7 +448,7 @@ def main():
         cfg = {'workload': '{} = {}'.format(wl.key, wl.name), 'raw_patch': args.raw_patch, 'rgb_patch': 2 * args.raw_patch,
                'batch_per_gpu': wl.batch, 'global_batch': world * wl.batch, 'parallelism': 'dp%d' % world,
                'world_size': world, 'backend': torch.distributed.get_backend() if world > 1 else None,
-               'hip_graph': bool(args.graph), 'loss': loss,
+               'hip_graph': bool(getattr(wl, 'graph', False)), 'loss': loss,
                'achieved_tflops_whole_step': value * wl.gflop_per_unit / 1e3,
                'block_ms_per_step': [round(v, 4) for v in blocks], 'median_block_ms_per_step': float(np.median(blocks))}
         if wl.hbm_bytes_per_unit is not None:
@@ -462,15 +468,15 @@ def main():
                          'frac': dom['tflops'] / peak, 'traffic': dom['traffic'], 'kernel': dom['kernel'],
                          'ms_per_launch': dom['ms_per_launch'], 'flops_per_launch': dom['flops_per_launch']},
         }
-        if world == 1 and args.dtype == 'bf16' and not args.no_parity_mode and wl.key in ('c4', 'c5') and not args.graph:
-            _ops.set_compute('f32')                           # same step, exact float32 MFMA (the parity-test mode)
+        if world == 1 and args.dtype == 'bf16' and not args.no_parity_mode and wl.key in ('c4', 'c5'):
+            _ops.set_compute('f32')                           # same step, exact float32 MFMA (the parity-test mode), eager
             for _ in range(2):
-                step()
+                wl.eager()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             n32 = 5
             for _ in range(n32):
-                step()
+                wl.eager()
             torch.cuda.synchronize()
             dt32 = (time.perf_counter() - t1) / n32
             dom32 = wl.dominant(dev)

@@ -439,7 +439,7 @@ int launch_cconv(CConvParams p, hipStream_t s) {
     p.tiles_y = cdiv(p.H, TR);
     p.tiles_x = cdiv(p.W, TW);
     const long total = (long)p.N * p.tiles_y * p.tiles_x;
-    const long cap = 256L * (lds > 40000 ? 3 : 6);              // persistent: a few workgroups per CU
+    const long cap = 256L * (lds > 40000 ? 3 : (lds > 20000 ? 4 : 8));      // persistent: exactly the resident workgroups (LDS / VGPR bound)
     auto k = cconv_kernel<TPR, RPT>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)(total < cap ? total : cap)), dim3(256), lds, s, p.in, p.w, p.out_f32, p.out_c4, p);
@@ -619,7 +619,8 @@ __global__ __launch_bounds__(256) void conv1_wgrad_pooled_kernel(const void* __r
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int E_TR = 8, E_TW = 64, E_HR = E_TR + 4, E_HC = E_TW + 4;
 constexpr int E_DZ_BYTES = E_HR * E_HC * 64 + 12 * 64;                       // + slack: the last fragment over-reads 12 pixels
-constexpr int E_P_BYTES = E_HC * 64;                                         // per wave: [position][16] float32
+constexpr int E_PS = E_HC;                                                   // floats per P row: (4 kg + reg) * 68 = 16 kg + 4 reg
+constexpr int E_P_BYTES = 16 * E_PS * 4;                                     // (mod 32 banks) -> both accesses conflict-free
 
 template <bool GB>
 __global__ __launch_bounds__(256) void conv1_dgrad_pooled_kernel(const void* __restrict__ gp, const unsigned char* __restrict__ pidx,
@@ -715,18 +716,24 @@ __global__ __launch_bounds__(256) void conv1_dgrad_pooled_kernel(const void* __r
                     const bf16x8 b = *reinterpret_cast<const bf16x8*>(sZ + ((r + 4 - ky) * E_HC + q) * 64 + slot);
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ky], b, acc, 0, 0, 0);
                 }
-                // D: column = position q (lane & 15), rows m = 4 kg + reg
-                if (q < E_HC) *reinterpret_cast<f32x4*>(sP + q * 16 + 4 * kg) = acc;
+                // D: column = position q (lane & 15), rows m = 4 kg + reg -> P[m][q] (m-major: the 16 lanes of a row group write
+                // 16 consecutive floats, the two groups of a 32-lane pass sit 16 banks apart)
+                if (q < E_HC) {
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) sP[(4 * kg + reg) * E_PS + q] = acc[reg];
+                }
             }
             __builtin_amdgcn_wave_barrier();                             // sP is private to the wave: LDS ops complete in order
             const int oy = y0 + r;
+            // lane = output column x0 + lane, all three channels: every read is 64 consecutive floats of one P row
+            float o3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-            for (int it = 0; it < 3; ++it) {
-                const int o = lane + 64 * it, vi = o / 3, ci = o - 3 * vi;           // output column x0 + vi, channel ci
-                float sacc = 0.f;
+            for (int kx = 0; kx < 5; ++kx)
 #pragma unroll
-                for (int kx = 0; kx < 5; ++kx) sacc += sP[(vi + 4 - kx) * 16 + kx * 3 + ci];     // q = x + 2 - kx, tile col q + 2
-                if (oy < H && x0 + vi < W) dc[((long)(n * H + oy) * W + x0 + vi) * 3 + ci] = sacc;
+                for (int ci = 0; ci < 3; ++ci) o3[ci] += sP[(kx * 3 + ci) * E_PS + lane + 4 - kx];     // q = x + 2 - kx (+2 halo)
+            if (oy < H && x0 + lane < W) {
+                float* d = dc + ((long)(n * H + oy) * W + x0 + lane) * 3;
+                d[0] = o3[0]; d[1] = o3[1]; d[2] = o3[2];
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -740,7 +747,7 @@ int launch_conv1_pool(const void* c4, const float* w, const float* bias, void* p
                       int wd, float alpha, int out_bf16, hipStream_t s) {
     const int tiles_y = cdiv(h, 8), tiles_x = cdiv(wd, TWD);
     const long total = (long)n * tiles_y * tiles_x;
-    const long cap = 256L * (TWD > 64 ? 4 : 8);
+    const long cap = 256L * 3;                  // persistent: 3 workgroups per CU are resident (167 registers per lane)
     const dim3 grid((unsigned)(total < cap ? total : cap));
     if (out_bf16)
         hipLaunchKernelGGL((conv1_pool_fwd_kernel<TWD, true>), grid, dim3(256), 0, s, c4, w, bias, pooled, pidx, n, h, wd, alpha,
