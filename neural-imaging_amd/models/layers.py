@@ -108,8 +108,10 @@ class ConstrainedConv2D(object):
         return (c4 if c4_only else y), nf
 
     def backward_params(self, store, x, dy):
-        dnf = ops.conv2d_wgrad(x, dy, 5, pads=(2, 2), pad_mode=1)
-        ops.constrained_kernel_bwd(store.p[self.name + '/kernel'], dnf, store.g[self.name + '/kernel'], self.strength)
+        # on the side stream like every other parameter gradient (it only needs x and dy; the input gradient runs beside it)
+        with ops.side_stream(x, dy):
+            dnf = ops.conv2d_wgrad(x, dy, 5, pads=(2, 2), pad_mode=1)
+            ops.constrained_kernel_bwd(store.p[self.name + '/kernel'], dnf, store.g[self.name + '/kernel'], self.strength)
 
     def backward_input(self, nf, dy):
         # correlation with the flipped filter + the terms the SYMMETRIC pad folds back onto the image border

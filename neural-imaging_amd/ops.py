@@ -182,6 +182,21 @@ class _on_side_stream(object):
         return self.ctx.__exit__(*exc)
 
 
+class side_stream(object):
+    """with side_stream(t1, t2, ...): launches inside run on the side stream (after everything queued so far on the launch
+    stream; the tensors are pinned against early reuse), or in place when the side stream is disabled.  Tensors ALLOCATED
+    inside belong to the side stream's pool - keep them local to the block."""
+
+    def __init__(self, *tensors):
+        self.ctx = _on_side_stream(*tensors) if _SIDE['enabled'] else None
+
+    def __enter__(self):
+        return self.ctx.__enter__() if self.ctx is not None else None
+
+    def __exit__(self, *exc):
+        return self.ctx.__exit__(*exc) if self.ctx is not None else False
+
+
 def join_side_stream():
     """Make the current stream wait for the parameter-gradient kernels launched on the side stream."""
     if _SIDE['dirty'] and _SIDE['stream'] is not None:
