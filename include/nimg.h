@@ -266,6 +266,19 @@ int nimg_isp_residual_bwd(const float* dy, const float* f, const float* alpha, f
 /* Dropout of the FAN's hidden Dense layers at training time (models/forensics.py:88), forward and backward alike:
  * y = keep[i] ? x[i] * scale : 0, keep = the Bernoulli(1 - rate) mask bytes, scale = 1 / (1 - rate). */
 int nimg_mask_scale(const float* x, const uint8_t* keep, float* y, long count, float scale, void* stream);
+/* Backward of the FAN's fused conv + LeakyReLU + MaxPool2D layers conv2..4 (models/forensics.py:73-77) straight from the POOLED
+ * gradient g (bf16, already x LeakyReLU') and the arg-max bytes: the MaxPool2D routing is applied while the kernels stage their
+ * tiles, so the full-resolution gradient (4x the bytes, 3/4 zeros) is never written nor re-read.  5x5, stride 1, SAME.
+ *   _fwd_bf16_unpool:   input gradient = convolution of the un-pooled g with wb = nimg_conv_weights_bf16(w, mode 1); arguments as
+ *                       nimg_conv2d_fwd_bf16_ex with (h, wd) the FULL resolution; flags may add NIMG_BF16_OUT / NIMG_BF16_MASK
+ *   _wgrad_bf16_unpool: dw (5,5,cin,cout) / db (cout) from the layer input `in` (n,h,wd,cin) bf16 and (g, idx) */
+int nimg_conv2d_fwd_bf16_unpool(const void* in_pooled, const unsigned char* in_idx, int c1, const void* wb, const float* bias,
+                                float* out1, int o1, const float* act_mask, int n, int h, int w_, int ks, int pad_t, int pad_l,
+                                int hout, int wout, int act, float alpha, int flags, void* stream);
+int nimg_conv2d_wgrad_bf16_unpool(const void* in, int cin, const void* g, const unsigned char* idx, int cout, float* dw, float* db,
+                                  int n, int h, int w_, int ks, int accumulate, void* workspace, size_t workspace_bytes,
+                                  void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * FAN front end (csrc/frontend.hip): ConstrainedConv2D, models/layers.py:56-57 (tf.pad SYMMETRIC + VALID conv2d) and the
  * first FAN convolution, models/forensics.py:69-70, as row-band kernels (float32 VALU stencil / bf16 MFMA).

@@ -119,6 +119,8 @@ struct ConvParamsB {
     float alpha;
     int convt;            // 1: Conv2DTranspose(2x2, stride 2) as four 1x1 products; workgroup id & 3 = output phase (dy, dx)
     int flags;            // NIMG_BF16_IN: in1 holds bf16 (C2 == 0); _OUT: out1 / pool_out are bf16; _MASK: act1 is bf16
+    const unsigned char* in_idx;   // UNP kernels: in1 is the POOLED tensor (N, H/2, W/2, C1) bf16 and in_idx its arg-max bytes;
+                                   // the convolution runs on their 2x2 un-pooling (H x W), built while staging
 };
 
 // INB: in1 is stored as bf16 (compile-time: a run-time branch around the prefetch loads makes the backend wait for them at
@@ -128,9 +130,23 @@ struct ConvParamsB {
 // out-of-range offsets that the hardware answers with zeros.  hipcc wraps every predicated flat load in s_and_saveexec /
 // branch / zero-fill / 64-bit address arithmetic (~9 instructions x 17 loads per thread and chunk, issued in front of the
 // MFMA loop); a buffer load is one instruction.
-template <int KS, int STRIDE, int TH, int TW, int NB, int TN, bool INB, bool BUF = false>
+// UNP (with BUF): in1 is a POOLED gradient + arg-max bytes; a halo pixel (y, x) reads pooled pixel (y/2, x/2) and keeps channel
+// c iff argmax == 2 (y & 1) + (x & 1) - the MaxPool2D routing as a packed byte-mask operation on the staged 16 bytes, so the
+// full-resolution gradient (4x the bytes, 3/4 of them zeros) is never written to HBM nor read back.
+__device__ __forceinline__ unsigned unp_eq_bytes(unsigned k, unsigned pos) {          // 0xFF in every byte of k equal to pos
+    const unsigned x = k ^ (pos * 0x01010101u);
+    return (((x | (x >> 1)) & 0x01010101u) ^ 0x01010101u) * 0xFFu;
+}
+__device__ __forceinline__ uint4 unp_route(uint4 g, unsigned k0, unsigned k1, unsigned pos) {
+    const unsigned m0 = unp_eq_bytes(k0, pos), m1 = unp_eq_bytes(k1, pos);
+    return make_uint4(g.x & __builtin_amdgcn_perm(m0, m0, 0x01010000u), g.y & __builtin_amdgcn_perm(m0, m0, 0x03030202u),
+                      g.z & __builtin_amdgcn_perm(m1, m1, 0x01010000u), g.w & __builtin_amdgcn_perm(m1, m1, 0x03030202u));
+}
+
+template <int KS, int STRIDE, int TH, int TW, int NB, int TN, bool INB, bool BUF = false, bool UNP = false>
 __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p) {
     constexpr int CK = 16;
+    static_assert(!UNP || (INB && BUF && STRIDE == 1), "un-pooling input: bf16 buffer-load path only");
     constexpr int THH = (TH - 1) * STRIDE + KS, TWH = (TW - 1) * STRIDE + KS;
     constexpr int NPIXH = NB * THH * TWH;
     constexpr int MFRAGS = NB * TH * TW / 32, NFRAGS = TN / 32;
@@ -188,6 +204,9 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
     // resolve it ONCE per workgroup.  Left inside fetch() it was ~700 instructions of branchy address arithmetic per
     // chunk in front of every MFMA loop (in-order issue: as long as the 100 MFMAs themselves).
     int apix[AP];
+    unsigned upos[UNP ? AP : 1];                         // UNP: position of the halo pixel inside its 2x2 pooling window
+    typedef unsigned int u32x2k __attribute__((ext_vector_type(2)));
+    u32x2k preK[UNP ? AP : 1];                           // UNP: the 8 arg-max bytes of the staged 8 channels
 #pragma unroll
     for (int q = 0; q < AP; ++q) {
         const int item = tid + q * 256;
@@ -196,7 +215,12 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
         int gy = iy0 + rem / TWH, gx = ix0 + rem % TWH;
         const int n = grp * NB + img;
         const bool ok = item < NPIXH * 2 && n < p.N && map_coord(gy, p.H, p.pad_mode) && map_coord(gx, p.W, p.pad_mode);
-        apix[q] = ok ? (n * p.H + gy) * p.W + gx : -1;
+        if constexpr (UNP) {
+            apix[q] = ok ? (n * (p.H >> 1) + (gy >> 1)) * (p.W >> 1) + (gx >> 1) : -1;
+            upos[q] = (unsigned)(((gy & 1) << 1) | (gx & 1));
+        } else {
+            apix[q] = ok ? (n * p.H + gy) * p.W + gx : -1;
+        }
     }
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     unsigned aoff[AP];                                   // BUF: byte offset of this thread's 16 B inside the input tensor
@@ -213,13 +237,20 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
     auto fetch = [&](int c0) {
         if constexpr (BUF) {
             const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float*>(p.in1), 0, (int)((long)p.N * p.H * p.W * p.C1 * 2), 0x00020000);
+                const_cast<float*>(p.in1), 0, (int)(((long)p.N * p.H * p.W * p.C1 * 2) >> (UNP ? 2 : 0)), 0x00020000);
             const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<__bf16*>(p.wb), 0, (int)((long)(p.CinP >> 4) * TAPS * 16 * Cout * 2), 0x00020000);
 #pragma unroll
             for (int q = 0; q < AP; ++q) {
                 const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, aoff[q], c0 * 2, 0);
                 preA[q][0] = *reinterpret_cast<const float4*>(&v);
+            }
+            if constexpr (UNP) {
+                const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<unsigned char*>(p.in_idx), 0, (int)(((long)p.N * p.H * p.W * p.C1) >> 2), 0x00020000);
+#pragma unroll
+                for (int q = 0; q < AP; ++q)        // byte offsets are half the bf16 offsets; padding stays out of range
+                    preK[q] = __builtin_amdgcn_raw_buffer_load_b64(rk, aoff[q] >= 0x80000000u ? 0x80000000u : aoff[q] >> 1, c0, 0);
             }
             const int chunk_base = (c0 >> 4) * (TAPS * 16 * 2) * Cout, qstride = (128 / TN) * Cout * 32;
 #pragma unroll
@@ -268,6 +299,7 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
                 uint4 packed;
                 if constexpr (INB) {
                     packed = *reinterpret_cast<const uint4*>(&preA[q][0]);
+                    if constexpr (UNP) packed = unp_route(packed, preK[q][0], preK[q][1], upos[q]);
                 } else {
                     const float f[8] = {preA[q][0].x, preA[q][0].y, preA[q][0].z, preA[q][0].w,
                                         preA[q][1].x, preA[q][1].y, preA[q][1].z, preA[q][1].w};
@@ -413,7 +445,8 @@ int launch_conv_b(const ConvParamsB& p, hipStream_t stream) {
     if constexpr (INB && !BUF && KS == 5 && STRIDE == 1 && 128 % TN == 0) {
         static const bool no_buf = getenv("NIMG_NO_BUFFER_LOADS") != nullptr;
         const int Cin = p.C1 + p.C2, Cout = p.O1 + p.O2;
-        const long in_bytes = (long)p.N * p.H * p.W * p.C1 * 2, w_bytes = (long)(p.CinP >> 4) * KS * KS * 16 * Cout * 2;
+        const long in_bytes = ((long)p.N * p.H * p.W * p.C1 * 2) >> (p.in_idx ? 2 : 0);
+        const long w_bytes = (long)(p.CinP >> 4) * KS * KS * 16 * Cout * 2;
         if (!no_buf && p.C2 == 0 && Cin % 16 == 0 && Cout % TN == 0 && !p.convt && in_bytes < (1l << 31) - 65536 &&
             w_bytes < (1l << 31) - 65536)
             return launch_conv_b<KS, STRIDE, TH, TW, NB, TN, true, true>(p, stream);
@@ -429,6 +462,10 @@ int launch_conv_b(const ConvParamsB& p, hipStream_t stream) {
     q.tiles_x = cdiv(p.Wout, TW);
     const long blocks = (long)cdiv(p.O1 + p.O2, TN) * q.tiles_y * q.tiles_x * cdiv(p.N, NB) * (p.convt ? 4 : 1);
     auto kern = conv_fwd_bf16_kernel<KS, STRIDE, TH, TW, NB, TN, INB, BUF>;
+    if (p.in_idx) {                     // the input is a pooled tensor + arg-max bytes: only the buffer-load variants un-pool
+        if constexpr (INB && BUF && STRIDE == 1) kern = conv_fwd_bf16_kernel<KS, STRIDE, TH, TW, NB, TN, true, true, true>;
+        else return NIMG_ERR_ARG;
+    }
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, q);
     NIMG_CHECK_LAUNCH();
@@ -505,8 +542,11 @@ constexpr int B_ZS = 192;      // dz tile row stride in bytes (64 co bf16 = 128 
 // registers (one wave per SIMD, nothing to hide LDS / barrier latency behind) - with 8 it is 4 taps = 128, two per SIMD.
 // TH = output rows per staged tile (8, or 16 for 5x5: the per-tile staging overhead - ~500 instructions of address
 // arithmetic, converts and LDS writes - is then amortised over twice as many MFMAs)
-template <int KS, int STRIDE, int NW, bool INB, bool DZB, int TH>
+// UNP (with DZB): dz is the POOLED gradient (N, Hout/2, Wout/2, Cout) bf16 and p.dz_idx its arg-max bytes; the 2x2 un-pooling
+// happens while the dz tile is staged (unp_route: packed byte masks), the full-resolution gradient never exists in HBM.
+template <int KS, int STRIDE, int NW, bool INB, bool DZB, int TH, bool UNP = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const WgradParamsB p) {
+    static_assert(!UNP || (DZB && STRIDE == 1), "un-pooling dz: bf16-stored pooled gradient, stride 1");
     constexpr int TAPS = KS * KS, NT = (TAPS + NW - 1) / NW, NTHR = NW * 64;
     constexpr int THH = (TH - 1) * STRIDE + KS, TWH = (B_TW - 1) * STRIDE + KS;
     constexpr int NPIXH = THH * TWH, NPIX = TH * B_TW;
@@ -545,6 +585,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const Wgrad
     constexpr int IP = (NPIXH * 4 + NTHR - 1) / NTHR, ZP = (NPIX * 8) / NTHR;
     static_assert((NPIX * 8) % NTHR == 0, "dz tile must divide over the threads");
     float4 preI[IP][2], preZ[ZP][2];
+    uint2 preZK[UNP ? ZP : 1];
     auto fetch = [&](int wk_) {
         const int n_ = (int)(wk_ / tiles), tile_ = (int)(wk_ % tiles);
         const int ty_ = (tile_ / p.tiles_x) * TH, tx_ = (tile_ % p.tiles_x) * B_TW;
@@ -572,8 +613,11 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const Wgrad
             const int pix = item >> 3, c = co0 + (item & 7) * 8;
             const int oy = ty_ + pix / B_TW, ox = tx_ + pix % B_TW;
             preZ[q][0] = preZ[q][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (UNP) preZK[q] = make_uint2(0xffffffffu, 0xffffffffu);
             if (oy < p.Hout && ox < p.Wout && c < p.Cout) {
-                const long zo = (((long)n_ * p.Hout + oy) * p.Wout + ox) * p.Cout + c;
+                const long zo = UNP ? (((long)n_ * (p.Hout >> 1) + (oy >> 1)) * (p.Wout >> 1) + (ox >> 1)) * p.Cout + c
+                                    : (((long)n_ * p.Hout + oy) * p.Wout + ox) * p.Cout + c;
+                if constexpr (UNP) preZK[q] = *reinterpret_cast<const uint2*>(p.dz_idx + zo);
                 if constexpr (DZB) {                 // Cout % 8 == 0 (entry point)
                     preZ[q][0] = *reinterpret_cast<const float4*>(reinterpret_cast<const __bf16*>(p.dz) + zo);
                 } else {
@@ -608,7 +652,14 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const Wgrad
             float f[8];
             bf16x8 b;
             if constexpr (DZB) {
-                b = *reinterpret_cast<const bf16x8*>(&preZ[q][0]);
+                if constexpr (UNP) {                 // route: keep a channel iff this pixel was its window's arg-max
+                    const int pix_ = item >> 3;      // tile origin (ty, tx) is even: the window position is the pixel's parity
+                    const unsigned pos = (unsigned)((((pix_ / B_TW) & 1) << 1) | ((pix_ % B_TW) & 1));
+                    const uint4 routed = unp_route(*reinterpret_cast<const uint4*>(&preZ[q][0]), preZK[q].x, preZK[q].y, pos);
+                    b = *reinterpret_cast<const bf16x8*>(&routed);
+                } else {
+                    b = *reinterpret_cast<const bf16x8*>(&preZ[q][0]);
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] = (float)b[e];
             } else {
@@ -712,7 +763,7 @@ int nimg_conv_weights_bf16_batch(const void* table, int n_entries, void* stream)
 static int conv2d_fwd_bf16_impl(const float* in1, int c1, const float* in2, int c2, const void* wb, const float* bias,
                          float* out1, int o1, float* out2, int o2, const float* act_mask, int n, int h, int wd,
                          int ks, int stride, int pad_t, int pad_l, int pad_mode, int hout, int wout, int act,
-                         float alpha, int flags, void* stream) {
+                         float alpha, int flags, void* stream, const unsigned char* in_idx = nullptr) {
     if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!in1 || !wb || !out1 || c1 <= 0 || c2 < 0 || o1 <= 0 || o2 < 0 || n < 0 || h <= 0 || wd <= 0) return NIMG_ERR_ARG;
     if ((c2 > 0 && !in2) || (o2 > 0 && !out2) || hout <= 0 || wout <= 0 || pad_t < 0 || pad_l < 0) return NIMG_ERR_ARG;
@@ -721,8 +772,9 @@ static int conv2d_fwd_bf16_impl(const float* in1, int c1, const float* in2, int 
     if (n == 0) return NIMG_OK;
     ConvParamsB p;
     p.in1 = in1; p.in2 = in2; p.wb = (const __bf16*)wb; p.bias = bias; p.out1 = out1; p.out2 = out2; p.act1 = act_mask;
-    p.pool_out = nullptr; p.pool_idx = nullptr; p.convt = 0; p.flags = flags;
+    p.pool_out = nullptr; p.pool_idx = nullptr; p.convt = 0; p.flags = flags; p.in_idx = in_idx;
     if ((flags & NIMG_BF16_IN) && c2 != 0) return NIMG_ERR_ARG;
+    if (in_idx && (!(flags & NIMG_BF16_IN) || stride != 1 || ks != 5 || (h & 1) || (wd & 1) || pad_mode != 0)) return NIMG_ERR_ARG;
     if ((flags & (NIMG_BF16_OUT | NIMG_BF16_MASK)) && (o2 != 0 || (o1 & 3))) return NIMG_ERR_ARG;
     p.C1 = c1; p.C2 = c2; p.O1 = o1; p.O2 = o2; p.CinP = (c1 + c2 + 15) / 16 * 16;
     p.N = n; p.H = h; p.W = wd; p.Hout = hout; p.Wout = wout; p.pad_t = pad_t; p.pad_l = pad_l;
@@ -752,6 +804,19 @@ int nimg_conv2d_fwd_bf16_ex(const float* in1, int c1, const float* in2, int c2, 
                                 pad_mode, hout, wout, act, alpha, flags, stream);
 }
 
+/* The same convolution on the 2x2 UN-POOLING of a pooled bf16 tensor: in_pooled (n, h/2, wd/2, c1) bf16 + in_idx arg-max bytes
+ * stand for the (n, h, wd, c1) tensor that holds in_pooled[y/2][x/2][c] where in_idx[y/2][x/2][c] == 2 (y & 1) + (x & 1) and zero
+ * elsewhere (the gradient MaxPool2D hands back).  Used as the input-gradient pass of the FAN's fused conv + pool layers: the
+ * full-resolution gradient never exists in HBM.  5x5, stride 1, zero padding, c1 % 16 == 0, cout % 32 == 0 (else NIMG_ERR_ARG:
+ * un-pool explicitly with nimg_maxpool2_unpool_ex and call nimg_conv2d_fwd_bf16_ex). */
+int nimg_conv2d_fwd_bf16_unpool(const void* in_pooled, const unsigned char* in_idx, int c1, const void* wb, const float* bias,
+                                float* out1, int o1, const float* act_mask, int n, int h, int wd, int ks, int pad_t, int pad_l,
+                                int hout, int wout, int act, float alpha, int flags, void* stream) {
+    if (!in_idx) return NIMG_ERR_ARG;
+    return conv2d_fwd_bf16_impl((const float*)in_pooled, c1, nullptr, 0, wb, bias, out1, o1, nullptr, 0, act_mask, n, h, wd, ks, 1,
+                                pad_t, pad_l, 0, hout, wout, act, alpha, flags | NIMG_BF16_IN, stream, in_idx);
+}
+
 /* Conv2DTranspose(cout, 2x2, stride 2) forward (pipelines.py:205) on the matrix core: four 1x1 products, one per output
  * phase (dy, dx), in a single launch.  wb = nimg_conv_weights_bf16(w, 2, 2, cin'=cout, cout'=cin, mode 1) of the Keras
  * kernel (2,2,Cout,Cin).  x (n,h,wd,cin) -> y (n,2h,2wd,cout). */
@@ -762,7 +827,7 @@ int nimg_convt2x2_fwd_bf16(const float* x, const void* wb, const float* bias, fl
     if (n == 0) return NIMG_OK;
     ConvParamsB p;
     p.in1 = x; p.in2 = nullptr; p.wb = (const __bf16*)wb; p.bias = bias; p.out1 = y; p.out2 = nullptr; p.act1 = nullptr;
-    p.pool_out = nullptr; p.pool_idx = nullptr; p.convt = 1; p.flags = 0;
+    p.pool_out = nullptr; p.pool_idx = nullptr; p.convt = 1; p.flags = 0; p.in_idx = nullptr;
     p.C1 = cin; p.C2 = 0; p.O1 = cout; p.O2 = 0; p.CinP = (cin + 15) / 16 * 16;
     p.N = n; p.H = h; p.W = wd; p.Hout = h; p.Wout = wd; p.pad_t = 0; p.pad_l = 0;
     p.tiles_y = p.tiles_x = 0; p.act = 0; p.pad_mode = 0; p.alpha = 0.f;
@@ -796,7 +861,9 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
     if ((flags & NIMG_BF16_IN) && (c2 != 0 || (c1 & 7))) return NIMG_ERR_ARG;
     if ((flags & NIMG_BF16_DZ) && (cout & 7)) return NIMG_ERR_ARG;
     if (flags && !dz_idx && c2 == 0 && c1 <= 4) return NIMG_ERR_ARG;        /* the packed / tiny kernels stage float32 */
-    if (dz_idx && (flags & ~NIMG_BF16_DZ)) return NIMG_ERR_ARG;
+    if (dz_idx && c1 <= 4 && (flags & ~NIMG_BF16_DZ)) return NIMG_ERR_ARG;
+    if (dz_idx && c1 > 4 && (flags != (NIMG_BF16_IN | NIMG_BF16_DZ) || stride != 1 || ks != 5 || (hout & 1) || (wout & 1)))
+        return NIMG_ERR_ARG;         /* un-pooling dz in the generic kernel: bf16-stored operands of the FAN's 5x5 layers */
     if (!in1 || !dz || !dw || c1 <= 0 || c2 < 0 || cout <= 0 || n <= 0 || h <= 0 || wd <= 0) return NIMG_ERR_ARG;
     if ((c2 > 0 && !in2) || hout <= 0 || wout <= 0 || !workspace || pad_mode < 0 || pad_mode > 2) return NIMG_ERR_ARG;
     const int cin = c1 + c2;
@@ -847,7 +914,7 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
     }
     if ((c1 % 4) || (c2 % 4) || (cout % 4) || (c2 > 0 && (c1 % 8))) return NIMG_ERR_ARG;
     WgradParamsB p;
-    p.in1 = in1; p.in2 = in2; p.dz = dz; p.dz_idx = nullptr; p.partial = (float*)workspace; p.db_partial = nullptr;
+    p.in1 = in1; p.in2 = in2; p.dz = dz; p.dz_idx = dz_idx; p.partial = (float*)workspace; p.db_partial = nullptr;
     p.flags = flags;
     p.C1 = c1; p.C2 = c2; p.Cout = cout; p.N = n; p.H = h; p.W = wd; p.Hout = hout; p.Wout = wout;
     p.pad_t = pad_t; p.pad_l = pad_l; p.pad_mode = pad_mode;
@@ -866,6 +933,10 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
         constexpr size_t lds_t = (size_t)THH * TWH * 64 + (size_t)TH_ * B_TW * B_ZS;                          \
         constexpr size_t lds = lds_t > (size_t)NW_ * 64 * 8 * 4 ? lds_t : (size_t)NW_ * 64 * 8 * 4;          \
         auto k = conv_wgrad_bf16_kernel<KS_, ST_, NW_, INB_, DZB_, TH_>;                                      \
+        if (p.dz_idx) {                                                                                       \
+            if constexpr (DZB_ && ST_ == 1 && KS_ == 5) k = conv_wgrad_bf16_kernel<KS_, ST_, NW_, INB_, true, TH_, true>;    \
+            else return NIMG_ERR_ARG;                                                                         \
+        }                                                                                                     \
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
         hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NW_ * 64), lds, s, p);                             \
     } while (0)
@@ -909,6 +980,17 @@ int nimg_conv2d_wgrad_bf16_ex(const float* in1, int c1, const float* in2, int c2
                               void* stream) {
     return wgrad_bf16_impl(in1, c1, in2, c2, dz, nullptr, cout, dw, db, n, h, wd, ks, stride, pad_t, pad_l, pad_mode, hout,
                            wout, accumulate, workspace, workspace_bytes, flags, stream);
+}
+
+/* Weight (+bias) gradient of a fused conv + pool layer with MANY input channels (the FAN's conv2..4, 5x5, stride 1, SAME) from
+ * the POOLED gradient: in (n,h,wd,cin) bf16, g (n,h/2,wd/2,cout) bf16 already multiplied by LeakyReLU', idx its arg-max bytes.
+ * The 2x2 un-pooling happens while the gradient tile is staged.  cin % 8 == 0, cout % 8 == 0, h, wd even. */
+int nimg_conv2d_wgrad_bf16_unpool(const void* in, int cin, const void* g, const unsigned char* idx, int cout, float* dw, float* db,
+                                  int n, int h, int wd, int ks, int accumulate, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+    if (!idx || ks != 5 || (h & 1) || (wd & 1)) return NIMG_ERR_ARG;
+    return wgrad_bf16_impl((const float*)in, cin, nullptr, 0, (const float*)g, idx, cout, dw, db, n, h, wd, ks, 1, 2, 2, 0, h, wd,
+                           accumulate, workspace, workspace_bytes, NIMG_BF16_IN | NIMG_BF16_DZ, stream);
 }
 
 /* Weight (+bias) gradient of a fused conv+pool layer (nimg_conv2d_pool_fwd_bf16) with few input channels (cin 3|4):
@@ -1488,7 +1570,7 @@ int nimg_conv2d_pool_fwd_bf16_ex(const float* in, int cin, const float* w, const
     if (!wb || (cin % 8)) return NIMG_ERR_ARG;
     ConvParamsB p;
     p.in1 = in; p.in2 = nullptr; p.wb = (const __bf16*)wb; p.bias = bias; p.out1 = nullptr; p.out2 = nullptr;
-    p.act1 = nullptr; p.pool_out = pool_out; p.pool_idx = pool_idx; p.convt = 0; p.flags = flags;
+    p.act1 = nullptr; p.pool_out = pool_out; p.pool_idx = pool_idx; p.convt = 0; p.flags = flags; p.in_idx = nullptr;
     p.C1 = cin; p.C2 = 0; p.O1 = cout; p.O2 = 0; p.CinP = (cin + 15) / 16 * 16;
     p.N = n; p.H = h; p.W = wd; p.Hout = h; p.Wout = wd; p.pad_t = p.pad_l = (ks - 1) / 2;
     p.tiles_y = p.tiles_x = 0; p.act = act; p.pad_mode = 0; p.alpha = alpha;

@@ -10,6 +10,7 @@
 // This file is compiled with -fno-slp-vectorize (csrc/Makefile): the stencil wants v_fmac_f32 v, s, v; hipcc's SLP pass
 // otherwise builds v_pk_fma_f32 pairs with a v_mov per operand (gfx950's VALU already retires one f32 FMA per lane and clock,
 // so the packed form buys nothing and the moves cost issue slots).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -439,7 +440,8 @@ int launch_cconv(CConvParams p, hipStream_t s) {
     p.tiles_y = cdiv(p.H, TR);
     p.tiles_x = cdiv(p.W, TW);
     const long total = (long)p.N * p.tiles_y * p.tiles_x;
-    const long cap = 256L * (lds > 40000 ? 3 : (lds > 20000 ? 4 : 8));      // persistent: exactly the resident workgroups (LDS / VGPR bound)
+    static const int capmul = getenv("NIMG_CCONV_CAP") ? atoi(getenv("NIMG_CCONV_CAP")) : 0;
+    const long cap = 256L * (capmul > 0 ? capmul : (lds > 40000 ? 3 : (lds > 20000 ? 4 : 8)));   // persistent: the resident workgroups
     auto k = cconv_kernel<TPR, RPT>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)(total < cap ? total : cap)), dim3(256), lds, s, p.in, p.w, p.out_f32, p.out_c4, p);
@@ -747,7 +749,8 @@ int launch_conv1_pool(const void* c4, const float* w, const float* bias, void* p
                       int wd, float alpha, int out_bf16, hipStream_t s) {
     const int tiles_y = cdiv(h, 8), tiles_x = cdiv(wd, TWD);
     const long total = (long)n * tiles_y * tiles_x;
-    const long cap = 256L * 3;                  // persistent: 3 workgroups per CU are resident (167 registers per lane)
+    static const int capmul = getenv("NIMG_CONV1_CAP") ? atoi(getenv("NIMG_CONV1_CAP")) : 0;
+    const long cap = 256L * (capmul > 0 ? capmul : 3);       // persistent: 3 workgroups per CU are resident (167 registers per lane)
     const dim3 grid((unsigned)(total < cap ? total : cap));
     if (out_bf16)
         hipLaunchKernelGGL((conv1_pool_fwd_kernel<TWD, true>), grid, dim3(256), 0, s, c4, w, bias, pooled, pidx, n, h, wd, alpha,
@@ -843,7 +846,12 @@ int nimg_cconv3(const float* in, const float* w, float* out_f32, void* out_c4, i
         p.in = in + px0 * 3; p.w = w; p.out_f32 = out_f32 ? out_f32 + px0 * 3 : nullptr;
         p.out_c4 = out_c4 ? (uint2*)out_c4 + px0 : nullptr;
         p.N = n - n0 < chunk ? n - n0 : chunk; p.H = h; p.W = wd; p.pad_mode = pad_mode; p.tiles_y = p.tiles_x = 0;
-        const int rc = wd > 96 ? launch_cconv<64, 2>(p, (hipStream_t)stream) : launch_cconv<16, 1>(p, (hipStream_t)stream);
+        static const int variant = getenv("NIMG_CCONV_VARIANT") ? atoi(getenv("NIMG_CCONV_VARIANT")) : 0;   // timing experiments
+        const int rc = wd <= 96 ? launch_cconv<16, 1>(p, (hipStream_t)stream)
+                     : variant == 1 ? launch_cconv<64, 1>(p, (hipStream_t)stream)
+                     : variant == 2 ? launch_cconv<64, 4>(p, (hipStream_t)stream)
+                     : variant == 3 ? launch_cconv<32, 2>(p, (hipStream_t)stream)
+                                    : launch_cconv<64, 2>(p, (hipStream_t)stream);
         if (rc != NIMG_OK) return rc;
     }
     return NIMG_OK;

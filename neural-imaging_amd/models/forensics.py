@@ -220,6 +220,14 @@ class FAN(TFModel):
                                             db=P.g[conv.name + '/bias'], side=True)
                     d_pool = ops.conv2d_dgrad_pooled(d_pool, t['idx{}'.format(i)], P.p[conv.name + '/kernel'])
                 continue
+            if fused(i) and ops.unpool_fold_ok(inp, d_pool, conv.cin, conv.cout, conv.ks):
+                # throughput mode, 5x5 layers: both gradient kernels read (pooled gradient, arg-max bytes) and route while
+                # staging - the full-resolution gradient (4x the bytes, 3/4 zeros) is never written nor re-read
+                ops.conv2d_wgrad_unpool(inp, d_pool, t['idx{}'.format(i)], conv.ks, dw=P.g[conv.name + '/kernel'],
+                                        db=P.g[conv.name + '/bias'], side=True)
+                d_pool = ops.conv2d_dgrad_unpool(d_pool, t['idx{}'.format(i)], P.p[conv.name + '/kernel'], act_mask=prev_mask,
+                                                 out_bf16=g_bf16(i - 1))
+                continue
             if fused(i):
                 # throughput mode: the un-pooled gradient only feeds bf16 MFMA kernels - store it as bf16 (same bits)
                 as_bf16 = ops.COMPUTE == 'bf16' and ops.STORE_BF16 and conv.cout % 8 == 0 and conv.cin % 8 == 0

@@ -475,6 +475,49 @@ def maxpool2_unpool(dp, idx, pooled, apply_mask=True, out=None, out_bf16=False):
     return out
 
 
+# The FAN's conv2..4 backward reads the pooled gradient directly (un-pooled while staging); NIMG_NO_UNPOOL_FOLD=1 materialises
+# the full-resolution gradient first (A/B runs).
+UNPOOL_FOLD = _os.environ.get('NIMG_NO_UNPOOL_FOLD') is None
+
+
+def unpool_fold_ok(x, g, cin, cout, ks):
+    """True when the 5x5 backward kernels can take (pooled gradient, arg-max bytes) instead of the un-pooled gradient."""
+    return UNPOOL_FOLD and COMPUTE == 'bf16' and ks == 5 and _is_bf16(x) and _is_bf16(g) and cin % 16 == 0 and \
+        cout % 64 == 0 and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0
+
+
+def conv2d_dgrad_unpool(g, idx, w, act_mask=None, out_bf16=False):
+    """Input gradient of a fused 5x5 conv + pool layer from the pooled gradient g (N,H/2,W/2,Cout) bf16 + arg-max bytes."""
+    _f32(w)
+    _fb(g, act_mask)
+    _chk(idx)
+    n, hp, wp, cz = g.shape
+    ks, ci = w.shape[0], w.shape[2]
+    out = torch.empty((n, 2 * hp, 2 * wp, ci), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=g.device)
+    wb = weights_bf16(w, 1)
+    flags = (BF16_OUT if out_bf16 else 0) | (BF16_MASK if _is_bf16(act_mask) else 0)
+    _lib.call('nimg_conv2d_fwd_bf16_unpool', _p(g), _p(idx), cz, _p(wb), None, _p(out), ci, _p(act_mask), n, 2 * hp, 2 * wp, ks,
+              ks - 1 - (ks - 1) // 2, ks - 1 - (ks - 1) // 2, 2 * hp, 2 * wp, 0, LRELU_ALPHA, flags, _stream())
+    return out
+
+
+def conv2d_wgrad_unpool(x, g, idx, ks, dw, db=None, side=False):
+    """Weight / bias gradient of a fused 5x5 conv + pool layer from its bf16 input x and the pooled gradient + arg-max bytes."""
+    if side and _SIDE['enabled'] and dw is not None:
+        with _on_side_stream(x, g, idx):
+            return conv2d_wgrad_unpool(x, g, idx, ks, dw, db=db, side=False)
+    _f32(dw, db)
+    _fb(x, g)
+    _chk(idx)
+    n, h, wd, cin = x.shape
+    cout = g.shape[3]
+    need = _lib.load().nimg_conv2d_wgrad_bf16_workspace_bytes(cin, cout, ks, ks, n, h, wd)
+    ws = (_ws_side if torch.cuda.current_stream(x.device) == _SIDE['stream'] else _ws).get(need, x.device)
+    _lib.call('nimg_conv2d_wgrad_bf16_unpool', _p(x), cin, _p(g), _p(idx), cout, _p(dw), _p(db), n, h, wd, ks, 0, _p(ws),
+              ws.numel(), _stream())
+    return dw
+
+
 def pooled_backward_ok(cin, cout, ks):
     """True when the backward of a fused conv+pool layer can consume the pooled gradient directly (no un-pooling
     pass): throughput mode, the FAN conv1 shape class."""

@@ -715,6 +715,67 @@ def test_conv2d_bf16_mode(dev, bf16_mode, case):
         assert_close(dx.cpu().numpy(), x.grad.numpy(), 0.0, 1.5e-2, what='bf16 dgrad {}'.format(case))
 
 
+@pytest.mark.parametrize('shape', [(1, 64, 64, 64, 128), (1, 32, 32, 128, 256)])
+@pytest.mark.parametrize('stored_bf16', [False, True])
+def test_dominant_conv5_at_bench_shapes(dev, bf16_mode, shape, stored_bf16):
+    """The kernel family bench.py's roofline is quoted on - conv_fwd_bf16_kernel<5,1,16,16,1,64,...> / conv_wgrad_bf16_kernel<5,..>
+    at the layer shapes of the bench (FAN conv3: 64 -> 128 @ 64x64, conv4: 128 -> 256 @ 32x32; 4 and 8 channel chunks, 16x16
+    tiles), forward (plain and with the fused LeakyReLU + pool epilogue), input gradient and weight gradient against the float64
+    oracle, with float32 tensors and with the bf16-stored tensors the throughput-mode FAN feeds it."""
+    from neural_imaging_amd import ops
+    n, h, w, cin, cout = shape
+    x_np, dz_np = rnd((n, h, w, cin), 1), rnd((n, h, w, cout), 5)
+    if stored_bf16:      # the tensors live in HBM as bf16: the oracle sees the same rounded values
+        x_np, dz_np = _bf16_round(x_np).numpy().astype(np.float32), _bf16_round(dz_np).numpy().astype(np.float32)
+    x = to64(x_np).requires_grad_(True)
+    wt = to64(rnd((5, 5, cin, cout), 3, -0.05, 0.05)).requires_grad_(True)
+    b = to64(rnd((cout,), 4))
+    z = T.conv2d(x, wt, b, 1, 'SAME')
+    (z * to64(dz_np)).sum().backward()
+    dt = torch.bfloat16 if stored_bf16 else torch.float32
+    xg, dzg = g(x_np, dev).to(dt), g(dz_np, dev).to(dt)
+    wg, bg = g(wt.detach().numpy(), dev), g(b.numpy(), dev)
+    out = ops.conv2d(xg, wg, bg)
+    assert_close(out.cpu().numpy(), z.detach().numpy(), 0.0, 1.5e-2, what='fwd')
+    pooled, idx = ops.conv2d_pool(xg, wg, bg, out_bf16=stored_bf16)
+    act = T.leaky_relu(z.detach())
+    assert_close(pooled.float().cpu().numpy(), T.max_pool2(act).numpy(), 0.0, 1.5e-2, what='fwd + lrelu + pool')
+    win = act.numpy().reshape(n, h // 2, 2, w // 2, 2, cout).transpose(0, 1, 3, 5, 2, 4).reshape(n, h // 2, w // 2, cout, 4)
+    srt = np.sort(win, axis=-1)
+    clear = (srt[..., 3] - srt[..., 2]) > 2e-2 * np.abs(act.numpy()).max()
+    assert clear.mean() > 0.8 and np.array_equal(idx.cpu().numpy()[clear], win.argmax(axis=-1)[clear])
+    dx = ops.conv2d_dgrad(dzg, wg, (h, w), out_bf16=stored_bf16)
+    assert_close(dx.float().cpu().numpy(), x.grad.numpy(), 0.0, 1.5e-2, what='dgrad')
+    dbf = torch.empty((cout,), device=dev)
+    dw = ops.conv2d_wgrad(xg, dzg, 5, db=dbf)
+    assert_close(dw.cpu().numpy(), wt.grad.numpy(), 0.0, 1.5e-2, what='wgrad')
+    assert_close(dbf.cpu().numpy(), dz_np.astype(np.float64).sum(axis=(0, 1, 2)), 0.0, 1e-4, what='bias grad')
+
+
+@pytest.mark.parametrize('shape', [(2, 32, 32, 32, 64), (1, 64, 64, 64, 128), (3, 16, 48, 128, 256)])
+def test_unpool_folded_into_conv5_backward(dev, bf16_mode, shape):
+    """nimg_conv2d_fwd_bf16_unpool / nimg_conv2d_wgrad_bf16_unpool: the 5x5 input- and weight-gradient kernels reading the pooled
+    gradient + arg-max bytes are bit-identical to un-pooling first (nimg_maxpool2_unpool_ex) and running the plain kernels."""
+    from neural_imaging_amd import ops
+    n, h, w, cin, cout = shape
+    x = g(rnd((n, h, w, cin), 1), dev).to(torch.bfloat16)
+    gp = g(rnd((n, h // 2, w // 2, cout), 2), dev).to(torch.bfloat16)
+    idx = torch.from_numpy(np.random.default_rng(3).integers(0, 4, size=(n, h // 2, w // 2, cout)).astype(np.uint8)).to(dev)
+    wt = g(rnd((5, 5, cin, cout), 4, -0.05, 0.05), dev)
+    mask = g(rnd((n, h, w, cin), 5), dev).to(torch.bfloat16)
+    assert ops.unpool_fold_ok(x, gp, cin, cout, 5)
+    dz = ops.maxpool2_unpool(gp, idx, None, apply_mask=False, out_bf16=True)
+    for out_bf16, am in ((False, None), (True, mask)):
+        ref = ops.conv2d_dgrad(dz, wt, (h, w), act_mask=am, out_bf16=out_bf16)
+        got = ops.conv2d_dgrad_unpool(gp, idx, wt, act_mask=am, out_bf16=out_bf16)
+        assert torch.equal(ref, got), 'input gradient'
+    dw_ref, db_ref = torch.empty_like(wt), torch.empty((cout,), device=dev)
+    ops.conv2d_wgrad(x, dz, 5, dw=dw_ref, db=db_ref)
+    dw, db = torch.empty_like(wt), torch.empty((cout,), device=dev)
+    ops.conv2d_wgrad_unpool(x, gp, idx, 5, dw, db=db)
+    assert torch.equal(dw_ref, dw) and torch.equal(db_ref, db), 'weight / bias gradient'
+
+
 def test_fan_conv1_input_gradient_bf16(dev, bf16_mode):
     """kx-folded MFMA input gradient of the FAN's first convolution (5x5, 3 <- 32), incl. partial tiles."""
     from neural_imaging_amd import ops
