@@ -990,3 +990,32 @@ def test_device_dataset(dev):
     with pytest.raises(ValueError):
         a.next_training_batch(1, 6, 64)
 
+
+
+def test_torch_library_custom_ops(dev):
+    """neural_imaging_amd.torch_ops: the C-ABI kernels as dispatcher-visible PyTorch custom ops (namespace nimg) with autograd -
+    dJPEG and Conv2D gradients through torch.autograd equal the explicit backward entry points."""
+    from neural_imaging_amd import ops, torch_ops
+    x = g(natural_images(2, 32, 32, seed=3), dev).requires_grad_(True)
+    q = ops.qtables_device(75, dev)
+    y = torch.ops.nimg.djpeg(x, q, 'soft')
+    gy = g(rnd((2, 32, 32, 3), 2), dev)
+    y.backward(gy)
+    y_ref, mask, _, _ = ops.djpeg_fwd(x.detach(), q, 'soft', want_mask=True)
+    assert torch.equal(y.detach(), y_ref) and torch.equal(x.grad, ops.djpeg_bwd(x.detach(), gy, mask, q, 'soft'))
+    a = g(rnd((2, 16, 16, 8), 4), dev).requires_grad_(True)
+    w = g(rnd((3, 3, 8, 16), 5, -0.2, 0.2), dev).requires_grad_(True)
+    b = g(rnd((16,), 6), dev).requires_grad_(True)
+    z = torch_ops.conv2d(a, w, b, 1, 'leaky_relu')
+    gz = g(rnd((2, 16, 16, 16), 7), dev)
+    z.backward(gz)
+    at, wt, bt = to64(a.detach().cpu().numpy()).requires_grad_(True), to64(w.detach().cpu().numpy()).requires_grad_(True), \
+        to64(b.detach().cpu().numpy()).requires_grad_(True)
+    zr = T.leaky_relu(T.conv2d(at, wt, bt))
+    (zr * to64(gz.cpu().numpy())).sum().backward()
+    assert_close(z.detach().cpu().numpy(), zr.detach().numpy(), 1e-4, what='custom-op conv fwd')
+    assert_close(a.grad.cpu().numpy(), at.grad.numpy(), 1e-4, GRTOL, what='custom-op conv d input')
+    assert_close(w.grad.cpu().numpy(), wt.grad.numpy(), 1e-4, GRTOL, what='custom-op conv d kernel')
+    assert_close(b.grad.cpu().numpy(), bt.grad.numpy(), 1e-4, GRTOL, what='custom-op conv d bias')
+    with pytest.raises(NotImplementedError):
+        torch.ops.nimg.cconv3(torch.zeros(1, 8, 8, 3), torch.zeros(5, 5, 3, 3), 1)        # no CPU kernel is registered
