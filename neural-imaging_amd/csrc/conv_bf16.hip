@@ -145,7 +145,11 @@ __device__ __forceinline__ uint4 unp_route(uint4 g, unsigned k0, unsigned k1, un
 
 template <int KS, int STRIDE, int TH, int TW, int NB, int TN, bool INB, bool BUF = false, bool UNP = false>
 __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p) {
-    constexpr int CK = 16;
+    // K chunk: 16 channels (one MFMA k-step per tap), or 32 for the 3x3 layers with float32 tensors (UNet / TwitterDCN): their
+    // 9-tap chunks are only 36 MFMAs per wave between barrier pairs - too short to cover the staging round trip - so they
+    // stage two k-steps at a time (half the barriers, twice the matrix work behind every prefetch)
+    constexpr int CK = (KS == 3 && !INB && !BUF) ? 32 : 16;
+    constexpr int CKH = CK / 8;                          // 16-byte slots (8 channels) per pixel / weight row
     static_assert(!UNP || (INB && BUF && STRIDE == 1), "un-pooling input: bf16 buffer-load path only");
     constexpr int THH = (TH - 1) * STRIDE + KS, TWH = (TW - 1) * STRIDE + KS;
     constexpr int NPIXH = NB * THH * TWH;
@@ -160,9 +164,9 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
     // all 64 banks exactly once, and a tap is a compile-time offset (ky*32 + kx) on one per-fragment base register.
     // Otherwise: [pixel][2] 16-byte halves, XOR-swizzled by pixel.
     constexpr bool PLANAR = (STRIDE == 1 && TW == 16 && NB == 1 && KS == 5);   // 3x3: the extra registers cost a wave per SIMD
-    constexpr int PLSZ = THH * 32, A_ENTRIES = PLANAR ? 2 * PLSZ : NPIXH * 2;
+    constexpr int PLSZ = THH * 32, A_ENTRIES = PLANAR ? 2 * PLSZ : NPIXH * CKH;
     uint4* sA = reinterpret_cast<uint4*>(smem_raw);
-    uint4* sB = sA + A_ENTRIES;                                           // [TAPS*TN][2]
+    uint4* sB = sA + A_ENTRIES;                                           // [TAPS*TN][CKH]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
 
     // Async-stage split (issue early / write late): the global loads of chunk c+1 are issued into registers before the
     // MFMA loop of chunk c and committed to LDS after it, so HBM/L2 latency hides under the matrix work.
-    constexpr int AP = (NPIXH * 2 + 255) / 256, BP = (TAPS * TN * 2 + 255) / 256;
+    constexpr int AP = (NPIXH * CKH + 255) / 256, BP = (TAPS * TN * CKH + 255) / 256;
     float4 preA[AP][2];
     uint4 preB[BP];
     // The halo-pixel -> image-pixel map (padding mode, tile clipping, image index) does not depend on the channel chunk:
@@ -210,11 +214,11 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
 #pragma unroll
     for (int q = 0; q < AP; ++q) {
         const int item = tid + q * 256;
-        const int pix = item >> 1;
+        const int pix = item / CKH;
         const int img = pix / (THH * TWH), rem = pix % (THH * TWH);
         int gy = iy0 + rem / TWH, gx = ix0 + rem % TWH;
         const int n = grp * NB + img;
-        const bool ok = item < NPIXH * 2 && n < p.N && map_coord(gy, p.H, p.pad_mode) && map_coord(gx, p.W, p.pad_mode);
+        const bool ok = item < NPIXH * CKH && n < p.N && map_coord(gy, p.H, p.pad_mode) && map_coord(gx, p.W, p.pad_mode);
         if constexpr (UNP) {
             apix[q] = ok ? (n * (p.H >> 1) + (gy >> 1)) * (p.W >> 1) + (gx >> 1) : -1;
             upos[q] = (unsigned)(((gy & 1) << 1) | (gx & 1));
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
             }
             return;
         }
-        const int c = c0 + (tid & 1) * 8;               // item = tid + 256 q: the 8-channel half is the thread's parity
+        const int c = c0 + (tid & (CKH - 1)) * 8;       // item = tid + 256 q: the 8-channel slot is fixed per thread
 #pragma unroll
         for (int q = 0; q < AP; ++q) {
             preA[q][0] = preA[q][1] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -272,20 +276,22 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
                 } else {
                     const float* src = c < p.C1 ? p.in1 + pixoff * p.C1 + c : p.in2 + pixoff * p.C2 + (c - p.C1);
                     preA[q][0] = *reinterpret_cast<const float4*>(src);
-                    preA[q][1] = *reinterpret_cast<const float4*>(src + 4);
+                    if (c + 4 < Cin) preA[q][1] = *reinterpret_cast<const float4*>(src + 4);     // Cin % 8 == 4: a 4-channel tail
                 }
             }
         }
         // wave-uniform base of this K chunk (the transposed convolution reads tap slot 3 - phase of a 4-tap image)
-        const __bf16* wchunk = (KS == 1 && p.convt) ? p.wb + ((long)(c0 >> 4) * 4 + (3 - phase)) * 16 * Cout
-                                                    : p.wb + (long)(c0 >> 4) * (TAPS * 16) * Cout;
+        const int h8 = tid & (CKH - 1), c16 = (c0 >> 4) + (h8 >> 1);       // this thread's 16-channel image of the chunk
+        const __bf16* wchunk = (KS == 1 && p.convt) ? p.wb + ((long)c16 * 4 + (3 - phase)) * 16 * Cout
+                                                    : p.wb + (long)c16 * (TAPS * 16) * Cout;
+        const bool wok = c16 * 16 < p.CinP;
 #pragma unroll
         for (int q = 0; q < BP; ++q) {
             const int item = tid + q * 256;
-            const int h8 = item & 1, row = item >> 1, j = row % TN, tap = row / TN;
+            const int row = item / CKH, j = row % TN, tap = row / TN;
             preB[q] = make_uint4(0u, 0u, 0u, 0u);
-            if (item < TAPS * TN * 2 && co0 + j < Cout)
-                preB[q] = *reinterpret_cast<const uint4*>(wchunk + (unsigned)((tap * Cout + co0 + j) * 16 + h8 * 8));
+            if (item < TAPS * TN * CKH && co0 + j < Cout && wok)
+                preB[q] = *reinterpret_cast<const uint4*>(wchunk + (unsigned)((tap * Cout + co0 + j) * 16 + (h8 & 1) * 8));
         }
     };
     fetch(0);
@@ -294,8 +300,8 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
 #pragma unroll
         for (int q = 0; q < AP; ++q) {
             const int item = tid + q * 256;
-            if (item < NPIXH * 2) {
-                const int pix = item >> 1, h8 = item & 1;
+            if (item < NPIXH * CKH) {
+                const int pix = item / CKH, h8 = item % CKH;
                 uint4 packed;
                 if constexpr (INB) {
                     packed = *reinterpret_cast<const uint4*>(&preA[q][0]);
@@ -307,15 +313,17 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
                     packed = *reinterpret_cast<const uint4*>(&b);
                 }
                 if constexpr (PLANAR) sA[h8 * PLSZ + (pix / TWH) * 32 + pix % TWH] = packed;
-                else sA[pix * 2 + (h8 ^ ((pix >> 3) & 1))] = packed;
+                else if constexpr (CKH == 2) sA[pix * 2 + (h8 ^ ((pix >> 3) & 1))] = packed;
+                else sA[pix * 4 + (h8 ^ ((pix >> 2) & 3))] = packed;
             }
         }
 #pragma unroll
         for (int q = 0; q < BP; ++q) {
             const int item = tid + q * 256;
-            if (item < TAPS * TN * 2) {
-                const int h8 = item & 1, row = item >> 1;
-                sB[row * 2 + (h8 ^ ((row >> 3) & 1))] = preB[q];
+            if (item < TAPS * TN * CKH) {
+                const int h8 = item % CKH, row = item / CKH;
+                if constexpr (CKH == 2) sB[row * 2 + (h8 ^ ((row >> 3) & 1))] = preB[q];
+                else sB[row * 4 + (h8 ^ ((row >> 2) & 3))] = preB[q];
             }
         }
         __syncthreads();
@@ -326,24 +334,29 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
         for (int kx = 0; kx < KS; ++kx) {            // one kernel row unrolled: the next taps' ds_reads overlap the MFMAs
             const int tap = ky * KS + kx;
             const int toff = PLANAR ? ky * 32 + kx : ky * TWH + kx;
-            bf16x8 a[MI], b[NI];
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                const int pix = abase[mi] + toff;
-                const uint4 v = PLANAR ? sA[pix] : sA[pix * 2 + (half ^ ((pix >> 3) & 1))];
-                a[mi] = *reinterpret_cast<const bf16x8*>(&v);
+            for (int ks2 = 0; ks2 < CKH / 2; ++ks2) {        // MFMA k-steps of this chunk (16 channels each)
+                bf16x8 a[MI], b[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int pix = abase[mi] + toff;
+                    const uint4 v = PLANAR ? sA[pix] : (CKH == 2 ? sA[pix * 2 + (half ^ ((pix >> 3) & 1))]
+                                                                 : sA[pix * 4 + ((2 * ks2 + half) ^ ((pix >> 2) & 3))]);
+                    a[mi] = *reinterpret_cast<const bf16x8*>(&v);
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int row = tap * TN + (wn * NI + ni) * 32 + (lane & 31);
+                    const uint4 v = CKH == 2 ? sB[row * 2 + (half ^ ((row >> 3) & 1))]
+                                             : sB[row * 4 + ((2 * ks2 + half) ^ ((row >> 2) & 3))];
+                    b[ni] = *reinterpret_cast<const bf16x8*>(&v);
+                }
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
             }
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const int row = tap * TN + (wn * NI + ni) * 32 + (lane & 31);
-                const uint4 v = sB[row * 2 + (half ^ ((row >> 3) & 1))];
-                b[ni] = *reinterpret_cast<const bf16x8*>(&v);
-            }
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
         }
     }
     // ---- epilogue, fused activation + 2x2 max-pool (16x16 tiles; the entry point guarantees even Hout/Wout, Cout % 4 == 0)
@@ -453,8 +466,9 @@ int launch_conv_b(const ConvParamsB& p, hipStream_t stream) {
     }
     constexpr int THH = (TH - 1) * STRIDE + KS, TWH = (TW - 1) * STRIDE + KS;
     constexpr bool PLANAR = (STRIDE == 1 && TW == 16 && NB == 1 && KS == 5);   // 3x3: the extra registers cost a wave per SIMD
-    constexpr size_t a_entries = PLANAR ? (size_t)2 * THH * 32 : (size_t)NB * THH * TWH * 2;
-    constexpr size_t lds_tiles = (a_entries + (size_t)KS * KS * TN * 2) * sizeof(uint4);
+    constexpr int CKH = (KS == 3 && !INB && !BUF) ? 4 : 2;             // the kernel's K chunk in 8-channel slots
+    constexpr size_t a_entries = PLANAR ? (size_t)2 * THH * 32 : (size_t)NB * THH * TWH * CKH;
+    constexpr size_t lds_tiles = (a_entries + (size_t)KS * KS * TN * CKH) * sizeof(uint4);
     constexpr size_t lds_epi = (size_t)4 * 32 * (TN + EPI_PAD) * sizeof(float);
     constexpr size_t lds = lds_tiles > lds_epi ? lds_tiles : lds_epi;
     ConvParamsB q = p;
@@ -768,7 +782,8 @@ static int conv2d_fwd_bf16_impl(const float* in1, int c1, const float* in2, int 
     if (!in1 || !wb || !out1 || c1 <= 0 || c2 < 0 || o1 <= 0 || o2 < 0 || n < 0 || h <= 0 || wd <= 0) return NIMG_ERR_ARG;
     if ((c2 > 0 && !in2) || (o2 > 0 && !out2) || hout <= 0 || wout <= 0 || pad_t < 0 || pad_l < 0) return NIMG_ERR_ARG;
     if (act < 0 || act > 1 || pad_mode < 0 || pad_mode > 2) return NIMG_ERR_ARG;
-    if ((c1 % 8) || (c2 % 8)) return NIMG_ERR_ARG;      // 8-channel (two float4) staging granules
+    if (c2 == 0 ? ((c1 % 4) || ((flags & NIMG_BF16_IN) && (c1 % 8))) : ((c1 % 8) || (c2 % 8)))
+        return NIMG_ERR_ARG;                           // 8-channel staging granules (a single float32 input may end on 4)
     if (n == 0) return NIMG_OK;
     ConvParamsB p;
     p.in1 = in1; p.in2 = in2; p.wb = (const __bf16*)wb; p.bias = bias; p.out1 = out1; p.out2 = out2; p.act1 = act_mask;

@@ -38,8 +38,14 @@ __global__ __launch_bounds__(256) void cconv_kernel(const float* __restrict__ p_
     constexpr int TW = 4 * TPR, TROWS = 256 / TPR, TR = TROWS * RPT, HR = TR + 4, HC = TW + 4;
     constexpr int RS = (HC * 3 + 3) / 4 * 4;                 // floats per tile row, 16-byte multiple
     constexpr int NPIX = HR * HC, PPT = (NPIX + 255) / 256;
-    extern __shared__ __attribute__((aligned(16))) float tile[];      // [HR][RS]
+    extern __shared__ __attribute__((aligned(16))) float tile[];      // [HR][RS], then the 5 x 48 filter taps
+    float* wl = tile + HR * RS;                                       // [ky][48]: 45 weights of a kernel row + 3 pad
     const int tid = threadIdx.x, tx = tid % TPR, ty = tid / TPR;
+    // The 225 filter weights are wave-uniform.  As SGPR operands (v_fmac_f32 v, s, v) the FMAs issue at ~0.6x the rate of the
+    // all-VGPR form on gfx950 (tools/probe/fma_rate.hip: 64 vs 39 us for the same instruction count at 4 waves per SIMD), and
+    // the FMA stream is what bounds this kernel - so a kernel row's 45 weights are fetched from LDS with broadcast reads
+    // (every lane the same address) into VGPRs instead.
+    for (int i = tid; i < 5 * 48; i += 256) wl[i] = (i % 48) < 45 ? p_w[(i / 48) * 45 + i % 48] : 0.f;
     const int tiles = p.tiles_y * p.tiles_x;
     const int total = p.N * tiles;                     // < 2^31 / (12 * 32): the entry point bounds the batch
 
@@ -111,10 +117,12 @@ __global__ __launch_bounds__(256) void cconv_kernel(const float* __restrict__ p_
             for (int j = 0; j < 4; ++j) acc[r][j][0] = acc[r][j][1] = acc[r][j][2] = 0.f;
 #pragma unroll 1
         for (int ky = 0; ky < 5; ++ky) {
-            const float* wk = p_w + ky * 45;                    // [kx][ci][co]: 45 wave-uniform values -> SGPRs
-            float wr[45];
+            float wr[48];                                       // [kx][ci][co]: this kernel row's 45 weights (+3 pad)
 #pragma unroll
-            for (int i = 0; i < 45; ++i) wr[i] = wk[i];
+            for (int i = 0; i < 12; ++i) {
+                const float4 w4 = *reinterpret_cast<const float4*>(wl + ky * 48 + 4 * i);
+                wr[4 * i] = w4.x; wr[4 * i + 1] = w4.y; wr[4 * i + 2] = w4.z; wr[4 * i + 3] = w4.w;
+            }
 #pragma unroll
             for (int r = 0; r < RPT; ++r) {
                 const float4* row = reinterpret_cast<const float4*>(tile + (ty * RPT + r + ky) * RS + tx * 12);
@@ -436,7 +444,7 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_kernel(const void* __restr
 template <int TPR, int RPT>
 int launch_cconv(CConvParams p, hipStream_t s) {
     constexpr int TW = 4 * TPR, TR = (256 / TPR) * RPT, HR = TR + 4, HC = TW + 4, RS = (HC * 3 + 3) / 4 * 4;
-    constexpr size_t lds = (size_t)HR * RS * sizeof(float);
+    constexpr size_t lds = ((size_t)HR * RS + 5 * 48) * sizeof(float);
     p.tiles_y = cdiv(p.H, TR);
     p.tiles_x = cdiv(p.W, TW);
     const long total = (long)p.N * p.tiles_y * p.tiles_x;

@@ -292,7 +292,8 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
             pad_mode == 0 and bias is None and act is None:
         _lib.call('nimg_conv2d_dgrad_fewin_bf16', _p(x), _p(w), _p(out), 3, 32, n, h, wd, 5, _stream())
         return out
-    if COMPUTE == 'bf16' and not _f32_only and c1 % 8 == 0 and c2 % 8 == 0 and cout >= 8:
+    if COMPUTE == 'bf16' and not _f32_only and c2 % 8 == 0 and cout >= 8 and \
+            (c1 % 8 == 0 or (c2 == 0 and c1 % 4 == 0 and c1 >= 8 and not _is_bf16(x))):
         wb = weights_bf16(w, _wmode)
         flags = (BF16_IN if _is_bf16(x) else 0) | (BF16_OUT if _is_bf16(out) else 0) | \
             (BF16_MASK if _is_bf16(act_mask) else 0)

@@ -689,7 +689,7 @@ def test_bf16_storage_is_bit_neutral(dev, bf16_mode):
 
 
 BF16_CASES = [(2, 40, 72, 3, 0, 32, 5, 1), (2, 24, 24, 4, 0, 64, 3, 1), (2, 32, 32, 32, 0, 64, 5, 1), (2, 16, 16, 16, 16, 32, 3, 1), (5, 8, 8, 64, 0, 128, 3, 1),
-              (2, 20, 24, 8, 0, 24, 3, 1), (3, 16, 16, 64, 0, 64, 1, 1), (2, 32, 32, 64, 0, 128, 5, 2)]
+              (2, 20, 24, 8, 0, 24, 3, 1), (2, 16, 24, 12, 0, 32, 3, 1), (3, 16, 16, 64, 0, 64, 1, 1), (2, 32, 32, 64, 0, 128, 5, 2)]
 
 
 @pytest.mark.parametrize('case', BF16_CASES)
