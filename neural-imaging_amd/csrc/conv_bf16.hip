@@ -145,10 +145,15 @@ __device__ __forceinline__ uint4 unp_route(uint4 g, unsigned k0, unsigned k1, un
 
 template <int KS, int STRIDE, int TH, int TW, int NB, int TN, bool INB, bool BUF = false, bool UNP = false>
 __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p) {
-    // K chunk: 16 channels (one MFMA k-step per tap), or 32 for the 3x3 layers with float32 tensors (UNet / TwitterDCN): their
-    // 9-tap chunks are only 36 MFMAs per wave between barrier pairs - too short to cover the staging round trip - so they
-    // stage two k-steps at a time (half the barriers, twice the matrix work behind every prefetch)
+    // K chunk: 16 channels (one MFMA k-step per tap).  -DNIMG_CK32 stages 32 channels (two k-steps, half the barriers) for the
+    // 3x3 layers with float32 tensors (UNet / TwitterDCN) - measured on the bench step: the 8x8 bottleneck variant gains 12 %
+    // (43 -> 38 us) but the 16x16 variants LOSE 4-22 % (47 -> 49 / 58 us: twice the LDS per workgroup and 84 staging registers
+    // cost more than the halved barrier count returns), -5 % on the whole step - so it stays an experiment switch.
+#ifdef NIMG_CK32
     constexpr int CK = (KS == 3 && !INB && !BUF) ? 32 : 16;
+#else
+    constexpr int CK = 16;
+#endif
     constexpr int CKH = CK / 8;                          // 16-byte slots (8 channels) per pixel / weight row
     static_assert(!UNP || (INB && BUF && STRIDE == 1), "un-pooling input: bf16 buffer-load path only");
     constexpr int THH = (TH - 1) * STRIDE + KS, TWH = (TW - 1) * STRIDE + KS;
@@ -466,7 +471,11 @@ int launch_conv_b(const ConvParamsB& p, hipStream_t stream) {
     }
     constexpr int THH = (TH - 1) * STRIDE + KS, TWH = (TW - 1) * STRIDE + KS;
     constexpr bool PLANAR = (STRIDE == 1 && TW == 16 && NB == 1 && KS == 5);   // 3x3: the extra registers cost a wave per SIMD
+#ifdef NIMG_CK32
     constexpr int CKH = (KS == 3 && !INB && !BUF) ? 4 : 2;             // the kernel's K chunk in 8-channel slots
+#else
+    constexpr int CKH = 2;
+#endif
     constexpr size_t a_entries = PLANAR ? (size_t)2 * THH * 32 : (size_t)NB * THH * TWH * CKH;
     constexpr size_t lds_tiles = (a_entries + (size_t)KS * KS * TN * CKH) * sizeof(uint4);
     constexpr size_t lds_epi = (size_t)4 * 32 * (TN + EPI_PAD) * sizeof(float);
