@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box session, made of the stages named on the command line; everything lands under gpurun_out/<tag>/.
 #   gpurun --timeout 900 -- 'bash tools/gpu_check.sh r02_b tests c4 prof'
-# stages: tests | tests:<pytest -k expression> | c4 | c4nocpu | c4eager | c3 | c5 | n2 | prof | pmc:<counter> | py:<script and args>
+# stages: tests | tests:<pytest -k expression> | c4 | c4nocpu | c4eager | c3 | c5 | n2 | prof | trace | pmc:<counter> | py:<script and args>
 TAG=${1:-r02}
 shift
 OUT=gpurun_out/$TAG
@@ -25,6 +25,9 @@ for ST in "$@"; do
             python $ROOT/bench.py --steps 5 --warmup 2 --no-graph --no-cpu-baseline --no-parity-mode > $ROOT/$OUT/prof.log 2>&1)
           find $OUT/prof -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
           find $OUT/prof -name '*kernel_trace.csv' -delete; note "prof done"; head -25 $OUT/kernel_stats.csv | cut -c1-160 ;;
+    trace) (cd /tmp && NIMG_NO_SIDE_STREAM=1 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $ROOT/$OUT/trace -o c4 -- \
+            python $ROOT/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-parity-mode > $ROOT/$OUT/trace.log 2>&1)
+          find $OUT/trace -name '*kernel_trace.csv' | head -1 | xargs -I{} cp {} $OUT/kernel_trace.csv; rm -rf $OUT/trace; note "trace done" ;;
     pmc:*) C=${ST#pmc:}
           (cd /tmp && timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $ROOT/$OUT/pmc_$C -o p -- \
             python $ROOT/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-parity-mode > $ROOT/$OUT/pmc_$C.log 2>&1)
