@@ -1129,3 +1129,62 @@ def test_validate_fan_on_device(dev):
     cm = torch.zeros((3, 3), dtype=torch.int64, device=dev)
     pred = ops.confusion_accumulate(probs, lab, cm)
     assert pred.tolist() == [1, 0, 2] and cm.tolist() == [[1, 0, 1], [0, 1, 0], [0, 0, 0]]      # first maximum wins
+
+
+def test_twitter_dcn_at_256(dev):
+    """configs[2] at its real size: TwitterDCN-32C on a 256x256 patch (models/compression.py:197-279) - hard latent indices
+    exact, reconstruction 1e-4, entropy 1e-5 and the training loss against the float64 oracle."""
+    from neural_imaging_amd import ops
+    from neural_imaging_amd.models import compression
+    dcn = compression.TwitterDCN(patch_size=256, device=dev)
+    x = natural_images(1, 256, 256, seed=17)
+    p = onets.OrderedDict((k, to64(v)) for k, v in dcn.state_dict().items())
+    with torch.no_grad():
+        y_ref, ent_ref, lat_ref = onets.dcn_forward(p, to64(x))
+        loss_ref = float(onets.dcn_loss(to64(x), y_ref, ent_ref, 250.0))
+    xt = torch.from_numpy(x).to(dev)
+    y, ent, ctx = dcn.forward(xt, training=True)
+    lat = ctx[0]['latent'].cpu().numpy()
+    assert lat.shape == (1, 32, 32, 32)
+    assert np.array_equal(np.round(lat), np.round(lat_ref.numpy())), 'latent indices differ'
+    assert_close(y.cpu().numpy(), y_ref.numpy(), 1e-4, what='DCN reconstruction at 256x256')
+    assert abs(float(ent.item()) - float(ent_ref)) < 1e-5
+    l2, _ = ops.l2_loss(xt, y)
+    assert abs(float(l2.item()) + 250.0 * float(ent.item()) - loss_ref) / loss_ref < 1e-4
+
+
+def test_full_channel_with_learned_codec_in_throughput_mode(dev):
+    """configs[4]: UNet -> manipulations -> TwitterDCN -> FAN, trainable {nip, dcn}, in the bf16 throughput mode: losses against
+    the float64 oracle of the same step and against the float32 mode of the same weights; gradient directions of the two modes."""
+    from neural_imaging_amd import ops
+    from neural_imaging_amd.models import compression
+    from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
+    manips = ['sharpen:1', 'resample:50', 'gaussian:0.83', 'jpeg:80']
+    rgb = natural_images(2, 128, 128, seed=9)
+    raw = bayer_from_rgb(rgb)
+    res = {}
+    for mode in ('f32', 'bf16'):
+        ops.set_compute(mode)
+        dcn = compression.TwitterDCN(patch_size=128, device=dev)
+        dist = {'downsampling': 'none', 'compression': 'dcn', 'compression_params': {'model': dcn}}
+        wf = ManipulationClassification('UNet', manipulations=manips, distribution=dist, trainable={'nip', 'dcn'},
+                                        raw_patch_size=64, device=dev)
+        if mode == 'f32':
+            ref = owf.Workflow(manipulations=manips, codec='dcn', trainable=('nip', 'dcn'))
+            _sync_oracle(wf, ref)
+            ref.dcn = onets.OrderedDict((k, to64(v)) for k, v in dcn.state_dict().items())
+            with torch.no_grad():       # forward only: the three loss terms of workflows/...:267-277
+                Yr, cr, Cr, er, pr = ref.run_workflow(to64(raw))
+                parts_ref = {'ce': float(T.sparse_ce_from_probs(pr, ref.batch_labels(2))), 'nip': float(T.mse255(to64(rgb), Yr)),
+                             'dcn': float(onets.dcn_loss(cr, Cr, er))}
+        loss, parts = wf.training_step(raw, rgb, lambda_nip=0.1, lambda_dcn=0.1, learning_rate=1e-4)
+        res[mode] = (float(parts['ce']), float(parts['nip']), float(parts['dcn']), grads_of(wf.nip), grads_of(dcn), grads_of(wf.fan))
+    for mode, (tce, trel) in (('f32', (5e-3, 1e-3)), ('bf16', (5e-2, 2e-2))):
+        ce, nip, dl = res[mode][:3]
+        assert abs(ce - parts_ref['ce']) < tce, (mode, ce, parts_ref['ce'])
+        assert abs(nip - parts_ref['nip']) / parts_ref['nip'] < trel, (mode, nip, parts_ref['nip'])
+        assert abs(dl - parts_ref['dcn']) / parts_ref['dcn'] < trel, (mode, dl, parts_ref['dcn'])
+    cos = lambda a, b: float(a.ravel() @ b.ravel() / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+    for gi, keys in ((3, ('ec12/kernel', 'dc42/kernel')), (4, ('e2/kernel', 'er2a/kernel', 'd256/kernel')), (5, ('conv3/kernel', 'dense/kernel'))):
+        for k in keys:
+            assert cos(res['f32'][gi][k], res['bf16'][gi][k]) > 0.9, (k, cos(res['f32'][gi][k], res['bf16'][gi][k]))
