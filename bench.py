@@ -419,12 +419,14 @@ def main():
     edges = [round(i * args.steps / nblk) for i in range(nblk + 1)]
     barrier()
     t0 = time.perf_counter()
+    c0 = time.thread_time()                    # CPU time this thread spends issuing the steps (host cost of the launch path)
     last = None
     for i in range(args.steps):
         if i in edges:
             marks[edges.index(i)].record()
         last = step()
     marks[nblk].record()
+    host_cpu_ms = 1e3 * (time.thread_time() - c0) / max(args.steps, 1)
     barrier()
     dt = time.perf_counter() - t0
     wl.finish()
@@ -448,7 +450,7 @@ def main():
         cfg = {'workload': '{} = {}'.format(wl.key, wl.name), 'raw_patch': args.raw_patch, 'rgb_patch': 2 * args.raw_patch,
                'batch_per_gpu': wl.batch, 'global_batch': world * wl.batch, 'parallelism': 'dp%d' % world,
                'world_size': world, 'backend': torch.distributed.get_backend() if world > 1 else None,
-               'hip_graph': bool(getattr(wl, 'graph', False)), 'loss': loss,
+               'hip_graph': bool(getattr(wl, 'graph', False)), 'host_cpu_ms_per_step': host_cpu_ms, 'loss': loss,
                'achieved_tflops_whole_step': value * wl.gflop_per_unit / 1e3,
                'block_ms_per_step': [round(v, 4) for v in blocks], 'median_block_ms_per_step': float(np.median(blocks))}
         if wl.hbm_bytes_per_unit is not None:
