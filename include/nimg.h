@@ -129,6 +129,9 @@ int nimg_d2s_clip_fwd(const float* x, float* y, int n, int h, int w, int cout, f
 int nimg_d2s_clip_bwd(const float* dy, float* dx, int n, int h, int w, int cout, float scale, void* stream);
 int nimg_lrelu_bwd(const float* dy, const float* yact, float* dz, long count, float alpha, void* stream);
 int nimg_add(const float* a, const float* b, float* out, long count, void* stream);
+/* out = sum of 2..6 float32 tensors of `count` elements (count % 4 == 0; `inputs` is a HOST array of device pointers; out may
+ * alias an input): the per-manipulation gradients of workflows/manipulation_classification.py:199-208 summed in one pass. */
+int nimg_add_n(const float* const* inputs, int n_inputs, float* out, long count, void* stream);
 /* avg_pool downsampling of the channel, workflows/manipulation_classification.py:235 */
 int nimg_avgpool_fwd(const float* x, float* y, int n, int h, int w, int c, int factor, void* stream);
 int nimg_avgpool_bwd(const float* dy, float* dx, int n, int h, int w, int c, int factor, void* stream);
@@ -303,7 +306,7 @@ int nimg_conv1_pool_fwd_c4(const void* c4, const float* w, const float* bias, vo
 /* Weight and bias gradient of that convolution from the POOLED gradient (backward of nimg_conv1_pool_fwd_c4; the tape of
  * forensics.py:118-124 for this layer): dw (5,5,3,32) (+)= sum c (x) dz, db (32) (+)= sum dz with dz = the MaxPool2D routing of g
  * by the arg-max bytes.  c4 as above; g (n,h/2,w/2,32) bf16 (g_bf16 = 1) or float32, already multiplied by LeakyReLU';
- * db may be NULL.  workspace: nimg_conv1_wgrad_c4_workspace_bytes() bytes (per-wave slabs, reduced in a fixed order). */
+ * db may be NULL.  workspace: nimg_conv1_wgrad_c4_workspace_bytes() bytes (one slab per workgroup, reduced in a fixed order). */
 size_t nimg_conv1_wgrad_c4_workspace_bytes(void);
 int nimg_conv1_wgrad_c4(const void* c4, const void* g, const unsigned char* pool_idx, float* dw, float* db, int n, int h, int w_,
                         int g_bf16, int accumulate, void* workspace, size_t workspace_bytes, void* stream);

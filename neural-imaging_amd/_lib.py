@@ -38,6 +38,7 @@ PROTOTYPES = {
     'nimg_d2s_clip_bwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, P]),
     'nimg_lrelu_bwd': (c_int, [P, P, P, c_long, c_float, P]),
     'nimg_add': (c_int, [P, P, P, c_long, P]),
+    'nimg_add_n': (c_int, [P, c_int, P, c_long, P]),
     'nimg_avgpool_fwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'nimg_avgpool_bwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'nimg_mse255_workspace_bytes': (c_size_t, []),

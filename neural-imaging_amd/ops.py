@@ -591,6 +591,23 @@ def add(a, b, out=None):
     return o
 
 
+def add_n(tensors, out=None):
+    """out = sum of 2..6 same-sized float32 tensors in one pass (out may be one of them)."""
+    import ctypes
+    _f32(*tensors)
+    _f32(out)
+    n = tensors[0].numel()
+    if not 2 <= len(tensors) <= 6 or any(t.numel() != n for t in tensors) or (n & 3):
+        o = tensors[0] if out is None else out
+        for t in tensors[1:]:
+            o = add(o, t, out=out if out is not None else None)
+        return o
+    o = torch.empty_like(tensors[0]) if out is None else out
+    ptrs = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    _lib.call('nimg_add_n', ptrs, len(tensors), _p(o), n, _stream())
+    return o
+
+
 def avgpool(x, f):
     _f32(x)
     n, h, w, c = x.shape

@@ -287,9 +287,14 @@ class ManipulationClassification(object):
                 dc = self.codec.backward(cctx, dC) if train_nip else None
         if train_nip:
             dm = self._downsampling_bwd(dc)
-            dY = dm[:b].clone() if len(self._operations) else dm[:b]
-            for k, (name, op) in enumerate(self._operations.items()):
-                ops.add(dY, op.backward(mctxs[k], dm[(k + 1) * b:(k + 2) * b]), out=dY)
+            # d loss / d Y = the native branch's gradient + every manipulation's input gradient, summed in one pass (in place
+            # in dm[:b]: dm is this step's own scratch)
+            parts_dY = [dm[:b]] + [op.backward(mctxs[k], dm[(k + 1) * b:(k + 2) * b])
+                                   for k, (name, op) in enumerate(self._operations.items())]
+            dY = dm[:b]
+            for i in range(0, len(parts_dY) - 1, 5):            # nimg_add_n takes up to 6 tensors per launch
+                chunk = ([dY] if i else [parts_dY[0]]) + parts_dY[i + 1:i + 6]
+                ops.add_n(chunk, out=dY)
             loss_nip, _ = self.nip.loss_and_grad(Y, target, grad_scale=float(lambda_nip), grad_out=dY, accumulate=True)
             if world > 1 and hasattr(self.nip, 'decoder_grads'):
                 # two buckets: the decoder's gradients (its backward runs first) travel while the encoder backward
