@@ -458,6 +458,258 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Ring form of the 5x5 stride-1 convolution over bf16-stored activations with Cout % 64 == 0 (FAN conv2 / conv3 / conv4
+// forward, conv4 / conv3 input gradient): 4 waves x 8 accumulator fragments per workgroup -
+//     TN = 128: 16 x 16 pixels x 128 output channels, 2 x 4 fragments per wave;  TN = 64: 32 x 16 pixels x 64, 4 x 2.
+// conv_fwd_bf16_kernel stages the whole 25-tap weight tile of a 16-channel chunk through registers (52 VGPRs, 13
+// ds_write_b128 per thread and chunk, 51 KB of LDS for 64 output channels) behind two barriers per chunk.  Here the weights
+// arrive one KERNEL ROW at a time (5 taps x TN co x 16 ci = 20 / 10 KB) by LDS-DMA (buffer_load_dwordx4 ... lds: no staging
+// registers, no write pass) into a two-slot ring - row r + 1 lands while the MFMAs of row r run, one barrier per row - and
+// the halo tile of the next chunk (12.5 / 22.5 KB, through registers: padding, un-pool routing) is committed to the second
+// of two A buffers (TN = 128) or between two barriers at the chunk boundary (TN = 64: one buffer, LDS budget).  The freed
+// registers hold the 8-fragment block: 6 ds_read_b128 per 8 MFMAs instead of 4 per 4, the halo tile is staged once per
+// 128 channels (or per 512 pixels) instead of once per 64 x 256, and half as many workgroups pay the prologue / epilogue.
+// LDS-DMA writes base + 16 lane: the ring image is lane-linear per 1 KB piece and the XOR swizzle of the 16-byte halves
+// (conflict-free ds_read_b128) is applied on the SOURCE address.  LDS: 80 KB (TN = 128) / 56 KB -> two workgroups per CU.
+//
+// One LDS-DMA piece: 64 lanes x 16 B from buffer `rsrc` (per-lane byte offset voff + scalar soff) to LDS bytes
+// [lds_addr, lds_addr + 1024), lane-linear.  Issued as inline asm on purpose: hipcc orders the builtin form
+// (__builtin_amdgcn_raw_ptr_buffer_load_lds) against every later ds_read - it emits s_waitcnt vmcnt(0) right behind the
+// issue, which serialises the transfer with the MFMA loop it is meant to run under.  The asm form is invisible to the
+// compiler's counters (its own waits only become conservative: loads retire in order); the kernel waits for the DMA itself
+// (dma_wait) in front of the barrier that publishes the slot.
+typedef unsigned int r_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void glds16(r_u32x4 rsrc, unsigned lds_addr, unsigned voff, int soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <int TN>
+struct RingGeom {
+    static constexpr int NI = TN / 32, MI = 8 / NI;          // fragment block of a wave (4 waves stacked along the pixels)
+    static constexpr int TH = 8 * MI, TW = 16, THH = TH + 4, TWH = TW + 4;
+    static constexpr int NPIXH = THH * TWH, AP = (NPIXH * 2 + 255) / 256;
+    static constexpr int PLSZ = THH * 32;                    // uint4 entries of one k-half plane of the halo tile
+    static constexpr int ABUF = 2 * PLSZ;                    // one A buffer
+    static constexpr bool ADBL = TN == 128;                  // two A buffers
+    static constexpr int SLOT = 5 * TN * 2;                  // one ring slot: [5 taps x TN co][2 halves]
+    static constexpr int PIECES = 5 * NI, NPW = (PIECES + 3) / 4;     // 1 KB DMA pieces per kernel row, per wave
+    static constexpr size_t LDS_TILES = (size_t)(2 * SLOT + (ADBL ? 2 : 1) * ABUF) * sizeof(uint4);
+    static constexpr size_t LDS_EPI = (size_t)4 * 32 * (TN + EPI_PAD) * sizeof(float);
+    static constexpr size_t LDS = LDS_TILES > LDS_EPI ? LDS_TILES : LDS_EPI;
+};
+
+template <int TN, bool UNP>
+__global__ __launch_bounds__(256, 2) void conv5_ring_kernel(const ConvParamsB p) {
+    using G = RingGeom<TN>;
+    constexpr int NI = G::NI, MI = G::MI, TH = G::TH, TW = G::TW, TWH = G::TWH, NPIXH = G::NPIXH, AP = G::AP;
+    constexpr int PLSZ = G::PLSZ, ABUF = G::ABUF, SLOT = G::SLOT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint4* sB = reinterpret_cast<uint4*>(smem_raw);          // ring first: the LDS-DMA base (M0) stays below 64 KB
+    uint4* sA = sB + 2 * SLOT;
+    const unsigned sB_addr = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)smem_raw;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Cout = p.O1;
+    const int cot = Cout / TN;
+    int bid = xcd_order(blockIdx.x);
+    const int co0 = (bid % cot) * TN;
+    bid /= cot;
+    const int tiles = p.tiles_y * p.tiles_x;
+    const int tile = bid % tiles, grp = bid / tiles;
+    const int ty0 = (tile / p.tiles_x) * TH, tx0 = (tile % p.tiles_x) * TW;
+    const int iy0 = ty0 - p.pad_t, ix0 = tx0 - p.pad_l;
+    const int half = lane >> 5;
+
+    int abase[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int P = (wave * MI + mi) * 32 + (lane & 31);
+        abase[mi] = half * PLSZ + (P / TW) * 32 + (P % TW);
+    }
+    const int bbase = (lane & 31) * 2 + (half ^ (((lane & 31) >> 3) & 1));
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[mi][ni][j] = 0.0f;
+
+    // halo tile: NPIXH pixels x 2 eight-channel slots, items of 16 B, item = tid + 256 q (the slot is fixed per thread)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x2k __attribute__((ext_vector_type(2)));
+    unsigned aoff[AP], upos[UNP ? AP : 1];
+    int adst[AP];
+#pragma unroll
+    for (int q = 0; q < AP; ++q) {
+        const int item = tid + q * 256, pix = item >> 1;
+        int gy = iy0 + pix / TWH, gx = ix0 + pix % TWH;
+        const bool ok = (item < NPIXH * 2) & (grp < p.N) & map_coord(gy, p.H, p.pad_mode) & map_coord(gx, p.W, p.pad_mode);
+        int apix;
+        if constexpr (UNP) {
+            apix = (grp * (p.H >> 1) + (gy >> 1)) * (p.W >> 1) + (gx >> 1);
+            upos[q] = (unsigned)(((gy & 1) << 1) | (gx & 1));
+        } else {
+            apix = (grp * p.H + gy) * p.W + gx;
+        }
+        aoff[q] = ok ? (unsigned)((apix * p.C1 + (tid & 1) * 8) * 2) : 0x80000000u;
+        adst[q] = (tid & 1) * PLSZ + (pix / TWH) * 32 + pix % TWH;
+    }
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.in1), 0, (int)(((long)p.N * p.H * p.W * p.C1 * 2) >> (UNP ? 2 : 0)), 0x00020000);
+    const unsigned long wb_addr = (unsigned long)p.wb;
+    const r_u32x4 rb = {(unsigned)wb_addr, (unsigned)(wb_addr >> 32) & 0xffffu,
+                        (unsigned)((long)(p.CinP >> 4) * 25 * 16 * Cout * 2), 0x00020000u};
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(UNP ? p.in_idx : reinterpret_cast<const unsigned char*>(p.in1)), 0,
+        (int)(((long)p.N * p.H * p.W * p.C1) >> 2), 0x00020000);
+    uint4 preA[AP];
+    u32x2k preK[UNP ? AP : 1];
+    auto fetchA = [&](int c0) {
+#pragma unroll
+        for (int q = 0; q < AP; ++q) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, aoff[q], c0 * 2, 0);
+            preA[q] = *reinterpret_cast<const uint4*>(&v);
+            if constexpr (UNP)
+                preK[q] = __builtin_amdgcn_raw_buffer_load_b64(rk, aoff[q] >= 0x80000000u ? 0x80000000u : aoff[q] >> 1, c0, 0);
+        }
+    };
+    auto commitA = [&](int buf) {                       // buf: entry offset of the A buffer
+#pragma unroll
+        for (int q = 0; q < AP; ++q) {
+            if (tid + q * 256 < NPIXH * 2) {
+                uint4 v = preA[q];
+                if constexpr (UNP) v = unp_route(v, preK[q][0], preK[q][1], upos[q]);
+                sA[buf + adst[q]] = v;
+            }
+        }
+    };
+    // weights wb[chunk][tap][co][16]: one kernel row of a chunk = 5 taps x TN co x 32 B = 5 NI pieces of 1 KB (piece k =
+    // tap k / NI, 32-channel block k % NI, at ring byte 1024 k); wave w moves the pieces w, w + 4, ...  Lane l of a piece
+    // writes 16-byte position l: row l >> 1, and position parity (l & 1) must hold half h = (l & 1) ^ (row >> 3 & 1) - the
+    // swizzle the fragment reads undo.
+    const unsigned bvoff = (unsigned)(((co0 + (lane >> 1)) * 16 + (((lane & 1) ^ ((lane >> 4) & 1)) * 8)) * 2);
+    auto gldsB = [&](int chunk, int ky, int slot) {
+#pragma unroll
+        for (int j = 0; j < G::NPW; ++j) {
+            const int k = wave + 4 * j;
+            if (G::PIECES % 4 == 0 || k < G::PIECES) {
+                const int soff = ((chunk * 25 + ky * 5 + k / NI) * Cout + (k % NI) * 32) * 32;
+                glds16(rb, sB_addr + (unsigned)((slot * SLOT + k * 64) * 16), bvoff, soff);
+            }
+        }
+    };
+    const int chunks = p.C1 >> 4;
+    gldsB(0, 0, 0);
+    fetchA(0);
+    commitA(0);
+    dma_wait();
+    __syncthreads();
+    for (int c = 0; c < chunks; ++c) {
+        const int ab = G::ADBL ? (c & 1) * ABUF : 0;
+        const bool more = c + 1 < chunks;
+#pragma unroll
+        for (int ky = 0; ky < 5; ++ky) {
+            const int slot = (c + ky) & 1;                 // (5 c + ky) & 1
+            if (ky < 4) gldsB(c, ky + 1, slot ^ 1);
+            else if (more) gldsB(c + 1, 0, slot ^ 1);
+            if (ky == 0 && more) fetchA((c + 1) * 16);
+            const uint4* sBs = sB + slot * SLOT + bbase;
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) {
+                bf16x8 a[MI], b[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const uint4 v = sA[ab + abase[mi] + ky * 32 + kx];
+                    a[mi] = *reinterpret_cast<const bf16x8*>(&v);
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const uint4 v = sBs[(kx * TN + ni * 32) * 2];
+                    b[ni] = *reinterpret_cast<const bf16x8*>(&v);
+                }
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            }
+            if (G::ADBL && ky == 4 && more) commitA(ab ^ ABUF);
+            dma_wait();                                    // the next kernel row has landed ...
+            __syncthreads();                               // ... and everyone is done with this one (slot and A buffer free)
+            if (!G::ADBL && ky == 4 && more) {
+                commitA(0);
+                __syncthreads();
+            }
+        }
+    }
+    // epilogue: per-wave private LDS scratch (the loop's last barrier released the tiles) -> wave-level ordering only
+    float* elds = reinterpret_cast<float*>(smem_raw) + wave * (32 * (NI * 32 + EPI_PAD));
+    if (p.pool_out) {                                      // fused activation + 2x2 max-pool (even Hout / Wout)
+        const int Hp = p.Hout >> 1, Wp = p.Wout >> 1;
+        const float al = p.act == 1 ? p.alpha : 1.0f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int py = (ty0 >> 1) + wave * MI + mi;
+            pool_via_lds<NI, false>(acc[mi], elds, lane, al,
+                [&](int c) {
+                    return p.bias ? *reinterpret_cast<const float4*>(p.bias + co0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                },
+                [&](int pc, int c, float4 v, uchar4 k) {
+                    const int co = co0 + c, px = (tx0 >> 1) + pc;
+                    if (grp >= p.N || py >= Hp || px >= Wp) return;
+                    const long o = (((long)grp * Hp + py) * Wp + px) * Cout + co;
+                    if (p.flags & NIMG_BF16_OUT) store4_bf16(p.pool_out, o, v);
+                    else *reinterpret_cast<float4*>(p.pool_out + o) = v;
+                    if (p.pool_idx) *reinterpret_cast<uchar4*>(p.pool_idx + o) = k;
+                });
+        }
+        return;
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        epilogue_via_lds<NI, false>(acc[mi], elds, lane, [&](int row, int c, float4 v) {
+            const int co = co0 + c;
+            const int P = (wave * MI + mi) * 32 + row;
+            const int oy = ty0 + P / TW, ox = tx0 + P % TW;
+            if (grp >= p.N || oy >= p.Hout || ox >= p.Wout) return;
+            const long o = (((long)grp * p.Hout + oy) * p.Wout + ox) * Cout + co;
+            if (p.bias) {
+                const float4 b = *reinterpret_cast<const float4*>(p.bias + co);
+                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+            }
+            if (p.act == 1) {
+                v.x = lrelu(v.x, p.alpha); v.y = lrelu(v.y, p.alpha); v.z = lrelu(v.z, p.alpha); v.w = lrelu(v.w, p.alpha);
+            }
+            if (p.act1) {
+                const float4 m = (p.flags & NIMG_BF16_MASK) ? load4_bf16(p.act1, o) : *reinterpret_cast<const float4*>(p.act1 + o);
+                v.x *= m.x > 0.f ? 1.0f : p.alpha; v.y *= m.y > 0.f ? 1.0f : p.alpha;
+                v.z *= m.z > 0.f ? 1.0f : p.alpha; v.w *= m.w > 0.f ? 1.0f : p.alpha;
+            }
+            if (p.flags & NIMG_BF16_OUT) store4_bf16(p.out1, o, v);
+            else *reinterpret_cast<float4*>(p.out1 + o) = v;
+        });
+    }
+}
+
+template <int TN>
+int launch_conv5_ring(const ConvParamsB& p, hipStream_t stream) {
+    using G = RingGeom<TN>;
+    ConvParamsB q = p;
+    q.tiles_y = cdiv(p.Hout, G::TH);
+    q.tiles_x = cdiv(p.Wout, G::TW);
+    const long blocks = (long)(p.O1 / TN) * q.tiles_y * q.tiles_x * p.N;
+    auto kern = p.in_idx ? conv5_ring_kernel<TN, true> : conv5_ring_kernel<TN, false>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), G::LDS, stream, q);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
 template <int KS, int STRIDE, int TH, int TW, int NB, int TN, bool INB = false, bool BUF = false>
 int launch_conv_b(const ConvParamsB& p, hipStream_t stream) {
     if constexpr (INB && !BUF && KS == 5 && STRIDE == 1 && 128 % TN == 0) {
@@ -466,8 +718,17 @@ int launch_conv_b(const ConvParamsB& p, hipStream_t stream) {
         const long in_bytes = ((long)p.N * p.H * p.W * p.C1 * 2) >> (p.in_idx ? 2 : 0);
         const long w_bytes = (long)(p.CinP >> 4) * KS * KS * 16 * Cout * 2;
         if (!no_buf && p.C2 == 0 && Cin % 16 == 0 && Cout % TN == 0 && !p.convt && in_bytes < (1l << 31) - 65536 &&
-            w_bytes < (1l << 31) - 65536)
+            w_bytes < (1l << 31) - 65536) {
+            if constexpr (TH == 16 && TW == 16 && NB == 1 && TN == 64) {
+                static const bool no_ring = getenv("NIMG_NO_CONV5_RING") != nullptr;
+                static const bool no_ring64 = getenv("NIMG_NO_CONV5_RING64") != nullptr;
+                if (!no_ring && p.O2 == 0 && p.pad_t == 2 && p.pad_l == 2 && p.Hout == p.H && p.Wout == p.W) {
+                    if (Cout % 128 == 0) return launch_conv5_ring<128>(p, stream);
+                    if (!no_ring64 && p.Hout >= 32) return launch_conv5_ring<64>(p, stream);
+                }
+            }
             return launch_conv_b<KS, STRIDE, TH, TW, NB, TN, true, true>(p, stream);
+        }
     }
     constexpr int THH = (TH - 1) * STRIDE + KS, TWH = (TW - 1) * STRIDE + KS;
     constexpr bool PLANAR = (STRIDE == 1 && TW == 16 && NB == 1 && KS == 5);   // 3x3: the extra registers cost a wave per SIMD

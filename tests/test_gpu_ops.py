@@ -715,13 +715,16 @@ def test_conv2d_bf16_mode(dev, bf16_mode, case):
         assert_close(dx.cpu().numpy(), x.grad.numpy(), 0.0, 1.5e-2, what='bf16 dgrad {}'.format(case))
 
 
-@pytest.mark.parametrize('shape', [(1, 64, 64, 64, 128), (1, 32, 32, 128, 256)])
+@pytest.mark.parametrize('shape', [(1, 64, 64, 64, 128), (1, 32, 32, 128, 256), (1, 128, 128, 32, 64), (2, 48, 40, 64, 64),
+                                   (2, 24, 40, 32, 128)])
 @pytest.mark.parametrize('stored_bf16', [False, True])
 def test_dominant_conv5_at_bench_shapes(dev, bf16_mode, shape, stored_bf16):
-    """The kernel family bench.py's roofline is quoted on - conv_fwd_bf16_kernel<5,1,16,16,1,64,...> / conv_wgrad_bf16_kernel<5,..>
-    at the layer shapes of the bench (FAN conv3: 64 -> 128 @ 64x64, conv4: 128 -> 256 @ 32x32; 4 and 8 channel chunks, 16x16
-    tiles), forward (plain and with the fused LeakyReLU + pool epilogue), input gradient and weight gradient against the float64
-    oracle, with float32 tensors and with the bf16-stored tensors the throughput-mode FAN feeds it."""
+    """The kernel family bench.py's roofline is quoted on - conv5_ring_kernel<128 / 64> (bf16-stored tensors, Cout % 64 == 0),
+    conv_fwd_bf16_kernel<5,1,16,16,1,64,...> (float32 tensors) and conv_wgrad_bf16_kernel<5,..> - at the layer shapes of the
+    bench (FAN conv2: 32 -> 64 @ 128x128, conv3: 64 -> 128 @ 64x64, conv4: 128 -> 256 @ 32x32; 2, 4 and 8 channel chunks) and
+    at two ragged sizes (partial 32x16 / 16x16 tiles), forward (plain and with the fused LeakyReLU + pool epilogue), input
+    gradient and weight gradient against the float64 oracle, with float32 tensors and with the bf16-stored tensors the
+    throughput-mode FAN feeds it."""
     from neural_imaging_amd import ops
     n, h, w, cin, cout = shape
     x_np, dz_np = rnd((n, h, w, cin), 1), rnd((n, h, w, cout), 5)
@@ -743,7 +746,7 @@ def test_dominant_conv5_at_bench_shapes(dev, bf16_mode, shape, stored_bf16):
     win = act.numpy().reshape(n, h // 2, 2, w // 2, 2, cout).transpose(0, 1, 3, 5, 2, 4).reshape(n, h // 2, w // 2, cout, 4)
     srt = np.sort(win, axis=-1)
     clear = (srt[..., 3] - srt[..., 2]) > 2e-2 * np.abs(act.numpy()).max()
-    assert clear.mean() > 0.8 and np.array_equal(idx.cpu().numpy()[clear], win.argmax(axis=-1)[clear])
+    assert clear.mean() > 0.7 and np.array_equal(idx.cpu().numpy()[clear], win.argmax(axis=-1)[clear])
     dx = ops.conv2d_dgrad(dzg, wg, (h, w), out_bf16=stored_bf16)
     assert_close(dx.float().cpu().numpy(), x.grad.numpy(), 0.0, 1.5e-2, what='dgrad')
     dbf = torch.empty((cout,), device=dev)
