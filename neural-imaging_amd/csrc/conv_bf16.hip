@@ -959,14 +959,16 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const Wgrad
         }
         __syncthreads();
         if (wk + 1 < w_end) fetch(wk + 1);
+        // KS == 1 has one tap: the waves share the tile's pixel rows instead (each keeps a partial of the same 32 x 64 block,
+        // folded through LDS behind the loop) - with the tap split three of the four waves had nothing to multiply
 #pragma unroll 1
-        for (int r = 0; r < TH; ++r) {
+        for (int r = (KS == 1 ? wave : 0); r < TH; r += (KS == 1 ? NW : 1)) {
             const unsigned char* zr = sZ + (r * B_TW) * B_ZS + z_lane;
             const bf16x8 b0 = tr_read8(zr, zr + 4 * B_ZS);
             const bf16x8 b1 = tr_read8(zr + 64, zr + 4 * B_ZS + 64);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const int tap = wave + NW * t;
+                const int tap = KS == 1 ? 0 : wave + NW * t;
                 if (tap < TAPS) {
                     const unsigned char* ir = sI + ((r * STRIDE + tap / KS) * TWH + (tap % KS)) * 64 + a_lane;
                     const bf16x8 a = tr_read8(ir, ir + 4 * STRIDE * 64);
@@ -988,10 +990,29 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const Wgrad
             p.db_partial[(long)split * p.Cout + co0 + tid] = sum;
         }
     }
+    if constexpr (KS == 1) {                    // fold the waves' row partials: waves 1.. park theirs in LDS, wave 0 adds in order
+        static_assert((NW - 1) * 2 * 16 * 64 * 4 <= NPIXH * 64 + NPIX * B_ZS, "fold scratch fits the tiles");
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem_raw);
+        if (wave > 0) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) red[(((wave - 1) * 2 + ni) * 16 + j) * 64 + lane] = acc[0][ni][j];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 1; w < NW; ++w)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[0][ni][j] += red[(((w - 1) * 2 + ni) * 16 + j) * 64 + lane];
+    }
     float* slab = p.partial + (long)split * TAPS * Cin * p.Cout;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int tap = wave + NW * t;
+        const int tap = KS == 1 ? 0 : wave + NW * t;
         if (tap >= TAPS) continue;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
