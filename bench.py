@@ -214,7 +214,8 @@ def time_conv5_dominant(dev, n, reps=20):
     flops = 2.0 * 25 * 64 * 128 * 64 * 64 * n
     kname = 'conv_fwd_kernel<5,1,16,16,1,64,8>' if ops.COMPUTE == 'f32' else (
         'conv5_ring_kernel<128>' if stored_bf16 else 'conv_fwd_bf16_kernel<5,1,16,16,1,64>')
-    traffic = _pmc_traffic('r01_pmc_dominant_kernel.json', 'bf16_stored_input_pooled' if stored_bf16 else ops.COMPUTE, n)
+    traffic = _pmc_traffic('r02_pmc_ring_kernel.json', 'bf16_stored_input_pooled', n) if stored_bf16 else \
+        _pmc_traffic('r01_pmc_dominant_kernel.json', ops.COMPUTE, n)
     return {'kernel': kname + ' (FAN conv3 fwd{}, {}x64x64x64->128)'.format(' + LReLU + pool' if stored_bf16 else '', n),
             'traffic': traffic, 'flops_per_launch': flops, 'ms_per_launch': ms, 'tflops': flops / (ms * 1e-3) / 1e12}
 
