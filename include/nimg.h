@@ -31,8 +31,8 @@ extern "C" {
 #define NIMG_ERR_WORKSPACE (-3) /* workspace too small */
 
 /* tensor-storage flags of the *_ex throughput-mode entry points: the named tensor holds bf16 instead of float32 */
-#define NIMG_BF16_IN 1    /* in1 (convolutions: requires c2 == 0, c1 % 8 == 0) / dp (un-pool) */
-#define NIMG_BF16_OUT 2   /* out1 / pool_out / dz of the un-pool */
+#define NIMG_BF16_IN 1    /* in1 AND in2 (convolutions: c1 % 8 == 0, c2 % 8 == 0) / dp (un-pool) */
+#define NIMG_BF16_OUT 2   /* out1 AND out2 (o1 % 4 == 0, o2 % 4 == 0) / pool_out / dz of the un-pool */
 #define NIMG_BF16_MASK 4  /* act_mask */
 #define NIMG_BF16_DZ 8    /* dz of a weight gradient (cout % 8 == 0) */
 
@@ -91,6 +91,9 @@ int nimg_conv2d_wgrad(const float* in1, int c1, const float* in2, int c2, const 
 size_t nimg_bias_grad_workspace_bytes(long npix, int cout);
 int nimg_bias_grad(const float* dz, float* db, long npix, int cout, int accumulate, void* workspace,
                    size_t workspace_bytes, void* stream);
+/* flags: NIMG_BF16_DZ = dz is stored as bf16 (cout % 4 == 0, cout / 4 divides 256); sums in float32 */
+int nimg_bias_grad_ex(const float* dz, float* db, long npix, int cout, int accumulate, void* workspace,
+                      size_t workspace_bytes, int flags, void* stream);
 /* Conv2DTranspose(k=2,s=2,SAME), kernel (2,2,cout,cin) - models/pipelines.py:205.  Its input gradient is
  * nimg_conv2d_fwd(ks=2,stride=2) on the same kernel, its weight gradient nimg_conv2d_wgrad(ks=2,stride=2) with the
  * roles of input and output gradient swapped (see neural-imaging_amd/models/pipelines.py). */
@@ -105,6 +108,12 @@ int nimg_maxpool2_fwd(const float* x, float* y, int n, int h, int w, int c, void
 /* dz = (route dp to the FIRST arg-max of each window) [+ add] [* LeakyReLU'(yact)]; add may alias dz */
 int nimg_maxpool2_bwd(const float* dp, const float* yact, const float* add, float* dz, int n, int h, int w, int c,
                       int apply_lrelu_mask, float alpha, void* stream);
+/* The same two passes on bf16-stored tensors (UNet activations / gradients in throughput mode: pipelines.py:197 and its
+ * gradient); h, w even, c % 8 == 0; every tensor argument is bf16.  Rounding is monotonic, so pooling the rounded tensor
+ * equals rounding the pooled one. */
+int nimg_maxpool2_fwd_bf16(const void* x, void* y, int n, int h, int w, int c, void* stream);
+int nimg_maxpool2_bwd_bf16(const void* dp, const void* yact, const void* add, void* dz, int n, int h, int w, int c,
+                           int apply_lrelu_mask, float alpha, void* stream);
 /* Fused Conv2D(SAME, stride 1) -> [LeakyReLU] -> MaxPool2D(2) of the FAN feature extractor (models/forensics.py:69-77:
  * every conv{i} is followed by its pool; the full-resolution activation is consumed by nothing else), float32 MFMA.
  * pool_out (n,h/2,w/2,cout) receives the pooled activation, pool_idx (same shape, bytes; may be NULL for inference)
@@ -393,6 +402,9 @@ int nimg_maxpool2_unpool_ex(const float* dp, const unsigned char* idx, const flo
  * (2,2,Cout,Cin) kernel; x (n,h,wd,cin) -> y (n,2h,2wd,cout); cin % 8 == 0. */
 int nimg_convt2x2_fwd_bf16(const float* x, const void* wb, const float* bias, float* y, int n, int h, int wd, int cin,
                            int cout, void* stream);
+/* flags: NIMG_BF16_IN = x is stored as bf16, NIMG_BF16_OUT = y is stored as bf16 (cout % 4 == 0) */
+int nimg_convt2x2_fwd_bf16_ex(const float* x, const void* wb, const float* bias, float* y, int n, int h, int wd, int cin,
+                              int cout, int flags, void* stream);
 /* every bf16 weight image of a model in one launch: `table` = n_entries x 4 int64 on the device,
  * {w pointer, wb pointer, (kh*kw << 32) | mode, (cin << 32) | cout}, each entry as nimg_conv_weights_bf16 would build it */
 int nimg_conv_weights_bf16_batch(const void* table, int n_entries, void* stream);
@@ -411,6 +423,9 @@ int nimg_conv2d_wgrad_bf16(const float* in1, int c1, const float* in2, int c2, c
  * FORWARD kernel as stored).  nimg_conv2d_wgrad_bf16 picks the (tap, ci)-packed weight-gradient kernel by itself. */
 int nimg_conv2d_fwd_smallc_bf16(const float* in, int cin, const float* w, const float* bias, float* out, int cout,
                                 int n, int h, int wd, int ks, int pad_mode, int act, float alpha, void* stream);
+/* flags: NIMG_BF16_OUT = out is stored as bf16 (cout % 4 == 0): the UNet's first convolution (pipelines.py:191, 4 -> 32) */
+int nimg_conv2d_fwd_smallc_bf16_ex(const float* in, int cin, const float* w, const float* bias, float* out, int cout,
+                                   int n, int h, int wd, int ks, int pad_mode, int act, float alpha, int flags, void* stream);
 int nimg_conv2d_dgrad_fewin_bf16(const float* dz, const float* w, float* out, int ci, int cz, int n, int h, int wd,
                                  int ks, void* stream);
 

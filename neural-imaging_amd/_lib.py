@@ -27,9 +27,12 @@ PROTOTYPES = {
                                   c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'nimg_bias_grad_workspace_bytes': (c_size_t, [c_long, c_int]),
     'nimg_bias_grad': (c_int, [P, P, c_long, c_int, c_int, P, c_size_t, P]),
+    'nimg_bias_grad_ex': (c_int, [P, P, c_long, c_int, c_int, P, c_size_t, c_int, P]),
     'nimg_convt2x2_fwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'nimg_maxpool2_fwd': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'nimg_maxpool2_bwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, P]),
+    'nimg_maxpool2_fwd_bf16': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'nimg_maxpool2_bwd_bf16': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, P]),
     'nimg_conv2d_pool_fwd': (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P]),
     'nimg_conv2d_pool_fwd_bf16': (c_int, [P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                           P]),
@@ -122,8 +125,11 @@ PROTOTYPES = {
     'nimg_maxpool2_unpool_ex': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),
     'nimg_conv_weights_bf16_batch': (c_int, [P, c_int, P]),
     'nimg_convt2x2_fwd_bf16': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'nimg_convt2x2_fwd_bf16_ex': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'nimg_conv2d_fwd_smallc_bf16': (c_int, [P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                             c_float, P]),
+    'nimg_conv2d_fwd_smallc_bf16_ex': (c_int, [P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                               c_float, c_int, P]),
     'nimg_conv2d_dgrad_fewin_bf16': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'nimg_awgn_fwd': (c_int, [P, P, P, P, c_long, c_float, P]),
     'nimg_awgn_bwd': (c_int, [P, P, P, P, P, c_long, c_float, P]),

@@ -118,7 +118,7 @@ struct ConvParamsB {
     int tiles_y, tiles_x, act, pad_mode;
     float alpha;
     int convt;            // 1: Conv2DTranspose(2x2, stride 2) as four 1x1 products; workgroup id & 3 = output phase (dy, dx)
-    int flags;            // NIMG_BF16_IN: in1 holds bf16 (C2 == 0); _OUT: out1 / pool_out are bf16; _MASK: act1 is bf16
+    int flags;            // NIMG_BF16_IN: in1 (and in2) hold bf16; _OUT: out1 / out2 / pool_out are bf16; _MASK: act1 is bf16
     const unsigned char* in_idx;   // UNP kernels: in1 is the POOLED tensor (N, H/2, W/2, C1) bf16 and in_idx its arg-max bytes;
                                    // the convolution runs on their 2x2 un-pooling (H x W), built while staging
 };
@@ -276,8 +276,10 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
             preA[q][0] = preA[q][1] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (apix[q] >= 0 && c < Cin) {
                 const long pixoff = apix[q];
-                if constexpr (INB) {                 // the tensor already holds bf16: 16 bytes = this item's 8 channels
-                    preA[q][0] = *reinterpret_cast<const float4*>(reinterpret_cast<const __bf16*>(p.in1) + pixoff * p.C1 + c);
+                if constexpr (INB) {                 // the tensors already hold bf16: 16 bytes = this item's 8 channels
+                    const __bf16* src = c < p.C1 ? reinterpret_cast<const __bf16*>(p.in1) + pixoff * p.C1 + c
+                                                 : reinterpret_cast<const __bf16*>(p.in2) + pixoff * p.C2 + (c - p.C1);
+                    preA[q][0] = *reinterpret_cast<const float4*>(src);
                 } else {
                     const float* src = c < p.C1 ? p.in1 + pixoff * p.C1 + c : p.in2 + pixoff * p.C2 + (c - p.C1);
                     preA[q][0] = *reinterpret_cast<const float4*>(src);
@@ -423,7 +425,8 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
                     if (p.flags & NIMG_BF16_OUT) store4_bf16(p.out1, pixoff * p.O1 + co, v);
                     else *reinterpret_cast<float4*>(p.out1 + pixoff * p.O1 + co) = v;
                 } else {
-                    *reinterpret_cast<float4*>(p.out2 + pixoff * p.O2 + (co - p.O1)) = v;
+                    if (p.flags & NIMG_BF16_OUT) store4_bf16(p.out2, pixoff * p.O2 + (co - p.O1), v);
+                    else *reinterpret_cast<float4*>(p.out2 + pixoff * p.O2 + (co - p.O1)) = v;
                 }
             });
         }
@@ -776,7 +779,9 @@ int dispatch_b_t(const ConvParamsB& p, hipStream_t s) {
 
 template <int KS, int STRIDE>
 int dispatch_b(const ConvParamsB& p, hipStream_t s) {
-    if constexpr (STRIDE == 1) {          // bf16-stored inputs exist for the stride-1 layers only (FAN)
+    if constexpr (STRIDE == 1) {          // bf16-stored inputs: the stride-1 layers (FAN, UNet) ...
+        if (p.flags & NIMG_BF16_IN) return dispatch_b_t<KS, STRIDE, true>(p, s);
+    } else if constexpr (KS == 2) {       // ... and for the 2x2 / stride-2 form (input gradient of the UNet's Conv2DTranspose)
         if (p.flags & NIMG_BF16_IN) return dispatch_b_t<KS, STRIDE, true>(p, s);
     } else {
         if (p.flags & NIMG_BF16_IN) return NIMG_ERR_ARG;
@@ -796,7 +801,7 @@ struct WgradParamsB {
     int C1, C2, Cout;
     int N, H, W, Hout, Wout, pad_t, pad_l;
     int tiles_y, tiles_x, splits, work_per_split, pad_mode;
-    int flags;                     // NIMG_BF16_IN: in1 holds bf16 (C2 == 0); NIMG_BF16_DZ: dz holds bf16
+    int flags;                     // NIMG_BF16_IN: in1 (and in2) hold bf16; NIMG_BF16_DZ: dz holds bf16
 };
 
 constexpr int B_TH = 8, B_TW = 16, B_CI = 32, B_CO = 64;
@@ -882,8 +887,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const Wgrad
             preI[q][0] = preI[q][1] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (item < NPIXH * 4 && c < Cin && map_coord(gy, p.H, p.pad_mode) && map_coord(gx, p.W, p.pad_mode)) {
                 const long pixoff = ((long)n_ * p.H + gy) * p.W + gx;
-                if constexpr (INB) {                 // Cin % 8 == 0 (entry point): the 8 channels are one 16-byte load
-                    preI[q][0] = *reinterpret_cast<const float4*>(reinterpret_cast<const __bf16*>(p.in1) + pixoff * p.C1 + c);
+                if constexpr (INB) {                 // C1 % 8 == 0, C2 % 8 == 0 (entry point): the 8 channels are one 16-byte load
+                    const __bf16* src = c < p.C1 ? reinterpret_cast<const __bf16*>(p.in1) + pixoff * p.C1 + c
+                                                 : reinterpret_cast<const __bf16*>(p.in2) + pixoff * p.C2 + (c - p.C1);
+                    preI[q][0] = *reinterpret_cast<const float4*>(src);
                 } else {
                     const float* src = c < p.C1 ? p.in1 + pixoff * p.C1 + c : p.in2 + pixoff * p.C2 + (c - p.C1);
                     preI[q][0] = *reinterpret_cast<const float4*>(src);
@@ -1079,9 +1086,9 @@ static int conv2d_fwd_bf16_impl(const float* in1, int c1, const float* in2, int 
     ConvParamsB p;
     p.in1 = in1; p.in2 = in2; p.wb = (const __bf16*)wb; p.bias = bias; p.out1 = out1; p.out2 = out2; p.act1 = act_mask;
     p.pool_out = nullptr; p.pool_idx = nullptr; p.convt = 0; p.flags = flags; p.in_idx = in_idx;
-    if ((flags & NIMG_BF16_IN) && c2 != 0) return NIMG_ERR_ARG;
     if (in_idx && (!(flags & NIMG_BF16_IN) || stride != 1 || ks != 5 || (h & 1) || (wd & 1) || pad_mode != 0)) return NIMG_ERR_ARG;
-    if ((flags & (NIMG_BF16_OUT | NIMG_BF16_MASK)) && (o2 != 0 || (o1 & 3))) return NIMG_ERR_ARG;
+    if ((flags & (NIMG_BF16_OUT | NIMG_BF16_MASK)) && ((o1 & 3) || (o2 & 3))) return NIMG_ERR_ARG;   // vector epilogue only
+    if ((flags & NIMG_BF16_MASK) && o2 != 0) return NIMG_ERR_ARG;
     p.C1 = c1; p.C2 = c2; p.O1 = o1; p.O2 = o2; p.CinP = (c1 + c2 + 15) / 16 * 16;
     p.N = n; p.H = h; p.W = wd; p.Hout = hout; p.Wout = wout; p.pad_t = pad_t; p.pad_l = pad_l;
     p.tiles_y = p.tiles_x = 0; p.act = act; p.pad_mode = pad_mode; p.alpha = alpha;
@@ -1128,12 +1135,18 @@ int nimg_conv2d_fwd_bf16_unpool(const void* in_pooled, const unsigned char* in_i
  * kernel (2,2,Cout,Cin).  x (n,h,wd,cin) -> y (n,2h,2wd,cout). */
 int nimg_convt2x2_fwd_bf16(const float* x, const void* wb, const float* bias, float* y, int n, int h, int wd, int cin,
                            int cout, void* stream) {
+    return nimg_convt2x2_fwd_bf16_ex(x, wb, bias, y, n, h, wd, cin, cout, 0, stream);
+}
+
+/* flags: NIMG_BF16_IN = x is stored as bf16, NIMG_BF16_OUT = y is stored as bf16 (cout % 4 == 0) */
+int nimg_convt2x2_fwd_bf16_ex(const float* x, const void* wb, const float* bias, float* y, int n, int h, int wd, int cin,
+                              int cout, int flags, void* stream) {
     if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!x || !wb || !y || n < 0 || h <= 0 || wd <= 0 || cin <= 0 || cout <= 0 || (cin % 8)) return NIMG_ERR_ARG;
-    if (n == 0) return NIMG_OK;
+    if ((flags & ~(NIMG_BF16_IN | NIMG_BF16_OUT)) || ((flags & NIMG_BF16_OUT) && (cout & 3))) return NIMG_ERR_ARG;
     ConvParamsB p;
     p.in1 = x; p.in2 = nullptr; p.wb = (const __bf16*)wb; p.bias = bias; p.out1 = y; p.out2 = nullptr; p.act1 = nullptr;
-    p.pool_out = nullptr; p.pool_idx = nullptr; p.convt = 1; p.flags = 0; p.in_idx = nullptr;
+    p.pool_out = nullptr; p.pool_idx = nullptr; p.convt = 1; p.flags = flags; p.in_idx = nullptr;
     p.C1 = cin; p.C2 = 0; p.O1 = cout; p.O2 = 0; p.CinP = (cin + 15) / 16 * 16;
     p.N = n; p.H = h; p.W = wd; p.Hout = h; p.Wout = wd; p.pad_t = 0; p.pad_l = 0;
     p.tiles_y = p.tiles_x = 0; p.act = 0; p.pad_mode = 0; p.alpha = 0.f;
@@ -1164,7 +1177,7 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
                            const unsigned char* dz_idx, int cout, float* dw, float* db, int n, int h, int wd, int ks,
                            int stride, int pad_t, int pad_l, int pad_mode, int hout, int wout, int accumulate,
                            void* workspace, size_t workspace_bytes, int flags, void* stream) {
-    if ((flags & NIMG_BF16_IN) && (c2 != 0 || (c1 & 7))) return NIMG_ERR_ARG;
+    if ((flags & NIMG_BF16_IN) && ((c1 & 7) || (c2 & 7))) return NIMG_ERR_ARG;        /* in1 and in2 are both bf16 then */
     if ((flags & NIMG_BF16_DZ) && (cout & 7)) return NIMG_ERR_ARG;
     if (flags && !dz_idx && c2 == 0 && c1 <= 4) return NIMG_ERR_ARG;        /* the packed / tiny kernels stage float32 */
     if (dz_idx && c1 <= 4 && (flags & ~NIMG_BF16_DZ)) return NIMG_ERR_ARG;
@@ -1250,11 +1263,13 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
     do {                                                                                                      \
         constexpr int NW = KS_ == 5 ? 8 : 4;                                                                  \
         constexpr int TH_ = (KS_ == 5 && ST_ == 1) ? 16 : B_TH;                                               \
-        constexpr int S1 = ST_ == 1 ? ST_ : 1;              /* bf16-stored operands exist for stride 1 only */    \
-        constexpr int T1 = ST_ == 1 ? TH_ : B_TH;                                                             \
-        if (ST_ == 1 && (p.flags & NIMG_BF16_IN) && (p.flags & NIMG_BF16_DZ)) NIMG_WGB1(KS_, S1, NW, true, true, T1);    \
-        else if (ST_ == 1 && (p.flags & NIMG_BF16_IN)) NIMG_WGB1(KS_, S1, NW, true, false, T1);               \
-        else if (ST_ == 1 && (p.flags & NIMG_BF16_DZ)) NIMG_WGB1(KS_, S1, NW, false, true, T1);               \
+        /* bf16-stored operands: the stride-1 layers and the 2x2 / stride-2 form (UNet Conv2DTranspose weight gradient) */ \
+        constexpr bool BFOK = ST_ == 1 || KS_ == 2;                                                           \
+        constexpr int S1 = BFOK ? ST_ : 1;                                                                    \
+        constexpr int T1 = BFOK ? TH_ : B_TH;                                                                 \
+        if (BFOK && (p.flags & NIMG_BF16_IN) && (p.flags & NIMG_BF16_DZ)) NIMG_WGB1(KS_, S1, NW, true, true, T1);    \
+        else if (BFOK && (p.flags & NIMG_BF16_IN)) NIMG_WGB1(KS_, S1, NW, true, false, T1);                   \
+        else if (BFOK && (p.flags & NIMG_BF16_DZ)) NIMG_WGB1(KS_, S1, NW, false, true, T1);                   \
         else if (p.flags) return NIMG_ERR_ARG;                                                                \
         else NIMG_WGB1(KS_, ST_, NW, false, false, TH_);                                                      \
     } while (0)
@@ -1482,7 +1497,9 @@ __global__ __launch_bounds__(256) void conv_fwd_packed_bf16_kernel(const float* 
                     if (act == 1) {
                         v.x = lrelu(v.x, alpha); v.y = lrelu(v.y, alpha); v.z = lrelu(v.z, alpha); v.w = lrelu(v.w, alpha);
                     }
-                    *reinterpret_cast<float4*>(out + (((long)n * H + oy) * W + ox) * Cout + co) = v;
+                    const long o = (((long)n * H + oy) * W + ox) * Cout + co;
+                    if (out_bf16) store4_bf16(out, o, v);
+                    else *reinterpret_cast<float4*>(out + o) = v;
                 });
             }
             continue;
@@ -1844,11 +1861,17 @@ static int launch_packed_bf16(const float* in, int cin, const float* w, const fl
 
 int nimg_conv2d_fwd_smallc_bf16(const float* in, int cin, const float* w, const float* bias, float* out, int cout,
                                 int n, int h, int wd, int ks, int pad_mode, int act, float alpha, void* stream) {
+    return nimg_conv2d_fwd_smallc_bf16_ex(in, cin, w, bias, out, cout, n, h, wd, ks, pad_mode, act, alpha, 0, stream);
+}
+
+/* flags: NIMG_BF16_OUT = out is stored as bf16 (cout % 4 == 0) */
+int nimg_conv2d_fwd_smallc_bf16_ex(const float* in, int cin, const float* w, const float* bias, float* out, int cout,
+                                   int n, int h, int wd, int ks, int pad_mode, int act, float alpha, int flags, void* stream) {
     if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!in || !w || !out || n < 0 || h <= 0 || wd <= 0 || cout <= 0 || pad_mode < 0 || pad_mode > 2) return NIMG_ERR_ARG;
-    if (n == 0) return NIMG_OK;
+    if ((flags & ~NIMG_BF16_OUT) || ((flags & NIMG_BF16_OUT) && (cout & 3))) return NIMG_ERR_ARG;
     return launch_packed_bf16(in, cin, w, bias, out, nullptr, nullptr, cout, n, h, wd, ks, pad_mode, act, alpha,
-                              (hipStream_t)stream);
+                              (hipStream_t)stream, (flags & NIMG_BF16_OUT) ? 1 : 0);
 }
 
 /* conv (SAME, stride 1) + optional LeakyReLU + 2x2/2 max-pool in one pass, bf16 operands: w = f32 kernel (used when

@@ -300,6 +300,21 @@ __global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __r
 }
 
 // float4 variant (cout % 4 == 0 and cout/4 divides 256): 16-byte loads, 4 independent accumulators per thread
+// BF: dz is stored as bf16 (8-byte loads of 4 channels, summed in float32)
+typedef __bf16 bg_bf16x4 __attribute__((ext_vector_type(4)));
+template <bool BF>
+struct BiasSrc {
+    const void* base;
+    __device__ __forceinline__ float4 operator[](long i) const {
+        if constexpr (BF) {
+            const bg_bf16x4 v = reinterpret_cast<const bg_bf16x4*>(base)[i];
+            return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+        } else {
+            return reinterpret_cast<const float4*>(base)[i];
+        }
+    }
+};
+template <bool BF>
 __global__ __launch_bounds__(256) void bias_grad_partial4_kernel(const float* __restrict__ dz,
                                                                  float* __restrict__ partial, long npix, int cout,
                                                                  long pix_per_block) {
@@ -307,19 +322,19 @@ __global__ __launch_bounds__(256) void bias_grad_partial4_kernel(const float* __
     const int tid = threadIdx.x, cq = cout >> 2, phases = 256 / cq;
     const int c = tid % cq, ph = tid / cq;
     const long p0 = (long)blockIdx.x * pix_per_block, p1 = min(npix, p0 + pix_per_block);
-    const float4* src = reinterpret_cast<const float4*>(dz) + c;
+    const BiasSrc<BF> srcb{dz};
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
     long px = p0 + ph;
     for (; px + 3L * phases < p1; px += 4L * phases) {
-        const float4 v0 = src[px * cq], v1 = src[(px + phases) * cq], v2 = src[(px + 2L * phases) * cq],
-                     v3 = src[(px + 3L * phases) * cq];
+        const float4 v0 = srcb[px * cq + c], v1 = srcb[(px + phases) * cq + c], v2 = srcb[(px + 2L * phases) * cq + c],
+                     v3 = srcb[(px + 3L * phases) * cq + c];
         a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
         a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
         a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
         a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
     }
     for (; px < p1; px += phases) {
-        const float4 v = src[px * cq];
+        const float4 v = srcb[px * cq + c];
         a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w;
     }
     red4[tid] = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y),
@@ -458,14 +473,24 @@ size_t nimg_bias_grad_workspace_bytes(long npix, int cout) {
 
 int nimg_bias_grad(const float* dz, float* db, long npix, int cout, int accumulate, void* workspace,
                    size_t workspace_bytes, void* stream) {
-    if (!dz || !db || npix <= 0 || cout <= 0 || !workspace) return NIMG_ERR_ARG;
+    return nimg_bias_grad_ex(dz, db, npix, cout, accumulate, workspace, workspace_bytes, 0, stream);
+}
+
+/* flags: NIMG_BF16_DZ = dz is stored as bf16 (cout % 4 == 0 and cout / 4 divides 256) */
+int nimg_bias_grad_ex(const float* dz, float* db, long npix, int cout, int accumulate, void* workspace,
+                      size_t workspace_bytes, int flags, void* stream) {
+    if (!dz || !db || npix <= 0 || cout <= 0 || !workspace || (flags & ~NIMG_BF16_DZ)) return NIMG_ERR_ARG;
+    if ((flags & NIMG_BF16_DZ) && !((cout & 3) == 0 && (cout >> 2) <= 256 && 256 % (cout >> 2) == 0)) return NIMG_ERR_ARG;
     if (workspace_bytes < nimg_bias_grad_workspace_bytes(npix, cout)) return NIMG_ERR_WORKSPACE;
     const long blocks = bias_grad_blocks(npix);
     const long ppb = (npix + blocks - 1) / blocks;
     hipStream_t s = (hipStream_t)stream;
-    if ((cout & 3) == 0 && (cout >> 2) <= 256 && 256 % (cout >> 2) == 0)
-        hipLaunchKernelGGL(bias_grad_partial4_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dz, (float*)workspace, npix,
-                           cout, ppb);
+    if (flags & NIMG_BF16_DZ)
+        hipLaunchKernelGGL(bias_grad_partial4_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, dz, (float*)workspace,
+                           npix, cout, ppb);
+    else if ((cout & 3) == 0 && (cout >> 2) <= 256 && 256 % (cout >> 2) == 0)
+        hipLaunchKernelGGL(bias_grad_partial4_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, dz, (float*)workspace,
+                           npix, cout, ppb);
     else
         hipLaunchKernelGGL(bias_grad_partial_kernel, dim3((unsigned)blocks), dim3(256), 256 * sizeof(float), s, dz,
                            (float*)workspace, npix, cout, ppb);

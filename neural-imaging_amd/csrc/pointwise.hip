@@ -127,6 +127,71 @@ __global__ void maxpool2_unpool_kernel(const float* __restrict__ dp, const unsig
     }
 }
 
+// bf16-stored activations (UNet in throughput mode): 8 channels = 16 bytes per lane.  Rounding to bf16 is monotonic, so
+// the maximum of the rounded values is the rounded maximum - pooling bf16 tensors changes nothing for their bf16 consumers.
+typedef __bf16 nimg_bf16x8 __attribute__((ext_vector_type(8)));
+__global__ void maxpool2_fwd_bf16_kernel(const __bf16* __restrict__ x, __bf16* __restrict__ y, int n, int h, int w, int c) {
+    const int ho = h / 2, wo = w / 2, cv = c / 8;
+    const long total = (long)n * ho * wo * cv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % cv) * 8;
+        long r = i / cv;
+        const int ox = (int)(r % wo);
+        r /= wo;
+        const int oy = (int)(r % ho), im = (int)(r / ho);
+        const __bf16* p00 = x + (((long)im * h + 2 * oy) * w + 2 * ox) * c + cc;
+        const __bf16* p10 = p00 + (long)w * c;
+        const nimg_bf16x8 a = *reinterpret_cast<const nimg_bf16x8*>(p00), b = *reinterpret_cast<const nimg_bf16x8*>(p00 + c);
+        const nimg_bf16x8 d = *reinterpret_cast<const nimg_bf16x8*>(p10), e = *reinterpret_cast<const nimg_bf16x8*>(p10 + c);
+        nimg_bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            o[k] = (__bf16)fmaxf(fmaxf((float)a[k], (float)b[k]), fmaxf((float)d[k], (float)e[k]));
+        *reinterpret_cast<nimg_bf16x8*>(y + (((long)im * ho + oy) * wo + ox) * c + cc) = o;
+    }
+}
+
+// maxpool2_bwd_kernel on bf16-stored tensors (dp, yact, add, dz all bf16): same first-maximum routing, skip-gradient add
+// and LeakyReLU' factor, float32 arithmetic per element, one rounding at the store.
+__global__ void maxpool2_bwd_bf16_kernel(const __bf16* __restrict__ dp, const __bf16* __restrict__ yact, const __bf16* add,
+                                         __bf16* dz, int n, int h, int w, int c, int apply_mask, float alpha) {
+    const int ho = h / 2, wo = w / 2, cv = c / 8;
+    const long total = (long)n * ho * wo * cv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % cv) * 8;
+        long r = i / cv;
+        const int ox = (int)(r % wo);
+        r /= wo;
+        const int oy = (int)(r % ho), im = (int)(r / ho);
+        const long base = (((long)im * h + 2 * oy) * w + 2 * ox) * c + cc;
+        const long offs[4] = {0, (long)c, (long)w * c, (long)w * c + c};
+        nimg_bf16x8 v[4], a[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            v[q] = *reinterpret_cast<const nimg_bf16x8*>(yact + base + offs[q]);
+            if (add) a[q] = *reinterpret_cast<const nimg_bf16x8*>(add + base + offs[q]);
+        }
+        const nimg_bf16x8 g = *reinterpret_cast<const nimg_bf16x8*>(dp + (((long)im * ho + oy) * wo + ox) * c + cc);
+        nimg_bf16x8 o[4];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float v0 = (float)v[0][k], v1 = (float)v[1][k], v2 = (float)v[2][k], v3 = (float)v[3][k];
+            const float m = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+            const int sel = v0 == m ? 0 : (v1 == m ? 1 : (v2 == m ? 2 : 3));
+            const float vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float t = (q == sel) ? (float)g[k] : 0.f;
+                if (add) t += (float)a[q][k];
+                if (apply_mask) t *= (vv[q] > 0.f ? 1.0f : alpha);
+                o[q][k] = (__bf16)t;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<nimg_bf16x8*>(dz + base + offs[q]) = o[q];
+    }
+}
+
 // V channels per thread; V == 4 moves float4s (16 B per lane, coalesced along the NHWC channel axis)
 template <int V>
 __global__ void maxpool2_bwd_kernel(const float* __restrict__ dp, const float* __restrict__ yact,
@@ -593,6 +658,27 @@ int nimg_maxpool2_bwd(const float* dp, const float* yact, const float* add, floa
     else
         hipLaunchKernelGGL(maxpool2_bwd_kernel<1>, dim3(grid_for((long)n * (h / 2) * (w / 2) * c)), dim3(256), 0, s,
                            dp, yact, add, dz, n, h, w, c, apply_lrelu_mask, alpha);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+/* MaxPool2D(2) forward / backward on bf16-stored NHWC tensors (even h, w; c % 8 == 0): see nimg_maxpool2_fwd / _bwd */
+int nimg_maxpool2_fwd_bf16(const void* x, void* y, int n, int h, int w, int c, void* stream) {
+    if (n == 0) return NIMG_OK;
+    if (!x || !y || n < 0 || h < 2 || w < 2 || c <= 0 || (h & 1) || (w & 1) || (c & 7)) return NIMG_ERR_ARG;
+    hipLaunchKernelGGL(maxpool2_fwd_bf16_kernel, dim3(grid_for((long)n * (h / 2) * (w / 2) * (c / 8))), dim3(256), 0,
+                       (hipStream_t)stream, (const __bf16*)x, (__bf16*)y, n, h, w, c);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_maxpool2_bwd_bf16(const void* dp, const void* yact, const void* add, void* dz, int n, int h, int w, int c,
+                           int apply_lrelu_mask, float alpha, void* stream) {
+    if (n == 0) return NIMG_OK;
+    if (!dp || !yact || !dz || n < 0 || h < 2 || w < 2 || c <= 0 || (h & 1) || (w & 1) || (c & 7)) return NIMG_ERR_ARG;
+    hipLaunchKernelGGL(maxpool2_bwd_bf16_kernel, dim3(grid_for((long)n * (h / 2) * (w / 2) * (c / 8))), dim3(256), 0,
+                       (hipStream_t)stream, (const __bf16*)dp, (const __bf16*)yact, (const __bf16*)add, (__bf16*)dz, n, h, w, c,
+                       apply_lrelu_mask, alpha);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }

@@ -34,9 +34,9 @@ class Conv2D(object):
         store.p[self.name + '/kernel'].copy_(k)
         store.p[self.name + '/bias'].zero_()
 
-    def forward(self, store, x, x2=None):
+    def forward(self, store, x, x2=None, out_bf16=False):
         return ops.conv2d(x, store.p[self.name + '/kernel'], store.p[self.name + '/bias'], x2=x2,
-                          stride=self.stride, act=self.activation)
+                          stride=self.stride, act=self.activation, out_bf16=out_bf16)
 
     def can_pool(self, x):
         return self.stride == 1 and self.cin2 == 0 and self.ks in (3, 5) and self.cout % 4 == 0 and \
@@ -76,15 +76,15 @@ class Conv2DTranspose2x2(object):
         store.p[self.name + '/kernel'].copy_(k)
         store.p[self.name + '/bias'].zero_()
 
-    def forward(self, store, x):
-        return ops.convt2x2(x, store.p[self.name + '/kernel'], store.p[self.name + '/bias'])
+    def forward(self, store, x, out_bf16=False):
+        return ops.convt2x2(x, store.p[self.name + '/kernel'], store.p[self.name + '/bias'], out_bf16=out_bf16)
 
     def backward_params(self, store, x, dy):
         ops.convt2x2_wgrad(x, dy, dw=store.g[self.name + '/kernel'], side=True)
         ops.bias_grad(dy, db=store.g[self.name + '/bias'], side=True)
 
-    def backward_input(self, store, dy, act_mask=None):
-        return ops.convt2x2_dgrad(dy, store.p[self.name + '/kernel'], act_mask=act_mask)
+    def backward_input(self, store, dy, act_mask=None, out_bf16=False):
+        return ops.convt2x2_dgrad(dy, store.p[self.name + '/kernel'], act_mask=act_mask, out_bf16=out_bf16)
 
 
 class ConstrainedConv2D(object):

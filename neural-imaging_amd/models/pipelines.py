@@ -142,21 +142,32 @@ class UNet(NIPModel):
     def model_code(self):
         return '{}_{}'.format(self.class_name, self._h.n_steps)
 
+    @staticmethod
+    def _store_bf16(x):
+        """Throughput mode keeps the UNet's internal activations and gradients in HBM as bf16 (like the FAN's): every consumer
+        is a kernel that rounds them to bf16 MFMA operands, takes their sign (LeakyReLU') or their maximum (rounding is
+        monotonic), so the forward pass is bit-neutral and the level-1 / level-2 layers - HBM-bound at float32 - move half the
+        bytes.  The RAW input, the 12-channel output of the last convolution and the gradient that feeds the 4-channel
+        weight-gradient kernel stay float32.  (forward() also asks for even sizes at every pooled level.)"""
+        return ops.COMPUTE == 'bf16' and ops.STORE_BF16 and x.is_cuda
+
     def forward(self, x, training=False):
         self._model.refresh_images()
         L, P, ns = self._layers, self._model, self._h.n_steps
+        sb = self._store_bf16(x) and x.shape[1] % (1 << (ns - 1)) == 0 and x.shape[2] % (1 << (ns - 1)) == 0
         t = OrderedDict()
         t['ep0'] = x
         for n in range(1, ns + 1):
-            t['ec{}1'.format(n)] = L['ec{}1'.format(n)].forward(P, t['ep{}'.format(n - 1)])
-            t['ec{}2'.format(n)] = L['ec{}2'.format(n)].forward(P, t['ec{}1'.format(n)])
+            t['ec{}1'.format(n)] = L['ec{}1'.format(n)].forward(P, t['ep{}'.format(n - 1)], out_bf16=sb)
+            t['ec{}2'.format(n)] = L['ec{}2'.format(n)].forward(P, t['ec{}1'.format(n)], out_bf16=sb)
             if n < ns:
                 t['ep{}'.format(n)] = ops.maxpool2(t['ec{}2'.format(n)])
         t['dc02'] = t['ec{}2'.format(ns)]
         for n in range(1, ns):
-            t['dct{}'.format(n)] = L['dct{}'.format(n)].forward(P, t['dc{}2'.format(n - 1)])
-            t['dc{}1'.format(n)] = L['dc{}1'.format(n)].forward(P, t['dct{}'.format(n)], t['ec{}2'.format(ns - n)])
-            t['dc{}2'.format(n)] = L['dc{}2'.format(n)].forward(P, t['dc{}1'.format(n)])
+            t['dct{}'.format(n)] = L['dct{}'.format(n)].forward(P, t['dc{}2'.format(n - 1)], out_bf16=sb)
+            t['dc{}1'.format(n)] = L['dc{}1'.format(n)].forward(P, t['dct{}'.format(n)], t['ec{}2'.format(ns - n)],
+                                                              out_bf16=sb)
+            t['dc{}2'.format(n)] = L['dc{}2'.format(n)].forward(P, t['dc{}1'.format(n)], out_bf16=sb)
         t['dc{}'.format(ns)] = L['dc{}'.format(ns)].forward(P, t['dc{}2'.format(ns - 1)])
         y = ops.d2s_clip(t['dc{}'.format(ns)], 1.0, 0.0, True)
         return y, (t if training else None)
@@ -171,16 +182,17 @@ class UNet(NIPModel):
         while the encoder backward runs)."""
         L, P, ns = self._layers, self._model, self._h.n_steps
         hw = lambda a: (a.shape[1], a.shape[2])
+        sb = t['ec12'].dtype == torch.bfloat16              # the forward pass stored its activations as bf16: so are the gradients
         # head: d2s + clip are straight-through
         dz = ops.d2s_clip_bwd(dy, 1.0)
         last = 'dc{}2'.format(ns - 1)
         L['dc{}'.format(ns)].backward_params(P, t[last], dz)
-        dz = L['dc{}'.format(ns)].backward_input(P, dz, hw(t[last]), act_mask=t[last])       # dZ of dc{ns-1}2
+        dz = L['dc{}'.format(ns)].backward_input(P, dz, hw(t[last]), act_mask=t[last], out_bf16=sb)   # dZ of dc{ns-1}2
         d_skip = {}
         for n in range(ns - 1, 0, -1):
             a1, up, skip = t['dc{}1'.format(n)], t['dct{}'.format(n)], t['ec{}2'.format(ns - n)]
             L['dc{}2'.format(n)].backward_params(P, a1, dz)
-            dz1 = L['dc{}2'.format(n)].backward_input(P, dz, hw(a1), act_mask=a1)           # dZ of dc{n}1
+            dz1 = L['dc{}2'.format(n)].backward_input(P, dz, hw(a1), act_mask=a1, out_bf16=sb)      # dZ of dc{n}1
             L['dc{}1'.format(n)].backward_params(P, up, dz1, x2=skip)
             d_up = torch.empty_like(up)
             d_sk = torch.empty_like(skip)
@@ -188,16 +200,17 @@ class UNet(NIPModel):
             d_skip[ns - n] = d_sk
             prev = t['dc{}2'.format(n - 1)]
             L['dct{}'.format(n)].backward_params(P, prev, d_up)
-            dz = L['dct{}'.format(n)].backward_input(P, d_up, act_mask=prev)                # dZ of dc{n-1}2 / ec{ns}2
+            dz = L['dct{}'.format(n)].backward_input(P, d_up, act_mask=prev, out_bf16=sb)   # dZ of dc{n-1}2 / ec{ns}2
         if on_decoder_done is not None:
             on_decoder_done()
         for n in range(ns, 0, -1):
             a1, inp = t['ec{}1'.format(n)], t['ep{}'.format(n - 1)]
             L['ec{}2'.format(n)].backward_params(P, a1, dz)
-            dz1 = L['ec{}2'.format(n)].backward_input(P, dz, hw(a1), act_mask=a1)
+            # the first layer's weight gradient (4 input channels: the (tap, ci)-packed kernel) stages float32
+            dz1 = L['ec{}2'.format(n)].backward_input(P, dz, hw(a1), act_mask=a1, out_bf16=sb and n > 1)
             L['ec{}1'.format(n)].backward_params(P, inp, dz1)
             if n > 1:
-                d_pool = L['ec{}1'.format(n)].backward_input(P, dz1, hw(inp))
+                d_pool = L['ec{}1'.format(n)].backward_input(P, dz1, hw(inp), out_bf16=sb)
                 prev = t['ec{}2'.format(n - 1)]
                 dz = ops.maxpool2_bwd(d_pool, prev, add=d_skip[n - 1], apply_mask=True, out=d_skip[n - 1])
         ops.join_side_stream()

@@ -250,8 +250,10 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
            act_mask=None, pads=None, out_hw=None, _wmode=0, _f32_only=False, mask_alpha=None, out_bf16=False):
     """x (N,H,W,C1) [+ x2 (N,H,W,C2)], w (k,k,C1+C2,Cout) HWIO.  padding 'SAME' (TF) | 'VALID' | explicit pads/out_hw.
     out/out2: optional pre-allocated outputs (out2 splits the output channels: Cout = out.C + out2.C)."""
-    _f32(w, bias, x2, out2)
-    _fb(x, out, act_mask)
+    _f32(w, bias)
+    _fb(x, x2, out, out2, act_mask)
+    if (x2 is not None and x2.dtype != x.dtype) or (out2 is not None and out is not None and out2.dtype != out.dtype):
+        raise RuntimeError('the two halves of a split input / output must be stored alike (both float32 or both bfloat16)')
     n, h, wd, c1 = x.shape
     c2 = 0 if x2 is None else x2.shape[3]
     ks = w.shape[0]
@@ -284,12 +286,13 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
     if COMPUTE == 'bf16' and not _f32_only and _wmode == 0 and c2 == 0 and out2 is None and act_mask is None and \
             c1 in (3, 4) and ks in (3, 5) and stride == 1 and cout >= 8 and (ho, wo) == (h, wd) and \
             (pt, pl) == ((ks - 1) // 2, (ks - 1) // 2):
-        _lib.call('nimg_conv2d_fwd_smallc_bf16', _p(x), c1, _p(w), _p(bias), _p(out), cout, n, h, wd, ks, pad_mode,
-                  act_id, alpha, _stream())
+        _f32(x)
+        _lib.call('nimg_conv2d_fwd_smallc_bf16_ex', _p(x), c1, _p(w), _p(bias), _p(out), cout, n, h, wd, ks, pad_mode,
+                  act_id, alpha, BF16_OUT if _is_bf16(out) else 0, _stream())
         return out
     if COMPUTE == 'bf16' and not _f32_only and _wmode == 1 and c2 == 0 and out2 is None and act_mask is None and \
             c1 == 32 and cout == 3 and ks == 5 and stride == 1 and (ho, wo) == (h, wd) and (pt, pl) == (2, 2) and \
-            pad_mode == 0 and bias is None and act is None:
+            pad_mode == 0 and bias is None and act is None and not _is_bf16(x) and not _is_bf16(out):
         _lib.call('nimg_conv2d_dgrad_fewin_bf16', _p(x), _p(w), _p(out), 3, 32, n, h, wd, 5, _stream())
         return out
     if COMPUTE == 'bf16' and not _f32_only and c2 % 8 == 0 and cout >= 8 and \
@@ -300,7 +303,7 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
         _lib.call('nimg_conv2d_fwd_bf16_ex', _p(x), c1, _p(x2), c2, _p(wb), _p(bias), _p(out), o1, _p(out2), o2,
                   _p(act_mask), n, h, wd, ks, stride, pt, pl, pad_mode, ho, wo, act_id, alpha, flags, _stream())
         return out if out2 is None else (out, out2)
-    if _is_bf16(x) or _is_bf16(out) or _is_bf16(act_mask):
+    if _is_bf16(x) or _is_bf16(out) or _is_bf16(act_mask) or _is_bf16(x2) or _is_bf16(out2):
         raise RuntimeError('bf16-stored tensor reached a float32 convolution path')
     if _wmode == 1:
         w = flip_weights(w)
@@ -343,8 +346,10 @@ def conv2d_wgrad(x, dz, ks, x2=None, stride=1, padding='SAME', pad_mode=0, pads=
         with _on_side_stream(x, dz, x2):
             return conv2d_wgrad(x, dz, ks, x2=x2, stride=stride, padding=padding, pad_mode=pad_mode, pads=pads, dw=dw,
                                 accumulate=accumulate, db=db, side=False)
-    _f32(x2, dw, db)
-    _fb(x, dz)
+    _f32(dw, db)
+    _fb(x, x2, dz)
+    if x2 is not None and x2.dtype != x.dtype:
+        raise RuntimeError('the two halves of a split input must be stored alike (both float32 or both bfloat16)')
     n, h, wd, c1 = x.shape
     c2 = 0 if x2 is None else x2.shape[3]
     _, ho, wo, cout = dz.shape
@@ -379,35 +384,41 @@ def bias_grad(dz, db=None, accumulate=False, side=False):
     if side and _SIDE['enabled'] and db is not None:
         with _on_side_stream(dz):
             return bias_grad(dz, db=db, accumulate=accumulate, side=False)
-    _f32(dz, db)
+    _f32(db)
+    _fb(dz)
     cout = dz.shape[-1]
     npix = dz.numel() // cout
     if db is None:
         db = torch.empty((cout,), dtype=torch.float32, device=dz.device)
     need = _lib.load().nimg_bias_grad_workspace_bytes(npix, cout)
     ws = (_ws_side if torch.cuda.current_stream(dz.device) == _SIDE['stream'] else _ws).get(need, dz.device)
-    _lib.call('nimg_bias_grad', _p(dz), _p(db), npix, cout, 1 if accumulate else 0, _p(ws), ws.numel(), _stream())
+    _lib.call('nimg_bias_grad_ex', _p(dz), _p(db), npix, cout, 1 if accumulate else 0, _p(ws), ws.numel(),
+              BF16_DZ if _is_bf16(dz) else 0, _stream())
     return db
 
 
-def convt2x2(x, w, bias):
-    """Conv2DTranspose(k=2,s=2); w (2,2,Cout,Cin)."""
-    _f32(x, w, bias)
+def convt2x2(x, w, bias, out_bf16=False):
+    """Conv2DTranspose(k=2,s=2); w (2,2,Cout,Cin).  Throughput mode: x may be stored as bf16, y can be (out_bf16)."""
+    _f32(w, bias)
+    _fb(x)
     n, h, wd, cin = x.shape
     cout = w.shape[2]
-    y = torch.empty((n, 2 * h, 2 * wd, cout), dtype=torch.float32, device=x.device)
+    y = torch.empty((n, 2 * h, 2 * wd, cout), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
     if COMPUTE == 'bf16' and cin % 8 == 0 and cout >= 8:
         wb = weights_bf16(w, 1)                # (2,2,Cout,Cin) read as HWIO with the channel roles swapped
-        _lib.call('nimg_convt2x2_fwd_bf16', _p(x), _p(wb), _p(bias), _p(y), n, h, wd, cin, cout, _stream())
+        _lib.call('nimg_convt2x2_fwd_bf16_ex', _p(x), _p(wb), _p(bias), _p(y), n, h, wd, cin, cout,
+                  (BF16_IN if _is_bf16(x) else 0) | (BF16_OUT if out_bf16 else 0), _stream())
         return y
+    if _is_bf16(x) or out_bf16:
+        raise RuntimeError('bf16-stored tensor reached a float32 transposed-convolution path')
     _lib.call('nimg_convt2x2_fwd', _p(x), _p(w), _p(bias), _p(y), n, h, wd, cin, cout, _stream())
     return y
 
 
-def convt2x2_dgrad(dy, w, act_mask=None):
+def convt2x2_dgrad(dy, w, act_mask=None, out_bf16=False):
     """d input of Conv2DTranspose = strided 2x2 conv of dy with the same kernel viewed as (2,2,Cin'=Cout,Cout'=Cin)."""
     n, h2, w2, _ = dy.shape
-    return conv2d(dy, w, None, stride=2, pads=(0, 0), out_hw=(h2 // 2, w2 // 2), act_mask=act_mask)
+    return conv2d(dy, w, None, stride=2, pads=(0, 0), out_hw=(h2 // 2, w2 // 2), act_mask=act_mask, out_bf16=out_bf16)
 
 
 def convt2x2_wgrad(x, dy, dw=None, side=False):
@@ -418,17 +429,28 @@ def convt2x2_wgrad(x, dy, dw=None, side=False):
 # ----------------------------------------------------------------------------------------------------------------
 # pooling / layout / element-wise
 def maxpool2(x):
-    _f32(x)
+    """MaxPool2D(2); a bf16-stored tensor (even h, w; c % 8 == 0) is pooled as bf16."""
+    _fb(x)
     n, h, w, c = x.shape
-    y = torch.empty((n, h // 2, w // 2, c), dtype=torch.float32, device=x.device)
+    y = torch.empty((n, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
+    if _is_bf16(x):
+        _lib.call('nimg_maxpool2_fwd_bf16', _p(x), _p(y), n, h, w, c, _stream())
+        return y
     _lib.call('nimg_maxpool2_fwd', _p(x), _p(y), n, h, w, c, _stream())
     return y
 
 
 def maxpool2_bwd(dp, yact, add=None, apply_mask=True, out=None):
-    _f32(dp, yact, add, out)
+    _fb(dp, yact, add, out)
     n, h, w, c = yact.shape
     dz = torch.empty_like(yact) if out is None else out
+    if _is_bf16(yact):
+        if any(t is not None and not _is_bf16(t) for t in (dp, add, dz)):
+            raise RuntimeError('maxpool2_bwd on a bf16-stored activation needs bf16-stored gradients')
+        _lib.call('nimg_maxpool2_bwd_bf16', _p(dp), _p(yact), _p(add), _p(dz), n, h, w, c, 1 if apply_mask else 0,
+                  LRELU_ALPHA, _stream())
+        return dz
+    _f32(dp, add, dz)
     _lib.call('nimg_maxpool2_bwd', _p(dp), _p(yact), _p(add), _p(dz), n, h, w, c, 1 if apply_mask else 0,
               LRELU_ALPHA, _stream())
     return dz

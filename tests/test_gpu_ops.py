@@ -779,6 +779,55 @@ def test_unpool_folded_into_conv5_backward(dev, bf16_mode, shape):
     assert torch.equal(dw_ref, dw) and torch.equal(db_ref, db), 'weight / bias gradient'
 
 
+def test_bf16_stored_unet_ops(dev, bf16_mode):
+    """The throughput-mode entry points on bf16-STORED tensors (UNet activations / gradients): two-tensor inputs and outputs,
+    the 2x2 / stride-2 forms behind Conv2DTranspose, max-pool forward / backward, the bias gradient, the 4-channel first
+    convolution with a bf16 output.  Each equals the same op on float32 copies of the same (rounded) values, rounded once."""
+    from neural_imaging_amd import ops
+    bf = torch.bfloat16
+    n, h, w, c = 2, 16, 24, 32
+    x1, x2 = g(rnd((n, h, w, c), 1), dev).to(bf), g(rnd((n, h, w, c), 2), dev).to(bf)
+    wt = g(rnd((3, 3, 2 * c, c), 3, -0.05, 0.05), dev)
+    b = g(rnd((c,), 4), dev)
+    y16 = ops.conv2d(x1, wt, b, x2=x2, act='leaky_relu', out_bf16=True)
+    y32 = ops.conv2d(x1.float(), wt, b, x2=x2.float(), act='leaky_relu')
+    assert y16.dtype == bf and torch.equal(y16, y32.to(bf)), 'two-input forward'
+    dz = g(rnd((n, h, w, c), 5), dev).to(bf)
+    d1, d2 = torch.empty_like(x1), torch.empty_like(x2)
+    ops.conv2d_dgrad(dz, wt, (h, w), out=d1, out2=d2)
+    e1, e2 = torch.empty((n, h, w, c), device=dev), torch.empty((n, h, w, c), device=dev)
+    ops.conv2d_dgrad(dz.float(), wt, (h, w), out=e1, out2=e2)
+    assert torch.equal(d1, e1.to(bf)) and torch.equal(d2, e2.to(bf)), 'two-output input gradient'
+    dw16, db16 = torch.empty_like(wt), torch.empty((c,), device=dev)
+    ops.conv2d_wgrad(x1, dz, 3, x2=x2, dw=dw16, db=db16)
+    dw32, db32 = torch.empty_like(wt), torch.empty((c,), device=dev)
+    ops.conv2d_wgrad(x1.float(), dz.float(), 3, x2=x2.float(), dw=dw32, db=db32)
+    assert torch.equal(dw16, dw32) and torch.allclose(db16, db32, rtol=0, atol=1e-5 * float(db32.abs().max())), 'two-input wgrad'
+    # Conv2DTranspose: forward, input gradient (2x2 / stride 2 with the LeakyReLU' mask), weight gradient, bias gradient
+    wt2 = g(rnd((2, 2, c, 2 * c), 6, -0.05, 0.05), dev)                     # (2,2,Cout,Cin)
+    xin = g(rnd((n, h // 2, w // 2, 2 * c), 7), dev).to(bf)
+    up16 = ops.convt2x2(xin, wt2, b, out_bf16=True)
+    up32 = ops.convt2x2(xin.float(), wt2, b)
+    assert up16.dtype == bf and torch.equal(up16, up32.to(bf)), 'transposed convolution'
+    g16 = ops.convt2x2_dgrad(dz, wt2, act_mask=xin, out_bf16=True)
+    g32 = ops.convt2x2_dgrad(dz.float(), wt2, act_mask=xin.float())
+    assert g16.dtype == bf and torch.equal(g16, g32.to(bf)), 'transposed convolution: input gradient'
+    assert torch.equal(ops.convt2x2_wgrad(xin, dz), ops.convt2x2_wgrad(xin.float(), dz.float())), 'transposed convolution: wgrad'
+    assert torch.allclose(ops.bias_grad(dz), ops.bias_grad(dz.float()), rtol=0, atol=1e-5 * float(dz.float().abs().sum())), 'bias'
+    # pooling
+    p16 = ops.maxpool2(x1)
+    assert p16.dtype == bf and torch.equal(p16, ops.maxpool2(x1.float()).to(bf)), 'max-pool'
+    dp = g(rnd((n, h // 2, w // 2, c), 8), dev).to(bf)
+    q16 = ops.maxpool2_bwd(dp, x1, add=x2, apply_mask=True)
+    q32 = ops.maxpool2_bwd(dp.float(), x1.float(), add=x2.float(), apply_mask=True)
+    assert q16.dtype == bf and torch.equal(q16, q32.to(bf)), 'max-pool backward'
+    # first convolution of the UNet: 4 float32 channels in, bf16 out
+    raw = g(rnd((n, h, w, 4), 9), dev)
+    w4 = g(rnd((3, 3, 4, c), 10, -0.2, 0.2), dev)
+    f16 = ops.conv2d(raw, w4, b, act='leaky_relu', out_bf16=True)
+    assert f16.dtype == bf and torch.equal(f16, ops.conv2d(raw, w4, b, act='leaky_relu').to(bf)), 'first convolution'
+
+
 def test_fan_conv1_input_gradient_bf16(dev, bf16_mode):
     """kx-folded MFMA input gradient of the FAN's first convolution (5x5, 3 <- 32), incl. partial tiles."""
     from neural_imaging_amd import ops
