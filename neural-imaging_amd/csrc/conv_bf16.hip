@@ -715,14 +715,14 @@ int launch_conv5_ring(const ConvParamsB& p, hipStream_t stream) {
 
 template <int KS, int STRIDE, int TH, int TW, int NB, int TN, bool INB = false, bool BUF = false>
 int launch_conv_b(const ConvParamsB& p, hipStream_t stream) {
-    if constexpr (INB && !BUF && KS == 5 && STRIDE == 1 && 128 % TN == 0) {
+    if constexpr (INB && !BUF && (KS == 5 || KS == 3) && STRIDE == 1 && 128 % TN == 0) {
         static const bool no_buf = getenv("NIMG_NO_BUFFER_LOADS") != nullptr;
         const int Cin = p.C1 + p.C2, Cout = p.O1 + p.O2;
         const long in_bytes = ((long)p.N * p.H * p.W * p.C1 * 2) >> (p.in_idx ? 2 : 0);
         const long w_bytes = (long)(p.CinP >> 4) * KS * KS * 16 * Cout * 2;
         if (!no_buf && p.C2 == 0 && Cin % 16 == 0 && Cout % TN == 0 && !p.convt && in_bytes < (1l << 31) - 65536 &&
             w_bytes < (1l << 31) - 65536) {
-            if constexpr (TH == 16 && TW == 16 && NB == 1 && TN == 64) {
+            if constexpr (KS == 5 && TH == 16 && TW == 16 && NB == 1 && TN == 64) {
                 static const bool no_ring = getenv("NIMG_NO_CONV5_RING") != nullptr;
                 static const bool no_ring64 = getenv("NIMG_NO_CONV5_RING64") != nullptr;
                 if (!no_ring && p.O2 == 0 && p.pad_t == 2 && p.pad_l == 2 && p.Hout == p.H && p.Wout == p.W) {
