@@ -329,6 +329,46 @@ __global__ void d2s_clip_fwd_kernel(const float* __restrict__ x, float* __restri
         y[i] = o;
     }
 }
+// co == 3 (every NIP of the reference ends in depth_to_space of 12 channels): one thread per INPUT pixel - its 12 floats are
+// three 16-byte loads, and they land as two runs of 6 contiguous floats (output rows 2y and 2y + 1, pixels 2x and 2x + 1):
+// 8-byte stores.  The per-element form above spends its time on 64-bit divisions and 4-byte accesses (2.5 TB/s).
+__global__ void d2s_clip3_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long npix, int h, int w, float scale,
+                                     float shift, int clip) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % w);
+        const long r = i / w;
+        const int yy = (int)(r % h);
+        const long im = r / h;
+        const float4* src = reinterpret_cast<const float4*>(x + i * 12);
+        const float4 a = src[0], b = src[1], c = src[2];
+        float v[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            float o = scale * v[k] + shift;
+            if (clip) o = fminf(fmaxf(o, 0.f), 1.f);
+            v[k] = o;
+        }
+        float2* top = reinterpret_cast<float2*>(y + ((im * 2 * h + 2 * yy) * (2L * w) + 2 * xx) * 3);
+        float2* bot = reinterpret_cast<float2*>(y + ((im * 2 * h + 2 * yy + 1) * (2L * w) + 2 * xx) * 3);
+        top[0] = make_float2(v[0], v[1]); top[1] = make_float2(v[2], v[3]); top[2] = make_float2(v[4], v[5]);
+        bot[0] = make_float2(v[6], v[7]); bot[1] = make_float2(v[8], v[9]); bot[2] = make_float2(v[10], v[11]);
+    }
+}
+__global__ void d2s_clip3_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long npix, int h, int w, float scale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % w);
+        const long r = i / w;
+        const int yy = (int)(r % h);
+        const long im = r / h;
+        const float2* top = reinterpret_cast<const float2*>(dy + ((im * 2 * h + 2 * yy) * (2L * w) + 2 * xx) * 3);
+        const float2* bot = reinterpret_cast<const float2*>(dy + ((im * 2 * h + 2 * yy + 1) * (2L * w) + 2 * xx) * 3);
+        const float2 t0 = top[0], t1 = top[1], t2 = top[2], b0 = bot[0], b1 = bot[1], b2 = bot[2];
+        float4* dst = reinterpret_cast<float4*>(dx + i * 12);
+        dst[0] = make_float4(scale * t0.x, scale * t0.y, scale * t1.x, scale * t1.y);
+        dst[1] = make_float4(scale * t2.x, scale * t2.y, scale * b0.x, scale * b0.y);
+        dst[2] = make_float4(scale * b1.x, scale * b1.y, scale * b2.x, scale * b2.y);
+    }
+}
 // gradient: straight-through (identity through the clip), dx = scale * space_to_depth(dy)
 __global__ void d2s_clip_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int n, int h, int w,
                                     int co, float scale) {
@@ -732,6 +772,12 @@ int nimg_d2s_clip_fwd(const float* x, float* y, int n, int h, int w, int cout, f
     if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!x || !y || n < 0 || h <= 0 || w <= 0 || cout <= 0) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
+    if (cout == 3) {
+        hipLaunchKernelGGL(d2s_clip3_fwd_kernel, dim3(grid_for((long)n * h * w)), dim3(256), 0, (hipStream_t)stream, x, y,
+                           (long)n * h * w, h, w, scale, shift, clip);
+        NIMG_CHECK_LAUNCH();
+        return NIMG_OK;
+    }
     hipLaunchKernelGGL(d2s_clip_fwd_kernel, dim3(grid_for((long)n * h * w * 4 * cout)), dim3(256), 0,
                        (hipStream_t)stream, x, y, n, h, w, cout, scale, shift, clip);
     NIMG_CHECK_LAUNCH();
@@ -742,6 +788,12 @@ int nimg_d2s_clip_bwd(const float* dy, float* dx, int n, int h, int w, int cout,
     if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!dy || !dx || n < 0 || h <= 0 || w <= 0 || cout <= 0) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
+    if (cout == 3) {
+        hipLaunchKernelGGL(d2s_clip3_bwd_kernel, dim3(grid_for((long)n * h * w)), dim3(256), 0, (hipStream_t)stream, dy, dx,
+                           (long)n * h * w, h, w, scale);
+        NIMG_CHECK_LAUNCH();
+        return NIMG_OK;
+    }
     hipLaunchKernelGGL(d2s_clip_bwd_kernel, dim3(grid_for((long)n * h * w * 4 * cout)), dim3(256), 0,
                        (hipStream_t)stream, dy, dx, n, h, w, cout, scale);
     NIMG_CHECK_LAUNCH();
