@@ -143,17 +143,20 @@ __device__ __forceinline__ uint4 unp_route(uint4 g, unsigned k0, unsigned k1, un
                       g.z & __builtin_amdgcn_perm(m1, m1, 0x01010000u), g.w & __builtin_amdgcn_perm(m1, m1, 0x03030202u));
 }
 
-template <int KS, int STRIDE, int TH, int TW, int NB, int TN, bool INB, bool BUF = false, bool UNP = false>
+template <int KS, int STRIDE, int TH, int TW, int NB, int TN, bool INB, bool BUF = false, bool UNP = false, int CKT = 16>
 __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p) {
     // K chunk: 16 channels (one MFMA k-step per tap).  -DNIMG_CK32 stages 32 channels (two k-steps, half the barriers) for the
     // 3x3 layers with float32 tensors (UNet / TwitterDCN) - measured on the bench step: the 8x8 bottleneck variant gains 12 %
     // (43 -> 38 us) but the 16x16 variants LOSE 4-22 % (47 -> 49 / 58 us: twice the LDS per workgroup and 84 staging registers
     // cost more than the halved barrier count returns), -5 % on the whole step - so it stays an experiment switch.
+    // CKT = 64 (1x1 kernels with Cin % 64 == 0: FAN conv5, the UNet's Conv2DTranspose): a 1x1 layer has ONE tap per chunk, i.e.
+    // 4 MFMAs per wave between two barriers with 16-channel chunks; 64 channels make it 16.
 #ifdef NIMG_CK32
-    constexpr int CK = (KS == 3 && !INB && !BUF) ? 32 : 16;
+    constexpr int CK = CKT != 16 ? CKT : ((KS == 3 && !INB && !BUF) ? 32 : 16);
 #else
-    constexpr int CK = 16;
+    constexpr int CK = CKT;
 #endif
+    static_assert(CK == 16 || CK == 32 || (CK == 64 && KS == 1 && !BUF), "K chunk");
     constexpr int CKH = CK / 8;                          // 16-byte slots (8 channels) per pixel / weight row
     static_assert(!UNP || (INB && BUF && STRIDE == 1), "un-pooling input: bf16 buffer-load path only");
     constexpr int THH = (TH - 1) * STRIDE + KS, TWH = (TW - 1) * STRIDE + KS;
@@ -321,7 +324,9 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
                 }
                 if constexpr (PLANAR) sA[h8 * PLSZ + (pix / TWH) * 32 + pix % TWH] = packed;
                 else if constexpr (CKH == 2) sA[pix * 2 + (h8 ^ ((pix >> 3) & 1))] = packed;
-                else sA[pix * 4 + (h8 ^ ((pix >> 2) & 3))] = packed;
+                else if constexpr (CKH == 4) sA[pix * 4 + (h8 ^ ((pix >> 2) & 3))] = packed;
+                else sA[pix * 8 + (h8 ^ ((pix >> 1) & 7))] = packed;     // 128-byte rows: a b128 lane group = 8 even + 8 odd
+                                                                         // pixels, (pix >> 1) & 7 distinct inside each set
             }
         }
 #pragma unroll
@@ -330,7 +335,8 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
             if (item < TAPS * TN * CKH) {
                 const int h8 = item % CKH, row = item / CKH;
                 if constexpr (CKH == 2) sB[row * 2 + (h8 ^ ((row >> 3) & 1))] = preB[q];
-                else sB[row * 4 + (h8 ^ ((row >> 2) & 3))] = preB[q];
+                else if constexpr (CKH == 4) sB[row * 4 + (h8 ^ ((row >> 2) & 3))] = preB[q];
+                else sB[row * 8 + (h8 ^ ((row >> 1) & 7))] = preB[q];
             }
         }
         __syncthreads();
@@ -348,14 +354,16 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
                 for (int mi = 0; mi < MI; ++mi) {
                     const int pix = abase[mi] + toff;
                     const uint4 v = PLANAR ? sA[pix] : (CKH == 2 ? sA[pix * 2 + (half ^ ((pix >> 3) & 1))]
-                                                                 : sA[pix * 4 + ((2 * ks2 + half) ^ ((pix >> 2) & 3))]);
+                                             : (CKH == 4 ? sA[pix * 4 + ((2 * ks2 + half) ^ ((pix >> 2) & 3))]
+                                                         : sA[pix * 8 + ((2 * ks2 + half) ^ ((pix >> 1) & 7))]));
                     a[mi] = *reinterpret_cast<const bf16x8*>(&v);
                 }
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                     const int row = tap * TN + (wn * NI + ni) * 32 + (lane & 31);
                     const uint4 v = CKH == 2 ? sB[row * 2 + (half ^ ((row >> 3) & 1))]
-                                             : sB[row * 4 + ((2 * ks2 + half) ^ ((row >> 2) & 3))];
+                                             : (CKH == 4 ? sB[row * 4 + ((2 * ks2 + half) ^ ((row >> 2) & 3))]
+                                                         : sB[row * 8 + ((2 * ks2 + half) ^ ((row >> 1) & 7))]);
                     b[ni] = *reinterpret_cast<const bf16x8*>(&v);
                 }
 #pragma unroll
@@ -713,8 +721,13 @@ int launch_conv5_ring(const ConvParamsB& p, hipStream_t stream) {
     return NIMG_OK;
 }
 
-template <int KS, int STRIDE, int TH, int TW, int NB, int TN, bool INB = false, bool BUF = false>
+template <int KS, int STRIDE, int TH, int TW, int NB, int TN, bool INB = false, bool BUF = false, int CKT = 16>
 int launch_conv_b(const ConvParamsB& p, hipStream_t stream) {
+    if constexpr (KS == 1 && !BUF && CKT == 16) {          // 1x1: 64-channel K chunks when the channels allow
+        static const bool no_ck64 = getenv("NIMG_NO_CK64") != nullptr;
+        if (!no_ck64 && (p.C1 + p.C2) % 64 == 0 && (p.C2 == 0 || p.C1 % 64 == 0))
+            return launch_conv_b<KS, STRIDE, TH, TW, NB, TN, INB, false, 64>(p, stream);
+    }
     if constexpr (INB && !BUF && (KS == 5 || KS == 3) && STRIDE == 1 && 128 % TN == 0) {
         static const bool no_buf = getenv("NIMG_NO_BUFFER_LOADS") != nullptr;
         const int Cin = p.C1 + p.C2, Cout = p.O1 + p.O2;
@@ -736,9 +749,9 @@ int launch_conv_b(const ConvParamsB& p, hipStream_t stream) {
     constexpr int THH = (TH - 1) * STRIDE + KS, TWH = (TW - 1) * STRIDE + KS;
     constexpr bool PLANAR = (STRIDE == 1 && TW == 16 && NB == 1 && KS == 5);   // 3x3: the extra registers cost a wave per SIMD
 #ifdef NIMG_CK32
-    constexpr int CKH = (KS == 3 && !INB && !BUF) ? 4 : 2;             // the kernel's K chunk in 8-channel slots
+    constexpr int CKH = CKT != 16 ? CKT / 8 : ((KS == 3 && !INB && !BUF) ? 4 : 2);     // the kernel's K chunk in 8-channel slots
 #else
-    constexpr int CKH = 2;
+    constexpr int CKH = CKT / 8;
 #endif
     constexpr size_t a_entries = PLANAR ? (size_t)2 * THH * 32 : (size_t)NB * THH * TWH * CKH;
     constexpr size_t lds_tiles = (a_entries + (size_t)KS * KS * TN * CKH) * sizeof(uint4);
@@ -748,9 +761,9 @@ int launch_conv_b(const ConvParamsB& p, hipStream_t stream) {
     q.tiles_y = cdiv(p.Hout, TH);
     q.tiles_x = cdiv(p.Wout, TW);
     const long blocks = (long)cdiv(p.O1 + p.O2, TN) * q.tiles_y * q.tiles_x * cdiv(p.N, NB) * (p.convt ? 4 : 1);
-    auto kern = conv_fwd_bf16_kernel<KS, STRIDE, TH, TW, NB, TN, INB, BUF>;
+    auto kern = conv_fwd_bf16_kernel<KS, STRIDE, TH, TW, NB, TN, INB, BUF, false, CKT>;
     if (p.in_idx) {                     // the input is a pooled tensor + arg-max bytes: only the buffer-load variants un-pool
-        if constexpr (INB && BUF && STRIDE == 1) kern = conv_fwd_bf16_kernel<KS, STRIDE, TH, TW, NB, TN, true, true, true>;
+        if constexpr (INB && BUF && STRIDE == 1 && CKT == 16) kern = conv_fwd_bf16_kernel<KS, STRIDE, TH, TW, NB, TN, true, true, true>;
         else return NIMG_ERR_ARG;
     }
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
