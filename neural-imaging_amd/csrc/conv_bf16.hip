@@ -1047,10 +1047,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const Wgrad
     }
 }
 
-int splits_for(int cin, int cout, int n, int hout, int wout, int th = B_TH) {
+int splits_for(int cin, int cout, int n, int hout, int wout, int th = B_TH, int target_blocks = 512) {
     const long blocks_io = (long)cdiv(cin, B_CI) * cdiv(cout, B_CO);
     const long work = (long)n * cdiv(hout, th) * cdiv(wout, B_TW);
-    long splits = (512 + blocks_io - 1) / blocks_io;
+    long splits = (target_blocks + blocks_io - 1) / blocks_io;
     if (splits > work) splits = work;
     if (splits < 1) splits = 1;
     const long wps = (work + splits - 1) / splits;
@@ -1252,7 +1252,10 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
     p.pad_t = pad_t; p.pad_l = pad_l; p.pad_mode = pad_mode;
     const int th = (stride == 1 && ks == 5) ? 16 : B_TH;
     p.tiles_y = cdiv(hout, th); p.tiles_x = cdiv(wout, B_TW);
-    p.splits = splits_for(cin, cout, n, hout, wout, th);       // <= splits_for(.., B_TH): the workspace bound holds
+    // the 8-wave 5x5 kernel runs ONE workgroup per CU: 256 workgroups are one full round, and half the slabs to write and reduce
+    static const int wg5_env = getenv("NIMG_WGRAD5_BLOCKS") ? atoi(getenv("NIMG_WGRAD5_BLOCKS")) : 256;
+    const int wg5 = wg5_env < 32 ? 32 : (wg5_env > 512 ? 512 : wg5_env);        // 512 = what the workspace bound assumes
+    p.splits = splits_for(cin, cout, n, hout, wout, th, (stride == 1 && ks == 5) ? wg5 : 512);   // <= splits_for(.., B_TH): the workspace bound holds
     const long work = (long)n * p.tiles_y * p.tiles_x;
     p.work_per_split = (int)((work + p.splits - 1) / p.splits);
     const long count = (long)ks * ks * cin * cout;
