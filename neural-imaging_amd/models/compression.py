@@ -139,6 +139,19 @@ class DCN(TFModel):
     def summary_compact(self):
         return '{} {}-D'.format(self.class_name, self.latent_shape[-1])
 
+    def keras_layers(self):
+        """The reference saves `codec` = Model(x -> [decoder(encoder(x)), entropy]) (compression.py:274-279): its weight file has
+        TWO top-level layers, the nested Models 'encoder' (its convolutions + the DiscreteLatent scaling factor) and 'decoder',
+        each listing its variables as '<layer>/<variable>:0' - so does the file written here (Keras loads by layer order and
+        checks the layer count; a flat list of 19 layers would be refused)."""
+        groups = [('encoder', []), ('decoder', [])]
+        which = 0
+        for lname, ws in super().keras_layers():
+            groups[which][1].extend(ws)
+            if lname == 'latent_scaling':
+                which = 1
+        return groups
+
     @property
     def model_code(self):
         return '{}-{}C'.format(type(self).__name__, self._h.n_features)

@@ -223,7 +223,15 @@ def test_keras_checkpoints_of_every_model(tmp_path):
         b.load_model(d)
         for n, x, y in zip(a.parameter_names, a.parameters, b.parameters):
             assert torch.equal(x, y), (a.class_name, n)
+    # the codec's file has the reference's layout: two nested Models, 'encoder' (9 convolutions + the latent scale) and 'decoder'
+    layers = keras_h5.load_weights(path)
+    assert [l for l, _ in layers] == ['encoder', 'decoder'] and len(layers[0][1]) == 19 and len(layers[1][1]) == 18
+    assert layers[0][1][-1][0].startswith('latent_scaling') and all(w.endswith(':0') for _, ws in layers for w, _ in ws)
     isp = makers[3](1)
+    a = isp
+    a.save_model(str(tmp_path / 'isp'))
+    stored = [w for _, ws in keras_h5.load_weights(os.path.join(str(tmp_path / 'isp'), a.scoped_name, a.class_name.lower() + '.h5'))
+              for w, _ in ws]
     assert not any('up' in w or 'srgb' in w for w in stored[-3:]) and isp._h5_skip == ('up/kernel', 'srgb/kernel')
     # a file of another architecture is refused with the offending tensor named
     unet = pipelines.UNet(patch_size=16, device='cpu')
