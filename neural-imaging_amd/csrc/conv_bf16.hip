@@ -472,7 +472,9 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
 // ------------------------------------------------------------------------------------------------------------------
 // Ring form of the 5x5 stride-1 convolution over bf16-stored activations with Cout % 64 == 0 (FAN conv2 / conv3 / conv4
 // forward, conv4 / conv3 input gradient): 4 waves x 8 accumulator fragments per workgroup -
-//     TN = 128: 16 x 16 pixels x 128 output channels, 2 x 4 fragments per wave;  TN = 64: 32 x 16 pixels x 64, 4 x 2.
+//     TN = 128: 16 x 16 pixels x 128 output channels, 2 x 4 fragments per wave;  TN = 64: 32 x 16 pixels x 64, 4 x 2;
+//     TN = 32 (conv2's input gradient, 64 -> 32): 32 x 16 pixels x 32, 4 x 1 fragments - 64 accumulator registers, three
+//     workgroups per CU (47 KB of LDS).
 // conv_fwd_bf16_kernel stages the whole 25-tap weight tile of a 16-channel chunk through registers (52 VGPRs, 13
 // ds_write_b128 per thread and chunk, 51 KB of LDS for 64 output channels) behind two barriers per chunk.  Here the weights
 // arrive one KERNEL ROW at a time (5 taps x TN co x 16 ci = 20 / 10 KB) by LDS-DMA (buffer_load_dwordx4 ... lds: no staging
@@ -500,7 +502,7 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 
 template <int TN>
 struct RingGeom {
-    static constexpr int NI = TN / 32, MI = 8 / NI;          // fragment block of a wave (4 waves stacked along the pixels)
+    static constexpr int NI = TN / 32, MI = NI == 1 ? 4 : 8 / NI;   // fragment block of a wave (4 waves stacked along the pixels)
     static constexpr int TH = 8 * MI, TW = 16, THH = TH + 4, TWH = TW + 4;
     static constexpr int NPIXH = THH * TWH, AP = (NPIXH * 2 + 255) / 256;
     static constexpr int PLSZ = THH * 32;                    // uint4 entries of one k-half plane of the halo tile
@@ -514,7 +516,7 @@ struct RingGeom {
 };
 
 template <int TN, bool UNP>
-__global__ __launch_bounds__(256, 2) void conv5_ring_kernel(const ConvParamsB p) {
+__global__ __launch_bounds__(256, TN == 32 ? 3 : 2) void conv5_ring_kernel(const ConvParamsB p) {
     using G = RingGeom<TN>;
     constexpr int NI = G::NI, MI = G::MI, TH = G::TH, TW = G::TW, TWH = G::TWH, NPIXH = G::NPIXH, AP = G::AP;
     constexpr int PLSZ = G::PLSZ, ABUF = G::ABUF, SLOT = G::SLOT;
@@ -784,6 +786,14 @@ int dispatch_b_t(const ConvParamsB& p, hipStream_t s) {
     // narrow outputs (Cout <= 32) of big images: a 32x16-pixel tile keeps 64 accumulator registers per wave (4 x 1
     // fragments) and stages a third fewer bytes per pixel than 16x16
     if constexpr (STRIDE == 1 && KS == 5) {
+        if constexpr (INB) {                // ring form for exactly 32 output channels (FAN conv2 input gradient)
+            static const bool no_ring32 = getenv("NIMG_NO_CONV5_RING32") != nullptr || getenv("NIMG_NO_CONV5_RING") != nullptr ||
+                                          getenv("NIMG_NO_BUFFER_LOADS") != nullptr;
+            const long in_bytes = ((long)p.N * p.H * p.W * p.C1 * 2) >> (p.in_idx ? 2 : 0);
+            if (!no_ring32 && Cout == 32 && p.O2 == 0 && p.C2 == 0 && p.C1 % 16 == 0 && !p.convt && p.pad_t == 2 && p.pad_l == 2 &&
+                p.Hout == p.H && p.Wout == p.W && p.Hout >= 32 && in_bytes < (1l << 31) - 65536)
+                return launch_conv5_ring<32>(p, s);
+        }
         if (Cout <= 32 && !p.pool_out && p.Hout % 32 == 0 && (long)cdiv(p.Hout, 32) * cdiv(p.Wout, 16) * p.N >= 2048)
             return launch_conv_b<KS, STRIDE, 32, 16, 1, 32, INB>(p, s);
     }
