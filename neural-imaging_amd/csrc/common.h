@@ -127,6 +127,46 @@ __device__ __forceinline__ void pool_via_lds(const nimg_f32x16 (&acc)[NI], float
     }
 }
 
+// Lane-local form of pool_via_lds (same arithmetic, same tie rule, bit-identical results).  A lane's 16 accumulator registers
+// are rows {0-3, 8-11, 16-19, 24-27} (+4 for lanes 32-63) of ONE output channel: with the fragment's 32 rows = two 16-pixel
+// tile rows these are the COMPLETE 2x2 windows of pooled columns {0, 1, 4, 5} (+2) - registers (2q, 2q+1, 2q+8, 2q+9) for the
+// lane's window q.  Bias, activation, maximum and arg-max therefore need no other lane; only the 4 pooled values and 4 arg-max
+// bytes per fragment (instead of 16 values) go through LDS to come back as channel-contiguous vectors.
+//   lds: this wave's scratch, >= 8 * (NI*32 + EPI_PAD) floats + 8 * NI*32 bytes;  bias1(c): bias of strip-local channel c
+template <int NI, typename Bias, typename Emit>
+__device__ __forceinline__ void pool_in_regs(const nimg_f32x16 (&acc)[NI], float* lds, int lane, float alpha, Bias bias1,
+                                             Emit emit) {
+    constexpr int RS = NI * 32 + EPI_PAD;
+    unsigned char* lidx = reinterpret_cast<unsigned char*>(lds + 8 * RS);
+    const int half = lane >> 5, n = lane & 31;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const float b = bias1(ni * 32 + n);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int pc = (q & 1) + 4 * (q >> 1) + 2 * half;
+            const float v0 = lrelu(acc[ni][2 * q] + b, alpha), v1 = lrelu(acc[ni][2 * q + 1] + b, alpha);
+            const float v2 = lrelu(acc[ni][2 * q + 8] + b, alpha), v3 = lrelu(acc[ni][2 * q + 9] + b, alpha);
+            float m = v0;
+            unsigned char k = 0;
+            if (v1 > m) { m = v1; k = 1; }
+            if (v2 > m) { m = v2; k = 2; }
+            if (v3 > m) { m = v3; k = 3; }
+            lds[pc * RS + ni * 32 + n] = m;
+            lidx[pc * (NI * 32) + ni * 32 + n] = k;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        const int idx = it * 64 + lane, pc = idx / (NI * 8), c = (idx % (NI * 8)) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(lds + pc * RS + c);
+        const uchar4 k = *reinterpret_cast<const uchar4*>(lidx + pc * (NI * 32) + c);
+        emit(pc, c, v, k);
+    }
+}
+
 // dst[i] = sum_k partial[k][i] over `splits` slabs, in a fixed order => deterministic (split-K weight gradients, fused
 // bias sums).  A workgroup of 256 covers 16 float4 columns x 16 slab segments: thread (col, seg) adds slabs seg, seg+16,
 // ... (two independent accumulators), then the 16 segment sums are added in order through LDS - so thousands of slabs

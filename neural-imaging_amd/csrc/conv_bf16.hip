@@ -668,10 +668,8 @@ __global__ __launch_bounds__(256, TN == 32 ? 3 : 2) void conv5_ring_kernel(const
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int py = (ty0 >> 1) + wave * MI + mi;
-            pool_via_lds<NI, false>(acc[mi], elds, lane, al,
-                [&](int c) {
-                    return p.bias ? *reinterpret_cast<const float4*>(p.bias + co0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-                },
+            pool_in_regs<NI>(acc[mi], elds, lane, al,
+                [&](int c) { return p.bias ? p.bias[co0 + c] : 0.f; },
                 [&](int pc, int c, float4 v, uchar4 k) {
                     const int co = co0 + c, px = (tx0 >> 1) + pc;
                     if (grp >= p.N || py >= Hp || px >= Wp) return;
