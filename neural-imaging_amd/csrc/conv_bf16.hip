@@ -854,8 +854,14 @@ constexpr int B_ZS = 192;      // dz tile row stride in bytes (64 co bf16 = 128 
 // arithmetic, converts and LDS writes - is then amortised over twice as many MFMAs)
 // UNP (with DZB): dz is the POOLED gradient (N, Hout/2, Wout/2, Cout) bf16 and p.dz_idx its arg-max bytes; the 2x2 un-pooling
 // happens while the dz tile is staged (unp_route: packed byte masks), the full-resolution gradient never exists in HBM.
-template <int KS, int STRIDE, int NW, bool INB, bool DZB, int TH, bool UNP = false>
+// NCO = 32-channel output fragments per workgroup: 2 (a 64-wide dz tile) or 1 for layers with Cout <= 32 (UNet level 1), where
+// half of the 64-wide tile would be zeros: half the MFMAs, 4 instead of 5 operand reads per pixel row, and the unpadded 64-byte
+// tile rows already spread four consecutive pixels over the four bank quarters.
+template <int KS, int STRIDE, int NW, bool INB, bool DZB, int TH, bool UNP = false, int NCO = 2>
 __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const WgradParamsB p) {
+    constexpr int TCO = 32 * NCO, ZS = NCO == 2 ? B_ZS : 64, ZI = 4 * NCO;      // dz tile: channels, row stride, 16-byte items per pixel
+    static_assert(NCO == 1 || NCO == 2, "one or two output fragments");
+    static_assert(!UNP || NCO == 2, "un-pooling dz: 64-wide tile");
     static_assert(!UNP || (DZB && STRIDE == 1), "un-pooling dz: bf16-stored pooled gradient, stride 1");
     constexpr int TAPS = KS * KS, NT = (TAPS + NW - 1) / NW, NTHR = NW * 64;
     constexpr int THH = (TH - 1) * STRIDE + KS, TWH = (B_TW - 1) * STRIDE + KS;
@@ -863,23 +869,23 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const Wgrad
     static_assert(STRIDE == 1 || STRIDE == 2, "stride");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned char* sI = smem_raw;                   // [NPIXH][32 ci] bf16, 64 B per pixel
-    unsigned char* sZ = smem_raw + NPIXH * 64;      // [NPIX][64 co] bf16, B_ZS bytes per pixel
+    unsigned char* sZ = smem_raw + NPIXH * 64;      // [NPIX][TCO co] bf16, ZS bytes per pixel
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Cin = p.C1 + p.C2;
-    const int cib = (Cin + B_CI - 1) / B_CI, cob = (p.Cout + B_CO - 1) / B_CO;
+    const int cib = (Cin + B_CI - 1) / B_CI, cob = (p.Cout + TCO - 1) / TCO;
     int bid = xcd_order(blockIdx.x);
     const int ci0 = (bid % cib) * B_CI;
     bid /= cib;
-    const int co0 = (bid % cob) * B_CO;
+    const int co0 = (bid % cob) * TCO;
     const int split = bid / cob;
     const int half = lane >> 5, g = lane & 15, sub = (lane >> 4) & 1;
 
-    f32x16 acc[NT][2];
+    f32x16 acc[NT][NCO];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NCO; ++ni)
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[t][ni][j] = 0.0f;
     const int tiles = p.tiles_y * p.tiles_x;
@@ -890,10 +896,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const Wgrad
     float bacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // per-lane constant parts of the transpose-read addresses
     const int a_lane = ((half * 8 + (g >> 2)) * STRIDE) * 64 + (sub * 16 + (g & 3) * 4) * 2;   // + pixel terms
-    const int z_lane = (half * 8 + (g >> 2)) * B_ZS + (sub * 16 + (g & 3) * 4) * 2;
+    const int z_lane = (half * 8 + (g >> 2)) * ZS + (sub * 16 + (g & 3) * 4) * 2;
     // async-stage split: tile t+1 travels HBM -> registers while tile t is multiplied
-    constexpr int IP = (NPIXH * 4 + NTHR - 1) / NTHR, ZP = (NPIX * 8) / NTHR;
-    static_assert((NPIX * 8) % NTHR == 0, "dz tile must divide over the threads");
+    constexpr int IP = (NPIXH * 4 + NTHR - 1) / NTHR, ZP = (NPIX * ZI) / NTHR;
+    static_assert((NPIX * ZI) % NTHR == 0 && NTHR % ZI == 0, "dz tile must divide over the threads");
     float4 preI[IP][2], preZ[ZP][2];
     uint2 preZK[UNP ? ZP : 1];
     auto fetch = [&](int wk_) {
@@ -922,7 +928,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const Wgrad
 #pragma unroll
         for (int q = 0; q < ZP; ++q) {
             const int item = tid + q * NTHR;
-            const int pix = item >> 3, c = co0 + (item & 7) * 8;
+            const int pix = item / ZI, c = co0 + (item % ZI) * 8;
             const int oy = ty_ + pix / B_TW, ox = tx_ + pix % B_TW;
             preZ[q][0] = preZ[q][1] = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (UNP) preZK[q] = make_uint2(0xffffffffu, 0xffffffffu);
@@ -965,7 +971,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const Wgrad
             bf16x8 b;
             if constexpr (DZB) {
                 if constexpr (UNP) {                 // route: keep a channel iff this pixel was its window's arg-max
-                    const int pix_ = item >> 3;      // tile origin (ty, tx) is even: the window position is the pixel's parity
+                    const int pix_ = item / ZI;      // tile origin (ty, tx) is even: the window position is the pixel's parity
                     const unsigned pos = (unsigned)((((pix_ / B_TW) & 1) << 1) | ((pix_ % B_TW) & 1));
                     const uint4 routed = unp_route(*reinterpret_cast<const uint4*>(&preZ[q][0]), preZK[q].x, preZK[q].y, pos);
                     b = *reinterpret_cast<const bf16x8*>(&routed);
@@ -983,7 +989,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const Wgrad
 #pragma unroll
                 for (int e = 0; e < 8; ++e) bacc[e] += f[e];
             }
-            *reinterpret_cast<uint4*>(sZ + (item >> 3) * B_ZS + (item & 7) * 16) = *reinterpret_cast<const uint4*>(&b);
+            *reinterpret_cast<uint4*>(sZ + (item / ZI) * ZS + (item % ZI) * 16) = *reinterpret_cast<const uint4*>(&b);
         }
         __syncthreads();
         if (wk + 1 < w_end) fetch(wk + 1);
@@ -991,35 +997,37 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const Wgrad
         // folded through LDS behind the loop) - with the tap split three of the four waves had nothing to multiply
 #pragma unroll 1
         for (int r = (KS == 1 ? wave : 0); r < TH; r += (KS == 1 ? NW : 1)) {
-            const unsigned char* zr = sZ + (r * B_TW) * B_ZS + z_lane;
-            const bf16x8 b0 = tr_read8(zr, zr + 4 * B_ZS);
-            const bf16x8 b1 = tr_read8(zr + 64, zr + 4 * B_ZS + 64);
+            const unsigned char* zr = sZ + (r * B_TW) * ZS + z_lane;
+            bf16x8 bfr[NCO];
+#pragma unroll
+            for (int ni = 0; ni < NCO; ++ni) bfr[ni] = tr_read8(zr + 64 * ni, zr + 4 * ZS + 64 * ni);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int tap = KS == 1 ? 0 : wave + NW * t;
                 if (tap < TAPS) {
                     const unsigned char* ir = sI + ((r * STRIDE + tap / KS) * TWH + (tap % KS)) * 64 + a_lane;
                     const bf16x8 a = tr_read8(ir, ir + 4 * STRIDE * 64);
-                    acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[t][0], 0, 0, 0);
-                    acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[t][1], 0, 0, 0);
+#pragma unroll
+                    for (int ni = 0; ni < NCO; ++ni)
+                        acc[t][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfr[ni], acc[t][ni], 0, 0, 0);
                 }
             }
         }
     }
-    if (do_bias) {                              // thread t holds channels (t & 7) * 8 .. + 7: reduce the NTHR/8 owners
+    if (do_bias) {                              // thread t holds channels (t % ZI) * 8 .. + 7: reduce the NTHR / ZI owners
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem_raw);
 #pragma unroll
         for (int e = 0; e < 8; ++e) red[tid * 8 + e] = bacc[e];
         __syncthreads();
-        if (tid < B_CO && co0 + tid < p.Cout) {
+        if (tid < TCO && co0 + tid < p.Cout) {
             float sum = 0.f;
-            for (int o = 0; o < NTHR / 8; ++o) sum += red[(o * 8 + (tid >> 3)) * 8 + (tid & 7)];
+            for (int o = 0; o < NTHR / ZI; ++o) sum += red[(o * ZI + (tid >> 3)) * 8 + (tid & 7)];
             p.db_partial[(long)split * p.Cout + co0 + tid] = sum;
         }
     }
     if constexpr (KS == 1) {                    // fold the waves' row partials: waves 1.. park theirs in LDS, wave 0 adds in order
-        static_assert((NW - 1) * 2 * 16 * 64 * 4 <= NPIXH * 64 + NPIX * B_ZS, "fold scratch fits the tiles");
+        static_assert(NCO == 2 && (NW - 1) * 2 * 16 * 64 * 4 <= NPIXH * 64 + NPIX * B_ZS, "fold scratch fits the tiles");
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem_raw);
         if (wave > 0) {
@@ -1043,7 +1051,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const Wgrad
         const int tap = KS == 1 ? 0 : wave + NW * t;
         if (tap >= TAPS) continue;
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
+        for (int ni = 0; ni < NCO; ++ni) {
             const int co = co0 + ni * 32 + (lane & 31);
             if (co >= p.Cout) continue;
 #pragma unroll
@@ -1276,6 +1284,10 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
         constexpr size_t lds_t = (size_t)THH * TWH * 64 + (size_t)TH_ * B_TW * B_ZS;                          \
         constexpr size_t lds = lds_t > (size_t)NW_ * 64 * 8 * 4 ? lds_t : (size_t)NW_ * 64 * 8 * 4;          \
         auto k = conv_wgrad_bf16_kernel<KS_, ST_, NW_, INB_, DZB_, TH_>;                                      \
+        if constexpr (KS_ == 3 && ST_ == 1) {                  /* narrow outputs: a 32-wide dz tile */            \
+            static const bool no_narrow = getenv("NIMG_NO_NARROW_WGRAD") != nullptr;                          \
+            if (!no_narrow && p.Cout <= 32 && !p.dz_idx) k = conv_wgrad_bf16_kernel<KS_, ST_, NW_, INB_, DZB_, TH_, false, 1>;  \
+        }                                                                                                     \
         if (p.dz_idx) {                                                                                       \
             if constexpr (DZB_ && ST_ == 1 && KS_ == 5) k = conv_wgrad_bf16_kernel<KS_, ST_, NW_, INB_, true, TH_, true>;    \
             else return NIMG_ERR_ARG;                                                                         \
