@@ -278,6 +278,59 @@ __global__ void sharpen_fwd_kernel(const float* __restrict__ x, float* __restric
     }
 }
 
+// LDS-tiled sharpen forward (images of at least 16 x 16): rgb2hsv (two divisions) is evaluated ONCE per pixel of the 18 x 18
+// SYMMETRIC-mapped neighbourhood of a 16 x 16 tile instead of nine times per output pixel; the 3 x 3 filter then reads the
+// staged (h, s, v) triples.  Same per-pixel functions and the same tap order as sharpen_fwd_kernel: identical results.
+__global__ __launch_bounds__(256) void sharpen_fwd_tiled_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                float* __restrict__ aux, uint8_t* __restrict__ mask,
+                                                                const float* __restrict__ gk9, int n, int h, int w,
+                                                                int tiles_y, int tiles_x) {
+    __shared__ float4 sh[18 * 19];
+    __shared__ float sg[9];
+    const int tid = threadIdx.x;
+    if (tid < 9) sg[tid] = gk9[tid];
+    const int tiles = tiles_y * tiles_x;
+    const long im = blockIdx.x / tiles;
+    const int tile = blockIdx.x % tiles, y0 = (tile / tiles_x) * 16, x0 = (tile % tiles_x) * 16;
+    for (int i = tid; i < 324; i += 256) {
+        const int r = i / 18, c = i % 18;
+        int gy = y0 - 1 + r, gx = x0 - 1 + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy < h + 1 && gx < w + 1) {                    // beyond the mirrored ring of a partial tile: never read
+            map_coord(gy, h, 1);
+            map_coord(gx, w, 1);
+            const float* p = x + ((im * h + gy) * w + gx) * 3;
+            rgb2hsv(p[0], p[1], p[2], v.x, v.y, v.z);
+        }
+        sh[r * 19 + c] = v;
+    }
+    __syncthreads();
+    const int ly = tid >> 4, lx = tid & 15, py = y0 + ly, px = x0 + lx;
+    if (py >= h || px >= w) return;
+    float ho = 0.f, vo = 0.f, so = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const float4 t = sh[(ly + ky) * 19 + lx + kx];
+            ho = fmaf(t.x, sg[ky * 3 + kx], ho);
+            vo = fmaf(t.z, sg[ky * 3 + kx], vo);
+            if (ky == 2 && kx == 2) so = t.y;             // S channel: single corner tap [2,2] = 1
+        }
+    float r, gg, b;
+    hsv2rgb(ho, so, vo, r, gg, b);
+    const float o[3] = {r, gg, b};
+    const long i = (im * h + py) * w + px;
+    uint32_t m = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        m |= (o[c] >= 0.f && o[c] <= 1.f) ? (1u << c) : 0u;
+        y[i * 3 + c] = fminf(fmaxf(o[c], 0.f), 1.f);
+    }
+    if (aux) { aux[i * 3] = ho; aux[i * 3 + 1] = so; aux[i * 3 + 2] = vo; }
+    if (mask) mask[i] = (uint8_t)m;
+}
+
 // backward stage A (per output pixel): d(filtered hsv) = J_hsv2rgb^T (dy * clipmask); written in place of aux
 __global__ void sharpen_bwd_a_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ mask, float* aux,
                                      long total) {
@@ -522,8 +575,13 @@ int nimg_sharpen_fwd(const float* x, float* y, float* aux_hsv, uint8_t* mask, co
     if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!x || !y || !gk9 || n < 0 || h < 3 || w < 3) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
-    hipLaunchKernelGGL(sharpen_fwd_kernel, dim3(grid_for((long)n * h * w)), dim3(256), 0, (hipStream_t)stream, x, y,
-                       aux_hsv, mask, gk9, n, h, w);
+    const int ty = (h + 15) / 16, tx = (w + 15) / 16;
+    if (h >= 16 && w >= 16 && (long)n * ty * tx < (1L << 31))
+        hipLaunchKernelGGL(sharpen_fwd_tiled_kernel, dim3((unsigned)((long)n * ty * tx)), dim3(256), 0, (hipStream_t)stream,
+                           x, y, aux_hsv, mask, gk9, n, h, w, ty, tx);
+    else
+        hipLaunchKernelGGL(sharpen_fwd_kernel, dim3(grid_for((long)n * h * w)), dim3(256), 0, (hipStream_t)stream, x, y,
+                           aux_hsv, mask, gk9, n, h, w);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Dump gaussian forward / backward outputs for fixed inputs (A/B of two library builds: run once per NIMG_LIBPATH, compare)."""
+"""Dump gaussian and sharpen forward / backward outputs for fixed inputs (A/B of two library builds: run once per NIMG_LIBPATH, compare)."""
 import importlib, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,5 +17,8 @@ for (n, h, w) in [(2, 64, 64), (1, 50, 37), (3, 16, 16), (1, 256, 256)]:
     dy = torch.randn((n, h, w, 3), generator=gen).to(dev)
     dx = op.backward(ctx, dy)
     out += [y.cpu(), dx.cpu()]
+    sh = th.Sharpen()
+    y2, ctx2 = sh.forward(x.clamp(0, 1), 1.0, training=True)
+    out += [y2.cpu(), sh.backward(ctx2, dy).cpu()]
 torch.save(out, sys.argv[1])
 print('saved', sys.argv[1])
