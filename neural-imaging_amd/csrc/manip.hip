@@ -353,6 +353,80 @@ __global__ void sharpen_bwd_a_kernel(const float* __restrict__ dy, const uint8_t
     }
 }
 
+// rgb_to_hsv backward at one pixel: (gh, gs, gv) = gradient w.r.t. its (h, s, v) -> d = gradient w.r.t. (r, g, b)
+__device__ __forceinline__ void hsv_backward(float r, float gg, float bb, float gh, float gs, float gv, float (&d)[3]) {
+    const int imax = (r >= gg && r >= bb) ? 0 : (gg >= bb ? 1 : 2);
+    const int imin = (r <= gg && r <= bb) ? 0 : (gg <= bb ? 1 : 2);
+    const float c3[3] = {r, gg, bb};
+    const float v = c3[imax], mn = c3[imin], rng = v - mn;
+    d[0] = d[1] = d[2] = 0.f;
+    float g_rng = 0.f, g_v = gv;
+    if (v > 0.f) { g_rng += gs / v; g_v -= gs * rng / (v * v); }
+    if (rng > 0.f) {
+        const float norm = 1.0f / (6.0f * rng);
+        // hue branch (same order as the forward): operands (a - b)
+        int ia, ib;
+        if (r == v) { ia = 1; ib = 2; } else if (gg == v) { ia = 2; ib = 0; } else { ia = 0; ib = 1; }
+        d[ia] += gh * norm;
+        d[ib] -= gh * norm;
+        g_rng -= gh * norm * (c3[ia] - c3[ib]) / rng;
+    }
+    d[imax] += g_v + g_rng;
+    d[imin] -= g_rng;
+}
+
+// LDS-tiled stage B (images of at least 16 x 16): the 18 x 18 neighbourhood of d(filtered hsv) is staged once (zeros outside
+// the image); same source / tap order as sharpen_bwd_b_kernel, identical results.
+__global__ __launch_bounds__(256) void sharpen_bwd_b_tiled_kernel(const float* __restrict__ x, const float* __restrict__ dhsv,
+                                                                  float* __restrict__ dx, const float* __restrict__ gk9,
+                                                                  int n, int h, int w, int tiles_y, int tiles_x) {
+    __shared__ float4 sd[18 * 19];
+    __shared__ float sg[9];
+    const int tid = threadIdx.x;
+    if (tid < 9) sg[tid] = gk9[tid];
+    const int tiles = tiles_y * tiles_x;
+    const long im = blockIdx.x / tiles;
+    const int tile = blockIdx.x % tiles, y0 = (tile / tiles_x) * 16, x0 = (tile % tiles_x) * 16;
+    for (int i = tid; i < 324; i += 256) {
+        const int r = i / 18, c = i % 18, gy = y0 - 1 + r, gx = x0 - 1 + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy >= 0 && gy < h && gx >= 0 && gx < w) {
+            const float* p = dhsv + ((im * h + gy) * w + gx) * 3;
+            v = make_float4(p[0], p[1], p[2], 0.f);
+        }
+        sd[r * 19 + c] = v;
+    }
+    __syncthreads();
+    const int py = y0 + (tid >> 4), px = x0 + (tid & 15);
+    if (py >= h || px >= w) return;
+    int ys[2], xs[2];
+    const int ny = pad_sources(py, h, 1, 1, ys), nx = pad_sources(px, w, 1, 1, xs);
+    float gh = 0.f, gs = 0.f, gv = 0.f;
+    for (int a = 0; a < ny; ++a)
+        for (int b = 0; b < nx; ++b) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int oy = ys[a] - ky;
+                if (oy < 0 || oy >= h) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ox = xs[b] - kx;
+                    if (ox < 0 || ox >= w) continue;
+                    const float4 t = sd[(oy - y0 + 1) * 19 + (ox - x0 + 1)];
+                    gh = fmaf(t.x, sg[ky * 3 + kx], gh);
+                    gv = fmaf(t.z, sg[ky * 3 + kx], gv);
+                    if (ky == 2 && kx == 2) gs += t.y;
+                }
+            }
+        }
+    const long i = (im * h + py) * w + px;
+    float d[3];
+    hsv_backward(x[i * 3], x[i * 3 + 1], x[i * 3 + 2], gh, gs, gv, d);
+    dx[i * 3] = d[0];
+    dx[i * 3 + 1] = d[1];
+    dx[i * 3 + 2] = d[2];
+}
+
 // backward stage B (per input pixel): gather the filter transpose + pad fold, then J_rgb2hsv^T
 __global__ void sharpen_bwd_b_kernel(const float* __restrict__ x, const float* __restrict__ dhsv,
                                      float* __restrict__ dx, const float* __restrict__ gk9, int n, int h, int w) {
@@ -383,26 +457,8 @@ __global__ void sharpen_bwd_b_kernel(const float* __restrict__ x, const float* _
                     }
                 }
             }
-        // rgb_to_hsv backward at this pixel
-        const float r = x[i * 3], gg = x[i * 3 + 1], bb = x[i * 3 + 2];
-        const int imax = (r >= gg && r >= bb) ? 0 : (gg >= bb ? 1 : 2);
-        const int imin = (r <= gg && r <= bb) ? 0 : (gg <= bb ? 1 : 2);
-        const float c3[3] = {r, gg, bb};
-        const float v = c3[imax], mn = c3[imin], rng = v - mn;
-        float d[3] = {0.f, 0.f, 0.f};
-        float g_rng = 0.f, g_v = gv;
-        if (v > 0.f) { g_rng += gs / v; g_v -= gs * rng / (v * v); }
-        if (rng > 0.f) {
-            const float norm = 1.0f / (6.0f * rng);
-            // hue branch (same order as the forward): operands (a - b)
-            int ia, ib;
-            if (r == v) { ia = 1; ib = 2; } else if (gg == v) { ia = 2; ib = 0; } else { ia = 0; ib = 1; }
-            d[ia] += gh * norm;
-            d[ib] -= gh * norm;
-            g_rng -= gh * norm * (c3[ia] - c3[ib]) / rng;
-        }
-        d[imax] += g_v + g_rng;
-        d[imin] -= g_rng;
+        float d[3];
+        hsv_backward(x[i * 3], x[i * 3 + 1], x[i * 3 + 2], gh, gs, gv, d);
         dx[i * 3] = d[0];
         dx[i * 3 + 1] = d[1];
         dx[i * 3 + 2] = d[2];
@@ -595,8 +651,13 @@ int nimg_sharpen_bwd(const float* x, const float* dy, float* aux_hsv, const uint
     const long total = (long)n * h * w;
     hipLaunchKernelGGL(sharpen_bwd_a_kernel, dim3(grid_for(total)), dim3(256), 0, s, dy, mask, aux_hsv, total);
     NIMG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(sharpen_bwd_b_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, (const float*)aux_hsv, dx,
-                       gk9, n, h, w);
+    const int ty = (h + 15) / 16, tx = (w + 15) / 16;
+    if (h >= 16 && w >= 16 && (long)n * ty * tx < (1L << 31))
+        hipLaunchKernelGGL(sharpen_bwd_b_tiled_kernel, dim3((unsigned)((long)n * ty * tx)), dim3(256), 0, s, x,
+                           (const float*)aux_hsv, dx, gk9, n, h, w, ty, tx);
+    else
+        hipLaunchKernelGGL(sharpen_bwd_b_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, (const float*)aux_hsv, dx,
+                           gk9, n, h, w);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }
