@@ -202,7 +202,8 @@ __global__ __launch_bounds__(256) void gaussian_bwd_tiled_kernel(const float* __
             const long o = (im * h + gy) * w + gx;
             const uint32_t m = mask ? mask[o] : 7u;
             const float* p = dy + o * 3;
-            v = make_float4((m & 1u) ? p[0] : 0.f, (m & 2u) ? p[1] : 0.f, (m & 4u) ? p[2] : 0.f, 0.f);
+            const float p0 = p[0], p1 = p[1], p2 = p[2];      // unconditional loads, then selects (no branch per channel)
+            v = make_float4((m & 1u) ? p0 : 0.f, (m & 2u) ? p1 : 0.f, (m & 4u) ? p2 : 0.f, 0.f);
         }
         sd[r * 21 + c] = v;
     }
