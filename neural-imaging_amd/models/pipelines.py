@@ -481,6 +481,12 @@ class ClassicISP(NIPModel):
         self.set_srgb_conversion(srgb_mat)
         return super().process(batch_x, training)
 
+    def keras_layers(self):
+        """`_ClassicISP` is a subclassed tf.keras.Model whose only layer is the DemosaicingLayer (pipelines.py:416-432): its weight
+        file has ONE top-level group listing the layer's variables - alpha, the convolutions, then the frozen bilinear kernel
+        (trainable weights first, models/layers.py:206-233) - which is the parameter order here; so does the file written here."""
+        return [('demosaicing_layer', [w for _, ws in super().keras_layers() for w in ws])]
+
     @property
     def model_code(self):
         return 'ClassicISP_{cfa}_{k}x{k}_{fs}-{of}{r}'.format(

@@ -232,7 +232,9 @@ def test_keras_checkpoints_of_every_model(tmp_path):
     a.save_model(str(tmp_path / 'isp'))
     stored = [w for _, ws in keras_h5.load_weights(os.path.join(str(tmp_path / 'isp'), a.scoped_name, a.class_name.lower() + '.h5'))
               for w, _ in ws]
-    assert not any('up' in w or 'srgb' in w for w in stored[-3:]) and isp._h5_skip == ('up/kernel', 'srgb/kernel')
+    assert not any('up' in w or 'srgb' in w for w in stored) and isp._h5_skip == ('up/kernel', 'srgb/kernel')
+    isp_layers = keras_h5.load_weights(os.path.join(str(tmp_path / 'isp'), a.scoped_name, a.class_name.lower() + '.h5'))
+    assert [l for l, _ in isp_layers] == ['demosaicing_layer'] and stored[0].endswith('alpha:0') and 'bilinear' in stored[-1]
     # a file of another architecture is refused with the offending tensor named
     unet = pipelines.UNet(patch_size=16, device='cpu')
     with pytest.raises(ValueError):
