@@ -151,7 +151,9 @@ class UNet(NIPModel):
         weight-gradient kernel stay float32.  (forward() also asks for even sizes at every pooled level.)"""
         return ops.COMPUTE == 'bf16' and ops.STORE_BF16 and x.is_cuda
 
-    def forward(self, x, training=False):
+    writes_into = True            # forward(..., out=) develops straight into a caller's buffer (the workflow's class batch)
+
+    def forward(self, x, training=False, out=None):
         self._model.refresh_images()
         L, P, ns = self._layers, self._model, self._h.n_steps
         sb = self._store_bf16(x) and x.shape[1] % (1 << (ns - 1)) == 0 and x.shape[2] % (1 << (ns - 1)) == 0
@@ -169,7 +171,7 @@ class UNet(NIPModel):
                                                               out_bf16=sb)
             t['dc{}2'.format(n)] = L['dc{}2'.format(n)].forward(P, t['dc{}1'.format(n)], out_bf16=sb)
         t['dc{}'.format(ns)] = L['dc{}'.format(ns)].forward(P, t['dc{}2'.format(ns - 1)])
-        y = ops.d2s_clip(t['dc{}'.format(ns)], 1.0, 0.0, True)
+        y = ops.d2s_clip(t['dc{}'.format(ns)], 1.0, 0.0, True, out=out)
         return y, (t if training else None)
 
     def decoder_grads(self):

@@ -580,10 +580,12 @@ def conv2d_dgrad_pooled(g, idx, w, out=None):
     return out
 
 
-def d2s_clip(x, scale=1.0, shift=0.0, clip=True):
-    _f32(x)
+def d2s_clip(x, scale=1.0, shift=0.0, clip=True, out=None):
+    _f32(x, out)
     n, h, w, c4 = x.shape
-    y = torch.empty((n, 2 * h, 2 * w, c4 // 4), dtype=torch.float32, device=x.device)
+    if out is not None and tuple(out.shape) != (n, 2 * h, 2 * w, c4 // 4):
+        raise ValueError('d2s_clip: output shape mismatch')
+    y = torch.empty((n, 2 * h, 2 * w, c4 // 4), dtype=torch.float32, device=x.device) if out is None else out
     _lib.call('nimg_d2s_clip_fwd', _p(x), _p(y), n, h, w, c4 // 4, float(scale), float(shift), 1 if clip else 0,
               _stream())
     return y

@@ -141,11 +141,15 @@ class ManipulationClassification(object):
         return self._labels_cache[batch_size]
 
     # -- forward pieces (device tensors in/out) ------------------------------------------------------------------
-    def _manipulations(self, Y, randomize=False, override=None, training=False):
+    def _manipulations(self, Y, randomize=False, override=None, training=False, m=None):
+        """m: optional pre-allocated class batch whose first slice already IS Y (the NIP developed straight into it)."""
         override = override if override is not None else self._strengths
         b = Y.shape[0]
-        m = torch.empty((self.n_classes * b,) + tuple(Y.shape[1:]), dtype=torch.float32, device=Y.device)
-        m[:b].copy_(Y)
+        if m is None:
+            m = torch.empty((self.n_classes * b,) + tuple(Y.shape[1:]), dtype=torch.float32, device=Y.device)
+            m[:b].copy_(Y)
+        elif Y.data_ptr() != m.data_ptr() or m.shape[0] != self.n_classes * b:
+            raise ValueError('the class batch must start with the developed images')
         ctxs = []
         names = list(self._operations.keys())
         if randomize:         # one draw per operation and step from the numpy global stream (workflows/...:205); under data
@@ -248,8 +252,14 @@ class ManipulationClassification(object):
         world = parallel.world_size()
 
         # ---- forward
-        Y, nctx = self.nip.forward(x, training=train_nip)
-        m, mctxs = self._manipulations(Y, augment, training=train_nip)
+        m = None
+        if getattr(self.nip, 'writes_into', False):       # develop straight into the first slice of the class batch (saves a copy)
+            b = x.shape[0]
+            m = torch.empty((self.n_classes * b, 2 * x.shape[1], 2 * x.shape[2], 3), dtype=torch.float32, device=x.device)
+            Y, nctx = self.nip.forward(x, training=train_nip, out=m[:b])
+        else:
+            Y, nctx = self.nip.forward(x, training=train_nip)
+        m, mctxs = self._manipulations(Y, augment, training=train_nip, m=m)
         c = self._downsampling(m)
         C, entropy, cctx = self._codec_forward(c, training=need_upstream)
         _, fctx = self.fan.forward(C, self._device_labels(b), training=True)
