@@ -13,6 +13,9 @@
 #include <cstdlib>
 #include "common.h"
 
+// defined in wgrad5.hip: slabs written (0 = not its shape, -1 = launch error)
+int nimg_internal_wgrad5_alltaps(const void* in, int cin, const void* g, const unsigned char* idx, int cout, float* partial,
+                                 float* db_partial, int n, int h, int wd, int max_slabs, hipStream_t stream);
 // defined in conv_small.hip
 size_t nimg_internal_wgrad_tiny_bytes(int ks, int cin, int cout);
 int nimg_internal_conv_wgrad_tiny(const float* in, const float* dz, float* dw, int cin, int cout, int n, int h, int wd,
@@ -1281,9 +1284,21 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
     const long work = (long)n * p.tiles_y * p.tiles_x;
     p.work_per_split = (int)((work + p.splits - 1) / p.splits);
     const long count = (long)ks * ks * cin * cout;
+    hipStream_t s = (hipStream_t)stream;
+    if (dz_idx && ks == 5 && stride == 1 && c2 == 0 && pad_t == 2 && pad_l == 2 && hout == h && wout == wd && pad_mode == 0) {
+        // the FAN's conv2..4: all 25 taps in one wave (wgrad5.hip); slabs laid out inside the same workspace bound
+        const int max_slabs = splits_for(cin, cout, n, hout, wout);
+        float* dbp = db ? (float*)workspace + (size_t)max_slabs * count : nullptr;
+        const int slabs = nimg_internal_wgrad5_alltaps(in1, cin, dz, dz_idx, cout, (float*)workspace, dbp, n, h, wd, max_slabs, s);
+        if (slabs < 0) return NIMG_ERR_LAUNCH;
+        if (slabs > 0) {
+            launch_reduce2((const float*)workspace, dw, count, slabs, dbp, db, (long)cout, slabs, accumulate, s);
+            NIMG_CHECK_LAUNCH();
+            return NIMG_OK;
+        }
+    }
     if (db) p.db_partial = p.partial + (size_t)p.splits * count;
     const long blocks = (long)cdiv(cin, B_CI) * cdiv(cout, B_CO) * p.splits;
-    hipStream_t s = (hipStream_t)stream;
 #define NIMG_WGB1(KS_, ST_, NW_, INB_, DZB_, TH_)                                                               \
     do {                                                                                                      \
         constexpr int THH = (TH_ - 1) * ST_ + KS_, TWH = (B_TW - 1) * ST_ + KS_;                              \

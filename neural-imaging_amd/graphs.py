@@ -8,6 +8,10 @@ weight-gradient side stream is forked / joined inside the capture) and replays i
 host input is Keras Adam's bias-corrected rate lr * sqrt(1 - b2^t) / (1 - b1^t): it lives in a one-float device buffer that is
 refreshed before every replay (nimg_adam_step_dev reads it), so the captured launches never change.
 
+The graph holds raw addresses.  Buffers allocated inside the capture belong to the graph's private pool; the ones that live
+outside it (ops.Workspace scratch, cached filter tables) are pinned by the CapturedStep (ops.begin_pin_log / end_pin_log), so
+eager calls that follow - validation at another shape, a second captured step - can re-grow or evict them safely.
+
 Restrictions: fixed batch shape and hyper-parameters (lambda_*, manipulation strengths: augment=False), single process (the
 RCCL bucket launches are not captured), nan_check='deferred'.
 """
@@ -29,6 +33,7 @@ class CapturedStep(object):
         self.y = batch_y.detach().to(dev).clone().contiguous()
         self._rate_dev = torch.zeros(1, dtype=torch.float32, device=dev)
         # warm-up on a side stream (allocator / workspace growth, lazy module state), as torch's capture rules ask
+        ops.begin_pin_log()                   # every workspace / cached table the step touches from here on is pinned below
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
@@ -45,6 +50,14 @@ class CapturedStep(object):
                 self.out = flow.training_step(self.x, self.y, learning_rate=self.lr, **kw)
         finally:
             flow._lr_t_dev = None
+            # strong references to the external buffers whose addresses the graph holds (ops.Workspace scratch incl. the side
+            # stream's, filter-tap tables, the learned codec's latent workspace): eager calls after the capture may re-grow or
+            # evict them, the graph keeps replaying on these
+            self._pins = ops.end_pin_log()
+            lws = getattr(getattr(flow, 'codec', None), '_lws', None)
+            if lws is not None:
+                self._pins.append(lws)
+            self._pins.append(dict(flow._labels_cache))
         flow._step = self.t                 # the capture itself executed nothing
 
     def _set_rate(self, t):

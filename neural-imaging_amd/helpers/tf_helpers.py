@@ -27,11 +27,11 @@ class _TapCache(OrderedDict):
     def fetch(self, key, build):
         if key in self:
             self.move_to_end(key)
-            return self[key]
+            return ops.pin(self[key])
         self[key] = value = build()
         while len(self) > self.limit:
-            self.popitem(last=False)
-        return value
+            self.popitem(last=False)           # a captured step that replays on the evicted table holds its own reference
+        return ops.pin(value)
 
 
 class Sharpen(object):
@@ -134,11 +134,20 @@ def manipulation_gaussian(x, kernel, std, skip_clip=False):
 
 class Awgn(object):
     """manipulation_awgn(x, strength / 255) (tf_helpers.py:79-82; the workflow passes strength/255, workflows/...:122).
-    The noise is drawn on the device per call (per-rank generator under data parallelism) and kept for the backward."""
+    The noise is drawn on the device per call from an explicit generator - seeded per model and PER RANK under data parallelism
+    (parallel.rank_generator: the ranks' shards get different noise, rank 0 reproduces the single-process stream) - and kept
+    for the backward; a test injects `noise`."""
+
+    def __init__(self, seed=9731):
+        self._seed, self._gen = int(seed), None
 
     def forward(self, x, strength=5.1, out=None, training=False, noise=None):
         s = float(strength) / 255.0
-        noise = torch.randn_like(x) if noise is None else noise
+        if noise is None:
+            if self._gen is None or self._gen.device != x.device:
+                from .. import parallel
+                self._gen = parallel.rank_generator(self._seed, x.device)
+            noise = torch.randn(x.shape, device=x.device, dtype=x.dtype, generator=self._gen)
         y, mask = ops.awgn_fwd(x, noise, s, out=out, want_mask=training)
         return y, ({'x': x, 'noise': noise, 'mask': mask, 's': s} if training else None)
 

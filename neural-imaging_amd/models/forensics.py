@@ -150,9 +150,8 @@ class FAN(TFModel):
                     if self.dropout_masks is not None:
                         keep = self.dropout_masks[li].to(device=x.device, dtype=torch.uint8).reshape(head_in.shape).contiguous()
                     else:
-                        if self._dropout_gen is None:
-                            self._dropout_gen = torch.Generator(device=x.device)
-                            self._dropout_gen.manual_seed(self._dropout_seed)
+                        if self._dropout_gen is None:            # per rank: the shards of a global batch get different masks
+                            self._dropout_gen = parallel.rank_generator(self._dropout_seed, x.device)
                         keep = (torch.rand(head_in.shape, device=x.device, generator=self._dropout_gen) >= rate).to(torch.uint8)
                     head_in = ops.mask_scale(head_in, keep, 1.0 / (1.0 - rate))
                     t[d.name + '/keep'], t[d.name + '/dropped'] = keep, head_in

@@ -134,6 +134,36 @@ def same_pads(size, k, s):
     return out, total // 2
 
 
+# Buffers that live OUTSIDE a step's own allocations (the grow-only workspaces below, the manipulations' filter-tap cache)
+# are baked into a captured HIP graph as raw pointers.  While a pin log is open (graphs.CapturedStep opens one around its
+# warm-up and capture) every such buffer handed out is also recorded there; the capture keeps the list, so a later eager call
+# that re-grows a workspace or evicts a cached table replaces the OWNER's reference only - the memory the graph replays on
+# stays allocated for as long as the captured step lives.
+_PIN_LOG = None
+
+
+def begin_pin_log():
+    global _PIN_LOG
+    _PIN_LOG = []
+
+
+def end_pin_log():
+    global _PIN_LOG
+    log, _PIN_LOG = _PIN_LOG or [], None
+    seen, out = set(), []
+    for t in log:
+        if id(t) not in seen:
+            seen.add(id(t))
+            out.append(t)
+    return out
+
+
+def pin(t):
+    if _PIN_LOG is not None and t is not None:
+        _PIN_LOG.append(t)
+    return t
+
+
 class Workspace(object):
     """A grow-only scratch buffer (split-K slabs, reduction partials)."""
 
@@ -144,7 +174,7 @@ class Workspace(object):
         nbytes = max(int(nbytes), 256)
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
             self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        return self.buf
+        return pin(self.buf)
 
 
 _ws = Workspace()

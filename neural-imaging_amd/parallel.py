@@ -38,6 +38,15 @@ def init_from_env(backend=None):
     return ws
 
 
+def rank_generator(base_seed, device):
+    """A device generator for this rank's random draws (awgn noise, dropout masks): every rank must draw DIFFERENT numbers
+    for its shard (identical noise / masks on all ranks would correlate the shards of one global batch, SURVEY 8e caveat 3),
+    and rank 0 of any world reproduces the single-process stream: seed = base_seed + 1000003 * rank."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(base_seed) + 1000003 * rank())
+    return gen
+
+
 class GradientBucket(object):
     """Asynchronous sum all-reduce of one flat gradient buffer; wait() before the optimiser touches it."""
 

@@ -17,14 +17,21 @@ def dp_worker(rank, world, port, q):
     assert par.init_from_env('gloo') == world and par.world_size() == world and par.rank() == rank
     flat = torch.full((1000,), float(rank + 1))
     bucket = par.GradientBucket()
-    bucket.launch(flat)
+    for lo, hi in ((0, 100), (100, 600), (600, 1000)):              # three buckets in flight, like the channel's FAN / decoder / encoder
+        bucket.launch(flat[lo:hi])
     bucket.wait()
     flag = torch.tensor([1 if rank == 1 else 0], dtype=torch.int32)
     par.all_reduce_flag(flag)
-    batch = torch.arange(8).reshape(8, 1)
+    batch = torch.arange(4 * world).reshape(4 * world, 1)
     shard = par.shard_batch(batch, rank, world)
     drawn = par.broadcast_floats([0.25 + rank, 7.0 * (rank + 1)])
-    q.put((rank, float(flat[0]), int(flag[0]), shard.flatten().tolist(), drawn))
+    # this rank's random stream (awgn noise / dropout masks): through the model that draws it, on the CPU device here
+    from neural_imaging_amd.helpers import tf_helpers
+    awgn = tf_helpers.Awgn(seed=5)
+    gen = par.rank_generator(5, torch.device('cpu'))
+    noise = torch.randn((6,), generator=gen)
+    q.put((rank, [float(flat[0]), float(flat[599]), float(flat[999])], int(flag[0]), shard.flatten().tolist(), drawn,
+           noise.tolist(), awgn._seed))
     torch.distributed.destroy_process_group()
 
 

@@ -1139,6 +1139,49 @@ def test_captured_step_replays_the_eager_step(dev):
     assert captured._step == 5 and abs(float(runner._rate_dev.item()) - ops.adam_lr_t(1e-3, 5)) < 1e-10
 
 
+def test_captured_step_survives_workspace_regrowth(dev):
+    """the graph holds raw addresses of buffers that live outside its pool (ops.Workspace scratch, the
+    manipulations' filter-tap cache).  A LARGER eager step after the capture re-grows the workspaces and nine other strengths
+    evict the cached tables; CapturedStep pins what it captured on, so the replay still equals the eager step."""
+    from neural_imaging_amd import graphs, ops
+    from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
+    ops.set_compute('f32')
+    dist = {'downsampling': 'none', 'compression': 'jpeg', 'compression_params': {'quality': 80, 'codec': 'soft'}}
+    rgb = natural_images(2, 64, 64, seed=33)
+    raw = bayer_from_rgb(rgb)
+    bx, by = torch.from_numpy(raw).to(dev), torch.from_numpy(rgb).to(dev)
+    flows = [ManipulationClassification('UNet', distribution=dist, trainable={'nip'}, raw_patch_size=32, device=dev,
+                                        nan_check='deferred') for _ in range(2)]
+    eager, captured = flows
+    runner = graphs.CapturedStep(captured, bx, by, learning_rate=1e-3, lambda_nip=0.1, warmup=1)
+    eager.training_step(bx, by, lambda_nip=0.1, learning_rate=1e-3)          # = the capture's one warm-up step
+    assert torch.equal(eager.fan._model.flat, captured.fan._model.flat)
+    ws_before = ops._ws.buf.data_ptr()
+    assert any(t.data_ptr() == ws_before for t in runner._pins if isinstance(t, torch.Tensor))
+    # a bigger eager job on a third flow: more split-K scratch than the captured step ever asked for ...
+    big_rgb = natural_images(6, 128, 128, seed=34)
+    big = ManipulationClassification('UNet', distribution=dist, trainable={'nip'}, raw_patch_size=64, device=dev,
+                                     nan_check='deferred')
+    big.training_step(bayer_from_rgb(big_rgb), big_rgb, lambda_nip=0.1, learning_rate=1e-3)
+    for ws in (ops._ws, ops._ws_side):                                        # ... and an explicit re-growth of both
+        if ws.buf is not None:
+            ws.get(2 * ws.buf.numel(), dev)
+    assert ops._ws.buf.data_ptr() != ws_before
+    # ... and enough other strengths through the captured flow's own manipulations to evict its cached filter tables
+    Y = captured.nip.process(raw)
+    for k in range(10):
+        captured.run_manipulations(Y, override={'sharpen': 0.3 + 0.1 * k, 'resample': 50, 'gaussian': 0.6 + 0.1 * k, 'jpeg': 80})
+    junk = torch.full((ops._ws.buf.numel(),), 255, dtype=torch.uint8, device=dev)     # recycle freed blocks with garbage
+    del junk
+    torch.cuda.synchronize()
+    loss_e, _ = eager.training_step(bx, by, lambda_nip=0.1, learning_rate=1e-3)
+    loss_c, _ = runner.step()
+    eager.check_nan(), captured.check_nan()
+    assert abs(float(loss_e) - float(loss_c)) <= 1e-6 * abs(float(loss_e))
+    for a, b in ((eager.fan, captured.fan), (eager.nip, captured.nip)):
+        assert torch.equal(a._model.flat_grad, b._model.flat_grad)
+
+
 def test_validate_fan_on_device(dev):
     """validation.validate_fan (device-side decisions + confusion counts, one read-back) against the reference's host loop
     (training/validation.py:163-202) restated with numpy on the same decisions."""

@@ -776,7 +776,38 @@ def test_unpool_folded_into_conv5_backward(dev, bf16_mode, shape):
     ops.conv2d_wgrad(x, dz, 5, dw=dw_ref, db=db_ref)
     dw, db = torch.empty_like(wt), torch.empty((cout,), device=dev)
     ops.conv2d_wgrad_unpool(x, gp, idx, 5, dw, db=db)
-    assert torch.equal(dw_ref, dw) and torch.equal(db_ref, db), 'weight / bias gradient'
+    # the pooled form runs the all-taps kernel (csrc/wgrad5.hip) where its shape rules allow: same products, another summation
+    # order (float32 sums of exact bf16 x bf16 products) - test_wgrad5_alltaps_vs_oracle holds it to the float64 oracle
+    assert torch.allclose(dw_ref, dw, rtol=0, atol=2e-5 * float(dw_ref.abs().max())), 'weight gradient'
+    assert torch.allclose(db_ref, db, rtol=0, atol=2e-5 * float(gp.float().abs().sum(dim=(0, 1, 2)).max())), 'bias gradient'
+
+
+@pytest.mark.parametrize('shape', [(4, 128, 128, 32, 64), (5, 64, 64, 64, 128), (7, 32, 32, 128, 256), (1, 8, 16, 32, 64),
+                                   (3, 24, 32, 64, 192)])
+def test_wgrad5_alltaps_vs_oracle(dev, bf16_mode, shape):
+    """csrc/wgrad5.hip (all 25 taps in one wave, v_mfma_f32_16x16x32_bf16, shifted register windows, double-buffered tiles): weight
+    and bias gradient of the FAN's conv2 / conv3 / conv4 from (bf16 input, pooled bf16 gradient, arg-max bytes) at the bench's
+    layer shapes (32 -> 64 @ 128x128, 64 -> 128 @ 64x64, 128 -> 256 @ 32x32; batch sizes that do not divide over the splits), a
+    single-tile image and a 16-row-indivisible one (8-row tiles), against the float64 oracle on the same rounded values."""
+    from neural_imaging_amd import ops
+    n, h, w, cin, cout = shape
+    x_np = _bf16_round(rnd((n, h, w, cin), 11)).numpy().astype(np.float32)
+    gp_np = _bf16_round(rnd((n, h // 2, w // 2, cout), 12)).numpy().astype(np.float32)
+    idx_np = np.random.default_rng(13).integers(0, 4, size=(n, h // 2, w // 2, cout)).astype(np.uint8)
+    dz_np = np.zeros((n, h, w, cout), np.float32)
+    for pos in range(4):
+        dz_np[:, pos >> 1::2, pos & 1::2, :] = np.where(idx_np == pos, gp_np, 0.0)
+    x = to64(x_np)
+    wt = to64(np.zeros((5, 5, cin, cout))).requires_grad_(True)
+    z = T.conv2d(x, wt, None, 1, 'SAME')
+    (z * to64(dz_np)).sum().backward()
+    xg, gg = g(x_np, dev).to(torch.bfloat16), g(gp_np, dev).to(torch.bfloat16)
+    ig = torch.from_numpy(idx_np).to(dev)
+    assert ops.unpool_fold_ok(xg, gg, cin, cout, 5)
+    dw, db = torch.full((5, 5, cin, cout), 7.0, device=dev), torch.full((cout,), 7.0, device=dev)
+    ops.conv2d_wgrad_unpool(xg, gg, ig, 5, dw, db=db)
+    assert_close(dw.cpu().numpy(), wt.grad.numpy(), 0.0, 2e-5, what='wgrad')
+    assert_close(db.cpu().numpy(), dz_np.astype(np.float64).sum(axis=(0, 1, 2)), 0.0, 2e-5, what='bias grad')
 
 
 def test_bf16_stored_unet_ops(dev, bf16_mode):

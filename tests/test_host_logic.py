@@ -300,7 +300,7 @@ def test_host_dataset_from_directory_and_arrays(tmp_path):
         dataset.DeviceDataset(arr, device='cpu')
 
 
-def test_data_parallel_plumbing_gloo_world2():
+def _run_dp_workers(world):
     import torch.multiprocessing as mp
     from dp_worker import dp_worker
     s = socket.socket()
@@ -309,14 +309,30 @@ def test_data_parallel_plumbing_gloo_world2():
     s.close()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=dp_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in range(2))
+    res = sorted(q.get(timeout=180) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert res[0][1] == 3.0 and res[1][1] == 3.0                  # sum all-reduce of the flat gradient buffers
-    assert res[0][2] == 1 and res[1][2] == 1                      # NaN flag is OR-reduced
-    assert res[0][3] == [0, 1, 2, 3] and res[1][3] == [4, 5, 6, 7]
-    assert res[0][4] == [0.25, 7.0] and res[1][4] == [0.25, 7.0]  # rank 0's augmentation draws reach every rank
+    return res
+
+
+@pytest.mark.parametrize('world', [2, 8])
+def test_data_parallel_plumbing_gloo(world):
+    """parallel.py over gloo on CPU, 2 ranks and the 8 ranks of one MI355X node: three gradient buckets in flight (sum
+    all-reduce), NaN-flag OR, contiguous shards of the global batch, rank 0's augmentation draws broadcast, and the per-rank
+    random streams (awgn noise / dropout masks: every rank differs, rank 0 reproduces the single-process stream)."""
+    import torch
+    res = _run_dp_workers(world)
+    total = float(sum(range(1, world + 1)))
+    for r, out in enumerate(res):
+        assert out[0] == r and out[1] == [total, total, total]     # every bucket of the flat gradient buffer is summed
+        assert out[2] == 1                                        # NaN flag is OR-reduced
+        assert out[3] == list(range(4 * r, 4 * r + 4))
+        assert out[4] == [0.25, 7.0]                              # rank 0's augmentation draws reach every rank
+    streams = [tuple(out[5]) for out in res]
+    assert len(set(streams)) == world                             # no two ranks draw the same noise
+    single = torch.randn((6,), generator=torch.Generator().manual_seed(5)).tolist()
+    assert list(streams[0]) == single                             # rank 0 = the single-process stream

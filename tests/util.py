@@ -51,3 +51,52 @@ def assert_close(a, b, atol, rtol_max=None, what=''):
     ok = mx <= atol or (rtol_max is not None and rel <= rtol_max)
     assert ok, '{}: max abs err {:.3e}, rel-to-max {:.3e} (atol {}, rtol_max {})'.format(what, mx, rel, atol, rtol_max)
     return mx, rel
+
+
+
+def scene_images(n, h, w, seed=0, device='cpu'):
+    """Synthetic photographs with the statistics the channel needs to LEARN on (bench.py's trained-parity leg,
+    tools/train_parity.py): smooth colour gradients + a few soft-edged occluders + band-limited texture that is mostly
+    luminance (the cross-channel correlation a demosaicer exploits) + a little sensor noise, quantised to k/255.
+    Generated with torch on `device` (seeded per device type: a CPU and a GPU run draw different images) -> float32 tensor
+    (n, h, w, 3).  natural_images() above stays the input of the parity tests (their tolerances were tuned on it)."""
+    import torch.nn.functional as F
+    dev = torch.device(device)
+    g = torch.Generator(device=dev).manual_seed(int(seed))
+    rnd = lambda *s: torch.rand(*s, generator=g, device=dev)
+    nrm = lambda *s: torch.randn(*s, generator=g, device=dev)
+
+    def blur(x, sigma):                                  # x (n, c, h, w): separable gaussian, reflect borders
+        r = int(3 * sigma + 0.5)
+        k = torch.exp(-0.5 * (torch.arange(-r, r + 1, device=dev, dtype=torch.float32) / sigma) ** 2)
+        k = k / k.sum()
+        c = x.shape[1]
+        x = F.conv2d(F.pad(x, (r, r, 0, 0), mode='reflect'), k.view(1, 1, 1, -1).repeat(c, 1, 1, 1), groups=c)
+        return F.conv2d(F.pad(x, (0, 0, r, r), mode='reflect'), k.view(1, 1, -1, 1).repeat(c, 1, 1, 1), groups=c)
+
+    img = F.interpolate(rnd(n, 3, h // 32 + 2, w // 32 + 2), scale_factor=32, mode='bilinear', align_corners=False)
+    img = 0.15 + 0.7 * img[:, :, 16:16 + h, 16:16 + w]
+    yy = torch.arange(h, device=dev, dtype=torch.float32).view(1, h, 1)
+    xx = torch.arange(w, device=dev, dtype=torch.float32).view(1, 1, w)
+    for _ in range(3):                                   # occluders: half planes and discs with ~1 px soft edges
+        th = rnd(n, 1, 1) * (2 * np.pi)
+        cx, cy = rnd(n, 1, 1) * w, rnd(n, 1, 1) * h
+        disc = rnd(n, 1, 1) < 0.5
+        rad = (0.1 + 0.3 * rnd(n, 1, 1)) * min(h, w)
+        dx, dy = xx - cx, yy - cy
+        dist = torch.where(disc, rad - torch.sqrt(dx * dx + dy * dy), torch.cos(th) * dx + torch.sin(th) * dy)
+        mask = torch.sigmoid(dist / 0.7)
+        delta = (rnd(n, 3, 1, 1) - 0.5) * 0.7
+        img = img + mask[:, None] * delta
+    amp = 0.02 + 0.06 * rnd(n, 1, 1, 1)
+    lum = blur(nrm(n, 1, h, w), 1.2) * 3.0
+    chroma = blur(nrm(n, 3, h, w), 2.0) * 5.0
+    img = img + amp * lum + 0.3 * amp * chroma + 0.004 * nrm(n, 3, h, w)
+    img = torch.round(img.clamp(0, 1) * 255) / 255
+    return img.permute(0, 2, 3, 1).contiguous()
+
+
+def bayer_from_rgb_t(rgb):
+    """bayer_from_rgb() for a torch tensor (N,h,w,3) on any device."""
+    return torch.stack([rgb[:, 0::2, 0::2, 1], rgb[:, 0::2, 1::2, 2], rgb[:, 1::2, 0::2, 0], rgb[:, 1::2, 1::2, 1]],
+                       dim=-1).contiguous()
