@@ -58,6 +58,14 @@ int nimg_djpeg_fwd(const float* x, float* y, const float* qtab, uint8_t* mask, i
 /* gx = d loss / d x given gy = d loss / d y.  Recomputes the forward DCT from x (no saved coefficients). */
 int nimg_djpeg_bwd(const float* x, const float* gy, const uint8_t* mask, const float* qtab, float* gx,
                    int n, int h, int w, int rounding, void* stream);
+/* The same backward pass plus the gradient of TRAINABLE quantisation tables (DifferentiableJPEG(trainable=True),
+ * models/jpeg.py:57-62 add_weight('Q_mtx_luma' / 'Q_mtx_chroma'); gradient through X / Q ... * Q at :129-131):
+ * dq (2,8,8) float32 = [d loss / d Q_luma, d loss / d Q_chroma (Cb + Cr)], (+)= when accumulate.  Deterministic: per-wave
+ * partial sums in `workspace` (nimg_djpeg_dq_workspace_bytes), fixed-order reduction. */
+size_t nimg_djpeg_dq_workspace_bytes(int n, int h, int w);
+int nimg_djpeg_bwd_dq(const float* x, const float* gy, const uint8_t* mask, const float* qtab, float* gx, float* dq,
+                      int n, int h, int w, int rounding, int accumulate, void* workspace, size_t workspace_bytes,
+                      void* stream);
 /* IJG quality scaling - replaces jpeg_qtable, compression/jpeg_helpers.py:264-305.  HOST function: out64 is a host
  * pointer to 64 floats (row-major 8x8).  channel 0 = luma, >0 = chroma. */
 int nimg_jpeg_qtable(int quality, int channel, float* out64);

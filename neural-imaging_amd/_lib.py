@@ -18,6 +18,8 @@ PROTOTYPES = {
     'nimg_abi_version': (c_int, []),
     'nimg_djpeg_fwd': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'nimg_djpeg_bwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    'nimg_djpeg_dq_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'nimg_djpeg_bwd_dq': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'nimg_jpeg_qtable': (c_int, [c_int, c_int, P]),
     'nimg_conv2d_fwd': (c_int, [P, c_int, P, c_int, P, P, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int,
                                 c_int, c_int, c_int, c_int, c_int, c_int, c_float, P]),

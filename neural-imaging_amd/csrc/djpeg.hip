@@ -269,10 +269,16 @@ __global__ __launch_bounds__(256) void djpeg_fwd_kernel(const float* __restrict_
     store_strip(y, lds, t, h, w, lane);
 }
 
+// DQ: also the gradient of the quantisation tables (trainable=True, models/jpeg.py:57-62; X' = quant(X / Q) * Q at :129-131):
+// d X' / d Q = quant(z) - z quant'(z) with z = X / Q, summed over every block of the luma / of both chroma channels.  A lane
+// holds column r of its block, so it accumulates 2 x 8 table entries (u, r); the 8 blocks of the wave are folded with three
+// shuffles and lanes 0..7 write the wave's 128 partial sums (dq_partial[task][cls][u][r]); a fixed-order reduction finishes.
+template <bool DQ>
 __global__ __launch_bounds__(256) void djpeg_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                         const uint8_t* __restrict__ mask,
                                                         const float* __restrict__ qtab, float* __restrict__ gx,
-                                                        int n, int h, int w, int rounding) {
+                                                        float* __restrict__ dq_partial, int n, int h, int w,
+                                                        int rounding) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = lane >> 3, r = lane & 7;
@@ -320,6 +326,13 @@ __global__ __launch_bounds__(256) void djpeg_bwd_kernel(const float* __restrict_
     wave_sync();
     transpose24(lds, b, r, tx);
     transpose24(lds, b, r, tg);
+    float dqa[DQ ? 2 : 1][8];
+    if constexpr (DQ) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dqa[k][u] = 0.0f;
+    }
     if (active) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -329,10 +342,26 @@ __global__ __launch_bounds__(256) void djpeg_bwd_kernel(const float* __restrict_
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const float q = qtab[c * 64 + u * 8 + r];
-                G[u] *= quantise_grad(X[u] / q, rounding);       // (X/Q -> quant -> *Q): the Q factors cancel
+                const float z = X[u] / q;
+                const float qg = quantise_grad(z, rounding);
+                if constexpr (DQ) dqa[c == 0 ? 0 : 1][u] += G[u] * (quantise(z, rounding) - z * qg);
+                G[u] *= qg;                                      // (X/Q -> quant -> *Q): the Q factors cancel
             }
             dct_inv8(G, tg[c]);                                  // d b = F^T gX F : column pass
         }
+    }
+    if constexpr (DQ) {
+        const long task = (long)blockIdx.x * WAVES_PER_BLOCK + wave;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float v = dqa[k][u];
+                v += __shfl_xor(v, 8, 64);
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if (lane < 8) dq_partial[task * 128 + (k * 8 + u) * 8 + r] = v;
+            }
     }
     transpose24(lds, b, r, tg);
     if (active) {
@@ -381,8 +410,34 @@ int nimg_djpeg_bwd(const float* x, const float* gy, const uint8_t* mask, const f
     const long tasks = (long)n * (h / 8) * ((w + STRIP_PX - 1) / STRIP_PX);
     const int grid = nimg::cdiv(tasks, WAVES_PER_BLOCK);
     const size_t lds = (size_t)WAVES_PER_BLOCK * WAVE_LDS_F * sizeof(float);
-    hipLaunchKernelGGL(djpeg_bwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, x, gy, mask, qtab, gx, n,
-                       h, w, rounding);
+    hipLaunchKernelGGL(djpeg_bwd_kernel<false>, dim3(grid), dim3(256), lds, (hipStream_t)stream, x, gy, mask, qtab, gx,
+                       (float*)nullptr, n, h, w, rounding);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+size_t nimg_djpeg_dq_workspace_bytes(int n, int h, int w) {
+    if (n <= 0 || h <= 0 || w <= 0) return 0;
+    const long tasks = (long)n * (h / 8) * ((w + STRIP_PX - 1) / STRIP_PX);
+    return (size_t)nimg::cdiv(tasks, WAVES_PER_BLOCK) * WAVES_PER_BLOCK * 128 * sizeof(float);
+}
+
+int nimg_djpeg_bwd_dq(const float* x, const float* gy, const uint8_t* mask, const float* qtab, float* gx, float* dq,
+                      int n, int h, int w, int rounding, int accumulate, void* workspace, size_t workspace_bytes,
+                      void* stream) {
+    if (n == 0) return NIMG_OK;
+    if (!x || !gy || !mask || !qtab || !gx || !dq || !workspace || n < 0 || h <= 0 || w <= 0 || (h % 8) || (w % 8))
+        return NIMG_ERR_ARG;
+    if (rounding < NIMG_ROUND_ROUND || rounding > NIMG_ROUND_IDENTITY) return NIMG_ERR_ARG;
+    if (workspace_bytes < nimg_djpeg_dq_workspace_bytes(n, h, w)) return NIMG_ERR_WORKSPACE;
+    const long tasks = (long)n * (h / 8) * ((w + STRIP_PX - 1) / STRIP_PX);
+    const int grid = nimg::cdiv(tasks, WAVES_PER_BLOCK);
+    const size_t lds = (size_t)WAVES_PER_BLOCK * WAVE_LDS_F * sizeof(float);
+    hipLaunchKernelGGL(djpeg_bwd_kernel<true>, dim3(grid), dim3(256), lds, (hipStream_t)stream, x, gy, mask, qtab, gx,
+                       (float*)workspace, n, h, w, rounding);
+    NIMG_CHECK_LAUNCH();
+    nimg::launch_reduce2((const float*)workspace, dq, 128, grid * WAVES_PER_BLOCK, nullptr, nullptr, 0, 0, accumulate,
+                         (hipStream_t)stream);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }

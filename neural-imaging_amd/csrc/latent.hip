@@ -83,11 +83,27 @@ struct KernelW {
     double S, dS;
 };
 
+// base^(-m/2) for an integer m >= 1 (the t-Student kernel's exponent -(v + 1)/2 with the reference's integer v = 50,
+// tf_helpers.py:290,321): binary powering + one square root + one division, ~15 float64 operations where the generic pow()
+// spends ~300 (two calls per centre and latent value made these kernels 15 % of the codec's training step).  Every step is
+// rounded to 0.5 ulp: <= 1e-15 relative against pow(); an overflowing power gives 0 like pow()'s underflow would.
+__device__ __forceinline__ double pow_neg_half_int(double base, int m) {
+    double r = 1.0, b = base;
+    for (int n = m >> 1; n > 0; n >>= 1) {
+        if (n & 1) r *= b;
+        b *= b;
+    }
+    if (m & 1) r *= sqrt(base);
+    return 1.0 / r;
+}
+
 // kernel weights (+eps) and their derivative w.r.t. u, for all K centres
 __device__ __forceinline__ void eval_weights(double u, const float* __restrict__ cb, int K, double v, double gamma,
                                              KernelW& o, bool need_grad) {
     o.S = 0.0;
     o.dS = 0.0;
+    const double m_real = v + 1.0;
+    const int m_int = (v > 0.0 && m_real <= 1024.0 && m_real == floor(m_real)) ? (int)m_real : 0;      // 0: generic pow
     for (int k = 0; k < K; ++k) {
         const double t = gamma * (u - (double)cb[k]);
         double wk, dwk;
@@ -97,7 +113,7 @@ __device__ __forceinline__ void eval_weights(double u, const float* __restrict__
             dwk = wk * (-2.0 * gamma * d);
         } else {
             const double base = 1.0 + t * t / v;
-            wk = pow(base, -(v + 1.0) / 2.0);
+            wk = m_int ? pow_neg_half_int(base, m_int) : pow(base, -(v + 1.0) / 2.0);
             dwk = wk * (-(v + 1.0) / v) * gamma * t / base;
         }
         o.w[k] = wk + 1e-72;
@@ -149,12 +165,22 @@ __global__ __launch_bounds__(256) void soft_codebook_fwd_kernel(const float* __r
 }
 
 // hist_sum[k] = sum_blocks partial (fixed order)
-__global__ void hist_reduce_kernel(const double* __restrict__ partial, int nblocks, int K, double* __restrict__ hist_sum) {
-    const int k = threadIdx.x;
-    if (k >= K) return;
+// 1024 threads = 16 segments x up to 64 centres: segment g adds the blocks g, g + 16, ... in order, then the 16 segment sums
+// are added in order - the same result whatever the machine does, and 64 loads in a chain instead of 1024
+__global__ __launch_bounds__(1024) void hist_reduce_kernel(const double* __restrict__ partial, int nblocks, int K,
+                                                           double* __restrict__ hist_sum) {
+    __shared__ double seg[16][MAXK];
+    const int k = threadIdx.x & 63, g = threadIdx.x >> 6;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[(long)b * K + k];
-    hist_sum[k] = s;
+    if (k < K)
+        for (int b = g; b < nblocks; b += 16) s += partial[(long)b * K + k];
+    seg[g][k] = s;
+    __syncthreads();
+    if (g == 0 && k < K) {
+        double t = 0.0;
+        for (int j = 0; j < 16; ++j) t += seg[j][k];
+        hist_sum[k] = t;
+    }
 }
 
 // entropy (bits) and dH/d(hist_sum) from the global weight sums; tf_helpers.py:326-331
@@ -228,10 +254,15 @@ __global__ __launch_bounds__(256) void soft_codebook_bwd_kernel(const float* __r
 
 __global__ void dscale_final_kernel(const double* __restrict__ partial, int nblocks, float* __restrict__ dscale,
                                     int accumulate) {
+    __shared__ double seg[64];
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 64) s += partial[b];          // 64 interleaved chains, then a fixed-order finish
+    seg[threadIdx.x] = s;
+    __syncthreads();
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += partial[b];
-        dscale[0] = accumulate ? dscale[0] + (float)s : (float)s;
+        double t = 0.0;
+        for (int j = 0; j < 64; ++j) t += seg[j];
+        dscale[0] = accumulate ? dscale[0] + (float)t : (float)t;
     }
 }
 
@@ -343,7 +374,7 @@ int nimg_latent_fwd(const float* z, const float* scale, const float* codebook, i
     hipLaunchKernelGGL(soft_codebook_fwd_kernel, dim3(grid), dim3(256), 0, s, z, scale, codebook, K, (double)v,
                        (double)gamma, latent, part, count, soft_codebook);
     NIMG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(hist_reduce_kernel, dim3(1), dim3(64), 0, s, (const double*)part, grid, K, hsum);
+    hipLaunchKernelGGL(hist_reduce_kernel, dim3(1), dim3(1024), 0, s, (const double*)part, grid, K, hsum);
     NIMG_CHECK_LAUNCH();
     if (finalize) {       // single process: the local histogram is the global one
         hipLaunchKernelGGL(entropy_finalize_kernel, dim3(1), dim3(64), 0, s, (const double*)hsum, K,

@@ -6,8 +6,12 @@
 // shifted input fragment per tap (12 ds_read_b64_tr_b16 per 8 MFMAs); all 8 waves of the ONE workgroup a CU holds stage the
 // next tile at the same time behind two barriers (nothing multiplies meanwhile), and a tile costs ~500 instructions of address
 // arithmetic per wave.  Here a wave owns ALL 25 taps of one 16 ci x 32 co block as 25 x 2 accumulators of
-// v_mfma_f32_16x16x32_bf16 (200 AGPRs: hipcc keeps MFMA accumulators in the AGPR half only, so 25 32x32 blocks = 400 registers
-// spill; one wave per SIMD on the unified 512-entry file) and walks a tile 8 columns x 4 rows (K = 32 pixels) at a time:
+// v_mfma_f32_16x16x32_bf16 (200 AGPRs.  hipcc keeps MFMA accumulators in the AGPR half only: the 32 ci x 32 co block of
+// v_mfma_f32_32x32x16_bf16 - 400 accumulator registers, half the instructions per FLOP - compiles to v_accvgpr_read / _write
+// shuffles between the halves, ~30 per MFMA, or to scratch spills.  Splitting the accumulators by hand - 16 taps through the
+// builtin (AGPRs), 9 through an inline-asm MFMA with a VGPR-constrained accumulator and its own s_nop wait states - compiles
+// clean and is correct, but measured 8 % SLOWER (profiles/r03_f_wgrad5_m32_ab.txt: 1.58 vs 1.47 ms for the three layers): its
+// 8-row tiles double the staging instructions, which one wave per SIMD cannot hide.  One wave per SIMD on the 512-entry file) and walks a tile 8 columns x 4 rows (K = 32 pixels) at a time:
 //   * the two dz fragments of the step (4 transpose reads) feed 50 MFMAs;
 //   * per kernel row ky the input operand is read as 12 consecutive pixels per K group (3 transpose reads: 8 own + 4 halo):
 //     kx = 0 / 4 are its first / last 8 pixels, kx = 1 / 3 that register window shifted by one pixel (K = pixels, two bf16 per
@@ -314,6 +318,8 @@ int launch(Wg5Params p, int max_slabs, hipStream_t stream) {
     if (hipGetLastError() != hipSuccess) return -1;
     return (int)splits;
 }
+
+
 
 }  // namespace
 

@@ -104,7 +104,8 @@ class FAN(TFModel):
         t = OrderedDict()
         t['x'] = x
         c1 = self._convs[0]
-        front = ops.front_end_ok(c1.cin, c1.cout, c1.ks, x.shape[1], x.shape[2]) and c1.activation == 'leaky_relu'
+        front = ops.front_end_ok(c1.cin, c1.cout, c1.ks, x.shape[1], x.shape[2], n=x.shape[0] if training else None) and \
+            c1.activation == 'leaky_relu'
         # throughput mode: the filtered image leaves as 8-byte bf16 {c, 1} pixels, the form the row-band conv1 kernels read
         net, nf = self._constrained.forward(P, x, c4_only=front)
         t['constrained'], t['nf'] = net, nf

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from .. import ops
-from ..device import DeviceArray, to_device
+from ..device import DeviceArray, default_device, to_device
 from ..helpers.utils import is_number
 from ..compression.jpeg_helpers import jpeg_qf_estimation
 from .tfmodel import ParamStore, TFModel
@@ -45,14 +45,22 @@ class DifferentiableJPEG(object):
             raise ValueError('Invalid JPEG quality: requires int in [1,100] or an iterable with least 2 such numbers')
         if rounding_approximation is not None and rounding_approximation not in ['sin', 'harmonic', 'soft']:
             raise ValueError('Unsupported rounding approximation: {}'.format(rounding_approximation))
-        if trainable:
-            raise NotImplementedError('trainable quantisation tables are "under development" in the reference too')
         self.quality = quality
         self.trainable = trainable
         self.rounding_approximation = rounding_approximation
         self.rounding_approximation_steps = rounding_approximation_steps
         self.device = device
         self._q_cache = {}
+        # trainable=True (models/jpeg.py:57-62): two (8,8) weights 'Q_mtx_luma' / 'Q_mtx_chroma', initialised from the IJG tables
+        # of a numeric quality or ones; the chroma table serves Cb and Cr (:125-128).  Both sit back to back in ONE flat buffer
+        # (64 floats each = the ParamStore's alignment), which is also the (2,8,8) layout nimg_djpeg_bwd_dq writes.
+        self.params = None
+        if trainable:
+            self.params = ParamStore([('Q_mtx_luma', (8, 8)), ('Q_mtx_chroma', (8, 8))],
+                                     device if device is not None else default_device())
+            init = ops.qtables_device(quality if is_number(quality) else None, 'cpu')
+            self.params.p['Q_mtx_luma'].copy_(init[0])
+            self.params.p['Q_mtx_chroma'].copy_(init[1])
 
     def qtables(self, quality, device):
         key = (quality if is_number(quality) else None, str(device))
@@ -60,8 +68,13 @@ class DifferentiableJPEG(object):
             self._q_cache[key] = ops.qtables_device(key[0], device)
         return self._q_cache[key]
 
+    def trainable_tables(self):
+        """(3,8,8) [Y, Cb, Cr] view of the trainable weights for the kernel (one small gather per forward pass)."""
+        return self.params.flat.view(2, 8, 8)[[0, 1, 1]].contiguous()
+
     def __call__(self, x, quality=None):
-        q = self.qtables(self.quality if quality is None else quality, x.device)
+        q = self.trainable_tables() if (self.trainable and quality is None) else \
+            self.qtables(self.quality if quality is None else quality, x.device)
         y, _, _, xdq = ops.djpeg_fwd(x, q, self.rounding_approximation, want_mask=False, want_xdq=True)
         return y, xdq
 
@@ -72,8 +85,11 @@ class JPEG(TFModel):
         super().__init__(device=device)
         if codec is not None and codec not in ['libjpeg', 'soft', 'sin', 'harmonic']:
             raise ValueError('Unsupported codec version: {}'.format(codec))
-        self._codec_model = None if codec == 'libjpeg' else DifferentiableJPEG(quality, codec, trainable=trainable)
-        self._model = ParamStore([], self.device)        # no trainable parameters
+        self._codec_model = None if codec == 'libjpeg' else DifferentiableJPEG(quality, codec, trainable=trainable,
+                                                                               device=self.device)
+        # no trainable parameters unless trainable=True: then the two quantisation tables (models/jpeg.py:57-62)
+        self._model = self._codec_model.params if (trainable and self._codec_model is not None) else ParamStore([], self.device)
+        self.trainable = bool(trainable)
         self.codec = codec
         self.quality = quality
         self.loss = self._mse
@@ -102,14 +118,20 @@ class JPEG(TFModel):
 
     # forward/backward used by the workflow ----------------------------------------------------------------------
     def forward(self, x, quality=None, training=False, out=None):
-        quality = self.resolve_quality(self.quality if quality is None else quality)
         if self._codec_model is None:
             raise NotImplementedError('the libjpeg codec is CPU validation tooling (out of scope, SURVEY 2 row 10)')
-        q = self._codec_model.qtables(quality, x.device)
+        learned = self.trainable and quality is None        # an explicit quality swaps in that quality's tables (jpeg.py:235-243)
+        if learned:
+            q = self._codec_model.trainable_tables()
+        else:
+            q = self._codec_model.qtables(self.resolve_quality(self.quality if quality is None else quality), x.device)
         y, mask, _, _ = ops.djpeg_fwd(x, q, self.codec, want_mask=training, out=out)
-        return y, ({'x': x, 'mask': mask, 'q': q} if training else None)
+        return y, ({'x': x, 'mask': mask, 'q': q, 'learned': learned} if training else None)
 
-    def backward(self, ctx, dy):
+    def backward(self, ctx, dy, accumulate=False):
+        """d loss / d x; with trainable tables also fills (accumulate: adds to) their gradients in the model's gradient buffer."""
+        if ctx.get('learned'):
+            return ops.djpeg_bwd(ctx['x'], dy, ctx['mask'], ctx['q'], self.codec, dq=self._model.flat_grad, accumulate=accumulate)
         return ops.djpeg_bwd(ctx['x'], dy, ctx['mask'], ctx['q'], self.codec)
 
     def process(self, batch_x, quality=None, return_entropy=False):

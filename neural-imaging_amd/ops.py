@@ -265,12 +265,22 @@ def djpeg_fwd(x, qtab, rounding='soft', want_mask=True, want_idx=False, want_xdq
     return y, mask, idx, xdq
 
 
-def djpeg_bwd(x, gy, mask, qtab, rounding='soft', out=None):
-    _f32(x, gy, qtab)
+def djpeg_bwd(x, gy, mask, qtab, rounding='soft', out=None, dq=None, accumulate=False):
+    """gx = d loss / d x; with dq (a (2,8,8) or 128-element float32 buffer) also the gradient of trainable quantisation
+    tables, [luma, chroma (Cb + Cr)], (+)= when accumulate."""
+    _f32(x, gy, qtab, dq)
     _chk(mask)
     n, h, w, _ = x.shape
     gx = torch.empty_like(x) if out is None else out
-    _lib.call('nimg_djpeg_bwd', _p(x), _p(gy), _p(mask), _p(qtab), _p(gx), n, h, w, ROUNDING[rounding], _stream())
+    if dq is None:
+        _lib.call('nimg_djpeg_bwd', _p(x), _p(gy), _p(mask), _p(qtab), _p(gx), n, h, w, ROUNDING[rounding], _stream())
+        return gx
+    if dq.numel() != 128 or not dq.is_contiguous():
+        raise ValueError('dq: 128 contiguous float32 values (2 x 8 x 8) expected')
+    need = _lib.load().nimg_djpeg_dq_workspace_bytes(n, h, w)
+    ws = _ws.get(need, x.device)
+    _lib.call('nimg_djpeg_bwd_dq', _p(x), _p(gy), _p(mask), _p(qtab), _p(gx), _p(dq), n, h, w, ROUNDING[rounding],
+              1 if accumulate else 0, _p(ws), need, _stream())
     return gx
 
 
@@ -535,8 +545,12 @@ UNPOOL_FOLD = _os.environ.get('NIMG_NO_UNPOOL_FOLD') is None
 
 def unpool_fold_ok(x, g, cin, cout, ks):
     """True when the 5x5 backward kernels can take (pooled gradient, arg-max bytes) instead of the un-pooled gradient."""
-    return UNPOOL_FOLD and COMPUTE == 'bf16' and ks == 5 and _is_bf16(x) and _is_bf16(g) and cin % 16 == 0 and \
-        cout % 64 == 0 and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0
+    # the C side (nimg_conv2d_fwd_bf16_unpool / nimg_conv2d_wgrad_bf16_unpool) needs its buffer-load variants: descriptors
+    # address < 2 GB, the input-gradient pass writes cin channels in 32-wide tiles, NIMG_NO_BUFFER_LOADS leaves them out
+    small = max(x.numel(), g.numel()) * 2 < (1 << 31) - 65536 and 25 * cin * cout * 2 < (1 << 31) - 65536
+    return UNPOOL_FOLD and COMPUTE == 'bf16' and ks == 5 and _is_bf16(x) and _is_bf16(g) and cin % 32 == 0 and \
+        cout % 64 == 0 and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 and small and \
+        _os.environ.get('NIMG_NO_BUFFER_LOADS') is None
 
 
 def conv2d_dgrad_unpool(g, idx, w, act_mask=None, out_bf16=False):
@@ -651,10 +665,15 @@ def add_n(tensors, out=None):
     _f32(*tensors)
     _f32(out)
     n = tensors[0].numel()
-    if not 2 <= len(tensors) <= 6 or any(t.numel() != n for t in tensors) or (n & 3):
-        o = tensors[0] if out is None else out
-        for t in tensors[1:]:
-            o = add(o, t, out=out if out is not None else None)
+    if any(t.numel() != n for t in tensors) or (out is not None and out.numel() != n):
+        raise ValueError('add_n: the tensors differ in size')
+    if len(tensors) == 1:
+        return tensors[0] if out is None else out.copy_(tensors[0])
+    unaligned = any(t.data_ptr() % 16 for t in tensors) or (out is not None and out.data_ptr() % 16)
+    if len(tensors) > 6 or (n & 3) or unaligned:          # pairwise chain (the one-pass kernel moves 16-byte vectors)
+        o = add(tensors[0], tensors[1], out=out)           # starts from tensors[0] whatever `out` holds
+        for t in tensors[2:]:
+            o = add(o, t, out=o)
         return o
     o = torch.empty_like(tensors[0]) if out is None else out
     ptrs = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
@@ -785,9 +804,12 @@ def cconv3(x, w, pad_mode=1, out=None, want_f32=True, want_c4=False):
 FRONT_END = _os.environ.get('NIMG_OLD_FRONTEND') is None
 
 
-def front_end_ok(cin, cout, ks, h, w):
+def front_end_ok(cin, cout, ks, h, w, n=None):
+    """The FAN front-end kernels (csrc/frontend.hip) take this first layer; with `n` also: its backward entry points address
+    their tensors through 32-bit buffer descriptors (the forward chunks the batch, they do not)."""
+    small = n is None or n * h * w * 16 < (1 << 31) - 65536            # pooled gradient (n,h/2,w/2,32) bf16, pixels (n,h,w,4) bf16
     return FRONT_END and COMPUTE == 'bf16' and cin == 3 and cout == 32 and ks == 5 and h % 2 == 0 and w % 2 == 0 and \
-        h >= 4 and w >= 4
+        h >= 4 and w >= 4 and small
 
 
 def conv1_pool_c4(c4, w, bias, act='leaky_relu', want_idx=True, out_bf16=True):

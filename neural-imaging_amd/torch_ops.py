@@ -6,10 +6,17 @@ same entry points to PyTorch itself, so that a caller who composes the channel w
 with autograd formulas:
 
     import neural_imaging_amd.torch_ops                     # registers the ops
-    y = torch.ops.nimg.djpeg(x, qtab, 'soft')               # models/jpeg.py:91-159, differentiable (nimg_djpeg_fwd / _bwd)
-    z = torch.ops.nimg.conv2d(x, w, b, 1, 'leaky_relu')      # Conv2D SAME (+bias, LeakyReLU 0.2): nimg_conv2d_* fwd / dgrad / wgrad
-    c = torch.ops.nimg.cconv3(x, nf, 1)                     # ConstrainedConv2D core (models/layers.py:56-57): nimg_cconv3 (+ _dgrad_border)
-    p, k = torch.ops.nimg.conv_lrelu_pool(x, w, b)           # FAN feature stage (models/forensics.py:69-70): nimg_conv2d_pool_fwd*
+    y = torch.ops.nimg.djpeg(x, qtab, 'soft')               # models/jpeg.py:91-159, DIFFERENTIABLE (nimg_djpeg_fwd / _bwd)
+    z = torch.ops.nimg.conv2d(x, w, b, 1, 'leaky_relu')      # Conv2D SAME (+bias, LeakyReLU 0.2), DIFFERENTIABLE at stride 1:
+                                                            #   nimg_conv2d_* forward / input gradient / weight gradient
+    c = torch.ops.nimg.cconv3(x, nf, 1)                     # ConstrainedConv2D core (models/layers.py:56-57), forward only
+    d = torch.ops.nimg.cconv3_dgrad(dy, nf)                 #   its input gradient as an op of its own (nimg_cconv3 + _dgrad_border)
+    p, k = torch.ops.nimg.conv_lrelu_pool(x, w, b)           # FAN feature stage (models/forensics.py:69-70), forward only
+
+Autograd: `djpeg` and `conv2d` carry Autograd kernels (autograd.Function over the raw ops djpeg_fwd / djpeg_bwd and conv2d_fwd /
+conv2d_dgrad / conv2d_wgrad).  The forward-only ops REFUSE inputs that require grad (NotImplementedError) instead of silently
+cutting the graph; the package's own models run these stages through explicit backward calls (models/layers.py,
+models/forensics.py), not through the dispatcher.
 
 Tensors are contiguous float32 NHWC on the GPU; weights are Keras HWIO.  No CPU implementation is registered: calling an op
 with CPU tensors raises (there is no fallback anywhere in this package).
@@ -27,6 +34,7 @@ def _define():
     lib.define('djpeg_fwd(Tensor x, Tensor qtab, str rounding) -> (Tensor, Tensor)')
     lib.define('djpeg_bwd(Tensor x, Tensor gy, Tensor mask, Tensor qtab, str rounding) -> Tensor')
     lib.define('conv2d(Tensor x, Tensor w, Tensor? bias, int stride, str act) -> Tensor')
+    lib.define('conv2d_fwd(Tensor x, Tensor w, Tensor? bias, int stride, str act) -> Tensor')
     lib.define('conv2d_dgrad(Tensor dz, Tensor w, int h, int w_) -> Tensor')
     lib.define('conv2d_wgrad(Tensor x, Tensor dz, int ks, int stride) -> (Tensor, Tensor)')
     lib.define('cconv3(Tensor x, Tensor w, int pad_mode) -> Tensor')
@@ -89,7 +97,7 @@ class _Conv2D(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, stride, act):
-        y = torch.ops.nimg.conv2d(x, w, bias, stride, act)
+        y = torch.ops.nimg.conv2d_fwd(x, w, bias, stride, act)
         ctx.save_for_backward(x, w, y)
         ctx.stride, ctx.act, ctx.has_bias = stride, act, bias is not None
         return y
@@ -126,6 +134,7 @@ def _register():
     impl.impl('djpeg_fwd', _djpeg_fwd)
     impl.impl('djpeg_bwd', _djpeg_bwd)
     impl.impl('conv2d', _conv2d)
+    impl.impl('conv2d_fwd', _conv2d)
     impl.impl('conv2d_dgrad', _conv2d_dgrad)
     impl.impl('conv2d_wgrad', _conv2d_wgrad)
     impl.impl('cconv3', _cconv3)
@@ -135,6 +144,18 @@ def _register():
     auto = torch.library.Library(_LIB, 'IMPL', 'Autograd')
     auto.impl('djpeg', lambda x, qtab, rounding: _DJpeg.apply(x, qtab, rounding))
     impl.impl('djpeg', lambda x, qtab, rounding: _djpeg_fwd(x, qtab, rounding)[0])
+    auto.impl('conv2d', lambda x, w, bias, stride, act: _Conv2D.apply(x, w, bias, stride, act))
+
+    def forward_only(name):
+        def kernel(*args):
+            if torch.is_grad_enabled() and any(isinstance(a, torch.Tensor) and a.requires_grad for a in args):
+                raise NotImplementedError('torch.ops.nimg.{} is forward-only: no autograd formula is registered (the models of '
+                                          'this package run its backward pass explicitly)'.format(name))
+            with torch._C._AutoDispatchBelowAutograd():
+                return getattr(torch.ops.nimg, name)(*args)
+        return kernel
+    for name in ('cconv3', 'cconv3_dgrad', 'conv_lrelu_pool'):
+        auto.impl(name, forward_only(name))
     return lib, impl, auto
 
 
@@ -142,8 +163,8 @@ _HANDLES = _register()          # keep the Library objects alive: dropping them 
 
 
 def conv2d(x, w, bias=None, stride=1, act=''):
-    """Differentiable Conv2D(SAME) on the library's kernels (autograd.Function over torch.ops.nimg.conv2d*)."""
-    return _Conv2D.apply(x, w, bias, stride, act)
+    """Differentiable Conv2D(SAME) on the library's kernels = torch.ops.nimg.conv2d."""
+    return torch.ops.nimg.conv2d(x, w, bias, stride, act)
 
 
 def djpeg(x, qtab, rounding='soft'):

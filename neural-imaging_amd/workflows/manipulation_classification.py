@@ -294,7 +294,23 @@ class ManipulationClassification(object):
                     ops.nan_flag(self.codec._model.flat_grad, self._nan_flag)
                     self._bucket.launch(self.codec._model.flat_grad)
             else:
-                dc = self.codec.backward(cctx, dC) if train_nip else None
+                dc_direct = None
+                if train_dcn:
+                    # trainable quantisation tables (JPEG(trainable=True), models/jpeg.py:57-62): the codec's loss is Keras'
+                    # MeanSquaredError(c, C) on [0,1] images (models/jpeg.py:197; its NaN "entropy" sample weight is ignored,
+                    # SURVEY 8a quirk 11) = mse255 / 255^2, a MEAN - averaged over ranks like the other terms
+                    lam = float(lambda_dcn) / (255.0 * 255.0)
+                    mse, _ = ops.mse255(C, c, grad_scale=lam, grad_out=dC, accumulate=True)          # d/dC
+                    if train_nip:
+                        dc_direct = torch.empty_like(c)
+                        ops.mse255(c, C, grad_scale=lam, grad_out=dc_direct, accumulate=False)       # d/dc
+                    loss_dcn = (mse, None)
+                dc = self.codec.backward(cctx, dC)           # fills the table gradients when the tables are trainable
+                if dc_direct is not None:
+                    ops.add(dc, dc_direct, out=dc)
+                if train_dcn:
+                    ops.nan_flag(self.codec._model.flat_grad, self._nan_flag)
+                    self._bucket.launch(self.codec._model.flat_grad)
         if train_nip:
             dm = self._downsampling_bwd(dc)
             # d loss / d Y = the native branch's gradient + every manipulation's input gradient, summed in one pass (in place
@@ -341,7 +357,9 @@ class ManipulationClassification(object):
             self.codec._model.adam(learning_rate, self._step, gscale, skip_flag=self._nan_flag, lr_t_dev=rate)
 
         dcn_value = np.nan
-        if loss_dcn is not None:           # codec.loss = l2 + w H, read from the device only when somebody looks at it
+        if loss_dcn is not None and loss_dcn[1] is None:       # JPEG with trainable tables: MeanSquaredError on [0,1] images
+            dcn_value = _LazySum(torch.zeros_like(loss_dcn[0]), loss_dcn[0], 1.0 / (255.0 * 255.0))
+        elif loss_dcn is not None:         # codec.loss = l2 + w H, read from the device only when somebody looks at it
             dcn_value = _LazySum(loss_dcn[0], loss_dcn[1], self.codec._h.entropy_weight)
         loss = _LazyLoss(loss_ce, loss_nip, float(lambda_nip) if 'nip' in self._trainable else 0.0,
                          dcn_value if loss_dcn is not None else None, float(lambda_dcn))

@@ -39,7 +39,7 @@ def apply_manipulation(name, y, s, awgn_noise=None):
 class Workflow(object):
     def __init__(self, manipulations=('sharpen', 'resample', 'gaussian', 'jpeg'), downsampling='none',
                  codec='jpeg', jpeg_quality=80, jpeg_codec='soft', trainable=('nip',), dtype=torch.float64,
-                 unet_seed=1234, fan_seed=4321, dcn_seed=777, nip='UNet', strengths=None):
+                 unet_seed=1234, fan_seed=4321, dcn_seed=777, nip='UNet', strengths=None, jpeg_trainable=False):
         self.dtype = dtype
         self.strengths = dict(DEFAULT_STRENGTHS)
         names = set()
@@ -61,6 +61,11 @@ class Workflow(object):
         self.nip = nets.unet_init(unet_seed, dtype=dtype) if nip == 'UNet' else OrderedDict()
         self.fan = nets.fan_init(self.n_classes, fan_seed, dtype=dtype)
         self.dcn = nets.dcn_init(dcn_seed, dtype=dtype) if codec == 'dcn' else OrderedDict()
+        # JPEG(trainable=True): the quantisation tables are the codec's two weights (models/jpeg.py:57-62), IJG-initialised
+        self.jpeg_tables = OrderedDict()
+        if codec == 'jpeg' and jpeg_trainable:
+            q = djpeg.qtables_torch(jpeg_quality, dtype)
+            self.jpeg_tables = OrderedDict([('Q_mtx_luma', q[0].clone()), ('Q_mtx_chroma', q[1].clone())])
         self._m = self._v = None
         self._t = 0
 
@@ -70,7 +75,7 @@ class Workflow(object):
         if 'nip' in self.trainable:
             ps += list(self.nip.values())
         if 'dcn' in self.trainable:
-            ps += list(self.dcn.values())
+            ps += list(self.dcn.values()) + list(self.jpeg_tables.values())
         return ps
 
     @property
@@ -99,6 +104,9 @@ class Workflow(object):
         return bm
 
     def run_compression(self, bc):
+        if self.codec == 'jpeg' and self.jpeg_tables:
+            ql, qc = self.jpeg_tables['Q_mtx_luma'], self.jpeg_tables['Q_mtx_chroma']
+            return djpeg.djpeg_torch(bc, None, self.jpeg_codec, q=torch.stack([ql, qc, qc]))[0], float('nan')
         if self.codec == 'jpeg':
             return djpeg.djpeg_torch(bc, self.jpeg_quality, self.jpeg_codec)[0], float('nan')
         if self.codec == 'dcn':
@@ -132,6 +140,10 @@ class Workflow(object):
         loss_dcn = None
         if self.codec == 'dcn':
             loss_dcn = nets.dcn_loss(c, C, ent)
+            if 'dcn' in self.trainable:
+                loss = loss + lambda_dcn * loss_dcn
+        if self.jpeg_tables:               # JPEG.loss = Keras MeanSquaredError(c, C) (models/jpeg.py:197; NaN sample weight ignored)
+            loss_dcn = ((c - C) ** 2).mean()
             if 'dcn' in self.trainable:
                 loss = loss + lambda_dcn * loss_dcn
         grads = torch.autograd.grad(loss, params, allow_unused=True)

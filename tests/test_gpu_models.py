@@ -520,6 +520,10 @@ def test_fan_bf16_storage_is_bit_neutral(dev):
     for k in a[3]:
         if k.endswith('/bias') and k.startswith('conv'):      # float32 column sums of the (rounded vs exact) gradient tile
             assert np.allclose(a[3][k], b[3][k], rtol=0, atol=2e-3 * np.abs(b[3][k]).max()), k
+        elif k in ('conv2/kernel', 'conv3/kernel', 'conv4/kernel'):
+            # the bf16-stored path takes the pooled-gradient weight-gradient kernel (csrc/wgrad5.hip), the float32-stored one the
+            # 8-wave kernel on the un-pooled gradient: the same exact bf16 x bf16 products, summed in float32 in another order
+            assert np.allclose(a[3][k], b[3][k], rtol=0, atol=2e-5 * np.abs(b[3][k]).max()), k
         else:
             assert np.array_equal(a[3][k], b[3][k]), k
 
@@ -681,6 +685,45 @@ def test_workflow_training_step_smooth_channel(dev, trainable):
     assert max(np.abs(sd[k] - ref.fan[k].numpy()).max() for k in sd) < 4.5e-4          # <= 2 steps x 2 lr
     expect = float(parts['ce']) + (lam * float(parts['nip']) if 'nip' in trainable else 0)
     assert float(loss) == pytest.approx(expect, rel=1e-5)
+
+
+def test_workflow_with_trainable_jpeg_tables(dev):
+    """The channel with JPEG(trainable=True) as its codec and trainable = {nip, dcn}: the quantisation tables are the codec's
+    weights (models/jpeg.py:57-62), the codec's loss term is lambda_dcn * MeanSquaredError(c, C) (models/jpeg.py:197,
+    workflows/...:275-277) and one shared Adam step moves FAN, NIP and tables.  'sin' codec (continuous), against the oracle."""
+    from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
+    manips = ['resample:50']                  # no hard clip between the NIP and the codec: no kinks for float32 to land on
+    dist = {'downsampling': 'none', 'compression': 'jpeg',
+            'compression_params': {'quality': 70, 'codec': 'sin', 'trainable': True}}
+    wf = ManipulationClassification('UNet', manipulations=manips, distribution=dist, trainable={'nip', 'dcn'}, raw_patch_size=32,
+                                    device=dev)
+    ref = owf.Workflow(manipulations=manips, trainable=('nip', 'dcn'), jpeg_quality=70, jpeg_codec='sin', jpeg_trainable=True)
+    _sync_oracle(wf, ref)
+    rgb = natural_images(2, 64, 64, seed=18)
+    raw = bayer_from_rgb(rgb)
+    lam, lam_dcn = 0.1, 50.0
+    loss_ref, parts_ref, params, grads, _ = ref.loss_and_grads(to64(raw), to64(rgb), lam, lam_dcn)
+    q_before = wf.codec._model.flat.clone()
+    loss, parts = wf.training_step(raw, rgb, lambda_nip=lam, lambda_dcn=lam_dcn, learning_rate=1e-3)
+    assert abs(float(parts['ce']) - parts_ref['ce']) < 1e-3
+    assert abs(float(parts['dcn']) - parts_ref['dcn']) / parts_ref['dcn'] < 1e-3
+    names = list(ref.fan.keys()) + list(ref.nip.keys()) + list(ref.jpeg_tables.keys())
+    got = grads_of(wf.fan)
+    got.update(grads_of(wf.nip))
+    got.update(grads_of(wf.codec))
+    refg = dict(zip(names, grads))
+    # four FAN images only: the float32 noise of the bias / 3-channel filter sums (5e-3 on the 8-image channel tests) is 1 - 2 %
+    check_grads(got, refg, list(ref.fan.keys()) + list(ref.nip.keys()), tol=2.5e-2)
+    # a table entry's gradient is a sum over every block of terms z cos(2 pi z) - sin(2 pi z) / (2 pi) with z = X / Q up to ~100:
+    # signs alternate and the sum is small against its terms, so it is held to 2 % of the largest entry plus the direction
+    # (tests/test_gpu_ops.py::test_djpeg_trainable_tables pins the kernel itself at 3e-4 on given gradients)
+    for k in ref.jpeg_tables:
+        a, b = got[k].ravel().astype(np.float64), refg[k].numpy().ravel()
+        assert np.abs(a - b).max() <= 2e-2 * np.abs(b).max(), (k, np.abs(a - b).max() / np.abs(b).max())
+        assert float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b))) > 0.999, k
+    moved = (wf.codec._model.flat - q_before).abs()
+    assert float(moved.max()) <= 1.001e-3 and float(moved.mean()) > 5e-4          # Adam's first step: +-lr per entry
+    assert float(loss) == pytest.approx(float(parts['ce']) + lam * float(parts['nip']) + lam_dcn * float(parts['dcn']), rel=1e-5)
 
 
 def test_workflow_training_step_default_channel(dev):

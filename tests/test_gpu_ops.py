@@ -83,6 +83,44 @@ def test_djpeg_modes_fwd_bwd(dev, mode):
     assert_close(gx.cpu().numpy(), gn, 1e-5, GRTOL * 3, what='djpeg bwd ' + mode)
 
 
+@pytest.mark.parametrize('mode', ['soft', 'sin', 'harmonic'])
+def test_djpeg_trainable_tables(dev, mode):
+    """DifferentiableJPEG(trainable=True) (models/jpeg.py:57-62): the two (8,8) weights Q_mtx_luma / Q_mtx_chroma feed the kernel
+    ([Y, Cb, Cr] = [luma, chroma, chroma], :125-128) and receive their gradient through X / Q -> quant -> * Q (:129-131) from
+    nimg_djpeg_bwd_dq; oracle = autograd of oracle/djpeg.py in float64 with the tables as leaves.  Also the explicit-quality
+    swap (a numeric quality passed to forward uses that quality's constant tables, :235-243) and accumulation."""
+    from neural_imaging_amd.models import jpeg as mj
+    x = natural_images(3, 32, 48, seed=21)
+    gy = rnd(x.shape, 22)
+    rng = np.random.default_rng(23)
+    ql = (ot.jpeg_qtable(60, 0) * rng.uniform(0.7, 1.3, (8, 8))).astype(np.float32)       # non-integer: they are weights now
+    qc = (ot.jpeg_qtable(60, 1) * rng.uniform(0.7, 1.3, (8, 8))).astype(np.float32)
+    tl, tc = to64(ql).requires_grad_(True), to64(qc).requires_grad_(True)
+    xt = to64(x).requires_grad_(True)
+    y_ref, _, _ = odj.djpeg_torch(xt, mode=mode, q=torch.stack([tl, tc, tc]))
+    (y_ref * to64(gy)).sum().backward()
+    codec = mj.JPEG(quality=60, codec=mode, trainable=True, device=dev)
+    assert codec.parameter_names == ['Q_mtx_luma', 'Q_mtx_chroma'] and codec.count_parameters() == 128
+    assert np.array_equal(codec.state_dict()['Q_mtx_chroma'], ot.jpeg_qtable(60, 1).astype(np.float32))     # initialiser
+    codec.load_state_dict({'Q_mtx_luma': ql, 'Q_mtx_chroma': qc})
+    y, ctx = codec.forward(g(x, dev), training=True)
+    assert_close(y.cpu().numpy(), y_ref.detach().numpy(), ATOL, what='fwd with trained tables')
+    gx = codec.backward(ctx, g(gy, dev))
+    assert_close(gx.cpu().numpy(), xt.grad.numpy(), 1e-5, GRTOL * 3, what='d/dx')
+    dq = codec._model.flat_grad.view(2, 8, 8).cpu().numpy()
+    assert_close(dq[0], tl.grad.numpy(), 1e-6, GRTOL * 3, what='d/dQ luma')
+    assert_close(dq[1], tc.grad.numpy(), 1e-6, GRTOL * 3, what='d/dQ chroma')
+    codec.backward(ctx, g(gy, dev), accumulate=True)
+    assert_close(codec._model.flat_grad.view(2, 8, 8).cpu().numpy(), 2 * dq, 1e-6, 1e-5, what='accumulate')
+    # an explicit quality bypasses the weights (and leaves their gradients alone)
+    y80, ctx80 = codec.forward(g(x, dev), quality=80, training=True)
+    plain = mj.JPEG(quality=80, codec=mode, device=dev)
+    assert torch.equal(y80, plain.forward(g(x, dev))[0])
+    before = codec._model.flat_grad.clone()
+    codec.backward(ctx80, g(gy, dev))
+    assert torch.equal(before, codec._model.flat_grad)
+
+
 def test_djpeg_properties_full_size(dev):
     """BASELINE size (batch of 256x256): size-independent properties instead of the (slow) oracle."""
     from neural_imaging_amd import ops
@@ -1102,3 +1140,13 @@ def test_torch_library_custom_ops(dev):
     assert_close(b.grad.cpu().numpy(), bt.grad.numpy(), 1e-4, GRTOL, what='custom-op conv d bias')
     with pytest.raises(NotImplementedError):
         torch.ops.nimg.cconv3(torch.zeros(1, 8, 8, 3), torch.zeros(5, 5, 3, 3), 1)        # no CPU kernel is registered
+    # the dispatcher op itself is differentiable: same gradients as the Python front door above
+    a2, w2 = a.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)
+    torch.ops.nimg.conv2d(a2, w2, b.detach(), 1, 'leaky_relu').backward(gz)
+    assert torch.equal(a2.grad, a.grad) and torch.equal(w2.grad, w.grad)
+    # forward-only ops refuse inputs that require grad instead of silently cutting the graph; without grad they run
+    img = g(natural_images(1, 16, 16, seed=9), dev)
+    nf = g(rnd((5, 5, 3, 3), 8, -0.1, 0.1), dev)
+    assert torch.ops.nimg.cconv3(img, nf, 1).shape == (1, 16, 16, 3)
+    with pytest.raises(NotImplementedError):
+        torch.ops.nimg.cconv3(img.clone().requires_grad_(True), nf, 1)
