@@ -399,6 +399,7 @@ def main():
     ap.add_argument('--parity-steps', type=int, default=600,
                     help='joint training steps of the trained-parity leg (0 = skip); the NIP is pre-trained for 2.5 x as many '
                          'steps first and each mode trains a quarter as many more from the checkpoint')
+    ap.add_argument('--no-side-workloads', action='store_true', help='skip the short c3 / c5 runs of the default c4 line')
     ap.add_argument('--no-graph', dest='graph', action='store_false',
                     help='launch every kernel of the timed steps eagerly (default at N = 1: the step is captured once into a HIP '
                          'graph and replayed - same kernels, same order, one launch call per step)')
@@ -553,6 +554,28 @@ def main():
                     line['parity_tail_isp_psnr_delta_db'] = par['after_tail']['isp_psnr_delta_db']
                 cfg['mode_parity_after_training'] = par
                 _ops.set_compute(args.dtype)
+        if world == 1 and args.dtype == 'bf16' and wl.key == 'c4' and not args.no_parity_mode and not args.no_side_workloads:
+            # configs 3 and 5 of BASELINE.json on the same line (flat scalars: the driver's parser keeps those): 30 timed steps each
+            for key in ('c3', 'c5'):
+                try:
+                    a2 = argparse.Namespace(**dict(vars(args), workload=key, batch=0))
+                    w2 = WORKLOADS[key](a2)
+                    step2 = w2.build(dev, rank)
+                    for _ in range(5):
+                        step2()
+                    torch.cuda.synchronize()
+                    t2 = time.perf_counter()
+                    for _ in range(30):
+                        step2()
+                    torch.cuda.synchronize()
+                    dt2 = (time.perf_counter() - t2) / 30
+                    w2.finish()
+                    line[key + '_patches_per_s'] = w2.batch / dt2
+                    line[key + '_ms_per_step'] = 1e3 * dt2
+                    line[key + '_tflops'] = w2.batch / dt2 * w2.gflop_per_unit / 1e3
+                    del w2, step2
+                except Exception as e:                       # a side figure must never take the headline line down
+                    line[key + '_error'] = repr(e)[:200]
         if not args.no_cpu_baseline and world == 1:
             line['cpu_baseline'] = cpu_baseline(wl.key, args.raw_patch)
         print(json.dumps(line))

@@ -16,6 +16,9 @@
 // defined in wgrad5.hip: slabs written (0 = not its shape, -1 = launch error)
 int nimg_internal_wgrad5_alltaps(const void* in, int cin, const void* g, const unsigned char* idx, int cout, float* partial,
                                  float* db_partial, int n, int h, int wd, int max_slabs, hipStream_t stream);
+// defined in wgrad3.hip: same contract for the UNet's 3x3 layers (bf16 input(s) and output gradient)
+int nimg_internal_wgrad3_alltaps(const void* in1, int c1, const void* in2, int c2, const void* dz, int cout, float* partial,
+                                 float* db_partial, int n, int h, int wd, int max_slabs, hipStream_t stream);
 // defined in conv_small.hip
 size_t nimg_internal_wgrad_tiny_bytes(int ks, int cin, int cout);
 int nimg_internal_conv_wgrad_tiny(const float* in, const float* dz, float* dw, int cin, int cout, int n, int h, int wd,
@@ -781,7 +784,10 @@ int dispatch_b_t(const ConvParamsB& p, hipStream_t s) {
     const bool small = (p.Hout <= 8 && p.Wout <= 8);
     const long blocks64 = (long)cdiv(Cout, 64) * cdiv(p.Hout, small ? 8 : 16) * cdiv(p.Wout, small ? 8 : 16) *
                           cdiv(p.N, small ? 4 : 1);
-    const bool tn32 = (Cout <= 32) || (blocks64 < 512 && Cout % 64 != 0) || (blocks64 < 384);
+    // few workgroups = few co-resident ones per CU to cover each other's staging latency: below the threshold the 32-channel
+    // tile (twice the workgroups) wins (NIMG_TN32_BELOW overrides it for A/B runs)
+    static const long tn32_below = getenv("NIMG_TN32_BELOW") ? atol(getenv("NIMG_TN32_BELOW")) : 384;
+    const bool tn32 = (Cout <= 32) || (blocks64 < 512 && Cout % 64 != 0) || (blocks64 < tn32_below);
     if (small)
         return tn32 ? launch_conv_b<KS, STRIDE, 8, 8, 4, 32, INB>(p, s) : launch_conv_b<KS, STRIDE, 8, 8, 4, 64, INB>(p, s);
     // narrow outputs (Cout <= 32) of big images: a 32x16-pixel tile keeps 64 accumulator registers per wave (4 x 1
@@ -1290,6 +1296,19 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
         const int max_slabs = splits_for(cin, cout, n, hout, wout);
         float* dbp = db ? (float*)workspace + (size_t)max_slabs * count : nullptr;
         const int slabs = nimg_internal_wgrad5_alltaps(in1, cin, dz, dz_idx, cout, (float*)workspace, dbp, n, h, wd, max_slabs, s);
+        if (slabs < 0) return NIMG_ERR_LAUNCH;
+        if (slabs > 0) {
+            launch_reduce2((const float*)workspace, dw, count, slabs, dbp, db, (long)cout, slabs, accumulate, s);
+            NIMG_CHECK_LAUNCH();
+            return NIMG_OK;
+        }
+    }
+    if (!dz_idx && ks == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && hout == h && wout == wd && pad_mode == 0 &&
+        flags == (NIMG_BF16_IN | NIMG_BF16_DZ)) {
+        // the UNet's 3x3 layers with bf16-stored tensors: all 9 taps in one wave, double-buffered tiles (wgrad3.hip)
+        const int max_slabs = splits_for(cin, cout, n, hout, wout);
+        float* dbp = db ? (float*)workspace + (size_t)max_slabs * count : nullptr;
+        const int slabs = nimg_internal_wgrad3_alltaps(in1, c1, in2, c2, dz, cout, (float*)workspace, dbp, n, h, wd, max_slabs, s);
         if (slabs < 0) return NIMG_ERR_LAUNCH;
         if (slabs > 0) {
             launch_reduce2((const float*)workspace, dw, count, slabs, dbp, db, (long)cout, slabs, accumulate, s);

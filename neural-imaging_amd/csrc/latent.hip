@@ -8,6 +8,8 @@
 // The entropy is a BATCH-GLOBAL statistic: forward accumulates the soft histogram in per-workgroup float64 partials, a
 // finalise kernel reduces them in a fixed order (deterministic), computes H and dH/dhist; the backward kernel needs only
 // those 2^bpf numbers.  Under data parallelism the partial histograms are what gets all-reduced.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -360,6 +362,12 @@ size_t nimg_latent_workspace_bytes(int codebook_size) {
     return (size_t)(1024 * (size_t)codebook_size + 2 * (size_t)codebook_size + 1024) * sizeof(double);
 }
 
+/* diagnostic switch: NIMG_LATENT_GENERIC_POW=1 nudges v off the integers, which sends the kernels down the generic pow() path */
+static double kernel_v(float v) {
+    static const bool generic = getenv("NIMG_LATENT_GENERIC_POW") != nullptr;
+    return generic ? (double)v + 1e-9 : (double)v;
+}
+
 int nimg_latent_fwd(const float* z, const float* scale, const float* codebook, int codebook_size, float v,
                     float gamma, int soft_codebook, float* latent, float* entropy, long count, long count_global,
                     void* workspace, size_t workspace_bytes, int finalize, void* stream) {
@@ -371,7 +379,7 @@ int nimg_latent_fwd(const float* z, const float* scale, const float* codebook, i
     double* part = (double*)workspace;
     double* hsum = part + 1024 * (size_t)K;
     double* dH = hsum + K;
-    hipLaunchKernelGGL(soft_codebook_fwd_kernel, dim3(grid), dim3(256), 0, s, z, scale, codebook, K, (double)v,
+    hipLaunchKernelGGL(soft_codebook_fwd_kernel, dim3(grid), dim3(256), 0, s, z, scale, codebook, K, kernel_v(v),
                        (double)gamma, latent, part, count, soft_codebook);
     NIMG_CHECK_LAUNCH();
     hipLaunchKernelGGL(hist_reduce_kernel, dim3(1), dim3(1024), 0, s, (const double*)part, grid, K, hsum);
@@ -408,7 +416,7 @@ int nimg_latent_bwd(const float* z, const float* scale, const float* latent, con
     double* dH = part + 1024 * (size_t)K + K;
     double* dsp = dH + K;
     hipLaunchKernelGGL(soft_codebook_bwd_kernel, dim3(grid), dim3(256), 0, s, z, scale, latent, dlatent,
-                       (const double*)dH, entropy_coef, codebook, K, (double)v, (double)gamma, dz, dsp, count,
+                       (const double*)dH, entropy_coef, codebook, K, kernel_v(v), (double)gamma, dz, dsp, count,
                        soft_codebook);
     NIMG_CHECK_LAUNCH();
     if (dscale) {

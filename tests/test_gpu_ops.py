@@ -848,6 +848,29 @@ def test_wgrad5_alltaps_vs_oracle(dev, bf16_mode, shape):
     assert_close(db.cpu().numpy(), dz_np.astype(np.float64).sum(axis=(0, 1, 2)), 0.0, 2e-5, what='bias grad')
 
 
+@pytest.mark.parametrize('shape', [(3, 128, 128, 32, 0, 32), (2, 128, 128, 32, 32, 32), (3, 64, 64, 32, 0, 64),
+                                   (3, 64, 64, 64, 64, 64), (5, 32, 32, 128, 128, 128), (7, 16, 16, 256, 0, 256),
+                                   (2, 24, 32, 64, 0, 32), (1, 8, 16, 32, 0, 128), (3, 16, 16, 512, 0, 256)])
+def test_wgrad3_alltaps_vs_oracle(dev, bf16_mode, shape):
+    """csrc/wgrad3.hip (all 9 taps in one wave, v_mfma_f32_16x16x32_bf16, double-buffered tiles with two tiles of loads in
+    flight, row groups folded through LDS): weight and bias gradient of the UNet's 3x3 layers from bf16-stored tensors at its
+    layer shapes - level 1 (Cout 32, 16-row tiles, four row groups), the two-tensor decoder inputs, levels 2 - 4, an image the
+    16-row tiles do not divide, a single-tile image - against the float64 oracle on the same rounded values."""
+    from neural_imaging_amd import ops
+    n, h, w, c1, c2, cout = shape
+    x1 = _bf16_round(rnd((n, h, w, c1), 31)).numpy().astype(np.float32)
+    x2 = _bf16_round(rnd((n, h, w, c2), 32)).numpy().astype(np.float32) if c2 else None
+    dz = _bf16_round(rnd((n, h, w, cout), 33)).numpy().astype(np.float32)
+    xin = np.concatenate([x1, x2], axis=-1) if c2 else x1
+    wt = to64(np.zeros((3, 3, c1 + c2, cout))).requires_grad_(True)
+    (T.conv2d(to64(xin), wt, None, 1, 'SAME') * to64(dz)).sum().backward()
+    bf = torch.bfloat16
+    dw, db = torch.full((3, 3, c1 + c2, cout), 7.0, device=dev), torch.full((cout,), 7.0, device=dev)
+    ops.conv2d_wgrad(g(x1, dev).to(bf), g(dz, dev).to(bf), 3, x2=g(x2, dev).to(bf) if c2 else None, dw=dw, db=db)
+    assert_close(dw.cpu().numpy(), wt.grad.numpy(), 0.0, 2e-5, what='wgrad')
+    assert_close(db.cpu().numpy(), dz.astype(np.float64).sum(axis=(0, 1, 2)), 0.0, 2e-5, what='bias grad')
+
+
 def test_bf16_stored_unet_ops(dev, bf16_mode):
     """The throughput-mode entry points on bf16-STORED tensors (UNet activations / gradients): two-tensor inputs and outputs,
     the 2x2 / stride-2 forms behind Conv2DTranspose, max-pool forward / backward, the bias gradient, the 4-channel first
