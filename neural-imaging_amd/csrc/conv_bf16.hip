@@ -347,10 +347,14 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
         }
         __syncthreads();
         if (ci0 + CK < Cin) fetch(ci0 + CK);
-#pragma unroll 1
+        // one kernel row unrolled: the next taps' ds_reads overlap the MFMAs.  The 32-channel tiles of the small kernels (the
+        // UNet's deep and narrow layers: one or two workgroups per CU, nobody else to cover an LDS round trip) unroll ALL
+        // taps - one exposed read latency per chunk instead of one per kernel row: ec42 / ec52 / dc11 -9 ... -13 %; the 64-channel
+        // tiles lose 2 - 3 % with it (profiles/r03_m_conv3_unroll_ab.txt)
+#pragma unroll(KS <= 3 && TN == 32 ? KS : 1)
         for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
-        for (int kx = 0; kx < KS; ++kx) {            // one kernel row unrolled: the next taps' ds_reads overlap the MFMAs
+        for (int kx = 0; kx < KS; ++kx) {
             const int tap = ky * KS + kx;
             const int toff = PLANAR ? ky * 32 + kx : ky * TWH + kx;
 #pragma unroll
