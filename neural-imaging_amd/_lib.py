@@ -157,6 +157,11 @@ def load():
     if not os.path.isfile(LIB_PATH):
         raise RuntimeError('libnimg.so not found at {} - build it with neural-imaging_amd/csrc/build.sh '
                            '(or __graft_entry__.build()); there is no CPU fallback'.format(LIB_PATH))
+    # torch first: its wheel carries its own copy of the HIP runtime, and libnimg.so must bind to THAT instance (the streams and
+    # device pointers it is handed come from it).  Loaded before torch, libnimg.so pulls in /opt/rocm's libamdhip64 as a second
+    # runtime and every launch on a torch stream fails (seen as NIMG_ERR_LAUNCH from `python __graft_entry__.py smoke`, whose
+    # build() loaded the library before anything had imported torch).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError here == ABI drift; let it propagate

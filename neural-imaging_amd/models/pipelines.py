@@ -146,8 +146,11 @@ class UNet(NIPModel):
     def _store_bf16(x):
         """Throughput mode keeps the UNet's internal activations and gradients in HBM as bf16 (like the FAN's): every consumer
         is a kernel that rounds them to bf16 MFMA operands, takes their sign (LeakyReLU') or their maximum (rounding is
-        monotonic), so the forward pass is bit-neutral and the level-1 / level-2 layers - HBM-bound at float32 - move half the
-        bytes.  The RAW input, the 12-channel output of the last convolution and the gradient that feeds the 4-channel
+        monotonic), so the FORWARD pass is bit-neutral and the level-1 / level-2 layers - HBM-bound at float32 - move half the
+        bytes.  The BACKWARD pass is not bit-neutral: the skip gradients are rounded to bf16 before they are accumulated, and
+        maxpool2_bwd_bf16 routes to the first maximum of the ROUNDED activations - rounding creates ties that float32 does not
+        have, so a few gradients take another window position than in the float32-stored path (and than tf's max-pool gradient);
+        per-parameter cosine > 0.995 against the float32-stored run (tests/test_gpu_models.py::test_unet_bf16_storage).  The RAW input, the 12-channel output of the last convolution and the gradient that feeds the 4-channel
         weight-gradient kernel stay float32.  (forward() also asks for even sizes at every pooled level.)"""
         return ops.COMPUTE == 'bf16' and ops.STORE_BF16 and x.is_cuda
 
