@@ -213,6 +213,13 @@ int nimg_gaussian_fwd(const float* x, float* y, uint8_t* mask, const float* gk25
                       void* stream);
 int nimg_gaussian_bwd(const float* dy, const uint8_t* mask, float* dx, const float* gk25, int n, int h, int w,
                       void* stream);
+/* any odd k x k (k <= 31) per-channel filter with a mirrored border (pad_mode 1 SYMMETRIC, 2 REFLECT) and an optional hard
+ * clip: manipulation_gaussian with kernel != 5 (:113-125, REFLECT), manipulation_sharpen(hsv=False) (:156-184, SYMMETRIC),
+ * residual(hsv=False) (:127-154, REFLECT, clip 0).  taps = k*k floats (device), mask as nimg_gaussian_fwd (may be NULL). */
+int nimg_dwfilter_fwd(const float* x, float* y, uint8_t* mask, const float* taps, int k, int pad_mode, int n, int h, int w,
+                      int clip, void* stream);
+int nimg_dwfilter_bwd(const float* dy, const uint8_t* mask, float* dx, const float* taps, int k, int pad_mode, int n, int h,
+                      int w, void* stream);
 /* manipulation_sharpen(hsv=True) :156-184 - gk9 = 3x3 H/V filter (device); aux_hsv (n,h,w,3) scratch kept between
  * forward and backward (filtered HSV; overwritten by the backward) */
 int nimg_sharpen_fwd(const float* x, float* y, float* aux_hsv, uint8_t* mask, const float* gk9, int n, int h, int w,

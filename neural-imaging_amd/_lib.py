@@ -58,6 +58,8 @@ PROTOTYPES = {
     'nimg_fold_pad': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'nimg_gaussian_fwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'nimg_gaussian_bwd': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    'nimg_dwfilter_fwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    'nimg_dwfilter_bwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'nimg_sharpen_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
     'nimg_sharpen_bwd': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, P]),
     'nimg_affine': (c_int, [P, P, c_long, c_float, c_float, P]),

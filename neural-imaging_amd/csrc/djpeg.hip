@@ -13,6 +13,7 @@
 //   every dot product is an fmaf chain in ascending index order starting from the first product;
 //   row pass first (T = b * F^T), column pass second (X = F * T); IDCT column pass first, row pass second.
 //   Compiled with -ffp-contract=off so the explicit fmaf()s are the only fused operations.
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -25,6 +26,13 @@ constexpr int STAGE_F = 8 * ROW_STRIDE;   // staging floats per wave
 constexpr int TILE_F = 3 * 8 * 72;        // transpose tiles: [ch][block][8][9]
 constexpr int WAVE_LDS_F = (STAGE_F > TILE_F ? STAGE_F : TILE_F);
 constexpr int WAVES_PER_BLOCK = 4;
+// workgroups per CU the register allocation aims at (LDS holds 5): A/B builds override these (csrc/Makefile EXTRA=)
+#ifndef DJ_FWD_WGS
+#define DJ_FWD_WGS 4
+#endif
+#ifndef DJ_BWD_WGS
+#define DJ_BWD_WGS 3
+#endif
 
 // Every LDS region of these kernels (staging rows, transpose tiles) is PRIVATE to one wave, and a wave's LDS operations
 // complete in issue order: what has to be prevented is only the compiler moving reads above writes.  A workgroup barrier here
@@ -86,20 +94,26 @@ __device__ __forceinline__ Task decode_task(long task, long n_tasks, int hb, int
     return t;
 }
 
-// global (8 rows x up to 64 px x 3 ch) -> LDS staging rows, float4 granularity (w % 8 == 0 => 24-float = 96-byte
-// block granules, always 16-byte aligned)
-__device__ __forceinline__ void load_strip(const float* __restrict__ src, float* lds, const Task& t, int h, int w,
-                                           int lane) {
+// One strip of a task, global <-> registers: 8 rows x up to 64 px x 3 ch as 6 float4 per lane (w % 8 == 0 => 24-float = 96-byte
+// block granules, always 16-byte aligned); item it * 64 + lane = (row, float4 column) of the strip.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void fetch_strip(const float* __restrict__ src, f32x4 (&pre)[6], const Task& t, int h, int w,
+                                            int lane) {
     const int strip_f = min(STRIP_PX, w - t.x0) * 3;      // valid floats per row
 #pragma unroll
     for (int it = 0; it < 6; ++it) {
         const int idx = it * 64 + lane;                   // 0..383 float4 slots
         const int row = idx / 48, c4 = idx % 48;
-        if (t.valid && c4 * 4 < strip_f) {
-            const float4 v = *reinterpret_cast<const float4*>(
-                src + (((long)t.n * h + t.by * 8 + row) * w + t.x0) * 3 + c4 * 4);
-            *reinterpret_cast<float4*>(lds + row * ROW_STRIDE + c4 * 4) = v;
-        }
+        if (t.valid && c4 * 4 < strip_f)
+            pre[it] = *reinterpret_cast<const f32x4*>(src + (((long)t.n * h + t.by * 8 + row) * w + t.x0) * 3 + c4 * 4);
+    }
+}
+// registers -> LDS staging rows (every slot is written: lanes beyond a ragged strip stage stale values nobody reads back)
+__device__ __forceinline__ void commit_strip(float* lds, const f32x4 (&pre)[6], int lane) {
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+        const int idx = it * 64 + lane;
+        *reinterpret_cast<f32x4*>(lds + (idx / 48) * ROW_STRIDE + (idx % 48) * 4) = pre[it];
     }
 }
 
@@ -147,34 +161,46 @@ __device__ __forceinline__ void transpose24(float* tile, int b, int r, float (&v
     wave_sync();
 }
 
-__device__ __forceinline__ float quantise(float u, int rounding) {
-    switch (rounding) {
-        case NIMG_ROUND_ROUND:
-        case NIMG_ROUND_SOFT:
-            return rintf(u);                                   // half-to-even == tf.round
-        case NIMG_ROUND_SIN:
-            return u - sinpif(2.0f * (u - rintf(u))) * 0.15915494309189535f;   // sin(2 pi u)/(2 pi), periodic
-        case NIMG_ROUND_HARMONIC:
-            return u - sinpif(2.0f * (u - rintf(u))) * 0.3183098861837907f;    // sin(2 pi u)/pi
-        default:
-            return u;
+// Rounding approximations (models/jpeg.py:40-52 / 133-149).  QMODE of the forward: ROUND and SOFT both round to nearest.
+enum { Q_RINT = 0, Q_SIN = 1, Q_HARMONIC = 2, Q_IDENTITY = 3 };
+__host__ __device__ constexpr int fwd_mode(int rounding) {
+    return rounding == NIMG_ROUND_SIN ? Q_SIN : rounding == NIMG_ROUND_HARMONIC ? Q_HARMONIC
+         : rounding == NIMG_ROUND_IDENTITY ? Q_IDENTITY : Q_RINT;
+}
+template <int QMODE>
+__device__ __forceinline__ float quantise(float u) {
+    if constexpr (QMODE == Q_RINT) return rintf(u);                                     // half-to-even == tf.round
+    else if constexpr (QMODE == Q_SIN) return u - sinpif(2.0f * (u - rintf(u))) * 0.15915494309189535f;   // sin(2 pi u)/(2 pi)
+    else if constexpr (QMODE == Q_HARMONIC) return u - sinpif(2.0f * (u - rintf(u))) * 0.3183098861837907f;   // sin(2 pi u)/pi
+    else return u;
+}
+// gradient modes of the backward: ROUND has none, SOFT and SIN share 1 - cos(2 pi u)
+enum { G_ZERO = 0, G_SOFT = 1, G_HARMONIC = 2, G_ONE = 3 };
+__host__ __device__ constexpr int bwd_mode(int rounding) {
+    return rounding == NIMG_ROUND_ROUND ? G_ZERO : rounding == NIMG_ROUND_HARMONIC ? G_HARMONIC
+         : rounding == NIMG_ROUND_IDENTITY ? G_ONE : G_SOFT;
+}
+template <int GMODE>
+__device__ __forceinline__ float quantise_grad(float u) {
+    if constexpr (GMODE == G_ZERO) return 0.0f;
+    else if constexpr (GMODE == G_ONE) return 1.0f;
+    else {
+        const float c = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(u));   // v_cos_f32 takes revolutions
+        return GMODE == G_SOFT ? 1.0f - c : 1.0f - 2.0f * c;
     }
 }
 
-__device__ __forceinline__ float quantise_grad(float u, int rounding) {
-    // v_cos_f32 takes revolutions: cos(2 pi u) = amdgcn_cos(fract(u))
-    const float c = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(u));
-    switch (rounding) {
-        case NIMG_ROUND_SOFT:
-        case NIMG_ROUND_SIN:
-            return 1.0f - c;
-        case NIMG_ROUND_HARMONIC:
-            return 1.0f - 2.0f * c;
-        case NIMG_ROUND_IDENTITY:
-            return 1.0f;
-        default:
-            return 0.0f;
-    }
+// x / q.  EXACT = IEEE division.  Otherwise Markstein's correction of x * rc with rc = RN(1 / q): y0 = RN(x rc), r = RN(x - q y0)
+// (exact in an fma), y = RN(y0 + r rc) - equal to RN(x / q) for every float x (no underflow) and every INTEGER q in 1 .. 255,
+// which is checked exhaustively on the CPU (tools/probe/div_markstein_check.c: 255 divisors x 2^23 mantissas, the identity is
+// invariant under scaling x by powers of two); 3 VALU instructions instead of hipcc's 11-instruction division.  x = -0 gives
+// +0 (IEEE: -0): invisible in the indices, the image and the mask.  A table with any other entry takes the EXACT path.
+template <bool EXACT>
+__device__ __forceinline__ float div_q(float x, float q, float rc) {
+    if constexpr (EXACT) return x / q;
+    const float y0 = x * rc;
+    const float r = __builtin_fmaf(-y0, q, x);
+    return __builtin_fmaf(r, rc, y0);
 }
 
 // rgb (x255) -> ycbcr - 127, for the 8 pixels of this lane's row; out[c][j]
@@ -193,51 +219,95 @@ __device__ __forceinline__ void colour_fwd(const float (&px)[24], float (&ycc)[3
     }
 }
 
-__global__ __launch_bounds__(256) void djpeg_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+// The quantisation tables of a workgroup in LDS, transposed to [c][r][u] so that lane (b, r) reads the 8 entries of its column
+// with two 16-byte reads (8 distinct addresses per wave), next to their reciprocals; returns whether every entry is an integer
+// in 1 .. 255 (the IJG tables: always; trainable tables: not after the first update), i.e. whether div_q<false> is exact.
+__device__ __forceinline__ bool stage_tables(const float* __restrict__ qtab, float* qT, int* flag) {
+    const int tid = threadIdx.x;
+    if (tid == 0) *flag = 1;
+    __syncthreads();
+    if (tid < 192) {
+        const float q = qtab[tid];
+        const int c = tid >> 6, u = (tid >> 3) & 7, r = tid & 7;
+        qT[(c * 8 + r) * 8 + u] = q;
+        qT[192 + (c * 8 + r) * 8 + u] = 1.0f / q;
+        if (!(q >= 1.0f && q <= 255.0f && q == rintf(q))) *flag = 0;
+    }
+    __syncthreads();
+    return __builtin_amdgcn_readfirstlane(*flag) != 0;
+}
+__device__ __forceinline__ void read_tables(const float* qT, int c, int r, float (&q)[8], float (&rc)[8]) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float4 a = *reinterpret_cast<const float4*>(qT + (c * 8 + r) * 8 + 4 * k);
+        const float4 b = *reinterpret_cast<const float4*>(qT + 192 + (c * 8 + r) * 8 + 4 * k);
+        q[4 * k] = a.x; q[4 * k + 1] = a.y; q[4 * k + 2] = a.z; q[4 * k + 3] = a.w;
+        rc[4 * k] = b.x; rc[4 * k + 1] = b.y; rc[4 * k + 2] = b.z; rc[4 * k + 3] = b.w;
+    }
+}
+
+// column pass, quantisation, inverse column pass of one wave task (v: T columns in, S columns out)
+template <int QMODE, bool EXACT>
+__device__ __forceinline__ void quantise_columns(float (&v)[3][8], const float* qT, const Task& t, int b, int r, int hb, int wb,
+                                                 int16_t* __restrict__ idx, float* __restrict__ xdq) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float X[8], q[8], rc[8];
+        dct_fwd8(v[c], X);                                       // X[u][col r] = sum_i F[u][i] T[i][r]
+        read_tables(qT, c, r, q, rc);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float qi = quantise<QMODE>(div_q<EXACT>(X[u], q[u], rc[u]));
+            X[u] = qi * q[u];
+            if (idx || xdq) {
+                const long o = ((((long)t.n * 3 + c) * hb + t.by) * wb + (t.x0 / 8 + b)) * 64 + u * 8 + r;
+                if (idx) idx[o] = (int16_t)qi;
+                if (xdq) xdq[o] = X[u];
+            }
+        }
+        dct_inv8(X, v[c]);                                       // S[i][col r] = sum_u F[u][i] Xd[u][r]
+    }
+}
+
+// One task per wave; the 5 workgroups a CU holds (LDS) overlap one wave's memory round trip with the others' arithmetic.
+template <int QMODE>
+__global__ __launch_bounds__(256, DJ_FWD_WGS) void djpeg_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                         const float* __restrict__ qtab, uint8_t* __restrict__ mask,
                                                         int16_t* __restrict__ idx, float* __restrict__ xdq, int n,
-                                                        int h, int w, int rounding) {
+                                                        int h, int w) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = lane >> 3, r = lane & 7;
     float* lds = smem + wave * WAVE_LDS_F;
+    float* qT = smem + WAVES_PER_BLOCK * WAVE_LDS_F;
     const int hb = h / 8, wb = w / 8, strips = (w + STRIP_PX - 1) / STRIP_PX;
     const long n_tasks = (long)n * hb * strips;
     const Task t = decode_task((long)blockIdx.x * WAVES_PER_BLOCK + wave, n_tasks, hb, strips);
     const bool active = t.valid && (t.x0 + b * 8 < w);
+    constexpr float kRc255 = 1.0f / 255.0f;
 
-    load_strip(x, lds, t, h, w, lane);
+    f32x4 pre[6] = {};
+    fetch_strip(x, pre, t, h, w, lane);                              // in flight while the tables are staged
+    const bool fast = stage_tables(qtab, qT, reinterpret_cast<int*>(qT + 384));
+    commit_strip(lds, pre, lane);
     wave_sync();
     float px[24];
     float v[3][8];
-    if (active) {
-        read_row24(lds, b, r, px);
+    read_row24(lds, b, r, px);
+    wave_sync();
+    {
         float ycc[3][8];
         colour_fwd(px, ycc);
 #pragma unroll
         for (int c = 0; c < 3; ++c) dct_fwd8(ycc[c], v[c]);          // T[r][k] = sum_j b[r][j] F[k][j]
     }
-    wave_sync();
     transpose24(lds, b, r, v);                                       // lane now holds T[0..7][col r]
     if (active) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float X[8];
-            dct_fwd8(v[c], X);                                       // X[u][col r] = sum_i F[u][i] T[i][r]
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float q = qtab[c * 64 + u * 8 + r];
-                const float qi = quantise(X[u] / q, rounding);
-                X[u] = qi * q;
-                const long o = ((((long)t.n * 3 + c) * hb + t.by) * wb + (t.x0 / 8 + b)) * 64 + u * 8 + r;
-                if (idx) idx[o] = (int16_t)qi;
-                if (xdq) xdq[o] = X[u];
-            }
-            dct_inv8(X, v[c]);                                       // S[i][col r] = sum_u F[u][i] Xd[u][r]
-        }
+        if (fast) quantise_columns<QMODE, false>(v, qT, t, b, r, hb, wb, idx, xdq);
+        else quantise_columns<QMODE, true>(v, qT, t, b, r, hb, wb, idx, xdq);
     }
     transpose24(lds, b, r, v);                                       // lane holds S[row r][0..7]
-    if (active) {
+    {
         float q3[3][8];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -255,14 +325,15 @@ __global__ __launch_bounds__(256) void djpeg_fwd_kernel(const float* __restrict_
                 acc = __builtin_fmaf(q3[0][j], kCI[c][1], acc);
                 acc = __builtin_fmaf(q3[1][j], kCI[c][2], acc);
                 acc = __builtin_fmaf(q3[2][j], kCI[c][3], acc);
-                acc = acc / 255.0f;
-                m |= (acc >= 0.0f && acc <= 1.0f) ? (1u << c) : 0u;
-                px[3 * j + c] = fminf(fmaxf(acc, 0.0f), 1.0f);
+                acc = div_q<false>(acc, 255.0f, kRc255);
+                const float cl = __builtin_amdgcn_fmed3f(acc, 0.0f, 1.0f);          // = fminf(fmaxf(acc, 0), 1)
+                m |= cl == acc ? (1u << c) : 0u;                                    // inside [0, 1]: the clip passes the gradient
+                px[3 * j + c] = cl;
             }
             if (j < 4) mlo |= m << (8 * j); else mhi |= m << (8 * (j - 4));
         }
         write_row24(lds, b, r, px);
-        if (mask)
+        if (mask && active)
             *reinterpret_cast<uint2*>(mask + ((long)t.n * h + t.by * 8 + r) * w + t.x0 + b * 8) = make_uint2(mlo, mhi);
     }
     wave_sync();
@@ -273,42 +344,50 @@ __global__ __launch_bounds__(256) void djpeg_fwd_kernel(const float* __restrict_
 // d X' / d Q = quant(z) - z quant'(z) with z = X / Q, summed over every block of the luma / of both chroma channels.  A lane
 // holds column r of its block, so it accumulates 2 x 8 table entries (u, r); the 8 blocks of the wave are folded with three
 // shuffles and lanes 0..7 write the wave's 128 partial sums (dq_partial[task][cls][u][r]); a fixed-order reduction finishes.
-template <bool DQ>
-__global__ __launch_bounds__(256) void djpeg_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+// Always the IEEE division (trained tables are not integers).
+template <int RND, bool DQ>
+__global__ __launch_bounds__(256, DQ ? 3 : DJ_BWD_WGS) void djpeg_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                         const uint8_t* __restrict__ mask,
                                                         const float* __restrict__ qtab, float* __restrict__ gx,
-                                                        float* __restrict__ dq_partial, int n, int h, int w,
-                                                        int rounding) {
+                                                        float* __restrict__ dq_partial, int n, int h, int w) {
+    constexpr int GMODE = bwd_mode(RND), QMODE = fwd_mode(RND);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = lane >> 3, r = lane & 7;
     float* lds = smem + wave * WAVE_LDS_F;
+    float* qT = smem + WAVES_PER_BLOCK * WAVE_LDS_F;
     const int hb = h / 8, strips = (w + STRIP_PX - 1) / STRIP_PX;
     const long n_tasks = (long)n * hb * strips;
     const Task t = decode_task((long)blockIdx.x * WAVES_PER_BLOCK + wave, n_tasks, hb, strips);
     const bool active = t.valid && (t.x0 + b * 8 < w);
+    f32x4 pre[6] = {};
+    fetch_strip(x, pre, t, h, w, lane);                              // in flight while the tables are staged
+    const bool fast = stage_tables(qtab, qT, reinterpret_cast<int*>(qT + 384)) && !DQ;
 
     float px[24];
     float tx[3][8];    // forward coefficients path (from x)
     float tg[3][8];    // gradient path (from gy)
-
     // ---- recompute the forward row pass from x
-    load_strip(x, lds, t, h, w, lane);
+    commit_strip(lds, pre, lane);
+    fetch_strip(gy, pre, t, h, w, lane);                             // the gradient strip arrives under the first row pass
+    uint2 mm = make_uint2(0u, 0u);
+    if (active) mm = *reinterpret_cast<const uint2*>(mask + ((long)t.n * h + t.by * 8 + r) * w + t.x0 + b * 8);
     wave_sync();
-    if (active) {
-        read_row24(lds, b, r, px);
+    read_row24(lds, b, r, px);
+    wave_sync();
+    {
         float ycc[3][8];
         colour_fwd(px, ycc);
 #pragma unroll
         for (int c = 0; c < 3; ++c) dct_fwd8(ycc[c], tx[c]);
     }
-    wave_sync();
     // ---- gradient: clip mask, /255, transpose(colour_I), row pass (d xi = F^T dXd F  =>  dXd = F g F^T)
-    load_strip(gy, lds, t, h, w, lane);
+    commit_strip(lds, pre, lane);
     wave_sync();
-    if (active) {
-        read_row24(lds, b, r, px);
-        const uint2 mm = *reinterpret_cast<const uint2*>(mask + ((long)t.n * h + t.by * 8 + r) * w + t.x0 + b * 8);
+    read_row24(lds, b, r, px);
+    wave_sync();
+    {
+#pragma clang fp contract(fast)       // gradient arithmetic carries no bit-exact contract (the recomputed forward above does)
         float gq[3][8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -323,7 +402,6 @@ __global__ __launch_bounds__(256) void djpeg_bwd_kernel(const float* __restrict_
 #pragma unroll
         for (int c = 0; c < 3; ++c) dct_fwd8(gq[c], tg[c]);
     }
-    wave_sync();
     transpose24(lds, b, r, tx);
     transpose24(lds, b, r, tg);
     float dqa[DQ ? 2 : 1][8];
@@ -334,21 +412,25 @@ __global__ __launch_bounds__(256) void djpeg_bwd_kernel(const float* __restrict_
             for (int u = 0; u < 8; ++u) dqa[k][u] = 0.0f;
     }
     if (active) {
+        auto columns = [&](auto exact) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float X[8], G[8];
-            dct_fwd8(tx[c], X);
-            dct_fwd8(tg[c], G);
+            for (int c = 0; c < 3; ++c) {
+                float X[8], G[8], q[8], rc[8];
+                dct_fwd8(tx[c], X);
+                dct_fwd8(tg[c], G);
+                read_tables(qT, c, r, q, rc);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float q = qtab[c * 64 + u * 8 + r];
-                const float z = X[u] / q;
-                const float qg = quantise_grad(z, rounding);
-                if constexpr (DQ) dqa[c == 0 ? 0 : 1][u] += G[u] * (quantise(z, rounding) - z * qg);
-                G[u] *= qg;                                      // (X/Q -> quant -> *Q): the Q factors cancel
+                for (int u = 0; u < 8; ++u) {
+                    const float z = div_q<decltype(exact)::value>(X[u], q[u], rc[u]);
+                    const float qg = quantise_grad<GMODE>(z);
+                    if constexpr (DQ) dqa[c == 0 ? 0 : 1][u] += G[u] * (quantise<QMODE>(z) - z * qg);
+                    G[u] *= qg;                                      // (X/Q -> quant -> *Q): the Q factors cancel
+                }
+                dct_inv8(G, tg[c]);                                  // d b = F^T gX F : column pass
             }
-            dct_inv8(G, tg[c]);                                  // d b = F^T gX F : column pass
-        }
+        };
+        if (fast) columns(std::false_type{});
+        else columns(std::true_type{});
     }
     if constexpr (DQ) {
         const long task = (long)blockIdx.x * WAVES_PER_BLOCK + wave;
@@ -364,10 +446,11 @@ __global__ __launch_bounds__(256) void djpeg_bwd_kernel(const float* __restrict_
             }
     }
     transpose24(lds, b, r, tg);
-    if (active) {
+    {
+#pragma clang fp contract(fast)
         float gb[3][8];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) dct_inv8(tg[c], gb[c]);      // row pass
+        for (int c = 0; c < 3; ++c) dct_inv8(tg[c], gb[c]);          // row pass
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -378,6 +461,23 @@ __global__ __launch_bounds__(256) void djpeg_bwd_kernel(const float* __restrict_
     }
     wave_sync();
     store_strip(gx, lds, t, h, w, lane);
+}
+
+inline int persistent_grid(long tasks) { return (int)((tasks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK); }   // one task per wave
+constexpr size_t kLds = ((size_t)WAVES_PER_BLOCK * WAVE_LDS_F + 384 + 4) * sizeof(float);
+
+template <bool DQ, typename... A>
+void launch_bwd(int rounding, int grid, hipStream_t s, A... a) {
+    const dim3 g(grid), b(256);
+    switch (rounding) {
+        case NIMG_ROUND_ROUND: hipLaunchKernelGGL((djpeg_bwd_kernel<NIMG_ROUND_ROUND, DQ>), g, b, kLds, s, a...); break;
+        case NIMG_ROUND_SIN:                               // without the table gradient SIN and SOFT are one kernel
+            if constexpr (DQ) { hipLaunchKernelGGL((djpeg_bwd_kernel<NIMG_ROUND_SIN, DQ>), g, b, kLds, s, a...); break; }
+            [[fallthrough]];
+        case NIMG_ROUND_SOFT: hipLaunchKernelGGL((djpeg_bwd_kernel<NIMG_ROUND_SOFT, DQ>), g, b, kLds, s, a...); break;
+        case NIMG_ROUND_HARMONIC: hipLaunchKernelGGL((djpeg_bwd_kernel<NIMG_ROUND_HARMONIC, DQ>), g, b, kLds, s, a...); break;
+        default: hipLaunchKernelGGL((djpeg_bwd_kernel<NIMG_ROUND_IDENTITY, DQ>), g, b, kLds, s, a...); break;
+    }
 }
 
 }  // namespace
@@ -393,10 +493,16 @@ int nimg_djpeg_fwd(const float* x, float* y, const float* qtab, uint8_t* mask, i
     if (rounding < NIMG_ROUND_ROUND || rounding > NIMG_ROUND_IDENTITY) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
     const long tasks = (long)n * (h / 8) * ((w + STRIP_PX - 1) / STRIP_PX);
-    const int grid = nimg::cdiv(tasks, WAVES_PER_BLOCK);
-    const size_t lds = (size_t)WAVES_PER_BLOCK * WAVE_LDS_F * sizeof(float);
-    hipLaunchKernelGGL(djpeg_fwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, x, y, qtab, mask, idx,
-                       xdq, n, h, w, rounding);
+    const dim3 grid(persistent_grid(tasks)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (fwd_mode(rounding)) {
+        case Q_RINT: hipLaunchKernelGGL(djpeg_fwd_kernel<Q_RINT>, grid, block, kLds, s, x, y, qtab, mask, idx, xdq, n, h, w); break;
+        case Q_SIN: hipLaunchKernelGGL(djpeg_fwd_kernel<Q_SIN>, grid, block, kLds, s, x, y, qtab, mask, idx, xdq, n, h, w); break;
+        case Q_HARMONIC:
+            hipLaunchKernelGGL(djpeg_fwd_kernel<Q_HARMONIC>, grid, block, kLds, s, x, y, qtab, mask, idx, xdq, n, h, w);
+            break;
+        default: hipLaunchKernelGGL(djpeg_fwd_kernel<Q_IDENTITY>, grid, block, kLds, s, x, y, qtab, mask, idx, xdq, n, h, w); break;
+    }
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }
@@ -408,10 +514,7 @@ int nimg_djpeg_bwd(const float* x, const float* gy, const uint8_t* mask, const f
     if (rounding < NIMG_ROUND_ROUND || rounding > NIMG_ROUND_IDENTITY) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
     const long tasks = (long)n * (h / 8) * ((w + STRIP_PX - 1) / STRIP_PX);
-    const int grid = nimg::cdiv(tasks, WAVES_PER_BLOCK);
-    const size_t lds = (size_t)WAVES_PER_BLOCK * WAVE_LDS_F * sizeof(float);
-    hipLaunchKernelGGL(djpeg_bwd_kernel<false>, dim3(grid), dim3(256), lds, (hipStream_t)stream, x, gy, mask, qtab, gx,
-                       (float*)nullptr, n, h, w, rounding);
+    launch_bwd<false>(rounding, persistent_grid(tasks), (hipStream_t)stream, x, gy, mask, qtab, gx, (float*)nullptr, n, h, w);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }
@@ -431,10 +534,8 @@ int nimg_djpeg_bwd_dq(const float* x, const float* gy, const uint8_t* mask, cons
     if (rounding < NIMG_ROUND_ROUND || rounding > NIMG_ROUND_IDENTITY) return NIMG_ERR_ARG;
     if (workspace_bytes < nimg_djpeg_dq_workspace_bytes(n, h, w)) return NIMG_ERR_WORKSPACE;
     const long tasks = (long)n * (h / 8) * ((w + STRIP_PX - 1) / STRIP_PX);
-    const int grid = nimg::cdiv(tasks, WAVES_PER_BLOCK);
-    const size_t lds = (size_t)WAVES_PER_BLOCK * WAVE_LDS_F * sizeof(float);
-    hipLaunchKernelGGL(djpeg_bwd_kernel<true>, dim3(grid), dim3(256), lds, (hipStream_t)stream, x, gy, mask, qtab, gx,
-                       (float*)workspace, n, h, w, rounding);
+    const int grid = persistent_grid(tasks);
+    launch_bwd<true>(rounding, grid, (hipStream_t)stream, x, gy, mask, qtab, gx, (float*)workspace, n, h, w);
     NIMG_CHECK_LAUNCH();
     nimg::launch_reduce2((const float*)workspace, dq, 128, grid * WAVES_PER_BLOCK, nullptr, nullptr, 0, 0, accumulate,
                          (hipStream_t)stream);

@@ -591,6 +591,82 @@ __global__ void avgpool_bwd_kernel(const float* __restrict__ dy, float* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Any odd k x k per-channel (diagonal) filter with a mirrored border and an optional hard clip: manipulation_gaussian with a
+// kernel other than 5 (tf_helpers.py:113-125, REFLECT), manipulation_sharpen(hsv=False) (:156-184, SYMMETRIC) and
+// residual(hsv=False) (:127-154, REFLECT, no clip).  Off the training hot path (the workflow uses the 5x5 / hsv kernels
+// above): one thread per pixel, taps in LDS, tap order (ky, then kx) as the 5x5 kernel.
+__global__ void dwfilter_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ mask,
+                                    const float* __restrict__ gk, int k, int mode, int n, int h, int w, int clip) {
+    extern __shared__ float taps[];
+    for (int i = threadIdx.x; i < k * k; i += blockDim.x) taps[i] = gk[i];
+    __syncthreads();
+    const long total = (long)n * h * w;
+    const int P = k / 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int px = (int)(i % w), py = (int)((i / w) % h);
+        const long im = i / ((long)w * h);
+        float acc[3] = {0.f, 0.f, 0.f};
+        for (int ky = 0; ky < k; ++ky) {
+            int yy = py + ky - P;
+            map_coord(yy, h, mode);
+            for (int kx = 0; kx < k; ++kx) {
+                int xx = px + kx - P;
+                map_coord(xx, w, mode);
+                const float* p = x + ((im * h + yy) * w + xx) * 3;
+                const float wv = taps[ky * k + kx];
+                acc[0] = fmaf(p[0], wv, acc[0]);
+                acc[1] = fmaf(p[1], wv, acc[1]);
+                acc[2] = fmaf(p[2], wv, acc[2]);
+            }
+        }
+        uint32_t m = 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            m |= (acc[c] >= 0.f && acc[c] <= 1.f) ? (1u << c) : 0u;
+            y[i * 3 + c] = clip ? fminf(fmaxf(acc[c], 0.f), 1.f) : acc[c];
+        }
+        if (mask) mask[i] = clip ? (uint8_t)m : (uint8_t)7;
+    }
+}
+
+__global__ void dwfilter_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ mask,
+                                    float* __restrict__ dx, const float* __restrict__ gk, int k, int mode, int n, int h,
+                                    int w) {
+    extern __shared__ float taps[];
+    for (int i = threadIdx.x; i < k * k; i += blockDim.x) taps[i] = gk[i];
+    __syncthreads();
+    const long total = (long)n * h * w;
+    const int P = k / 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int px = (int)(i % w), py = (int)((i / w) % h);
+        const long im = i / ((long)w * h);
+        int ys[2], xs[2];
+        const int ny = pad_sources(py, h, P, mode, ys), nx = pad_sources(px, w, P, mode, xs);
+        float acc[3] = {0.f, 0.f, 0.f};
+        for (int a = 0; a < ny; ++a)
+            for (int b = 0; b < nx; ++b)
+                for (int ky = 0; ky < k; ++ky) {
+                    const int oy = ys[a] - ky;           // output row that read padded row ys[a] with tap ky
+                    if (oy < 0 || oy >= h) continue;
+                    for (int kx = 0; kx < k; ++kx) {
+                        const int ox = xs[b] - kx;
+                        if (ox < 0 || ox >= w) continue;
+                        const long o = (im * h + oy) * w + ox;
+                        const uint32_t m = mask ? mask[o] : 7u;
+                        const float wv = taps[ky * k + kx];
+                        const float* p = dy + o * 3;
+                        if (m & 1u) acc[0] = fmaf(p[0], wv, acc[0]);
+                        if (m & 2u) acc[1] = fmaf(p[1], wv, acc[1]);
+                        if (m & 4u) acc[2] = fmaf(p[2], wv, acc[2]);
+                    }
+                }
+        dx[i * 3 + 0] = acc[0];
+        dx[i * 3 + 1] = acc[1];
+        dx[i * 3 + 2] = acc[2];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -623,6 +699,30 @@ int nimg_gaussian_bwd(const float* dy, const uint8_t* mask, float* dx, const flo
     else
         hipLaunchKernelGGL(gaussian_bwd_kernel, dim3(grid_for((long)n * h * w)), dim3(256), 0, (hipStream_t)stream, dy,
                            mask, dx, gk25, n, h, w);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_dwfilter_fwd(const float* x, float* y, uint8_t* mask, const float* taps, int k, int pad_mode, int n, int h, int w,
+                      int clip, void* stream) {
+    if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
+    /* a mirrored border of k/2 pixels needs k/2 (SYMMETRIC) or k/2 + 1 (REFLECT) pixels to mirror */
+    if (!x || !y || !taps || n < 0 || k < 1 || k > 31 || !(k & 1) || (pad_mode != 1 && pad_mode != 2)) return NIMG_ERR_ARG;
+    if (h < k / 2 + (pad_mode == 2) || w < k / 2 + (pad_mode == 2) || h < 1 || w < 1) return NIMG_ERR_ARG;
+    hipLaunchKernelGGL(dwfilter_fwd_kernel, dim3(grid_for((long)n * h * w)), dim3(256), (size_t)k * k * sizeof(float),
+                       (hipStream_t)stream, x, y, mask, taps, k, pad_mode, n, h, w, clip);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_dwfilter_bwd(const float* dy, const uint8_t* mask, float* dx, const float* taps, int k, int pad_mode, int n, int h,
+                      int w, void* stream) {
+    if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
+    if (!dy || !dx || !taps || n < 0 || k < 1 || k > 31 || !(k & 1) || (pad_mode != 1 && pad_mode != 2)) return NIMG_ERR_ARG;
+    /* the fold of the padded-domain gradient assumes at most ONE mirrored source per pixel and axis */
+    if (h < 2 * (k / 2) + 1 || w < 2 * (k / 2) + 1) return NIMG_ERR_ARG;
+    hipLaunchKernelGGL(dwfilter_bwd_kernel, dim3(grid_for((long)n * h * w)), dim3(256), (size_t)k * k * sizeof(float),
+                       (hipStream_t)stream, dy, mask, dx, taps, k, pad_mode, n, h, w);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }

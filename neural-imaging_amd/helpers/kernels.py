@@ -56,6 +56,22 @@ def bilinear_axis_matrix(in_size, out_size):
     return m
 
 
+def nearest_axis_matrix(in_size, out_size):
+    """Dense (out,in) 0/1 matrix of tf.image.resize(nearest) along one axis: half-pixel centres, source index
+    floor((o + 0.5) * in/out) in float32, clamped to the last pixel (ResizeNearestNeighbor, half_pixel_centers=True)."""
+    m = np.zeros((out_size, in_size), np.float64)
+    scale = np.float32(in_size) / np.float32(out_size)
+    for o in range(out_size):
+        src = int(np.floor((np.float32(o) + np.float32(0.5)) * scale))
+        m[o, min(src, in_size - 1)] = 1.0
+    return m
+
+
+def residual_kernel():
+    """3x3 high-pass taps of residual() (helpers/tf_helpers.py:131)."""
+    return np.array([[-0.0833, -0.1667, -0.0833], [-0.1667, 1, -0.1667], [-0.0833, -0.1667, -0.0833]])
+
+
 def upsampling_kernel(cfa_pattern='gbrg'):
     """(4,12) 1x1 kernel that scatters the RAW planes [R, G (first in raster order), G (second), B] of a 2x2 Bayer cell
     to the (position, colour) slots depth_to_space(2) expects - slot = 2*dy + dx, colour R/G/B = 0/1/2 - for the CFA

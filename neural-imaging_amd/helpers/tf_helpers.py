@@ -3,8 +3,9 @@ Photo manipulations and image losses of the channel on the HIP kernels.  Same fu
 the reference's helpers/tf_helpers.py (manipulation_* :68-184, mse :31-32); each manipulation also exists as an object
 with forward(x, strength, out) / backward(ctx, dy), which is what the workflow's training step uses.
 
-Implemented: sharpen (hsv=True, incl. the S-channel corner-tap quirk), resample (bilinear down+up, any factor),
-gaussian (5x5, any std), awgn (device-side noise), gamma, median (odd kernels up to 9).
+Implemented: sharpen (hsv=True incl. the S-channel corner-tap quirk, and hsv=False), resample (bilinear or nearest down+up, any
+factor), gaussian (any odd kernel, any std; the workflow's 5x5 has its own LDS-tiled kernel), residual (hsv=False), awgn
+(device-side noise), gamma, median (odd kernels up to 9).  tf.image.resize's other methods (bicubic, lanczos, area ...) raise.
 """
 from collections import OrderedDict
 
@@ -35,9 +36,11 @@ class _TapCache(OrderedDict):
 
 
 class Sharpen(object):
-    """manipulation_sharpen(x, strength, hsv=True)  (tf_helpers.py:156-184)"""
+    """manipulation_sharpen(x, strength, hsv)  (tf_helpers.py:156-184); hsv=True is the workflow's form (fused rgb->hsv->filter
+    ->rgb kernel), hsv=False the plain per-channel 3x3 filter with a SYMMETRIC border."""
 
-    def __init__(self):
+    def __init__(self, hsv=True):
+        self.hsv = bool(hsv)
         self._cache = _TapCache()
 
     def taps(self, strength, device):
@@ -47,39 +50,74 @@ class Sharpen(object):
 
     def forward(self, x, strength=1, out=None, training=False):
         gk = self.taps(strength, x.device)
+        if not self.hsv:
+            y, mask = ops.dwfilter_fwd(x, gk, 3, 'SYMMETRIC', out=out, clip=True, want_mask=training)
+            return y, ({'mask': mask, 'gk': gk} if training else None)
         y, aux, mask = ops.sharpen_fwd(x, gk, out=out, want_aux=training)
         return y, ({'x': x, 'aux': aux, 'mask': mask, 'gk': gk} if training else None)
 
     def backward(self, ctx, dy):
+        if not self.hsv:
+            return ops.dwfilter_bwd(dy, ctx['mask'], ctx['gk'], 3, 'SYMMETRIC')
         return ops.sharpen_bwd(ctx['x'], dy, ctx['aux'], ctx['mask'], ctx['gk'])
 
 
 class Gaussian(object):
-    """manipulation_gaussian(x, 5, std)  (tf_helpers.py:113-125)"""
+    """manipulation_gaussian(x, kernel, std)  (tf_helpers.py:113-125).  kernel = 5 (the workflow's, :114) runs the LDS-tiled 5x5
+    kernel; any other odd size the generic per-channel filter (REFLECT border).  An even kernel is refused: tf.pad by kernel//2
+    followed by a VALID convolution would return an image one pixel larger than its input."""
 
     def __init__(self, kernel=5):
-        if kernel != 5:
-            raise NotImplementedError('only the 5x5 gaussian used by the workflow is built')
+        self.kernel = int(kernel)
+        if self.kernel < 1 or self.kernel % 2 == 0 or self.kernel > 31:
+            raise ValueError('gaussian kernel: an odd size in 1 .. 31, got {}'.format(kernel))
         self._cache = _TapCache()
 
     def taps(self, std, device):
         return self._cache.fetch((float(std), str(device)), lambda: torch.from_numpy(
-            hk.gkern(5, float(std)).astype(np.float32).reshape(-1)).to(device))
+            hk.gkern(self.kernel, float(std)).astype(np.float32).reshape(-1)).to(device))
 
     def forward(self, x, std=0.83, out=None, training=False, skip_clip=False):
         gk = self.taps(std, x.device)
-        y, mask = ops.gaussian_fwd(x, gk, out=out, clip=not skip_clip, want_mask=training)
+        if self.kernel == 5:
+            y, mask = ops.gaussian_fwd(x, gk, out=out, clip=not skip_clip, want_mask=training)
+        else:
+            y, mask = ops.dwfilter_fwd(x, gk, self.kernel, 'REFLECT', out=out, clip=not skip_clip, want_mask=training)
         return y, ({'mask': mask, 'gk': gk} if training else None)
 
     def backward(self, ctx, dy):
-        return ops.gaussian_bwd(dy, ctx['mask'], ctx['gk'])
+        if self.kernel == 5:
+            return ops.gaussian_bwd(dy, ctx['mask'], ctx['gk'])
+        return ops.dwfilter_bwd(dy, ctx['mask'], ctx['gk'], self.kernel, 'REFLECT')
+
+
+class Residual(object):
+    """residual(x, hsv=False) (tf_helpers.py:127-154): the fixed 3x3 high-pass filter, REFLECT border, no clip."""
+
+    def __init__(self):
+        self._cache = _TapCache()
+
+    def forward(self, x, out=None, training=False):
+        gk = self._cache.fetch(str(x.device), lambda: torch.from_numpy(
+            hk.residual_kernel().astype(np.float32).reshape(-1)).to(x.device))
+        y, _ = ops.dwfilter_fwd(x, gk, 3, 'REFLECT', out=out, clip=False, want_mask=False)
+        return y, ({'gk': gk} if training else None)
+
+    def backward(self, ctx, dy):
+        return ops.dwfilter_bwd(dy, None, ctx['gk'], 3, 'REFLECT')
 
 
 class Resample(object):
-    """manipulation_resample(x, factor) (tf_helpers.py:68-76): bilinear down to floor(H*factor/100) and back up, both
-    dims sized from shape[1].  The composition is one banded linear operator M per axis: y = M x M^T, dx = M^T dy M."""
+    """manipulation_resample(x, factor, method) (tf_helpers.py:68-76): down to floor(H*factor/100) and back up, both dims sized
+    from shape[1].  For the separable linear methods (bilinear - the workflow's - and nearest) the composition is one banded
+    linear operator M per axis: y = M x M^T, dx = M^T dy M."""
 
-    def __init__(self):
+    METHODS = {'bilinear': hk.bilinear_axis_matrix, 'nearest': hk.nearest_axis_matrix}
+
+    def __init__(self, method='bilinear'):
+        if method not in self.METHODS:
+            raise NotImplementedError('tf.image.resize method {!r}: only {} are built'.format(method, sorted(self.METHODS)))
+        self.method = method
         self._cache = {}
 
     def operator(self, size, factor, device):
@@ -88,7 +126,10 @@ class Resample(object):
         small = size * int(factor) // 100
         key = (size, small, str(device))
         if key not in self._cache:
-            m = hk.bilinear_axis_matrix(small, size) @ hk.bilinear_axis_matrix(size, small)
+            if small < 1:
+                raise ValueError('resample factor {} leaves no pixels of a {}-pixel patch'.format(factor, size))
+            axis = self.METHODS[self.method]
+            m = axis(small, size) @ axis(size, small)
             self._cache[key] = ops.AxisOperator(m, device)
         return self._cache[key]
 
@@ -106,7 +147,8 @@ class Resample(object):
         return ops.sparse_axis_apply(tmp, op.bwd, 1, op.in_size)
 
 
-_sharpen, _gaussian, _resample = Sharpen(), Gaussian(), Resample()
+_sharpen, _sharpen_rgb, _gaussian, _resample, _residual = Sharpen(), Sharpen(hsv=False), Gaussian(), Resample(), Residual()
+_gaussians, _resamples = {5: _gaussian}, {'bilinear': _resample}
 
 
 def _dev(x):
@@ -115,21 +157,26 @@ def _dev(x):
 
 
 def manipulation_sharpen(x, strength=1, hsv=True):
-    if not hsv:
-        raise NotImplementedError('the workflow always uses hsv=True (workflows/manipulation_classification.py:107)')
-    return DeviceArray(_sharpen.forward(to_device(x, _dev(x)), strength)[0])
+    return DeviceArray((_sharpen if hsv else _sharpen_rgb).forward(to_device(x, _dev(x)), strength)[0])
+
+
+def residual(x, hsv=False):
+    if hsv:
+        raise NotImplementedError('residual(hsv=True) has no caller in the reference')
+    return DeviceArray(_residual.forward(to_device(x, _dev(x)))[0])
 
 
 def manipulation_resample(x, factor=50, method='bilinear'):
-    if method != 'bilinear':
-        raise NotImplementedError(method)
-    return DeviceArray(_resample.forward(to_device(x, _dev(x)), factor)[0])
+    if method not in _resamples:
+        _resamples[method] = Resample(method)
+    return DeviceArray(_resamples[method].forward(to_device(x, _dev(x)), factor)[0])
 
 
 def manipulation_gaussian(x, kernel, std, skip_clip=False):
-    if int(kernel) != 5:
-        raise NotImplementedError('only the 5x5 gaussian used by the workflow is built')
-    return DeviceArray(_gaussian.forward(to_device(x, _dev(x)), std, skip_clip=skip_clip)[0])
+    kernel = int(kernel)
+    if kernel not in _gaussians:
+        _gaussians[kernel] = Gaussian(kernel)
+    return DeviceArray(_gaussians[kernel].forward(to_device(x, _dev(x)), std, skip_clip=skip_clip)[0])
 
 
 class Awgn(object):

@@ -896,6 +896,27 @@ def gaussian_bwd(dy, mask, gk25):
     return dx
 
 
+def dwfilter_fwd(x, taps, k, pad_mode, out=None, clip=True, want_mask=True):
+    """Any odd k x k per-channel filter, mirrored border (pad_mode 'SYMMETRIC' | 'REFLECT'), optional clip + pass mask."""
+    _f32(x, taps, out)
+    n, h, w, _ = x.shape
+    if taps.numel() != k * k:
+        raise ValueError('taps: k*k floats')
+    y = torch.empty_like(x) if out is None else out
+    mask = torch.empty((n, h, w), dtype=torch.uint8, device=x.device) if want_mask else None
+    _lib.call('nimg_dwfilter_fwd', _p(x), _p(y), _p(mask), _p(taps), int(k), PAD_MODES[pad_mode], n, h, w,
+              1 if clip else 0, _stream())
+    return y, mask
+
+
+def dwfilter_bwd(dy, mask, taps, k, pad_mode):
+    _f32(dy, taps)
+    n, h, w, _ = dy.shape
+    dx = torch.empty_like(dy)
+    _lib.call('nimg_dwfilter_bwd', _p(dy), _p(mask), _p(dx), _p(taps), int(k), PAD_MODES[pad_mode], n, h, w, _stream())
+    return dx
+
+
 def sharpen_fwd(x, gk9, out=None, want_aux=True):
     _f32(x, gk9, out)
     n, h, w, _ = x.shape

@@ -21,13 +21,21 @@ def manipulation_sharpen(x, strength=1, hsv=True):
     return torch.clamp(y, 0, 1)
 
 
-def manipulation_resample(x, factor=50):
+def manipulation_resample(x, factor=50, method='bilinear'):
     """tf_helpers.py:68-76: both dims sized from shape[1]."""
     if 0 < factor <= 1:
         factor = 100 * factor
     s = x.shape[1] * int(factor) // 100
-    down = T.resize_bilinear(x, s, s)
-    return T.resize_bilinear(down, x.shape[1], x.shape[1])
+    resize = {'bilinear': T.resize_bilinear, 'nearest': T.resize_nearest}[method]
+    down = resize(x, s, s)
+    return resize(down, x.shape[1], x.shape[1])
+
+
+def residual(x):
+    """tf_helpers.py:127-154 with hsv=False: REFLECT pad 1, the fixed 3x3 high-pass per channel, no clip."""
+    gk = np.array([[-0.0833, -0.1667, -0.0833], [-0.1667, 1, -0.1667], [-0.0833, -0.1667, -0.0833]])
+    gf = torch.tensor(tables.repeat_2dfilter(gk, 3).astype(np.float32), dtype=x.dtype)
+    return T.conv2d(T.pad2d(x, 1, 'REFLECT'), gf, None, 1, 'VALID')
 
 
 def manipulation_gaussian(x, kernel=5, std=0.83, skip_clip=False):

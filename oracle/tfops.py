@@ -133,6 +133,19 @@ def resize_bilinear(x, out_h, out_w):
     return t + (b - t) * yt
 
 
+def resize_nearest(x, out_h, out_w):
+    """tf.image.resize(method='nearest') = ResizeNearestNeighbor(half_pixel_centers=True, align_corners=False): source index
+    min(floor((o + 0.5f) * (in / out)), in - 1), evaluated in float32 (tensorflow/core/kernels/image/resize_nearest_neighbor_op.cc
+    with HalfPixelScalerForNN; not vendored in /root/reference - restated from the published kernel, parity unpinned here)."""
+    n, h, w, c = x.shape
+
+    def table(in_size, out_size):
+        scale = np.float32(in_size) / np.float32(out_size)
+        return np.array([min(int(math.floor((np.float32(o) + np.float32(0.5)) * scale)), in_size - 1) for o in range(out_size)])
+
+    return x[:, table(h, out_h)][:, :, table(w, out_w)]
+
+
 # ---------------------------------------------------------------------------------------------
 # colour spaces (tf.image.rgb_to_hsv / hsv_to_rgb; tensorflow/core/kernels/colorspace_op.h)
 def rgb_to_hsv(x):

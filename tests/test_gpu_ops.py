@@ -574,6 +574,62 @@ def test_manipulations_fwd_bwd(dev, name):
     assert_close(dx.cpu().numpy(), x.grad.numpy(), 2e-4, 3e-4, what=name + ' bwd')
 
 
+@pytest.mark.parametrize('name', ['gaussian3x3', 'gaussian7x7', 'gaussian9x9_noclip', 'gaussian1x1', 'sharpen_rgb',
+                                  'sharpen_rgb_strong', 'residual', 'nearest50', 'nearest30'])
+def test_manipulations_general_forms(dev, name):
+    """The forms of the manipulations the workflow does not use (tf_helpers.py:68-184 with kernel != 5, hsv=False,
+    method='nearest'), through both the objects (forward + backward) and the reference-named functions."""
+    from neural_imaging_amd.helpers import tf_helpers as th
+    hw = (20, 20) if name.startswith('nearest') else (24, 18)
+    x_np = np.ascontiguousarray(natural_images(2, 24, 24, seed=11)[:, :hw[0], :hw[1]])
+    if name.startswith('sharpen'):
+        x_np = np.clip(x_np * 1.3 - 0.1, 0, 1).astype(np.float32)       # exercise the hard clip too
+    x = to64(x_np).requires_grad_(True)
+    xd = g(x_np, dev)
+    if name.startswith('gaussian'):
+        k = int(name[8])
+        noclip = name.endswith('noclip')
+        std = 1.7 if k > 3 else 0.6
+        ref = om.manipulation_gaussian(x, k, std, skip_clip=noclip)
+        op = th.Gaussian(k)
+        y, ctx = op.forward(xd, std, training=True, skip_clip=noclip)
+        fn = th.manipulation_gaussian(xd, k, std, skip_clip=noclip)
+    elif name.startswith('sharpen'):
+        s = 2.5 if name.endswith('strong') else 1.0
+        ref = om.manipulation_sharpen(x, s, hsv=False)
+        op = th.Sharpen(hsv=False)
+        y, ctx = op.forward(xd, s, training=True)
+        fn = th.manipulation_sharpen(xd, s, hsv=False)
+    elif name == 'residual':
+        ref = om.residual(x)
+        op = th.Residual()
+        y, ctx = op.forward(xd, training=True)
+        fn = th.residual(xd)
+    else:
+        f = int(name[7:])
+        ref = om.manipulation_resample(x, f, 'nearest')
+        op = th.Resample('nearest')
+        y, ctx = op.forward(xd, f, training=True)
+        fn = th.manipulation_resample(xd, f, 'nearest')
+    dy = rnd(tuple(ref.shape), 3)
+    (ref * to64(dy)).sum().backward()
+    assert_close(y.cpu().numpy(), ref.detach().numpy(), ATOL, what=name + ' fwd')
+    assert np.array_equal(fn.t.cpu().numpy(), y.cpu().numpy()), 'function and object forms differ'
+    dx = op.backward(ctx, g(dy, dev))
+    assert_close(dx.cpu().numpy(), x.grad.numpy(), 2e-4, 3e-4, what=name + ' bwd')
+
+
+def test_manipulations_unbuilt_forms_raise(dev):
+    from neural_imaging_amd.helpers import tf_helpers as th
+    x = g(natural_images(1, 16, 16, seed=2), dev)
+    with pytest.raises(NotImplementedError):
+        th.manipulation_resample(x, 50, 'bicubic')
+    with pytest.raises(ValueError):
+        th.manipulation_gaussian(x, 4, 1.0)
+    with pytest.raises(RuntimeError):
+        th.manipulation_gaussian(x[:, :3, :3].contiguous(), 9, 1.0)           # nothing to mirror: refused by the C ABI
+
+
 @pytest.mark.parametrize('hw', [(24, 40), (16, 16), (50, 18), (8, 12)])
 def test_gaussian_backward_tiled_and_plain(dev, hw):
     """The LDS-tiled backward (images >= 16x16, partial border tiles) and the plain kernel (smaller images) against autograd

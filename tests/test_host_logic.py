@@ -67,6 +67,35 @@ def test_jpeg_quality_resolution():
     assert jpeg.JPEG((50, 90), 'soft', device='cpu').summary() == 'JPEG (soft) QF~[50,90]'
 
 
+def test_djpeg_reciprocal_division_is_the_ieee_quotient(tmp_path):
+    """csrc/djpeg.hip divides by the IJG table entries with a correctly rounded reciprocal + one residual correction; the claim
+    'equal to x / q for every float x and every integer q in 1 .. 255' is checked here on every 7th mantissa (the full sweep,
+    tools/probe/div_markstein_check.c without an argument, takes ~15 core-seconds and is what the kernel comment cites)."""
+    import subprocess
+    exe = str(tmp_path / 'chk')
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'probe', 'div_markstein_check.c')
+    subprocess.run(['gcc', '-O2', '-ffp-contract=off', src, '-lm', '-o', exe], check=True)
+    out = subprocess.run([exe, '7'], check=True, capture_output=True, text=True).stdout
+    assert out.startswith('mismatches 0 '), out
+    assert int(out.split('alone:')[1].strip(' )\n')) > 0          # the correction is needed: x * rc alone is often 1 ulp off
+
+
+def test_nearest_resample_operator_matches_oracle():
+    """method='nearest' of manipulation_resample (tf_helpers.py:68-76): the composed axis operator picks the pixels the restated
+    ResizeNearestNeighbor picks; down by 2 keeps the odd pixels (floor((o + 0.5) * 2) = 2 o + 1), up by 2 repeats each twice."""
+    assert hk.nearest_axis_matrix(8, 4).argmax(axis=1).tolist() == [1, 3, 5, 7]
+    assert hk.nearest_axis_matrix(4, 8).argmax(axis=1).tolist() == [0, 0, 1, 1, 2, 2, 3, 3]
+    for size, factor in ((32, 50), (64, 73), (20, 30), (48, 100)):
+        small = size * factor // 100
+        m = hk.nearest_axis_matrix(small, size) @ hk.nearest_axis_matrix(size, small)
+        assert ((m == 0) | (m == 1)).all() and (m.sum(axis=1) == 1).all()
+        x = torch.rand(1, size, size, 2, dtype=torch.float64)
+        ref = T.resize_nearest(T.resize_nearest(x, small, small), size, size)
+        got = torch.einsum('ab,nbwc->nawc', torch.tensor(m), x)
+        got = torch.einsum('ab,nhbc->nhac', torch.tensor(m), got)
+        assert torch.equal(got, ref)
+
+
 def test_resample_operator_matches_oracle():
     for size, factor in ((32, 50), (64, 73), (48, 40)):
         small = size * factor // 100
