@@ -13,7 +13,8 @@ Workloads (BASELINE.json configs):
   c4 (default, configs[3], the configuration the metric is quoted on): B = 64 raw patches / GPU -> UNet -> (5B,256,256,3)
       [native, sharpen:1, resample:50, gaussian:0.83, jpeg:80] -> dJPEG(80, soft) -> FAN -> CE + 0.1 mse255 -> backward to the
       UNet and FAN weights -> gradient all-reduce (N > 1) -> Keras Adam.  Unit = one raw patch.
-  c3 (configs[2]): TwitterDCN-32C training step on B = 16 RGB patches of 256x256 (l2 + 250 H).  Unit = one RGB patch.
+  c3 (configs[2]): TwitterDCN-32C training step on B = 50 RGB patches of 256x256 (l2 + 250 H; the batch size train_dcn.py:102
+      fixes).  Unit = one RGB patch.
   c5 (configs[4]): the full channel with the learned codec, UNet -> manipulations -> TwitterDCN-32C -> FAN, B = 16 raw
       patches / GPU (128 global on 8 GPUs), trainable nip + dcn, lambda_dcn 0.1.  Unit = one raw patch.
 A "step" = one training step on a synthetic batch already resident in HBM.  Weak scaling: every rank processes its own B
@@ -150,7 +151,7 @@ class ChannelDCN(ChannelJPEG):
 class TrainDCN(Workload):
     key = 'c3'
     name = 'train_dcn TwitterDCN-32C on 256x256 RGB patches, l2_loss + 250 H, soft-codebook 5 bpf'
-    default_batch = 16
+    default_batch = 50          # training_spec['batch_size'] of the reference's train_dcn.py:102
     gflop_per_unit = 2 * 3 * GMAC_DCN
 
     def build(self, dev, rank):

@@ -351,6 +351,15 @@ int nimg_gamma_ste_fwd(const float* x, float* y, long count, float lo, float hi,
 int nimg_gamma_ste_bwd(const float* x, const float* dy, float* dx, long count, float lo, float hi, float exponent,
                        void* stream);
 /* out (n,2h,2w,c) = in with zeros inserted (stride-2 transposed convolution = zero insertion + stride-1 conv) */
+/* 5x5 stride-2 TF-SAME convolution (Conv2D(.., 5, strides=2) of TwitterDCN, models/compression.py:217-229) as a 3x3 stride-1
+ * convolution over the space-to-depth image (even h, w; cp >= 4 c block channels, the rest zero):
+ *   s2d2_affine_bf16       y (n,h/2,w/2,cp) bf16: y[by][bx][(2 pr + pc) c + ci] = a x[2by + pr][2bx + pc][ci] + b
+ *   s2d_conv_weights       w5 (5,5,cin,cout) -> w3 (3,3,cp,cout), tap ky = 2 dy + pr - 1;  _bwd gathers dw3 back into dw5
+ *   d2s2_scale             x (n,h,w,c) = scale * depth-to-space of xs (n,h/2,w/2,cp): the input gradient of the layer */
+int nimg_s2d2_affine_bf16(const float* x, void* y, int n, int h, int w, int c, int cp, float a, float b, void* stream);
+int nimg_s2d_conv_weights(const float* w5, float* w3, int cin, int cp, int cout, void* stream);
+int nimg_s2d_conv_weights_bwd(const float* dw3, float* dw5, int cin, int cp, int cout, int accumulate, void* stream);
+int nimg_d2s2_scale(const float* xs, float* x, int n, int h, int w, int c, int cp, float scale, void* stream);
 int nimg_zero_insert2(const float* in, float* out, int n, int h, int w, int c, void* stream);
 /* DiscreteLatent (models/layers.py:183-203): latent = Quantization('soft-codebook' | identity)(scale * z) evaluated in
  * float64 like the reference (layers.py:141), plus the batch-global differentiable entropy of the latent

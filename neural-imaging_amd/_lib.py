@@ -65,6 +65,10 @@ PROTOTYPES = {
     'nimg_affine': (c_int, [P, P, c_long, c_float, c_float, P]),
     'nimg_lrelu_fwd': (c_int, [P, P, c_long, c_float, P]),
     'nimg_zero_insert2': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'nimg_s2d2_affine_bf16': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, P]),
+    'nimg_s2d_conv_weights': (c_int, [P, P, c_int, c_int, c_int, P]),
+    'nimg_s2d_conv_weights_bwd': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'nimg_d2s2_scale': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_float, P]),
     'nimg_latent_workspace_bytes': (c_size_t, [c_int]),
     'nimg_latent_fwd': (c_int, [P, P, P, c_int, c_float, c_float, c_int, P, P, c_long, c_long, P, c_size_t, c_int, P]),
     'nimg_latent_entropy_finalize': (c_int, [c_int, c_long, P, P, P]),

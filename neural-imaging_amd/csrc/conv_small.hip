@@ -225,13 +225,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_c3k5_kernel(const TinyWPara
     const int ky = tid / TR, row = tid % TR;
     const bool active = tid < KS * TR;
     const long total = (long)p.N * p.tiles_y * p.tiles_x;
-    float acc[KS][3][3];
+    // 45 FMAs per tile column as 25 instructions (the VALU retires v_pk_fma_f32 at the rate of v_fma_f32): the outputs (co0, co1)
+    // of a (kx, ci) pair up against the gradient pair {d.x, d.y} with the input value broadcast (op_sel), output co2 of
+    // (ci0, ci1) pairs up against the input pair {w.x, w.y} with d.z broadcast, (ci2, co2) stays scalar.  Same products in the
+    // same order per accumulator as the scalar form.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 a01[KS][3], a2p[KS];
+    float a22[KS];
 #pragma unroll
-    for (int a = 0; a < KS; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) acc[a][b][c] = 0.f;
+    for (int a = 0; a < KS; ++a) {
+        a01[a][0] = a01[a][1] = a01[a][2] = a2p[a] = f32x2{0.f, 0.f};
+        a22[a] = 0.f;
+    }
     float px[NXP][3], pd[NDP][3];
     auto fetch = [&](long t) {
         const int n = (int)(t / (p.tiles_y * p.tiles_x)), tile = (int)(t % (p.tiles_y * p.tiles_x));
@@ -283,21 +288,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_c3k5_kernel(const TinyWPara
                 for (int k = 0; k < KS - 1; ++k) w[k] = w[k + 1];
                 w[KS - 1] = xr[c + KS - 1];
                 const float4 d = dr[c];
+                const f32x2 d01 = {d.x, d.y}, dzz = {d.z, d.z};
 #pragma unroll
                 for (int kx = 0; kx < KS; ++kx) {
-                    acc[kx][0][0] = fmaf(w[kx].x, d.x, acc[kx][0][0]);
-                    acc[kx][0][1] = fmaf(w[kx].x, d.y, acc[kx][0][1]);
-                    acc[kx][0][2] = fmaf(w[kx].x, d.z, acc[kx][0][2]);
-                    acc[kx][1][0] = fmaf(w[kx].y, d.x, acc[kx][1][0]);
-                    acc[kx][1][1] = fmaf(w[kx].y, d.y, acc[kx][1][1]);
-                    acc[kx][1][2] = fmaf(w[kx].y, d.z, acc[kx][1][2]);
-                    acc[kx][2][0] = fmaf(w[kx].z, d.x, acc[kx][2][0]);
-                    acc[kx][2][1] = fmaf(w[kx].z, d.y, acc[kx][2][1]);
-                    acc[kx][2][2] = fmaf(w[kx].z, d.z, acc[kx][2][2]);
+                    a01[kx][0] = __builtin_elementwise_fma(f32x2{w[kx].x, w[kx].x}, d01, a01[kx][0]);
+                    a01[kx][1] = __builtin_elementwise_fma(f32x2{w[kx].y, w[kx].y}, d01, a01[kx][1]);
+                    a01[kx][2] = __builtin_elementwise_fma(f32x2{w[kx].z, w[kx].z}, d01, a01[kx][2]);
+                    a2p[kx] = __builtin_elementwise_fma(f32x2{w[kx].x, w[kx].y}, dzz, a2p[kx]);
+                    a22[kx] = fmaf(w[kx].z, d.z, a22[kx]);
                 }
             }
         }
     }
+    float acc[KS][3][3];
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) {
+            acc[kx][ci][0] = a01[kx][ci][0];
+            acc[kx][ci][1] = a01[kx][ci][1];
+            acc[kx][ci][2] = ci < 2 ? a2p[kx][ci] : a22[kx];
+        }
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem4);              // [45][240]
     if (active) {

@@ -256,9 +256,18 @@ __global__ void cdgrad_border_kernel(const float* __restrict__ dc, const float* 
 // no gather, no conversion, no packing.  Slot order: k-steps 0..4 = kernel rows (lane half h takes kx = 2h, 2h+1), k-step 5
 // = column kx = 4 of rows 2h, 2h+1, k-step 6 = tap (4,4): inside a k-step the two lane halves differ by ONE constant LDS
 // offset, so three per-lane base addresses serve every read.
-// Output layout D^T (couts along the accumulator registers, pixels along the lanes): the 2x2 pool is one DPP exchange with
-// the neighbouring lane plus the second output row's accumulator - no LDS turn-around; v_permlane32_swap then leaves every even
-// lane with 16 consecutive channels of one pooled pixel = 16-byte stores (pooled bf16 / float32 and the arg-max bytes).
+// Output layout D^T (couts along the accumulator registers, pixels along the lanes).  A unit is 2 output rows x 64 columns in
+// FOUR accumulators: lane column nl computes pixel columns 2 nl and 2 nl + 1 (the B operand of the odd column is the even
+// column's window one pixel on: 3 reads serve both), so the whole 2x2 pooling window of 16 output channels sits in ONE lane -
+// 9 compare / select instructions per pooled value, no lane exchange, nothing computed twice (the first version pooled through
+// a DPP exchange with the neighbouring lane, both lanes of a pair doing the same 17 instructions per value: the kernel was
+// bound by VALU issue, 394 instructions per 64 pixels; now ~150).  LeakyReLU is monotonic (0 < alpha <= 1, checked by the entry
+// point), so the window is pooled on the raw sums and bias + activation are applied to the winner only.  The weight rows are
+// permuted (MFMA row m <-> output channel 16 ((m >> 2) & 1) + 4 (m >> 3) + (m & 3)) so that a lane's 16 registers are 16
+// CONSECUTIVE channels of one pooled pixel: two 16-byte stores of bf16 values and one of arg-max bytes per lane, every lane.
+#ifndef CONV1_WGS
+#define CONV1_WGS 3       // resident workgroups per CU the register allocation of conv1_pool_fwd_kernel aims at (A/B: EXTRA=-DCONV1_WGS=2)
+#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -283,14 +292,14 @@ __device__ __forceinline__ void conv1_slot(int ks, int h, int j, int& ky, int& k
 }
 
 template <int TWD, bool OUT_BF16>
-__global__ __launch_bounds__(256) void conv1_pool_fwd_kernel(const void* __restrict__ c4, const float* __restrict__ w,
+__global__ __launch_bounds__(256, CONV1_WGS) void conv1_pool_fwd_kernel(const void* __restrict__ c4, const float* __restrict__ w,
                                                              const float* __restrict__ bias, void* __restrict__ pooled,
                                                              unsigned char* __restrict__ pidx, int N, int H, int W,
                                                              float alpha, int tiles_y, int tiles_x) {
     constexpr int TRD = 8, HR = TRD + 4, HC = TWD + 4, NPC = HC / 2;            // tile rows / halo rows / halo cols / pixel pairs
     constexpr int PT = NPC <= 64 ? 64 : 128, RG = 256 / PT, RPTS = (HR + RG - 1) / RG;
     constexpr int EXC = NPC > PT ? NPC - PT : 0, EXN = EXC * HR;
-    constexpr int UC = TWD / 32, UNITS = (TRD / 2) * UC;
+    constexpr int UC = TWD / 64, UNITS = (TRD / 2) * UC;
     constexpr unsigned OOB = 0x80000000u;
     static_assert(EXN <= 256 && HC % 2 == 0, "staging layout");
     __shared__ __attribute__((aligned(16))) uint4 tile[HR * NPC];                 // [row][pixel pair]: 8 B per pixel
@@ -298,7 +307,8 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_kernel(const void* __restr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles = tiles_y * tiles_x, total = N * tiles;
 
-    // A operand: this lane's cout m = nl, K values of the lane half, for the 7 k-steps
+    // A operand: MFMA row m = nl holds output channel co_a, K values of the lane half, for the 7 k-steps
+    const int co_a = 16 * ((nl >> 2) & 1) + 4 * (nl >> 3) + (nl & 3);
     bf16x8 wa[7];
 #pragma unroll
     for (int ks = 0; ks < 7; ++ks)
@@ -308,11 +318,11 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_kernel(const void* __restr
             conv1_slot(ks, h, j, ky, kx);
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                wa[ks][4 * j + c] = (__bf16)((ky >= 0 && c < 3) ? w[((ky * 5 + kx) * 3 + c) * 32 + nl] : 0.f);
+                wa[ks][4 * j + c] = (__bf16)((ky >= 0 && c < 3) ? w[((ky * 5 + kx) * 3 + c) * 32 + co_a] : 0.f);
         }
-    float br[16];                                     // bias of the 16 couts this lane's accumulator registers hold
+    float br[16];                                     // bias of the 16 couts this lane's accumulator registers hold: 16 h + r
 #pragma unroll
-    for (int r = 0; r < 16; ++r) br[r] = bias ? bias[(r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
+    for (int r = 0; r < 16; ++r) br[r] = bias ? bias[16 * h + r] : 0.f;
 
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(c4), 0, (int)((long)N * H * W * 8),
                                                                          0x00020000);
@@ -357,84 +367,80 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_kernel(const void* __restr
         const unsigned char* tb = reinterpret_cast<const unsigned char*>(tile);
         for (int u = wave; u < UNITS; u += 4) {
             const int ur = u / UC, uc = u % UC;
-            // pixel (row 2ur [+1], column 32uc + nl) tap (ky, kx) sits at tile[(2ur [+1] + ky)][32uc + nl + kx]
-            const int a0 = ((2 * ur) * HC + 32 * uc + nl) * 8;
+            // pixel (row 2ur [+1], column 64uc + 2nl [+1]) tap (ky, kx) sits at tile[(2ur [+1] + ky)][64uc + 2nl [+1] + kx]
+            const int a0 = ((2 * ur) * HC + 64 * uc + 2 * nl) * 8;
             const int baseA = a0 + h * 16, baseB = a0 + h * (2 * HC * 8);
-            f32x16 acc0, acc1;
+            f32x16 acc[2][2];                                      // [output row][column parity]
+            auto rd = [&](int off) { return *reinterpret_cast<const u32x2*>(tb + off); };
+            auto op = [](u32x2 lo, u32x2 hi) {
+                u32x4 b;
+                b[0] = lo[0]; b[1] = lo[1]; b[2] = hi[0]; b[3] = hi[1];
+                return *reinterpret_cast<const bf16x8*>(&b);
+            };
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = br[r];
+            for (int ks = 0; ks < 7; ++ks)
 #pragma unroll
-            for (int ks = 0; ks < 7; ++ks) {
-                int o0, o1, base;
-                if (ks < 5) { base = baseA; o0 = (ks * HC) * 8; o1 = o0 + 8; }
-                else if (ks == 5) { base = baseB; o0 = 4 * 8; o1 = (HC + 4) * 8; }
-                else { base = a0; o0 = o1 = (4 * HC + 4) * 8; }
-                u32x4 b0, b1;
-                const u32x2 p00 = *reinterpret_cast<const u32x2*>(tb + base + o0);
-                const u32x2 p01 = *reinterpret_cast<const u32x2*>(tb + base + o1);
-                const u32x2 p10 = *reinterpret_cast<const u32x2*>(tb + base + o0 + HC * 8);
-                const u32x2 p11 = *reinterpret_cast<const u32x2*>(tb + base + o1 + HC * 8);
-                b0[0] = p00[0]; b0[1] = p00[1]; b0[2] = p01[0]; b0[3] = p01[1];
-                b1[0] = p10[0]; b1[1] = p10[1]; b1[2] = p11[0]; b1[3] = p11[1];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks], *reinterpret_cast<const bf16x8*>(&b0), acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks], *reinterpret_cast<const bf16x8*>(&b1), acc1, 0, 0, 0);
-            }
-            // bias is in the accumulator already; LeakyReLU, then the 2x2 window = {own, lane^1} x {row 0, row 1}: the even lane
-            // of a pair sees it in window order (first maximum wins, like nimg_maxpool2_fwd) and keeps the result
+                for (int row = 0; row < 2; ++row) {
+                    bf16x8 b0, b1;                                 // B operands of the even / odd pixel column
+                    if (ks < 5) {                                  // taps kx = 2h, 2h + 1 (even column) / one pixel on (odd column)
+                        const int o = baseA + (ks + row) * HC * 8;
+                        const u32x2 q0 = rd(o), q1 = rd(o + 8), q2 = rd(o + 16);
+                        b0 = op(q0, q1);
+                        b1 = op(q1, q2);
+                    } else if (ks == 5) {                          // kx = 4 of kernel rows 2h, 2h + 1
+                        const int o = baseB + row * HC * 8 + 4 * 8;
+                        b0 = op(rd(o), rd(o + HC * 8));
+                        b1 = op(rd(o + 8), rd(o + HC * 8 + 8));
+                    } else {                                       // tap (4, 4)
+                        const int o = a0 + ((4 + row) * HC + 4) * 8;
+                        const u32x2 q0 = rd(o), q1 = rd(o + 8);
+                        b0 = op(q0, q0);
+                        b1 = op(q1, q1);
+                    }
+                    if (ks == 0) {
+                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[row][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0], b0, zero, 0, 0, 0);
+                        acc[row][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0], b1, zero, 0, 0, 0);
+                    } else {
+                        acc[row][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks], b0, acc[row][0], 0, 0, 0);
+                        acc[row][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks], b1, acc[row][1], 0, 0, 0);
+                    }
+                }
+            // the 2x2 window in window order (top-left, top-right, bottom-left, bottom-right): the first maximum wins, like
+            // nimg_maxpool2_fwd; compare + select throughout (each compare also yields the arg-max bit)
             float mx[16];
             unsigned kk[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                // compare + select throughout (each compare also yields the arg-max bit; fmaxf would add a canonicalising
-                // v_max per accumulator / DPP value under IEEE mode)
-                const float z0 = acc0[r], z1 = acc1[r];
-                const float v0 = z0 > 0.f ? z0 : alpha * z0, v1 = z1 > 0.f ? z1 : alpha * z1;
-                const float q0 = dpp_swap1(v0), q1 = dpp_swap1(v1);
-                const bool rt = q0 > v0, rb = q1 > v1;
-                const float mt = rt ? q0 : v0, mb = rb ? q1 : v1;
+                const float tl = acc[0][0][r], tr = acc[0][1][r], bl = acc[1][0][r], bq = acc[1][1][r];
+                const bool rt = tr > tl, rb = bq > bl;
+                const float mt = rt ? tr : tl, mb = rb ? bq : bl;
                 const unsigned kt = rt ? 1u : 0u, kb = rb ? 3u : 2u;
                 const bool bot = mb > mt;
-                mx[r] = bot ? mb : mt;
+                const float v = (bot ? mb : mt) + br[r];
+                mx[r] = __builtin_fmaxf(v, alpha * v);            // LeakyReLU, 0 < alpha <= 1
                 kk[r] = bot ? kb : kt;
             }
-            // registers 0..7 = couts {0-3, 8-11} + 4h, 8..15 = {16-19, 24-27} + 4h.  Swapping the upper group of the low lane
-            // half with the lower group of the high half leaves lane half h with the 16 couts 16h .. 16h+15, in memory order
-            unsigned ib[4];
+            const int py = (y0 + 2 * ur) >> 1, px = ((x0 + 64 * uc) >> 1) + nl;
+            if (py < Hp && px < Wp) {
+                const long po = ((long)(n * Hp + py) * Wp + px) * 32 + 16 * h;
+                if (pidx) {
+                    unsigned ib[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) ib[g] = kk[4 * g] | (kk[4 * g + 1] << 8) | (kk[4 * g + 2] << 16) | (kk[4 * g + 3] << 24);
-            const int py = ((y0 + 2 * ur) >> 1), px = (x0 + 32 * uc + nl) >> 1;
-            const bool st = ((lane & 1) == 0) && py < Hp && px < Wp;
-            const long po = ((long)(n * Hp + py) * Wp + px) * 32 + 16 * h;
-            {
-                u32x2 s0 = __builtin_amdgcn_permlane32_swap(ib[0], ib[2], false, false);
-                u32x2 s1 = __builtin_amdgcn_permlane32_swap(ib[1], ib[3], false, false);
-                // permlane32_swap(L, U): lanes 32-63 of L <-> lanes 0-31 of U.  Low half: L' = own lower group, U' = the high
-                // half's lower group; high half: L' = the low half's upper group, U' = own upper group - memory order L', U'
-                if (st && pidx) *reinterpret_cast<uint4*>(pidx + po) = make_uint4(s0[0], s0[1], s1[0], s1[1]);
-            }
-            if constexpr (OUT_BF16) {
-                unsigned pb[8];
-#pragma unroll
-                for (int g = 0; g < 8; ++g) pb[g] = pk_bf16(mx[2 * g], mx[2 * g + 1]);
-                u32x2 s[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) s[g] = __builtin_amdgcn_permlane32_swap(pb[g], pb[g + 4], false, false);
-                if (st) {
-                    uint4* d = reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(pooled) + po);
-                    d[0] = make_uint4(s[0][0], s[1][0], s[0][1], s[1][1]);
-                    d[1] = make_uint4(s[2][0], s[3][0], s[2][1], s[3][1]);
+                    for (int g = 0; g < 4; ++g) ib[g] = kk[4 * g] | (kk[4 * g + 1] << 8) | (kk[4 * g + 2] << 16) | (kk[4 * g + 3] << 24);
+                    *reinterpret_cast<uint4*>(pidx + po) = make_uint4(ib[0], ib[1], ib[2], ib[3]);
                 }
-            } else {
-                u32x2 s[8];
+                if constexpr (OUT_BF16) {
+                    unsigned pb[8];
 #pragma unroll
-                for (int g = 0; g < 8; ++g)
-                    s[g] = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx[g]), __float_as_uint(mx[g + 8]), false, false);
-                if (st) {
-                    uint4* d = reinterpret_cast<uint4*>(reinterpret_cast<float*>(pooled) + po);
-                    d[0] = make_uint4(s[0][0], s[1][0], s[2][0], s[3][0]);
-                    d[1] = make_uint4(s[0][1], s[1][1], s[2][1], s[3][1]);
-                    d[2] = make_uint4(s[4][0], s[5][0], s[6][0], s[7][0]);
-                    d[3] = make_uint4(s[4][1], s[5][1], s[6][1], s[7][1]);
+                    for (int g = 0; g < 8; ++g) pb[g] = pk_bf16(mx[2 * g], mx[2 * g + 1]);
+                    uint4* d = reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(pooled) + po);
+                    d[0] = make_uint4(pb[0], pb[1], pb[2], pb[3]);
+                    d[1] = make_uint4(pb[4], pb[5], pb[6], pb[7]);
+                } else {
+                    float4* d = reinterpret_cast<float4*>(reinterpret_cast<float*>(pooled) + po);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) d[g] = make_float4(mx[4 * g], mx[4 * g + 1], mx[4 * g + 2], mx[4 * g + 3]);
                 }
             }
         }
@@ -781,7 +787,7 @@ int launch_conv1_pool(const void* c4, const float* w, const float* bias, void* p
     const int tiles_y = cdiv(h, 8), tiles_x = cdiv(wd, TWD);
     const long total = (long)n * tiles_y * tiles_x;
     static const int capmul = getenv("NIMG_CONV1_CAP") ? atoi(getenv("NIMG_CONV1_CAP")) : 0;
-    const long cap = 256L * (capmul > 0 ? capmul : 3);       // persistent: 3 workgroups per CU are resident (167 registers per lane)
+    const long cap = 256L * (capmul > 0 ? capmul : CONV1_WGS);      // persistent: the resident workgroups (167 registers per lane)
     const dim3 grid((unsigned)(total < cap ? total : cap));
     if (out_bf16)
         hipLaunchKernelGGL((conv1_pool_fwd_kernel<TWD, true>), grid, dim3(256), 0, s, c4, w, bias, pooled, pidx, n, h, wd, alpha,

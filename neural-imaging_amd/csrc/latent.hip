@@ -10,6 +10,7 @@
 // those 2^bpf numbers.  Under data parallelism the partial histograms are what gets all-reduced.
 #include <stdlib.h>
 
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -76,6 +77,78 @@ __global__ void zero_insert2_kernel(const float* __restrict__ in, float* __restr
         const int Y = (int)(r % (2 * h));
         const long im = r / (2 * h);
         out[i] = ((X | Y) & 1) ? 0.f : in[((im * h + (Y >> 1)) * w + (X >> 1)) * c + ch];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// A 5x5 stride-2 TF-SAME convolution over an even-sized image IS a 3x3 stride-1 SAME convolution over its space-to-depth image
+// (block (by, bx) = input pixels (2by + pr, 2bx + pc), channel (pr, pc, ci)): output row oy reads input rows 2oy - 1 .. 2oy + 3 =
+// blocks oy - 1 (phase 1), oy (phases 0, 1), oy + 1 (phases 0, 1), i.e. tap ky = 2 dy + pr - 1 of block offset dy in 0..2
+// (the combination dy = 0, pr = 0 does not exist: a zero weight); the zero padding of the block image is TF's (1, 2) padding.
+// The strided layers of the codec (models/compression.py:217-229) run through the stride-1 MFMA kernels this way - the first one
+// (3 input channels: 12 of 16 block channels) in forward, weight gradient and input gradient, the others in the input gradient,
+// which otherwise is a stride-1 correlation over a zero-stuffed gradient (4x the products and a 4x larger tensor).
+//   s2d2_affine_bf16:      y[by][bx][(2 pr + pc) c + ci] = bf16(a x[2by + pr][2bx + pc][ci] + b), channels >= 4c zero
+//   s2d_conv_weights:      w3[dy][dx][(2 pr + pc) c + ci][co] = w5[2dy + pr - 1][2dx + pc - 1][ci][co] (0 outside 0..4)
+//   s2d_conv_weights_bwd:  the gather back, dw5[ky][kx][ci][co] (+)= dw3[...]
+//   d2s2_scale:            x[2by + pr][2bx + pc][ci] = scale * xs[by][bx][(2 pr + pc) c + ci]
+__global__ void s2d2_affine_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y, int n, int h, int w, int c, int cp,
+                                        float a, float b) {
+    const int hb = h >> 1, wb = w >> 1;
+    const long total = (long)n * hb * wb * cp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % cp);
+        long r = i / cp;
+        const int bx = (int)(r % wb);
+        r /= wb;
+        const int by = (int)(r % hb);
+        const long im = r / hb;
+        float v = 0.f;
+        if (q < 4 * c) {
+            const int ph = q / c, ci = q % c;
+            v = fmaf(a, x[((im * h + 2 * by + (ph >> 1)) * w + 2 * bx + (ph & 1)) * c + ci], b);
+        }
+        y[i] = (__bf16)v;
+    }
+}
+
+__global__ void s2d_conv_weights_kernel(const float* __restrict__ w5, float* __restrict__ w3, int c, int cp, int cout) {
+    const int total = 9 * cp * cout;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int co = i % cout, q = (i / cout) % cp, tap = i / (cout * cp);
+        float v = 0.f;
+        if (q < 4 * c) {
+            const int ph = q / c, ci = q % c;
+            const int ky = 2 * (tap / 3) + (ph >> 1) - 1, kx = 2 * (tap % 3) + (ph & 1) - 1;
+            if (ky >= 0 && kx >= 0) v = w5[((ky * 5 + kx) * c + ci) * cout + co];
+        }
+        w3[i] = v;
+    }
+}
+
+__global__ void s2d_conv_weights_bwd_kernel(const float* __restrict__ dw3, float* __restrict__ dw5, int c, int cp, int cout,
+                                            int accumulate) {
+    const int total = 25 * c * cout;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int co = i % cout, ci = (i / cout) % c, kx = (i / (cout * c)) % 5, ky = i / (cout * c * 5);
+        const int dy = (ky + 1) >> 1, pr = (ky + 1) & 1, dx = (kx + 1) >> 1, pc = (kx + 1) & 1;
+        const float v = dw3[(((dy * 3 + dx) * cp) + (2 * pr + pc) * c + ci) * cout + co];
+        dw5[i] = accumulate ? dw5[i] + v : v;
+    }
+}
+
+__global__ void d2s2_scale_kernel(const float* __restrict__ xs, float* __restrict__ x, int n, int h, int w, int c, int cp,
+                                  float scale) {
+    const int hb = h >> 1, wb = w >> 1;
+    const long total = (long)n * h * w * c;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % c);
+        long r = i / c;
+        const int px = (int)(r % w);
+        r /= w;
+        const int py = (int)(r % h);
+        const long im = r / h;
+        x[i] = scale * xs[((im * hb + (py >> 1)) * wb + (px >> 1)) * cp + (2 * (py & 1) + (px & 1)) * c + ci];
     }
 }
 
@@ -164,6 +237,138 @@ __global__ __launch_bounds__(256) void soft_codebook_fwd_kernel(const float* __r
     }
     __syncthreads();
     if (threadIdx.x < K) hist_partial[(long)blockIdx.x * K + threadIdx.x] = sh[threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same two kernels for the case every trained codec uses (t-Student kernel with an integer v + 1, tf_helpers.py:290,321),
+// with the codebook size as a template parameter.  The generic kernels above index `double w[64]` / `hacc[64]` with run-time
+// loops, which puts 1.5 KB per thread into scratch memory, divide by S once per centre, and take a square root and a division
+// per weight; they cost 0.99 + 0.90 ms per training step of the codec at B = 50 (16 % of it).  Here
+//   * base^-(m/2) = r^m with r = base^-1/2 from v_rsq_f32 refined by two Newton steps in float64 (error ~1e-16 before the
+//     powering, <= 1e-14 after it) and the powering a run of wave-uniform multiplies - no division, no square root;
+//   * everything the outputs need is a running sum (S, sum w c, arg max; in the backward sum dH dw, sum dH w, sum c dw, sum c w),
+//     the only arrays - the weights at the latent value and the per-thread histogram - are fully unrolled registers;
+//   * one reciprocal of S per latent value.
+__device__ __forceinline__ double rsqrt_refined(double x) {
+    double r = (double)__builtin_amdgcn_rsqf((float)x);       // 1 ulp of float32; x >= 1 here, +inf gives 0 (weight 0)
+    r = r * __builtin_fma(-0.5 * x, r * r, 1.5);
+    r = r * __builtin_fma(-0.5 * x, r * r, 1.5);
+    return r;
+}
+__device__ __forceinline__ double pow_int(double r, int m) {  // r^m, m wave-uniform, m >= 1
+    double acc = (m & 1) ? r : 1.0, b = r;
+    for (int n = m >> 1; n > 0; n >>= 1) {
+        b *= b;
+        if (n & 1) acc *= b;
+    }
+    return acc;
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void soft_codebook_fwd_fast_kernel(const float* __restrict__ z, const float* __restrict__ scale,
+                                                                     const float* __restrict__ cb, int m, double inv_v,
+                                                                     double gamma, float* __restrict__ latent,
+                                                                     double* __restrict__ hist_partial, long count,
+                                                                     int soft_codebook) {
+    __shared__ double sh[K];
+    if (threadIdx.x < K) sh[threadIdx.x] = 0.0;
+    __syncthreads();
+    const float s = scale ? scale[0] : 1.0f;
+    double hacc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) hacc[k] = 0.0;
+    auto weight = [&](double u, int k) {                                     // cb[k]: wave-uniform, read through the scalar cache
+        const double t = gamma * (u - (double)cb[k]);
+        return pow_int(rsqrt_refined(__builtin_fma(t * t, inv_v, 1.0)), m) + 1e-72;
+    };
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        const float zs = z[i] * s;                                           // layers.py:197-198 (float32 product)
+        float lat = zs;
+        if (soft_codebook) {
+            double S = 0.0, wc = 0.0, best = -1.0;
+            float hard = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const double w = weight((double)zs, k);
+                S += w;
+                wc = __builtin_fma(w, (double)cb[k], wc);
+                if (w > best) { best = w; hard = cb[k]; }                    // first maximum, like tf.argmax
+            }
+            const float softf = (float)(wc / S), hardf = hard;
+            lat = (hardf - softf) + softf;                                   // stop_gradient(hard - soft) + soft
+        }
+        latent[i] = lat;
+        double w[K], S = 0.0;                                                // entropy(latent, codebook), layers.py:201
+#pragma unroll
+        for (int k = 0; k < K; ++k) { w[k] = weight((double)lat, k); S += w[k]; }
+        const double inv = 1.0 / S;
+#pragma unroll
+        for (int k = 0; k < K; ++k) hacc[k] = __builtin_fma(w[k], inv, hacc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const double t = wave_sum_d(hacc[k]);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&sh[k], t);                   // LDS float64 atomics, 4 waves
+    }
+    __syncthreads();
+    if (threadIdx.x < K) hist_partial[(long)blockIdx.x * K + threadIdx.x] = sh[threadIdx.x];
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void soft_codebook_bwd_fast_kernel(const float* __restrict__ z, const float* __restrict__ scale,
+                                                                     const float* __restrict__ latent,
+                                                                     const float* __restrict__ dlat,
+                                                                     const double* __restrict__ dH_dsum, float coef,
+                                                                     const float* __restrict__ cb, int m, double inv_v,
+                                                                     double gamma, float* __restrict__ dz,
+                                                                     double* __restrict__ dscale_partial, long count,
+                                                                     int soft_codebook) {
+    __shared__ double red[4];
+    const float s = scale ? scale[0] : 1.0f;
+    const double dfac = -(double)m * inv_v * gamma;                          // d w / d u = w * dfac * t / base = w * dfac * t * r^2
+    // sums over the centres at u: S = sum w, dS = sum dw, A = sum q dw, B = sum q w  ->  sum q d(w / S)/du = A / S - B dS / S^2
+    // with q = dH/dsum (entropy term) or q = the centres (soft value); both tables are wave-uniform (scalar cache)
+    auto sums = [&](double u, auto use_dh) {
+        double S = 0.0, dS = 0.0, A = 0.0, B = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const double ck = (double)cb[k];
+            const double qk = decltype(use_dh)::value ? dH_dsum[k] : ck;
+            const double t = gamma * (u - ck);
+            const double r = rsqrt_refined(__builtin_fma(t * t, inv_v, 1.0));
+            const double w0 = pow_int(r, m);
+            const double dw = w0 * (dfac * t) * (r * r);
+            const double w = w0 + 1e-72;
+            S += w; dS += dw;
+            A = __builtin_fma(qk, dw, A);
+            B = __builtin_fma(qk, w, B);
+        }
+        const double inv = 1.0 / S;
+        return (A - B * dS * inv) * inv;
+    };
+    double dsum = 0.0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        double g = dlat ? (double)dlat[i] : 0.0;
+        if (coef != 0.f) g += (double)coef * sums((double)latent[i], std::true_type{});
+        const float zs = z[i] * s;
+        const double dsoft = soft_codebook ? sums((double)zs, std::false_type{}) : 1.0;
+        const double gz = g * dsoft;                 // gradient w.r.t. zs = scale * z
+        dz[i] = (float)(gz * (double)s);
+        dsum += gz * (double)z[i];
+    }
+    dsum = wave_sum_d(dsum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dsum;
+    __syncthreads();
+    if (threadIdx.x == 0) dscale_partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// the fast kernels serve power-of-two codebooks of 8 .. 32 centres (3 .. 5 bits per feature; the reference trains 5) under the
+// t-Student kernel with an integer v + 1; anything else runs the generic kernels.  NIMG_LATENT_GENERIC=1: always generic (A/B)
+inline int fast_exponent(int K, double v) {
+    static const bool generic = getenv("NIMG_LATENT_GENERIC") != nullptr;
+    const double m = v + 1.0;
+    if (generic || !(K == 8 || K == 16 || K == 32) || !(v > 0.0) || m > 1024.0 || m != floor(m)) return 0;
+    return (int)m;
 }
 
 // hist_sum[k] = sum_blocks partial (fixed order)
@@ -347,6 +552,40 @@ int nimg_pad2d(const float* x, float* y, int n, int h, int w, int c, int pad, in
     return NIMG_OK;
 }
 
+int nimg_s2d2_affine_bf16(const float* x, void* y, int n, int h, int w, int c, int cp, float a, float b, void* stream) {
+    if (n == 0) return NIMG_OK;
+    if (!x || !y || n < 0 || h < 2 || w < 2 || (h & 1) || (w & 1) || c < 1 || cp < 4 * c) return NIMG_ERR_ARG;
+    hipLaunchKernelGGL(s2d2_affine_bf16_kernel, dim3(grid_for((long)n * (h / 2) * (w / 2) * cp)), dim3(256), 0, (hipStream_t)stream,
+                       x, (__bf16*)y, n, h, w, c, cp, a, b);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_s2d_conv_weights(const float* w5, float* w3, int cin, int cp, int cout, void* stream) {
+    if (!w5 || !w3 || cin < 1 || cp < 4 * cin || cout < 1) return NIMG_ERR_ARG;
+    hipLaunchKernelGGL(s2d_conv_weights_kernel, dim3(grid_for(9L * cp * cout)), dim3(256), 0, (hipStream_t)stream, w5, w3, cin, cp,
+                       cout);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_s2d_conv_weights_bwd(const float* dw3, float* dw5, int cin, int cp, int cout, int accumulate, void* stream) {
+    if (!dw3 || !dw5 || cin < 1 || cp < 4 * cin || cout < 1) return NIMG_ERR_ARG;
+    hipLaunchKernelGGL(s2d_conv_weights_bwd_kernel, dim3(grid_for(25L * cin * cout)), dim3(256), 0, (hipStream_t)stream, dw3, dw5,
+                       cin, cp, cout, accumulate);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_d2s2_scale(const float* xs, float* x, int n, int h, int w, int c, int cp, float scale, void* stream) {
+    if (n == 0) return NIMG_OK;
+    if (!xs || !x || n < 0 || h < 2 || w < 2 || (h & 1) || (w & 1) || c < 1 || cp < 4 * c) return NIMG_ERR_ARG;
+    hipLaunchKernelGGL(d2s2_scale_kernel, dim3(grid_for((long)n * h * w * c)), dim3(256), 0, (hipStream_t)stream, xs, x, n, h, w, c,
+                       cp, scale);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
 int nimg_zero_insert2(const float* in, float* out, int n, int h, int w, int c, void* stream) {
     if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!in || !out || n < 0 || h <= 0 || w <= 0 || c <= 0) return NIMG_ERR_ARG;
@@ -379,8 +618,20 @@ int nimg_latent_fwd(const float* z, const float* scale, const float* codebook, i
     double* part = (double*)workspace;
     double* hsum = part + 1024 * (size_t)K;
     double* dH = hsum + K;
-    hipLaunchKernelGGL(soft_codebook_fwd_kernel, dim3(grid), dim3(256), 0, s, z, scale, codebook, K, kernel_v(v),
-                       (double)gamma, latent, part, count, soft_codebook);
+    const double vd = kernel_v(v);
+    const int m = fast_exponent(K, vd);
+    if (m && K == 32)
+        hipLaunchKernelGGL(soft_codebook_fwd_fast_kernel<32>, dim3(grid), dim3(256), 0, s, z, scale, codebook, m, 1.0 / vd,
+                           (double)gamma, latent, part, count, soft_codebook);
+    else if (m && K == 16)
+        hipLaunchKernelGGL(soft_codebook_fwd_fast_kernel<16>, dim3(grid), dim3(256), 0, s, z, scale, codebook, m, 1.0 / vd,
+                           (double)gamma, latent, part, count, soft_codebook);
+    else if (m && K == 8)
+        hipLaunchKernelGGL(soft_codebook_fwd_fast_kernel<8>, dim3(grid), dim3(256), 0, s, z, scale, codebook, m, 1.0 / vd,
+                           (double)gamma, latent, part, count, soft_codebook);
+    else
+        hipLaunchKernelGGL(soft_codebook_fwd_kernel, dim3(grid), dim3(256), 0, s, z, scale, codebook, K, vd, (double)gamma,
+                           latent, part, count, soft_codebook);
     NIMG_CHECK_LAUNCH();
     hipLaunchKernelGGL(hist_reduce_kernel, dim3(1), dim3(1024), 0, s, (const double*)part, grid, K, hsum);
     NIMG_CHECK_LAUNCH();
@@ -415,9 +666,20 @@ int nimg_latent_bwd(const float* z, const float* scale, const float* latent, con
     double* part = (double*)workspace;
     double* dH = part + 1024 * (size_t)K + K;
     double* dsp = dH + K;
-    hipLaunchKernelGGL(soft_codebook_bwd_kernel, dim3(grid), dim3(256), 0, s, z, scale, latent, dlatent,
-                       (const double*)dH, entropy_coef, codebook, K, kernel_v(v), (double)gamma, dz, dsp, count,
-                       soft_codebook);
+    const double vd = kernel_v(v);
+    const int m = fast_exponent(K, vd);
+    if (m && K == 32)
+        hipLaunchKernelGGL(soft_codebook_bwd_fast_kernel<32>, dim3(grid), dim3(256), 0, s, z, scale, latent, dlatent,
+                           (const double*)dH, entropy_coef, codebook, m, 1.0 / vd, (double)gamma, dz, dsp, count, soft_codebook);
+    else if (m && K == 16)
+        hipLaunchKernelGGL(soft_codebook_bwd_fast_kernel<16>, dim3(grid), dim3(256), 0, s, z, scale, latent, dlatent,
+                           (const double*)dH, entropy_coef, codebook, m, 1.0 / vd, (double)gamma, dz, dsp, count, soft_codebook);
+    else if (m && K == 8)
+        hipLaunchKernelGGL(soft_codebook_bwd_fast_kernel<8>, dim3(grid), dim3(256), 0, s, z, scale, latent, dlatent,
+                           (const double*)dH, entropy_coef, codebook, m, 1.0 / vd, (double)gamma, dz, dsp, count, soft_codebook);
+    else
+        hipLaunchKernelGGL(soft_codebook_bwd_kernel, dim3(grid), dim3(256), 0, s, z, scale, latent, dlatent,
+                           (const double*)dH, entropy_coef, codebook, K, vd, (double)gamma, dz, dsp, count, soft_codebook);
     NIMG_CHECK_LAUNCH();
     if (dscale) {
         hipLaunchKernelGGL(dscale_final_kernel, dim3(1), dim3(64), 0, s, (const double*)dsp, grid, dscale,

@@ -18,7 +18,7 @@ import torch
 from .. import ops, parallel
 from ..device import DeviceArray, to_device
 from ..helpers import paramspec
-from .layers import Conv2D
+from .layers import Conv2D, Conv5x5Stride2Image
 from .tfmodel import ParamStore, TFModel
 
 
@@ -185,7 +185,7 @@ class TwitterDCN(DCN):
             self.latent_shape = (self.patch_size // 8, self.patch_size // 8, nf)
             self.n_latent = int(np.prod(self.latent_shape))
         L = OrderedDict()
-        L['e1'] = Conv2D('e1', 5, 3, 64, 'leaky_relu', stride=2)
+        L['e1'] = Conv5x5Stride2Image('e1', 5, 3, 64, 'leaky_relu', stride=2)
         L['e2'] = Conv2D('e2', 5, 64, 128, None, stride=2)
         for b in (1, 2, 3):
             L['er{}a'.format(b)] = Conv2D('er{}a'.format(b), 3, 128, 128, 'leaky_relu')
@@ -225,8 +225,8 @@ class TwitterDCN(DCN):
         L, P = self._layers, self._model
         P.refresh_images()
         t = OrderedDict()
-        t['x0'] = ops.affine(x, 2.0, -1.0)
-        t['e1'] = L['e1'].forward(P, t['x0'])
+        self._in_hw = (x.shape[1], x.shape[2])
+        t['e1'], t['x0'] = L['e1'].forward_image(P, x, 2.0, -1.0)       # x0 = 2 x - 1 (or its bf16 space-to-depth image)
         t['e2'] = L['e2'].forward(P, t['e1'])
         net = t['e2']
         t['n0'] = net
@@ -315,7 +315,7 @@ class TwitterDCN(DCN):
             d_net = ops.add(d_net, d_in)
         L['e2'].backward_params(P, et['e1'], d_net)
         dz1 = L['e2'].backward_input(P, d_net, hw(et['e1']), act_mask=et['e1'])
-        L['e1'].backward_params(P, et['x0'], dz1)
-        dx = ops.affine(L['e1'].backward_input(P, dz1, hw(et['x0'])), 2.0, 0.0) if need_input_grad else None
+        L['e1'].backward_params_image(P, et['x0'], dz1)
+        dx = L['e1'].backward_input_image(P, dz1, self._in_hw, 2.0) if need_input_grad else None
         ops.join_side_stream()
         return dx

@@ -60,6 +60,37 @@ class Conv2D(object):
                                 out=out, out2=out2, out_bf16=out_bf16)
 
 
+class Conv5x5Stride2Image(Conv2D):
+    """The codec's first layer, Conv2D(64, 5, strides=2, 'SAME') on the RGB image (models/compression.py:217): same (5,5,3,64)
+    kernel + bias parameters.  In throughput mode it runs as a 3x3 stride-1 convolution over the bf16 space-to-depth image of
+    a x + b (12 of 16 block channels, ops.s2d2_affine / s2d_conv_weights): forward, weight gradient (gathered back into the 5x5
+    layout) and input gradient all take the stride-1 MFMA kernels instead of the float32 small-channel ones (0.46 + 1.53 ms per
+    step at B = 50, and 3.2 ms for the zero-stuffed input gradient at B = 80).  Parity mode: the plain strided layer."""
+
+    def s2d_ok(self, x):
+        return ops.s2d_conv_ok(self.ks, self.stride, x.shape[1], x.shape[2], self.cin) and self.cin2 == 0 and 4 * self.cin <= 16
+
+    def forward_image(self, store, x, a, b):
+        """-> (y, ctx): the layer applied to a x + b; ctx is what the backward passes need (the block image or a x + b)."""
+        if not self.s2d_ok(x):
+            x0 = ops.affine(x, a, b)
+            return self.forward(store, x0), x0
+        xs = ops.s2d2_affine(x, a, b, cp=16)
+        w3 = ops.s2d_conv_weights(store.p[self.name + '/kernel'], cp=16)
+        return ops.conv2d(xs, w3, store.p[self.name + '/bias'], act=self.activation), xs
+
+    def backward_params_image(self, store, ctx, dz):
+        if ctx.dtype != torch.bfloat16:
+            return self.backward_params(store, ctx, dz)
+        with ops.side_stream(ctx, dz):
+            dw3 = ops.conv2d_wgrad(ctx, dz, 3, db=store.g[self.name + '/bias'])
+            ops.s2d_conv_weights_bwd(dw3, store.g[self.name + '/kernel'])
+
+    def backward_input_image(self, store, dz, in_hw, a):
+        """d loss / d x of y = layer(a x + b)."""
+        return ops.conv2d_dgrad_strided2(dz, store.p[self.name + '/kernel'], in_hw, scale=a)
+
+
 class Conv2DTranspose2x2(object):
     """Conv2DTranspose(cout, [2,2], [2,2], 'SAME'), kernel (2,2,Cout,Cin) + bias, no activation (pipelines.py:205)."""
 

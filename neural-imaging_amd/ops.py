@@ -802,6 +802,8 @@ def cconv3(x, w, pad_mode=1, out=None, want_f32=True, want_c4=False):
 # The row-band front-end kernels (csrc/frontend.hip) serve the FAN's standard first layer in throughput mode; NIMG_OLD_FRONTEND=1
 # keeps the generic small-channel kernels (A/B runs).
 FRONT_END = _os.environ.get('NIMG_OLD_FRONTEND') is None
+# 5x5 stride-2 layers as 3x3 stride-1 layers over the space-to-depth image (throughput mode); NIMG_NO_S2D_CONV=1: the strided kernels
+S2D_CONV = _os.environ.get('NIMG_NO_S2D_CONV') is None
 
 
 def front_end_ok(cin, cout, ks, h, w, n=None):
@@ -992,17 +994,71 @@ def zero_insert2(x):
     return y
 
 
-def conv2d_dgrad_strided2(dz, w, in_hw):
-    """Input gradient of a stride-2 TF-SAME convolution: zero insertion + stride-1 correlation with the flipped
-    kernel (pad = ks-1-pad_before)."""
+def s2d2_affine(x, a=1.0, b=0.0, cp=None):
+    """bf16 space-to-depth image (N,H/2,W/2,cp) of a x + b: block channel (2 pr + pc) C + ci = pixel (2by + pr, 2bx + pc)."""
+    _f32(x)
+    n, h, w, c = x.shape
+    cp = (4 * c + 15) // 16 * 16 if cp is None else cp
+    y = torch.empty((n, h // 2, w // 2, cp), dtype=torch.bfloat16, device=x.device)
+    _lib.call('nimg_s2d2_affine_bf16', _p(x), _p(y), n, h, w, c, cp, float(a), float(b), _stream())
+    return y
+
+
+def s2d_conv_weights(w5, cp=None):
+    """(5,5,Cin,Cout) kernel of a stride-2 SAME convolution -> the (3,3,cp,Cout) kernel of the equivalent stride-1 convolution
+    over the space-to-depth image."""
+    _f32(w5)
+    if w5.shape[0] != 5 or w5.shape[1] != 5:
+        raise ValueError('s2d_conv_weights: a 5x5 kernel expected')
+    cin, cout = w5.shape[2], w5.shape[3]
+    cp = (4 * cin + 15) // 16 * 16 if cp is None else cp
+    w3 = torch.empty((3, 3, cp, cout), dtype=torch.float32, device=w5.device)
+    _lib.call('nimg_s2d_conv_weights', _p(w5), _p(w3), cin, cp, cout, _stream())
+    return w3
+
+
+def s2d_conv_weights_bwd(dw3, dw5, accumulate=False):
+    _f32(dw3, dw5)
+    cp, cout = dw3.shape[2], dw3.shape[3]
+    cin = dw5.shape[2]
+    if tuple(dw3.shape[:2]) != (3, 3) or tuple(dw5.shape) != (5, 5, cin, cout) or cp < 4 * cin:
+        raise ValueError('s2d_conv_weights_bwd: (3,3,cp,Cout) -> (5,5,Cin,Cout) with cp >= 4 Cin')
+    _lib.call('nimg_s2d_conv_weights_bwd', _p(dw3), _p(dw5), cin, cp, cout, 1 if accumulate else 0, _stream())
+    return dw5
+
+
+def d2s2_scale(xs, c, scale=1.0):
+    """(N,H/2,W/2,cp) float32 block image -> scale * its depth-to-space image (N,H,W,c)."""
+    _f32(xs)
+    n, hb, wb, cp = xs.shape
+    x = torch.empty((n, 2 * hb, 2 * wb, c), dtype=torch.float32, device=xs.device)
+    _lib.call('nimg_d2s2_scale', _p(xs), _p(x), n, 2 * hb, 2 * wb, c, cp, float(scale), _stream())
+    return x
+
+
+def s2d_conv_ok(ks, stride, h, w, cin):
+    """A 5x5 stride-2 SAME layer over an even-sized image can run as a 3x3 stride-1 layer over the space-to-depth image."""
+    return COMPUTE == 'bf16' and S2D_CONV and ks == 5 and stride == 2 and h % 2 == 0 and w % 2 == 0 and cin >= 1
+
+
+def conv2d_dgrad_strided2(dz, w, in_hw, scale=1.0):
+    """Input gradient of a stride-2 TF-SAME convolution.  Throughput mode: the 3x3 stride-1 input gradient of the equivalent
+    convolution over the space-to-depth image, then depth-to-space (s2d_conv_weights).  Parity mode: zero insertion + stride-1
+    correlation with the flipped kernel (pad = ks-1-pad_before)."""
     ks = w.shape[0]
     h, wd = in_hw
+    cin = w.shape[2]
+    if s2d_conv_ok(ks, 2, h, wd, cin) and not _is_bf16(dz):
+        w3 = s2d_conv_weights(w)
+        dxs = conv2d_dgrad(dz, w3, (h // 2, wd // 2))
+        return d2s2_scale(dxs, cin, scale)
     _, pt = same_pads(h, ks, 2)
     _, pl = same_pads(wd, ks, 2)
     up = zero_insert2(dz)
     if up.shape[1] != h or up.shape[2] != wd:
         raise NotImplementedError('strided dgrad is built for even input sizes')
-    return conv2d(up, w, None, pads=(ks - 1 - pt, ks - 1 - pl), out_hw=(h, wd), _wmode=1)
+    d = conv2d(up, w, None, pads=(ks - 1 - pt, ks - 1 - pl), out_hw=(h, wd), _wmode=1)
+    return d if scale == 1.0 else affine(d, scale, 0.0)
 
 
 class LatentWorkspace(object):

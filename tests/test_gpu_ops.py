@@ -680,6 +680,54 @@ def test_latent_soft_codebook_and_entropy(dev):
     assert float(e0.item()) < 1e-4 and abs(float(e5.item()) - 5.0) < 1e-3
 
 
+@pytest.mark.parametrize('shape', [(2, 32, 48, 3, 64), (1, 16, 16, 8, 16), (2, 24, 40, 64, 32)])
+def test_stride2_conv_as_space_to_depth_conv(dev, shape):
+    """A 5x5 stride-2 TF-SAME layer evaluated as a 3x3 stride-1 layer over the space-to-depth image (csrc/latent.hip s2d kernels,
+    models/layers.py Conv5x5Stride2Image; models/compression.py:217-229): forward, weight / bias gradient and input gradient
+    against float64 autograd through the strided convolution on the same bf16-rounded operands."""
+    from neural_imaging_amd import ops
+    from neural_imaging_amd.models.layers import Conv5x5Stride2Image
+    from neural_imaging_amd.models.tfmodel import ParamStore
+    ops.set_compute('bf16')
+    try:
+        n, h, w, cin, cout = shape
+        img = rnd((n, h, w, cin), 31, 0.0, 1.0)
+        wk = rnd((5, 5, cin, cout), 32, -0.2, 0.2)
+        b = rnd((cout,), 33, -0.1, 0.1)
+        x0 = _bf16_round(2.0 * img.astype(np.float32) - 1.0).requires_grad_(True)        # what the bf16 block image holds
+        wr = _bf16_round(wk).requires_grad_(True)
+        bb = to64(b).requires_grad_(True)
+        ref = T.conv2d(x0, wr, bb, 2, 'SAME')
+        dz = rnd(tuple(ref.shape), 34)
+        (ref * to64(dz)).sum().backward()
+        # the weight transform and its adjoint
+        w3 = ops.s2d_conv_weights(g(wk, dev))
+        cp = w3.shape[2]
+        assert cp % 16 == 0 and cp >= 4 * cin and float(w3.abs().sum()) == pytest.approx(float(np.abs(wk).sum()), rel=1e-5)
+        probe = rnd((3, 3, cp, cout), 35)
+        back = ops.s2d_conv_weights_bwd(g(probe, dev), torch.zeros((5, 5, cin, cout), device=dev))
+        assert abs(float((w3 * g(probe, dev)).sum()) - float((back * g(wk, dev)).sum())) < 1e-3          # <T w, p> == <w, T^t p>
+        if cin == 3:
+            layer = Conv5x5Stride2Image('e1', 5, 3, cout, None, stride=2)
+            store = ParamStore(layer.specs(), dev)
+            store.p['e1/kernel'].copy_(g(wk, dev))
+            store.p['e1/bias'].copy_(g(b, dev))
+            y, ctx = layer.forward_image(store, g(img, dev), 2.0, -1.0)
+            assert ctx.dtype == torch.bfloat16 and tuple(ctx.shape) == (n, h // 2, w // 2, 16)
+            assert_close(y.cpu().numpy(), ref.detach().numpy(), 2e-3, 1e-3, what='s2d forward')
+            layer.backward_params_image(store, ctx, g(dz, dev))
+            ops.join_side_stream()
+            assert_close(store.g['e1/kernel'].cpu().numpy(), wr.grad.numpy(), 2e-3, 1e-2, what='s2d weight gradient')
+            assert_close(store.g['e1/bias'].cpu().numpy(), bb.grad.numpy(), 1e-4, 1e-3, what='s2d bias gradient')
+            dx = layer.backward_input_image(store, g(dz, dev), (h, w), 2.0)
+            assert_close(dx.cpu().numpy(), 2.0 * x0.grad.numpy(), 2e-3, 1e-2, what='s2d input gradient of the image layer')
+        else:
+            dxs = ops.conv2d_dgrad_strided2(g(dz, dev), g(wk, dev), (h, w))
+            assert_close(dxs.cpu().numpy(), x0.grad.numpy(), 2e-3, 1e-2, what='s2d input gradient')
+    finally:
+        ops.set_compute('f32')
+
+
 def test_strided_dgrad_and_codec_small_ops(dev):
     from neural_imaging_amd import ops
     n, h, w, cin, cout, ks = 2, 16, 24, 8, 16, 5
