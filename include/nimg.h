@@ -293,6 +293,12 @@ int nimg_isp_residual_bwd(const float* dy, const float* f, const float* alpha, f
 /* Dropout of the FAN's hidden Dense layers at training time (models/forensics.py:88), forward and backward alike:
  * y = keep[i] ? x[i] * scale : 0, keep = the Bernoulli(1 - rate) mask bytes, scale = 1 / (1 - rate). */
 int nimg_mask_scale(const float* x, const uint8_t* keep, float* y, long count, float scale, void* stream);
+/* nimg_conv2d_fwd_bf16_ex + `residual` (float32, the shape of out1) added after bias, activation and mask: a residual block's skip
+ * connection in the same pass (net + conv(a) forward, d_net + mask * dgrad backward; models/compression.py:224-227, 240-243).
+ * 3x3, stride 1, float32 output with o1 % 4 == 0. */
+int nimg_conv2d_fwd_bf16_res(const float* in1, int c1, const void* wb, const float* bias, float* out1, int o1,
+                             const float* act_mask, const float* residual, int n, int h, int wd, int ks, int pad_t, int pad_l,
+                             int pad_mode, int hout, int wout, int act, float alpha, int flags, void* stream);
 /* Backward of the FAN's fused conv + LeakyReLU + MaxPool2D layers conv2..4 (models/forensics.py:73-77) straight from the POOLED
  * gradient g (bf16, already x LeakyReLU') and the arg-max bytes: the MaxPool2D routing is applied while the kernels stage their
  * tiles, so the full-resolution gradient (4x the bytes, 3/4 zeros) is never written nor re-read.  5x5, stride 1, SAME.

@@ -235,8 +235,7 @@ class TwitterDCN(DCN):
             t['er{}in'.format(b)] = inp
             a = L['er{}a'.format(b)].forward(P, inp)
             t['er{}a'.format(b)] = a
-            r = L['er{}b'.format(b)].forward(P, a)
-            net = ops.add(net, r)
+            net = L['er{}b'.format(b)].forward(P, a, residual=net)          # net + conv(a), one pass
             t['n{}'.format(b)] = net
         t['zl'] = L['elat'].forward(P, net)
         if self._lws is None or self._lws.buf.device != x.device:
@@ -263,8 +262,7 @@ class TwitterDCN(DCN):
         for b in (1, 2, 3):
             a = L['dr{}a'.format(b)].forward(P, net)
             t['dr{}a'.format(b)] = a
-            r = L['dr{}b'.format(b)].forward(P, a)
-            net = ops.add(net, r)
+            net = L['dr{}b'.format(b)].forward(P, a, residual=net)
             t['i{}'.format(b)] = net
         t['d256'] = L['d256'].forward(P, net)
         t['i4'] = ops.d2s_clip(t['d256'], 1.0, 0.0, False)
@@ -294,7 +292,7 @@ class TwitterDCN(DCN):
             L['dr{}b'.format(b)].backward_params(P, a, d_net)
             dza = L['dr{}b'.format(b)].backward_input(P, d_net, hw(a), act_mask=a)
             L['dr{}a'.format(b)].backward_params(P, inp, dza)
-            d_net = ops.add(d_net, L['dr{}a'.format(b)].backward_input(P, dza, hw(inp)))
+            d_net = L['dr{}a'.format(b)].backward_input(P, dza, hw(inp), residual=d_net)
         dz = ops.d2s_clip_bwd(d_net, 1.0)
         L['d512'].backward_params(P, dt['latent'], dz)
         d_lat = L['d512'].backward_input(P, dz, hw(dt['latent']))
@@ -311,8 +309,8 @@ class TwitterDCN(DCN):
             dza = L['er{}b'.format(b)].backward_input(P, d_net, hw(a), act_mask=a)
             L['er{}a'.format(b)].backward_params(P, inp, dza)
             # block 1 was fed LeakyReLU(e2): its input gradient goes through that activation (mask by sign of e2)
-            d_in = L['er{}a'.format(b)].backward_input(P, dza, hw(inp), act_mask=et['e2'] if b == 1 else None)
-            d_net = ops.add(d_net, d_in)
+            d_net = L['er{}a'.format(b)].backward_input(P, dza, hw(inp), act_mask=et['e2'] if b == 1 else None,
+                                                        residual=d_net)
         L['e2'].backward_params(P, et['e1'], d_net)
         dz1 = L['e2'].backward_input(P, d_net, hw(et['e1']), act_mask=et['e1'])
         L['e1'].backward_params_image(P, et['x0'], dz1)

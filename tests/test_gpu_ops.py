@@ -728,6 +728,38 @@ def test_stride2_conv_as_space_to_depth_conv(dev, shape):
         ops.set_compute('f32')
 
 
+def test_conv3x3_with_fused_residual(dev):
+    """nimg_conv2d_fwd_bf16_res: the skip connection of a residual block added in the convolution's epilogue - forward
+    (net + conv(a) + bias) and input gradient (d_net + mask * dgrad) - equals the separate convolution followed by ops.add,
+    bit for bit; parity mode falls back to exactly that pair."""
+    from neural_imaging_amd import ops
+    n, h, w, c = 2, 24, 40, 32
+    x, r = g(rnd((n, h, w, c), 41), dev), g(rnd((n, h, w, c), 42), dev)
+    wk, b = g(rnd((3, 3, c, c), 43, -0.1, 0.1), dev), g(rnd((c,), 44, -0.1, 0.1), dev)
+    mask = g(rnd((n, h, w, c), 45), dev)
+    for mode in ('bf16', 'f32'):
+        ops.set_compute(mode)
+        try:
+            plain = ops.conv2d(x, wk, b)
+            fused = ops.conv2d(x, wk, b, residual=r)
+            assert torch.equal(fused, plain + r), mode
+            dplain = ops.conv2d_dgrad(x, wk, (h, w), act_mask=mask)
+            dfused = ops.conv2d_dgrad(x, wk, (h, w), act_mask=mask, residual=r)
+            assert torch.equal(dfused, dplain + r), mode
+        finally:
+            ops.set_compute('f32')
+    ops.set_compute('bf16')
+    try:
+        with pytest.raises(RuntimeError):           # the C ABI refuses shapes the fused epilogue does not serve
+            from neural_imaging_amd import _lib
+            wb = ops.weights_bf16(g(rnd((5, 5, c, c), 46), dev), 0)
+            out = torch.empty_like(x)
+            _lib.call('nimg_conv2d_fwd_bf16_res', x.data_ptr(), c, wb.data_ptr(), None, out.data_ptr(), c, None, r.data_ptr(), n, h,
+                      w, 5, 2, 2, 0, h, w, 0, 0.2, 0, torch.cuda.current_stream().cuda_stream)
+    finally:
+        ops.set_compute('f32')
+
+
 def test_strided_dgrad_and_codec_small_ops(dev):
     from neural_imaging_amd import ops
     n, h, w, cin, cout, ks = 2, 16, 24, 8, 16, 5
