@@ -1333,6 +1333,85 @@ def test_twitter_dcn_at_256(dev):
     assert abs(float(l2.item()) + 250.0 * float(ent.item()) - loss_ref) / loss_ref < 1e-4
 
 
+def test_full_channel_smooth_variant_bf16_gradient_directions(dev):
+    """configs[4] with every ill-conditioned or hard decision taken out of the channel: the throughput mode's gradient of EVERY
+    parameter tensor of UNet, codec and FAN must point where the float32 mode's does (cosine > 0.98; a wrong sign or a dropped term
+    in one layer fails this, which the 0.7 floor the real channel needs for the UNet would not catch).  Taken out
+    (tools/c5_wf_diag.py measures each): the jpeg manipulation and the codec's hard latent (rounding='identity'), the entropy term
+    (the soft histogram of a CONTINUOUS latent is steep between the centres: its gradient decorrelates under bf16 perturbations;
+    at the hard-quantised latent of the real codec it is stable), and the sharpen manipulation - its backward runs through
+    rgb->hsv, whose Jacobian grows like 1 / (max - min) on near-grey pixels; the codec's summed l2 term sends a large gradient
+    through it and the two modes' UNet outputs differ enough there for the few dominating pixels to change (|g| 4.3e4 vs 1.9e5,
+    median cosine 0.42) - a property of the reference's channel, not of either mode.  With resample + gaussian the smallest
+    cosine over all tensors is 0.995."""
+    from neural_imaging_amd import ops
+    from neural_imaging_amd.models import compression
+    from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
+    manips = ['resample:50', 'gaussian:0.83']
+    rgb = natural_images(2, 128, 128, seed=9)
+    raw = bayer_from_rgb(rgb)
+    res = {}
+    try:
+        for mode in ('f32', 'bf16'):
+            ops.set_compute(mode)
+            dcn = compression.TwitterDCN(patch_size=128, rounding='identity', entropy_weight=0, device=dev)
+            dist = {'downsampling': 'none', 'compression': 'dcn', 'compression_params': {'model': dcn}}
+            wf = ManipulationClassification('UNet', manipulations=manips, distribution=dist, trainable={'nip', 'dcn'},
+                                            raw_patch_size=64, device=dev)
+            loss, parts = wf.training_step(raw, rgb, lambda_nip=0.1, lambda_dcn=0.1, learning_rate=1e-4)
+            res[mode] = (float(parts['ce']), float(parts['nip']), float(parts['dcn']),
+                         {'nip/' + k: v for k, v in grads_of(wf.nip).items()}, {'dcn/' + k: v for k, v in grads_of(dcn).items()},
+                         {'fan/' + k: v for k, v in grads_of(wf.fan).items()})
+    finally:
+        ops.set_compute('f32')
+    assert abs(res['bf16'][0] - res['f32'][0]) < 5e-2
+    assert abs(res['bf16'][1] - res['f32'][1]) / res['f32'][1] < 2e-2 and abs(res['bf16'][2] - res['f32'][2]) / res['f32'][2] < 2e-2
+    cos = lambda a, b: float(a.ravel() @ b.ravel() / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+    low = {}
+    for gi in (3, 4, 5):
+        for k, a in res['f32'][gi].items():
+            if a.size >= 16 and np.linalg.norm(a) > 0:          # scalars (latent scaling) and untouched tensors carry no direction
+                c = cos(a, res['bf16'][gi][k])
+                if c <= 0.98:
+                    low[k] = round(c, 4)
+    assert not low, sorted(low.items(), key=lambda kv: kv[1])[:40]
+
+
+def test_dcn_bf16_storage_inside_residual_blocks_is_bit_neutral(dev):
+    """Throughput mode stores the tensors inside the codec's residual blocks (the activation between the two convolutions and
+    its gradient) as bf16: their consumers round to bf16 or test the sign, so the reconstruction, the latent and the entropy are
+    bit-identical to float32 storage, the weight gradients agree to summation order (different kernel variants take bf16 inputs)
+    and only the bias gradients of the blocks' first layers see the rounding (they sum the stored gradient)."""
+    from neural_imaging_amd import ops
+    from neural_imaging_amd.models import compression
+    x = torch.from_numpy(natural_images(2, 64, 64, seed=23)).to(dev)
+    ops.set_compute('bf16')
+    out = {}
+    try:
+        for store in (True, False):
+            ops.STORE_BF16 = store
+            dcn = compression.TwitterDCN(patch_size=64, device=dev)
+            y, ent, ctx = dcn.forward(x, training=True)
+            assert (ctx[0]['er1a'].dtype == torch.bfloat16) == store and ctx[0]['n1'].dtype == torch.float32
+            _, dy = ops.l2_loss(x, y, grad_scale=1.0)
+            dcn.backward(ctx, dy, entropy_coef=250.0)
+            ops.join_side_stream()
+            out[store] = (y.clone(), ctx[0]['latent'].clone(), float(ent.item()),
+                          {k: v.clone() for k, v in dcn._model.g.items()})
+    finally:
+        ops.STORE_BF16 = True
+        ops.set_compute('f32')
+    assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1]) and out[True][2] == out[False][2]
+    worst = {'kernel': 0.0, 'bias': 0.0}
+    for k, gb in out[False][3].items():
+        rel = float((out[True][3][k] - gb).abs().max()) / (float(gb.abs().max()) + 1e-30)
+        kind = 'bias' if k.endswith('/bias') else 'kernel'
+        worst[kind] = max(worst[kind], rel)
+    # kernels: the same bf16 products, another summation order.  Biases of the blocks' first layers: the fused bias gradient sums
+    # the gradient tensor as stored - bf16-rounded values instead of float32 ones (unbiased, 2^-9 relative per element)
+    assert worst['kernel'] < 5e-5 and worst['bias'] < 3e-3, worst
+
+
 def test_full_channel_with_learned_codec_in_throughput_mode(dev):
     """configs[4]: UNet -> manipulations -> TwitterDCN -> FAN, trainable {nip, dcn}, in the bf16 throughput mode: losses against
     the float64 oracle of the same step and against the float32 mode of the same weights; gradient directions of the two modes."""
