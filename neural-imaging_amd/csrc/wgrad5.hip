@@ -321,6 +321,268 @@ int launch(Wg5Params p, int max_slabs, hipStream_t stream) {
 
 
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Structured-sparsity form.  dz is the 2x2 UN-POOLING of the pooled gradient: of the four pixels of a pooling window exactly one
+// carries a channel's gradient.  v_smfmac_f32_16x16x64_bf16 multiplies a 2:4-sparse A (two kept elements + two 2-bit positions
+// per group of four K values) by a dense B over K = 64 in the cycles the dense 16x16x32 takes.  With K = pixels,
+//     D[co][ci] += A[co][pixel] B[pixel][ci],     A = dz^T compressed, B = the (tap-shifted) input,
+// and the K groups chosen as COLUMN STRIPS - the four pixels (r0..r3, c) of a step of four tile rows: the upper window (rows r0,
+// r1) and the lower one (r2, r3) put at most one value each into the strip - the pooled tensor IS the compressed operand: kept
+// element 0 = the upper window's gradient if its arg-max sits in this column (else 0) at position (arg-max row), kept element 1 =
+// the lower window's at position 2 + (arg-max row).  No un-pooling pass, no routed tile in LDS (10 KB pooled instead of 49 KB),
+// and a step covers 64 pixels with the 50 matrix instructions that covered 32.  (tools/probe/smfmac_probe.hip measured the
+// operand layout used below - A lane group g holds logical K 16 g .. 16 g + 15, B lane group b element j holds K 8 b + j for
+// j < 8 and 32 + 8 b + j - 8 above; the two kept elements of a group may carry ANY positions - and the issue rate: 1.92 x the
+// dense-equivalent products of v_mfma_f32_32x32x16_bf16.)
+// B operand of tap (ky, kx) for lane group b: the strips of columns 4 b + kx + {0, 1, 2, 3}, rows ky .. ky + 3 of the step - ONE
+// ds_read_b64_tr_b16 per strip (its four "pixels" are the four rows), four reads = the eight operand registers, nothing to
+// shift or copy.  A wave owns 16 input x ALL 64 output channels of the workgroup for HALF the taps (13 x 4 accumulators of
+// four registers = 208): one operand (4 reads) feeds four matrix instructions - with two it was the LDS (4 waves x 4 reads x 2
+// cycles per 32 cycles of matrix work) that bound the kernel.  The waves of a workgroup are (input-channel half) x (taps 0..12 |
+// 12..24; tap 12 is computed twice and stored once).  (Sharing registers between taps costs hipcc a v_mov per shared
+// register - its operand tuples cannot overlap - or, with two horizontal pixels per register, a v_alignbit per odd tap: the
+// first version of this kernel, 60 + 58 VALU per 50 instructions, profiles/r03_z_wgrad5_sparse_v1_ab.txt.)
+// Logical K groups of lane group b: 2 b, 2 b + 1 (j < 8) and 8 + 2 b, 9 + 2 b = columns 4 b .. 4 b + 3, so A lane group g lists
+// the columns c, c + 1, c + 4, c + 5 with c = {0, 8, 2, 10}[g] = both column parities of the pooled pixels (upper | lower, c / 2)
+// and (upper | lower, c / 2 + 2): one transpose read of the pooled tile gives (upper, lower) pairs, a 16-bit column-parity mask
+// tile splits them over the even / odd column strip, and the index word comes the same way from a 16-bit tile of pre-shifted
+// position pieces (both written by the staging pass from the arg-max bytes).
+// LDS: input pixels 96 B apart, rows 2080 B; pooled pixels 160 B apart, rows 1312 B - the eight 32-byte pieces of every
+// 32-lane read fall into the eight bank octets.
+template <int TH>
+struct Wg5SGeom {
+    static constexpr int THH = TH + 4, TWH = 20;
+    static constexpr int XP = 96, XR = TWH * XP + 160;            // input pixel / row stride
+    static constexpr int GP = 160, GR = 8 * GP + 32;              // pooled pixel / row stride (gradient, mask and index tiles alike)
+    static constexpr int IBYTES = THH * XR, GBYTES = (TH / 2) * GR, BUF = IBYTES + 3 * GBYTES;
+    static constexpr int IP = (THH + 2) / 3;
+    static constexpr int ZITEMS = (TH / 2) * 8 * 8, ZP = ZITEMS / 256;
+    static constexpr size_t LDS = (size_t)2 * BUF;
+    static_assert(ZITEMS % 256 == 0 && TH % 4 == 0, "pooled tile divides over the threads; a step is 4 rows");
+    static_assert(LDS <= 160 * 1024, "two tile buffers fit the LDS");
+};
+typedef __bf16 bf16x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x8 __attribute__((ext_vector_type(8)));
+
+template <int TH>
+__global__ __launch_bounds__(256, 1) void conv5_wgrad_sparse_kernel(const Wg5Params p) {
+    using G = Wg5SGeom<TH>;
+    constexpr int XP = G::XP, XR = G::XR, GP = G::GP, GR = G::GR, IP = G::IP, ZP = G::ZP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ai = wave & 1, th = wave >> 1;                       // this wave's 16 input channels, its half of the taps
+    const int tap0 = 12 * th;                                      // taps tap0 .. tap0 + 12
+    const int cib = p.Cin / 32, cob = p.Cout / 64;
+    int bid = xcd_order(blockIdx.x);
+    const int ci0 = (bid % cib) * 32;
+    bid /= cib;
+    const int co0 = (bid % cob) * 64;
+    const int split = bid / cob;
+    const int q = lane >> 4, g = lane & 15;                        // lane group (K range), row / column of the fragment
+    const int Hp = p.H >> 1, Wp = p.W >> 1;
+
+    constexpr int NF = 4, NTAP = 13;
+    f32x4 acc[NF][NTAP];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) acc[f][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum[NF] = {0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = p.db_partial && ci0 == 0 && ai == 0 && th == 0;
+
+    const int tiles = p.tiles_y * p.tiles_x;
+    const int work_total = p.N * tiles;
+    const int w_begin = split * p.work_per_split;
+    const int w_end = min(work_total, w_begin + p.work_per_split);
+
+    // ---- staging maps (as conv5_wgrad_alltaps_kernel; the pooled gradient goes to LDS AS IT IS, next to the mask and index tiles)
+    const int ihy0 = tid < 240 ? tid / 80 : 100000, ihx = (tid % 80) >> 2;
+    const int ic8 = (tid & 3) * 8;
+    const int icommit = ihx * XP + (tid & 3) * 16;
+    const int zc8 = (tid & 7) * 8;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.in), 0, (int)((long)p.N * p.H * p.W * p.Cin * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.g), 0, (int)((long)p.N * Hp * Wp * p.Cout * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(p.idx), 0, (int)((long)p.N * Hp * Wp * p.Cout), 0x00020000);
+    u32x4 preI[IP], preZ[ZP];
+    u32x2 preK[ZP];
+    auto fetch = [&](int wk) {
+        const int n = wk / tiles, tile = wk - n * tiles;
+        const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+        const int iy0 = ty * TH - 2, ix0 = tx * 16 - 2;
+        const int gx = ix0 + ihx;
+        const bool okx = (unsigned)gx < (unsigned)p.W;
+#pragma unroll
+        for (int i = 0; i < IP; ++i) {
+            const int gy = iy0 + ihy0 + 3 * i;
+            const bool ok = okx & ((unsigned)gy < (unsigned)p.H) & (ihy0 + 3 * i < G::THH);
+            const unsigned off = ok ? (unsigned)((((n * p.H + gy) * p.W + gx) * p.Cin + ci0 + ic8) * 2) : 0x80000000u;
+            preI[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < ZP; ++i) {
+            const int ppix = (tid + i * 256) >> 3;                 // pooled pixel of the (TH/2) x 8 pooled tile
+            const unsigned e = (unsigned)(((n * Hp + ty * (TH / 2) + (ppix >> 3)) * Wp + tx * 8 + (ppix & 7)) * p.Cout + co0 + zc8);
+            preZ[i] = __builtin_amdgcn_raw_buffer_load_b128(rz, e * 2, 0, 0);
+            preK[i] = __builtin_amdgcn_raw_buffer_load_b64(rk, e, 0, 0);
+        }
+    };
+    auto commit = [&](unsigned char* buf) {
+#pragma unroll
+        for (int i = 0; i < IP; ++i)
+            if (ihy0 + 3 * i < G::THH) *reinterpret_cast<u32x4*>(buf + (ihy0 + 3 * i) * XR + icommit) = preI[i];
+        unsigned char* gb = buf + G::IBYTES;
+#pragma unroll
+        for (int i = 0; i < ZP; ++i) {
+            const int ppix = (tid + i * 256) >> 3, pr = ppix >> 3, pc = ppix & 7;
+            const int o = pr * GR + pc * GP + zc8 * 2;
+            *reinterpret_cast<u32x4*>(gb + o) = preZ[i];
+            // arg-max byte k = 2 (row) + (column) of the window, per channel -> two 16-bit tiles: the column-parity mask (0xffff:
+            // the value belongs to the odd column strip) and this window's piece of the index word: position (row, or 2 + row
+            // for the lower window of a step = odd pooled row) at the two kept slots it can occupy, (u, u + 2) + 4 x bit 1 of the
+            // pooled column - the order the A fragment lists its windows in
+            const unsigned u = (unsigned)(pr & 1), s8 = 8u * (unsigned)((pc >> 1) & 1);
+            u32x4 m16, x16;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const unsigned e2 = __builtin_amdgcn_perm(0u, preK[i][d >> 1], (d & 1) ? 0x0c030c02u : 0x0c010c00u);     // two bytes -> two halves
+                m16[d] = (e2 & 0x00010001u) * 0xffffu;
+                const unsigned val = ((e2 >> 1) & 0x00010001u) + u * 0x00020002u;
+                x16[d] = ((val << (2 * u)) | (val << (2 * u + 4))) << s8;
+            }
+            *reinterpret_cast<u32x4*>(gb + G::GBYTES + o) = m16;
+            *reinterpret_cast<u32x4*>(gb + 2 * G::GBYTES + o) = x16;
+        }
+    };
+    // transpose-read addresses.  Input strip: lane g of a 16-lane group supplies "pixel" j = g >> 2 = row j of the strip,
+    // channels (g & 3) * 4 .. + 3 of its wave's 16; lane group q = image columns 4 q ..
+    const int jx = g >> 2;
+    const int x_lane = jx * XR + 4 * q * XP + ai * 32 + (g & 3) * 8;      // + (step row + ky) * XR + (kx + i) * XP
+    // pooled tiles: lane group q lists the windows (upper, c), (lower, c), (upper, c + 2), (lower, c + 2), c = {0, 4, 1, 5}[q]
+    const int pcA = (q & 1) * 4 + (q >> 1);
+    const int z_lane = (jx & 1) * GR + (pcA + 2 * (jx >> 1)) * GP + (g & 3) * 8;               // + f * 32, + step * 2 * GR
+    auto tr2 = [](const unsigned char* a) {
+        const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)a);
+        return *reinterpret_cast<const u32x2*>(&v);
+    };
+
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)smem_raw;
+    if (w_begin < w_end) {
+        fetch(w_begin);
+        commit(smem_raw);
+    }
+    __syncthreads();
+    for (int wk = w_begin; wk < w_end; ++wk) {
+        const int par = (wk - w_begin) & 1;
+        const bool more = wk + 1 < w_end;
+        if (more) fetch(wk + 1);
+        const unsigned char* sI = smem_raw + par * G::BUF;
+        const unsigned char* sG = sI + G::IBYTES;
+        auto trl = [](unsigned lds_addr) {                 // transpose read at a 32-bit LDS address
+            const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(unsigned long)lds_addr);
+            return *reinterpret_cast<const u32x2*>(&v);
+        };
+        auto readB = [&](unsigned xr) {                    // xr: LDS address of this lane's first strip of the tap
+            // neighbouring taps read the same strips: left to itself hipcc merges those loads and then copies every shared
+            // register into each tap's operand tuple (120 v_accvgpr_mov per 50 matrix instructions) - an opaque address per tap
+            // keeps the loads apart
+            asm volatile("" : "+v"(xr));
+            const u32x2 r0 = trl(xr), r1 = trl(xr + XP), r2 = trl(xr + 2 * XP), r3 = trl(xr + 3 * XP);
+            const u32x4 q0 = __builtin_shufflevector(r0, r1, 0, 1, 2, 3), q1 = __builtin_shufflevector(r2, r3, 0, 1, 2, 3);
+            const u32x8 b8 = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7);
+            return *reinterpret_cast<const bf16x16*>(&b8);
+        };
+        auto readA = [&](const unsigned char* zr, unsigned (&a)[NF][4], unsigned (&ix)[NF]) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const u32x2 v = tr2(zr + f * 32), m = tr2(zr + G::GBYTES + f * 32), k = tr2(zr + 2 * G::GBYTES + f * 32);
+                a[f][0] = v[0] & ~m[0]; a[f][1] = v[0] & m[0];           // (upper, lower) of pooled column c: even strip, odd strip
+                a[f][2] = v[1] & ~m[1]; a[f][3] = v[1] & m[1];           // ... of pooled column c + 2
+                const unsigned t = k[0] | k[1];
+                ix[f] = t | (t >> 16);                                   // bits 15..0 are read
+                if (do_bias) bsum[f] += __uint_as_float(v[0] << 16) + __uint_as_float(v[0] & 0xffff0000u) +
+                                        __uint_as_float(v[1] << 16) + __uint_as_float(v[1] & 0xffff0000u);
+            }
+        };
+        constexpr int STEPS = TH / 4, NT = STEPS * NTAP, DIST = 3;    // this wave's taps of a tile; operand requests run DIST taps ahead
+        const unsigned x0 = lds0 + (unsigned)(par * G::BUF + x_lane);
+        auto tap_addr = [&](int T) {
+            const int tap = tap0 + T % NTAP;                        // wave-uniform: scalar arithmetic
+            return x0 + (unsigned)((T / NTAP) * (4 * XR) + (tap / 5) * XR + (tap % 5) * XP);
+        };
+        // the gradient fragments of all steps of the tile first (48 reads, 80 registers), then ONE software pipeline over the
+        // wave's 52 taps of the tile: with one wave per SIMD nobody else covers the LDS latency (~100 cycles), so the four strips
+        // of tap T + 3 are requested in front of the instructions of tap T - a ring of four operand buffers, everything
+        // unrolled (static register numbers), the order pinned per tap
+        unsigned a4[STEPS][NF][4], ix[STEPS][NF];
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) readA(sG + z_lane + st * (2 * GR), a4[st], ix[st]);
+        bf16x16 ring[DIST + 1];
+#pragma unroll
+        for (int d = 0; d < DIST; ++d) ring[d] = readB(tap_addr(d));
+        // the pipeline description starts with the requests issued so far: 3 per fragment and step, 4 per tap
+        __builtin_amdgcn_sched_group_barrier(0x100, 3 * NF * STEPS + 4 * DIST, 0);
+#pragma unroll
+        for (int T = 0; T < NT; ++T) {
+            const int st = T / NTAP, t = T % NTAP;
+            if (T + DIST < NT) ring[(T + DIST) % (DIST + 1)] = readB(tap_addr(T + DIST));
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+                acc[f][t] = __builtin_amdgcn_smfmac_f32_16x16x64_bf16(*reinterpret_cast<const bf16x8*>(a4[st][f]), ring[T % (DIST + 1)],
+                                                                      acc[f][t], (int)ix[st][f], 0, 0);
+            if (T + DIST < NT) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);      // DS read x 4
+            __builtin_amdgcn_sched_group_barrier(0x008, NF, 0);                         // MFMA x 4
+        }
+        if (more) commit(smem_raw + (par ^ 1) * G::BUF);
+        __syncthreads();
+    }
+    if (do_bias) {                              // lanes g, g + 16, g + 32, g + 48 hold the four window groups of one channel
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            float v = bsum[f];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lane < 16) p.db_partial[(long)split * p.Cout + co0 + f * 16 + lane] = v;
+        }
+    }
+    // D row m = 4 q + j = output channel, column = lane & 15 = input channel: 16-byte stores along the output channels; the
+    // second tap half starts at tap 12, which the first one stores
+    float* slab = p.partial + (long)split * 25 * p.Cin * p.Cout;
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
+        if (th == 1 && t == 0) continue;
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+            *reinterpret_cast<f32x4*>(slab + ((long)(tap0 + t) * p.Cin + ci0 + 16 * ai + g) * p.Cout + co0 + f * 16 + 4 * q) = acc[f][t];
+    }
+}
+
+template <int TH>
+int launch_sparse(Wg5Params p, int max_slabs, hipStream_t stream) {
+    using G = Wg5SGeom<TH>;
+    p.tiles_y = p.H / TH;
+    p.tiles_x = p.W / 16;
+    const long work = (long)p.N * p.tiles_y * p.tiles_x;
+    const long blocks_io = (long)(p.Cin / 32) * (p.Cout / 64);
+    static const int target = getenv("NIMG_WGRAD5_ALLTAPS_BLOCKS") ? atoi(getenv("NIMG_WGRAD5_ALLTAPS_BLOCKS")) : 256;
+    long splits = (target + blocks_io - 1) / blocks_io;
+    if (splits > max_slabs) splits = max_slabs;
+    if (splits > work) splits = work;
+    if (splits < 1) return 0;
+    const long wps = (work + splits - 1) / splits;
+    splits = (work + wps - 1) / wps;
+    p.work_per_split = (int)wps;
+    auto kern = conv5_wgrad_sparse_kernel<TH>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(blocks_io * splits)), dim3(256), G::LDS, stream, p);
+    if (hipGetLastError() != hipSuccess) return -1;
+    return (int)splits;
+}
+
 }  // namespace
 
 // Weight-gradient slabs (+ bias partials) of a 5x5 / stride 1 / SAME layer from its bf16 input and the POOLED bf16 gradient +
@@ -336,6 +598,8 @@ int nimg_internal_wgrad5_alltaps(const void* in, int cin, const void* g, const u
     p.in = in; p.g = g; p.idx = idx; p.partial = partial; p.db_partial = db_partial;
     p.Cin = cin; p.Cout = cout; p.N = n; p.H = h; p.W = wd;
     p.tiles_y = p.tiles_x = p.work_per_split = 0;
+    // NIMG_NO_WGRAD5_SPARSE is read per call (A/B in one process); h % 16: the sparse form is built for 16-row tiles
+    if (!getenv("NIMG_NO_WGRAD5_SPARSE") && h % 16 == 0) return launch_sparse<16>(p, max_slabs, stream);
     static const bool th8 = getenv("NIMG_WGRAD5_TH8") != nullptr, kx3l = getenv("NIMG_WGRAD5_KX3L") != nullptr;
     static const int sched = getenv("NIMG_WGRAD5_SCHED") ? atoi(getenv("NIMG_WGRAD5_SCHED")) : 2;
     const int variant = ((th8 || (h % 16)) ? 4 : 0) | (kx3l ? 2 : 0) | (sched == 1 ? 1 : 0);
