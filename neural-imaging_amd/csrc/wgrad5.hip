@@ -504,8 +504,12 @@ __global__ __launch_bounds__(256, 1) void conv5_wgrad_sparse_kernel(const Wg5Par
                 a[f][2] = v[1] & ~m[1]; a[f][3] = v[1] & m[1];           // ... of pooled column c + 2
                 const unsigned t = k[0] | k[1];
                 ix[f] = t | (t >> 16);                                   // bits 15..0 are read
-                if (do_bias) bsum[f] += __uint_as_float(v[0] << 16) + __uint_as_float(v[0] & 0xffff0000u) +
-                                        __uint_as_float(v[1] << 16) + __uint_as_float(v[1] & 0xffff0000u);
+                // bias gradient = the plain sum of the pooled gradient: two v_dot2c_f32_bf16 against (1, 1), unconditionally - a
+                // branch on do_bias here cuts the fragment reads of a tile into 16 blocks, each waiting for its own LDS round trip
+                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                const unsigned ones = 0x3f803f80u, v0 = v[0], v1 = v[1];
+                bsum[f] = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const bf16x2*>(&v0), *reinterpret_cast<const bf16x2*>(&ones), bsum[f], false);
+                bsum[f] = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const bf16x2*>(&v1), *reinterpret_cast<const bf16x2*>(&ones), bsum[f], false);
             }
         };
         constexpr int STEPS = TH / 4, NT = STEPS * NTAP, DIST = 3;    // this wave's taps of a tile; operand requests run DIST taps ahead

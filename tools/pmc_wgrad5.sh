@@ -14,7 +14,7 @@ run() {  # name, env, counters...
   find $OUT/raw_$name -name '*counter_collection.csv' | head -1 | xargs -I{} cp {} $OUT/$name.csv
   rm -rf $OUT/raw_$name
 }
-for v in new:A=1 old:NIMG_NO_WGRAD5_ALLTAPS=1 ${PMC_EXTRA}; do
+for v in ${PMC_SET:-new:A=1 old:NIMG_NO_WGRAD5_ALLTAPS=1} ${PMC_EXTRA}; do
   run ${v%%:*}_sq1 ${v#*:} SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE
   run ${v%%:*}_sq2 ${v#*:} SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU
 done
