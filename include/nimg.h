@@ -293,6 +293,15 @@ int nimg_isp_residual_bwd(const float* dy, const float* f, const float* alpha, f
 /* Dropout of the FAN's hidden Dense layers at training time (models/forensics.py:88), forward and backward alike:
  * y = keep[i] ? x[i] * scale : 0, keep = the Bernoulli(1 - rate) mask bytes, scale = 1 / (1 - rate). */
 int nimg_mask_scale(const float* x, const uint8_t* keep, float* y, long count, float scale, void* stream);
+/* Input gradient of a fused 5x5 conv + pool layer (stride 1, SAME) from the POOLED gradient g (n, h/2, wd/2, cout) bf16 + arg-max
+ * bytes on the 2:4 structured-sparsity matrix instruction (csrc/dgrad5s.hip): the same result as nimg_conv2d_fwd_bf16_unpool to
+ * summation order.  `image` = nimg_conv5_dgrad_sparse_weights(w (5,5,cin,cout) float32) of nimg_conv5_dgrad_sparse_image_bytes
+ * bytes, rebuilt whenever w changes.  out (n, h, wd, cin) float32 | bf16 (NIMG_BF16_OUT), act_mask optional (float32 | bf16 with
+ * NIMG_BF16_MASK): out *= act_mask > 0 ? 1 : alpha.  cin % 32 == 0, cout % 8 == 0, even h / wd (else NIMG_ERR_ARG). */
+size_t nimg_conv5_dgrad_sparse_image_bytes(int cin, int cout);
+int nimg_conv5_dgrad_sparse_weights(const float* w, void* image, int cin, int cout, void* stream);
+int nimg_conv5_dgrad_sparse(const void* g, const unsigned char* idx, int cout, const void* image, void* out, int cin,
+                            const void* act_mask, int n, int h, int wd, float alpha, int flags, void* stream);
 /* nimg_conv2d_fwd_bf16_ex + `residual` (float32, the shape of out1) added after bias, activation and mask: a residual block's skip
  * connection in the same pass (net + conv(a) forward, d_net + mask * dgrad backward; models/compression.py:224-227, 240-243).
  * 3x3, stride 1, float32 output with o1 % 4 == 0. */

@@ -579,8 +579,15 @@ def conv2d_dgrad_unpool(g, idx, w, act_mask=None, out_bf16=False):
     n, hp, wp, cz = g.shape
     ks, ci = w.shape[0], w.shape[2]
     out = torch.empty((n, 2 * hp, 2 * wp, ci), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=g.device)
-    wb = weights_bf16(w, 1)
     flags = (BF16_OUT if out_bf16 else 0) | (BF16_MASK if _is_bf16(act_mask) else 0)
+    if SPARSE_DGRAD and ks == 5 and ci % 32 == 0 and cz % 8 == 0 and _is_bf16(g) and g.numel() * 2 < (1 << 31) - 65536:
+        # the pooled gradient as the compressed operand of the structured-sparsity matrix instruction (csrc/dgrad5s.hip)
+        img = torch.empty(int(_lib.load().nimg_conv5_dgrad_sparse_image_bytes(ci, cz)), dtype=torch.uint8, device=g.device)
+        _lib.call('nimg_conv5_dgrad_sparse_weights', _p(w), _p(img), ci, cz, _stream())
+        _lib.call('nimg_conv5_dgrad_sparse', _p(g), _p(idx), cz, _p(img), _p(out), ci, _p(act_mask), n, 2 * hp, 2 * wp, LRELU_ALPHA,
+                  flags, _stream())
+        return out
+    wb = weights_bf16(w, 1)
     _lib.call('nimg_conv2d_fwd_bf16_unpool', _p(g), _p(idx), cz, _p(wb), None, _p(out), ci, _p(act_mask), n, 2 * hp, 2 * wp, ks,
               ks - 1 - (ks - 1) // 2, ks - 1 - (ks - 1) // 2, 2 * hp, 2 * wp, 0, LRELU_ALPHA, flags, _stream())
     return out
@@ -822,6 +829,9 @@ def cconv3(x, w, pad_mode=1, out=None, want_f32=True, want_c4=False):
 FRONT_END = _os.environ.get('NIMG_OLD_FRONTEND') is None
 # 5x5 stride-2 layers as 3x3 stride-1 layers over the space-to-depth image (throughput mode); NIMG_NO_S2D_CONV=1: the strided kernels
 S2D_CONV = _os.environ.get('NIMG_NO_S2D_CONV') is None
+# 5x5 input gradients of the fused conv + pool layers on the sparse matrix instruction (csrc/dgrad5s.hip): correct, but at
+# parity with the ring kernels (its dense operand is twice the LDS bytes per matrix cycle) - off unless NIMG_SPARSE_DGRAD=1
+SPARSE_DGRAD = _os.environ.get('NIMG_SPARSE_DGRAD') is not None
 
 
 def front_end_ok(cin, cout, ks, h, w, n=None):

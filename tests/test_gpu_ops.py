@@ -944,8 +944,18 @@ def test_unpool_folded_into_conv5_backward(dev, bf16_mode, shape):
     dz = ops.maxpool2_unpool(gp, idx, None, apply_mask=False, out_bf16=True)
     for out_bf16, am in ((False, None), (True, mask)):
         ref = ops.conv2d_dgrad(dz, wt, (h, w), act_mask=am, out_bf16=out_bf16)
-        got = ops.conv2d_dgrad_unpool(gp, idx, wt, act_mask=am, out_bf16=out_bf16)
-        assert torch.equal(ref, got), 'input gradient'
+        was = ops.SPARSE_DGRAD
+        try:
+            ops.SPARSE_DGRAD = False
+            got = ops.conv2d_dgrad_unpool(gp, idx, wt, act_mask=am, out_bf16=out_bf16)
+            assert torch.equal(ref, got), 'input gradient'
+            # the structured-sparsity form (csrc/dgrad5s.hip): the same bf16 products, another summation order
+            ops.SPARSE_DGRAD = True
+            sp = ops.conv2d_dgrad_unpool(gp, idx, wt, act_mask=am, out_bf16=out_bf16)
+        finally:
+            ops.SPARSE_DGRAD = was
+        tol = (8e-3 if out_bf16 else 2e-5) * float(ref.float().abs().max())
+        assert float((sp.float() - ref.float()).abs().max()) <= tol, 'input gradient, sparse form'
     dw_ref, db_ref = torch.empty_like(wt), torch.empty((cout,), device=dev)
     ops.conv2d_wgrad(x, dz, 5, dw=dw_ref, db=db_ref)
     dw, db = torch.empty_like(wt), torch.empty((cout,), device=dev)
@@ -954,6 +964,39 @@ def test_unpool_folded_into_conv5_backward(dev, bf16_mode, shape):
     # order (float32 sums of exact bf16 x bf16 products) - test_wgrad5_alltaps_vs_oracle holds it to the float64 oracle
     assert torch.allclose(dw_ref, dw, rtol=0, atol=2e-5 * float(dw_ref.abs().max())), 'weight gradient'
     assert torch.allclose(db_ref, db, rtol=0, atol=2e-5 * float(gp.float().abs().sum(dim=(0, 1, 2)).max())), 'bias gradient'
+
+
+@pytest.mark.parametrize('shape', [(2, 128, 128, 32, 64), (3, 64, 64, 64, 128), (2, 32, 32, 128, 256), (1, 8, 16, 32, 64),
+                                   (3, 24, 40, 64, 72), (1, 36, 34, 32, 8)])
+def test_dgrad5_sparse_vs_oracle(dev, bf16_mode, shape):
+    """csrc/dgrad5s.hip (v_smfmac_f32_32x32x32_bf16: the pooled gradient as the compressed operand, the arg-max byte as its index):
+    input gradient of a fused 5x5 conv + pool layer at the FAN's layer shapes, an image smaller than one 16 x 16 pooled tile, sizes
+    the tiles do not divide and channel counts off the usual multiples, against float64 autograd through the convolution on
+    the same rounded values - with and without the LeakyReLU' mask of the layer below, float32 and bf16 outputs."""
+    from neural_imaging_amd import ops
+    n, h, w, cin, cout = shape
+    gp_np = _bf16_round(rnd((n, h // 2, w // 2, cout), 12)).numpy().astype(np.float32)
+    idx_np = np.random.default_rng(13).integers(0, 4, size=(n, h // 2, w // 2, cout)).astype(np.uint8)
+    dz_np = np.zeros((n, h, w, cout), np.float32)
+    for pos in range(4):
+        dz_np[:, pos >> 1::2, pos & 1::2, :] = np.where(idx_np == pos, gp_np, 0.0)
+    wt_np = rnd((5, 5, cin, cout), 14, -0.05, 0.05)
+    x = to64(np.zeros((n, h, w, cin))).requires_grad_(True)
+    (T.conv2d(x, _bf16_round(wt_np), None, 1, 'SAME') * to64(dz_np)).sum().backward()
+    ref = x.grad.numpy()
+    mask_np = rnd((n, h, w, cin), 15)
+    gg, ig = g(gp_np, dev).to(torch.bfloat16), torch.from_numpy(idx_np).to(dev)
+    was = ops.SPARSE_DGRAD
+    ops.SPARSE_DGRAD = True                      # off by default (at parity with the ring kernels): the kernel is kept and held to the oracle
+    try:
+        got = ops.conv2d_dgrad_unpool(gg, ig, g(wt_np, dev))
+        gm = ops.conv2d_dgrad_unpool(gg, ig, g(wt_np, dev), act_mask=g(mask_np, dev).to(torch.bfloat16), out_bf16=True)
+    finally:
+        ops.SPARSE_DGRAD = was
+    assert_close(got.cpu().numpy(), ref, 0.0, 2e-5, what='sparse dgrad')
+    refm = ref * np.where(_bf16_round(mask_np).numpy() > 0, 1.0, 0.2)
+    assert gm.dtype == torch.bfloat16
+    assert_close(gm.float().cpu().numpy(), refm, 0.0, 8e-3, what='sparse dgrad, masked, bf16 out')
 
 
 @pytest.mark.parametrize('shape', [(4, 128, 128, 32, 64), (5, 64, 64, 64, 128), (7, 32, 32, 128, 256), (1, 8, 16, 32, 64),
