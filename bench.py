@@ -402,8 +402,10 @@ def main():
                          'steps first and each mode trains a quarter as many more from the checkpoint')
     ap.add_argument('--no-side-workloads', action='store_true', help='skip the short c3 / c5 runs of the default c4 line')
     ap.add_argument('--no-graph', dest='graph', action='store_false',
-                    help='launch every kernel of the timed steps eagerly (default at N = 1: the step is captured once into a HIP '
-                         'graph and replayed - same kernels, same order, one launch call per step)')
+                    help='launch every kernel of the timed steps eagerly (default at N = 1: the step is ALSO captured into a HIP '
+                         'graph - same kernels, same order, one launch call per step - and whichever of the two launch paths '
+                         'runs the warm-up steps faster is used for the timed ones)')
+    ap.add_argument('--force-graph', action='store_true', help='time the graph replay even if eager launches were faster')
     ap.add_argument('--backend', default=None, help='torch.distributed backend (default: nccl = RCCL); gloo is for a '
                                                      'functional check of the N>1 path on a one-GPU box')
     ap.add_argument('--single-device', action='store_true', help='functional check only: every rank uses cuda:0')
@@ -444,6 +446,22 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    launch_modes = None
+    if getattr(wl, 'graph', False) and hasattr(wl, 'eager') and not args.force_graph:
+        # launch path: graph replay (one host call per step) or eager launches (~3 ms of host time per 9 ms step at C4).  On this
+        # stack the replay of the ~165-kernel two-stream step is 3 - 5 % SLOWER than the eager launches
+        # (profiles/r03_ae_graph_vs_eager.txt), on a loaded host it would be the other way round - so both are timed during the
+        # warm-up (untimed part of the run) and the faster one runs the K timed steps
+        launch_modes = {}
+        for name, fn in (('graph', step), ('eager', wl.eager)):
+            torch.cuda.synchronize()
+            t_m = time.perf_counter()
+            for _ in range(max(args.warmup, 5)):
+                fn()
+            torch.cuda.synchronize()
+            launch_modes[name] = 1e3 * (time.perf_counter() - t_m) / max(args.warmup, 5)
+        if launch_modes['eager'] < launch_modes['graph']:
+            step, wl.graph = wl.eager, False
     nblk = 5 if args.steps >= 5 else 1
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(nblk + 1)]
     edges = [round(i * args.steps / nblk) for i in range(nblk + 1)]
@@ -483,6 +501,8 @@ def main():
                'hip_graph': bool(getattr(wl, 'graph', False)), 'host_cpu_ms_per_step': host_cpu_ms, 'loss': loss,
                'achieved_tflops_whole_step': value * wl.gflop_per_unit / 1e3,
                'block_ms_per_step': [round(v, 4) for v in blocks], 'median_block_ms_per_step': float(np.median(blocks))}
+        if launch_modes is not None:
+            cfg['launch_mode_warmup_ms_per_step'] = {k: round(v, 4) for k, v in launch_modes.items()}
         if world == 1 and getattr(wl, 'graph', False):
             # what the data-parallel step (always eager: the RCCL launches stay outside a captured graph) costs the host per
             # step: CPU time of this thread issuing 10 eager steps, and their wall time, next to the replayed figure above
