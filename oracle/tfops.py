@@ -133,6 +133,34 @@ def resize_bilinear(x, out_h, out_w):
     return t + (b - t) * yt
 
 
+def space_to_depth2(x, cp=None):
+    """(N,H,W,C) -> (N,H/2,W/2,cp): block channel (2 pr + pc) C + c = pixel (2by + pr, 2bx + pc); channels >= 4 C are zero."""
+    n, h, w, c = x.shape
+    cp = 4 * c if cp is None else cp
+    y = torch.zeros((n, h // 2, w // 2, cp), dtype=x.dtype)
+    for pr in range(2):
+        for pc in range(2):
+            y[..., (2 * pr + pc) * c:(2 * pr + pc + 1) * c] = x[:, pr::2, pc::2, :]
+    return y
+
+
+def s2d_conv_weights(w5, cp=None):
+    """The 3x3 stride-1 kernel over the space-to-depth image that equals a 5x5 stride-2 TF-SAME convolution over an even-sized
+    image: tap ky = 2 dy + pr - 1 of block offset dy (0 outside 0..4).  Test-side statement of the identity the throughput mode
+    runs the codec's strided layers through (neural-imaging_amd/csrc/latent.hip s2d_conv_weights_kernel)."""
+    cin, cout = w5.shape[2], w5.shape[3]
+    cp = 4 * cin if cp is None else cp
+    w3 = torch.zeros((3, 3, cp, cout), dtype=w5.dtype)
+    for dy in range(3):
+        for dx in range(3):
+            for pr in range(2):
+                for pc in range(2):
+                    ky, kx = 2 * dy + pr - 1, 2 * dx + pc - 1
+                    if 0 <= ky <= 4 and 0 <= kx <= 4:
+                        w3[dy, dx, (2 * pr + pc) * cin:(2 * pr + pc + 1) * cin, :] = w5[ky, kx]
+    return w3
+
+
 def resize_nearest(x, out_h, out_w):
     """tf.image.resize(method='nearest') = ResizeNearestNeighbor(half_pixel_centers=True, align_corners=False): source index
     min(floor((o + 0.5f) * (in / out)), in - 1), evaluated in float32 (tensorflow/core/kernels/image/resize_nearest_neighbor_op.cc

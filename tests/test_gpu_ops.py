@@ -704,6 +704,7 @@ def test_stride2_conv_as_space_to_depth_conv(dev, shape):
         w3 = ops.s2d_conv_weights(g(wk, dev))
         cp = w3.shape[2]
         assert cp % 16 == 0 and cp >= 4 * cin and float(w3.abs().sum()) == pytest.approx(float(np.abs(wk).sum()), rel=1e-5)
+        assert np.array_equal(w3.cpu().numpy(), T.s2d_conv_weights(torch.from_numpy(wk), cp).numpy())      # the oracle's statement of it
         probe = rnd((3, 3, cp, cout), 35)
         back = ops.s2d_conv_weights_bwd(g(probe, dev), torch.zeros((5, 5, cin, cout), device=dev))
         assert abs(float((w3 * g(probe, dev)).sum()) - float((back * g(wk, dev)).sum())) < 1e-3          # <T w, p> == <w, T^t p>

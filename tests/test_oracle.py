@@ -266,3 +266,21 @@ def test_oracle_datafeed_policy_consistency():
     assert x.dtype == np.float32 and np.array_equal(x[0], (raw[1, 2:6, 1:5] / 65535.0).astype(np.float32))
     assert np.array_equal(y[1], (rgb[0, :8, :8] / 255.0).astype(np.float32))
 
+
+def test_stride2_conv_is_a_conv_over_the_space_to_depth_image():
+    """The identity behind the throughput-mode form of the codec's strided layers (models/compression.py:217-229): a 5x5 stride-2
+    TF-SAME convolution over an even-sized image equals a 3x3 stride-1 SAME convolution over its space-to-depth image with the
+    re-arranged kernel - forward and, through autograd, both gradients (the kernel gradient maps back by the transposed gather)."""
+    g = torch.Generator().manual_seed(5)
+    for (n, h, w, cin, cout, cp) in ((2, 16, 24, 3, 8, 16), (1, 8, 8, 5, 4, None)):
+        x = torch.randn((n, h, w, cin), dtype=torch.float64, generator=g).requires_grad_(True)
+        w5 = torch.randn((5, 5, cin, cout), dtype=torch.float64, generator=g).requires_grad_(True)
+        b = torch.randn((cout,), dtype=torch.float64, generator=g)
+        ref = T.conv2d(x, w5, b, 2, 'SAME')
+        got = T.conv2d(T.space_to_depth2(x, cp), T.s2d_conv_weights(w5, cp), b, 1, 'SAME')
+        assert ref.shape == got.shape == (n, h // 2, w // 2, cout) and float((ref - got).abs().max()) < 1e-12
+        dy = torch.randn(ref.shape, dtype=torch.float64, generator=g)
+        gx, gw = torch.autograd.grad((ref * dy).sum(), (x, w5))
+        gx2, gw2 = torch.autograd.grad((got * dy).sum(), (x, w5))
+        assert float((gx - gx2).abs().max()) < 1e-12 and float((gw - gw2).abs().max()) < 1e-12
+
