@@ -302,12 +302,14 @@ size_t nimg_conv5_dgrad_sparse_image_bytes(int cin, int cout);
 int nimg_conv5_dgrad_sparse_weights(const float* w, void* image, int cin, int cout, void* stream);
 int nimg_conv5_dgrad_sparse(const void* g, const unsigned char* idx, int cout, const void* image, void* out, int cin,
                             const void* act_mask, int n, int h, int wd, float alpha, int flags, void* stream);
-/* nimg_conv2d_fwd_bf16_ex + `residual` (float32, the shape of out1) added after bias, activation and mask: a residual block's skip
- * connection in the same pass (net + conv(a) forward, d_net + mask * dgrad backward; models/compression.py:224-227, 240-243).
- * 3x3, stride 1, float32 output with o1 % 4 == 0. */
+/* nimg_conv2d_fwd_bf16_ex for the layers of a residual block (models/compression.py:224-227, 240-243): `residual` (float32, the
+ * shape of out1, optional) is added after bias, activation and mask (net + conv(a) forward, d_net + mask * dgrad backward), and
+ * `out_bf16_copy` (optional) receives the same result rounded to bf16 next to the float32 out1 (the exact float32 stream for the
+ * skip sum, the bf16 copy for the convolutions / weight gradients that read it).  At least one of the two; 3x3, stride 1,
+ * float32 output with o1 % 4 == 0. */
 int nimg_conv2d_fwd_bf16_res(const float* in1, int c1, const void* wb, const float* bias, float* out1, int o1,
-                             const float* act_mask, const float* residual, int n, int h, int wd, int ks, int pad_t, int pad_l,
-                             int pad_mode, int hout, int wout, int act, float alpha, int flags, void* stream);
+                             const float* act_mask, const float* residual, void* out_bf16_copy, int n, int h, int wd, int ks,
+                             int pad_t, int pad_l, int pad_mode, int hout, int wout, int act, float alpha, int flags, void* stream);
 /* Backward of the FAN's fused conv + LeakyReLU + MaxPool2D layers conv2..4 (models/forensics.py:73-77) straight from the POOLED
  * gradient g (bf16, already x LeakyReLU') and the arg-max bytes: the MaxPool2D routing is applied while the kernels stage their
  * tiles, so the full-resolution gradient (4x the bytes, 3/4 zeros) is never written nor re-read.  5x5, stride 1, SAME.

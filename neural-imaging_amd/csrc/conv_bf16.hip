@@ -129,6 +129,9 @@ struct ConvParamsB {
                                    // the convolution runs on their 2x2 un-pooling (H x W), built while staging
     const float* res;              // optional float32 tensor of out1's shape added to the result (after bias, activation and mask):
                                    // the skip connection of a residual block, forward and backward (3x3, float32 output)
+    float* out1b;                  // optional SECOND copy of out1 as bf16 (float32 out1 only): the running float32 sum of a residual
+                                   // stream stays exact while its consumers - convolutions and weight gradients, which round to
+                                   // bf16 anyway - read half the bytes through the bf16-input kernels
 };
 
 // INB: in1 is stored as bf16 (compile-time: a run-time branch around the prefetch loads makes the backend wait for them at
@@ -446,6 +449,7 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
                         const float4 r = *reinterpret_cast<const float4*>(p.res + pixoff * p.O1 + co);
                         v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                     }
+                    if (p.out1b) store4_bf16(p.out1b, pixoff * p.O1 + co, v);
                     if (p.flags & NIMG_BF16_OUT) store4_bf16(p.out1, pixoff * p.O1 + co, v);
                     else *reinterpret_cast<float4*>(p.out1 + pixoff * p.O1 + co) = v;
                 } else {
@@ -1124,7 +1128,7 @@ static int conv2d_fwd_bf16_impl(const float* in1, int c1, const float* in2, int 
                          float* out1, int o1, float* out2, int o2, const float* act_mask, int n, int h, int wd,
                          int ks, int stride, int pad_t, int pad_l, int pad_mode, int hout, int wout, int act,
                          float alpha, int flags, void* stream, const unsigned char* in_idx = nullptr,
-                         const float* res = nullptr) {
+                         const float* res = nullptr, void* out1b = nullptr) {
     if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!in1 || !wb || !out1 || c1 <= 0 || c2 < 0 || o1 <= 0 || o2 < 0 || n < 0 || h <= 0 || wd <= 0) return NIMG_ERR_ARG;
     if ((c2 > 0 && !in2) || (o2 > 0 && !out2) || hout <= 0 || wout <= 0 || pad_t < 0 || pad_l < 0) return NIMG_ERR_ARG;
@@ -1135,7 +1139,8 @@ static int conv2d_fwd_bf16_impl(const float* in1, int c1, const float* in2, int 
     ConvParamsB p;
     p.in1 = in1; p.in2 = in2; p.wb = (const __bf16*)wb; p.bias = bias; p.out1 = out1; p.out2 = out2; p.act1 = act_mask;
     p.pool_out = nullptr; p.pool_idx = nullptr; p.convt = 0; p.flags = flags; p.in_idx = in_idx; p.res = res;
-    if (res && (ks != 3 || stride != 1 || o2 != 0 || (o1 & 3) || (flags & NIMG_BF16_OUT))) return NIMG_ERR_ARG;
+    p.out1b = (float*)out1b;
+    if ((res || out1b) && (ks != 3 || stride != 1 || o2 != 0 || (o1 & 3) || (flags & NIMG_BF16_OUT))) return NIMG_ERR_ARG;
     if (in_idx && (!(flags & NIMG_BF16_IN) || stride != 1 || ks != 5 || (h & 1) || (wd & 1) || pad_mode != 0)) return NIMG_ERR_ARG;
     if ((flags & (NIMG_BF16_OUT | NIMG_BF16_MASK)) && ((o1 & 3) || (o2 & 3))) return NIMG_ERR_ARG;   // vector epilogue only
     if ((flags & NIMG_BF16_MASK) && o2 != 0) return NIMG_ERR_ARG;
@@ -1167,15 +1172,17 @@ int nimg_conv2d_fwd_bf16_ex(const float* in1, int c1, const float* in2, int c2, 
                                 pad_mode, hout, wout, act, alpha, flags, stream);
 }
 
-/* nimg_conv2d_fwd_bf16_ex + `residual` (float32, the shape of out1) added to the result after bias, activation and mask: the skip
- * connection of a residual block in one pass - net + conv(a) forward, d_net + mask * dgrad backward (models/compression.py:224-227,
- * 240-243).  3x3, stride 1, one float32 output with o1 % 4 == 0 (else NIMG_ERR_ARG). */
+/* nimg_conv2d_fwd_bf16_ex for the layers of a residual block (models/compression.py:224-227, 240-243): `residual` (float32, the
+ * shape of out1, optional) is added to the result after bias, activation and mask - net + conv(a) forward, d_net + mask * dgrad
+ * backward, one pass - and `out_bf16_copy` (optional) receives the same result rounded to bf16 next to the float32 out1: the
+ * residual stream keeps its exact float32 sum, its consumers read the bf16 copy.  At least one of the two; 3x3, stride 1, one
+ * float32 output with o1 % 4 == 0 (else NIMG_ERR_ARG). */
 int nimg_conv2d_fwd_bf16_res(const float* in1, int c1, const void* wb, const float* bias, float* out1, int o1,
-                             const float* act_mask, const float* residual, int n, int h, int wd, int ks, int pad_t, int pad_l,
-                             int pad_mode, int hout, int wout, int act, float alpha, int flags, void* stream) {
-    if (!residual) return NIMG_ERR_ARG;
+                             const float* act_mask, const float* residual, void* out_bf16_copy, int n, int h, int wd, int ks,
+                             int pad_t, int pad_l, int pad_mode, int hout, int wout, int act, float alpha, int flags, void* stream) {
+    if (!residual && !out_bf16_copy) return NIMG_ERR_ARG;
     return conv2d_fwd_bf16_impl(in1, c1, nullptr, 0, wb, bias, out1, o1, nullptr, 0, act_mask, n, h, wd, ks, 1, pad_t, pad_l,
-                                pad_mode, hout, wout, act, alpha, flags, stream, nullptr, residual);
+                                pad_mode, hout, wout, act, alpha, flags, stream, nullptr, residual, out_bf16_copy);
 }
 
 /* The same convolution on the 2x2 UN-POOLING of a pooled bf16 tensor: in_pooled (n, h/2, wd/2, c1) bf16 + in_idx arg-max bytes
@@ -1207,7 +1214,7 @@ int nimg_convt2x2_fwd_bf16_ex(const float* x, const void* wb, const float* bias,
     if ((flags & ~(NIMG_BF16_IN | NIMG_BF16_OUT)) || ((flags & NIMG_BF16_OUT) && (cout & 3))) return NIMG_ERR_ARG;
     ConvParamsB p;
     p.in1 = x; p.in2 = nullptr; p.wb = (const __bf16*)wb; p.bias = bias; p.out1 = y; p.out2 = nullptr; p.act1 = nullptr;
-    p.pool_out = nullptr; p.pool_idx = nullptr; p.convt = 1; p.flags = flags; p.in_idx = nullptr; p.res = nullptr;
+    p.pool_out = nullptr; p.pool_idx = nullptr; p.convt = 1; p.flags = flags; p.in_idx = nullptr; p.res = nullptr; p.out1b = nullptr;
     p.C1 = cin; p.C2 = 0; p.O1 = cout; p.O2 = 0; p.CinP = (cin + 15) / 16 * 16;
     p.N = n; p.H = h; p.W = wd; p.Hout = h; p.Wout = wd; p.pad_t = 0; p.pad_l = 0;
     p.tiles_y = p.tiles_x = 0; p.act = 0; p.pad_mode = 0; p.alpha = 0.f;
@@ -2024,6 +2031,7 @@ int nimg_conv2d_pool_fwd_bf16_ex(const float* in, int cin, const float* w, const
     ConvParamsB p;
     p.in1 = in; p.in2 = nullptr; p.wb = (const __bf16*)wb; p.bias = bias; p.out1 = nullptr; p.out2 = nullptr;
     p.act1 = nullptr; p.pool_out = pool_out; p.pool_idx = pool_idx; p.convt = 0; p.flags = flags; p.in_idx = nullptr; p.res = nullptr;
+    p.out1b = nullptr;
     p.C1 = cin; p.C2 = 0; p.O1 = cout; p.O2 = 0; p.CinP = (cin + 15) / 16 * 16;
     p.N = n; p.H = h; p.W = wd; p.Hout = h; p.Wout = wd; p.pad_t = p.pad_l = (ks - 1) / 2;
     p.tiles_y = p.tiles_x = 0; p.act = act; p.pad_mode = 0; p.alpha = alpha;

@@ -10,6 +10,7 @@ DiscreteLatent -> Conv3x3 512 -> d2s -> 3 residual blocks -> Conv3x3 256 +LReLU 
 As in the reference the latent scale is always trainable and the codebook never, whatever
 scale_latent / train_codebook say; they are recorded hyper-parameters only.
 """
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -228,8 +229,18 @@ class TwitterDCN(DCN):
         bf16 on the way to the matrix core anyway) and the LeakyReLU' sign test: the forward pass is bit-identical, the weight
         gradients agree to summation order; the fused BIAS gradient of a block's first layer sums the stored (now bf16-rounded)
         gradient - an unbiased 2^-9 relative rounding per element (test_dcn_bf16_storage_inside_residual_blocks_is_bit_neutral).
-        The residual stream itself (a running float32 sum) stays float32."""
+        The residual stream itself (a running float32 sum) stays float32; the kernels that write it also write a bf16 COPY
+        (ops.conv2d bf16_copy) - what its consumers (the next block's first convolution, the weight gradients, the input
+        gradient of the block's second layer) would round it to on the way to the matrix core - so that all 3x3 work of the
+        blocks reads bf16 operands through the bf16-input kernels (weight gradient: the all-taps kernel) while the skip sums
+        read and write the exact float32 tensor."""
         return ops.COMPUTE == 'bf16' and ops.STORE_BF16
+
+    @staticmethod
+    def _operand(t, tb):
+        """The tensor a convolution / weight gradient reads: the bf16 copy of a residual-stream tensor where one exists
+        (NIMG_NO_BF16_COPY=1 keeps the float32 tensor: the A/B switch of tools/r03_ah.sh)."""
+        return t if tb is None or os.environ.get('NIMG_NO_BF16_COPY') else tb
 
     def encode(self, x, training=False):
         L, P = self._layers, self._model
@@ -238,14 +249,17 @@ class TwitterDCN(DCN):
         self._in_hw = (x.shape[1], x.shape[2])
         t['e1'], t['x0'] = L['e1'].forward_image(P, x, 2.0, -1.0)       # x0 = 2 x - 1 (or its bf16 space-to-depth image)
         t['e2'] = L['e2'].forward(P, t['e1'])
-        net = t['e2']
+        net, net_b = t['e2'], None
         t['n0'] = net
+        bf = self._bf16_inner()
         for b in (1, 2, 3):
-            inp = ops.lrelu(net) if b == 1 else net
+            inp = ops.lrelu(net) if b == 1 else self._operand(net, net_b)
             t['er{}in'.format(b)] = inp
-            a = L['er{}a'.format(b)].forward(P, inp, out_bf16=self._bf16_inner())
+            a = L['er{}a'.format(b)].forward(P, inp, out_bf16=bf)
             t['er{}a'.format(b)] = a
-            net = L['er{}b'.format(b)].forward(P, a, residual=net)          # net + conv(a), one pass
+            want = bf and b < 3                             # the last block feeds the stride-2 latent layer (float32 input)
+            net = L['er{}b'.format(b)].forward(P, a, residual=net, bf16_copy=want)                  # net + conv(a), one pass
+            net, net_b = net if want else (net, None)
             t['n{}'.format(b)] = net
         t['zl'] = L['elat'].forward(P, net)
         if self._lws is None or self._lws.buf.device != x.device:
@@ -269,12 +283,16 @@ class TwitterDCN(DCN):
         t['d512'] = L['d512'].forward(P, lat)
         net = ops.d2s_clip(t['d512'], 1.0, 0.0, False)
         t['i0'] = net
+        net_b, bf = None, self._bf16_inner()
         for b in (1, 2, 3):
-            a = L['dr{}a'.format(b)].forward(P, net, out_bf16=self._bf16_inner())
+            t['dr{}in'.format(b)] = self._operand(net, net_b)
+            a = L['dr{}a'.format(b)].forward(P, t['dr{}in'.format(b)], out_bf16=bf)
             t['dr{}a'.format(b)] = a
-            net = L['dr{}b'.format(b)].forward(P, a, residual=net)
+            net = L['dr{}b'.format(b)].forward(P, a, residual=net, bf16_copy=bf)
+            net, net_b = net if bf else (net, None)
             t['i{}'.format(b)] = net
-        t['d256'] = L['d256'].forward(P, net)
+        t['d256in'] = self._operand(net, net_b)
+        t['d256'] = L['d256'].forward(P, t['d256in'])
         t['i4'] = ops.d2s_clip(t['d256'], 1.0, 0.0, False)
         t['d12'] = L['d12'].forward(P, t['i4'])
         y = ops.d2s_clip(t['d12'], 0.5, 0.5, True)               # (x + 1) / 2 then straight-through clip
@@ -295,14 +313,18 @@ class TwitterDCN(DCN):
         L['d12'].backward_params(P, dt['i4'], dz)
         d_i4 = L['d12'].backward_input(P, dz, hw(dt['i4']))
         dz = ops.lrelu_bwd(ops.d2s_clip_bwd(d_i4, 1.0), dt['d256'])
-        L['d256'].backward_params(P, dt['i3'], dz)
-        d_net = L['d256'].backward_input(P, dz, hw(dt['i3']))
+        bf = self._bf16_inner()
+        L['d256'].backward_params(P, dt['d256in'], dz)
+        d_net = L['d256'].backward_input(P, dz, hw(dt['i3']), bf16_copy=bf)
+        d_net, d_net_b = d_net if bf else (d_net, None)
         for b in (3, 2, 1):
-            a, inp = dt['dr{}a'.format(b)], dt['i{}'.format(b - 1)]
-            L['dr{}b'.format(b)].backward_params(P, a, d_net)
-            dza = L['dr{}b'.format(b)].backward_input(P, d_net, hw(a), act_mask=a, out_bf16=self._bf16_inner())
+            a, inp = dt['dr{}a'.format(b)], dt['dr{}in'.format(b)]
+            dzs = self._operand(d_net, d_net_b)         # the matrix-core operand form of the stream's gradient
+            L['dr{}b'.format(b)].backward_params(P, a, dzs)
+            dza = L['dr{}b'.format(b)].backward_input(P, dzs, hw(a), act_mask=a, out_bf16=bf)
             L['dr{}a'.format(b)].backward_params(P, inp, dza)
-            d_net = L['dr{}a'.format(b)].backward_input(P, dza, hw(inp), residual=d_net)
+            d_net = L['dr{}a'.format(b)].backward_input(P, dza, hw(inp), residual=d_net, bf16_copy=bf and b > 1)
+            d_net, d_net_b = d_net if bf and b > 1 else (d_net, None)
         dz = ops.d2s_clip_bwd(d_net, 1.0)
         L['d512'].backward_params(P, dt['latent'], dz)
         d_lat = L['d512'].backward_input(P, dz, hw(dt['latent']))
@@ -312,15 +334,17 @@ class TwitterDCN(DCN):
                              self._lws, dscale=P.g['latent_scaling'].view(1), soft_codebook=soft)
         # ---- encoder
         L['elat'].backward_params(P, et['n3'], dzl)
-        d_net = L['elat'].backward_input(P, dzl, hw(et['n3']))
+        d_net, d_net_b = L['elat'].backward_input(P, dzl, hw(et['n3'])), None
         for b in (3, 2, 1):
             a, inp = et['er{}a'.format(b)], et['er{}in'.format(b)]
-            L['er{}b'.format(b)].backward_params(P, a, d_net)
-            dza = L['er{}b'.format(b)].backward_input(P, d_net, hw(a), act_mask=a, out_bf16=self._bf16_inner())
+            dzs = self._operand(d_net, d_net_b)
+            L['er{}b'.format(b)].backward_params(P, a, dzs)
+            dza = L['er{}b'.format(b)].backward_input(P, dzs, hw(a), act_mask=a, out_bf16=bf)
             L['er{}a'.format(b)].backward_params(P, inp, dza)
             # block 1 was fed LeakyReLU(e2): its input gradient goes through that activation (mask by sign of e2)
             d_net = L['er{}a'.format(b)].backward_input(P, dza, hw(inp), act_mask=et['e2'] if b == 1 else None,
-                                                        residual=d_net)
+                                                        residual=d_net, bf16_copy=bf and b > 1)
+            d_net, d_net_b = d_net if bf and b > 1 else (d_net, None)
         L['e2'].backward_params(P, et['e1'], d_net)
         dz1 = L['e2'].backward_input(P, d_net, hw(et['e1']), act_mask=et['e1'])
         L['e1'].backward_params_image(P, et['x0'], dz1)

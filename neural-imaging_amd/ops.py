@@ -287,12 +287,17 @@ def djpeg_bwd(x, gy, mask, qtab, rounding='soft', out=None, dq=None, accumulate=
 # ----------------------------------------------------------------------------------------------------------------
 # convolutions
 def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mode=0, out=None, out2=None,
-           act_mask=None, pads=None, out_hw=None, _wmode=0, _f32_only=False, mask_alpha=None, out_bf16=False, residual=None):
+           act_mask=None, pads=None, out_hw=None, _wmode=0, _f32_only=False, mask_alpha=None, out_bf16=False, residual=None,
+           bf16_copy=False):
     """x (N,H,W,C1) [+ x2 (N,H,W,C2)], w (k,k,C1+C2,Cout) HWIO.  padding 'SAME' (TF) | 'VALID' | explicit pads/out_hw.
     out/out2: optional pre-allocated outputs (out2 splits the output channels: Cout = out.C + out2.C).
     residual: float32 tensor of the output's shape added to the result (a residual block's skip connection; fused into the
-    3x3 throughput-mode kernel, a separate add elsewhere)."""
-    if residual is not None:
+    3x3 throughput-mode kernel, a separate add elsewhere).
+    bf16_copy: return (out, copy) with `copy` = the float32 result rounded to bf16 by the same kernel (None where the fused
+    kernel does not apply, i.e. in float32 mode): what the bf16 kernels downstream would round it to anyway, at half the
+    bytes."""
+    copy = None
+    if residual is not None or bf16_copy:
         _f32(residual)
         fused = COMPUTE == 'bf16' and not _f32_only and x2 is None and out2 is None and stride == 1 and w.shape[0] == 3 and \
             not out_bf16 and (out is None or out.dtype == torch.float32) and x.shape[3] % 8 == 0 and \
@@ -301,7 +306,9 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
             y = conv2d(x, w, bias, x2=x2, stride=stride, padding=padding, act=act, pad_mode=pad_mode, out=out, out2=out2,
                        act_mask=act_mask, pads=pads, out_hw=out_hw, _wmode=_wmode, _f32_only=_f32_only, mask_alpha=mask_alpha,
                        out_bf16=out_bf16)
-            return add(residual, y, out=y)
+            if residual is not None:
+                add(residual, y, out=y)
+            return (y, None) if bf16_copy else y
     _f32(w, bias)
     _fb(x, x2, out, out2, act_mask)
     if (x2 is not None and x2.dtype != x.dtype) or (out2 is not None and out is not None and out2.dtype != out.dtype):
@@ -352,12 +359,14 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
         wb = weights_bf16(w, _wmode)
         flags = (BF16_IN if _is_bf16(x) else 0) | (BF16_OUT if _is_bf16(out) else 0) | \
             (BF16_MASK if _is_bf16(act_mask) else 0)
-        if residual is not None:
-            if tuple(residual.shape) != tuple(out.shape):
+        if residual is not None or bf16_copy:
+            if residual is not None and tuple(residual.shape) != tuple(out.shape):
                 raise ValueError('residual: the shape of the output expected')
-            _lib.call('nimg_conv2d_fwd_bf16_res', _p(x), c1, _p(wb), _p(bias), _p(out), o1, _p(act_mask), _p(residual), n, h, wd,
-                      ks, pt, pl, pad_mode, ho, wo, act_id, alpha, flags, _stream())
-            return out
+            if bf16_copy:
+                copy = torch.empty(out.shape, dtype=torch.bfloat16, device=out.device)
+            _lib.call('nimg_conv2d_fwd_bf16_res', _p(x), c1, _p(wb), _p(bias), _p(out), o1, _p(act_mask), _p(residual), _p(copy),
+                      n, h, wd, ks, pt, pl, pad_mode, ho, wo, act_id, alpha, flags, _stream())
+            return (out, copy) if bf16_copy else out
         _lib.call('nimg_conv2d_fwd_bf16_ex', _p(x), c1, _p(x2), c2, _p(wb), _p(bias), _p(out), o1, _p(out2), o2,
                   _p(act_mask), n, h, wd, ks, stride, pt, pl, pad_mode, ho, wo, act_id, alpha, flags, _stream())
         return out if out2 is None else (out, out2)
@@ -380,7 +389,7 @@ def flip_weights(w, out=None):
 
 
 def conv2d_dgrad(dz, w, in_hw, stride=1, padding='SAME', act_mask=None, out=None, out2=None, mask_alpha=None,
-                 out_bf16=False, residual=None):
+                 out_bf16=False, residual=None, bf16_copy=False):
     """Input gradient of conv2d (stride 1, odd kernel): correlation of dz with the flipped kernel."""
     if stride != 1:
         raise NotImplementedError('strided dgrad is expressed by the caller (see models/compression.py)')
@@ -393,7 +402,7 @@ def conv2d_dgrad(dz, w, in_hw, stride=1, padding='SAME', act_mask=None, out=None
         pt = pl = 0
     # forward used pad (pt, pl); the gradient correlation needs ks-1-pt / ks-1-pl; the kernel is read flipped/transposed
     return conv2d(dz, w, None, pads=(ks - 1 - pt, ks - 1 - pl), out_hw=(h, wd), act_mask=act_mask, out=out,
-                  out2=out2, _wmode=1, mask_alpha=mask_alpha, out_bf16=out_bf16, residual=residual)
+                  out2=out2, _wmode=1, mask_alpha=mask_alpha, out_bf16=out_bf16, residual=residual, bf16_copy=bf16_copy)
 
 
 def conv2d_wgrad(x, dz, ks, x2=None, stride=1, padding='SAME', pad_mode=0, pads=None, dw=None, accumulate=False,

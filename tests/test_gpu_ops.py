@@ -747,16 +747,37 @@ def test_conv3x3_with_fused_residual(dev):
             dplain = ops.conv2d_dgrad(x, wk, (h, w), act_mask=mask)
             dfused = ops.conv2d_dgrad(x, wk, (h, w), act_mask=mask, residual=r)
             assert torch.equal(dfused, dplain + r), mode
+            # the bf16 copy written next to the float32 result: that result rounded to nearest-even, nothing else - and a
+            # convolution reading the copy equals the convolution reading the float32 tensor (which rounds on its way in)
+            for res in (r, None):
+                both, copy = ops.conv2d(x, wk, b, residual=res, bf16_copy=True)
+                assert torch.equal(both, fused if res is not None else plain), mode
+                dboth, dcopy = ops.conv2d_dgrad(x, wk, (h, w), act_mask=mask, residual=res, bf16_copy=True)
+                assert torch.equal(dboth, dfused if res is not None else dplain), mode
+                if mode == 'bf16':
+                    assert copy.dtype == torch.bfloat16 and torch.equal(copy, both.to(torch.bfloat16))
+                    assert torch.equal(dcopy, dboth.to(torch.bfloat16))
+                    assert_close(ops.conv2d(copy, wk, b).cpu().numpy(), ops.conv2d(both, wk, b).cpu().numpy(), 1e-5, 1e-5,
+                                 what='conv of the bf16 copy')        # same operands, the kernels' summation orders
+                    dw_c = ops.conv2d_wgrad(copy, dcopy, 3)
+                    dw_f = ops.conv2d_wgrad(both, dboth, 3)
+                    assert_close(dw_c.cpu().numpy(), dw_f.cpu().numpy(), 1e-6, 2e-5, what='wgrad from the bf16 copies')
+                else:
+                    assert copy is None and dcopy is None           # float32 mode has no bf16 tensors
         finally:
             ops.set_compute('f32')
     ops.set_compute('bf16')
     try:
+        from neural_imaging_amd import _lib
+        wb = ops.weights_bf16(g(rnd((5, 5, c, c), 46), dev), 0)
+        out = torch.empty_like(x)
         with pytest.raises(RuntimeError):           # the C ABI refuses shapes the fused epilogue does not serve
-            from neural_imaging_amd import _lib
-            wb = ops.weights_bf16(g(rnd((5, 5, c, c), 46), dev), 0)
-            out = torch.empty_like(x)
-            _lib.call('nimg_conv2d_fwd_bf16_res', x.data_ptr(), c, wb.data_ptr(), None, out.data_ptr(), c, None, r.data_ptr(), n, h,
-                      w, 5, 2, 2, 0, h, w, 0, 0.2, 0, torch.cuda.current_stream().cuda_stream)
+            _lib.call('nimg_conv2d_fwd_bf16_res', x.data_ptr(), c, wb.data_ptr(), None, out.data_ptr(), c, None, r.data_ptr(), None,
+                      n, h, w, 5, 2, 2, 0, h, w, 0, 0.2, 0, torch.cuda.current_stream().cuda_stream)
+        wb3 = ops.weights_bf16(wk, 0)
+        with pytest.raises(RuntimeError):           # ... and a call that asks for neither the skip sum nor the copy
+            _lib.call('nimg_conv2d_fwd_bf16_res', x.data_ptr(), c, wb3.data_ptr(), None, out.data_ptr(), c, None, None, None,
+                      n, h, w, 3, 1, 1, 0, h, w, 0, 0.2, 0, torch.cuda.current_stream().cuda_stream)
     finally:
         ops.set_compute('f32')
 
