@@ -35,6 +35,11 @@ extern "C" {
 #define NIMG_BF16_OUT 2   /* out1 AND out2 (o1 % 4 == 0, o2 % 4 == 0) / pool_out / dz of the un-pool */
 #define NIMG_BF16_MASK 4  /* act_mask */
 #define NIMG_BF16_DZ 8    /* dz of a weight gradient (cout % 8 == 0) */
+#define NIMG_D2S_OUT 16   /* 3x3 stride-1 convolutions (o1 % 16 == 0, no out2): out1 - and the act_mask / residual / bf16 copy that
+                           * share its indexing - is the depth_to_space(2) image (n, 2 hout, 2 wout, o1 / 4) of the result, the
+                           * tf.nn.depth_to_space layout (block 2 dy + dx of pixel (y, x) -> pixel (2y + dy, 2x + dx)):
+                           * models/compression.py:233,245,249 forward, and the input gradient of a stride-2 layer computed
+                           * over its space-to-depth image (nimg_s2d_conv_weights) */
 
 /* library / ABI version, bumped on any signature change */
 int nimg_abi_version(void);

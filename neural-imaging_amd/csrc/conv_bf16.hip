@@ -439,19 +439,24 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
                     v.x = lrelu(v.x, p.alpha); v.y = lrelu(v.y, p.alpha); v.z = lrelu(v.z, p.alpha); v.w = lrelu(v.w, p.alpha);
                 }
                 if (co < p.O1) {
+                    long o = pixoff * p.O1 + co;
+                    if (p.flags & NIMG_D2S_OUT) {      // depth_to_space(2): channel block (2 dy + dx) of pixel (oy, ox) is pixel
+                        const int cd = p.O1 >> 2, blk = co / cd;                 // (2 oy + dy, 2 ox + dx) of the output
+                        o = (((long)n * 2 * p.Hout + 2 * oy + (blk >> 1)) * (2 * p.Wout) + 2 * ox + (blk & 1)) * cd + (co - blk * cd);
+                    }
                     if (p.act1) {
-                        const float4 m = (p.flags & NIMG_BF16_MASK) ? load4_bf16(p.act1, pixoff * p.O1 + co)
-                                                                    : *reinterpret_cast<const float4*>(p.act1 + pixoff * p.O1 + co);
+                        const float4 m = (p.flags & NIMG_BF16_MASK) ? load4_bf16(p.act1, o)
+                                                                    : *reinterpret_cast<const float4*>(p.act1 + o);
                         v.x *= m.x > 0.f ? 1.0f : p.alpha; v.y *= m.y > 0.f ? 1.0f : p.alpha;
                         v.z *= m.z > 0.f ? 1.0f : p.alpha; v.w *= m.w > 0.f ? 1.0f : p.alpha;
                     }
                     if (p.res) {
-                        const float4 r = *reinterpret_cast<const float4*>(p.res + pixoff * p.O1 + co);
+                        const float4 r = *reinterpret_cast<const float4*>(p.res + o);
                         v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                     }
-                    if (p.out1b) store4_bf16(p.out1b, pixoff * p.O1 + co, v);
-                    if (p.flags & NIMG_BF16_OUT) store4_bf16(p.out1, pixoff * p.O1 + co, v);
-                    else *reinterpret_cast<float4*>(p.out1 + pixoff * p.O1 + co) = v;
+                    if (p.out1b) store4_bf16(p.out1b, o, v);
+                    if (p.flags & NIMG_BF16_OUT) store4_bf16(p.out1, o, v);
+                    else *reinterpret_cast<float4*>(p.out1 + o) = v;
                 } else {
                     if (p.flags & NIMG_BF16_OUT) store4_bf16(p.out2, pixoff * p.O2 + (co - p.O1), v);
                     else *reinterpret_cast<float4*>(p.out2 + pixoff * p.O2 + (co - p.O1)) = v;
@@ -1144,6 +1149,7 @@ static int conv2d_fwd_bf16_impl(const float* in1, int c1, const float* in2, int 
     if (in_idx && (!(flags & NIMG_BF16_IN) || stride != 1 || ks != 5 || (h & 1) || (wd & 1) || pad_mode != 0)) return NIMG_ERR_ARG;
     if ((flags & (NIMG_BF16_OUT | NIMG_BF16_MASK)) && ((o1 & 3) || (o2 & 3))) return NIMG_ERR_ARG;   // vector epilogue only
     if ((flags & NIMG_BF16_MASK) && o2 != 0) return NIMG_ERR_ARG;
+    if ((flags & NIMG_D2S_OUT) && (ks != 3 || stride != 1 || o2 != 0 || (o1 & 15) || in_idx)) return NIMG_ERR_ARG;
     p.C1 = c1; p.C2 = c2; p.O1 = o1; p.O2 = o2; p.CinP = (c1 + c2 + 15) / 16 * 16;
     p.N = n; p.H = h; p.W = wd; p.Hout = hout; p.Wout = wout; p.pad_t = pad_t; p.pad_l = pad_l;
     p.tiles_y = p.tiles_x = 0; p.act = act; p.pad_mode = pad_mode; p.alpha = alpha;

@@ -280,8 +280,7 @@ class TwitterDCN(DCN):
         P.refresh_images()
         t = OrderedDict()
         t['latent'] = lat
-        t['d512'] = L['d512'].forward(P, lat)
-        net = ops.d2s_clip(t['d512'], 1.0, 0.0, False)
+        net = L['d512'].forward(P, lat, d2s_out=True)           # depth_to_space written by the convolution itself
         t['i0'] = net
         net_b, bf = None, self._bf16_inner()
         for b in (1, 2, 3):
@@ -292,8 +291,7 @@ class TwitterDCN(DCN):
             net, net_b = net if bf else (net, None)
             t['i{}'.format(b)] = net
         t['d256in'] = self._operand(net, net_b)
-        t['d256'] = L['d256'].forward(P, t['d256in'])
-        t['i4'] = ops.d2s_clip(t['d256'], 1.0, 0.0, False)
+        t['i4'] = L['d256'].forward(P, t['d256in'], d2s_out=True)        # conv + LeakyReLU + depth_to_space
         t['d12'] = L['d12'].forward(P, t['i4'])
         y = ops.d2s_clip(t['d12'], 0.5, 0.5, True)               # (x + 1) / 2 then straight-through clip
         return y, (t if training else None)
@@ -311,8 +309,10 @@ class TwitterDCN(DCN):
         # ---- decoder
         dz = ops.d2s_clip_bwd(dy, 0.5)
         L['d12'].backward_params(P, dt['i4'], dz)
-        d_i4 = L['d12'].backward_input(P, dz, hw(dt['i4']))
-        dz = ops.lrelu_bwd(ops.d2s_clip_bwd(d_i4, 1.0), dt['d256'])
+        # LeakyReLU' of the d256 layer is taken on its depth-to-space image i4 (same signs, permuted), in the epilogue of
+        # this input gradient; the space_to_depth of the result is then the gradient at d256's output
+        d_i4 = L['d12'].backward_input(P, dz, hw(dt['i4']), act_mask=dt['i4'])
+        dz = ops.d2s_clip_bwd(d_i4, 1.0)
         bf = self._bf16_inner()
         L['d256'].backward_params(P, dt['d256in'], dz)
         d_net = L['d256'].backward_input(P, dz, hw(dt['i3']), bf16_copy=bf)

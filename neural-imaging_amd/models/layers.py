@@ -34,11 +34,12 @@ class Conv2D(object):
         store.p[self.name + '/kernel'].copy_(k)
         store.p[self.name + '/bias'].zero_()
 
-    def forward(self, store, x, x2=None, out_bf16=False, residual=None, bf16_copy=False):
+    def forward(self, store, x, x2=None, out_bf16=False, residual=None, bf16_copy=False, d2s_out=False):
         """residual: the skip tensor of a residual block, added to the layer's output in the same pass (ops.conv2d);
-        bf16_copy: returns (out, bf16 copy of out or None), see ops.conv2d."""
+        bf16_copy: returns (out, bf16 copy of out or None); d2s_out: returns tf.nn.depth_to_space(out, 2), see ops.conv2d."""
         return ops.conv2d(x, store.p[self.name + '/kernel'], store.p[self.name + '/bias'], x2=x2,
-                          stride=self.stride, act=self.activation, out_bf16=out_bf16, residual=residual, bf16_copy=bf16_copy)
+                          stride=self.stride, act=self.activation, out_bf16=out_bf16, residual=residual, bf16_copy=bf16_copy,
+                          d2s_out=d2s_out)
 
     def can_pool(self, x):
         return self.stride == 1 and self.cin2 == 0 and self.ks in (3, 5) and self.cout % 4 == 0 and \
@@ -59,8 +60,7 @@ class Conv2D(object):
         """residual: the gradient arriving over the block's skip connection, added in the same pass (stride-1 layers);
         bf16_copy: returns (gradient, bf16 copy of it or None), see ops.conv2d."""
         if self.stride == 2:
-            d = ops.conv2d_dgrad_strided2(dz, store.p[self.name + '/kernel'], in_hw)
-            d = d if act_mask is None else ops.lrelu_bwd(d, act_mask, out=d)
+            d = ops.conv2d_dgrad_strided2(dz, store.p[self.name + '/kernel'], in_hw, act_mask=act_mask)
             d = d if residual is None else ops.add(residual, d, out=d)
             return (d, None) if bf16_copy else d
         return ops.conv2d_dgrad(dz, store.p[self.name + '/kernel'], in_hw, stride=self.stride, act_mask=act_mask,

@@ -6,6 +6,7 @@ CUDA(HIP) tensors in NHWC and raises otherwise - there is no CPU path.
 TF padding semantics live here (same_pads): SAME is asymmetric for strided convolutions (extra sample after).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -112,7 +113,8 @@ def _f32(*ts):
     _chk(*ts)
 
 
-BF16_IN, BF16_OUT, BF16_MASK, BF16_DZ = 1, 2, 4, 8          # include/nimg.h NIMG_BF16_*
+D2S_EPILOGUE = os.environ.get('NIMG_NO_D2S_OUT') is None          # A/B switch: depth_to_space as a separate pass
+BF16_IN, BF16_OUT, BF16_MASK, BF16_DZ, D2S_OUT = 1, 2, 4, 8, 16          # include/nimg.h NIMG_BF16_*, NIMG_D2S_OUT
 
 
 def _fb(*ts):
@@ -288,8 +290,10 @@ def djpeg_bwd(x, gy, mask, qtab, rounding='soft', out=None, dq=None, accumulate=
 # convolutions
 def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mode=0, out=None, out2=None,
            act_mask=None, pads=None, out_hw=None, _wmode=0, _f32_only=False, mask_alpha=None, out_bf16=False, residual=None,
-           bf16_copy=False):
+           bf16_copy=False, d2s_out=False):
     """x (N,H,W,C1) [+ x2 (N,H,W,C2)], w (k,k,C1+C2,Cout) HWIO.  padding 'SAME' (TF) | 'VALID' | explicit pads/out_hw.
+    d2s_out: the result is returned as its depth_to_space(2) image (N, 2 Hout, 2 Wout, Cout / 4) - written in that layout by
+    the 3x3 throughput-mode kernel (act_mask then has that shape too), convolution + d2s_clip (+ lrelu_bwd) elsewhere.
     out/out2: optional pre-allocated outputs (out2 splits the output channels: Cout = out.C + out2.C).
     residual: float32 tensor of the output's shape added to the result (a residual block's skip connection; fused into the
     3x3 throughput-mode kernel, a separate add elsewhere).
@@ -297,6 +301,17 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
     kernel does not apply, i.e. in float32 mode): what the bf16 kernels downstream would round it to anyway, at half the
     bytes."""
     copy = None
+    if d2s_out:
+        co_ = w.shape[3] if _wmode == 0 else w.shape[2]
+        fused = COMPUTE == 'bf16' and not _f32_only and x2 is None and out is None and out2 is None and stride == 1 and \
+            w.shape[0] == 3 and co_ % 16 == 0 and x.shape[3] % 8 == 0 and D2S_EPILOGUE
+        if residual is not None or bf16_copy:
+            raise NotImplementedError('d2s_out with a residual / bf16 copy')
+        if not fused:
+            y = conv2d(x, w, bias, stride=stride, padding=padding, act=act, pad_mode=pad_mode, pads=pads, out_hw=out_hw,
+                       _wmode=_wmode, _f32_only=_f32_only)
+            y = d2s_clip(y, 1.0, 0.0, False)
+            return y if act_mask is None else lrelu_bwd(y, act_mask, out=y, alpha=mask_alpha)
     if residual is not None or bf16_copy:
         _f32(residual)
         fused = COMPUTE == 'bf16' and not _f32_only and x2 is None and out2 is None and stride == 1 and w.shape[0] == 3 and \
@@ -331,11 +346,14 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
     else:
         raise ValueError(padding)
     if out is None:
-        out = torch.empty((n, ho, wo, cout), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
-    o1 = out.shape[3]
+        out = torch.empty((n, 2 * ho, 2 * wo, cout // 4) if d2s_out else (n, ho, wo, cout),
+                          dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    o1 = cout if d2s_out else out.shape[3]
     o2 = 0 if out2 is None else out2.shape[3]
-    if o1 + o2 != cout or tuple(out.shape[:3]) != (n, ho, wo):
+    if o1 + o2 != cout or (not d2s_out and tuple(out.shape[:3]) != (n, ho, wo)):
         raise ValueError('output shape mismatch')
+    if d2s_out and act_mask is not None and tuple(act_mask.shape) != tuple(out.shape):
+        raise ValueError('d2s_out: the mask has the shape of the depth-to-space output')
     # activation: LeakyReLU(0.2) | ReLU (= slope 0); act_mask multiplies by the same-slope derivative (mask_alpha
     # overrides the slope for an input-gradient pass behind a ReLU layer)
     if act not in (None, 'leaky_relu', 'relu'):
@@ -358,7 +376,7 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
             (c1 % 8 == 0 or (c2 == 0 and c1 % 4 == 0 and c1 >= 8 and not _is_bf16(x))):
         wb = weights_bf16(w, _wmode)
         flags = (BF16_IN if _is_bf16(x) else 0) | (BF16_OUT if _is_bf16(out) else 0) | \
-            (BF16_MASK if _is_bf16(act_mask) else 0)
+            (BF16_MASK if _is_bf16(act_mask) else 0) | (D2S_OUT if d2s_out else 0)
         if residual is not None or bf16_copy:
             if residual is not None and tuple(residual.shape) != tuple(out.shape):
                 raise ValueError('residual: the shape of the output expected')
@@ -389,7 +407,7 @@ def flip_weights(w, out=None):
 
 
 def conv2d_dgrad(dz, w, in_hw, stride=1, padding='SAME', act_mask=None, out=None, out2=None, mask_alpha=None,
-                 out_bf16=False, residual=None, bf16_copy=False):
+                 out_bf16=False, residual=None, bf16_copy=False, d2s_out=False):
     """Input gradient of conv2d (stride 1, odd kernel): correlation of dz with the flipped kernel."""
     if stride != 1:
         raise NotImplementedError('strided dgrad is expressed by the caller (see models/compression.py)')
@@ -402,7 +420,8 @@ def conv2d_dgrad(dz, w, in_hw, stride=1, padding='SAME', act_mask=None, out=None
         pt = pl = 0
     # forward used pad (pt, pl); the gradient correlation needs ks-1-pt / ks-1-pl; the kernel is read flipped/transposed
     return conv2d(dz, w, None, pads=(ks - 1 - pt, ks - 1 - pl), out_hw=(h, wd), act_mask=act_mask, out=out,
-                  out2=out2, _wmode=1, mask_alpha=mask_alpha, out_bf16=out_bf16, residual=residual, bf16_copy=bf16_copy)
+                  out2=out2, _wmode=1, mask_alpha=mask_alpha, out_bf16=out_bf16, residual=residual, bf16_copy=bf16_copy,
+                  d2s_out=d2s_out)
 
 
 def conv2d_wgrad(x, dz, ks, x2=None, stride=1, padding='SAME', pad_mode=0, pads=None, dw=None, accumulate=False,
@@ -1078,24 +1097,30 @@ def s2d_conv_ok(ks, stride, h, w, cin):
     return COMPUTE == 'bf16' and S2D_CONV and ks == 5 and stride == 2 and h % 2 == 0 and w % 2 == 0 and cin >= 1
 
 
-def conv2d_dgrad_strided2(dz, w, in_hw, scale=1.0):
-    """Input gradient of a stride-2 TF-SAME convolution.  Throughput mode: the 3x3 stride-1 input gradient of the equivalent
-    convolution over the space-to-depth image, then depth-to-space (s2d_conv_weights).  Parity mode: zero insertion + stride-1
-    correlation with the flipped kernel (pad = ks-1-pad_before)."""
+def conv2d_dgrad_strided2(dz, w, in_hw, scale=1.0, act_mask=None):
+    """Input gradient of a stride-2 TF-SAME convolution (times LeakyReLU'(act_mask) if given).  Throughput mode: the 3x3
+    stride-1 input gradient of the equivalent convolution over the space-to-depth image (s2d_conv_weights), written straight
+    in the depth-to-space layout - and masked - by the kernel's epilogue (a separate d2s2_scale pass where the block channels
+    are padded, i.e. the 3-channel image layer).  Parity mode: zero insertion + stride-1 correlation with the flipped kernel
+    (pad = ks-1-pad_before)."""
     ks = w.shape[0]
     h, wd = in_hw
     cin = w.shape[2]
     if s2d_conv_ok(ks, 2, h, wd, cin) and not _is_bf16(dz):
         w3 = s2d_conv_weights(w)
+        if w3.shape[2] == 4 * cin and cin % 4 == 0 and scale == 1.0 and dz.shape[3] % 8 == 0:
+            return conv2d_dgrad(dz, w3, (h // 2, wd // 2), act_mask=act_mask, d2s_out=True)
         dxs = conv2d_dgrad(dz, w3, (h // 2, wd // 2))
-        return d2s2_scale(dxs, cin, scale)
-    _, pt = same_pads(h, ks, 2)
-    _, pl = same_pads(wd, ks, 2)
-    up = zero_insert2(dz)
-    if up.shape[1] != h or up.shape[2] != wd:
-        raise NotImplementedError('strided dgrad is built for even input sizes')
-    d = conv2d(up, w, None, pads=(ks - 1 - pt, ks - 1 - pl), out_hw=(h, wd), _wmode=1)
-    return d if scale == 1.0 else affine(d, scale, 0.0)
+        d = d2s2_scale(dxs, cin, scale)
+    else:
+        _, pt = same_pads(h, ks, 2)
+        _, pl = same_pads(wd, ks, 2)
+        up = zero_insert2(dz)
+        if up.shape[1] != h or up.shape[2] != wd:
+            raise NotImplementedError('strided dgrad is built for even input sizes')
+        d = conv2d(up, w, None, pads=(ks - 1 - pt, ks - 1 - pl), out_hw=(h, wd), _wmode=1)
+        d = d if scale == 1.0 else affine(d, scale, 0.0)
+    return d if act_mask is None else lrelu_bwd(d, act_mask, out=d)
 
 
 class LatentWorkspace(object):

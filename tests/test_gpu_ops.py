@@ -729,6 +729,50 @@ def test_stride2_conv_as_space_to_depth_conv(dev, shape):
         ops.set_compute('f32')
 
 
+def test_conv3x3_writing_its_depth_to_space_image(dev):
+    """NIMG_D2S_OUT: a 3x3 convolution whose epilogue stores tf.nn.depth_to_space(out, 2) (models/compression.py:233,245) - the
+    forward layers d512 / d256 (bias + LeakyReLU before the permutation) and the input gradient of a stride-2 layer over its
+    space-to-depth image (mask indexed in the output layout) - equals convolution -> d2s_clip (-> lrelu_bwd) bit for bit; the
+    float32 mode runs exactly that sequence.  The 16-byte d2s / s2d kernels are checked against the per-element forms."""
+    from neural_imaging_amd import ops
+    n, h, w, cin, cout = 2, 12, 20, 32, 64
+    x = g(rnd((n, h, w, cin), 51), dev)
+    wk, b = g(rnd((3, 3, cin, cout), 52, -0.1, 0.1), dev), g(rnd((cout,), 53, -0.1, 0.1), dev)
+    mask = g(rnd((n, 2 * h, 2 * w, cout // 4), 54), dev)
+    d2s_ref = lambda t: T.depth_to_space(t.double().cpu(), 2).float()
+    for mode in ('bf16', 'f32'):
+        ops.set_compute(mode)
+        try:
+            for act in (None, 'leaky_relu'):
+                plain = ops.conv2d(x, wk, b, act=act)
+                fused = ops.conv2d(x, wk, b, act=act, d2s_out=True)
+                assert tuple(fused.shape) == (n, 2 * h, 2 * w, cout // 4)
+                assert torch.equal(fused.cpu(), d2s_ref(plain)), (mode, act)
+            # input gradient of a stride-2 5x5 layer: (n, 2h, 2w, 16) <- dz (n, h, w, 32), masked by the layer's input
+            w5 = g(rnd((5, 5, 16, 32), 55, -0.1, 0.1), dev)
+            dz = g(rnd((n, h, w, 32), 56), dev)
+            d_fused = ops.conv2d_dgrad_strided2(dz, w5, (2 * h, 2 * w), act_mask=mask)
+            d_plain = ops.conv2d_dgrad_strided2(dz, w5, (2 * h, 2 * w))
+            assert torch.equal(d_fused, ops.lrelu_bwd(d_plain, mask)), mode
+            if mode == 'bf16':
+                w3 = ops.s2d_conv_weights(w5)
+                two_pass = ops.d2s2_scale(ops.conv2d_dgrad(dz, w3, (h, w)), 16, 1.0)
+                assert torch.equal(d_plain, two_pass)
+        finally:
+            ops.set_compute('f32')
+    for c in (4, 64, 6):            # 16-byte kernels (c % 4 == 0) and the per-element form
+        t = g(rnd((3, 6, 10, 4 * c), 57 + c, -0.5, 1.5), dev)
+        for scale, shift, clip in ((1.0, 0.0, False), (0.5, 0.5, True)):
+            y = ops.d2s_clip(t, scale, shift, clip)
+            ref = scale * T.depth_to_space(t.cpu(), 2) + shift
+            ref = ref.clamp(0.0, 1.0) if clip else ref
+            assert torch.equal(y.cpu(), ref), (c, clip)
+        dy = g(rnd((3, 12, 20, c), 58 + c), dev)
+        back = ops.d2s_clip_bwd(dy, 0.5)
+        assert tuple(back.shape) == (3, 6, 10, 4 * c)
+        assert torch.equal(T.depth_to_space(back.cpu(), 2), 0.5 * dy.cpu()), c
+
+
 def test_conv3x3_with_fused_residual(dev):
     """nimg_conv2d_fwd_bf16_res: the skip connection of a residual block added in the convolution's epilogue - forward
     (net + conv(a) + bias) and input gradient (d_net + mask * dgrad) - equals the separate convolution followed by ops.add,
