@@ -264,7 +264,22 @@ __device__ __forceinline__ double pow_int(double r, int m) {  // r^m, m wave-uni
     return acc;
 }
 
-template <int K>
+// The same run of multiplies for a COMPILE-TIME exponent (M = 51: the reference's v = 50, tf_helpers.py:290): the loop above
+// unrolls into 5 squarings + 3 products with no bit tests / selects - in the kernels below the runtime loop was ~48 of the ~85
+// instructions per weight.  Same operations in the same order, so bit-identical to pow_int(r, M).  M = 0: runtime exponent.
+template <int M>
+__device__ __forceinline__ double pow_fixed(double r, int m) {
+    if (M == 0) return pow_int(r, m);
+    double acc = (M & 1) ? r : 1.0, b = r;
+#pragma unroll
+    for (int n = M >> 1; n > 0; n >>= 1) {
+        b *= b;
+        if (n & 1) acc *= b;
+    }
+    return acc;
+}
+
+template <int K, int M>
 __global__ __launch_bounds__(256) void soft_codebook_fwd_fast_kernel(const float* __restrict__ z, const float* __restrict__ scale,
                                                                      const float* __restrict__ cb, int m, double inv_v,
                                                                      double gamma, float* __restrict__ latent,
@@ -279,7 +294,7 @@ __global__ __launch_bounds__(256) void soft_codebook_fwd_fast_kernel(const float
     for (int k = 0; k < K; ++k) hacc[k] = 0.0;
     auto weight = [&](double u, int k) {                                     // cb[k]: wave-uniform, read through the scalar cache
         const double t = gamma * (u - (double)cb[k]);
-        return pow_int(rsqrt_refined(__builtin_fma(t * t, inv_v, 1.0)), m) + 1e-72;
+        return pow_fixed<M>(rsqrt_refined(__builtin_fma(t * t, inv_v, 1.0)), m) + 1e-72;
     };
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
         const float zs = z[i] * s;                                           // layers.py:197-198 (float32 product)
@@ -314,7 +329,7 @@ __global__ __launch_bounds__(256) void soft_codebook_fwd_fast_kernel(const float
     if (threadIdx.x < K) hist_partial[(long)blockIdx.x * K + threadIdx.x] = sh[threadIdx.x];
 }
 
-template <int K>
+template <int K, int M>
 __global__ __launch_bounds__(256) void soft_codebook_bwd_fast_kernel(const float* __restrict__ z, const float* __restrict__ scale,
                                                                      const float* __restrict__ latent,
                                                                      const float* __restrict__ dlat,
@@ -336,7 +351,7 @@ __global__ __launch_bounds__(256) void soft_codebook_bwd_fast_kernel(const float
             const double qk = decltype(use_dh)::value ? dH_dsum[k] : ck;
             const double t = gamma * (u - ck);
             const double r = rsqrt_refined(__builtin_fma(t * t, inv_v, 1.0));
-            const double w0 = pow_int(r, m);
+            const double w0 = pow_fixed<M>(r, m);
             const double dw = w0 * (dfac * t) * (r * r);
             const double w = w0 + 1e-72;
             S += w; dS += dw;
@@ -393,28 +408,24 @@ __global__ __launch_bounds__(1024) void hist_reduce_kernel(const double* __restr
 // entropy (bits) and dH/d(hist_sum) from the global weight sums; tf_helpers.py:326-331
 __global__ void entropy_finalize_kernel(const double* __restrict__ hist_sum, int K, double n_total,
                                         float* __restrict__ entropy, double* __restrict__ dH_dsum) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double hc[MAXK], T = 0.0;
-    bool clipped[MAXK];
-    for (int k = 0; k < K; ++k) {
-        const double h = hist_sum[k] / n_total;
-        clipped[k] = h < 1e-9;
-        hc[k] = clipped[k] ? 1e-9 : h;
-        T += hc[k];
-    }
-    double H = 0.0;
-    for (int k = 0; k < K; ++k) {
-        const double q = hc[k] / T;
-        H -= q * log(q);
-    }
-    entropy[0] = (float)(H / 0.6931);
+    // one wave, lane k = centre k (K <= MAXK = 64); the three sums over the centres are butterfly sums in a fixed order.
+    // (One thread looping over the centres spent 40 us on its 3 K dependent float64 logarithms and divisions.)
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+    const int k = threadIdx.x;
+    const bool on = k < K;
+    const double h = on ? hist_sum[k] / n_total : 1.0;
+    const bool clipped = h < 1e-9;
+    const double hc = on ? (clipped ? 1e-9 : h) : 0.0;
+    const double T = wave_sum_d(hc);
+    const double q = on ? hc / T : 1.0;
+    const double lq = log(q);                                   // 0 on the idle lanes
+    const double H = -wave_sum_d(on ? q * lq : 0.0);
+    if (k == 0) entropy[0] = (float)(H / 0.6931);
     // dH/dhc_k = -(log q_k + 1)/T + (sum_j q_j (log q_j + 1))/T ;  then through the clip and the 1/n_total mean
-    double mean = 0.0;
-    for (int k = 0; k < K; ++k) { const double q = hc[k] / T; mean += q * (log(q) + 1.0); }
-    for (int k = 0; k < K; ++k) {
-        const double q = hc[k] / T;
-        const double d = (-(log(q) + 1.0) + mean) / T / 0.6931;
-        dH_dsum[k] = clipped[k] ? 0.0 : d / n_total;
+    const double mean = wave_sum_d(on ? q * (lq + 1.0) : 0.0);
+    if (on) {
+        const double d = (-(lq + 1.0) + mean) / T / 0.6931;
+        dH_dsum[k] = clipped ? 0.0 : d / n_total;
     }
 }
 
@@ -489,12 +500,14 @@ __global__ __launch_bounds__(256) void l2_loss_kernel(const float* __restrict__ 
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
+// out = sum of the per-block partial sums, in a fixed order: lane l of one wave adds partials l, l + 64, ... (independent
+// loads), then a butterfly over the lanes.  (One thread adding 1024 partials through 1024 dependent loads took 56 us.)
 __global__ void sum_final_kernel(const double* __restrict__ partial, int nblocks, float* out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int k = 0; k < nblocks; ++k) s += partial[k];
-        out[0] = (float)s;
-    }
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+    double s = 0.0;
+    for (int k = threadIdx.x; k < nblocks; k += 64) s += partial[k];
+    s = wave_sum_d(s);
+    if (threadIdx.x == 0) out[0] = (float)s;
 }
 
 }  // namespace
@@ -620,15 +633,16 @@ int nimg_latent_fwd(const float* z, const float* scale, const float* codebook, i
     double* dH = hsum + K;
     const double vd = kernel_v(v);
     const int m = fast_exponent(K, vd);
-    if (m && K == 32)
-        hipLaunchKernelGGL(soft_codebook_fwd_fast_kernel<32>, dim3(grid), dim3(256), 0, s, z, scale, codebook, m, 1.0 / vd,
-                           (double)gamma, latent, part, count, soft_codebook);
-    else if (m && K == 16)
-        hipLaunchKernelGGL(soft_codebook_fwd_fast_kernel<16>, dim3(grid), dim3(256), 0, s, z, scale, codebook, m, 1.0 / vd,
-                           (double)gamma, latent, part, count, soft_codebook);
-    else if (m && K == 8)
-        hipLaunchKernelGGL(soft_codebook_fwd_fast_kernel<8>, dim3(grid), dim3(256), 0, s, z, scale, codebook, m, 1.0 / vd,
-                           (double)gamma, latent, part, count, soft_codebook);
+#define NIMG_SCB_FWD(KK, MM)                                                                                              \
+    hipLaunchKernelGGL((soft_codebook_fwd_fast_kernel<KK, MM>), dim3(grid), dim3(256), 0, s, z, scale, codebook, m, 1.0 / vd, \
+                       (double)gamma, latent, part, count, soft_codebook)
+    if (m == 51 && K == 32) NIMG_SCB_FWD(32, 51);
+    else if (m == 51 && K == 16) NIMG_SCB_FWD(16, 51);
+    else if (m == 51 && K == 8) NIMG_SCB_FWD(8, 51);
+    else if (m && K == 32) NIMG_SCB_FWD(32, 0);
+    else if (m && K == 16) NIMG_SCB_FWD(16, 0);
+    else if (m && K == 8) NIMG_SCB_FWD(8, 0);
+#undef NIMG_SCB_FWD
     else
         hipLaunchKernelGGL(soft_codebook_fwd_kernel, dim3(grid), dim3(256), 0, s, z, scale, codebook, K, vd, (double)gamma,
                            latent, part, count, soft_codebook);
@@ -668,15 +682,16 @@ int nimg_latent_bwd(const float* z, const float* scale, const float* latent, con
     double* dsp = dH + K;
     const double vd = kernel_v(v);
     const int m = fast_exponent(K, vd);
-    if (m && K == 32)
-        hipLaunchKernelGGL(soft_codebook_bwd_fast_kernel<32>, dim3(grid), dim3(256), 0, s, z, scale, latent, dlatent,
-                           (const double*)dH, entropy_coef, codebook, m, 1.0 / vd, (double)gamma, dz, dsp, count, soft_codebook);
-    else if (m && K == 16)
-        hipLaunchKernelGGL(soft_codebook_bwd_fast_kernel<16>, dim3(grid), dim3(256), 0, s, z, scale, latent, dlatent,
-                           (const double*)dH, entropy_coef, codebook, m, 1.0 / vd, (double)gamma, dz, dsp, count, soft_codebook);
-    else if (m && K == 8)
-        hipLaunchKernelGGL(soft_codebook_bwd_fast_kernel<8>, dim3(grid), dim3(256), 0, s, z, scale, latent, dlatent,
-                           (const double*)dH, entropy_coef, codebook, m, 1.0 / vd, (double)gamma, dz, dsp, count, soft_codebook);
+#define NIMG_SCB_BWD(KK, MM)                                                                                          \
+    hipLaunchKernelGGL((soft_codebook_bwd_fast_kernel<KK, MM>), dim3(grid), dim3(256), 0, s, z, scale, latent, dlatent,   \
+                       (const double*)dH, entropy_coef, codebook, m, 1.0 / vd, (double)gamma, dz, dsp, count, soft_codebook)
+    if (m == 51 && K == 32) NIMG_SCB_BWD(32, 51);
+    else if (m == 51 && K == 16) NIMG_SCB_BWD(16, 51);
+    else if (m == 51 && K == 8) NIMG_SCB_BWD(8, 51);
+    else if (m && K == 32) NIMG_SCB_BWD(32, 0);
+    else if (m && K == 16) NIMG_SCB_BWD(16, 0);
+    else if (m && K == 8) NIMG_SCB_BWD(8, 0);
+#undef NIMG_SCB_BWD
     else
         hipLaunchKernelGGL(soft_codebook_bwd_kernel, dim3(grid), dim3(256), 0, s, z, scale, latent, dlatent,
                            (const double*)dH, entropy_coef, codebook, K, vd, (double)gamma, dz, dsp, count, soft_codebook);
