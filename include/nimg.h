@@ -40,6 +40,10 @@ extern "C" {
                            * tf.nn.depth_to_space layout (block 2 dy + dx of pixel (y, x) -> pixel (2y + dy, 2x + dx)):
                            * models/compression.py:233,245,249 forward, and the input gradient of a stride-2 layer computed
                            * over its space-to-depth image (nimg_s2d_conv_weights) */
+#define NIMG_S2D_OUT 32   /* 3x3 stride-1 convolutions (o1 % 4 == 0, even hout / wout, no out2): out1 (and the bf16 copy) is the
+                           * space_to_depth(2) image (n, hout / 2, wout / 2, 4 o1) of the result - the gradient of a depth_to_space
+                           * layer, written by the input-gradient pass that produces it (models/compression.py:233,245 backward);
+                           * act_mask and residual keep the convolution's own (n, hout, wout, o1) layout */
 
 /* library / ABI version, bumped on any signature change */
 int nimg_abi_version(void);

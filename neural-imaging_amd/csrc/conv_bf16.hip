@@ -454,6 +454,9 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
                         const float4 r = *reinterpret_cast<const float4*>(p.res + o);
                         v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                     }
+                    if (p.flags & NIMG_S2D_OUT)        // space_to_depth(2): pixel (oy, ox) is channel block 2 (oy & 1) + (ox & 1) of
+                        o = (((long)n * (p.Hout >> 1) + (oy >> 1)) * (p.Wout >> 1) + (ox >> 1)) * (4 * p.O1) +    // pixel (oy/2, ox/2);
+                            (2 * (oy & 1) + (ox & 1)) * p.O1 + co;                  // mask and residual keep the convolution's layout
                     if (p.out1b) store4_bf16(p.out1b, o, v);
                     if (p.flags & NIMG_BF16_OUT) store4_bf16(p.out1, o, v);
                     else *reinterpret_cast<float4*>(p.out1 + o) = v;
@@ -1145,11 +1148,15 @@ static int conv2d_fwd_bf16_impl(const float* in1, int c1, const float* in2, int 
     p.in1 = in1; p.in2 = in2; p.wb = (const __bf16*)wb; p.bias = bias; p.out1 = out1; p.out2 = out2; p.act1 = act_mask;
     p.pool_out = nullptr; p.pool_idx = nullptr; p.convt = 0; p.flags = flags; p.in_idx = in_idx; p.res = res;
     p.out1b = (float*)out1b;
-    if ((res || out1b) && (ks != 3 || stride != 1 || o2 != 0 || (o1 & 3) || (flags & NIMG_BF16_OUT))) return NIMG_ERR_ARG;
+    if ((res || out1b) && (ks != 3 || stride != 1 || o2 != 0 || (o1 & 3))) return NIMG_ERR_ARG;
+    if (out1b && (flags & NIMG_BF16_OUT)) return NIMG_ERR_ARG;
     if (in_idx && (!(flags & NIMG_BF16_IN) || stride != 1 || ks != 5 || (h & 1) || (wd & 1) || pad_mode != 0)) return NIMG_ERR_ARG;
     if ((flags & (NIMG_BF16_OUT | NIMG_BF16_MASK)) && ((o1 & 3) || (o2 & 3))) return NIMG_ERR_ARG;   // vector epilogue only
     if ((flags & NIMG_BF16_MASK) && o2 != 0) return NIMG_ERR_ARG;
     if ((flags & NIMG_D2S_OUT) && (ks != 3 || stride != 1 || o2 != 0 || (o1 & 15) || in_idx)) return NIMG_ERR_ARG;
+    if ((flags & NIMG_S2D_OUT) && (ks != 3 || stride != 1 || o2 != 0 || (o1 & 3) || in_idx || (hout & 1) || (wout & 1) ||
+                                   (flags & NIMG_D2S_OUT)))
+        return NIMG_ERR_ARG;
     p.C1 = c1; p.C2 = c2; p.O1 = o1; p.O2 = o2; p.CinP = (c1 + c2 + 15) / 16 * 16;
     p.N = n; p.H = h; p.W = wd; p.Hout = hout; p.Wout = wout; p.pad_t = pad_t; p.pad_l = pad_l;
     p.tiles_y = p.tiles_x = 0; p.act = act; p.pad_mode = pad_mode; p.alpha = alpha;

@@ -311,9 +311,8 @@ class TwitterDCN(DCN):
         L['d12'].backward_params(P, dt['i4'], dz)
         # LeakyReLU' of the d256 layer is taken on its depth-to-space image i4 (same signs, permuted), in the epilogue of
         # this input gradient; the space_to_depth of the result is then the gradient at d256's output
-        d_i4 = L['d12'].backward_input(P, dz, hw(dt['i4']), act_mask=dt['i4'])
-        dz = ops.d2s_clip_bwd(d_i4, 1.0)
         bf = self._bf16_inner()
+        dz = L['d12'].backward_input(P, dz, hw(dt['i4']), act_mask=dt['i4'], s2d_out=True, out_bf16=bf)
         L['d256'].backward_params(P, dt['d256in'], dz)
         d_net = L['d256'].backward_input(P, dz, hw(dt['i3']), bf16_copy=bf)
         d_net, d_net_b = d_net if bf else (d_net, None)
@@ -323,9 +322,11 @@ class TwitterDCN(DCN):
             L['dr{}b'.format(b)].backward_params(P, a, dzs)
             dza = L['dr{}b'.format(b)].backward_input(P, dzs, hw(a), act_mask=a, out_bf16=bf)
             L['dr{}a'.format(b)].backward_params(P, inp, dza)
-            d_net = L['dr{}a'.format(b)].backward_input(P, dza, hw(inp), residual=d_net, bf16_copy=bf and b > 1)
-            d_net, d_net_b = d_net if bf and b > 1 else (d_net, None)
-        dz = ops.d2s_clip_bwd(d_net, 1.0)
+            if b > 1:
+                d_net = L['dr{}a'.format(b)].backward_input(P, dza, hw(inp), residual=d_net, bf16_copy=bf)
+                d_net, d_net_b = d_net if bf else (d_net, None)
+            else:       # the gradient leaves the blocks through the depth_to_space behind d512: written as its space_to_depth
+                dz = L['dr1a'].backward_input(P, dza, hw(inp), residual=d_net, s2d_out=True, out_bf16=bf)
         L['d512'].backward_params(P, dt['latent'], dz)
         d_lat = L['d512'].backward_input(P, dz, hw(dt['latent']))
         # ---- latent

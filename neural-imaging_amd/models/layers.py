@@ -56,15 +56,17 @@ class Conv2D(object):
                          db=store.g[self.name + '/bias'], side=True)
 
     def backward_input(self, store, dz, in_hw, act_mask=None, out=None, out2=None, out_bf16=False, residual=None,
-                       bf16_copy=False):
+                       bf16_copy=False, s2d_out=False):
         """residual: the gradient arriving over the block's skip connection, added in the same pass (stride-1 layers);
-        bf16_copy: returns (gradient, bf16 copy of it or None), see ops.conv2d."""
+        bf16_copy: returns (gradient, bf16 copy of it or None); s2d_out: returns tf.nn.space_to_depth(gradient, 2) - the
+        gradient at the input of the depth_to_space layer that fed this one (stride-1 layers), see ops.conv2d."""
         if self.stride == 2:
             d = ops.conv2d_dgrad_strided2(dz, store.p[self.name + '/kernel'], in_hw, act_mask=act_mask)
             d = d if residual is None else ops.add(residual, d, out=d)
             return (d, None) if bf16_copy else d
         return ops.conv2d_dgrad(dz, store.p[self.name + '/kernel'], in_hw, stride=self.stride, act_mask=act_mask,
-                                out=out, out2=out2, out_bf16=out_bf16, residual=residual, bf16_copy=bf16_copy)
+                                out=out, out2=out2, out_bf16=out_bf16, residual=residual, bf16_copy=bf16_copy,
+                                s2d_out=s2d_out)
 
 
 class Conv5x5Stride2Image(Conv2D):

@@ -114,7 +114,7 @@ def _f32(*ts):
 
 
 D2S_EPILOGUE = os.environ.get('NIMG_NO_D2S_OUT') is None          # A/B switch: depth_to_space as a separate pass
-BF16_IN, BF16_OUT, BF16_MASK, BF16_DZ, D2S_OUT = 1, 2, 4, 8, 16          # include/nimg.h NIMG_BF16_*, NIMG_D2S_OUT
+BF16_IN, BF16_OUT, BF16_MASK, BF16_DZ, D2S_OUT, S2D_OUT = 1, 2, 4, 8, 16, 32          # include/nimg.h NIMG_BF16_*, NIMG_D2S_OUT
 
 
 def _fb(*ts):
@@ -290,10 +290,13 @@ def djpeg_bwd(x, gy, mask, qtab, rounding='soft', out=None, dq=None, accumulate=
 # convolutions
 def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mode=0, out=None, out2=None,
            act_mask=None, pads=None, out_hw=None, _wmode=0, _f32_only=False, mask_alpha=None, out_bf16=False, residual=None,
-           bf16_copy=False, d2s_out=False):
+           bf16_copy=False, d2s_out=False, s2d_out=False):
     """x (N,H,W,C1) [+ x2 (N,H,W,C2)], w (k,k,C1+C2,Cout) HWIO.  padding 'SAME' (TF) | 'VALID' | explicit pads/out_hw.
     d2s_out: the result is returned as its depth_to_space(2) image (N, 2 Hout, 2 Wout, Cout / 4) - written in that layout by
     the 3x3 throughput-mode kernel (act_mask then has that shape too), convolution + d2s_clip (+ lrelu_bwd) elsewhere.
+    s2d_out: the result is returned as its space_to_depth(2) image (N, Hout / 2, Wout / 2, 4 Cout), i.e. the gradient at the
+    input of a depth_to_space layer (act_mask / residual keep the (N, Hout, Wout, Cout) layout); 3x3 throughput-mode kernel
+    (bf16 if out_bf16), convolution + d2s_clip_bwd elsewhere.
     out/out2: optional pre-allocated outputs (out2 splits the output channels: Cout = out.C + out2.C).
     residual: float32 tensor of the output's shape added to the result (a residual block's skip connection; fused into the
     3x3 throughput-mode kernel, a separate add elsewhere).
@@ -301,6 +304,16 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
     kernel does not apply, i.e. in float32 mode): what the bf16 kernels downstream would round it to anyway, at half the
     bytes."""
     copy = None
+    if s2d_out:
+        co_ = w.shape[3] if _wmode == 0 else w.shape[2]
+        fused = COMPUTE == 'bf16' and not _f32_only and x2 is None and out is None and out2 is None and stride == 1 and \
+            w.shape[0] == 3 and co_ % 4 == 0 and co_ >= 8 and x.shape[3] % 4 == 0 and x.shape[3] >= 8 and \
+            (x.shape[3] % 8 == 0 or (not _is_bf16(x) and residual is None)) and D2S_EPILOGUE and not bf16_copy and \
+            not d2s_out
+        if not fused:
+            y = conv2d(x, w, bias, stride=stride, padding=padding, act=act, pad_mode=pad_mode, act_mask=act_mask, pads=pads,
+                       out_hw=out_hw, _wmode=_wmode, _f32_only=_f32_only, mask_alpha=mask_alpha, residual=residual)
+            return d2s_clip_bwd(y, 1.0)
     if d2s_out:
         co_ = w.shape[3] if _wmode == 0 else w.shape[2]
         fused = COMPUTE == 'bf16' and not _f32_only and x2 is None and out is None and out2 is None and stride == 1 and \
@@ -315,7 +328,7 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
     if residual is not None or bf16_copy:
         _f32(residual)
         fused = COMPUTE == 'bf16' and not _f32_only and x2 is None and out2 is None and stride == 1 and w.shape[0] == 3 and \
-            not out_bf16 and (out is None or out.dtype == torch.float32) and x.shape[3] % 8 == 0 and \
+            (s2d_out or (not out_bf16 and (out is None or out.dtype == torch.float32))) and x.shape[3] % 8 == 0 and \
             (w.shape[3] if _wmode == 0 else w.shape[2]) % 4 == 0 and (w.shape[3] if _wmode == 0 else w.shape[2]) >= 8
         if not fused:
             y = conv2d(x, w, bias, x2=x2, stride=stride, padding=padding, act=act, pad_mode=pad_mode, out=out, out2=out2,
@@ -345,12 +358,14 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
         ho, wo = (h - ks) // stride + 1, (wd - ks) // stride + 1
     else:
         raise ValueError(padding)
+    if s2d_out and (ho % 2 or wo % 2):
+        raise ValueError('s2d_out: even output size expected')
     if out is None:
-        out = torch.empty((n, 2 * ho, 2 * wo, cout // 4) if d2s_out else (n, ho, wo, cout),
-                          dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
-    o1 = cout if d2s_out else out.shape[3]
+        shape = (n, 2 * ho, 2 * wo, cout // 4) if d2s_out else ((n, ho // 2, wo // 2, 4 * cout) if s2d_out else (n, ho, wo, cout))
+        out = torch.empty(shape, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    o1 = cout if (d2s_out or s2d_out) else out.shape[3]
     o2 = 0 if out2 is None else out2.shape[3]
-    if o1 + o2 != cout or (not d2s_out and tuple(out.shape[:3]) != (n, ho, wo)):
+    if o1 + o2 != cout or (not (d2s_out or s2d_out) and tuple(out.shape[:3]) != (n, ho, wo)):
         raise ValueError('output shape mismatch')
     if d2s_out and act_mask is not None and tuple(act_mask.shape) != tuple(out.shape):
         raise ValueError('d2s_out: the mask has the shape of the depth-to-space output')
@@ -376,9 +391,9 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
             (c1 % 8 == 0 or (c2 == 0 and c1 % 4 == 0 and c1 >= 8 and not _is_bf16(x))):
         wb = weights_bf16(w, _wmode)
         flags = (BF16_IN if _is_bf16(x) else 0) | (BF16_OUT if _is_bf16(out) else 0) | \
-            (BF16_MASK if _is_bf16(act_mask) else 0) | (D2S_OUT if d2s_out else 0)
+            (BF16_MASK if _is_bf16(act_mask) else 0) | (D2S_OUT if d2s_out else 0) | (S2D_OUT if s2d_out else 0)
         if residual is not None or bf16_copy:
-            if residual is not None and tuple(residual.shape) != tuple(out.shape):
+            if residual is not None and tuple(residual.shape) != (n, ho, wo, cout):
                 raise ValueError('residual: the shape of the output expected')
             if bf16_copy:
                 copy = torch.empty(out.shape, dtype=torch.bfloat16, device=out.device)
@@ -407,7 +422,7 @@ def flip_weights(w, out=None):
 
 
 def conv2d_dgrad(dz, w, in_hw, stride=1, padding='SAME', act_mask=None, out=None, out2=None, mask_alpha=None,
-                 out_bf16=False, residual=None, bf16_copy=False, d2s_out=False):
+                 out_bf16=False, residual=None, bf16_copy=False, d2s_out=False, s2d_out=False):
     """Input gradient of conv2d (stride 1, odd kernel): correlation of dz with the flipped kernel."""
     if stride != 1:
         raise NotImplementedError('strided dgrad is expressed by the caller (see models/compression.py)')
@@ -421,7 +436,7 @@ def conv2d_dgrad(dz, w, in_hw, stride=1, padding='SAME', act_mask=None, out=None
     # forward used pad (pt, pl); the gradient correlation needs ks-1-pt / ks-1-pl; the kernel is read flipped/transposed
     return conv2d(dz, w, None, pads=(ks - 1 - pt, ks - 1 - pl), out_hw=(h, wd), act_mask=act_mask, out=out,
                   out2=out2, _wmode=1, mask_alpha=mask_alpha, out_bf16=out_bf16, residual=residual, bf16_copy=bf16_copy,
-                  d2s_out=d2s_out)
+                  d2s_out=d2s_out, s2d_out=s2d_out)
 
 
 def conv2d_wgrad(x, dz, ks, x2=None, stride=1, padding='SAME', pad_mode=0, pads=None, dw=None, accumulate=False,

@@ -758,6 +758,21 @@ def test_conv3x3_writing_its_depth_to_space_image(dev):
                 w3 = ops.s2d_conv_weights(w5)
                 two_pass = ops.d2s2_scale(ops.conv2d_dgrad(dz, w3, (h, w)), 16, 1.0)
                 assert torch.equal(d_plain, two_pass)
+            # NIMG_S2D_OUT: an input gradient written as space_to_depth(gradient) - what the depth_to_space layer in front of
+            # the convolution hands back to ITS producer - with mask and skip gradient in the convolution's own layout
+            m64, r64 = g(rnd((n, h, w, 64), 62), dev), g(rnd((n, h, w, 64), 63), dev)
+            s2d_ref = lambda t: T.space_to_depth(t.float().cpu(), 2)
+            for cg in (12, 16):                                  # 12: the codec's last layer (64 -> 12 channels)
+                gz = g(rnd((n, h, w, cg), 60 + cg), dev)
+                wz = g(rnd((3, 3, 64, cg), 61 + cg, -0.1, 0.1), dev)
+                for kw in (dict(act_mask=m64), dict(residual=r64), dict()):
+                    ref = ops.conv2d_dgrad(gz, wz, (h, w), **kw)
+                    got = ops.conv2d_dgrad(gz, wz, (h, w), s2d_out=True, **kw)
+                    assert tuple(got.shape) == (n, h // 2, w // 2, 256)
+                    assert torch.equal(got.cpu(), s2d_ref(ref)), (mode, cg, sorted(kw))
+                    if mode == 'bf16' and (cg % 8 == 0 or 'residual' not in kw):      # the shapes the fused epilogue serves
+                        gotb = ops.conv2d_dgrad(gz, wz, (h, w), s2d_out=True, out_bf16=True, **kw)
+                        assert gotb.dtype == torch.bfloat16 and torch.equal(gotb.cpu(), s2d_ref(ref).to(torch.bfloat16))
         finally:
             ops.set_compute('f32')
     for c in (4, 64, 6):            # 16-byte kernels (c % 4 == 0) and the per-element form
