@@ -40,6 +40,7 @@ extern "C" {
                            * tf.nn.depth_to_space layout (block 2 dy + dx of pixel (y, x) -> pixel (2y + dy, 2x + dx)):
                            * models/compression.py:233,245,249 forward, and the input gradient of a stride-2 layer computed
                            * over its space-to-depth image (nimg_s2d_conv_weights) */
+#define NIMG_COPY_LRELU 64 /* nimg_conv2d_fwd_bf16_res: the bf16 copy holds LeakyReLU(alpha) of the (activation-free) result */
 #define NIMG_S2D_OUT 32   /* 3x3 stride-1 convolutions (o1 % 4 == 0, even hout / wout, no out2): out1 (and the bf16 copy) is the
                            * space_to_depth(2) image (n, hout / 2, wout / 2, 4 o1) of the result - the gradient of a depth_to_space
                            * layer, written by the input-gradient pass that produces it (models/compression.py:233,245 backward);
@@ -314,11 +315,13 @@ int nimg_conv5_dgrad_sparse(const void* g, const unsigned char* idx, int cout, c
 /* nimg_conv2d_fwd_bf16_ex for the layers of a residual block (models/compression.py:224-227, 240-243): `residual` (float32, the
  * shape of out1, optional) is added after bias, activation and mask (net + conv(a) forward, d_net + mask * dgrad backward), and
  * `out_bf16_copy` (optional) receives the same result rounded to bf16 next to the float32 out1 (the exact float32 stream for the
- * skip sum, the bf16 copy for the convolutions / weight gradients that read it).  At least one of the two; 3x3, stride 1,
- * float32 output with o1 % 4 == 0. */
+ * skip sum, the bf16 copy for the convolutions / weight gradients that read it; with NIMG_COPY_LRELU the copy holds
+ * LeakyReLU(alpha) of the result, models/compression.py:224).  At least one of the two; float32 output with o1 % 4 == 0; the
+ * residual with 3x3 / stride 1 layers only. */
 int nimg_conv2d_fwd_bf16_res(const float* in1, int c1, const void* wb, const float* bias, float* out1, int o1,
                              const float* act_mask, const float* residual, void* out_bf16_copy, int n, int h, int wd, int ks,
-                             int pad_t, int pad_l, int pad_mode, int hout, int wout, int act, float alpha, int flags, void* stream);
+                             int stride, int pad_t, int pad_l, int pad_mode, int hout, int wout, int act, float alpha, int flags,
+                             void* stream);
 /* Backward of the FAN's fused conv + LeakyReLU + MaxPool2D layers conv2..4 (models/forensics.py:73-77) straight from the POOLED
  * gradient g (bf16, already x LeakyReLU') and the arg-max bytes: the MaxPool2D routing is applied while the kernels stage their
  * tiles, so the full-resolution gradient (4x the bytes, 3/4 zeros) is never written nor re-read.  5x5, stride 1, SAME.

@@ -110,7 +110,7 @@ PROTOTYPES = {
     'nimg_conv5_dgrad_sparse_weights': (c_int, [P, P, c_int, c_int, P]),
     'nimg_conv5_dgrad_sparse': (c_int, [P, P, c_int, P, P, c_int, P, c_int, c_int, c_int, c_float, c_int, P]),
     'nimg_conv2d_fwd_bf16_res': (c_int, [P, c_int, P, P, P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                 c_int, c_float, c_int, P]),
+                                 c_int, c_int, c_float, c_int, P]),
     'nimg_conv2d_fwd_bf16_unpool': (c_int, [P, P, c_int, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                             c_int, c_int, c_float, c_int, P]),
     'nimg_conv2d_wgrad_bf16_unpool': (c_int, [P, c_int, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),

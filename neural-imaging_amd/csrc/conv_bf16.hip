@@ -457,7 +457,11 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
                     if (p.flags & NIMG_S2D_OUT)        // space_to_depth(2): pixel (oy, ox) is channel block 2 (oy & 1) + (ox & 1) of
                         o = (((long)n * (p.Hout >> 1) + (oy >> 1)) * (p.Wout >> 1) + (ox >> 1)) * (4 * p.O1) +    // pixel (oy/2, ox/2);
                             (2 * (oy & 1) + (ox & 1)) * p.O1 + co;                  // mask and residual keep the convolution's layout
-                    if (p.out1b) store4_bf16(p.out1b, o, v);
+                    if (p.out1b) {
+                        float4 c = v;
+                        if (p.flags & NIMG_COPY_LRELU) { c.x = lrelu(c.x, p.alpha); c.y = lrelu(c.y, p.alpha); c.z = lrelu(c.z, p.alpha); c.w = lrelu(c.w, p.alpha); }
+                        store4_bf16(p.out1b, o, c);
+                    }
                     if (p.flags & NIMG_BF16_OUT) store4_bf16(p.out1, o, v);
                     else *reinterpret_cast<float4*>(p.out1 + o) = v;
                 } else {
@@ -1148,8 +1152,10 @@ static int conv2d_fwd_bf16_impl(const float* in1, int c1, const float* in2, int 
     p.in1 = in1; p.in2 = in2; p.wb = (const __bf16*)wb; p.bias = bias; p.out1 = out1; p.out2 = out2; p.act1 = act_mask;
     p.pool_out = nullptr; p.pool_idx = nullptr; p.convt = 0; p.flags = flags; p.in_idx = in_idx; p.res = res;
     p.out1b = (float*)out1b;
-    if ((res || out1b) && (ks != 3 || stride != 1 || o2 != 0 || (o1 & 3))) return NIMG_ERR_ARG;
+    if (res && (ks != 3 || stride != 1)) return NIMG_ERR_ARG;
+    if ((res || out1b) && (o2 != 0 || (o1 & 3))) return NIMG_ERR_ARG;
     if (out1b && (flags & NIMG_BF16_OUT)) return NIMG_ERR_ARG;
+    if ((flags & NIMG_COPY_LRELU) && (!out1b || act != 0)) return NIMG_ERR_ARG;
     if (in_idx && (!(flags & NIMG_BF16_IN) || stride != 1 || ks != 5 || (h & 1) || (wd & 1) || pad_mode != 0)) return NIMG_ERR_ARG;
     if ((flags & (NIMG_BF16_OUT | NIMG_BF16_MASK)) && ((o1 & 3) || (o2 & 3))) return NIMG_ERR_ARG;   // vector epilogue only
     if ((flags & NIMG_BF16_MASK) && o2 != 0) return NIMG_ERR_ARG;
@@ -1188,13 +1194,16 @@ int nimg_conv2d_fwd_bf16_ex(const float* in1, int c1, const float* in2, int c2, 
 /* nimg_conv2d_fwd_bf16_ex for the layers of a residual block (models/compression.py:224-227, 240-243): `residual` (float32, the
  * shape of out1, optional) is added to the result after bias, activation and mask - net + conv(a) forward, d_net + mask * dgrad
  * backward, one pass - and `out_bf16_copy` (optional) receives the same result rounded to bf16 next to the float32 out1: the
- * residual stream keeps its exact float32 sum, its consumers read the bf16 copy.  At least one of the two; 3x3, stride 1, one
- * float32 output with o1 % 4 == 0 (else NIMG_ERR_ARG). */
+ * residual stream keeps its exact float32 sum, its consumers read the bf16 copy (flag NIMG_COPY_LRELU: the copy holds
+ * LeakyReLU(alpha) of the result - the codec feeds its first block the activation of the tensor it skips around,
+ * models/compression.py:224).  At least one of the two; one float32 output with o1 % 4 == 0, the residual with 3x3 / stride 1
+ * layers only (else NIMG_ERR_ARG). */
 int nimg_conv2d_fwd_bf16_res(const float* in1, int c1, const void* wb, const float* bias, float* out1, int o1,
                              const float* act_mask, const float* residual, void* out_bf16_copy, int n, int h, int wd, int ks,
-                             int pad_t, int pad_l, int pad_mode, int hout, int wout, int act, float alpha, int flags, void* stream) {
+                             int stride, int pad_t, int pad_l, int pad_mode, int hout, int wout, int act, float alpha, int flags,
+                             void* stream) {
     if (!residual && !out_bf16_copy) return NIMG_ERR_ARG;
-    return conv2d_fwd_bf16_impl(in1, c1, nullptr, 0, wb, bias, out1, o1, nullptr, 0, act_mask, n, h, wd, ks, 1, pad_t, pad_l,
+    return conv2d_fwd_bf16_impl(in1, c1, nullptr, 0, wb, bias, out1, o1, nullptr, 0, act_mask, n, h, wd, ks, stride, pad_t, pad_l,
                                 pad_mode, hout, wout, act, alpha, flags, stream, nullptr, residual, out_bf16_copy);
 }
 

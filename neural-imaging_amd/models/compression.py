@@ -248,12 +248,13 @@ class TwitterDCN(DCN):
         t = OrderedDict()
         self._in_hw = (x.shape[1], x.shape[2])
         t['e1'], t['x0'] = L['e1'].forward_image(P, x, 2.0, -1.0)       # x0 = 2 x - 1 (or its bf16 space-to-depth image)
-        t['e2'] = L['e2'].forward(P, t['e1'])
+        bf = self._bf16_inner()
+        # block 1 reads LeakyReLU(e2) while its skip adds e2 itself (:224-227): the layer writes both, the activation as bf16
+        t['e2'], act0 = L['e2'].forward(P, t['e1'], bf16_copy=True, copy_lrelu=True) if bf else (L['e2'].forward(P, t['e1']), None)
         net, net_b = t['e2'], None
         t['n0'] = net
-        bf = self._bf16_inner()
         for b in (1, 2, 3):
-            inp = ops.lrelu(net) if b == 1 else self._operand(net, net_b)
+            inp = (ops.lrelu(net) if act0 is None else act0) if b == 1 else self._operand(net, net_b)
             t['er{}in'.format(b)] = inp
             a = L['er{}a'.format(b)].forward(P, inp, out_bf16=bf)
             t['er{}a'.format(b)] = a
@@ -291,7 +292,8 @@ class TwitterDCN(DCN):
             net, net_b = net if bf else (net, None)
             t['i{}'.format(b)] = net
         t['d256in'] = self._operand(net, net_b)
-        t['i4'] = L['d256'].forward(P, t['d256in'], d2s_out=True)        # conv + LeakyReLU + depth_to_space
+        # conv + LeakyReLU + depth_to_space; not a residual stream: stored as bf16 like every tensor that only feeds operands
+        t['i4'] = L['d256'].forward(P, t['d256in'], d2s_out=True, out_bf16=bf)
         t['d12'] = L['d12'].forward(P, t['i4'])
         y = ops.d2s_clip(t['d12'], 0.5, 0.5, True)               # (x + 1) / 2 then straight-through clip
         return y, (t if training else None)

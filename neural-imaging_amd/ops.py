@@ -114,7 +114,7 @@ def _f32(*ts):
 
 
 D2S_EPILOGUE = os.environ.get('NIMG_NO_D2S_OUT') is None          # A/B switch: depth_to_space as a separate pass
-BF16_IN, BF16_OUT, BF16_MASK, BF16_DZ, D2S_OUT, S2D_OUT = 1, 2, 4, 8, 16, 32          # include/nimg.h NIMG_BF16_*, NIMG_D2S_OUT
+BF16_IN, BF16_OUT, BF16_MASK, BF16_DZ, D2S_OUT, S2D_OUT, COPY_LRELU = 1, 2, 4, 8, 16, 32, 64          # include/nimg.h NIMG_BF16_*, NIMG_D2S_OUT
 
 
 def _fb(*ts):
@@ -290,7 +290,7 @@ def djpeg_bwd(x, gy, mask, qtab, rounding='soft', out=None, dq=None, accumulate=
 # convolutions
 def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mode=0, out=None, out2=None,
            act_mask=None, pads=None, out_hw=None, _wmode=0, _f32_only=False, mask_alpha=None, out_bf16=False, residual=None,
-           bf16_copy=False, d2s_out=False, s2d_out=False):
+           bf16_copy=False, d2s_out=False, s2d_out=False, copy_lrelu=False):
     """x (N,H,W,C1) [+ x2 (N,H,W,C2)], w (k,k,C1+C2,Cout) HWIO.  padding 'SAME' (TF) | 'VALID' | explicit pads/out_hw.
     d2s_out: the result is returned as its depth_to_space(2) image (N, 2 Hout, 2 Wout, Cout / 4) - written in that layout by
     the 3x3 throughput-mode kernel (act_mask then has that shape too), convolution + d2s_clip (+ lrelu_bwd) elsewhere.
@@ -302,7 +302,7 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
     3x3 throughput-mode kernel, a separate add elsewhere).
     bf16_copy: return (out, copy) with `copy` = the float32 result rounded to bf16 by the same kernel (None where the fused
     kernel does not apply, i.e. in float32 mode): what the bf16 kernels downstream would round it to anyway, at half the
-    bytes."""
+    bytes.  copy_lrelu: the copy holds LeakyReLU(0.2) of the (activation-free) result instead."""
     copy = None
     if s2d_out:
         co_ = w.shape[3] if _wmode == 0 else w.shape[2]
@@ -327,8 +327,10 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
             return y if act_mask is None else lrelu_bwd(y, act_mask, out=y, alpha=mask_alpha)
     if residual is not None or bf16_copy:
         _f32(residual)
-        fused = COMPUTE == 'bf16' and not _f32_only and x2 is None and out2 is None and stride == 1 and w.shape[0] == 3 and \
+        fused = COMPUTE == 'bf16' and not _f32_only and x2 is None and out2 is None and \
+            ((stride == 1 and w.shape[0] == 3) or (residual is None and (w.shape[0], stride) in ((1, 1), (5, 1), (5, 2)))) and \
             (s2d_out or (not out_bf16 and (out is None or out.dtype == torch.float32))) and x.shape[3] % 8 == 0 and \
+            not (copy_lrelu and act is not None) and \
             (w.shape[3] if _wmode == 0 else w.shape[2]) % 4 == 0 and (w.shape[3] if _wmode == 0 else w.shape[2]) >= 8
         if not fused:
             y = conv2d(x, w, bias, x2=x2, stride=stride, padding=padding, act=act, pad_mode=pad_mode, out=out, out2=out2,
@@ -398,7 +400,8 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
             if bf16_copy:
                 copy = torch.empty(out.shape, dtype=torch.bfloat16, device=out.device)
             _lib.call('nimg_conv2d_fwd_bf16_res', _p(x), c1, _p(wb), _p(bias), _p(out), o1, _p(act_mask), _p(residual), _p(copy),
-                      n, h, wd, ks, pt, pl, pad_mode, ho, wo, act_id, alpha, flags, _stream())
+                      n, h, wd, ks, stride, pt, pl, pad_mode, ho, wo, act_id, alpha, flags | (COPY_LRELU if copy_lrelu else 0),
+                      _stream())
             return (out, copy) if bf16_copy else out
         _lib.call('nimg_conv2d_fwd_bf16_ex', _p(x), c1, _p(x2), c2, _p(wb), _p(bias), _p(out), o1, _p(out2), o2,
                   _p(act_mask), n, h, wd, ks, stride, pt, pl, pad_mode, ho, wo, act_id, alpha, flags, _stream())

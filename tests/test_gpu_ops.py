@@ -823,6 +823,11 @@ def test_conv3x3_with_fused_residual(dev):
                     assert_close(dw_c.cpu().numpy(), dw_f.cpu().numpy(), 1e-6, 2e-5, what='wgrad from the bf16 copies')
                 else:
                     assert copy is None and dcopy is None           # float32 mode has no bf16 tensors
+            if mode == 'bf16':      # a stride-2 layer writing LeakyReLU(result) as the copy (the codec's e2 -> block 1)
+                w5 = g(rnd((5, 5, c, 64), 47, -0.05, 0.05), dev)
+                y5, a5 = ops.conv2d(x, w5, None, stride=2, bf16_copy=True, copy_lrelu=True)
+                assert torch.equal(y5, ops.conv2d(x, w5, None, stride=2))
+                assert torch.equal(a5, ops.lrelu(y5).to(torch.bfloat16))
         finally:
             ops.set_compute('f32')
     ops.set_compute('bf16')
@@ -832,11 +837,11 @@ def test_conv3x3_with_fused_residual(dev):
         out = torch.empty_like(x)
         with pytest.raises(RuntimeError):           # the C ABI refuses shapes the fused epilogue does not serve
             _lib.call('nimg_conv2d_fwd_bf16_res', x.data_ptr(), c, wb.data_ptr(), None, out.data_ptr(), c, None, r.data_ptr(), None,
-                      n, h, w, 5, 2, 2, 0, h, w, 0, 0.2, 0, torch.cuda.current_stream().cuda_stream)
+                      n, h, w, 5, 1, 2, 2, 0, h, w, 0, 0.2, 0, torch.cuda.current_stream().cuda_stream)
         wb3 = ops.weights_bf16(wk, 0)
         with pytest.raises(RuntimeError):           # ... and a call that asks for neither the skip sum nor the copy
             _lib.call('nimg_conv2d_fwd_bf16_res', x.data_ptr(), c, wb3.data_ptr(), None, out.data_ptr(), c, None, None, None,
-                      n, h, w, 3, 1, 1, 0, h, w, 0, 0.2, 0, torch.cuda.current_stream().cuda_stream)
+                      n, h, w, 3, 1, 1, 1, 0, h, w, 0, 0.2, 0, torch.cuda.current_stream().cuda_stream)
     finally:
         ops.set_compute('f32')
 

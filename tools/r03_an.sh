@@ -1,5 +1,5 @@
 #!/bin/bash
-# session an: space_to_depth in the epilogue of the decoder's input gradients - tests, then A/B of configs 3 / 5
+# session an: codec epilogue fusions - tests, then configs 3 / 5 (NIMG_NO_D2S_OUT=1: depth_to_space / space_to_depth as separate passes)
 OUT=gpurun_out/r03_an; mkdir -p $OUT
 timeout 900 python -m pytest tests -x -q -m gpu -k "depth_to_space or residual or dcn or DCN or codec or compression or full_channel or d2s" > $OUT/tests.txt 2>&1
 tail -4 $OUT/tests.txt
