@@ -7,7 +7,7 @@ of the dispatch stream - from the UNet's weights_bf16_batch_kernel launch (the f
 adam_kernel - and EVERY dispatch inside it is summed: bytes = 2 x FETCH_SIZE (gfx950 half-count correction of
 MI355X_MICROARCH.md's HBM section; KB as reported) + WRITE_SIZE.  Per-kernel sums are kept so the total can be audited.
 
-    python tools/pmc_step_total.py <FETCH csv> <WRITE csv> [batch] > profiles/r03_pmc_step_total.json
+    python tools/pmc_step_total.py <FETCH csv> <WRITE csv> [batch [c4|c3|c5]] > profiles/r03_pmc_step_total.json
 """
 import csv
 import json
@@ -21,11 +21,17 @@ def short(name):
     return re.sub(r'\(.*$', '', name)[:100]
 
 
-def last_step(path, counter):
+def last_step(path, counter, workload='c4'):
     rows = [r for r in csv.DictReader(open(path)) if r['Counter_Name'] == counter]
     rows.sort(key=lambda r: int(r['Dispatch_Id']))
     starts = [i for i, r in enumerate(rows) if 'weights_bf16_batch_kernel' in r['Kernel_Name']]
     adams = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
+    if workload != 'c4':
+        # configs 3 / 5: a step = everything after the previous step's last Adam launch up to its own last Adam launch
+        if len(adams) < 3 or len(adams) % 3:
+            raise SystemExit('{}: expected 3 steps, found {} Adam launches'.format(path, len(adams)))
+        aps = len(adams) // 3
+        return rows[adams[2 * aps - 1] + 1:adams[3 * aps - 1] + 1]
     # two image launches per step (UNet first, FAN second), two Adam launches per step (FAN, UNet)
     if len(starts) < 6 or len(adams) < 6:
         raise SystemExit('{}: expected 3 steps (6 weight-image and 6 Adam launches), found {} / {}'.format(path, len(starts), len(adams)))
@@ -34,7 +40,8 @@ def last_step(path, counter):
 
 
 def main():
-    fetch, write = last_step(sys.argv[1], 'FETCH_SIZE'), last_step(sys.argv[2], 'WRITE_SIZE')
+    workload = sys.argv[4] if len(sys.argv) > 4 else 'c4'
+    fetch, write = last_step(sys.argv[1], 'FETCH_SIZE', workload), last_step(sys.argv[2], 'WRITE_SIZE', workload)
     batch = int(sys.argv[3]) if len(sys.argv) > 3 else 64
     if [short(r['Kernel_Name']) for r in fetch] != [short(r['Kernel_Name']) for r in write]:
         raise SystemExit('the two passes do not list the same dispatch sequence')
@@ -54,8 +61,8 @@ def main():
     for e in per.values():
         e['bytes'] = e['fetch_bytes_x2'] + e['write_bytes']
         e['TBps_under_pmc'] = e['bytes'] / max(e['us_under_pmc'], 1e-9) / 1e6
-    out = {'what': 'HBM bytes of one C4 training step (all {} dispatches of the last of 3 eager steps), 2 x FETCH_SIZE + WRITE_SIZE, '
-                   'separate rocprofv3 --pmc passes'.format(len(fetch)),
+    out = {'what': 'HBM bytes of one {} training step (all {} dispatches of the last of 3 eager steps), 2 x FETCH_SIZE + WRITE_SIZE, '
+                   'separate rocprofv3 --pmc passes'.format(workload.upper(), len(fetch)),
            'batch_raw_patches': batch, 'dispatches': len(fetch),
            'fetch_bytes_x2': total_f, 'write_bytes': total_w, 'bytes_per_step': total_f + total_w,
            'bytes_per_raw_patch': (total_f + total_w) / batch,
