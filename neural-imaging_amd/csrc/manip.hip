@@ -143,6 +143,79 @@ __global__ __launch_bounds__(256) void gaussian_fwd_tiled_kernel(const float* __
     if (mask) mask[i] = clip ? (uint8_t)m : (uint8_t)7;
 }
 
+// Wide form (h % 16 == 0, w % 64 == 0: the bench images): a 16 x 64 tile, the thread owns FOUR consecutive pixels of a row.
+// The tile + its 2-pixel ring lives in LDS as the flat rows of the image (pixel c of the ring-extended row at floats 3c ..
+// 3c + 2): the 64 interior pixels of a row are 48 aligned 16-byte global loads (the 12-byte pixel accesses of the 16 x 16
+// form needed 3 dword loads per pixel), only the 2 + 2 ring pixels are mapped (REFLECT) one by one; a thread's 8-pixel
+// window of a tile row is six aligned ds_read_b128 shared by its four outputs (30 LDS reads per 4 pixels instead of 100),
+// its 12 results leave as three 16-byte stores and its four mask bytes as one dword.  Per output the same fmaf chain (ky, then
+// kx) as gaussian_fwd_kernel: identical results.
+constexpr int GW_RS = 208;            // floats per LDS row: 68 pixels x 3 = 204, padded to a multiple of 4
+__global__ __launch_bounds__(256) void gaussian_fwd_wide_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                uint8_t* __restrict__ mask, const float* __restrict__ gk,
+                                                                int n, int h, int w, int clip, int tiles_y, int tiles_x) {
+    __shared__ __attribute__((aligned(16))) float sx[20 * GW_RS];
+    const int tid = threadIdx.x;
+    const int tiles = tiles_y * tiles_x;
+    const long im = blockIdx.x / tiles;
+    const int tile = blockIdx.x % tiles, y0 = (tile / tiles_x) * 16, x0 = (tile % tiles_x) * 64;
+    for (int i = tid; i < 20 * 48; i += 256) {                   // interior columns: 48 float4 per staged row
+        const int r = i / 48, q = i % 48;
+        int gy = y0 - 2 + r;
+        map_coord(gy, h, 2);
+        const float4 v = reinterpret_cast<const float4*>(x + ((im * h + gy) * w + x0) * 3)[q];
+        float2* d = reinterpret_cast<float2*>(sx + r * GW_RS + 6 + 4 * q);       // 8-byte aligned (the ring shifts by 6 floats)
+        d[0] = make_float2(v.x, v.y);
+        d[1] = make_float2(v.z, v.w);
+    }
+    if (tid < 240) {                                             // ring columns: 4 pixels x 3 floats per staged row
+        const int r = tid / 12, j = tid % 12, c = j < 6 ? j / 3 : 64 + j / 3, ch = j % 3;
+        int gy = y0 - 2 + r, gx = x0 - 2 + c;
+        map_coord(gy, h, 2);
+        map_coord(gx, w, 2);
+        sx[r * GW_RS + c * 3 + ch] = x[((im * h + gy) * w + gx) * 3 + ch];
+    }
+    __syncthreads();
+    const int ly = tid >> 4, lq = tid & 15;                      // pixels 4 lq .. 4 lq + 3 of tile row ly
+    float acc[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j][0] = acc[j][1] = acc[j][2] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky) {
+        float win[24];
+        const float4* src = reinterpret_cast<const float4*>(sx + (ly + ky) * GW_RS + 12 * lq);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const float4 v = src[q];
+            win[4 * q] = v.x; win[4 * q + 1] = v.y; win[4 * q + 2] = v.z; win[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) {
+            const float wv = gk[ky * 5 + kx];                    // uniform: scalar loads
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[j][c] = fmaf(win[(j + kx) * 3 + c], wv, acc[j][c]);
+        }
+    }
+    const long i0 = (im * h + y0 + ly) * w + x0 + 4 * lq;
+    uint32_t mbits = 0;
+    float o[12];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float a = acc[j][c];
+            mbits |= (a >= 0.f && a <= 1.f) ? (1u << (8 * j + c)) : 0u;
+            o[j * 3 + c] = clip ? fminf(fmaxf(a, 0.f), 1.f) : a;
+        }
+    float4* dst = reinterpret_cast<float4*>(y + i0 * 3);
+    dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+    dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+    dst[2] = make_float4(o[8], o[9], o[10], o[11]);
+    if (mask) *reinterpret_cast<uint32_t*>(mask + i0) = clip ? mbits : 0x07070707u;
+}
+
 __global__ void gaussian_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ mask,
                                     float* __restrict__ dx, const float* __restrict__ gk, int n, int h, int w) {
     const long total = (long)n * h * w;
@@ -235,6 +308,134 @@ __global__ __launch_bounds__(256) void gaussian_bwd_tiled_kernel(const float* __
     dx[i * 3 + 0] = acc[0];
     dx[i * 3 + 1] = acc[1];
     dx[i * 3 + 2] = acc[2];
+}
+
+// Wide form of the backward pass (h % 16 == 0, w % 64 == 0), laid out like gaussian_fwd_wide_kernel: the masked gradient of a
+// 16 x 64 tile + ring as flat rows (zeros outside the image), four pixels per thread.  Every pixel first takes the term of its
+// own position in the padded domain - 25 taps over the shared register window, order (ky, kx) - then, for the pixels within two
+// of a border, the terms of the mirrored positions in the order of gaussian_bwd_kernel's loops: the same fmaf chain, identical
+// results.
+__global__ __launch_bounds__(256) void gaussian_bwd_wide_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ mask,
+                                                                float* __restrict__ dx, const float* __restrict__ gk,
+                                                                int n, int h, int w, int tiles_y, int tiles_x) {
+    __shared__ __attribute__((aligned(16))) float sd[20 * GW_RS];
+    const int tid = threadIdx.x;
+    const int tiles = tiles_y * tiles_x;
+    const long im = blockIdx.x / tiles;
+    const int tile = blockIdx.x % tiles, y0 = (tile / tiles_x) * 16, x0 = (tile % tiles_x) * 64;
+    for (int i = tid; i < 20 * 48; i += 256) {
+        const int r = i / 48, q = i % 48, gy = y0 - 2 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy >= 0 && gy < h) {
+            const long o = (im * h + gy) * w + x0;
+            v = reinterpret_cast<const float4*>(dy + o * 3)[q];
+            if (mask) {                                          // floats 4q .. 4q + 3 of the row belong to pixels p0 and p0 + 1
+                const int p0 = (4 * q) / 3, c0 = (4 * q) % 3;
+                const uint32_t m0 = mask[o + p0], m1 = mask[o + (p0 + 1 < 64 ? p0 + 1 : p0)];
+                const uint32_t bits = (m0 >> c0) | (m1 << (3 - c0));       // bit e = keep float 4q + e
+                v.x = (bits & 1u) ? v.x : 0.f; v.y = (bits & 2u) ? v.y : 0.f;
+                v.z = (bits & 4u) ? v.z : 0.f; v.w = (bits & 8u) ? v.w : 0.f;
+            }
+        }
+        float2* d = reinterpret_cast<float2*>(sd + r * GW_RS + 6 + 4 * q);
+        d[0] = make_float2(v.x, v.y);
+        d[1] = make_float2(v.z, v.w);
+    }
+    if (tid < 240) {
+        const int r = tid / 12, j = tid % 12, c = j < 6 ? j / 3 : 64 + j / 3, ch = j % 3;
+        const int gy = y0 - 2 + r, gx = x0 - 2 + c;
+        float v = 0.f;
+        if (gy >= 0 && gy < h && gx >= 0 && gx < w) {
+            const long o = (im * h + gy) * w + gx;
+            const uint32_t m = mask ? mask[o] : 7u;
+            v = ((m >> ch) & 1u) ? dy[o * 3 + ch] : 0.f;
+        }
+        sd[r * GW_RS + c * 3 + ch] = v;
+    }
+    __syncthreads();
+    const int ly = tid >> 4, lq = tid & 15, py = y0 + ly;
+    float acc[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j][0] = acc[j][1] = acc[j][2] = 0.f;
+    // own position: dx[py][px] += w[ky][kx] d[py + 2 - ky][px + 2 - kx]  ->  tile row ly + 4 - ky, window pixel j + 4 - kx
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky) {
+        float win[24];
+        const float4* src = reinterpret_cast<const float4*>(sd + (ly + 4 - ky) * GW_RS + 12 * lq);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const float4 v = src[q];
+            win[4 * q] = v.x; win[4 * q + 1] = v.y; win[4 * q + 2] = v.z; win[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) {
+            const float wv = gk[ky * 5 + kx];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[j][c] = fmaf(win[(j + 4 - kx) * 3 + c], wv, acc[j][c]);
+        }
+    }
+    // mirrored positions (REFLECT, P = 2): only rows / columns 1, 2 and size - 3, size - 2 have one
+    int ys[2];
+    const int ny = pad_sources(py, h, 2, 2, ys);
+    if (ny == 1) {
+        // rows away from the top / bottom border: only the first / last four pixels of an image row have a mirrored column.
+        // Column 1 mirrors to padded column 1 (taps kx = 0, 1 reach columns 1, 0), column 2 to padded column 0 (kx = 0 reaches
+        // column 0); on the right w - 3 -> w + 3 (kx = 4 reaches w - 1), w - 2 -> w + 2 (kx = 3, 4 reach w - 1, w - 2).  Those
+        // columns are window pixels 2, 3 (left) and 4, 5 (right) of the thread that owns the border pixels.
+        const bool lb = x0 + 4 * lq == 0, rb = x0 + 4 * lq + 4 == w;
+        if (lb || rb) {
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky) {
+                const float4* src = reinterpret_cast<const float4*>(sd + (ly + 4 - ky) * GW_RS + 12 * lq);
+                const float4 q1 = src[1], q2 = src[2], q3 = src[3], q4 = src[4];
+                const float win[16] = {q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w};
+                // win[f - 4] = float f of the window: pixel 2 = floats 6..8, 3 = 9..11, 4 = 12..14, 5 = 15..17
+                const float g0 = gk[ky * 5], g1 = gk[ky * 5 + 1], g3 = gk[ky * 5 + 3], g4 = gk[ky * 5 + 4];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if (lb) {
+                        acc[1][c] = fmaf(win[9 - 4 + c], g0, acc[1][c]);
+                        acc[1][c] = fmaf(win[6 - 4 + c], g1, acc[1][c]);
+                        acc[2][c] = fmaf(win[6 - 4 + c], g0, acc[2][c]);
+                    } else {
+                        acc[1][c] = fmaf(win[15 - 4 + c], g4, acc[1][c]);
+                        acc[2][c] = fmaf(win[15 - 4 + c], g3, acc[2][c]);
+                        acc[2][c] = fmaf(win[12 - 4 + c], g4, acc[2][c]);
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll                                                   // (acc[j] must stay in registers)
+        for (int j = 0; j < 4; ++j) {
+            const int px = x0 + 4 * lq + j;
+            int xs[2];
+            const int nx = pad_sources(px, w, 2, 2, xs);
+            for (int a = 0; a < ny; ++a)
+                for (int b = 0; b < nx; ++b) {
+                    if (a == 0 && b == 0) continue;              // the own position, summed above
+                    for (int ky = 0; ky < 5; ++ky) {
+                        const int oy = ys[a] - ky;
+                        if (oy < 0 || oy >= h) continue;
+                        for (int kx = 0; kx < 5; ++kx) {
+                            const int ox = xs[b] - kx;
+                            if (ox < 0 || ox >= w) continue;
+                            const float* v = sd + (oy - y0 + 2) * GW_RS + (ox - x0 + 2) * 3;
+                            const float wv = gk[ky * 5 + kx];
+                            acc[j][0] = fmaf(v[0], wv, acc[j][0]);
+                            acc[j][1] = fmaf(v[1], wv, acc[j][1]);
+                            acc[j][2] = fmaf(v[2], wv, acc[j][2]);
+                        }
+                    }
+                }
+        }
+    }
+    float4* dst = reinterpret_cast<float4*>(dx + ((im * h + py) * w + x0 + 4 * lq) * 3);
+    dst[0] = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[1][0]);
+    dst[1] = make_float4(acc[1][1], acc[1][2], acc[2][0], acc[2][1]);
+    dst[2] = make_float4(acc[2][2], acc[3][0], acc[3][1], acc[3][2]);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -677,7 +878,11 @@ int nimg_gaussian_fwd(const float* x, float* y, uint8_t* mask, const float* gk25
     if (!x || !y || !gk25 || n < 0 || h < 5 || w < 5) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
     const int ty = (h + 15) / 16, tx = (w + 15) / 16;
-    if (h >= 16 && w >= 16 && (long)n * ty * tx < (1L << 31))
+    static const bool narrow = getenv("NIMG_GAUSS_NARROW") != nullptr;            // A/B switch: the 16 x 16 form
+    if (!narrow && h % 16 == 0 && w % 64 == 0 && (long)n * h * w * 3 < (1L << 31))
+        hipLaunchKernelGGL(gaussian_fwd_wide_kernel, dim3((unsigned)((long)n * ty * (w / 64))), dim3(256), 0, (hipStream_t)stream,
+                           x, y, mask, gk25, n, h, w, clip, ty, w / 64);
+    else if (h >= 16 && w >= 16 && (long)n * ty * tx < (1L << 31))
         hipLaunchKernelGGL(gaussian_fwd_tiled_kernel, dim3((unsigned)((long)n * ty * tx)), dim3(256), 0, (hipStream_t)stream,
                            x, y, mask, gk25, n, h, w, clip, ty, tx);
     else
@@ -693,7 +898,11 @@ int nimg_gaussian_bwd(const float* dy, const uint8_t* mask, float* dx, const flo
     if (!dy || !dx || !gk25 || n < 0 || h < 5 || w < 5) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
     const int ty = (h + 15) / 16, tx = (w + 15) / 16;
-    if (h >= 16 && w >= 16 && (long)n * ty * tx < (1L << 31))
+    static const bool narrow = getenv("NIMG_GAUSS_NARROW") != nullptr;
+    if (!narrow && h % 16 == 0 && w % 64 == 0 && (long)n * h * w * 3 < (1L << 31))
+        hipLaunchKernelGGL(gaussian_bwd_wide_kernel, dim3((unsigned)((long)n * ty * (w / 64))), dim3(256), 0, (hipStream_t)stream,
+                           dy, mask, dx, gk25, n, h, w, ty, w / 64);
+    else if (h >= 16 && w >= 16 && (long)n * ty * tx < (1L << 31))
         hipLaunchKernelGGL(gaussian_bwd_tiled_kernel, dim3((unsigned)((long)n * ty * tx)), dim3(256), 0,
                            (hipStream_t)stream, dy, mask, dx, gk25, n, h, w, ty, tx);
     else

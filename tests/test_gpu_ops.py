@@ -630,9 +630,10 @@ def test_manipulations_unbuilt_forms_raise(dev):
         th.manipulation_gaussian(x[:, :3, :3].contiguous(), 9, 1.0)           # nothing to mirror: refused by the C ABI
 
 
-@pytest.mark.parametrize('hw', [(24, 40), (16, 16), (50, 18), (8, 12)])
+@pytest.mark.parametrize('hw', [(24, 40), (16, 16), (50, 18), (8, 12), (16, 64), (32, 128), (48, 192)])
 def test_gaussian_backward_tiled_and_plain(dev, hw):
-    """The LDS-tiled backward (images >= 16x16, partial border tiles) and the plain kernel (smaller images) against autograd
+    """The LDS-tiled kernels (images >= 16x16, partial border tiles), their wide form (h % 16 == 0, w % 64 == 0: one, two and
+    three tiles per row, mirrored borders inside and across tiles) and the plain kernels (smaller images) against autograd
     through the REFLECT-padded filter."""
     from neural_imaging_amd.helpers import tf_helpers as th
     h, w = hw
