@@ -717,6 +717,27 @@ __global__ void sparse_axis3_kernel(const float* __restrict__ in, float* __restr
     }
 }
 
+// 3-channel images whose flat rows are whole float4s (win % 4 == 0), operator along the ROWS (axis 0): the output row is a
+// weighted sum of whole input rows, so a thread owns one 16-byte granule of the flat output row - 16-byte loads and stores
+// instead of three dwords at a 12-byte stride; the same fmaf chain per float (CSR order).  (Along the columns the per-pixel
+// form stays: staging the input rows in LDS and gathering four pixels per thread ran at half its speed.)
+__global__ void sparse_axis3_rows_kernel(const float4* __restrict__ in, float4* __restrict__ out, const int* __restrict__ rowptr,
+                                         const int* __restrict__ col, const float* __restrict__ val, int n, int hin, int hout,
+                                         int row4) {
+    const int total = n * hout * row4;                      // < 2^31 (checked by the entry point)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int f = i % row4, r = i / row4, oy = r % hout, im = r / hout;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int e1 = rowptr[oy + 1];
+        for (int e = rowptr[oy]; e < e1; ++e) {
+            const float v = val[e];
+            const float4 p = in[(long)(im * hin + col[e]) * row4 + f];
+            a.x = fmaf(v, p.x, a.x); a.y = fmaf(v, p.y, a.y); a.z = fmaf(v, p.z, a.z); a.w = fmaf(v, p.w, a.w);
+        }
+        out[i] = a;
+    }
+}
+
 // fold a gradient defined on the padded domain (h+2P, w+2P) back onto the image
 __global__ void fold_pad_kernel(const float* __restrict__ dpad, float* __restrict__ dx, int n, int h, int w, int c,
                                 int P, int mode) {
@@ -980,6 +1001,15 @@ int nimg_sparse_axis_apply(const float* in, float* out, const int* rowptr, const
     if (axis != 0 && axis != 1) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
     const int hout = axis == 0 ? out_size : hin, wout = axis == 1 ? out_size : win;
+    static const bool scalar_form = getenv("NIMG_SPARSE_AXIS_SCALAR") != nullptr;            // A/B switch
+    const bool small = (long)n * hout * wout < (1L << 29) && (long)n * hin * win < (1L << 29);
+    if (c == 3 && !scalar_form && small && axis == 0 && win % 4 == 0) {
+        const int row4 = win * 3 / 4;
+        hipLaunchKernelGGL(sparse_axis3_rows_kernel, dim3(grid_for((long)n * hout * row4)), dim3(256), 0, (hipStream_t)stream,
+                           (const float4*)in, (float4*)out, rowptr, col, val, n, hin, hout, row4);
+        NIMG_CHECK_LAUNCH();
+        return NIMG_OK;
+    }
     if (c == 3 && (long)n * hout * wout < (1L << 31) && (long)n * hin * win < (1L << 31))
         hipLaunchKernelGGL(sparse_axis3_kernel, dim3(grid_for((long)n * hout * wout)), dim3(256), 0, (hipStream_t)stream,
                            in, out, rowptr, col, val, n, hin, win, hout, wout, axis);
