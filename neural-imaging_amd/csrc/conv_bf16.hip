@@ -1130,7 +1130,9 @@ int nimg_conv_weights_bf16(const float* w, void* wb, int ks_h, int ks_w, int cin
 int nimg_conv_weights_bf16_batch(const void* table, int n_entries, void* stream) {
     if (n_entries == 0) return NIMG_OK;
     if (!table || n_entries < 0) return NIMG_ERR_ARG;
-    hipLaunchKernelGGL(weights_bf16_batch_kernel, dim3(96, (unsigned)n_entries), dim3(256), 0, (hipStream_t)stream,
+    // 384 workgroups per entry: the launch lasts as long as its largest entry (512 x 512 x 9: 2304 tiles -> 6 per workgroup;
+    // with 96 it was 24 serial tiles = 36 of the launch's 40 us at the head of every step)
+    hipLaunchKernelGGL(weights_bf16_batch_kernel, dim3(384, (unsigned)n_entries), dim3(256), 0, (hipStream_t)stream,
                        (const long long*)table);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;

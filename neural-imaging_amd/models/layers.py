@@ -91,7 +91,7 @@ class Conv5x5Stride2Image(Conv2D):
     def backward_params_image(self, store, ctx, dz):
         if ctx.dtype != torch.bfloat16:
             return self.backward_params(store, ctx, dz)
-        with ops.side_stream(ctx, dz):
+        with ops.side_stream(ctx, dz, key=store.g[self.name + '/kernel'].data_ptr()):
             dw3 = ops.conv2d_wgrad(ctx, dz, 3, db=store.g[self.name + '/bias'])
             ops.s2d_conv_weights_bwd(dw3, store.g[self.name + '/kernel'])
 
@@ -149,7 +149,7 @@ class ConstrainedConv2D(object):
 
     def backward_params(self, store, x, dy):
         # on the side stream like every other parameter gradient (it only needs x and dy; the input gradient runs beside it)
-        with ops.side_stream(x, dy):
+        with ops.side_stream(x, dy, key=store.g[self.name + '/kernel'].data_ptr()):
             dnf = ops.conv2d_wgrad(x, dy, 5, pads=(2, 2), pad_mode=1)
             ops.constrained_kernel_bwd(store.p[self.name + '/kernel'], dnf, store.g[self.name + '/kernel'], self.strength)
 

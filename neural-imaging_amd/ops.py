@@ -180,34 +180,65 @@ class Workspace(object):
 
 
 _ws = Workspace()
-_ws_side = Workspace()          # split-K scratch of the kernels that run on the side stream
 
 # Weight / bias gradients of a layer and its input gradient depend only on the same dz, and many of them (the UNet
-# levels, 512 workgroups each) cannot fill 256 CUs on their own: layers launch their parameter gradients on a second HIP
-# stream so the two kernels share the machine.  The side stream first waits for everything queued on the launch stream,
+# levels, 512 workgroups each) cannot fill 256 CUs on their own: layers launch their parameter gradients on side HIP
+# streams so the kernels share the machine.  A side stream first waits for everything queued on the launch stream,
 # the tensors it reads are pinned against early reuse by the caching allocator (record_stream), and every consumer of
-# the gradient buffers (optimiser, all-reduce, NaN check, end of each model's backward) joins it.  NIMG_NO_SIDE_STREAM=1
-# keeps everything on one stream.
+# the gradient buffers (optimiser, all-reduce, NaN check, end of each model's backward) joins them.
+# NIMG_SIDE_STREAMS=n (default 3): the parameter gradients of different layers are independent of each other as well - on
+# ONE side stream the UNet's ~25 weight-gradient + slab-reduction pairs (20 - 70 us each, a dependent launch gap between
+# them) finish ~0.25 ms after the input-gradient chain they run beside (profiles/r03_ao_c4_launch_trace.txt); spread over three
+# they end with it.  A gradient buffer always goes to the same stream (`key`), so accumulating launches stay ordered; each
+# stream has its own split-K scratch.  NIMG_NO_SIDE_STREAM=1 keeps everything on one stream.
 import os as _os
 
-_SIDE = {'stream': None, 'enabled': _os.environ.get('NIMG_NO_SIDE_STREAM') is None, 'dirty': False}
+_SIDE = {'streams': [], 'ws': [Workspace()], 'n': max(1, int(_os.environ.get('NIMG_SIDE_STREAMS', '3'))), 'next': 0, 'keys': {},
+         'enabled': _os.environ.get('NIMG_NO_SIDE_STREAM') is None, 'dirty': set()}
+_ws_side = _SIDE['ws'][0]       # split-K scratch of the kernels that run on the (first) side stream
+
+
+def _side_index(key):
+    """The side stream of a gradient buffer: assigned round-robin when the buffer is first seen, the same one ever after."""
+    if key is None or _SIDE['n'] == 1:
+        return 0
+    k = _SIDE['keys'].get(key)
+    if k is None:
+        k = _SIDE['keys'][key] = _SIDE['next'] % _SIDE['n']
+        _SIDE['next'] += 1
+    return k
+
+
+def _ws_current(device):
+    """The scratch buffer of the stream the caller launches on."""
+    cur = torch.cuda.current_stream(device)
+    for k, st in enumerate(_SIDE['streams']):
+        if st is not None and cur == st:
+            return _SIDE['ws'][k]
+    return _ws
 
 
 class _on_side_stream(object):
-    def __init__(self, *tensors):
+    def __init__(self, *tensors, key=None):
         self.tensors = [t for t in tensors if t is not None]
+        self.k = _side_index(key)
 
     def __enter__(self):
         dev = self.tensors[0].device
-        if _SIDE['stream'] is None or _SIDE['stream'].device != dev:
-            _SIDE['stream'] = torch.cuda.Stream(device=dev)
-        side = _SIDE['stream']
+        streams, k = _SIDE['streams'], self.k
+        while len(streams) <= k:
+            streams.append(None)
+            if len(_SIDE['ws']) < len(streams):
+                _SIDE['ws'].append(Workspace())
+        if streams[k] is None or streams[k].device != dev:
+            streams[k] = torch.cuda.Stream(device=dev)
+        side = streams[k]
         side.wait_stream(torch.cuda.current_stream(dev))
         for t in self.tensors:
             t.record_stream(side)
         self.ctx = torch.cuda.stream(side)
         self.ctx.__enter__()
-        _SIDE['dirty'] = True
+        _SIDE['dirty'].add(k)
         return side
 
     def __exit__(self, *exc):
@@ -215,12 +246,12 @@ class _on_side_stream(object):
 
 
 class side_stream(object):
-    """with side_stream(t1, t2, ...): launches inside run on the side stream (after everything queued so far on the launch
-    stream; the tensors are pinned against early reuse), or in place when the side stream is disabled.  Tensors ALLOCATED
-    inside belong to the side stream's pool - keep them local to the block."""
+    """with side_stream(t1, t2, ..., key=buffer address): launches inside run on a side stream (after everything queued so far
+    on the launch stream; the tensors are pinned against early reuse), or in place when side streams are disabled.  Tensors
+    ALLOCATED inside belong to that stream's pool - keep them local to the block."""
 
-    def __init__(self, *tensors):
-        self.ctx = _on_side_stream(*tensors) if _SIDE['enabled'] else None
+    def __init__(self, *tensors, key=None):
+        self.ctx = _on_side_stream(*tensors, key=key) if _SIDE['enabled'] else None
 
     def __enter__(self):
         return self.ctx.__enter__() if self.ctx is not None else None
@@ -230,10 +261,12 @@ class side_stream(object):
 
 
 def join_side_stream():
-    """Make the current stream wait for the parameter-gradient kernels launched on the side stream."""
-    if _SIDE['dirty'] and _SIDE['stream'] is not None:
-        torch.cuda.current_stream(_SIDE['stream'].device).wait_stream(_SIDE['stream'])
-        _SIDE['dirty'] = False
+    """Make the current stream wait for the parameter-gradient kernels launched on the side streams."""
+    for k in sorted(_SIDE['dirty']):
+        st = _SIDE['streams'][k]
+        if st is not None:
+            torch.cuda.current_stream(st.device).wait_stream(st)
+    _SIDE['dirty'].clear()
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -447,7 +480,7 @@ def conv2d_wgrad(x, dz, ks, x2=None, stride=1, padding='SAME', pad_mode=0, pads=
     """dw (k,k,C1+C2,Cout) = sum over pixels of x (x) dz;  db (optional, Cout) = fused bias gradient.
     side=True: launch on the side stream (see _on_side_stream); dw / db must then be persistent buffers."""
     if side and _SIDE['enabled'] and dw is not None:
-        with _on_side_stream(x, dz, x2):
+        with _on_side_stream(x, dz, x2, key=dw.data_ptr()):
             return conv2d_wgrad(x, dz, ks, x2=x2, stride=stride, padding=padding, pad_mode=pad_mode, pads=pads, dw=dw,
                                 accumulate=accumulate, db=db, side=False)
     _f32(dw, db)
@@ -470,7 +503,7 @@ def conv2d_wgrad(x, dz, ks, x2=None, stride=1, padding='SAME', pad_mode=0, pads=
     if COMPUTE == 'bf16' and (packed_ok or (c1 % 4 == 0 and c2 % 4 == 0 and cout % 4 == 0 and c1 + c2 >= 8 and
                                             (c2 == 0 or c1 % 8 == 0))):
         need = _lib.load().nimg_conv2d_wgrad_bf16_workspace_bytes(c1 + c2, cout, ks, ks, n, ho, wo)
-        ws = (_ws_side if torch.cuda.current_stream(x.device) == _SIDE['stream'] else _ws).get(need, x.device)
+        ws = _ws_current(x.device).get(need, x.device)
         flags = (BF16_IN if _is_bf16(x) else 0) | (BF16_DZ if _is_bf16(dz) else 0)
         _lib.call('nimg_conv2d_wgrad_bf16_ex', _p(x), c1, _p(x2), c2, _p(dz), cout, _p(dw), _p(db), n, h, wd, ks, stride,
                   pt, pl, pad_mode, ho, wo, 1 if accumulate else 0, _p(ws), ws.numel(), flags, _stream())
@@ -478,7 +511,7 @@ def conv2d_wgrad(x, dz, ks, x2=None, stride=1, padding='SAME', pad_mode=0, pads=
     if _is_bf16(x) or _is_bf16(dz):
         raise RuntimeError('bf16-stored tensor reached a float32 weight-gradient path')
     need = _lib.load().nimg_conv2d_wgrad_workspace_bytes(c1 + c2, cout, ks, ks, n, ho, wo)
-    ws = (_ws_side if torch.cuda.current_stream(x.device) == _SIDE['stream'] else _ws).get(need, x.device)
+    ws = _ws_current(x.device).get(need, x.device)
     _lib.call('nimg_conv2d_wgrad', _p(x), c1, _p(x2), c2, _p(dz), cout, _p(dw), _p(db), n, h, wd, ks, stride, pt, pl,
               pad_mode, ho, wo, 1 if accumulate else 0, _p(ws), ws.numel(), _stream())
     return dw
@@ -486,7 +519,7 @@ def conv2d_wgrad(x, dz, ks, x2=None, stride=1, padding='SAME', pad_mode=0, pads=
 
 def bias_grad(dz, db=None, accumulate=False, side=False):
     if side and _SIDE['enabled'] and db is not None:
-        with _on_side_stream(dz):
+        with _on_side_stream(dz, key=db.data_ptr()):
             return bias_grad(dz, db=db, accumulate=accumulate, side=False)
     _f32(db)
     _fb(dz)
@@ -495,7 +528,7 @@ def bias_grad(dz, db=None, accumulate=False, side=False):
     if db is None:
         db = torch.empty((cout,), dtype=torch.float32, device=dz.device)
     need = _lib.load().nimg_bias_grad_workspace_bytes(npix, cout)
-    ws = (_ws_side if torch.cuda.current_stream(dz.device) == _SIDE['stream'] else _ws).get(need, dz.device)
+    ws = _ws_current(dz.device).get(need, dz.device)
     _lib.call('nimg_bias_grad_ex', _p(dz), _p(db), npix, cout, 1 if accumulate else 0, _p(ws), ws.numel(),
               BF16_DZ if _is_bf16(dz) else 0, _stream())
     return db
@@ -642,7 +675,7 @@ def conv2d_dgrad_unpool(g, idx, w, act_mask=None, out_bf16=False):
 def conv2d_wgrad_unpool(x, g, idx, ks, dw, db=None, side=False):
     """Weight / bias gradient of a fused 5x5 conv + pool layer from its bf16 input x and the pooled gradient + arg-max bytes."""
     if side and _SIDE['enabled'] and dw is not None:
-        with _on_side_stream(x, g, idx):
+        with _on_side_stream(x, g, idx, key=dw.data_ptr()):
             return conv2d_wgrad_unpool(x, g, idx, ks, dw, db=db, side=False)
     _f32(dw, db)
     _fb(x, g)
@@ -650,7 +683,7 @@ def conv2d_wgrad_unpool(x, g, idx, ks, dw, db=None, side=False):
     n, h, wd, cin = x.shape
     cout = g.shape[3]
     need = _lib.load().nimg_conv2d_wgrad_bf16_workspace_bytes(cin, cout, ks, ks, n, h, wd)
-    ws = (_ws_side if torch.cuda.current_stream(x.device) == _SIDE['stream'] else _ws).get(need, x.device)
+    ws = _ws_current(x.device).get(need, x.device)
     _lib.call('nimg_conv2d_wgrad_bf16_unpool', _p(x), cin, _p(g), _p(idx), cout, _p(dw), _p(db), n, h, wd, ks, 0, _p(ws),
               ws.numel(), _stream())
     return dw
@@ -665,7 +698,7 @@ def pooled_backward_ok(cin, cout, ks):
 def conv2d_wgrad_pooled(x, g, idx, ks, dw=None, db=None, side=False):
     """Weight / bias gradient of conv2d_pool from the pooled gradient g (already x LeakyReLU') and the arg-max bytes."""
     if side and _SIDE['enabled'] and dw is not None:
-        with _on_side_stream(x, g, idx):
+        with _on_side_stream(x, g, idx, key=dw.data_ptr()):
             return conv2d_wgrad_pooled(x, g, idx, ks, dw=dw, db=db, side=False)
     _f32(x, dw, db)
     _fb(g)
@@ -675,7 +708,7 @@ def conv2d_wgrad_pooled(x, g, idx, ks, dw=None, db=None, side=False):
     if dw is None:
         dw = torch.empty((ks, ks, cin, cout), dtype=torch.float32, device=x.device)
     need = _lib.load().nimg_conv2d_wgrad_bf16_workspace_bytes(cin, cout, ks, ks, n, h, wd)
-    ws = (_ws_side if torch.cuda.current_stream(x.device) == _SIDE['stream'] else _ws).get(need, x.device)
+    ws = _ws_current(x.device).get(need, x.device)
     _lib.call('nimg_conv2d_wgrad_pooled_bf16_ex', _p(x), cin, _p(g), _p(idx), cout, _p(dw), _p(db), n, h, wd, ks, 0, _p(ws),
               ws.numel(), BF16_DZ if _is_bf16(g) else 0, _stream())
     return dw
@@ -906,7 +939,7 @@ def conv1_pool_c4(c4, w, bias, act='leaky_relu', want_idx=True, out_bf16=True):
 def conv1_wgrad_c4(c4, g, idx, dw=None, db=None, accumulate=False, side=False):
     """Weight / bias gradient of conv1_pool_c4 from the pooled gradient g (already x LeakyReLU') and the arg-max bytes."""
     if side and _SIDE['enabled'] and dw is not None:
-        with _on_side_stream(c4, g, idx):
+        with _on_side_stream(c4, g, idx, key=dw.data_ptr()):
             return conv1_wgrad_c4(c4, g, idx, dw=dw, db=db, accumulate=accumulate, side=False)
     _f32(dw, db)
     _fb(g)
@@ -917,7 +950,7 @@ def conv1_wgrad_c4(c4, g, idx, dw=None, db=None, accumulate=False, side=False):
     if dw is None:
         dw = torch.empty((5, 5, 3, 32), dtype=torch.float32, device=c4.device)
     need = _lib.load().nimg_conv1_wgrad_c4_workspace_bytes()
-    ws = (_ws_side if torch.cuda.current_stream(c4.device) == _SIDE['stream'] else _ws).get(need, c4.device)
+    ws = _ws_current(c4.device).get(need, c4.device)
     _lib.call('nimg_conv1_wgrad_c4', _p(c4), _p(g), _p(idx), _p(dw), _p(db), n, h, wd, 1 if _is_bf16(g) else 0,
               1 if accumulate else 0, _p(ws), ws.numel(), _stream())
     return dw
