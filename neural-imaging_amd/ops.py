@@ -313,7 +313,7 @@ def djpeg_bwd(x, gy, mask, qtab, rounding='soft', out=None, dq=None, accumulate=
     if dq.numel() != 128 or not dq.is_contiguous():
         raise ValueError('dq: 128 contiguous float32 values (2 x 8 x 8) expected')
     need = _lib.load().nimg_djpeg_dq_workspace_bytes(n, h, w)
-    ws = _ws.get(need, x.device)
+    ws = _ws_current(x.device).get(need, x.device)
     _lib.call('nimg_djpeg_bwd_dq', _p(x), _p(gy), _p(mask), _p(qtab), _p(gx), _p(dq), n, h, w, ROUNDING[rounding],
               1 if accumulate else 0, _p(ws), need, _stream())
     return gx
