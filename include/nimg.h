@@ -46,7 +46,9 @@ extern "C" {
                            * layer, written by the input-gradient pass that produces it (models/compression.py:233,245 backward);
                            * act_mask and residual keep the convolution's own (n, hout, wout, o1) layout */
 
-/* library / ABI version, bumped on any signature change */
+/* library / ABI version, bumped on any signature change of an existing entry point (3: nimg_conv2d_fwd_bf16_res gained
+ * out_bf16_copy and stride).  A binding compares nimg_abi_version() with the NIMG_ABI_VERSION it was written against. */
+#define NIMG_ABI_VERSION 3
 int nimg_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------------

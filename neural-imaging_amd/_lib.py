@@ -160,6 +160,9 @@ ERRORS = {-1: 'NIMG_ERR_ARG (invalid argument / unsupported configuration)',
 _lib = None
 
 
+ABI_VERSION = 3         # include/nimg.h NIMG_ABI_VERSION
+
+
 def load():
     """Load libnimg.so (once) and attach prototypes.  Raises RuntimeError if it has not been built."""
     global _lib
@@ -178,6 +181,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError here == ABI drift; let it propagate
         fn.restype = res
         fn.argtypes = args
+    if lib.nimg_abi_version() != ABI_VERSION:
+        raise RuntimeError('libnimg.so at {} has ABI version {}, this binding was written against {} - rebuild it '
+                           '(neural-imaging_amd/csrc/build.sh)'.format(LIB_PATH, lib.nimg_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

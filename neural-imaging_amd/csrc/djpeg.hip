@@ -484,7 +484,7 @@ void launch_bwd(int rounding, int grid, hipStream_t s, A... a) {
 
 extern "C" {
 
-int nimg_abi_version(void) { return 1; }
+int nimg_abi_version(void) { return NIMG_ABI_VERSION; }
 
 int nimg_djpeg_fwd(const float* x, float* y, const float* qtab, uint8_t* mask, int16_t* idx, float* xdq, int n,
                    int h, int w, int rounding, void* stream) {

@@ -30,7 +30,9 @@ def test_python_prototypes_cover_the_header():
     syms = set(_header_symbols())
     assert syms == set(_lib.PROTOTYPES.keys()), syms ^ set(_lib.PROTOTYPES.keys())
     lib = _lib.load()
-    assert lib.nimg_abi_version() == 1
+    header = open(os.path.join(ROOT, 'include', 'nimg.h')).read()
+    declared = int(re.search(r'#define\s+NIMG_ABI_VERSION\s+(\d+)', header).group(1))
+    assert lib.nimg_abi_version() == declared == _lib.ABI_VERSION       # library, header and binding agree (load() checks too)
 
 
 def test_no_oracle_import_in_product():
