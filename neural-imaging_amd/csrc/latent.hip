@@ -152,6 +152,22 @@ __global__ void d2s2_scale_kernel(const float* __restrict__ xs, float* __restric
     }
 }
 
+// c == 3 out of cp == 16 block channels (the input gradient of the codec's first layer, models/compression.py:217): one thread per
+// BLOCK pixel - its 12 used floats are three of four 16-byte loads and land as two runs of 6 contiguous floats (rows 2y, 2y + 1):
+// 8-byte stores.  The per-element form spends its time on 64-bit divisions and 4-byte accesses (0.7 TB/s: 211 us per config-5 step).
+__global__ void d2s2_scale3_kernel(const float4* __restrict__ xs, float* __restrict__ x, int npix, int hb, int wb, float scale) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
+        const int bx = i % wb, r = i / wb, by = r % hb, im = r / hb;
+        const float4 a = xs[4L * i], b = xs[4L * i + 1], c = xs[4L * i + 2];
+        float2* top = reinterpret_cast<float2*>(x + (((long)im * 2 * hb + 2 * by) * (2L * wb) + 2 * bx) * 3);
+        float2* bot = reinterpret_cast<float2*>(x + (((long)im * 2 * hb + 2 * by + 1) * (2L * wb) + 2 * bx) * 3);
+        top[0] = make_float2(scale * a.x, scale * a.y); top[1] = make_float2(scale * a.z, scale * a.w);
+        top[2] = make_float2(scale * b.x, scale * b.y);
+        bot[0] = make_float2(scale * b.z, scale * b.w); bot[1] = make_float2(scale * c.x, scale * c.y);
+        bot[2] = make_float2(scale * c.z, scale * c.w);
+    }
+}
+
 struct KernelW {
     double w[MAXK];
     double dw[MAXK];
@@ -593,6 +609,13 @@ int nimg_s2d_conv_weights_bwd(const float* dw3, float* dw5, int cin, int cp, int
 int nimg_d2s2_scale(const float* xs, float* x, int n, int h, int w, int c, int cp, float scale, void* stream) {
     if (n == 0) return NIMG_OK;
     if (!xs || !x || n < 0 || h < 2 || w < 2 || (h & 1) || (w & 1) || c < 1 || cp < 4 * c) return NIMG_ERR_ARG;
+    if (c == 3 && cp == 16 && (long)n * h * w < (1L << 31)) {
+        const int npix = n * (h >> 1) * (w >> 1);
+        hipLaunchKernelGGL(d2s2_scale3_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, (const float4*)xs, x, npix,
+                           h >> 1, w >> 1, scale);
+        NIMG_CHECK_LAUNCH();
+        return NIMG_OK;
+    }
     hipLaunchKernelGGL(d2s2_scale_kernel, dim3(grid_for((long)n * h * w * c)), dim3(256), 0, (hipStream_t)stream, xs, x, n, h, w, c,
                        cp, scale);
     NIMG_CHECK_LAUNCH();

@@ -281,9 +281,10 @@ class TwitterDCN(DCN):
         P.refresh_images()
         t = OrderedDict()
         t['latent'] = lat
-        net = L['d512'].forward(P, lat, d2s_out=True)           # depth_to_space written by the convolution itself
-        t['i0'] = net
         net_b, bf = None, self._bf16_inner()
+        net = L['d512'].forward(P, lat, d2s_out=True, bf16_copy=bf)     # depth_to_space written by the convolution itself
+        net, net_b = net if bf else (net, None)
+        t['i0'] = net
         for b in (1, 2, 3):
             t['dr{}in'.format(b)] = self._operand(net, net_b)
             a = L['dr{}a'.format(b)].forward(P, t['dr{}in'.format(b)], out_bf16=bf)
@@ -346,10 +347,11 @@ class TwitterDCN(DCN):
             L['er{}a'.format(b)].backward_params(P, inp, dza)
             # block 1 was fed LeakyReLU(e2): its input gradient goes through that activation (mask by sign of e2)
             d_net = L['er{}a'.format(b)].backward_input(P, dza, hw(inp), act_mask=et['e2'] if b == 1 else None,
-                                                        residual=d_net, bf16_copy=bf and b > 1)
-            d_net, d_net_b = d_net if bf and b > 1 else (d_net, None)
+                                                        residual=d_net, bf16_copy=bf)
+            d_net, d_net_b = d_net if bf else (d_net, None)
         L['e2'].backward_params(P, et['e1'], d_net)
-        dz1 = L['e2'].backward_input(P, d_net, hw(et['e1']), act_mask=et['e1'])
+        # e1's gradient only feeds matrix-core operands (e1's weight / input gradient): stored as bf16
+        dz1 = L['e2'].backward_input(P, self._operand(d_net, d_net_b), hw(et['e1']), act_mask=et['e1'], out_bf16=bf)
         L['e1'].backward_params_image(P, et['x0'], dz1)
         dx = L['e1'].backward_input_image(P, dz1, self._in_hw, 2.0) if need_input_grad else None
         ops.join_side_stream()

@@ -61,7 +61,7 @@ class Conv2D(object):
         bf16_copy: returns (gradient, bf16 copy of it or None); s2d_out: returns tf.nn.space_to_depth(gradient, 2) - the
         gradient at the input of the depth_to_space layer that fed this one (stride-1 layers), see ops.conv2d."""
         if self.stride == 2:
-            d = ops.conv2d_dgrad_strided2(dz, store.p[self.name + '/kernel'], in_hw, act_mask=act_mask)
+            d = ops.conv2d_dgrad_strided2(dz, store.p[self.name + '/kernel'], in_hw, act_mask=act_mask, out_bf16=out_bf16)
             d = d if residual is None else ops.add(residual, d, out=d)
             return (d, None) if bf16_copy else d
         return ops.conv2d_dgrad(dz, store.p[self.name + '/kernel'], in_hw, stride=self.stride, act_mask=act_mask,

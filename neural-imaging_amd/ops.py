@@ -351,13 +351,14 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
         co_ = w.shape[3] if _wmode == 0 else w.shape[2]
         fused = COMPUTE == 'bf16' and not _f32_only and x2 is None and out is None and out2 is None and stride == 1 and \
             w.shape[0] == 3 and co_ % 16 == 0 and x.shape[3] % 8 == 0 and D2S_EPILOGUE
-        if residual is not None or bf16_copy:
-            raise NotImplementedError('d2s_out with a residual / bf16 copy')
+        if residual is not None:
+            raise NotImplementedError('d2s_out with a residual')
         if not fused:
             y = conv2d(x, w, bias, stride=stride, padding=padding, act=act, pad_mode=pad_mode, pads=pads, out_hw=out_hw,
                        _wmode=_wmode, _f32_only=_f32_only)
             y = d2s_clip(y, 1.0, 0.0, False)
-            return y if act_mask is None else lrelu_bwd(y, act_mask, out=y, alpha=mask_alpha)
+            y = y if act_mask is None else lrelu_bwd(y, act_mask, out=y, alpha=mask_alpha)
+            return (y, None) if bf16_copy else y
     if residual is not None or bf16_copy:
         _f32(residual)
         fused = COMPUTE == 'bf16' and not _f32_only and x2 is None and out2 is None and \
@@ -1148,7 +1149,7 @@ def s2d_conv_ok(ks, stride, h, w, cin):
     return COMPUTE == 'bf16' and S2D_CONV and ks == 5 and stride == 2 and h % 2 == 0 and w % 2 == 0 and cin >= 1
 
 
-def conv2d_dgrad_strided2(dz, w, in_hw, scale=1.0, act_mask=None):
+def conv2d_dgrad_strided2(dz, w, in_hw, scale=1.0, act_mask=None, out_bf16=False):
     """Input gradient of a stride-2 TF-SAME convolution (times LeakyReLU'(act_mask) if given).  Throughput mode: the 3x3
     stride-1 input gradient of the equivalent convolution over the space-to-depth image (s2d_conv_weights), written straight
     in the depth-to-space layout - and masked - by the kernel's epilogue (a separate d2s2_scale pass where the block channels
@@ -1157,10 +1158,11 @@ def conv2d_dgrad_strided2(dz, w, in_hw, scale=1.0, act_mask=None):
     ks = w.shape[0]
     h, wd = in_hw
     cin = w.shape[2]
-    if s2d_conv_ok(ks, 2, h, wd, cin) and not _is_bf16(dz):
+    if s2d_conv_ok(ks, 2, h, wd, cin) and (not _is_bf16(dz) or dz.shape[3] % 8 == 0):
         w3 = s2d_conv_weights(w)
-        if w3.shape[2] == 4 * cin and cin % 4 == 0 and scale == 1.0 and dz.shape[3] % 8 == 0:
-            return conv2d_dgrad(dz, w3, (h // 2, wd // 2), act_mask=act_mask, d2s_out=True)
+        if w3.shape[2] == 4 * cin and cin % 4 == 0 and scale == 1.0 and dz.shape[3] % 8 == 0 and D2S_EPILOGUE:
+            # (out_bf16: the gradient is stored as bf16 - for a tensor that only feeds matrix-core operands)
+            return conv2d_dgrad(dz, w3, (h // 2, wd // 2), act_mask=act_mask, d2s_out=True, out_bf16=out_bf16)
         dxs = conv2d_dgrad(dz, w3, (h // 2, wd // 2))
         d = d2s2_scale(dxs, cin, scale)
     else:
