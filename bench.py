@@ -594,6 +594,7 @@ def main():
                     line[key + '_patches_per_s'] = w2.batch / dt2
                     line[key + '_ms_per_step'] = 1e3 * dt2
                     line[key + '_tflops'] = w2.batch / dt2 * w2.gflop_per_unit / 1e3
+                    line[key + '_frac_of_mfma_peak'] = line[key + '_tflops'] / BF16_MFMA_PEAK_TFLOPS       # whole step, dense bf16 peak
                     del w2, step2
                 except Exception as e:                       # a side figure must never take the headline line down
                     line[key + '_error'] = repr(e)[:200]
