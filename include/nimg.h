@@ -197,10 +197,6 @@ int nimg_fan_head_fwd(const float* act, const float* w, const float* b, const in
 int nimg_fan_head_bwd(const float* act, const float* gap, const float* w, const float* dlogits,
                       const float* loss_per, float* dact, float* dw, float* db, float* loss, int n, int hw, int c,
                       int k, float loss_scale, float alpha, void* stream);
-/* ... with flags: NIMG_BF16_OUT = dact is stored as bf16 (c % 4 == 0) for the bf16-input gradient kernels of the 1x1 layer */
-int nimg_fan_head_bwd_ex(const float* act, const float* gap, const float* w, const float* dlogits,
-                         const float* loss_per, void* dact, float* dw, float* db, float* loss, int n, int hw, int c,
-                         int k, float loss_scale, float alpha, int flags, void* stream);
 /* tf.keras.optimizers.Adam over a flat buffer: theta -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps); g is pre-scaled
  * by grad_scale (e.g. 1/world_size after a sum all-reduce).  step is the 1-based iteration count.  skip_flag (optional
  * device int): when non-zero the update is skipped - the device-side form of the NaN guard at workflows/...:281-283. */

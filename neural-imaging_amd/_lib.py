@@ -50,7 +50,6 @@ PROTOTYPES = {
     'nimg_mse255': (c_int, [P, P, P, P, c_long, c_float, c_int, P, c_size_t, P]),
     'nimg_fan_head_fwd': (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     'nimg_fan_head_bwd': (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P]),
-    'nimg_fan_head_bwd_ex': (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, P]),
     'nimg_adam_step': (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_int, c_float, P, P]),
     'nimg_adam_step_dev': (c_int, [P, P, P, P, c_long, P, c_float, c_float, c_float, c_float, P, P]),
     'nimg_nan_flag': (c_int, [P, c_long, P, P]),

@@ -588,8 +588,6 @@ __global__ __launch_bounds__(64) void dense_bwd_params_kernel(const float* __res
 // d act[n][p][ch] = (sum_j dlogits[n][j] W[ch][j]) / hw * lrelu'(act).  Workgroup = one image: a thread owns 4 adjacent
 // channels, computes their k-term dot products ONCE, then streams the image's positions with 16-byte loads / stores (the
 // first version recomputed the dot product - and two 64-bit divisions - for every element: 12 % of the HBM rate).
-// OUTB: dact is stored as bf16 (its consumers are the 1x1 layer's weight / input gradient kernels: matrix-core operands).
-template <bool OUTB>
 __global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ w,
                                                       const float* __restrict__ act, float* __restrict__ dact,
                                                       int hw, int c, int k, float alpha, int parts) {
@@ -609,14 +607,8 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ 
         float4* d4 = reinterpret_cast<float4*>(dact + (long)n * hw * c);
         for (int p0 = part * ppi + prow; p0 < hw; p0 += parts * ppi) {
             const float4 a = a4[(long)p0 * c4 + cg];
-            const float4 o = make_float4(g[0] * (a.x > 0.f ? 1.0f : alpha), g[1] * (a.y > 0.f ? 1.0f : alpha),
-                                         g[2] * (a.z > 0.f ? 1.0f : alpha), g[3] * (a.w > 0.f ? 1.0f : alpha));
-            if constexpr (OUTB) {
-                const __bf16 h[4] = {(__bf16)o.x, (__bf16)o.y, (__bf16)o.z, (__bf16)o.w};
-                reinterpret_cast<uint2*>(dact)[((long)n * hw + p0) * c4 + cg] = *reinterpret_cast<const uint2*>(h);
-            } else {
-                d4[(long)p0 * c4 + cg] = o;
-            }
+            d4[(long)p0 * c4 + cg] = make_float4(g[0] * (a.x > 0.f ? 1.0f : alpha), g[1] * (a.y > 0.f ? 1.0f : alpha),
+                                                 g[2] * (a.z > 0.f ? 1.0f : alpha), g[3] * (a.w > 0.f ? 1.0f : alpha));
         }
         return;
     }
@@ -627,9 +619,7 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ 
         for (int j = 0; j < k; ++j) g = fmaf(dlogits[(long)n * k + j], w[ch * k + j], g);
         g /= (float)hw;
         const long o = (long)n * hw * c + i;
-        const float v = g * (act[o] > 0.f ? 1.0f : alpha);
-        if constexpr (OUTB) reinterpret_cast<__bf16*>(dact)[o] = (__bf16)v;
-        else dact[o] = v;
+        dact[o] = g * (act[o] > 0.f ? 1.0f : alpha);
     }
 }
 
@@ -992,26 +982,15 @@ int nimg_fan_head_fwd(const float* act, const float* w, const float* b, const in
 int nimg_fan_head_bwd(const float* act, const float* gap, const float* w, const float* dlogits,
                       const float* loss_per, float* dact, float* dw, float* db, float* loss, int n, int hw, int c,
                       int k, float loss_scale, float alpha, void* stream) {
-    return nimg_fan_head_bwd_ex(act, gap, w, dlogits, loss_per, dact, dw, db, loss, n, hw, c, k, loss_scale, alpha, 0, stream);
-}
-
-int nimg_fan_head_bwd_ex(const float* act, const float* gap, const float* w, const float* dlogits,
-                         const float* loss_per, void* dact, float* dw, float* db, float* loss, int n, int hw, int c,
-                         int k, float loss_scale, float alpha, int flags, void* stream) {
     if (!act || !gap || !w || !dlogits || !loss_per || !dact || !dw || !db || !loss) return NIMG_ERR_ARG;
-    if (n <= 0 || hw <= 0 || c <= 0 || k <= 0 || k > 16 || (flags & ~NIMG_BF16_OUT)) return NIMG_ERR_ARG;
-    if ((flags & NIMG_BF16_OUT) && (c & 3)) return NIMG_ERR_ARG;
+    if (n <= 0 || hw <= 0 || c <= 0 || k <= 0 || k > 16) return NIMG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(dense_bwd_params_kernel, dim3(c + 2), dim3(64), 0, s, gap, dlogits, loss_per, dw, db, loss, n, c, k,
                        loss_scale);
     NIMG_CHECK_LAUNCH();
     const int parts = n >= 1024 ? 1 : (n >= 256 ? 4 : 16);                   // workgroups per image: enough to fill 256 CUs
-    if (flags & NIMG_BF16_OUT)
-        hipLaunchKernelGGL(gap_bwd_kernel<true>, dim3((unsigned)(n * parts)), dim3(256), 0, s, dlogits, w, act, (float*)dact, hw,
-                           c, k, alpha, parts);
-    else
-        hipLaunchKernelGGL(gap_bwd_kernel<false>, dim3((unsigned)(n * parts)), dim3(256), 0, s, dlogits, w, act, (float*)dact, hw,
-                           c, k, alpha, parts);
+    hipLaunchKernelGGL(gap_bwd_kernel, dim3((unsigned)(n * parts)), dim3(256), 0, s, dlogits, w, act, dact, hw, c, k, alpha,
+                       parts);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }

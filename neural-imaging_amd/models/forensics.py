@@ -170,11 +170,8 @@ class FAN(TFModel):
         hw = lambda a: (a.shape[1], a.shape[2])
         a = t['conv1x1']
         # classifier backward; dz = gradient w.r.t. the PRE-activation of whatever fed the head (its LeakyReLU' applied)
-        # plain head (GAP -> classifier): dz only feeds the 1x1 layer's gradient kernels - bf16 in throughput mode
-        head_bf16 = ops.COMPUTE == 'bf16' and ops.STORE_BF16 and 'feat' not in t and self._use_gap
         dz, loss = ops.fan_head_bwd(t['head_in'], t['gap'], P.p[self._cls + '/kernel'], t['dlogits'], t['loss_per'],
-                                    t['loss_scale'], P.g[self._cls + '/kernel'], P.g[self._cls + '/bias'],
-                                    out_bf16=head_bf16)
+                                    t['loss_scale'], P.g[self._cls + '/kernel'], P.g[self._cls + '/bias'])
         if 'feat' in t:
             keep_scale = 1.0 / (1.0 - float(self._h.dropout))
             for i in range(len(self._hidden) - 1, -1, -1):

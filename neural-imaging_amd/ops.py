@@ -848,17 +848,14 @@ def fan_head_fwd(act, w, b, labels=None, loss_scale=1.0):
     return gap, probs, loss_per, dlogits
 
 
-def fan_head_bwd(act, gap, w, dlogits, loss_per, loss_scale, dw, db, out_bf16=False):
-    """out_bf16: the gradient of the 1x1 layer's pre-activation is stored as bf16 (throughput mode: it only feeds that layer's
-    weight / input gradient kernels, which then take their bf16-input forms)."""
+def fan_head_bwd(act, gap, w, dlogits, loss_per, loss_scale, dw, db):
     _f32(act, gap, w, dlogits, loss_per, dw, db)
     n, h, wd, c = act.shape
     k = w.shape[1]
-    out_bf16 = bool(out_bf16) and c % 8 == 0
-    dact = torch.empty(act.shape, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=act.device)
+    dact = torch.empty_like(act)
     loss = torch.empty((1,), dtype=torch.float32, device=act.device)
-    _lib.call('nimg_fan_head_bwd_ex', _p(act), _p(gap), _p(w), _p(dlogits), _p(loss_per), _p(dact), _p(dw), _p(db),
-              _p(loss), n, h * wd, c, k, float(loss_scale), LRELU_ALPHA, BF16_OUT if out_bf16 else 0, _stream())
+    _lib.call('nimg_fan_head_bwd', _p(act), _p(gap), _p(w), _p(dlogits), _p(loss_per), _p(dact), _p(dw), _p(db),
+              _p(loss), n, h * wd, c, k, float(loss_scale), LRELU_ALPHA, _stream())
     return dact, loss
 
 

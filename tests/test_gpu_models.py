@@ -569,11 +569,7 @@ def test_fan_bf16_storage_is_bit_neutral(dev):
     a, b = res[True], res[False]
     assert np.array_equal(a[0], b[0]) and a[1] == b[1] and np.array_equal(a[2], b[2])
     for k in a[3]:
-        if k == 'conv1x1/bias':
-            # the head hands the 1x1 layer ONE gradient value per image and channel (GAP: the same value at every position, times
-            # LeakyReLU'): stored as bf16 its rounding does not average out inside an image - bound 2^-8 of the largest entry
-            assert np.allclose(a[3][k], b[3][k], rtol=0, atol=5e-3 * np.abs(b[3][k]).max()), k
-        elif k.endswith('/bias') and k.startswith('conv'):    # float32 column sums of the (rounded vs exact) gradient tile
+        if k.endswith('/bias') and k.startswith('conv'):      # float32 column sums of the (rounded vs exact) gradient tile
             assert np.allclose(a[3][k], b[3][k], rtol=0, atol=2e-3 * np.abs(b[3][k]).max()), k
         elif k in ('conv2/kernel', 'conv3/kernel', 'conv4/kernel'):
             # the bf16-stored path takes the pooled-gradient weight-gradient kernel (csrc/wgrad5.hip), the float32-stored one the
