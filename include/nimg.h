@@ -40,6 +40,8 @@ extern "C" {
                            * tf.nn.depth_to_space layout (block 2 dy + dx of pixel (y, x) -> pixel (2y + dy, 2x + dx)):
                            * models/compression.py:233,245,249 forward, and the input gradient of a stride-2 layer computed
                            * over its space-to-depth image (nimg_s2d_conv_weights) */
+#define NIMG_MASK_CONV 128 /* with NIMG_D2S_OUT: act_mask keeps the convolution's own (n, hout, wout, o1) layout (the activation it masks
+                            * by was itself stored as a space-to-depth image) instead of the depth-to-space layout of out1 */
 #define NIMG_COPY_LRELU 64 /* nimg_conv2d_fwd_bf16_res: the bf16 copy holds LeakyReLU(alpha) of the (activation-free) result */
 #define NIMG_S2D_OUT 32   /* 3x3 stride-1 convolutions (o1 % 4 == 0, even hout / wout, no out2): out1 (and the bf16 copy) is the
                            * space_to_depth(2) image (n, hout / 2, wout / 2, 4 o1) of the result - the gradient of a depth_to_space

@@ -440,13 +440,15 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
                 }
                 if (co < p.O1) {
                     long o = pixoff * p.O1 + co;
+                    const long om_conv = o;            // NIMG_MASK_CONV: the mask keeps the convolution's own layout
                     if (p.flags & NIMG_D2S_OUT) {      // depth_to_space(2): channel block (2 dy + dx) of pixel (oy, ox) is pixel
                         const int cd = p.O1 >> 2, blk = co / cd;                 // (2 oy + dy, 2 ox + dx) of the output
                         o = (((long)n * 2 * p.Hout + 2 * oy + (blk >> 1)) * (2 * p.Wout) + 2 * ox + (blk & 1)) * cd + (co - blk * cd);
                     }
                     if (p.act1) {
-                        const float4 m = (p.flags & NIMG_BF16_MASK) ? load4_bf16(p.act1, o)
-                                                                    : *reinterpret_cast<const float4*>(p.act1 + o);
+                        const long om = (p.flags & NIMG_MASK_CONV) ? om_conv : o;
+                        const float4 m = (p.flags & NIMG_BF16_MASK) ? load4_bf16(p.act1, om)
+                                                                    : *reinterpret_cast<const float4*>(p.act1 + om);
                         v.x *= m.x > 0.f ? 1.0f : p.alpha; v.y *= m.y > 0.f ? 1.0f : p.alpha;
                         v.z *= m.z > 0.f ? 1.0f : p.alpha; v.w *= m.w > 0.f ? 1.0f : p.alpha;
                     }

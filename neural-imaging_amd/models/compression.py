@@ -247,10 +247,22 @@ class TwitterDCN(DCN):
         P.refresh_images()
         t = OrderedDict()
         self._in_hw = (x.shape[1], x.shape[2])
-        t['e1'], t['x0'] = L['e1'].forward_image(P, x, 2.0, -1.0)       # x0 = 2 x - 1 (or its bf16 space-to-depth image)
         bf = self._bf16_inner()
+        # throughput mode: e1's activation goes to HBM once, as the bf16 space-to-depth image e2 reads through the 3x3 kernels
+        chain = bf and not os.environ.get('NIMG_NO_S2D_CHAIN') and x.shape[1] % 4 == 0 and x.shape[2] % 4 == 0 and \
+            L['e1'].s2d_ok(x) and \
+            L['e2'].s2d_chain_ok((x.shape[1] // 2, x.shape[2] // 2))
+        if chain:
+            t['e1s'], t['x0'] = L['e1'].forward_image(P, x, 2.0, -1.0, s2d_out=True)
+        else:
+            t['e1'], t['x0'] = L['e1'].forward_image(P, x, 2.0, -1.0)   # x0 = 2 x - 1 (or its bf16 space-to-depth image)
         # block 1 reads LeakyReLU(e2) while its skip adds e2 itself (:224-227): the layer writes both, the activation as bf16
-        t['e2'], act0 = L['e2'].forward(P, t['e1'], bf16_copy=True, copy_lrelu=True) if bf else (L['e2'].forward(P, t['e1']), None)
+        if chain:
+            t['e2'], act0 = L['e2'].forward_s2d(P, t['e1s'], bf16_copy=True, copy_lrelu=True)
+        elif bf:
+            t['e2'], act0 = L['e2'].forward(P, t['e1'], bf16_copy=True, copy_lrelu=True)
+        else:
+            t['e2'], act0 = L['e2'].forward(P, t['e1']), None
         net, net_b = t['e2'], None
         t['n0'] = net
         for b in (1, 2, 3):
@@ -349,9 +361,15 @@ class TwitterDCN(DCN):
             d_net = L['er{}a'.format(b)].backward_input(P, dza, hw(inp), act_mask=et['e2'] if b == 1 else None,
                                                         residual=d_net, bf16_copy=bf)
             d_net, d_net_b = d_net if bf else (d_net, None)
-        L['e2'].backward_params(P, et['e1'], d_net)
         # e1's gradient only feeds matrix-core operands (e1's weight / input gradient): stored as bf16
-        dz1 = L['e2'].backward_input(P, self._operand(d_net, d_net_b), hw(et['e1']), act_mask=et['e1'], out_bf16=bf)
+        if 'e1s' in et:
+            e1s = et['e1s']
+            L['e2'].backward_params_s2d(P, e1s, self._operand(d_net, d_net_b))
+            dz1 = L['e2'].backward_input(P, self._operand(d_net, d_net_b), (2 * e1s.shape[1], 2 * e1s.shape[2]), act_mask=e1s,
+                                         out_bf16=bf, mask_s2d=True)
+        else:
+            L['e2'].backward_params(P, et['e1'], d_net)
+            dz1 = L['e2'].backward_input(P, self._operand(d_net, d_net_b), hw(et['e1']), act_mask=et['e1'], out_bf16=bf)
         L['e1'].backward_params_image(P, et['x0'], dz1)
         dx = L['e1'].backward_input_image(P, dz1, self._in_hw, 2.0) if need_input_grad else None
         ops.join_side_stream()

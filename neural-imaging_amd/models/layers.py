@@ -55,13 +55,31 @@ class Conv2D(object):
         ops.conv2d_wgrad(x, dz, self.ks, x2=x2, stride=self.stride, dw=store.g[self.name + '/kernel'],
                          db=store.g[self.name + '/bias'], side=True)
 
+    # -- a 5x5 stride-2 layer fed by a bf16 SPACE-TO-DEPTH image of its input (the codec's e2 behind e1, models/compression.py:
+    # 217-220): forward and weight gradient run as the equivalent 3x3 stride-1 layer (ops.s2d_conv_weights) on the bf16-input
+    # MFMA kernels instead of the float32 strided ones; the input gradient (backward_input, mask_s2d) already is that layer's.
+    def s2d_chain_ok(self, in_hw):
+        return self.stride == 2 and self.ks == 5 and self.cin2 == 0 and self.cin % 8 == 0 and self.cout % 8 == 0 and \
+            ops.COMPUTE == 'bf16' and ops.STORE_BF16 and ops.D2S_EPILOGUE and \
+            ops.s2d_conv_ok(self.ks, self.stride, in_hw[0], in_hw[1], self.cin)
+
+    def forward_s2d(self, store, xs, bf16_copy=False, copy_lrelu=False):
+        w3 = ops.s2d_conv_weights(store.p[self.name + '/kernel'])
+        return ops.conv2d(xs, w3, store.p[self.name + '/bias'], act=self.activation, bf16_copy=bf16_copy, copy_lrelu=copy_lrelu)
+
+    def backward_params_s2d(self, store, xs, dz):
+        with ops.side_stream(xs, dz, key=store.g[self.name + '/kernel'].data_ptr()):
+            dw3 = ops.conv2d_wgrad(xs, dz, 3, db=store.g[self.name + '/bias'])
+            ops.s2d_conv_weights_bwd(dw3, store.g[self.name + '/kernel'])
+
     def backward_input(self, store, dz, in_hw, act_mask=None, out=None, out2=None, out_bf16=False, residual=None,
-                       bf16_copy=False, s2d_out=False):
+                       bf16_copy=False, s2d_out=False, mask_s2d=False):
         """residual: the gradient arriving over the block's skip connection, added in the same pass (stride-1 layers);
         bf16_copy: returns (gradient, bf16 copy of it or None); s2d_out: returns tf.nn.space_to_depth(gradient, 2) - the
         gradient at the input of the depth_to_space layer that fed this one (stride-1 layers), see ops.conv2d."""
         if self.stride == 2:
-            d = ops.conv2d_dgrad_strided2(dz, store.p[self.name + '/kernel'], in_hw, act_mask=act_mask, out_bf16=out_bf16)
+            d = ops.conv2d_dgrad_strided2(dz, store.p[self.name + '/kernel'], in_hw, act_mask=act_mask, out_bf16=out_bf16,
+                                          mask_s2d=mask_s2d)
             d = d if residual is None else ops.add(residual, d, out=d)
             return (d, None) if bf16_copy else d
         return ops.conv2d_dgrad(dz, store.p[self.name + '/kernel'], in_hw, stride=self.stride, act_mask=act_mask,
@@ -79,14 +97,17 @@ class Conv5x5Stride2Image(Conv2D):
     def s2d_ok(self, x):
         return ops.s2d_conv_ok(self.ks, self.stride, x.shape[1], x.shape[2], self.cin) and self.cin2 == 0 and 4 * self.cin <= 16
 
-    def forward_image(self, store, x, a, b):
-        """-> (y, ctx): the layer applied to a x + b; ctx is what the backward passes need (the block image or a x + b)."""
+    def forward_image(self, store, x, a, b, s2d_out=False):
+        """-> (y, ctx): the layer applied to a x + b; ctx is what the backward passes need (the block image or a x + b).
+        s2d_out (only where s2d_ok): y is returned as its bf16 space-to-depth image - the form the next strided layer reads."""
         if not self.s2d_ok(x):
+            if s2d_out:
+                raise RuntimeError('s2d_out needs the space-to-depth form of the layer')
             x0 = ops.affine(x, a, b)
             return self.forward(store, x0), x0
         xs = ops.s2d2_affine(x, a, b, cp=16)
         w3 = ops.s2d_conv_weights(store.p[self.name + '/kernel'], cp=16)
-        return ops.conv2d(xs, w3, store.p[self.name + '/bias'], act=self.activation), xs
+        return ops.conv2d(xs, w3, store.p[self.name + '/bias'], act=self.activation, s2d_out=s2d_out, out_bf16=s2d_out), xs
 
     def backward_params_image(self, store, ctx, dz):
         if ctx.dtype != torch.bfloat16:

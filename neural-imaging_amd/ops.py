@@ -123,7 +123,7 @@ def _f32(*ts):
 
 
 D2S_EPILOGUE = os.environ.get('NIMG_NO_D2S_OUT') is None          # A/B switch: depth_to_space as a separate pass
-BF16_IN, BF16_OUT, BF16_MASK, BF16_DZ, D2S_OUT, S2D_OUT, COPY_LRELU = 1, 2, 4, 8, 16, 32, 64          # include/nimg.h NIMG_BF16_*, NIMG_D2S_OUT
+BF16_IN, BF16_OUT, BF16_MASK, BF16_DZ, D2S_OUT, S2D_OUT, COPY_LRELU, MASK_CONV = 1, 2, 4, 8, 16, 32, 64, 128          # include/nimg.h NIMG_BF16_*, NIMG_D2S_OUT
 
 
 def _fb(*ts):
@@ -334,10 +334,12 @@ def djpeg_bwd(x, gy, mask, qtab, rounding='soft', out=None, dq=None, accumulate=
 # convolutions
 def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mode=0, out=None, out2=None,
            act_mask=None, pads=None, out_hw=None, _wmode=0, _f32_only=False, mask_alpha=None, out_bf16=False, residual=None,
-           bf16_copy=False, d2s_out=False, s2d_out=False, copy_lrelu=False):
+           bf16_copy=False, d2s_out=False, s2d_out=False, copy_lrelu=False, mask_conv_layout=False):
     """x (N,H,W,C1) [+ x2 (N,H,W,C2)], w (k,k,C1+C2,Cout) HWIO.  padding 'SAME' (TF) | 'VALID' | explicit pads/out_hw.
     d2s_out: the result is returned as its depth_to_space(2) image (N, 2 Hout, 2 Wout, Cout / 4) - written in that layout by
-    the 3x3 throughput-mode kernel (act_mask then has that shape too), convolution + d2s_clip (+ lrelu_bwd) elsewhere.
+    the 3x3 throughput-mode kernel (act_mask then has that shape too - or, with mask_conv_layout, the convolution's own
+    (N, Hout, Wout, Cout) shape: the masking activation was stored as a space-to-depth image), convolution + d2s_clip
+    (+ lrelu_bwd) elsewhere.
     s2d_out: the result is returned as its space_to_depth(2) image (N, Hout / 2, Wout / 2, 4 Cout), i.e. the gradient at the
     input of a depth_to_space layer (act_mask / residual keep the (N, Hout, Wout, Cout) layout); 3x3 throughput-mode kernel
     (bf16 if out_bf16), convolution + d2s_clip_bwd elsewhere.
@@ -365,6 +367,8 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
         if residual is not None:
             raise NotImplementedError('d2s_out with a residual')
         if not fused:
+            if mask_conv_layout:
+                raise RuntimeError('a space-to-depth-stored mask needs the fused depth-to-space epilogue')
             y = conv2d(x, w, bias, stride=stride, padding=padding, act=act, pad_mode=pad_mode, pads=pads, out_hw=out_hw,
                        _wmode=_wmode, _f32_only=_f32_only)
             y = d2s_clip(y, 1.0, 0.0, False)
@@ -414,8 +418,9 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
     o2 = 0 if out2 is None else out2.shape[3]
     if o1 + o2 != cout or (not (d2s_out or s2d_out) and tuple(out.shape[:3]) != (n, ho, wo)):
         raise ValueError('output shape mismatch')
-    if d2s_out and act_mask is not None and tuple(act_mask.shape) != tuple(out.shape):
-        raise ValueError('d2s_out: the mask has the shape of the depth-to-space output')
+    if d2s_out and act_mask is not None and \
+            tuple(act_mask.shape) != ((n, ho, wo, cout) if mask_conv_layout else tuple(out.shape)):
+        raise ValueError('d2s_out: the mask has the shape of the depth-to-space output (or of the convolution, mask_conv_layout)')
     # activation: LeakyReLU(0.2) | ReLU (= slope 0); act_mask multiplies by the same-slope derivative (mask_alpha
     # overrides the slope for an input-gradient pass behind a ReLU layer)
     if act not in (None, 'leaky_relu', 'relu'):
@@ -438,7 +443,8 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
             (c1 % 8 == 0 or (c2 == 0 and c1 % 4 == 0 and c1 >= 8 and not _is_bf16(x))):
         wb = weights_bf16(w, _wmode)
         flags = (BF16_IN if _is_bf16(x) else 0) | (BF16_OUT if _is_bf16(out) else 0) | \
-            (BF16_MASK if _is_bf16(act_mask) else 0) | (D2S_OUT if d2s_out else 0) | (S2D_OUT if s2d_out else 0)
+            (BF16_MASK if _is_bf16(act_mask) else 0) | (D2S_OUT if d2s_out else 0) | (S2D_OUT if s2d_out else 0) | \
+            (MASK_CONV if (mask_conv_layout and d2s_out) else 0)
         if residual is not None or bf16_copy:
             if residual is not None and tuple(residual.shape) != (n, ho, wo, cout):
                 raise ValueError('residual: the shape of the output expected')
@@ -470,7 +476,7 @@ def flip_weights(w, out=None):
 
 
 def conv2d_dgrad(dz, w, in_hw, stride=1, padding='SAME', act_mask=None, out=None, out2=None, mask_alpha=None,
-                 out_bf16=False, residual=None, bf16_copy=False, d2s_out=False, s2d_out=False):
+                 out_bf16=False, residual=None, bf16_copy=False, d2s_out=False, s2d_out=False, mask_conv_layout=False):
     """Input gradient of conv2d (stride 1, odd kernel): correlation of dz with the flipped kernel."""
     if stride != 1:
         raise NotImplementedError('strided dgrad is expressed by the caller (see models/compression.py)')
@@ -484,7 +490,7 @@ def conv2d_dgrad(dz, w, in_hw, stride=1, padding='SAME', act_mask=None, out=None
     # forward used pad (pt, pl); the gradient correlation needs ks-1-pt / ks-1-pl; the kernel is read flipped/transposed
     return conv2d(dz, w, None, pads=(ks - 1 - pt, ks - 1 - pl), out_hw=(h, wd), act_mask=act_mask, out=out,
                   out2=out2, _wmode=1, mask_alpha=mask_alpha, out_bf16=out_bf16, residual=residual, bf16_copy=bf16_copy,
-                  d2s_out=d2s_out, s2d_out=s2d_out)
+                  d2s_out=d2s_out, s2d_out=s2d_out, mask_conv_layout=mask_conv_layout)
 
 
 def conv2d_wgrad(x, dz, ks, x2=None, stride=1, padding='SAME', pad_mode=0, pads=None, dw=None, accumulate=False,
@@ -1160,7 +1166,7 @@ def s2d_conv_ok(ks, stride, h, w, cin):
     return COMPUTE == 'bf16' and S2D_CONV and ks == 5 and stride == 2 and h % 2 == 0 and w % 2 == 0 and cin >= 1
 
 
-def conv2d_dgrad_strided2(dz, w, in_hw, scale=1.0, act_mask=None, out_bf16=False):
+def conv2d_dgrad_strided2(dz, w, in_hw, scale=1.0, act_mask=None, out_bf16=False, mask_s2d=False):
     """Input gradient of a stride-2 TF-SAME convolution (times LeakyReLU'(act_mask) if given).  Throughput mode: the 3x3
     stride-1 input gradient of the equivalent convolution over the space-to-depth image (s2d_conv_weights), written straight
     in the depth-to-space layout - and masked - by the kernel's epilogue (a separate d2s2_scale pass where the block channels
@@ -1173,7 +1179,11 @@ def conv2d_dgrad_strided2(dz, w, in_hw, scale=1.0, act_mask=None, out_bf16=False
         w3 = s2d_conv_weights(w)
         if w3.shape[2] == 4 * cin and cin % 4 == 0 and scale == 1.0 and dz.shape[3] % 8 == 0 and D2S_EPILOGUE:
             # (out_bf16: the gradient is stored as bf16 - for a tensor that only feeds matrix-core operands)
-            return conv2d_dgrad(dz, w3, (h // 2, wd // 2), act_mask=act_mask, d2s_out=True, out_bf16=out_bf16)
+            # (mask_s2d: act_mask is the space-to-depth image of the masking activation, i.e. in THIS convolution's layout)
+            return conv2d_dgrad(dz, w3, (h // 2, wd // 2), act_mask=act_mask, d2s_out=True, out_bf16=out_bf16,
+                                mask_conv_layout=mask_s2d)
+        if mask_s2d:
+            raise RuntimeError('a space-to-depth-stored mask needs the fused depth-to-space epilogue')
         dxs = conv2d_dgrad(dz, w3, (h // 2, wd // 2))
         d = d2s2_scale(dxs, cin, scale)
     else:

@@ -1377,13 +1377,18 @@ def test_full_channel_smooth_variant_bf16_gradient_directions(dev):
     assert not low, sorted(low.items(), key=lambda kv: kv[1])[:40]
 
 
-def test_dcn_bf16_storage_inside_residual_blocks_is_bit_neutral(dev):
+def test_dcn_bf16_storage_inside_residual_blocks_is_bit_neutral(dev, monkeypatch):
     """Throughput mode stores the tensors inside the codec's residual blocks (the activation between the two convolutions and
     its gradient) as bf16: their consumers round to bf16 or test the sign, so the reconstruction, the latent and the entropy are
     bit-identical to float32 storage, the weight gradients agree to summation order (different kernel variants take bf16 inputs)
-    and only the bias gradients of the blocks' first layers see the rounding (they sum the stored gradient)."""
+    and only the bias gradients of the blocks' first layers see the rounding (they sum the stored gradient).
+    (With bf16 storage the second layer otherwise runs as a 3x3 layer on the space-to-depth image of the first - ANOTHER kernel,
+    i.e. another float32 summation order, 3e-7 on its output, which the bf16 roundings and the gamma = 25 soft codebook behind
+    it turn into 2 % on the encoder's gradients: switched off here to compare storage with storage; that form has its own
+    oracle test, test_strided_layer_on_a_space_to_depth_stored_input, and runs in every other codec test.)"""
     from neural_imaging_amd import ops
     from neural_imaging_amd.models import compression
+    monkeypatch.setenv('NIMG_NO_S2D_CHAIN', '1')
     x = torch.from_numpy(natural_images(2, 64, 64, seed=23)).to(dev)
     ops.set_compute('bf16')
     out = {}

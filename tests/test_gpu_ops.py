@@ -730,6 +730,52 @@ def test_stride2_conv_as_space_to_depth_conv(dev, shape):
         ops.set_compute('f32')
 
 
+def test_strided_layer_on_a_space_to_depth_stored_input(dev):
+    """models/compression.py:217-220 in throughput mode: the first layer's activation exists only as its bf16 space-to-depth
+    image; the 5x5 stride-2 layer behind it runs forward and weight gradient as a 3x3 layer on that image (Conv2D.forward_s2d /
+    backward_params_s2d) and masks its input gradient with it (NIMG_MASK_CONV).  Against float64 autograd through the strided
+    convolution of the bf16-rounded activation."""
+    from neural_imaging_amd import ops
+    from neural_imaging_amd.models.layers import Conv2D
+    from neural_imaging_amd.models.tfmodel import ParamStore
+    n, h, w, cin, cout = 2, 32, 48, 16, 32                     # h x w = the resolution of the activation e1
+    ops.set_compute('bf16')
+    try:
+        layer = Conv2D('e2', 5, cin, cout, None, stride=2)
+        assert layer.s2d_chain_ok((h, w)) and not layer.s2d_chain_ok((h + 1, w))
+        store = ParamStore(layer.specs(), dev)
+        wk, b = rnd((5, 5, cin, cout), 71, -0.1, 0.1), rnd((cout,), 72, -0.1, 0.1)
+        store.p['e2/kernel'].copy_(g(wk, dev))
+        store.p['e2/bias'].copy_(g(b, dev))
+        e1 = rnd((n, h, w, cin), 73, -1.0, 1.0)
+        e1r = _bf16_round(e1).requires_grad_(True)            # what the bf16 image holds
+        wr = _bf16_round(wk).requires_grad_(True)
+        bb = to64(b).requires_grad_(True)
+        ref = T.conv2d(e1r, wr, bb, 2, 'SAME')
+        dz = rnd(tuple(ref.shape), 74)
+        dzr = _bf16_round(dz)
+        (ref * dzr).sum().backward()
+        e1s = g(T.space_to_depth(torch.from_numpy(e1), 2).numpy(), dev).to(torch.bfloat16)
+        y, act = layer.forward_s2d(store, e1s, bf16_copy=True, copy_lrelu=True)
+        assert_close(y.cpu().numpy(), ref.detach().numpy(), 2e-3, 1e-3, what='forward on the s2d image')
+        assert torch.equal(act, ops.lrelu(y).to(torch.bfloat16))
+        dzb = g(dz, dev).to(torch.bfloat16)
+        layer.backward_params_s2d(store, e1s, dzb)
+        ops.join_side_stream()
+        assert_close(store.g['e2/kernel'].cpu().numpy(), wr.grad.numpy(), 2e-3, 1e-2, what='weight gradient on the s2d image')
+        assert_close(store.g['e2/bias'].cpu().numpy(), dzr.sum((0, 1, 2)).numpy(), 1e-4, 1e-3, what='bias gradient')
+        # input gradient x LeakyReLU'(e1), the mask read from the s2d image; stored as bf16 or float32
+        want = e1r.grad * torch.where(e1r.detach() > 0, 1.0, 0.2)
+        for out_bf16 in (False, True):
+            d = layer.backward_input(store, dzb, (h, w), act_mask=e1s, out_bf16=out_bf16, mask_s2d=True)
+            assert d.dtype == (torch.bfloat16 if out_bf16 else torch.float32) and tuple(d.shape) == (n, h, w, cin)
+            assert_close(d.float().cpu().numpy(), want.numpy(), 1e-2 if out_bf16 else 2e-3, 1e-2, what='masked input gradient')
+        plain = layer.backward_input(store, dzb, (h, w), act_mask=g(e1, dev))      # the float32, depth-to-space-layout mask
+        assert torch.equal(plain, layer.backward_input(store, dzb, (h, w), act_mask=e1s, mask_s2d=True))
+    finally:
+        ops.set_compute('f32')
+
+
 def test_conv3x3_writing_its_depth_to_space_image(dev):
     """NIMG_D2S_OUT: a 3x3 convolution whose epilogue stores tf.nn.depth_to_space(out, 2) (models/compression.py:233,245) - the
     forward layers d512 / d256 (bias + LeakyReLU before the permutation) and the input gradient of a stride-2 layer over its
