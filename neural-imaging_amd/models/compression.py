@@ -252,6 +252,8 @@ class TwitterDCN(DCN):
         chain = bf and not os.environ.get('NIMG_NO_S2D_CHAIN') and x.shape[1] % 4 == 0 and x.shape[2] % 4 == 0 and \
             L['e1'].s2d_ok(x) and \
             L['e2'].s2d_chain_ok((x.shape[1] // 2, x.shape[2] // 2))
+        chain_lat = chain and x.shape[1] % 8 == 0 and x.shape[2] % 8 == 0 and \
+            L['elat'].s2d_chain_ok((x.shape[1] // 4, x.shape[2] // 4))
         if chain:
             t['e1s'], t['x0'] = L['e1'].forward_image(P, x, 2.0, -1.0, s2d_out=True)
         else:
@@ -270,11 +272,15 @@ class TwitterDCN(DCN):
             t['er{}in'.format(b)] = inp
             a = L['er{}a'.format(b)].forward(P, inp, out_bf16=bf)
             t['er{}a'.format(b)] = a
-            want = bf and b < 3                             # the last block feeds the stride-2 latent layer (float32 input)
+            if b == 3 and chain_lat:
+                # the last block's sum only feeds the stride-2 latent layer: written once, as its bf16 space-to-depth image
+                t['n3s'] = L['er3b'].forward(P, a, residual=net, s2d_out=True, out_bf16=True)
+                break
+            want = bf and b < 3
             net = L['er{}b'.format(b)].forward(P, a, residual=net, bf16_copy=want)                  # net + conv(a), one pass
             net, net_b = net if want else (net, None)
             t['n{}'.format(b)] = net
-        t['zl'] = L['elat'].forward(P, net)
+        t['zl'] = L['elat'].forward_s2d(P, t['n3s']) if chain_lat else L['elat'].forward(P, net)
         if self._lws is None or self._lws.buf.device != x.device:
             self._lws = ops.LatentWorkspace(self._codebook.numel(), x.device)
         world = parallel.world_size()
@@ -349,8 +355,12 @@ class TwitterDCN(DCN):
         dzl = ops.latent_bwd(et['zl'], P.p['latent_scaling'], et['latent'], d_lat, entropy_coef, self._codebook,
                              self._lws, dscale=P.g['latent_scaling'].view(1), soft_codebook=soft)
         # ---- encoder
-        L['elat'].backward_params(P, et['n3'], dzl)
-        d_net, d_net_b = L['elat'].backward_input(P, dzl, hw(et['n3'])), None
+        if 'n3s' in et:
+            L['elat'].backward_params_s2d(P, et['n3s'], dzl)
+            d_net, d_net_b = L['elat'].backward_input(P, dzl, (2 * et['n3s'].shape[1], 2 * et['n3s'].shape[2])), None
+        else:
+            L['elat'].backward_params(P, et['n3'], dzl)
+            d_net, d_net_b = L['elat'].backward_input(P, dzl, hw(et['n3'])), None
         for b in (3, 2, 1):
             a, inp = et['er{}a'.format(b)], et['er{}in'.format(b)]
             dzs = self._operand(d_net, d_net_b)

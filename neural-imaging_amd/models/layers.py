@@ -34,12 +34,14 @@ class Conv2D(object):
         store.p[self.name + '/kernel'].copy_(k)
         store.p[self.name + '/bias'].zero_()
 
-    def forward(self, store, x, x2=None, out_bf16=False, residual=None, bf16_copy=False, d2s_out=False, copy_lrelu=False):
+    def forward(self, store, x, x2=None, out_bf16=False, residual=None, bf16_copy=False, d2s_out=False, copy_lrelu=False,
+                s2d_out=False):
         """residual: the skip tensor of a residual block, added to the layer's output in the same pass (ops.conv2d);
-        bf16_copy: returns (out, bf16 copy of out or None); d2s_out: returns tf.nn.depth_to_space(out, 2), see ops.conv2d."""
+        bf16_copy: returns (out, bf16 copy of out or None); d2s_out / s2d_out: returns tf.nn.depth_to_space(out, 2) /
+        tf.nn.space_to_depth(out, 2), see ops.conv2d."""
         return ops.conv2d(x, store.p[self.name + '/kernel'], store.p[self.name + '/bias'], x2=x2,
                           stride=self.stride, act=self.activation, out_bf16=out_bf16, residual=residual, bf16_copy=bf16_copy,
-                          d2s_out=d2s_out, copy_lrelu=copy_lrelu)
+                          d2s_out=d2s_out, copy_lrelu=copy_lrelu, s2d_out=s2d_out)
 
     def can_pool(self, x):
         return self.stride == 1 and self.cin2 == 0 and self.ks in (3, 5) and self.cout % 4 == 0 and \

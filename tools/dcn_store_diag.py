@@ -26,7 +26,7 @@ for name, store, nochain in (('chain', True, False), ('nochain', True, True), ('
     torch.cuda.synchronize()
     out[name] = {k: v.clone() for k, v in dcn._model.g.items()}
     ctxs[name] = {k: v.float().clone() for k, v in ctx[0].items() if isinstance(v, torch.Tensor)}
-for k in ('e2', 'er1a', 'n1', 'n3', 'zl'):
+for k in ('e2', 'er1a', 'n1', 'n2', 'zl'):
     print('fwd', k, 'chain vs nochain', float((ctxs['chain'][k] - ctxs['nochain'][k]).abs().max()), ' nochain vs f32store',
           float((ctxs['nochain'][k] - ctxs['f32store'][k]).abs().max()))
 for k, gb in out['f32store'].items():

@@ -1,5 +1,5 @@
 #!/bin/bash
-# session bd: e1 stored as its bf16 space-to-depth image, e2 forward / weight gradient on the 3x3 kernels - tests, configs 3 / 5
+# session bd: e1 and the last block sum stored as bf16 space-to-depth images, e2 / elat forward + weight gradient on the 3x3 kernels - tests, configs 3 / 5
 OUT=gpurun_out/r03_bd; mkdir -p $OUT
 timeout 900 python -m pytest tests -x -q -m gpu -k "space_to_depth or depth_to_space or residual or dcn or DCN or codec or compression or full_channel or d2s or stride2 or strided" > $OUT/tests.txt 2>&1
 tail -4 $OUT/tests.txt
