@@ -80,6 +80,18 @@ def test_djpeg_reciprocal_division_is_the_ieee_quotient(tmp_path):
     assert int(out.split('alone:')[1].strip(' )\n')) > 0          # the correction is needed: x * rc alone is often 1 ulp off
 
 
+def test_side_stream_of_a_gradient_buffer_is_stable():
+    """ops._side_index: the parameter gradients are spread round-robin over the side streams, but a gradient buffer (the key) is
+    served by the same stream ever after - two launches that accumulate into one buffer must stay ordered."""
+    from neural_imaging_amd import ops
+    n = ops._SIDE['n']
+    keys = [('test-key', i) for i in range(3 * n + 1)]
+    first = [ops._side_index(k) for k in keys]
+    assert first == [ops._side_index(k) for k in keys]
+    assert all(0 <= k < n for k in first) and len(set(first)) == min(n, len(keys))
+    assert ops._side_index(None) == 0
+
+
 def test_nearest_resample_operator_matches_oracle():
     """method='nearest' of manipulation_resample (tf_helpers.py:68-76): the composed axis operator picks the pixels the restated
     ResizeNearestNeighbor picks; down by 2 keeps the odd pixels (floor((o + 0.5) * 2) = 2 o + 1), up by 2 repeats each twice."""
