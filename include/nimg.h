@@ -398,7 +398,11 @@ int nimg_zero_insert2(const float* in, float* out, int n, int h, int w, int c, v
  * float64 like the reference (layers.py:141), plus the batch-global differentiable entropy of the latent
  * (helpers/tf_helpers.py:290-333).  scale: device scalar (may be NULL = 1).  count_global: number of latent values over
  * ALL ranks (0 = count).  finalize = 0 leaves the K float64 histogram sums at workspace + 1024*K doubles for an
- * all-reduce; call nimg_latent_entropy_finalize afterwards. The workspace must stay untouched until nimg_latent_bwd. */
+ * all-reduce; call nimg_latent_entropy_finalize afterwards. The workspace must stay untouched until nimg_latent_bwd.
+ * soft_codebook: bit 0 = Quantization('soft-codebook') (else identity); bit 1 = the caller's promise that the codebook is
+ * unit-spaced (codebook[k] = codebook[0] + k, the reference's consecutive integers, models/layers.py:160-170): with gamma >= 25
+ * and v = 50 the kernels then evaluate, for a value inside the codebook's range, only the five centres around the nearest one -
+ * the weight of any other centre is below 2e-33 of the nearest one's, under the last bit of every float64 sum it would enter. */
 size_t nimg_latent_workspace_bytes(int codebook_size);
 int nimg_latent_fwd(const float* z, const float* scale, const float* codebook, int codebook_size, float v,
                     float gamma, int soft_codebook, float* latent, float* entropy, long count, long count_global,

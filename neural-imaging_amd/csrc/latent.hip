@@ -318,6 +318,130 @@ __device__ __forceinline__ double pow_fixed(double r, int m) {
     return acc;
 }
 
+// UNIT-SPACED codebooks (cb[k] = cb[0] + k, the reference's: consecutive integers, models/layers.py:160-170) under gamma >= 25,
+// v = 50: seen from a point u inside [cb[0] - 1/2, cb[K-1] + 1/2] the weight of a centre 2.5 or more away is below
+// (4.125 / 79.1)^25.5 = 2e-33 of the nearest centre's - thirteen orders under the resolution of the float64 sums it would be added
+// to.  The WIN kernels evaluate the five centres around the nearest one and nothing else (the full loop for points outside
+// that range): every float64 sum they form differs from the full one by less than its last bit, at 5 / K of the work.  The per-value
+// histogram terms go to the workgroup's LDS histogram by float64 atomics (dynamic centre index; the full kernels keep
+// K per-thread accumulators in registers).
+template <int M>
+__device__ __forceinline__ double t_weight(double u, double c, double gamma, double inv_v, int m, double& r_out, double& t_out) {
+    const double t = gamma * (u - c);
+    const double r = rsqrt_refined(__builtin_fma(t * t, inv_v, 1.0));
+    r_out = r; t_out = t;
+    return pow_fixed<M>(r, m);
+}
+
+template <int K, int M>
+__global__ __launch_bounds__(256) void soft_codebook_fwd_win_kernel(const float* __restrict__ z, const float* __restrict__ scale,
+                                                                    const float* __restrict__ cb, int m, double inv_v,
+                                                                    double gamma, float* __restrict__ latent,
+                                                                    double* __restrict__ hist_partial, long count,
+                                                                    int soft_codebook) {
+    __shared__ double sh[K];
+    if (threadIdx.x < K) sh[threadIdx.x] = 0.0;
+    __syncthreads();
+    const float s = scale ? scale[0] : 1.0f;
+    const float c0f = cb[0];
+    const double c0 = (double)c0f, lo = c0 - 0.5, hi = c0 + (double)(K - 1) + 0.5;
+    // the centres [ka, kb] that matter at u (all of them outside the range the bound above covers)
+    auto window = [&](double u, int& ka, int& kb) {
+        if (u >= lo && u <= hi) {
+            int k0 = (int)rint(u - c0);
+            k0 = k0 < 0 ? 0 : (k0 > K - 1 ? K - 1 : k0);
+            ka = k0 - 2 < 0 ? 0 : k0 - 2;
+            kb = k0 + 2 > K - 1 ? K - 1 : k0 + 2;
+        } else {
+            ka = 0; kb = K - 1;
+        }
+    };
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        const float zs = z[i] * s;                                           // layers.py:197-198 (float32 product)
+        float lat = zs;
+        int ka, kb;
+        double r, t;
+        if (soft_codebook) {
+            double S = 0.0, wc = 0.0, best = -1.0;
+            float hard = 0.f;
+            window((double)zs, ka, kb);
+            for (int k = ka; k <= kb; ++k) {
+                const float ckf = c0f + (float)k;                            // exact: the centres are cb[0] + k
+                const double w = t_weight<M>((double)zs, (double)ckf, gamma, inv_v, m, r, t) + 1e-72;
+                S += w;
+                wc = __builtin_fma(w, (double)ckf, wc);
+                if (w > best) { best = w; hard = ckf; }                      // first maximum, like tf.argmax
+            }
+            const float softf = (float)(wc / S), hardf = hard;
+            lat = (hardf - softf) + softf;                                   // stop_gradient(hard - soft) + soft
+        }
+        latent[i] = lat;
+        window((double)lat, ka, kb);                                         // entropy(latent, codebook), layers.py:201
+        double S = 0.0;
+        for (int k = ka; k <= kb; ++k) S += t_weight<M>((double)lat, c0 + (double)k, gamma, inv_v, m, r, t) + 1e-72;
+        const double inv = 1.0 / S;
+        for (int k = ka; k <= kb; ++k)
+            atomicAdd(&sh[k], (t_weight<M>((double)lat, c0 + (double)k, gamma, inv_v, m, r, t) + 1e-72) * inv);
+    }
+    __syncthreads();
+    if (threadIdx.x < K) hist_partial[(long)blockIdx.x * K + threadIdx.x] = sh[threadIdx.x];
+}
+
+template <int K, int M>
+__global__ __launch_bounds__(256) void soft_codebook_bwd_win_kernel(const float* __restrict__ z, const float* __restrict__ scale,
+                                                                    const float* __restrict__ latent,
+                                                                    const float* __restrict__ dlat,
+                                                                    const double* __restrict__ dH_dsum, float coef,
+                                                                    const float* __restrict__ cb, int m, double inv_v,
+                                                                    double gamma, float* __restrict__ dz,
+                                                                    double* __restrict__ dscale_partial, long count,
+                                                                    int soft_codebook) {
+    __shared__ double red[4];
+    __shared__ double sdh[K];
+    if (threadIdx.x < K) sdh[threadIdx.x] = dH_dsum[threadIdx.x];
+    __syncthreads();
+    const float s = scale ? scale[0] : 1.0f;
+    const double dfac = -(double)m * inv_v * gamma;
+    const double c0 = (double)cb[0], lo = c0 - 0.5, hi = c0 + (double)(K - 1) + 0.5;
+    auto sums = [&](double u, bool use_dh) {
+        int ka = 0, kb = K - 1;
+        if (u >= lo && u <= hi) {
+            int k0 = (int)rint(u - c0);
+            k0 = k0 < 0 ? 0 : (k0 > K - 1 ? K - 1 : k0);
+            ka = k0 - 2 < 0 ? 0 : k0 - 2;
+            kb = k0 + 2 > K - 1 ? K - 1 : k0 + 2;
+        }
+        double S = 0.0, dS = 0.0, A = 0.0, B = 0.0;
+        for (int k = ka; k <= kb; ++k) {
+            const double ck = c0 + (double)k;
+            const double qk = use_dh ? sdh[k] : ck;
+            double r, t;
+            const double w0 = t_weight<M>(u, ck, gamma, inv_v, m, r, t);
+            const double dw = w0 * (dfac * t) * (r * r);
+            const double w = w0 + 1e-72;
+            S += w; dS += dw;
+            A = __builtin_fma(qk, dw, A);
+            B = __builtin_fma(qk, w, B);
+        }
+        const double inv = 1.0 / S;
+        return (A - B * dS * inv) * inv;
+    };
+    double dsum = 0.0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        double g = dlat ? (double)dlat[i] : 0.0;
+        if (coef != 0.f) g += (double)coef * sums((double)latent[i], true);
+        const float zs = z[i] * s;
+        const double dsoft = soft_codebook ? sums((double)zs, false) : 1.0;
+        const double gz = g * dsoft;                 // gradient w.r.t. zs = scale * z
+        dz[i] = (float)(gz * (double)s);
+        dsum += gz * (double)z[i];
+    }
+    dsum = wave_sum_d(dsum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dsum;
+    __syncthreads();
+    if (threadIdx.x == 0) dscale_partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
 template <int K, int M>
 __global__ __launch_bounds__(256) void soft_codebook_fwd_fast_kernel(const float* __restrict__ z, const float* __restrict__ scale,
                                                                      const float* __restrict__ cb, int m, double inv_v,
@@ -689,7 +813,17 @@ int nimg_latent_fwd(const float* z, const float* scale, const float* codebook, i
 #define NIMG_SCB_FWD(KK, MM)                                                                                              \
     hipLaunchKernelGGL((soft_codebook_fwd_fast_kernel<KK, MM>), dim3(grid), dim3(256), 0, s, z, scale, codebook, m, 1.0 / vd, \
                        (double)gamma, latent, part, count, soft_codebook)
-    if (m == 51 && K == 32) NIMG_SCB_FWD(32, 51);
+    // soft_codebook bit 1 (a promise of the caller): unit-spaced codebook -> the windowed kernels (gamma >= 25, v = 50 only)
+    static const bool no_win = getenv("NIMG_LATENT_NO_WINDOW") != nullptr;
+    const bool win = (soft_codebook & 2) && m == 51 && gamma >= 25.0f && !no_win;
+    soft_codebook &= 1;
+#define NIMG_SCB_FWD_WIN(KK)                                                                                              \
+    hipLaunchKernelGGL((soft_codebook_fwd_win_kernel<KK, 51>), dim3(grid), dim3(256), 0, s, z, scale, codebook, m, 1.0 / vd, \
+                       (double)gamma, latent, part, count, soft_codebook)
+    if (win && K == 32) NIMG_SCB_FWD_WIN(32);
+    else if (win && K == 16) NIMG_SCB_FWD_WIN(16);
+    else if (win && K == 8) NIMG_SCB_FWD_WIN(8);
+    else if (m == 51 && K == 32) NIMG_SCB_FWD(32, 51);
     else if (m == 51 && K == 16) NIMG_SCB_FWD(16, 51);
     else if (m == 51 && K == 8) NIMG_SCB_FWD(8, 51);
     else if (m && K == 32) NIMG_SCB_FWD(32, 0);
@@ -738,7 +872,16 @@ int nimg_latent_bwd(const float* z, const float* scale, const float* latent, con
 #define NIMG_SCB_BWD(KK, MM)                                                                                          \
     hipLaunchKernelGGL((soft_codebook_bwd_fast_kernel<KK, MM>), dim3(grid), dim3(256), 0, s, z, scale, latent, dlatent,   \
                        (const double*)dH, entropy_coef, codebook, m, 1.0 / vd, (double)gamma, dz, dsp, count, soft_codebook)
-    if (m == 51 && K == 32) NIMG_SCB_BWD(32, 51);
+    static const bool no_win = getenv("NIMG_LATENT_NO_WINDOW") != nullptr;
+    const bool win = (soft_codebook & 2) && m == 51 && gamma >= 25.0f && !no_win;
+    soft_codebook &= 1;
+#define NIMG_SCB_BWD_WIN(KK)                                                                                          \
+    hipLaunchKernelGGL((soft_codebook_bwd_win_kernel<KK, 51>), dim3(grid), dim3(256), 0, s, z, scale, latent, dlatent,    \
+                       (const double*)dH, entropy_coef, codebook, m, 1.0 / vd, (double)gamma, dz, dsp, count, soft_codebook)
+    if (win && K == 32) NIMG_SCB_BWD_WIN(32);
+    else if (win && K == 16) NIMG_SCB_BWD_WIN(16);
+    else if (win && K == 8) NIMG_SCB_BWD_WIN(8);
+    else if (m == 51 && K == 32) NIMG_SCB_BWD(32, 51);
     else if (m == 51 && K == 16) NIMG_SCB_BWD(16, 51);
     else if (m == 51 && K == 8) NIMG_SCB_BWD(8, 51);
     else if (m && K == 32) NIMG_SCB_BWD(32, 0);

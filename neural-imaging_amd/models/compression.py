@@ -286,7 +286,8 @@ class TwitterDCN(DCN):
         world = parallel.world_size()
         count = t['zl'].numel()
         soft = self._h.rounding == 'soft-codebook'
-        lat, ent = ops.latent_fwd(t['zl'], P.p['latent_scaling'], self._codebook, self._lws, soft_codebook=soft,
+        # (self._codebook is torch.arange(qmin, qmax + 1): consecutive integers - the unit_codebook promise of ops.latent_fwd)
+        lat, ent = ops.latent_fwd(t['zl'], P.p['latent_scaling'], self._codebook, self._lws, soft_codebook=soft, unit_codebook=True,
                                   count_global=count * world, finalize=(world == 1))
         if world > 1:       # batch-global soft histogram: 2^bpf float64 sums are all-reduced (SURVEY 8e caveat 1)
             torch.distributed.all_reduce(self._lws.hist_sums())
@@ -353,7 +354,7 @@ class TwitterDCN(DCN):
         # ---- latent
         soft = self._h.rounding == 'soft-codebook'
         dzl = ops.latent_bwd(et['zl'], P.p['latent_scaling'], et['latent'], d_lat, entropy_coef, self._codebook,
-                             self._lws, dscale=P.g['latent_scaling'].view(1), soft_codebook=soft)
+                             self._lws, dscale=P.g['latent_scaling'].view(1), soft_codebook=soft, unit_codebook=True)
         # ---- encoder
         if 'n3s' in et:
             L['elat'].backward_params_s2d(P, et['n3s'], dzl)

@@ -1209,12 +1209,16 @@ class LatentWorkspace(object):
         return self.buf.view(torch.float64)[1024 * self.k:1024 * self.k + self.k]
 
 
-def latent_fwd(z, scale, codebook, ws, v=50.0, gamma=25.0, soft_codebook=True, count_global=0, finalize=True):
+def latent_fwd(z, scale, codebook, ws, v=50.0, gamma=25.0, soft_codebook=True, count_global=0, finalize=True,
+               unit_codebook=False):
+    """unit_codebook: the caller's promise that codebook[k] = codebook[0] + k (include/nimg.h: the kernels then evaluate only
+    the centres whose weight can reach the float64 sums)."""
     _f32(z, scale, codebook)
     latent = torch.empty_like(z)
     entropy = torch.empty((1,), dtype=torch.float32, device=z.device)
     _lib.call('nimg_latent_fwd', _p(z), _p(scale), _p(codebook), codebook.numel(), float(v), float(gamma),
-              1 if soft_codebook else 0, _p(latent), _p(entropy), z.numel(), int(count_global), _p(ws.buf),
+              (1 if soft_codebook else 0) | (2 if unit_codebook else 0), _p(latent), _p(entropy), z.numel(), int(count_global),
+              _p(ws.buf),
               ws.buf.numel(), 1 if finalize else 0, _stream())
     return latent, entropy
 
@@ -1224,11 +1228,12 @@ def latent_entropy_finalize(ws, count_global, entropy):
 
 
 def latent_bwd(z, scale, latent, dlatent, entropy_coef, codebook, ws, dscale=None, v=50.0, gamma=25.0,
-               soft_codebook=True, accumulate_dscale=False):
+               soft_codebook=True, accumulate_dscale=False, unit_codebook=False):
     _f32(z, scale, latent, dlatent, codebook, dscale)
     dz = torch.empty_like(z)
     _lib.call('nimg_latent_bwd', _p(z), _p(scale), _p(latent), _p(dlatent), float(entropy_coef), _p(codebook),
-              codebook.numel(), float(v), float(gamma), 1 if soft_codebook else 0, _p(dz), _p(dscale),
+              codebook.numel(), float(v), float(gamma), (1 if soft_codebook else 0) | (2 if unit_codebook else 0), _p(dz),
+              _p(dscale),
               1 if accumulate_dscale else 0, z.numel(), _p(ws.buf), ws.buf.numel(), _stream())
     return dz
 

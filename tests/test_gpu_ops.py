@@ -679,6 +679,27 @@ def test_latent_soft_codebook_and_entropy(dev):
     _, e0 = ops.latent_fwd(torch.zeros(4096, device=dev), one, g(cb, dev), ws)
     _, e5 = ops.latent_fwd(g(np.tile(cb, 128), dev), one, g(cb, dev), ws)
     assert float(e0.item()) < 1e-4 and abs(float(e5.item()) - 5.0) < 1e-3
+    # the windowed kernels (unit_codebook promise: only the five centres around the nearest one are evaluated inside the codebook's
+    # range) against the full ones AND the oracle: values at centres, at midpoints between centres, at the range ends and far
+    # outside (there the full loop runs)
+    zw = np.concatenate([cb, cb[:-1] + 0.5, cb[:-1] + 0.4999, [cb[0] - 0.5, cb[0] - 0.51, cb[-1] + 0.5, cb[-1] + 0.6,
+                                                                 -40.0, 55.0, cb[0] - 3.0], (rnd((400,), 5) * 20)]).astype(np.float32)
+    dlw = rnd(zw.shape, 6)
+    zt = to64(zw).requires_grad_(True)
+    latw = T.soft_codebook(zt, to64(cb))
+    entw, _ = T.entropy(latw, to64(cb))
+    ((latw * to64(dlw)).sum() + 250.0 * entw).backward()
+    res = {}
+    for unit in (False, True):
+        l_, e_ = ops.latent_fwd(g(zw, dev), one, g(cb, dev), ws, unit_codebook=unit)
+        d_ = ops.latent_bwd(g(zw, dev), one, l_, g(dlw, dev), 250.0, g(cb, dev), ws, dscale=dscale, unit_codebook=unit)
+        res[unit] = (l_.cpu().numpy(), float(e_.item()), d_.cpu().numpy(), float(dscale.item()))
+    assert np.array_equal(res[True][0], res[False][0]) and abs(res[True][1] - res[False][1]) < 1e-7
+    assert_close(res[True][2], res[False][2], 1e-9, 1e-6, what='windowed vs full dz')
+    assert abs(res[True][3] - res[False][3]) <= 1e-6 * abs(res[False][3]) + 1e-9
+    assert_close(res[True][0], latw.detach().numpy(), 1e-5, what='windowed latent vs oracle')
+    assert abs(res[True][1] - float(entw)) < 1e-5
+    assert_close(res[True][2], zt.grad.numpy(), 1e-6, 2e-4, what='windowed dz vs oracle')
 
 
 @pytest.mark.parametrize('shape', [(2, 32, 48, 3, 64), (1, 16, 16, 8, 16), (2, 24, 40, 64, 32)])
