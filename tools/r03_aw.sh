@@ -1,7 +1,7 @@
 #!/bin/bash
-# session aw / bb / bc / bf: final validation of round 3 - full GPU suite, smoke, bit-identity of the 16-byte resampling form, kernel statistics of
+# session aw / bb / bc / bf / bh: final validation of round 3 - full GPU suite, smoke, bit-identity of the 16-byte resampling form, kernel statistics of
 # the C4 step (one stream) and the default bench line
-OUT=$PWD/gpurun_out/r03_bf; mkdir -p $OUT
+OUT=$PWD/gpurun_out/r03_bh; mkdir -p $OUT
 export TMPDIR=/tmp
 ROOT=$PWD
 timeout 1500 python -m pytest tests -x -q -m gpu > $OUT/tests.txt 2>&1; tail -3 $OUT/tests.txt
@@ -10,7 +10,7 @@ python tools/resample_check.py $OUT/vec.pt 2>&1 | tail -1
 NIMG_SPARSE_AXIS_SCALAR=1 python tools/resample_check.py $OUT/scalar.pt 2>&1 | tail -1
 python - <<'PY'
 import torch
-a, b = torch.load('gpurun_out/r03_bf/vec.pt'), torch.load('gpurun_out/r03_bf/scalar.pt')
+a, b = torch.load('gpurun_out/r03_bh/vec.pt'), torch.load('gpurun_out/r03_bh/scalar.pt')
 print('resampling: 16-byte row form bit-identical to the per-pixel form:', all(torch.equal(x, y) for x, y in zip(a, b)), len(a))
 PY
 rm -f $OUT/vec.pt $OUT/scalar.pt
