@@ -350,6 +350,8 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
     kernel does not apply, i.e. in float32 mode): what the bf16 kernels downstream would round it to anyway, at half the
     bytes.  copy_lrelu: the copy holds LeakyReLU(0.2) of the (activation-free) result instead."""
     copy = None
+    if mask_conv_layout and not d2s_out:
+        raise ValueError('mask_conv_layout only has a meaning with d2s_out')
     if s2d_out:
         co_ = w.shape[3] if _wmode == 0 else w.shape[2]
         fused = COMPUTE == 'bf16' and not _f32_only and x2 is None and out is None and out2 is None and stride == 1 and \
