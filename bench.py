@@ -3,7 +3,7 @@
 bench.py - raw patches/s (forward + backward + Adam) of the imaging channel  UNet ISP -> manipulations -> codec -> FAN
 at 256x256 RGB (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--workload c4|c3|c5]
+    python bench.py --gpus N --steps K --warmup W [--workload c4|c2|c3|c5]
 
 N > 1 without a torch.distributed environment: bench.py re-launches itself as
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`
@@ -13,6 +13,8 @@ Workloads (BASELINE.json configs):
   c4 (default, configs[3], the configuration the metric is quoted on): B = 64 raw patches / GPU -> UNet -> (5B,256,256,3)
       [native, sharpen:1, resample:50, gaussian:0.83, jpeg:80] -> dJPEG(80, soft) -> FAN -> CE + 0.1 mse255 -> backward to the
       UNet and FAN weights -> gradient all-reduce (N > 1) -> Keras Adam.  Unit = one raw patch.
+  c2 (configs[1]): train_nip.py --nip UNet - NIPModel.training_step (L2 loss on 255-scaled images, Keras Adam) on B = 32 RAW
+      patches of 64x64x4 -> RGB 128x128 (training/pipeline.py:191-247, models/pipelines.py:77-90).  Unit = one raw patch.
   c3 (configs[2]): TwitterDCN-32C training step on B = 50 RGB patches of 256x256 (l2 + 250 H; the batch size train_dcn.py:102
       fixes).  Unit = one RGB patch.
   c5 (configs[4]): the full channel with the learned codec, UNet -> manipulations -> TwitterDCN-32C -> FAN, B = 16 raw
@@ -168,11 +170,58 @@ class TrainDCN(Workload):
         return time_conv3_dominant(dev, self.batch)
 
 
+class TrainNIP(Workload):
+    key = 'c2'
+    name = 'train_nip --nip UNet, L2 loss, RAW 64x64x4 -> RGB 128x128 (batch 32 x 128 x 128)'
+    default_batch = 32
+    raw_patch = 64               # BASELINE.json configs[1]: 128x128 RGB patches
+    gflop_per_unit = 2 * 3 * GMAC_UNET / 4
+
+    def build(self, dev, rank):
+        from neural_imaging_amd.models import pipelines
+        self.nip = pipelines.UNet(patch_size=self.raw_patch, device=dev)
+        raw, rgb = synthetic_batch(self.batch, self.raw_patch, seed=1234 + rank)
+        self.bx, self.by = torch.from_numpy(raw).to(dev), torch.from_numpy(rgb).to(dev)
+        self.graph = False
+        self.eager = lambda: self.nip.training_step(self.bx, self.by, learning_rate=1e-4)
+        return self.eager
+
+    def dominant(self, dev):
+        return time_unet_dominant(dev, self.batch, self.raw_patch)
+
+
+def c2_psnr_parity(dev, batch, steps=400, lr=3e-4):
+    """PSNR parity of the two compute modes on config 2 (BASELINE.json configs[1]: 'demosaic conv HIP kernels vs ... PSNR'): one
+    UNet initialisation trained `steps` NIPModel.training_step()s on the same batches of synthetic scenes in each mode, then the
+    held-out PSNR of each result in its own mode (models/pipelines.py:77-90; training/pipeline.py:191-247)."""
+    import train_parity as tp
+    from neural_imaging_amd import ops
+    from neural_imaging_amd.models import pipelines
+    rp = TrainNIP.raw_patch
+    pool = tp.make_pool(512, rp, 7100, dev)
+    held = tp.make_pool(256, rp, 9100, dev)
+    out = {}
+    for mode in ('bf16', 'f32'):
+        ops.set_compute(mode)
+        nip = pipelines.UNet(patch_size=rp, device=dev)
+        rng = np.random.RandomState(21)
+        for _ in range(steps):
+            idx = torch.from_numpy(rng.choice(pool[0].shape[0], batch, replace=False)).to(dev)
+            nip.training_step(pool[0][idx], pool[1][idx], learning_rate=lr)
+        mse = 0.0
+        for i in range(0, held[0].shape[0], 64):
+            y = nip.process(held[0][i:i + 64]).t.float()
+            mse += float(((y - held[1][i:i + 64]) ** 2).mean().item()) / (held[0].shape[0] // 64)
+        out[mode] = float(10 * np.log10(1.0 / mse))
+        del nip
+    return out
+
+
 def world_size():
     return int(os.environ.get('WORLD_SIZE', '1'))
 
 
-WORKLOADS = {w.key: w for w in (ChannelJPEG, TrainDCN, ChannelDCN)}
+WORKLOADS = {w.key: w for w in (ChannelJPEG, TrainNIP, TrainDCN, ChannelDCN)}
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -189,13 +238,30 @@ def _event_time(run, reps):
     return e0.elapsed_time(e1) / reps
 
 
-def _pmc_traffic(fname, key, n):
-    try:                                   # measured with rocprofv3 --pmc in separate passes, see profiles/README.md
-        with open(os.path.join(ROOT, 'profiles', fname)) as f:
+def _pmc_traffic(fname, key, n, stamped=False):
+    """HBM bytes per launch from a committed counter profile (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes, see
+    profiles/README.md), scaled to n images.  stamped: the file carries the hash of the kernel sources it was taken on
+    (tools/src_stamp.py) and is used only if that equals the sources of this run -> (bytes or None, source record)."""
+    path = os.path.join(ROOT, 'profiles', fname)
+    if stamped:
+        from src_stamp import load_if_current
+        data, src = load_if_current(path)
+        if data is None:
+            return None, src
+        try:
+            return data[key]['traffic_bytes_per_launch'] * n / data[key]['images'], src
+        except KeyError:
+            return None, dict(src, status='no entry ' + key)
+    try:
+        with open(path) as f:
             pmc = json.load(f)[key]
-        return pmc['traffic_bytes_per_launch'] * n / pmc['images']
+        return pmc['traffic_bytes_per_launch'] * n / pmc['images'], {'file': 'profiles/' + fname, 'status': 'unstamped'}
     except (OSError, KeyError, ValueError):
-        return None
+        return None, {'file': 'profiles/' + fname, 'status': 'missing'}
+
+
+PMC_RING = 'r04_pmc_ring_kernel.json'            # tools/pmc_ring.sh on the final build of the round
+PMC_STEP = 'r04_pmc_step_total.json'             # tools/pmc_step_total.py, same
 
 
 def time_conv5_dominant(dev, n, reps=20):
@@ -217,10 +283,10 @@ def time_conv5_dominant(dev, n, reps=20):
     flops = 2.0 * 25 * 64 * 128 * 64 * 64 * n
     kname = 'conv_fwd_kernel<5,1,16,16,1,64,8>' if ops.COMPUTE == 'f32' else (
         'conv5_ring_kernel<128>' if stored_bf16 else 'conv_fwd_bf16_kernel<5,1,16,16,1,64>')
-    traffic = _pmc_traffic('r02_pmc_ring_kernel.json', 'bf16_stored_input_pooled', n) if stored_bf16 else \
+    traffic, tsrc = _pmc_traffic(PMC_RING, 'bf16_stored_input_pooled', n, stamped=True) if stored_bf16 else \
         _pmc_traffic('r01_pmc_dominant_kernel.json', ops.COMPUTE, n)
     return {'kernel': kname + ' (FAN conv3 fwd{}, {}x64x64x64->128)'.format(' + LReLU + pool' if stored_bf16 else '', n),
-            'traffic': traffic, 'flops_per_launch': flops, 'ms_per_launch': ms, 'tflops': flops / (ms * 1e-3) / 1e12}
+            'traffic': traffic, 'traffic_source': tsrc, 'flops_per_launch': flops, 'ms_per_launch': ms, 'tflops': flops / (ms * 1e-3) / 1e12}
 
 
 def time_conv3_dominant(dev, n, reps=20):
@@ -233,9 +299,29 @@ def time_conv3_dominant(dev, n, reps=20):
     ms = _event_time(lambda: ops.conv2d(x, w, b, act='leaky_relu', out=out), reps)
     flops = 2.0 * 9 * 128 * 128 * 64 * 64 * n
     kname = 'conv_fwd_kernel<3,1,...>' if ops.COMPUTE == 'f32' else 'conv_fwd_bf16_kernel<3,1,16,16,1,64>'
-    traffic = _pmc_traffic('r02_pmc_dcn_kernel.json', ops.COMPUTE, n)
+    traffic, tsrc = _pmc_traffic('r02_pmc_dcn_kernel.json', ops.COMPUTE, n)
     return {'kernel': kname + ' (TwitterDCN residual conv fwd, {}x64x64x128->128)'.format(n), 'traffic': traffic,
+            'traffic_source': tsrc,
             'flops_per_launch': flops, 'ms_per_launch': ms, 'tflops': flops / (ms * 1e-3) / 1e12}
+
+
+def time_unet_dominant(dev, n, raw_patch, reps=20):
+    """UNet dc41 (3x3, concat(32 + 32) -> 32 at the RAW resolution: 302 of the 3079 MMAC per patch, the largest layer of the
+    ISP), as the model runs it in throughput mode: two bf16-stored inputs, bf16 output."""
+    from neural_imaging_amd import ops
+    h = raw_patch
+    stored_bf16 = ops.COMPUTE == 'bf16' and ops.STORE_BF16
+    a, b2 = torch.randn((n, h, h, 32), device=dev), torch.randn((n, h, h, 32), device=dev)
+    if stored_bf16:
+        a, b2 = a.to(torch.bfloat16), b2.to(torch.bfloat16)
+    w = torch.randn((3, 3, 64, 32), device=dev) * 0.05
+    b = torch.zeros((32,), device=dev)
+    ms = _event_time(lambda: ops.conv2d(a, w, b, act='leaky_relu', x2=b2, out_bf16=stored_bf16), reps)
+    flops = 2.0 * 9 * 64 * 32 * h * h * n
+    return {'kernel': 'conv_fwd_{}kernel<3,1,16,16,1,32> (UNet dc41 fwd, {}x{}x{}x(32+32)->32)'.format(
+                'bf16_' if ops.COMPUTE == 'bf16' else '', n, h, h),
+            'traffic': None, 'traffic_source': None, 'flops_per_launch': flops, 'ms_per_launch': ms,
+            'tflops': flops / (ms * 1e-3) / 1e12}
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -272,6 +358,24 @@ def cpu_baseline_worker(workload, raw_patch, budget_s):
         x = torch.from_numpy(natural_images(b, 2 * raw_patch, 2 * raw_patch, seed=99))
         trainer = onets.DCNTrainer(dcn)
         step = lambda: trainer.training_step(x, learning_rate=1e-4)
+    elif workload == 'c2':                  # NIPModel.training_step restated: tape over mse255(UNet(x), y), Keras Adam
+        from oracle import tfops as T
+        b = 8
+        p = onets.unet_init(1234, dtype=torch.float32)
+        ps = list(p.values())
+        raw, rgb = synthetic_batch(b, raw_patch, seed=99)
+        bx, by = torch.from_numpy(raw), torch.from_numpy(rgb)
+        state = {'t': 0, 'm': [torch.zeros_like(q) for q in ps], 'v': [torch.zeros_like(q) for q in ps]}
+
+        def step():
+            for q in ps:
+                q.requires_grad_(True)
+            grads = torch.autograd.grad(T.mse255(onets.unet_forward(p, bx), by), ps)
+            for q in ps:
+                q.requires_grad_(False)
+            state['t'] += 1
+            with torch.no_grad():
+                T.adam_step(ps, list(grads), state['m'], state['v'], state['t'], 1e-4)
     else:
         kw = dict(lambda_nip=0.1, learning_rate=1e-4)
         if workload == 'c5':
@@ -325,6 +429,37 @@ def self_launch(args):
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     env.setdefault('OMP_NUM_THREADS', '4')
     return subprocess.call(cmd, env=env)
+
+
+def dp1_nccl_leg(wl, n=20):
+    """Eager C4 steps with the data-parallel path live on ONE rank: `nccl` (= RCCL) process group of world size 1,
+    parallel.force_collectives() -> the FAN / UNet-decoder / UNet-encoder gradient buckets are launched as asynchronous
+    all-reduces while the backward pass continues, the NaN flag is MAX-reduced, Adam waits for the buckets.  Reported next to
+    the plain eager step timed the same way in the same process."""
+    from neural_imaging_amd import parallel
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t, c = time.perf_counter(), time.thread_time()
+        for _ in range(n):
+            fn()
+        host = 1e3 * (time.thread_time() - c) / n
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t) / n, host
+    plain_ms, plain_host = timed(wl.eager)
+    parallel.force_collectives(True)
+    try:
+        parallel.init_from_env('nccl')
+        assert parallel.is_distributed() and torch.distributed.get_backend() == 'nccl'
+        dp_ms, dp_host = timed(wl.eager)
+        wl.wf.check_nan()
+    finally:
+        parallel.force_collectives(False)
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+    return {'dp1_nccl_ms_per_step': dp_ms, 'dp1_nccl_host_cpu_ms_per_step': dp_host,
+            'dp1_plain_eager_ms_per_step': plain_ms, 'dp1_plain_eager_host_cpu_ms_per_step': plain_host}
 
 
 def trained_parity(wl, dev, pre, joint, tail):
@@ -413,7 +548,8 @@ def main():
     ap.add_argument('--parity-steps', type=int, default=600,
                     help='joint training steps of the trained-parity leg (0 = skip); the NIP is pre-trained for 2.5 x as many '
                          'steps first and each mode trains a quarter as many more from the checkpoint')
-    ap.add_argument('--no-side-workloads', action='store_true', help='skip the short c3 / c5 runs of the default c4 line')
+    ap.add_argument('--no-side-workloads', action='store_true', help='skip the short c2 / c3 / c5 runs of the default c4 line')
+    ap.add_argument('--no-dp1-nccl', action='store_true', help='skip the one-rank RCCL leg (dp1_nccl_*) of the default c4 line')
     ap.add_argument('--no-graph', dest='graph', action='store_false',
                     help='launch every kernel of the timed steps eagerly (default at N = 1: the step is ALSO captured into a HIP '
                          'graph - same kernels, same order, one launch call per step - and whichever of the two launch paths '
@@ -450,6 +586,8 @@ def main():
         raise SystemExit('--gpus {} but the process group has {} rank(s)'.format(args.gpus, world))
 
     wl = WORKLOADS[args.workload](args)
+    if getattr(wl, 'raw_patch', None):        # config 2 fixes its own patch size (128x128 RGB)
+        args.raw_patch = wl.raw_patch
     step = wl.build(dev, rank)
 
     def barrier():
@@ -535,21 +673,23 @@ def main():
             if args.dtype == 'bf16' and wl.key == 'c4':
                 # counter-based: HBM bytes of one step summed over ALL its dispatches (profiles/r03_pmc_step_total.json, made by
                 # tools/pmc_step_total.py from separate FETCH_SIZE / WRITE_SIZE passes at B = 64) x this run's step rate
-                try:
-                    with open(os.path.join(ROOT, 'profiles', 'r03_pmc_step_total.json')) as f:
-                        cfg['hbm_frac_whole_step_measured'] = value / world * json.load(f)['bytes_per_raw_patch'] / 8e12
-                except (OSError, KeyError, ValueError):
-                    cfg['hbm_frac_whole_step_measured'] = None
+                from src_stamp import load_if_current
+                data, src = load_if_current(os.path.join(ROOT, 'profiles', PMC_STEP))
+                cfg['hbm_frac_whole_step_measured'] = None if data is None else \
+                    value / world * data['bytes_per_raw_patch'] / 8e12
+                cfg['hbm_bytes_per_raw_patch_measured'] = None if data is None else data['bytes_per_raw_patch']
+                cfg['hbm_whole_step_source'] = src
         line = {
-            'metric': 'patches/s (fwd+bwd) ISP->JPEG->FAN @256^2' if wl.key == 'c4' else
-                      ('patches/s (fwd+bwd) TwitterDCN-32C @256^2' if wl.key == 'c3' else
-                       'patches/s (fwd+bwd) ISP->TwitterDCN->FAN @256^2'),
+            'metric': {'c4': 'patches/s (fwd+bwd) ISP->JPEG->FAN @256^2', 'c3': 'patches/s (fwd+bwd) TwitterDCN-32C @256^2',
+                       'c2': 'patches/s (fwd+bwd) UNet ISP RAW 64^2 -> RGB 128^2',
+                       'c5': 'patches/s (fwd+bwd) ISP->TwitterDCN->FAN @256^2'}[wl.key],
             'value': value, 'unit': 'patches/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
             'data': 'synthetic (natural-image-like RAW/RGB pairs, random-init weights)', 'config': cfg,
             'roofline': {'bound': 'mfma', 'achieved': dom['tflops'], 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': dom['tflops'] / peak, 'traffic': dom['traffic'], 'kernel': dom['kernel'],
-                         'ms_per_launch': dom['ms_per_launch'], 'flops_per_launch': dom['flops_per_launch']},
+                         'ms_per_launch': dom['ms_per_launch'], 'flops_per_launch': dom['flops_per_launch'],
+                         'traffic_source': dom.get('traffic_source')},
         }
         if world == 1 and args.dtype == 'bf16' and not args.no_parity_mode and wl.key in ('c4', 'c5'):
             _ops.set_compute('f32')                           # same step, exact float32 MFMA (the parity-test mode), eager
@@ -589,8 +729,8 @@ def main():
                 cfg['mode_parity_after_training'] = par
                 _ops.set_compute(args.dtype)
         if world == 1 and args.dtype == 'bf16' and wl.key == 'c4' and not args.no_parity_mode and not args.no_side_workloads:
-            # configs 3 and 5 of BASELINE.json on the same line (flat scalars: the driver's parser keeps those): 30 timed steps each
-            for key in ('c3', 'c5'):
+            # configs 2, 3 and 5 of BASELINE.json on the same line (flat scalars: the driver's parser keeps those): 30 timed steps each
+            for key in ('c2', 'c3', 'c5'):
                 try:
                     a2 = argparse.Namespace(**dict(vars(args), workload=key, batch=0))
                     w2 = WORKLOADS[key](a2)
@@ -608,9 +748,24 @@ def main():
                     line[key + '_ms_per_step'] = 1e3 * dt2
                     line[key + '_tflops'] = w2.batch / dt2 * w2.gflop_per_unit / 1e3
                     line[key + '_frac_of_mfma_peak'] = line[key + '_tflops'] / BF16_MFMA_PEAK_TFLOPS       # whole step, dense bf16 peak
+                    if key == 'c2':
+                        line['c2_dominant_kernel_frac_of_mfma_peak'] = w2.dominant(dev)['tflops'] / BF16_MFMA_PEAK_TFLOPS
                     del w2, step2
                 except Exception as e:                       # a side figure must never take the headline line down
                     line[key + '_error'] = repr(e)[:200]
+            try:                                             # config 2's "vs ... PSNR": both modes trained from one initialisation
+                psnr = c2_psnr_parity(dev, TrainNIP.default_batch)
+                line['c2_psnr_db_bf16'], line['c2_psnr_db_f32'] = psnr['bf16'], psnr['f32']
+            except Exception as e:
+                line['c2_psnr_error'] = repr(e)[:200]
+            _ops.set_compute(args.dtype)
+        if world == 1 and args.dtype == 'bf16' and wl.key == 'c4' and not args.no_dp1_nccl and not args.no_parity_mode:
+            # the data-parallel step through RCCL on this one GPU: a one-rank nccl group with the collectives
+            # forced - gradient buckets, NaN-flag reduction - next to the plain eager step of the same process
+            try:
+                line.update(dp1_nccl_leg(wl))
+            except Exception as e:
+                line['dp1_nccl_error'] = repr(e)[:200]
         if not args.no_cpu_baseline and world == 1:
             line['cpu_baseline'] = cpu_baseline(wl.key, args.raw_patch)
         print(json.dumps(line))

@@ -14,16 +14,18 @@ def jpeg_qtable(quality, channel=0):
 
 
 def zigzag(n):
-    """Zig-zag scan index matrix (jpeg_helpers.py:253-261)."""
-    def compare(xy):
-        x, y = xy
-        return (x + y, -y if (x + y) % 2 else y)
-    zz = np.zeros((n, n), dtype=np.uint16)
-    for i, (x, y) in enumerate(sorted(((x, y) for x in range(n) for y in range(n)), key=compare)):
-        zz[x, y] = i
-    return zz
+    """Zig-zag scan index matrix (jpeg_helpers.py:253-261): entry [r, c] = position of coefficient (r, c) in the scan.  The
+    scan walks the anti-diagonals d = r + c in order; odd diagonals run top-right -> bottom-left (r ascending), even ones the
+    other way."""
+    r, c = np.divmod(np.arange(n * n), n)
+    d = r + c
+    order = np.lexsort((np.where(d % 2 == 1, r, -r), d))          # primary key d, secondary the walking direction
+    zz = np.empty(n * n, dtype=np.uint16)
+    zz[order] = np.arange(n * n, dtype=np.uint16)
+    return zz.reshape(n, n)
 
 
 def jpeg_qf_estimation(q_mtx, channel=0):
-    errors = [np.mean(np.abs(jpeg_qtable(qf, channel) - q_mtx)) for qf in range(1, 101)]
-    return int(np.argmin(errors) + 1)
+    """The IJG quality 1..100 whose table of `channel` is closest (mean absolute difference) to q_mtx; ties -> the lowest."""
+    tables = np.stack([jpeg_qtable(qf, channel) for qf in range(1, 101)]).astype(np.float64)
+    return 1 + int(np.abs(tables - np.asarray(q_mtx, dtype=np.float64)).mean(axis=(1, 2)).argmin())

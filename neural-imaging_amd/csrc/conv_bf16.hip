@@ -772,7 +772,10 @@ int launch_conv_b(const ConvParamsB& p, hipStream_t stream) {
             if constexpr (KS == 5 && TH == 16 && TW == 16 && NB == 1 && TN == 64) {
                 static const bool no_ring = getenv("NIMG_NO_CONV5_RING") != nullptr;
                 static const bool no_ring64 = getenv("NIMG_NO_CONV5_RING64") != nullptr;
-                if (!no_ring && p.O2 == 0 && p.pad_t == 2 && p.pad_l == 2 && p.Hout == p.H && p.Wout == p.W) {
+                // the ring kernels' epilogue knows bias / activation / mask / pooling only: a second bf16 copy (out1b), a
+                // residual or a layout flag stays with the generic kernel, whose epilogue writes them
+                const bool plain_epi = !p.res && !p.out1b && !(p.flags & (NIMG_D2S_OUT | NIMG_S2D_OUT | NIMG_COPY_LRELU));
+                if (!no_ring && plain_epi && p.O2 == 0 && p.pad_t == 2 && p.pad_l == 2 && p.Hout == p.H && p.Wout == p.W) {
                     if (Cout % 128 == 0) return launch_conv5_ring<128>(p, stream);
                     if (!no_ring64 && p.Hout >= 32) return launch_conv5_ring<64>(p, stream);
                 }
@@ -825,7 +828,7 @@ int dispatch_b_t(const ConvParamsB& p, hipStream_t s) {
             static const bool no_ring32 = getenv("NIMG_NO_CONV5_RING32") != nullptr || getenv("NIMG_NO_CONV5_RING") != nullptr ||
                                           getenv("NIMG_NO_BUFFER_LOADS") != nullptr;
             const long in_bytes = ((long)p.N * p.H * p.W * p.C1 * 2) >> (p.in_idx ? 2 : 0);
-            if (!no_ring32 && Cout == 32 && p.O2 == 0 && p.C2 == 0 && p.C1 % 16 == 0 && !p.convt && p.pad_t == 2 && p.pad_l == 2 &&
+            if (!no_ring32 && !p.res && !p.out1b && !(p.flags & NIMG_COPY_LRELU) && Cout == 32 && p.O2 == 0 && p.C2 == 0 && p.C1 % 16 == 0 && !p.convt && p.pad_t == 2 && p.pad_l == 2 &&
                 p.Hout == p.H && p.Wout == p.W && p.Hout >= 32 && in_bytes < (1l << 31) - 65536)
                 return launch_conv5_ring<32>(p, s);
         }

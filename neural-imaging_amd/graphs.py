@@ -13,7 +13,8 @@ outside it (ops.Workspace scratch, cached filter tables) are pinned by the Captu
 eager calls that follow - validation at another shape, a second captured step - can re-grow or evict them safely.
 
 Restrictions: fixed batch shape and hyper-parameters (lambda_*, manipulation strengths: augment=False), single process (the
-RCCL bucket launches are not captured), nan_check='deferred'.
+RCCL bucket launches are not captured), nan_check='deferred'.  The private generators of an 'awgn' manipulation and of the FAN's
+dropout are registered with the graph (their offsets advance per replay); injected noise / masks cannot be captured.
 """
 import torch
 
@@ -23,7 +24,7 @@ from . import ops, parallel
 class CapturedStep(object):
 
     def __init__(self, flow, batch_x, batch_y, learning_rate=1e-4, warmup=3, **kw):
-        if parallel.world_size() > 1:
+        if parallel.is_distributed():
             raise RuntimeError('CapturedStep: the data-parallel step is not captured (RCCL launches stay eager)')
         if flow._nan_check != 'deferred' or kw.get('augment'):
             raise ValueError('CapturedStep needs nan_check="deferred" and augment=False (no host decisions inside a step)')
@@ -44,6 +45,12 @@ class CapturedStep(object):
         self.t = flow._step
         flow._lr_t_dev = self._rate_dev
         self.graph = torch.cuda.CUDAGraph()
+        # private random streams (awgn noise: helpers/tf_helpers.Awgn._gen; dropout masks: FAN._dropout_gen) were created by the
+        # warm-up steps; a capture may only draw from generators whose state the graph owns
+        for gen in [getattr(op, '_gen', None) for op in getattr(flow, '_operations', {}).values()] + \
+                [getattr(getattr(flow, 'fan', None), '_dropout_gen', None)]:
+            if isinstance(gen, torch.Generator):
+                self.graph.register_generator_state(gen)
         try:
             self._set_rate(self.t + 1)
             with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):

@@ -22,70 +22,81 @@ from . import loading
 from .loading import sample_patch
 
 
+_SEARCH_ROOTS = ('data/raw/training_data', 'data/rgb')            # where a bare data-set name is looked up (dataset.py:60-70)
+_FULL_SCALE = {'x': float(2 ** 16 - 1), 'y': float(2 ** 8 - 1)}    # uint16 RAW stacks, uint8 RGB
+_KINDS = {'xy': 'raw+rgb', 'y': 'rgb', 'x': 'raw'}
+
+
+def _find_directory(name):
+    """A path is taken as it is; a bare name is searched under the repository's data roots.  ValueError if nothing is there."""
+    if os.path.isdir(name):
+        return name
+    if not any(sep in name for sep in '/\\'):
+        for root in _SEARCH_ROOTS:
+            if os.path.isdir(os.path.join(root, name)):
+                return os.path.join(root, name)
+    raise ValueError('Cannot find the data directory: {}'.format(name))
+
+
+def _unit_range(kind, a):
+    """Integer samples -> float32 in [0, 1]: the float64 quotient rounded once (bit-exact with the reference's numpy)."""
+    return (a.astype(np.float64) / _FULL_SCALE[kind]).astype(np.float32)
+
+
 class Dataset(object):
+    """Host-side training data with the reference's interface (helpers/dataset.py:50-189): `data[split][kind]` holds the
+    full-resolution training images and the pre-cut validation patches, kind 'x' = RAW (n, H/2, W/2, 4) uint16, 'y' = RGB
+    (n, H, W, 3) uint8.  The container is filled either from a directory (loading.discover_images / load_images /
+    load_patches) or from arrays; everything else works on the arrays alone."""
+
+    # the label summary() / repr() print for the validation patches: the reference reports this one whatever policy the caller
+    # asked for (dataset.py:57), and scripts parse the summary line
+    VAL_DISCARD_LABEL = 'flat-aggressive'
 
     def __init__(self, data_directory, *, randomize=2468, load='xy', n_images=120, v_images=30, val_rgb_patch_size=128,
                  val_n_patches=1, val_discard='flat-aggressive'):
-        if not any(load == allowed for allowed in ['xy', 'x', 'y']):
+        if load not in _KINDS:
             raise ValueError('Invalid X/Y data requested!')
-        if not os.path.isdir(data_directory):
-            if '/' in data_directory or '\\' in data_directory:
-                raise ValueError('Cannot find the data directory: {}'.format(data_directory))
-            if os.path.isdir(os.path.join('data/raw/training_data/', data_directory)):
-                data_directory = os.path.join('data/raw/training_data/', data_directory)
-            elif os.path.isdir(os.path.join('data/rgb/', data_directory)):
-                data_directory = os.path.join('data/rgb/', data_directory)
-            else:
-                raise ValueError('Cannot find the data directory: {}'.format(data_directory))
-        self.files = {}
-        self._loaded_data = load
-        self._data_directory = data_directory
-        self._counts = (n_images, v_images, val_n_patches)
-        self._val_discard = 'flat-aggressive'           # sic: the reference reports this label whatever was asked for
-        self.files['training'], self.files['validation'] = loading.discover_images(
-            data_directory, randomize=randomize, n_images=n_images, v_images=v_images)
-        self.data = {
-            'training': loading.load_images(self.files['training'], data_directory, load=load),
-            'validation': loading.load_patches(self.files['validation'], data_directory,
-                                               patch_size=val_rgb_patch_size // 2, n_patches=val_n_patches, load=load,
-                                               discard=val_discard),
-        }
-        self._set_resolution()
+        root = _find_directory(data_directory)
+        train_files, val_files = loading.discover_images(root, randomize=randomize, n_images=n_images, v_images=v_images)
+        self._fill(root, load, {'training': train_files, 'validation': val_files},
+                   loading.load_images(train_files, root, load=load),
+                   loading.load_patches(val_files, root, patch_size=val_rgb_patch_size // 2, n_patches=val_n_patches,
+                                        load=load, discard=val_discard),
+                   (n_images, v_images, val_n_patches))
 
     @classmethod
     def from_arrays(cls, training, validation, load=None, name='arrays'):
         """training: {'x': (n, H/2, W/2, 4) uint16, 'y': (n, H, W, 3) uint8} full-resolution images, validation: the same
         keys holding patches - what the directory loader would have produced."""
-        self = cls.__new__(cls)
         load = load or ''.join(k for k in 'xy' if k in training)
-        if load not in ('xy', 'x', 'y'):
+        if load not in _KINDS:
             raise ValueError('Invalid X/Y data requested!')
         for split in (training, validation):
             for k in load:
                 want = np.uint16 if k == 'x' else np.uint8
                 if split[k].dtype != want or split[k].ndim != 4:
                     raise ValueError('{} data must be a 4-D {} array'.format('RAW' if k == 'x' else 'RGB', want.__name__))
-        n = len(training[load[0]])
-        self.files = {'training': ['{:04d}'.format(i) for i in range(n)],
-                      'validation': ['{:04d}'.format(i) for i in range(len(validation[load[0]]))]}
-        self._loaded_data, self._data_directory = load, name
-        self._counts = (n, len(validation[load[0]]), 1)
-        self._val_discard = 'flat-aggressive'
-        self.data = {'training': {k: training[k] for k in load}, 'validation': {k: validation[k] for k in load}}
-        self._set_resolution()
+        n, v = len(training[load[0]]), len(validation[load[0]])
+        self = cls.__new__(cls)
+        self._fill(name, load, {'training': ['{:04d}'.format(i) for i in range(n)],
+                                'validation': ['{:04d}'.format(i) for i in range(v)]},
+                   {k: training[k] for k in load}, {k: validation[k] for k in load}, (n, v, 1))
         return self
 
-    def _set_resolution(self):
-        if 'y' in self.data['training']:
-            self.H, self.W = self.data['training']['y'].shape[1:3]
-        else:
-            self.H, self.W = (2 * dim for dim in self.data['training']['x'].shape[1:3])
+    def _fill(self, name, load, files, training, validation, counts):
+        self._data_directory, self._loaded_data, self.files, self._counts = name, load, files, counts
+        self._val_discard = self.VAL_DISCARD_LABEL
+        self.data = {'training': training, 'validation': validation}
+        t = training
+        self.H, self.W = t['y'].shape[1:3] if 'y' in t else tuple(2 * d for d in t['x'].shape[1:3])
 
     def __getitem__(self, key):
-        if key in ['training', 'validation']:
-            return self.data[key]
-        raise KeyError('Key: {} not found!'.format(key))
+        if key not in self.data:
+            raise KeyError('Key: {} not found!'.format(key))
+        return self.data[key]
 
+    # ---- batches -------------------------------------------------------------------------------------------------------
     def _check_batch(self, batch_id, batch_size, discard):
         if discard is not None and 'y' not in self.data['training']:
             raise ValueError('Cannot discard patches if RGB data is not loaded.')
@@ -95,78 +106,31 @@ class Dataset(object):
     def _pack(self, x, y):
         return (x, y) if self._loaded_data == 'xy' else (y if self._loaded_data == 'y' else x)
 
+    def _crop(self, split, kind, ids, corners, rgb_patch_size):
+        """float32 patches of `kind` for images `ids` at RGB corners (xx, yy); RAW patches sit at half the coordinates."""
+        if kind not in self._loaded_data:
+            return None
+        side, div = (rgb_patch_size, 1) if kind == 'y' else (rgb_patch_size // 2, 2)
+        src = self.data[split][kind]
+        cut = [src[i, yy // div:yy // div + side, xx // div:xx // div + side] for i, (xx, yy) in zip(ids, corners)]
+        return _unit_range(kind, np.stack(cut))
+
     def next_training_batch(self, batch_id, batch_size, rgb_patch_size, discard='flat', max_attempts=25):
-        """One random patch of each of the batch's images (dataset.py:89-131) -> (RAW, RGB) float32 arrays in [0, 1]."""
+        """One random patch of each of the batch's images (dataset.py:89-131) -> (RAW, RGB) float32 arrays in [0, 1].  The
+        corners come from loading.sample_patch, image by image in batch order (that fixes the numpy RNG stream the golden
+        vectors replay); without RGB data the policy sees a black image, i.e. only discard=None is possible."""
         self._check_batch(batch_id, batch_size, discard)
-        ps = rgb_patch_size // 2
-        x = np.zeros((batch_size, ps, ps, 4), dtype=np.float32) if 'x' in self._loaded_data else None
-        y = np.zeros((batch_size, rgb_patch_size, rgb_patch_size, 3), dtype=np.float32) if 'y' in self._loaded_data else None
-        for b in range(batch_size):
-            bid = batch_id * batch_size + b
-            current_rgb = self.data['training']['y'][bid] if 'y' in self._loaded_data else \
-                np.zeros((self.H, self.W, 3), np.uint8)
-            xx, yy = sample_patch(current_rgb, rgb_patch_size, discard, max_attempts)
-            rx, ry = xx // 2, yy // 2
-            if x is not None:
-                x[b] = self.data['training']['x'][bid][ry:ry + ps, rx:rx + ps].astype(np.float64) / (2 ** 16 - 1)
-            if y is not None:
-                y[b] = current_rgb[yy:yy + rgb_patch_size, xx:xx + rgb_patch_size].astype(np.float64) / (2 ** 8 - 1)
-        return self._pack(x, y)
+        ids = range(batch_id * batch_size, (batch_id + 1) * batch_size)
+        rgb = self.data['training'].get('y')
+        blank = None if rgb is not None else np.zeros((self.H, self.W, 3), np.uint8)
+        corners = [sample_patch(rgb[i] if rgb is not None else blank, rgb_patch_size, discard, max_attempts) for i in ids]
+        return self._pack(self._crop('training', 'x', ids, corners, rgb_patch_size),
+                          self._crop('training', 'y', ids, corners, rgb_patch_size))
 
     def next_validation_batch(self, batch_id, batch_size):
         sl = slice(batch_id * batch_size, (batch_id + 1) * batch_size)
-        x = (self.data['validation']['x'][sl].astype(np.float64) / (2 ** 16 - 1)).astype(np.float32) \
-            if 'x' in self._loaded_data else None
-        y = (self.data['validation']['y'][sl].astype(np.float64) / (2 ** 8 - 1)).astype(np.float32) \
-            if 'y' in self._loaded_data else None
-        return self._pack(x, y)
-
-    def is_raw_and_rgb(self):
-        return len(self._loaded_data) == 2
-
-    @property
-    def rgb_patch_size(self):
-        if 'y' in self._loaded_data:
-            return self.data['validation']['y'].shape[1]
-        return 2 * self.data['validation']['x'].shape[1]
-
-    @property
-    def count_training(self):
-        return self.data['training'][self._loaded_data[0]].shape[0]
-
-    @property
-    def count_validation(self):
-        return self.data['validation'][self._loaded_data[0]].shape[0]
-
-    @property
-    def loaded_data(self):
-        return {'xy': 'raw+rgb', 'y': 'rgb', 'x': 'raw'}[self._loaded_data]
-
-    def shapes(self):
-        stats = {'path': self._data_directory}
-        for k in self._loaded_data:
-            stats['training/{}'.format(k)] = self.data['training'][k].shape
-            stats['validation/{}'.format(k)] = self.data['validation'][k].shape
-        return stats
-
-    def __repr__(self):
-        return 'Dataset("{}", load="{}", n_images={}, v_images={}, val_rgb_patch_size={}, discard="{}")'.format(
-            self._data_directory, self._loaded_data, self._counts[0], self._counts[1], self.rgb_patch_size,
-            self._val_discard)
-
-    def summary(self):
-        valid_label = '' if self._val_discard is None else ', {}'.format(self._val_discard)
-        return 'Dataset[{},{}] : {} train. images + {} valid. patches ({} px{})'.format(
-            os.path.split(self._data_directory)[-1], self.loaded_data, self.count_training, self.count_validation,
-            self.rgb_patch_size, valid_label)
-
-    def details(self):
-        label = [self.summary()]
-        for k, l in zip('xy', ['RAW', 'RGB']):
-            if k in self._loaded_data:
-                label.append('{} -> training {} + validation {}'.format(l, self.data['training'][k].shape,
-                                                                        self.data['validation'][k].shape))
-        return '\n'.join(label)
+        part = {k: _unit_range(k, self.data['validation'][k][sl]) for k in self._loaded_data}
+        return self._pack(part.get('x'), part.get('y'))
 
     def get_training_generator(self, batch_size, rgb_patch_size, discard='flat'):
         for batch_id in range(self.count_training // batch_size):
@@ -175,6 +139,50 @@ class Dataset(object):
     def get_validation_generator(self, batch_size):
         for batch_id in range(self.count_validation // batch_size):
             yield self.next_validation_batch(batch_id, batch_size)
+
+    # ---- descriptions ----------------------------------------------------------------------------------------------------
+    def is_raw_and_rgb(self):
+        return self._loaded_data == 'xy'
+
+    @property
+    def rgb_patch_size(self):
+        v = self.data['validation']
+        return v['y'].shape[1] if 'y' in v else 2 * v['x'].shape[1]
+
+    @property
+    def count_training(self):
+        return len(self.data['training'][self._loaded_data[0]])
+
+    @property
+    def count_validation(self):
+        return len(self.data['validation'][self._loaded_data[0]])
+
+    @property
+    def loaded_data(self):
+        return _KINDS[self._loaded_data]
+
+    def shapes(self):
+        out = {'path': self._data_directory}
+        for k in self._loaded_data:
+            for split in ('training', 'validation'):
+                out['{}/{}'.format(split, k)] = self.data[split][k].shape
+        return out
+
+    def __repr__(self):
+        return 'Dataset("{}", load="{}", n_images={}, v_images={}, val_rgb_patch_size={}, discard="{}")'.format(
+            self._data_directory, self._loaded_data, self._counts[0], self._counts[1], self.rgb_patch_size,
+            self._val_discard)
+
+    def summary(self):
+        return 'Dataset[{},{}] : {} train. images + {} valid. patches ({} px{})'.format(
+            os.path.basename(self._data_directory), self.loaded_data, self.count_training, self.count_validation,
+            self.rgb_patch_size, ', {}'.format(self._val_discard) if self._val_discard is not None else '')
+
+    def details(self):
+        lines = [self.summary()]
+        lines += ['{} -> training {} + validation {}'.format({'x': 'RAW', 'y': 'RGB'}[k], self.data['training'][k].shape,
+                                                             self.data['validation'][k].shape) for k in self._loaded_data]
+        return '\n'.join(lines)
 
 
 class DeviceDataset(object):

@@ -18,19 +18,21 @@ def listdir(path, regex='.*\\..*'):
 
 
 def discover_images(data_directory, n_images=120, v_images=30, extension='png', randomize=0):
-    """Training / validation split of the directory listing (loading.py:14-44): sorted names, shuffled by the numpy
-    global RNG seeded with `randomize` when it is non-zero; (0, -1) / (-1, 0) take every file for one side."""
-    files = listdir(data_directory, '.*\\.{}$'.format(extension))
+    """-> (training names, validation names): the first n_images and the next v_images of the directory's *.<extension>
+    listing (loading.py:14-44).  The listing is sorted; a non-zero `randomize` seeds numpy's GLOBAL generator and shuffles it
+    (the split is reproducible, and the patch sampler continues on that stream).  -1 for one side with 0 for the other means
+    "every file"."""
+    names = listdir(data_directory, '.*\\.{}$'.format(extension))
     if randomize:
         np.random.seed(randomize)
-        np.random.shuffle(files)
-    if n_images == 0 and v_images == -1:
-        v_images = len(files)
-    if n_images == -1 and v_images == 0:
-        n_images = len(files)
-    if len(files) < n_images + v_images:
+        np.random.shuffle(names)
+    if (n_images, v_images) == (0, -1):
+        v_images = len(names)
+    elif (n_images, v_images) == (-1, 0):
+        n_images = len(names)
+    if n_images + v_images > len(names):
         raise ValueError('Not enough images!')
-    return files[0:n_images], files[n_images:(n_images + v_images)]
+    return names[:n_images], names[n_images:n_images + v_images]
 
 
 def _read_rgb(path):
@@ -39,48 +41,46 @@ def _read_rgb(path):
         return np.asarray(im.convert('RGB'), dtype=np.uint8)
 
 
+def _read_pair(data_directory, name, extension, load):
+    """(RAW stack or None, RGB image or None) of one file name."""
+    stem = name[:-len(extension) - 1]
+    raw = np.load(os.path.join(data_directory, stem + '.npy')) if 'x' in load else None
+    rgb = _read_rgb(os.path.join(data_directory, name)) if 'y' in load else None
+    return raw, rgb
+
+
 def load_images(files, data_directory, extension='png', load='xy'):
-    """Full-resolution (raw, rgb) pairs -> {'x': (n, H/2, W/2, 4) uint16, 'y': (n, H, W, 3) uint8} (loading.py:47-88)."""
-    n_images = len(files)
-    if n_images == 0:
-        return {k: np.zeros(shape=(1, 1, 1, 1)) for k in load}
-    first = _read_rgb(os.path.join(data_directory, files[0]))
-    res = (first.shape[0] >> 1, first.shape[1] >> 1)
-    data = {}
+    """Full-resolution (raw, rgb) pairs -> {'x': (n, H/2, W/2, 4) uint16, 'y': (n, H, W, 3) uint8} (loading.py:47-88); an
+    empty file list answers 1x1x1x1 zeros per kind, like the reference."""
+    if not files:
+        return {k: np.zeros((1, 1, 1, 1)) for k in load}
+    pairs = [_read_pair(data_directory, f, extension, load) for f in files]
+    out = {}
     if 'x' in load:
-        data['x'] = np.zeros((n_images, res[0], res[1], 4), dtype=np.uint16)
+        out['x'] = np.stack([p[0] for p in pairs]).astype(np.uint16, copy=False)
     if 'y' in load:
-        data['y'] = np.zeros((n_images, 2 * res[0], 2 * res[1], 3), dtype=np.uint8)
-    for i, file in enumerate(files):
-        if 'x' in data:
-            data['x'][i] = np.load(os.path.join(data_directory, file.replace('.{}'.format(extension), '.npy')))
-        if 'y' in data:
-            data['y'][i] = _read_rgb(os.path.join(data_directory, file))
-    return data
+        out['y'] = np.stack([p[1] for p in pairs])
+    return out
 
 
 def load_patches(files, data_directory, patch_size=128, n_patches=100, discard='flat-aggressive', extension='png',
                  load='xy'):
-    """n_patches random (raw, rgb) patches per image; patch_size counts RAW pixels (loading.py:91-129)."""
-    max_attempts = 100
-    data = {}
-    if 'x' in load:
-        data['x'] = np.zeros((len(files) * n_patches, patch_size, patch_size, 4), dtype=np.uint16)
-    if 'y' in load:
-        data['y'] = np.zeros((len(files) * n_patches, 2 * patch_size, 2 * patch_size, 3), dtype=np.uint8)
-    for i, file in enumerate(files):
-        image_x = np.load(os.path.join(data_directory, file.replace('.{}'.format(extension), '.npy'))) if 'x' in data \
-            else None
-        # the reference samples on the RGB image; without it ('x' only) the coordinates fall back to (0, 0) there too
-        image_y = _read_rgb(os.path.join(data_directory, file))
-        for b in range(n_patches):
-            xx, yy = sample_patch(image_y, 2 * patch_size, discard, max_attempts)
-            rx, ry = xx // 2, yy // 2
-            if 'x' in data:
-                data['x'][i * n_patches + b] = image_x[ry:ry + patch_size, rx:rx + patch_size, :]
-            if 'y' in data:
-                data['y'][i * n_patches + b] = image_y[yy:yy + 2 * patch_size, xx:xx + 2 * patch_size, :]
-    return data
+    """n_patches random (raw, rgb) patches per image; patch_size counts RAW pixels (loading.py:91-129).  The corners are
+    drawn on the RGB image (100 attempts per patch), which is therefore always read."""
+    rgb_side = 2 * patch_size
+    cut = {k: [] for k in load}
+    for name in files:
+        raw, _ = _read_pair(data_directory, name, extension, 'x' if 'x' in load else '')
+        rgb = _read_rgb(os.path.join(data_directory, name))
+        for _ in range(n_patches):
+            xx, yy = sample_patch(rgb, rgb_side, discard, 100)
+            if 'x' in cut:
+                cut['x'].append(raw[yy // 2:yy // 2 + patch_size, xx // 2:xx // 2 + patch_size])
+            if 'y' in cut:
+                cut['y'].append(rgb[yy:yy + rgb_side, xx:xx + rgb_side])
+    shapes = {'x': (0, patch_size, patch_size, 4), 'y': (0, rgb_side, rgb_side, 3)}
+    types = {'x': np.uint16, 'y': np.uint8}
+    return {k: (np.stack(v).astype(types[k], copy=False) if v else np.zeros(shapes[k], types[k])) for k, v in cut.items()}
 
 
 def sample_patch(rgb_image, rgb_patch_size=128, discard=None, max_attempts=25):

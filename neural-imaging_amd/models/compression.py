@@ -23,6 +23,10 @@ from .layers import Conv2D, Conv5x5Stride2Image
 from .tfmodel import ParamStore, TFModel
 
 
+# A/B switches, read once at import (not per call in the hot path)
+_NO_BF16_COPY = bool(os.environ.get('NIMG_NO_BF16_COPY'))
+_NO_S2D_CHAIN = bool(os.environ.get('NIMG_NO_S2D_CHAIN'))
+
 class _Shape(object):
     def __init__(self, shape):
         self.shape = tuple(shape)
@@ -234,13 +238,15 @@ class TwitterDCN(DCN):
         gradient of the block's second layer) would round it to on the way to the matrix core - so that all 3x3 work of the
         blocks reads bf16 operands through the bf16-input kernels (weight gradient: the all-taps kernel) while the skip sums
         read and write the exact float32 tensor."""
-        return ops.COMPUTE == 'bf16' and ops.STORE_BF16
+        # the A/B switches that send the strided layers / depth-to-space epilogues down the unfused float32-output paths
+        # (NIMG_NO_S2D_CONV, NIMG_NO_D2S_OUT) also switch the bf16 storage off: those paths hand back float32 tensors
+        return ops.COMPUTE == 'bf16' and ops.STORE_BF16 and ops.S2D_CONV and ops.D2S_EPILOGUE
 
     @staticmethod
     def _operand(t, tb):
         """The tensor a convolution / weight gradient reads: the bf16 copy of a residual-stream tensor where one exists
         (NIMG_NO_BF16_COPY=1 keeps the float32 tensor: the A/B switch of tools/r03_ah.sh)."""
-        return t if tb is None or os.environ.get('NIMG_NO_BF16_COPY') else tb
+        return t if tb is None or _NO_BF16_COPY else tb
 
     def encode(self, x, training=False):
         L, P = self._layers, self._model
@@ -249,7 +255,7 @@ class TwitterDCN(DCN):
         self._in_hw = (x.shape[1], x.shape[2])
         bf = self._bf16_inner()
         # throughput mode: e1's activation goes to HBM once, as the bf16 space-to-depth image e2 reads through the 3x3 kernels
-        chain = bf and not os.environ.get('NIMG_NO_S2D_CHAIN') and x.shape[1] % 4 == 0 and x.shape[2] % 4 == 0 and \
+        chain = bf and not _NO_S2D_CHAIN and x.shape[1] % 4 == 0 and x.shape[2] % 4 == 0 and \
             L['e1'].s2d_ok(x) and \
             L['e2'].s2d_chain_ok((x.shape[1] // 2, x.shape[2] // 2))
         chain_lat = chain and x.shape[1] % 8 == 0 and x.shape[2] % 8 == 0 and \
@@ -283,13 +289,13 @@ class TwitterDCN(DCN):
         t['zl'] = L['elat'].forward_s2d(P, t['n3s']) if chain_lat else L['elat'].forward(P, net)
         if self._lws is None or self._lws.buf.device != x.device:
             self._lws = ops.LatentWorkspace(self._codebook.numel(), x.device)
-        world = parallel.world_size()
+        world, dp = parallel.world_size(), parallel.is_distributed()
         count = t['zl'].numel()
         soft = self._h.rounding == 'soft-codebook'
         # (self._codebook is torch.arange(qmin, qmax + 1): consecutive integers - the unit_codebook promise of ops.latent_fwd)
         lat, ent = ops.latent_fwd(t['zl'], P.p['latent_scaling'], self._codebook, self._lws, soft_codebook=soft, unit_codebook=True,
-                                  count_global=count * world, finalize=(world == 1))
-        if world > 1:       # batch-global soft histogram: 2^bpf float64 sums are all-reduced (SURVEY 8e caveat 1)
+                                  count_global=count * world, finalize=not dp)
+        if dp:              # batch-global soft histogram: 2^bpf float64 sums are all-reduced (SURVEY 8e caveat 1)
             torch.distributed.all_reduce(self._lws.hist_sums())
             ops.latent_entropy_finalize(self._lws, count * world, ent)
         t['latent'] = lat

@@ -73,7 +73,7 @@ class DifferentiableJPEG(object):
         return self.params.flat.view(2, 8, 8)[[0, 1, 1]].contiguous()
 
     def __call__(self, x, quality=None):
-        q = self.trainable_tables() if (self.trainable and quality is None) else \
+        q = self.trainable_tables() if (self.trainable and (quality is None or quality == self.quality)) else \
             self.qtables(self.quality if quality is None else quality, x.device)
         y, _, _, xdq = ops.djpeg_fwd(x, q, self.rounding_approximation, want_mask=False, want_xdq=True)
         return y, xdq
@@ -120,11 +120,15 @@ class JPEG(TFModel):
     def forward(self, x, quality=None, training=False, out=None):
         if self._codec_model is None:
             raise NotImplementedError('the libjpeg codec is CPU validation tooling (out of scope, SURVEY 2 row 10)')
-        learned = self.trainable and quality is None        # an explicit quality swaps in that quality's tables (jpeg.py:235-243)
+        # the quality is resolved FIRST (an invalid / unspecified one raises even with trainable tables); the model's own tables -
+        # the learned ones - serve iff the resolved quality is the constructor's, any other quality swaps in its IJG tables for
+        # this call (models/jpeg.py:210-243)
+        resolved = self.resolve_quality(self.quality if quality is None else quality)
+        learned = bool(self.trainable) and is_number(self.quality) and resolved == self.quality
         if learned:
             q = self._codec_model.trainable_tables()
         else:
-            q = self._codec_model.qtables(self.resolve_quality(self.quality if quality is None else quality), x.device)
+            q = self._codec_model.qtables(resolved, x.device)
         y, mask, _, _ = ops.djpeg_fwd(x, q, self.codec, want_mask=training, out=out)
         return y, ({'x': x, 'mask': mask, 'q': q, 'learned': learned} if training else None)
 
@@ -142,6 +146,8 @@ class JPEG(TFModel):
         return (y, np.nan) if return_entropy else y
 
     def __repr__(self):
+        if self._codec_model is not None:              # models/jpeg.py:253-257
+            return 'JPEG(quality={},codec="{}",trainable={})'.format(self.quality, self.codec, bool(self.trainable))
         return 'JPEG(quality={},codec="{}")'.format(self.quality, self.codec)
 
     def summary(self, quality=None):
@@ -150,13 +156,26 @@ class JPEG(TFModel):
     def summary_compact(self, quality=None):
         return 'JPEG ({}) {}'.format(self.codec, self._quality_mode(quality))
 
-    def estimate_qf(self, channel=0):
+    def _model_tables(self):
+        """The codec model's own (luma, chroma) tables on the host: the learned weights with trainable=True, else the IJG tables of
+        a numeric constructor quality, else ones (models/jpeg.py:57-66)."""
+        if self.trainable:
+            t = self._codec_model.params.flat.detach().cpu().view(2, 8, 8).numpy()
+            return t[0], t[1]
         q = self._codec_model.qtables(self.quality, torch.device('cpu')).numpy()
-        return jpeg_qf_estimation(q[0 if channel == 0 else 1], channel)
+        return q[0], q[1]
+
+    def estimate_qf(self, channel=0):
+        """Closest IJG quality of the current tables.  Like the reference (models/jpeg.py:265-269) the LUMA table is compared
+        whatever `channel` says - `channel` only picks the IJG family it is compared with."""
+        return jpeg_qf_estimation(self._model_tables()[0], channel)
 
     def _quality_mode(self, quality=None):
         quality = quality or self.quality
-        if is_number(quality):
+        if self.trainable and self._codec_model is not None:           # models/jpeg.py:274-278
+            luma, chroma = self._model_tables()
+            return 'trainable QF~{}/{}'.format(jpeg_qf_estimation(luma, 0), jpeg_qf_estimation(chroma, 1))
+        elif is_number(quality):
             return 'QF={}'.format(quality)
         elif hasattr(quality, '__getitem__') and len(quality) == 2:
             return 'QF~[{},{}]'.format(*quality)

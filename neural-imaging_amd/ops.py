@@ -361,7 +361,8 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
         if not fused:
             y = conv2d(x, w, bias, stride=stride, padding=padding, act=act, pad_mode=pad_mode, act_mask=act_mask, pads=pads,
                        out_hw=out_hw, _wmode=_wmode, _f32_only=_f32_only, mask_alpha=mask_alpha, residual=residual)
-            return d2s_clip_bwd(y, 1.0)
+            y = d2s_clip_bwd(y, 1.0)
+            return y.to(torch.bfloat16) if out_bf16 and COMPUTE == 'bf16' else y      # the caller's storage choice survives
     if d2s_out:
         co_ = w.shape[3] if _wmode == 0 else w.shape[2]
         fused = COMPUTE == 'bf16' and not _f32_only and x2 is None and out is None and out2 is None and stride == 1 and \
@@ -375,7 +376,9 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
                        _wmode=_wmode, _f32_only=_f32_only)
             y = d2s_clip(y, 1.0, 0.0, False)
             y = y if act_mask is None else lrelu_bwd(y, act_mask, out=y, alpha=mask_alpha)
-            return (y, None) if bf16_copy else y
+            if out_bf16 and COMPUTE == 'bf16':
+                y = y.to(torch.bfloat16)
+            return (y, y.to(torch.bfloat16) if COMPUTE == 'bf16' else None) if bf16_copy else y
     if residual is not None or bf16_copy:
         _f32(residual)
         fused = COMPUTE == 'bf16' and not _f32_only and x2 is None and out2 is None and \

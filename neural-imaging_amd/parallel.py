@@ -12,8 +12,21 @@ import torch
 import torch.distributed as dist
 
 
+# A one-rank group has nothing to exchange, so the collectives are skipped at world size 1 - unless they are forced
+# (force_collectives() / NIMG_DP_FORCE_COLLECTIVES=1): then every bucket launch, flag reduction, histogram all-reduce and
+# broadcast goes through the backend exactly as at N > 1.  That is how the RCCL stream / event hand-off with the library's
+# raw-stream launches is exercised on a one-GPU box (tests/test_gpu_models.py::test_data_parallel_step_nccl_world1,
+# bench.py `dp1_nccl_*`).
+_FORCE = os.environ.get('NIMG_DP_FORCE_COLLECTIVES', '0') == '1'
+
+
+def force_collectives(on=True):
+    global _FORCE
+    _FORCE = bool(on)
+
+
 def is_distributed():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE)
 
 
 def world_size():
@@ -27,15 +40,26 @@ def rank():
 def init_from_env(backend=None):
     """Initialise the process group from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun contract)."""
     ws = int(os.environ.get('WORLD_SIZE', '1'))
-    if ws <= 1 or (dist.is_available() and dist.is_initialized()):
+    if (ws <= 1 and not _FORCE) or (dist.is_available() and dist.is_initialized()):
         return ws
     if backend is None:
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
     if backend == 'nccl':
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if ws <= 1:                               # forced one-rank group: no launcher has set the rendezvous variables
+        os.environ.setdefault('MASTER_PORT', str(_free_port()))
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
     dist.init_process_group(backend=backend)
     return ws
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
 
 
 def rank_generator(base_seed, device):

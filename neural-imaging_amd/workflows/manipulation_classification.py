@@ -322,7 +322,7 @@ class ManipulationClassification(object):
                 chunk = ([dY] if i else [parts_dY[0]]) + parts_dY[i + 1:i + 6]
                 ops.add_n(chunk, out=dY)
             loss_nip, _ = self.nip.loss_and_grad(Y, target, grad_scale=float(lambda_nip), grad_out=dY, accumulate=True)
-            if world > 1 and hasattr(self.nip, 'decoder_grads'):
+            if parallel.is_distributed() and hasattr(self.nip, 'decoder_grads'):
                 # two buckets: the decoder's gradients (its backward runs first) travel while the encoder backward
                 # computes; only the encoder's slice is exposed at the end of the step
                 dec, enc = self.nip.decoder_grads()

@@ -78,3 +78,57 @@ def dp_step_worker(rank, world, port, q, codec, raw, rgb):
     q.put((rank, float(parts['ce']), float(parts['nip']), float(parts['dcn']), grads, params))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
+
+
+def dp_nccl_world1_worker(q, codec, raw, rgb, mode):
+    """The data-parallel code path through RCCL on ONE GPU: a one-rank `nccl` group with the collectives forced
+    (parallel.force_collectives) - three gradient buckets, NaN-flag reduction, the codec's histogram all-reduce all go through
+    ProcessGroupNCCL and its stream / event hand-off with the library's raw-stream launches - next to the plain step of an
+    identically initialised channel in the same process."""
+    import torch
+    importlib.import_module('neural-imaging_amd')
+    from neural_imaging_amd import _lib, ops, parallel as par
+    _lib.load()
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    ops.set_compute(mode)
+    bx, by = torch.from_numpy(raw).to(dev), torch.from_numpy(rgb).to(dev)
+    out = {}
+    for leg in ('plain', 'nccl'):
+        if leg == 'nccl':
+            par.force_collectives(True)
+            os.environ.pop('WORLD_SIZE', None)
+            par.init_from_env('nccl')
+            assert par.is_distributed() and par.world_size() == 1 and torch.distributed.get_backend() == 'nccl'
+        wf, kw = make_channel(codec, dev)
+        losses = []
+        for _ in range(3):                       # three steps: the second and third run on all-reduced, Adam-updated weights
+            loss, parts = wf.training_step(bx, by, learning_rate=1e-4, **kw)
+            losses.append((float(parts['ce']), float(parts['nip']), float(parts['dcn'])))
+        wf.check_nan()
+        out[leg] = (losses,) + channel_state(wf)
+        del wf
+    q.put(out)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def forced_world1_worker(q):
+    import torch
+    importlib.import_module('neural-imaging_amd')
+    from neural_imaging_amd import parallel as par
+    for k in ('RANK', 'WORLD_SIZE', 'MASTER_PORT'):
+        os.environ.pop(k, None)
+    assert par.init_from_env('gloo') == 1 and not par.is_distributed()          # a plain one-rank run starts no group
+    par.force_collectives(True)
+    par.init_from_env('gloo')
+    ok = par.is_distributed() and par.world_size() == 1 and par.rank() == 0
+    flat = torch.arange(10, dtype=torch.float32)
+    b = par.GradientBucket()
+    b.launch(flat[:4])
+    b.launch(flat[4:])
+    b.wait()
+    flag = torch.tensor([1], dtype=torch.int32)
+    par.all_reduce_flag(flag)
+    q.put((ok, flat.tolist(), int(flag[0]), par.broadcast_floats([0.5, 2.0]), par.sync_gradients(flat)))
+    torch.distributed.destroy_process_group()

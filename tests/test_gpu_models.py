@@ -1200,6 +1200,40 @@ def test_data_parallel_step_equals_global_batch(dev, codec):
         assert np.array_equal(res[0][4][k], res[1][4][k])          # both ranks hold the same reduced buffer
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('codec,mode', [('jpeg', 'f32'), ('jpeg', 'bf16'), ('dcn', 'f32')])
+def test_data_parallel_step_nccl_world1(dev, codec, mode):
+    """the data-parallel step through RCCL on the one GPU a test box has.  A one-rank `nccl` process group
+    with the collectives forced (parallel.force_collectives) sends the three gradient buckets (FAN, UNet decoder, UNet encoder
+    [, codec]), the NaN flag and the codec's entropy histogram through ProcessGroupNCCL - its stream / event hand-off with the
+    library's raw-stream launches and the side-stream joins is what this proves.  A sum over one rank is the identity, so three
+    training steps must leave losses, gradients and post-Adam parameters EQUAL to the plain step's (bit for bit with dJPEG; the
+    learned codec's float64 histogram uses LDS atomics whose order is not fixed: 1e-6)."""
+    import torch.multiprocessing as mp
+    from dp_worker import dp_nccl_world1_worker
+    rgb = natural_images(4, 64, 64, seed=22)
+    raw = bayer_from_rgb(rgb)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=dp_nccl_world1_worker, args=(q, codec, raw, rgb, mode))
+    p.start()
+    out = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    (l0, g0, p0), (l1, g1, p1) = out['plain'], out['nccl']
+    exact = codec == 'jpeg'
+    for a, b in zip(l0, l1):
+        for u, v in zip(a, b):
+            assert (u == v or (np.isnan(u) and np.isnan(v))) if exact else abs(u - v) <= 1e-6 * max(1.0, abs(u))
+    for k in range(len(g0)):
+        if exact:
+            assert np.array_equal(g0[k], g1[k]), ('gradients', k)
+            assert np.array_equal(p0[k], p1[k]), ('parameters after 3 Adam steps', k)
+        else:
+            assert np.abs(g0[k] - g1[k]).max() <= 1e-6 * np.abs(g0[k]).max() + 1e-12, ('gradients', k)
+            assert np.abs(p0[k] - p1[k]).max() <= 1e-6, ('parameters after 3 Adam steps', k)
+
+
 def test_captured_step_replays_the_eager_step(dev):
     """graphs.CapturedStep: the hipGraph replay of the training step walks the same weights trajectory as eager launches
     (including Keras Adam's per-step bias correction, which the replay reads from device memory)."""

@@ -119,6 +119,13 @@ def test_djpeg_trainable_tables(dev, mode):
     before = codec._model.flat_grad.clone()
     codec.backward(ctx80, g(gy, dev))
     assert torch.equal(before, codec._model.flat_grad)
+    # ... but an explicit quality EQUAL to the constructor's keeps the learned tables (the reference swaps only when the
+    # resolved quality differs, models/jpeg.py:235-243)
+    y60, ctx60 = codec.forward(g(x, dev), quality=60, training=True)
+    assert ctx60['learned'] and torch.equal(y60, y)
+    assert not torch.equal(y60, mj.JPEG(quality=60, codec=mode, device=dev).forward(g(x, dev))[0])
+    with pytest.raises(ValueError):                                        # unspecified quality: raises before any table is picked
+        mj.JPEG(quality=None, codec=mode, trainable=True, device=dev).forward(g(x, dev))
 
 
 def test_djpeg_properties_full_size(dev):
@@ -854,6 +861,26 @@ def test_conv3x3_writing_its_depth_to_space_image(dev):
         back = ops.d2s_clip_bwd(dy, 0.5)
         assert tuple(back.shape) == (3, 6, 10, 4 * c)
         assert torch.equal(T.depth_to_space(back.cpu(), 2), 0.5 * dy.cpu()), c
+
+
+def test_conv5x5_bf16_copy_at_ring_shapes(dev):
+    """a 5x5 stride-1 layer over a bf16-stored input whose shape selects the ring kernels (Cout % 128 == 0, Cout % 64
+    == 0 with H >= 32, Cout == 32) asked for the second bf16 copy of its float32 result.  The ring epilogue does not write that
+    copy, so the dispatch must keep such a call on the generic kernel: the copy is the float32 result rounded to bf16, and the
+    float32 result equals the plain call's (which does run the ring kernel) to summation order."""
+    from neural_imaging_amd import ops
+    ops.set_compute('bf16')
+    try:
+        for cin, cout, hw in ((32, 128, 32), (16, 64, 32), (32, 32, 32)):
+            x = g(rnd((2, hw, hw, cin), 61 + cout), dev).to(torch.bfloat16)
+            wk, b = g(rnd((5, 5, cin, cout), 62, -0.05, 0.05), dev), g(rnd((cout,), 63, -0.1, 0.1), dev)
+            plain = ops.conv2d(x, wk, b, act='leaky_relu')
+            both, copy = ops.conv2d(x, wk, b, act='leaky_relu', bf16_copy=True)
+            assert copy is not None and copy.dtype == torch.bfloat16
+            assert torch.equal(copy, both.to(torch.bfloat16)), (cin, cout)
+            assert_close(both.cpu().numpy(), plain.cpu().numpy(), 1e-5, 1e-5, what='5x5 bf16_copy vs the ring kernel')
+    finally:
+        ops.set_compute('f32')
 
 
 def test_conv3x3_with_fused_residual(dev):

@@ -65,6 +65,14 @@ def test_jpeg_quality_resolution():
     j = jpeg.JPEG(80, 'soft', device='cpu')
     assert j.summary() == 'JPEG (soft) QF=80' and j.count_parameters() == 0 and j.estimate_qf() == 80
     assert jpeg.JPEG((50, 90), 'soft', device='cpu').summary() == 'JPEG (soft) QF~[50,90]'
+    assert repr(j) == 'JPEG(quality=80,codec="soft",trainable=False)'                  # models/jpeg.py:253-257
+    # trainable tables (models/jpeg.py:57-62, 265-278): the summaries and the QF estimate read the LEARNED tables
+    jt = jpeg.JPEG(70, 'soft', trainable=True, device='cpu')
+    assert repr(jt) == 'JPEG(quality=70,codec="soft",trainable=True)' and jt.count_parameters() == 128
+    assert jt.summary() == 'JPEG (soft) trainable QF~70/70' and jt.estimate_qf() == 70
+    from neural_imaging_amd import ops as _ops
+    jt._model.p['Q_mtx_luma'].copy_(_ops.qtables_device(30, 'cpu')[0])
+    assert jt.estimate_qf() == 30 and jt.summary() == 'JPEG (soft) trainable QF~30/70'
 
 
 def test_djpeg_reciprocal_division_is_the_ieee_quotient(tmp_path):
@@ -377,3 +385,18 @@ def test_data_parallel_plumbing_gloo(world):
     assert len(set(streams)) == world                             # no two ranks draw the same noise
     single = torch.randn((6,), generator=torch.Generator().manual_seed(5)).tolist()
     assert list(streams[0]) == single                             # rank 0 = the single-process stream
+
+
+def test_forced_collectives_at_world_size_one():
+    """parallel.force_collectives(): a one-rank group whose collectives really run (the hook the nccl world-1 GPU test and
+    bench.py's dp1_nccl leg use) - sum over one rank is the identity, the world size stays 1 (Adam scale 1)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    from dp_worker import forced_world1_worker
+    p = ctx.Process(target=forced_world1_worker, args=(q,))
+    p.start()
+    ok, flat, flag, drawn, world = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and ok
+    assert flat == [float(i) for i in range(10)] and flag == 1 and drawn == [0.5, 2.0] and world == 1

@@ -21,7 +21,9 @@ run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INS
 run sq2 SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU
 cd $ROOT
 python - <<'PY'
-import csv, glob, json, os
+import csv, glob, json, os, sys
+sys.path.insert(0, 'tools')
+from src_stamp import csrc_sha16
 out = {}
 for path in sorted(glob.glob('gpurun_out/pmc_ring/*.csv')):
     rows = list(csv.DictReader(open(path)))
@@ -52,6 +54,6 @@ if out.get('GRBM_GUI_ACTIVE'):
 if out.get('SQ_LDS_IDX_ACTIVE'):
     d['lds_bank_conflict_frac_of_lds_cycles'] = out['SQ_LDS_BANK_CONFLICT'] / out['SQ_LDS_IDX_ACTIVE']
 out['derived'] = d
-json.dump({'bf16_stored_input_pooled': out}, open('gpurun_out/pmc_ring/summary.json', 'w'), indent=1)
+json.dump({'csrc_sha16': csrc_sha16('.'), 'bf16_stored_input_pooled': out}, open('gpurun_out/pmc_ring/summary.json', 'w'), indent=1)
 print(json.dumps(out, indent=1)[:2500])
 PY

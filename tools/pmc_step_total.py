@@ -11,8 +11,12 @@ MI355X_MICROARCH.md's HBM section; KB as reported) + WRITE_SIZE.  Per-kernel sum
 """
 import csv
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from src_stamp import csrc_sha16
 
 
 def short(name):
@@ -63,7 +67,7 @@ def main():
         e['TBps_under_pmc'] = e['bytes'] / max(e['us_under_pmc'], 1e-9) / 1e6
     out = {'what': 'HBM bytes of one {} training step (all {} dispatches of the last of 3 eager steps), 2 x FETCH_SIZE + WRITE_SIZE, '
                    'separate rocprofv3 --pmc passes'.format(workload.upper(), len(fetch)),
-           'batch_raw_patches': batch, 'dispatches': len(fetch),
+           'csrc_sha16': csrc_sha16(), 'batch_raw_patches': batch, 'dispatches': len(fetch),
            'fetch_bytes_x2': total_f, 'write_bytes': total_w, 'bytes_per_step': total_f + total_w,
            'bytes_per_raw_patch': (total_f + total_w) / batch,
            'kernel_us_under_pmc': dur,
