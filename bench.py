@@ -634,6 +634,7 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 
+    line = None
     if rank == 0:
         ms = 1e3 * dt / args.steps
         value = world * wl.batch * args.steps / dt
@@ -768,10 +769,19 @@ def main():
                 line['dp1_nccl_error'] = repr(e)[:200]
         if not args.no_cpu_baseline and world == 1:
             line['cpu_baseline'] = cpu_baseline(wl.key, args.raw_patch)
-        print(json.dumps(line))
+        line['launch_path'] = 'hip_graph_replay' if cfg['hip_graph'] else 'eager_launches'
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    # RCCL writes a version banner to the C stdout of the process that created a communicator; when stdout is a file or a pipe it
+    # sits in the C buffer until exit and would land BEHIND the result: drain it first, so that the JSON line is the last line
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        if world > 1:
+            time.sleep(0.5)                     # the other ranks drain theirs
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == '__main__':

@@ -1422,7 +1422,7 @@ def test_dcn_bf16_storage_inside_residual_blocks_is_bit_neutral(dev, monkeypatch
     oracle test, test_strided_layer_on_a_space_to_depth_stored_input, and runs in every other codec test.)"""
     from neural_imaging_amd import ops
     from neural_imaging_amd.models import compression
-    monkeypatch.setenv('NIMG_NO_S2D_CHAIN', '1')
+    monkeypatch.setattr(compression, '_NO_S2D_CHAIN', True)         # the A/B switch NIMG_NO_S2D_CHAIN, read once at import
     x = torch.from_numpy(natural_images(2, 64, 64, seed=23)).to(dev)
     ops.set_compute('bf16')
     out = {}
