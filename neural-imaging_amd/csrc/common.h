@@ -167,6 +167,66 @@ __device__ __forceinline__ void pool_in_regs(const nimg_f32x16 (&acc)[NI], float
     }
 }
 
+// The two epilogues above for bf16-STORED outputs, eight channels per lane: one 16-byte store (and one 16-byte mask load)
+// instead of two 8-byte ones - the store-issue rate, not the bytes, bounds a row-per-lane epilogue.  Same arithmetic per value.
+//   emit(row, c, float4 lo, float4 hi): channels c .. c+3 and c+4 .. c+7
+template <int NI, typename Emit>
+__device__ __forceinline__ void epilogue_via_lds8(const nimg_f32x16 (&acc)[NI], float* lds, int lane, Emit emit) {
+    constexpr int RS = NI * 32 + EPI_PAD;
+    const int half = lane >> 5, n = lane & 31;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) lds[((j & 3) + 8 * (j >> 2) + 4 * half) * RS + ni * 32 + n] = acc[ni][j];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < (32 * NI * 4) / 64; ++it) {
+        const int idx = it * 64 + lane, row = idx / (NI * 4), c8 = idx % (NI * 4);
+        const float4 lo = *reinterpret_cast<const float4*>(lds + row * RS + c8 * 8);
+        const float4 hi = *reinterpret_cast<const float4*>(lds + row * RS + c8 * 8 + 4);
+        emit(row, c8 * 8, lo, hi);
+    }
+}
+
+//   emit(pc, c, float4 lo, float4 hi, uint2 argmax bytes of the 8 channels)
+template <int NI, typename Bias, typename Emit>
+__device__ __forceinline__ void pool_in_regs8(const nimg_f32x16 (&acc)[NI], float* lds, int lane, float alpha, Bias bias1,
+                                              Emit emit) {
+    constexpr int RS = NI * 32 + EPI_PAD;
+    unsigned char* lidx = reinterpret_cast<unsigned char*>(lds + 8 * RS);
+    const int half = lane >> 5, n = lane & 31;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const float b = bias1(ni * 32 + n);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int pc = (q & 1) + 4 * (q >> 1) + 2 * half;
+            const float v0 = lrelu(acc[ni][2 * q] + b, alpha), v1 = lrelu(acc[ni][2 * q + 1] + b, alpha);
+            const float v2 = lrelu(acc[ni][2 * q + 8] + b, alpha), v3 = lrelu(acc[ni][2 * q + 9] + b, alpha);
+            float m = v0;
+            unsigned char k = 0;
+            if (v1 > m) { m = v1; k = 1; }
+            if (v2 > m) { m = v2; k = 2; }
+            if (v3 > m) { m = v3; k = 3; }
+            lds[pc * RS + ni * 32 + n] = m;
+            lidx[pc * (NI * 32) + ni * 32 + n] = k;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int ITEMS = 8 * NI * 4;                    // 8 pooled columns x NI*4 groups of 8 channels
+#pragma unroll
+    for (int it = 0; it * 64 < ITEMS; ++it) {
+        const int idx = it * 64 + lane, pc = idx / (NI * 4), c = (idx % (NI * 4)) * 8;
+        if (ITEMS % 64 != 0 && idx >= ITEMS) break;
+        const float4 lo = *reinterpret_cast<const float4*>(lds + pc * RS + c);
+        const float4 hi = *reinterpret_cast<const float4*>(lds + pc * RS + c + 4);
+        const uint2 k = *reinterpret_cast<const uint2*>(lidx + pc * (NI * 32) + c);
+        emit(pc, c, lo, hi, k);
+    }
+}
+
 // dst[i] = sum_k partial[k][i] over `splits` slabs, in a fixed order => deterministic (split-K weight gradients, fused
 // bias sums).  A workgroup of 256 covers 16 float4 columns x 16 slab segments: thread (col, seg) adds slabs seg, seg+16,
 // ... (two independent accumulators), then the 16 segment sums are added in order through LDS - so thousands of slabs

@@ -533,30 +533,55 @@ __device__ __forceinline__ void glds16(r_u32x4 rsrc, unsigned lds_addr, unsigned
                  : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <int N>
+__device__ __forceinline__ void dma_wait_leave() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }   // loads retire in order
 
-template <int TN>
+// Diagnostic builds only (tools/build_variant.sh + tools/ring_time.py; results are WRONG with any bit set): what the main loop of
+// the ring kernels spends where.  1: no weight DMA after the first kernel row; 2: no input fetch / commit after the first chunk;
+// 4: no barrier / DMA wait in the loop; 8: the operand fragments are read once, before the loop; 16: the epilogue stores nothing.
+#ifndef NIMG_RING_ABLATE
+#define NIMG_RING_ABLATE 0
+#endif
+
+// NW = waves per workgroup, stacked along the pixels: 4 (a 256- or 512-pixel tile, two or three workgroups per CU) or 8 (twice
+// the pixels against the SAME weight ring, one workgroup per CU = still two waves per SIMD).  The weights are 8x the bytes of
+// the input tile per K chunk (25 taps x 16 ci x TN co against one halo tile reused by all 25 taps), every workgroup streams
+// ALL of them from L2, and the stream is what the main loop loses most to (profiles/r04_b_ring_ablation.txt: without the
+// weight DMA the TN = 128 layers run 20 - 26 % faster, without the input fetch 6 %): doubling the pixels per workgroup halves
+// the DMA pieces and the L2 bytes per matrix instruction.
+template <int TN, int NW = 4>
 struct RingGeom {
-    static constexpr int NI = TN / 32, MI = NI == 1 ? 4 : 8 / NI;   // fragment block of a wave (4 waves stacked along the pixels)
-    static constexpr int TH = 8 * MI, TW = 16, THH = TH + 4, TWH = TW + 4;
-    static constexpr int NPIXH = THH * TWH, AP = (NPIXH * 2 + 255) / 256;
+    static constexpr int NI = TN / 32, MI = NI == 1 ? 4 : 8 / NI;   // fragment block of a wave (NW waves stacked along the pixels)
+    static constexpr int NT = 64 * NW;
+    static constexpr int TH = 2 * NW * MI, TW = 16, THH = TH + 4, TWH = TW + 4;
+    static constexpr int NPIXH = THH * TWH, AP = (NPIXH * 2 + NT - 1) / NT;
     static constexpr int PLSZ = THH * 32;                    // uint4 entries of one k-half plane of the halo tile
     static constexpr int ABUF = 2 * PLSZ;                    // one A buffer
     static constexpr bool ADBL = TN == 128;                  // two A buffers
     static constexpr int SLOT = 5 * TN * 2;                  // one ring slot: [5 taps x TN co][2 halves]
-    static constexpr int PIECES = 5 * NI, NPW = (PIECES + 3) / 4;     // 1 KB DMA pieces per kernel row, per wave
-    static constexpr size_t LDS_TILES = (size_t)(2 * SLOT + (ADBL ? 2 : 1) * ABUF) * sizeof(uint4);
-    static constexpr size_t LDS_EPI = (size_t)4 * 32 * (TN + EPI_PAD) * sizeof(float);
+    static constexpr int PIECES = 5 * NI, NPW = (PIECES + NW - 1) / NW;   // 1 KB DMA pieces per kernel row, per wave
+    // ring depth.  3 (with NW = 8, where the LDS of the one resident workgroup has the room): the row requested in phase r is
+    // needed in phase r + 2, so the wait at the end of a phase leaves the youngest row's transfers in flight (counted vmcnt)
+    // instead of draining the queue - a weight row gets two phases to arrive from L2 instead of one.
+#ifdef NIMG_RING_SLOTS2
+    static constexpr int NSLOT = 2;
+#else
+    static constexpr int NSLOT = NW == 8 ? 3 : 2;
+#endif
+    static constexpr size_t LDS_TILES = (size_t)(NSLOT * SLOT + (ADBL ? 2 : 1) * ABUF) * sizeof(uint4);
+    static constexpr size_t LDS_EPI = (size_t)NW * 32 * (TN + EPI_PAD) * sizeof(float);
     static constexpr size_t LDS = LDS_TILES > LDS_EPI ? LDS_TILES : LDS_EPI;
 };
 
-template <int TN, bool UNP>
-__global__ __launch_bounds__(256, TN == 32 ? 3 : 2) void conv5_ring_kernel(const ConvParamsB p) {
-    using G = RingGeom<TN>;
+template <int TN, bool UNP, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : (TN == 32 ? 3 : 2)) void conv5_ring_kernel(const ConvParamsB p) {
+    using G = RingGeom<TN, NW>;
+    constexpr int NT = G::NT;
     constexpr int NI = G::NI, MI = G::MI, TH = G::TH, TW = G::TW, TWH = G::TWH, NPIXH = G::NPIXH, AP = G::AP;
     constexpr int PLSZ = G::PLSZ, ABUF = G::ABUF, SLOT = G::SLOT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint4* sB = reinterpret_cast<uint4*>(smem_raw);          // ring first: the LDS-DMA base (M0) stays below 64 KB
-    uint4* sA = sB + 2 * SLOT;
+    uint4* sA = sB + G::NSLOT * SLOT;
     const unsigned sB_addr = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)smem_raw;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -593,7 +618,7 @@ __global__ __launch_bounds__(256, TN == 32 ? 3 : 2) void conv5_ring_kernel(const
     int adst[AP];
 #pragma unroll
     for (int q = 0; q < AP; ++q) {
-        const int item = tid + q * 256, pix = item >> 1;
+        const int item = tid + q * NT, pix = item >> 1;
         int gy = iy0 + pix / TWH, gx = ix0 + pix % TWH;
         const bool ok = (item < NPIXH * 2) & (grp < p.N) & map_coord(gy, p.H, p.pad_mode) & map_coord(gx, p.W, p.pad_mode);
         int apix;
@@ -628,7 +653,7 @@ __global__ __launch_bounds__(256, TN == 32 ? 3 : 2) void conv5_ring_kernel(const
     auto commitA = [&](int buf) {                       // buf: entry offset of the A buffer
 #pragma unroll
         for (int q = 0; q < AP; ++q) {
-            if (tid + q * 256 < NPIXH * 2) {
+            if (tid + q * NT < NPIXH * 2) {
                 uint4 v = preA[q];
                 if constexpr (UNP) v = unp_route(v, preK[q][0], preK[q][1], upos[q]);
                 sA[buf + adst[q]] = v;
@@ -643,8 +668,8 @@ __global__ __launch_bounds__(256, TN == 32 ? 3 : 2) void conv5_ring_kernel(const
     auto gldsB = [&](int chunk, int ky, int slot) {
 #pragma unroll
         for (int j = 0; j < G::NPW; ++j) {
-            const int k = wave + 4 * j;
-            if (G::PIECES % 4 == 0 || k < G::PIECES) {
+            const int k = wave + NW * j;
+            if (G::PIECES % NW == 0 || k < G::PIECES) {
                 const int soff = ((chunk * 25 + ky * 5 + k / NI) * Cout + (k % NI) * 32) * 32;
                 glds16(rb, sB_addr + (unsigned)((slot * SLOT + k * 64) * 16), bvoff, soff);
             }
@@ -652,30 +677,97 @@ __global__ __launch_bounds__(256, TN == 32 ? 3 : 2) void conv5_ring_kernel(const
     };
     const int chunks = p.C1 >> 4;
     gldsB(0, 0, 0);
+    if constexpr (G::NSLOT == 3) gldsB(0, 1, 1);
     fetchA(0);
     commitA(0);
     dma_wait();
     __syncthreads();
+    constexpr int ABL = NIMG_RING_ABLATE;
+    bf16x8 a0[MI], b0[NI];
+    if constexpr (ABL & 8) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) { const uint4 v = sA[abase[mi]]; a0[mi] = *reinterpret_cast<const bf16x8*>(&v); }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) { const uint4 v = sB[bbase + ni * 64]; b0[ni] = *reinterpret_cast<const bf16x8*>(&v); }
+    }
+    if constexpr (G::NSLOT == 3) {
+        static_assert(G::ADBL, "the three-slot ring is written for the double-buffered input tile");
+        // transfers of ONE wave per kernel row: waves below PIECES % NW move one piece more
+        constexpr int NLO = G::PIECES / NW, NREM = G::PIECES % NW;
+        constexpr int NA = AP * (UNP ? 2 : 1);             // the input prefetch of phase 0: loads queued BEHIND that phase's row
+        int s0 = 0;                                        // slot of kernel row 0 of this chunk = (5 c) % 3
+        for (int c = 0; c < chunks; ++c) {
+            const int ab = (c & 1) * ABUF;
+            const bool more = c + 1 < chunks;
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky) {
+                const int slot = (s0 + ky) % 3, slot2 = (s0 + ky + 2) % 3;
+                if (ky == 2 && more) commitA(ab ^ ABUF);   // (the compiler drains the queue for the prefetched registers here)
+                const bool issue = ky < 3 || more;         // row r + 2 exists
+                if (ky < 3) gldsB(c, ky + 2, slot2);
+                else if (more) gldsB(c + 1, ky - 3, slot2);
+                if (ky == 0 && more) fetchA((c + 1) * 16);
+                const uint4* sBs = sB + slot * SLOT + bbase;
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx) {
+                    bf16x8 a[MI], b[NI];
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const uint4 v = sA[ab + abase[mi] + ky * 32 + kx];
+                        a[mi] = *reinterpret_cast<const bf16x8*>(&v);
+                    }
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const uint4 v = sBs[(kx * TN + ni * 32) * 2];
+                        b[ni] = *reinterpret_cast<const bf16x8*>(&v);
+                    }
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                }
+                // row r + 1 must have landed; what may stay in flight is younger: this phase's row and, in phases 0 / 1 of a
+                // chunk, the input prefetch queued behind phase 0's row
+                if (!issue) dma_wait();
+                else if (ky < 2 && more) {
+                    if (NREM && wave < NREM) dma_wait_leave<NLO + 1 + NA>();
+                    else dma_wait_leave<NLO + NA>();
+                } else {
+                    if (NREM && wave < NREM) dma_wait_leave<NLO + 1>();
+                    else dma_wait_leave<NLO>();
+                }
+                // raw barrier: __syncthreads() may drain the memory queue for its fence - the youngest row has to stay in flight.
+                // What has to be ordered here is LDS only: this wave's tile writes (lgkmcnt) and its landed transfers (above).
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            s0 = (s0 + 2) % 3;
+        }
+    } else
     for (int c = 0; c < chunks; ++c) {
         const int ab = G::ADBL ? (c & 1) * ABUF : 0;
         const bool more = c + 1 < chunks;
 #pragma unroll
         for (int ky = 0; ky < 5; ++ky) {
             const int slot = (c + ky) & 1;                 // (5 c + ky) & 1
-            if (ky < 4) gldsB(c, ky + 1, slot ^ 1);
-            else if (more) gldsB(c + 1, 0, slot ^ 1);
-            if (ky == 0 && more) fetchA((c + 1) * 16);
+            if constexpr (!(ABL & 1)) {
+                if (ky < 4) gldsB(c, ky + 1, slot ^ 1);
+                else if (more) gldsB(c + 1, 0, slot ^ 1);
+            }
+            if constexpr (!(ABL & 2)) if (ky == 0 && more) fetchA((c + 1) * 16);
             const uint4* sBs = sB + slot * SLOT + bbase;
 #pragma unroll
             for (int kx = 0; kx < 5; ++kx) {
                 bf16x8 a[MI], b[NI];
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
+                    if constexpr (ABL & 8) { a[mi] = a0[mi]; continue; }
                     const uint4 v = sA[ab + abase[mi] + ky * 32 + kx];
                     a[mi] = *reinterpret_cast<const bf16x8*>(&v);
                 }
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
+                    if constexpr (ABL & 8) { b[ni] = b0[ni]; continue; }
                     const uint4 v = sBs[(kx * TN + ni * 32) * 2];
                     b[ni] = *reinterpret_cast<const bf16x8*>(&v);
                 }
@@ -685,20 +777,51 @@ __global__ __launch_bounds__(256, TN == 32 ? 3 : 2) void conv5_ring_kernel(const
                     for (int ni = 0; ni < NI; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
             }
-            if (G::ADBL && ky == 4 && more) commitA(ab ^ ABUF);
-            dma_wait();                                    // the next kernel row has landed ...
-            __syncthreads();                               // ... and everyone is done with this one (slot and A buffer free)
-            if (!G::ADBL && ky == 4 && more) {
+            if constexpr (!(ABL & 2)) if (G::ADBL && ky == 4 && more) commitA(ab ^ ABUF);
+            if constexpr (!(ABL & 4)) {
+                dma_wait();                                // the next kernel row has landed ...
+                __syncthreads();                           // ... and everyone is done with this one (slot and A buffer free)
+            }
+            if constexpr (!(ABL & 2)) if (!G::ADBL && ky == 4 && more) {
                 commitA(0);
-                __syncthreads();
+                if constexpr (!(ABL & 4)) __syncthreads();
             }
         }
+    }
+    if constexpr (ABL & 4) { dma_wait(); __syncthreads(); }
+    if constexpr (ABL & 16) {              // keep the accumulators alive without storing them
+        float sacc = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) sacc += acc[mi][ni][j];
+        if (sacc == 123.456f) p.out1[0] = sacc;
+        return;
     }
     // epilogue: per-wave private LDS scratch (the loop's last barrier released the tiles) -> wave-level ordering only
     float* elds = reinterpret_cast<float*>(smem_raw) + wave * (32 * (NI * 32 + EPI_PAD));
     if (p.pool_out) {                                      // fused activation + 2x2 max-pool (even Hout / Wout)
         const int Hp = p.Hout >> 1, Wp = p.Wout >> 1;
         const float al = p.act == 1 ? p.alpha : 1.0f;
+        if (p.flags & NIMG_BF16_OUT) {                     // bf16-stored: 16-byte stores of 8 channels (+ 8 arg-max bytes)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int py = (ty0 >> 1) + wave * MI + mi;
+                pool_in_regs8<NI>(acc[mi], elds, lane, al,
+                    [&](int c) { return p.bias ? p.bias[co0 + c] : 0.f; },
+                    [&](int pc, int c, float4 lo, float4 hi, uint2 k) {
+                        const int px = (tx0 >> 1) + pc;
+                        if (grp >= p.N || py >= Hp || px >= Wp) return;
+                        const long o = (((long)grp * Hp + py) * Wp + px) * Cout + co0 + c;
+                        const float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                        *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.pool_out) + o) = pack8(f);
+                        if (p.pool_idx) *reinterpret_cast<uint2*>(p.pool_idx + o) = k;
+                    });
+            }
+            return;
+        }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int py = (ty0 >> 1) + wave * MI + mi;
@@ -712,6 +835,33 @@ __global__ __launch_bounds__(256, TN == 32 ? 3 : 2) void conv5_ring_kernel(const
                     else *reinterpret_cast<float4*>(p.pool_out + o) = v;
                     if (p.pool_idx) *reinterpret_cast<uchar4*>(p.pool_idx + o) = k;
                 });
+        }
+        return;
+    }
+    if ((p.flags & NIMG_BF16_OUT) && (!p.act1 || (p.flags & NIMG_BF16_MASK))) {     // bf16-stored output (and mask): 16-byte rows
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            epilogue_via_lds8<NI>(acc[mi], elds, lane, [&](int row, int c, float4 lo, float4 hi) {
+                const int P = (wave * MI + mi) * 32 + row;
+                const int oy = ty0 + P / TW, ox = tx0 + P % TW;
+                if (grp >= p.N || oy >= p.Hout || ox >= p.Wout) return;
+                const long o = (((long)grp * p.Hout + oy) * p.Wout + ox) * Cout + co0 + c;
+                float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                if (p.bias) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += p.bias[co0 + c + e];
+                }
+                if (p.act == 1) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = lrelu(f[e], p.alpha);
+                }
+                if (p.act1) {
+                    const bf16x8 m = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(p.act1) + o);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] *= (float)m[e] > 0.f ? 1.0f : p.alpha;
+                }
+                *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.out1) + o) = pack8(f);
+            });
         }
         return;
     }
@@ -741,16 +891,24 @@ __global__ __launch_bounds__(256, TN == 32 ? 3 : 2) void conv5_ring_kernel(const
     }
 }
 
-template <int TN>
+template <int TN, int NW = 4>
 int launch_conv5_ring(const ConvParamsB& p, hipStream_t stream) {
-    using G = RingGeom<TN>;
+    using G = RingGeom<TN, NW>;
+    if constexpr (NW == 4 && TN == 128) {
+        // NIMG_RING_NW8=1 (A/B switch, not the product path): eight waves on a 32 x 16 tile against one three-slot weight ring.
+        // Measured (profiles/r04_ring_*.txt): half the weight DMA per matrix instruction raises the clock the chip sustains
+        // (1.81 -> 1.94 GHz on conv3) but the single resident workgroup loses more to its lock-step phases (MFMA pipe busy
+        // 0.665 -> 0.568): 436 -> 459 us.  The four-wave form with two independent workgroups per CU stays.
+        static const bool nw8 = getenv("NIMG_RING_NW8") != nullptr;
+        if (nw8 && p.Hout % 32 == 0) return launch_conv5_ring<TN, 8>(p, stream);
+    }
     ConvParamsB q = p;
     q.tiles_y = cdiv(p.Hout, G::TH);
     q.tiles_x = cdiv(p.Wout, G::TW);
     const long blocks = (long)(p.O1 / TN) * q.tiles_y * q.tiles_x * p.N;
-    auto kern = p.in_idx ? conv5_ring_kernel<TN, true> : conv5_ring_kernel<TN, false>;
+    auto kern = p.in_idx ? conv5_ring_kernel<TN, true, NW> : conv5_ring_kernel<TN, false, NW>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), G::LDS, stream, q);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(G::NT), G::LDS, stream, q);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }
@@ -776,7 +934,8 @@ int launch_conv_b(const ConvParamsB& p, hipStream_t stream) {
                 // residual or a layout flag stays with the generic kernel, whose epilogue writes them
                 const bool plain_epi = !p.res && !p.out1b && !(p.flags & (NIMG_D2S_OUT | NIMG_S2D_OUT | NIMG_COPY_LRELU));
                 if (!no_ring && plain_epi && p.O2 == 0 && p.pad_t == 2 && p.pad_l == 2 && p.Hout == p.H && p.Wout == p.W) {
-                    if (Cout % 128 == 0) return launch_conv5_ring<128>(p, stream);
+                    static const bool tn64 = getenv("NIMG_RING_TN64") != nullptr;      // A/B: 512 pixels x 64 channels per workgroup
+                    if (Cout % 128 == 0 && !(tn64 && p.Hout >= 32)) return launch_conv5_ring<128>(p, stream);
                     if (!no_ring64 && p.Hout >= 32) return launch_conv5_ring<64>(p, stream);
                 }
             }
