@@ -380,6 +380,13 @@ int nimg_confusion_accumulate(const float* probs, const int* labels, int* pred, 
                               void* stream);
 int nimg_sigmoid_fwd(const float* x, float* y, long count, void* stream);
 int nimg_sigmoid_bwd(const float* dy, const float* y, float* dx, long count, void* stream);
+/* The activations a UNet / FAN / TwitterDCN may be built with besides LeakyReLU(0.2) - helpers/tf_helpers.py:22-28
+ * `activation_mapping`, selected by the models' `activation=` hyper-parameter (models/pipelines.py:179, forensics.py:55,
+ * compression.py:202): kind 0 leaky_relu(alpha), 1 relu, 2 tanh, 3 sigmoid, 4 softsign x / (1 + |x|).  Element-wise on float32,
+ * y may alias x; the backward pass takes the derivative from the stored OUTPUT y (y > 0 ? 1 : alpha | y > 0 | 1 - y^2 |
+ * y (1 - y) | (1 - |y|)^2), dx may alias dy.  NIMG_ERR_ARG for another kind. */
+int nimg_activation_fwd(const float* x, float* y, long count, int kind, float alpha, void* stream);
+int nimg_activation_bwd(const float* dy, const float* y, float* dx, long count, int kind, float alpha, void* stream);
 int nimg_gamma_ste_fwd(const float* x, float* y, long count, float lo, float hi, float exponent, void* stream);
 int nimg_gamma_ste_bwd(const float* x, const float* dy, float* dx, long count, float lo, float hi, float exponent,
                        void* stream);

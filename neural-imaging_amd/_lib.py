@@ -94,6 +94,8 @@ PROTOTYPES = {
     'nimg_isp_residual_fwd': (c_int, [P, P, P, P, c_long, c_int, P]),
     'nimg_isp_residual_workspace_bytes': (c_long, []),
     'nimg_isp_residual_bwd': (c_int, [P, P, P, P, P, P, c_long, c_int, P]),
+    'nimg_activation_fwd': (c_int, [P, P, c_long, c_int, c_float, P]),
+    'nimg_activation_bwd': (c_int, [P, P, P, c_long, c_int, c_float, P]),
     'nimg_sigmoid_fwd': (c_int, [P, P, c_long, P]),
     'nimg_sigmoid_bwd': (c_int, [P, P, P, c_long, P]),
     'nimg_gamma_ste_fwd': (c_int, [P, P, c_long, c_float, c_float, c_float, P]),

@@ -75,6 +75,48 @@ __global__ void sigmoid_bwd_kernel(const float* __restrict__ dy, const float* __
     }
 }
 
+// activation_mapping of helpers/tf_helpers.py:22-28 as one element-wise pair; float4 streams with a scalar tail
+template <int KIND>
+__device__ __forceinline__ float act_f(float x, float alpha) {
+    if (KIND == 0) return x > 0.f ? x : alpha * x;
+    if (KIND == 1) return fmaxf(x, 0.f);
+    if (KIND == 2) return tanhf(x);
+    if (KIND == 3) return 1.0f / (1.0f + expf(-x));
+    return x / (1.0f + fabsf(x));
+}
+template <int KIND>
+__device__ __forceinline__ float act_d(float y, float alpha) {          // derivative, from the OUTPUT
+    if (KIND == 0) return y > 0.f ? 1.0f : alpha;
+    if (KIND == 1) return y > 0.f ? 1.0f : 0.f;
+    if (KIND == 2) return 1.0f - y * y;
+    if (KIND == 3) return y * (1.0f - y);
+    const float t = 1.0f - fabsf(y);                                    // y = x / (1 + |x|)  ->  1 / (1 + |x|) = 1 - |y|
+    return t * t;
+}
+template <int KIND>
+__global__ void activation_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long count, float alpha) {
+    const long n4 = count >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        reinterpret_cast<float4*>(y)[i] = make_float4(act_f<KIND>(v.x, alpha), act_f<KIND>(v.y, alpha), act_f<KIND>(v.z, alpha),
+                                                      act_f<KIND>(v.w, alpha));
+    }
+    for (long i = 4 * n4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+        y[i] = act_f<KIND>(x[i], alpha);
+}
+template <int KIND>
+__global__ void activation_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx,
+                                      long count, float alpha) {
+    const long n4 = count >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 g = reinterpret_cast<const float4*>(dy)[i], v = reinterpret_cast<const float4*>(y)[i];
+        reinterpret_cast<float4*>(dx)[i] = make_float4(g.x * act_d<KIND>(v.x, alpha), g.y * act_d<KIND>(v.y, alpha),
+                                                       g.z * act_d<KIND>(v.z, alpha), g.w * act_d<KIND>(v.w, alpha));
+    }
+    for (long i = 4 * n4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+        dx[i] = dy[i] * act_d<KIND>(y[i], alpha);
+}
+
 // y = pow(clip(x, lo, hi), e); the clip is straight-through: dx = dy e pow(clip(x), e - 1) everywhere
 __global__ void gamma_ste_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long count, float lo, float hi,
                                      float e) {
@@ -183,6 +225,40 @@ int nimg_sigmoid_bwd(const float* dy, const float* y, float* dx, long count, voi
     if (count == 0) return NIMG_OK;
     if (!dy || !y || !dx) return NIMG_ERR_ARG;
     hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, count);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_activation_fwd(const float* x, float* y, long count, int kind, float alpha, void* stream) {
+    if (count < 0 || kind < 0 || kind > 4) return NIMG_ERR_ARG;
+    if (count == 0) return NIMG_OK;
+    if (!x || !y || (((uintptr_t)x | (uintptr_t)y) & 15)) return NIMG_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int g = grid_for((count + 3) / 4);
+    switch (kind) {
+        case 0: hipLaunchKernelGGL(activation_fwd_kernel<0>, dim3(g), dim3(256), 0, s, x, y, count, alpha); break;
+        case 1: hipLaunchKernelGGL(activation_fwd_kernel<1>, dim3(g), dim3(256), 0, s, x, y, count, alpha); break;
+        case 2: hipLaunchKernelGGL(activation_fwd_kernel<2>, dim3(g), dim3(256), 0, s, x, y, count, alpha); break;
+        case 3: hipLaunchKernelGGL(activation_fwd_kernel<3>, dim3(g), dim3(256), 0, s, x, y, count, alpha); break;
+        default: hipLaunchKernelGGL(activation_fwd_kernel<4>, dim3(g), dim3(256), 0, s, x, y, count, alpha); break;
+    }
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_activation_bwd(const float* dy, const float* y, float* dx, long count, int kind, float alpha, void* stream) {
+    if (count < 0 || kind < 0 || kind > 4) return NIMG_ERR_ARG;
+    if (count == 0) return NIMG_OK;
+    if (!dy || !y || !dx || (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)dx) & 15)) return NIMG_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int g = grid_for((count + 3) / 4);
+    switch (kind) {
+        case 0: hipLaunchKernelGGL(activation_bwd_kernel<0>, dim3(g), dim3(256), 0, s, dy, y, dx, count, alpha); break;
+        case 1: hipLaunchKernelGGL(activation_bwd_kernel<1>, dim3(g), dim3(256), 0, s, dy, y, dx, count, alpha); break;
+        case 2: hipLaunchKernelGGL(activation_bwd_kernel<2>, dim3(g), dim3(256), 0, s, dy, y, dx, count, alpha); break;
+        case 3: hipLaunchKernelGGL(activation_bwd_kernel<3>, dim3(g), dim3(256), 0, s, dy, y, dx, count, alpha); break;
+        default: hipLaunchKernelGGL(activation_bwd_kernel<4>, dim3(g), dim3(256), 0, s, dy, y, dx, count, alpha); break;
+    }
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }

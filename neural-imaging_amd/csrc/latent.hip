@@ -17,7 +17,7 @@ namespace {
 
 using namespace nimg;
 
-constexpr int MAXK = 64;       // up to 6 bits per feature handled in registers; larger codebooks loop in chunks
+constexpr int MAXK = 256;      // up to 8 bits per feature (models/compression.py:53); the generic kernels keep K-sized arrays per thread
 
 inline int grid_for(long items) {
     long g = (items + 255) / 256;
@@ -191,6 +191,20 @@ __global__ void d2s2_scale3_kernel(const float4* __restrict__ xs, float* __restr
     }
 }
 
+// The latent's rounding when it is NOT the soft codebook (reference models/layers.py:118-134, Quantization.call), selected by bits 2-3
+// of the kernels' `soft_codebook` flag word: 0 identity; 1 'soft' = tf.round forward (half to even), the sinusoidal approximation's
+// derivative backward; 2 'sin' = x - sin(2 pi x) / (2 pi) forward and backward.  float32 like the reference's graph (the Python
+// constant 2 * np.pi becomes a float32 tensor constant next to a float32 operand).
+__device__ __forceinline__ float round_mode_fwd(float zs, int mode) {
+    const float tp = 6.2831855f;
+    if (mode == 1) return rintf(zs);
+    if (mode == 2) return zs - sinf(tp * zs) / tp;
+    return zs;
+}
+__device__ __forceinline__ double round_mode_bwd(float zs, int mode) {
+    return mode ? (double)(1.0f - cosf(6.2831855f * zs)) : 1.0;
+}
+
 struct KernelW {
     double w[MAXK];
     double dw[MAXK];
@@ -253,8 +267,8 @@ __global__ __launch_bounds__(256) void soft_codebook_fwd_kernel(const float* __r
     KernelW kw;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
         const float zs = z[i] * s;                                           // layers.py:197-198 (float32 product)
-        float lat = zs;
-        if (soft_codebook) {
+        float lat = round_mode_fwd(zs, soft_codebook >> 2);
+        if (soft_codebook & 1) {
             eval_weights((double)zs, cb, K, v, gamma, kw, false);
             double soft = 0.0, best = -1.0;
             int arg = 0;
@@ -358,10 +372,10 @@ __global__ __launch_bounds__(256) void soft_codebook_fwd_win_kernel(const float*
     };
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
         const float zs = z[i] * s;                                           // layers.py:197-198 (float32 product)
-        float lat = zs;
+        float lat = round_mode_fwd(zs, soft_codebook >> 2);
         int ka, kb;
         double r, t;
-        if (soft_codebook) {
+        if (soft_codebook & 1) {
             double S = 0.0, wc = 0.0, best = -1.0;
             float hard = 0.f;
             window((double)zs, ka, kb);
@@ -431,7 +445,7 @@ __global__ __launch_bounds__(256) void soft_codebook_bwd_win_kernel(const float*
         double g = dlat ? (double)dlat[i] : 0.0;
         if (coef != 0.f) g += (double)coef * sums((double)latent[i], true);
         const float zs = z[i] * s;
-        const double dsoft = soft_codebook ? sums((double)zs, false) : 1.0;
+        const double dsoft = (soft_codebook & 1) ? sums((double)zs, false) : round_mode_bwd(zs, soft_codebook >> 2);
         const double gz = g * dsoft;                 // gradient w.r.t. zs = scale * z
         dz[i] = (float)(gz * (double)s);
         dsum += gz * (double)z[i];
@@ -461,8 +475,8 @@ __global__ __launch_bounds__(256) void soft_codebook_fwd_fast_kernel(const float
     };
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
         const float zs = z[i] * s;                                           // layers.py:197-198 (float32 product)
-        float lat = zs;
-        if (soft_codebook) {
+        float lat = round_mode_fwd(zs, soft_codebook >> 2);
+        if (soft_codebook & 1) {
             double S = 0.0, wc = 0.0, best = -1.0;
             float hard = 0.f;
 #pragma unroll
@@ -529,7 +543,7 @@ __global__ __launch_bounds__(256) void soft_codebook_bwd_fast_kernel(const float
         double g = dlat ? (double)dlat[i] : 0.0;
         if (coef != 0.f) g += (double)coef * sums((double)latent[i], std::true_type{});
         const float zs = z[i] * s;
-        const double dsoft = soft_codebook ? sums((double)zs, std::false_type{}) : 1.0;
+        const double dsoft = (soft_codebook & 1) ? sums((double)zs, std::false_type{}) : round_mode_bwd(zs, soft_codebook >> 2);
         const double gz = g * dsoft;                 // gradient w.r.t. zs = scale * z
         dz[i] = (float)(gz * (double)s);
         dsum += gz * (double)z[i];
@@ -555,41 +569,61 @@ inline int fast_exponent(int K, double v) {
 __global__ __launch_bounds__(1024) void hist_reduce_kernel(const double* __restrict__ partial, int nblocks, int K,
                                                            double* __restrict__ hist_sum) {
     __shared__ double seg[16][MAXK];
-    const int k = threadIdx.x & 63, g = threadIdx.x >> 6;
-    double s = 0.0;
-    if (k < K)
+    const int k0 = threadIdx.x & 63, g = threadIdx.x >> 6;
+    for (int k = k0; k < K; k += 64) {                 // a lane serves centres k0, k0 + 64, ... (K <= 256)
+        double s = 0.0;
         for (int b = g; b < nblocks; b += 16) s += partial[(long)b * K + k];
-    seg[g][k] = s;
-    __syncthreads();
-    if (g == 0 && k < K) {
-        double t = 0.0;
-        for (int j = 0; j < 16; ++j) t += seg[j][k];
-        hist_sum[k] = t;
+        seg[g][k] = s;
     }
+    __syncthreads();
+    if (g == 0)
+        for (int k = k0; k < K; k += 64) {
+            double t = 0.0;
+            for (int j = 0; j < 16; ++j) t += seg[j][k];
+            hist_sum[k] = t;
+        }
 }
 
 // entropy (bits) and dH/d(hist_sum) from the global weight sums; tf_helpers.py:326-331
 __global__ void entropy_finalize_kernel(const double* __restrict__ hist_sum, int K, double n_total,
                                         float* __restrict__ entropy, double* __restrict__ dH_dsum) {
-    // one wave, lane k = centre k (K <= MAXK = 64); the three sums over the centres are butterfly sums in a fixed order.
-    // (One thread looping over the centres spent 40 us on its 3 K dependent float64 logarithms and divisions.)
+    // one wave, lane l = centres l, l + 64, l + 128, l + 192 (K <= MAXK = 256): per-lane partial sums in that order, then butterfly
+    // sums over the lanes - a fixed order.  (One thread looping over the centres spent 40 us on its 3 K dependent float64
+    // logarithms and divisions.)
     if (blockIdx.x != 0 || threadIdx.x >= 64) return;
-    const int k = threadIdx.x;
-    const bool on = k < K;
-    const double h = on ? hist_sum[k] / n_total : 1.0;
-    const bool clipped = h < 1e-9;
-    const double hc = on ? (clipped ? 1e-9 : h) : 0.0;
-    const double T = wave_sum_d(hc);
-    const double q = on ? hc / T : 1.0;
-    const double lq = log(q);                                   // 0 on the idle lanes
-    const double H = -wave_sum_d(on ? q * lq : 0.0);
-    if (k == 0) entropy[0] = (float)(H / 0.6931);
-    // dH/dhc_k = -(log q_k + 1)/T + (sum_j q_j (log q_j + 1))/T ;  then through the clip and the 1/n_total mean
-    const double mean = wave_sum_d(on ? q * (lq + 1.0) : 0.0);
-    if (on) {
-        const double d = (-(lq + 1.0) + mean) / T / 0.6931;
-        dH_dsum[k] = clipped ? 0.0 : d / n_total;
+    const int l = threadIdx.x;
+    constexpr int NPL = MAXK / 64;
+    double hc[NPL], lq[NPL], q[NPL];
+    bool on[NPL], clipped[NPL];
+    double part = 0.0;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        const int k = l + 64 * j;
+        on[j] = k < K;
+        const double h = on[j] ? hist_sum[k] / n_total : 1.0;
+        clipped[j] = h < 1e-9;
+        hc[j] = on[j] ? (clipped[j] ? 1e-9 : h) : 0.0;
+        part += hc[j];
     }
+    const double T = wave_sum_d(part);
+    double hp = 0.0, mp = 0.0;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        q[j] = on[j] ? hc[j] / T : 1.0;
+        lq[j] = log(q[j]);                                      // 0 on the idle slots
+        hp += on[j] ? q[j] * lq[j] : 0.0;
+        mp += on[j] ? q[j] * (lq[j] + 1.0) : 0.0;
+    }
+    const double H = -wave_sum_d(hp);
+    if (l == 0) entropy[0] = (float)(H / 0.6931);
+    // dH/dhc_k = -(log q_k + 1)/T + (sum_j q_j (log q_j + 1))/T ;  then through the clip and the 1/n_total mean
+    const double mean = wave_sum_d(mp);
+#pragma unroll
+    for (int j = 0; j < NPL; ++j)
+        if (on[j]) {
+            const double d = (-(lq[j] + 1.0) + mean) / T / 0.6931;
+            dH_dsum[l + 64 * j] = clipped[j] ? 0.0 : d / n_total;
+        }
 }
 
 // backward: dz = scale * dsoft/du(zs) * [ dlat + coef * sum_k dH_dsum[k] * dwn_k/du(lat) ];  dscale partial = sum z * (...)
@@ -615,9 +649,9 @@ __global__ __launch_bounds__(256) void soft_codebook_bwd_kernel(const float* __r
                 e += dH_dsum[k] * (kw.dw[k] * kw.S - kw.w[k] * kw.dS) / (kw.S * kw.S);
             g += (double)coef * e;
         }
-        double dsoft = 1.0;
         const float zs = z[i] * s;
-        if (soft_codebook) {
+        double dsoft = round_mode_bwd(zs, soft_codebook >> 2);
+        if (soft_codebook & 1) {
             eval_weights((double)zs, cb, K, v, gamma, kw, true);
             dsoft = 0.0;
             for (int k = 0; k < K; ++k)
@@ -816,7 +850,7 @@ int nimg_latent_fwd(const float* z, const float* scale, const float* codebook, i
     // soft_codebook bit 1 (a promise of the caller): unit-spaced codebook -> the windowed kernels (gamma >= 25, v = 50 only)
     static const bool no_win = getenv("NIMG_LATENT_NO_WINDOW") != nullptr;
     const bool win = (soft_codebook & 2) && m == 51 && gamma >= 25.0f && !no_win;
-    soft_codebook &= 1;
+    soft_codebook &= ~2;                       // bit 0: soft codebook; bits 2-3: rounding mode of the other branch
 #define NIMG_SCB_FWD_WIN(KK)                                                                                              \
     hipLaunchKernelGGL((soft_codebook_fwd_win_kernel<KK, 51>), dim3(grid), dim3(256), 0, s, z, scale, codebook, m, 1.0 / vd, \
                        (double)gamma, latent, part, count, soft_codebook)
@@ -874,7 +908,7 @@ int nimg_latent_bwd(const float* z, const float* scale, const float* latent, con
                        (const double*)dH, entropy_coef, codebook, m, 1.0 / vd, (double)gamma, dz, dsp, count, soft_codebook)
     static const bool no_win = getenv("NIMG_LATENT_NO_WINDOW") != nullptr;
     const bool win = (soft_codebook & 2) && m == 51 && gamma >= 25.0f && !no_win;
-    soft_codebook &= 1;
+    soft_codebook &= ~2;                       // bit 0: soft codebook; bits 2-3: rounding mode of the other branch
 #define NIMG_SCB_BWD_WIN(KK)                                                                                          \
     hipLaunchKernelGGL((soft_codebook_bwd_win_kernel<KK, 51>), dim3(grid), dim3(256), 0, s, z, scale, latent, dlatent,    \
                        (const double*)dH, entropy_coef, codebook, m, 1.0 / vd, (double)gamma, dz, dsp, count, soft_codebook)

@@ -60,11 +60,6 @@ class DCN(TFModel):
         })
         params = locals()
         self._h.update(**{k: params[k] for k in self._h.keys()})
-        if self._h.rounding not in ('soft-codebook', 'identity'):
-            raise NotImplementedError('latent rounding {} is not built (soft-codebook | identity)'.format(
-                self._h.rounding))
-        if self._h.latent_bpf > 6:
-            raise NotImplementedError('codebooks above 6 bits per feature are not built')
         self.patch_size = patch_size
         self._seed = seed
         self.x = _Shape((None, patch_size, patch_size, 3))
@@ -181,27 +176,29 @@ class _LazyDcnLoss(DeviceArray):
 class TwitterDCN(DCN):
 
     def construct_model(self, n_features=32, activation='leaky_relu'):
-        self._h.add({'n_features': (32, int, (4, 128)), 'activation': ('leaky_relu', str, {'leaky_relu'})})
+        self._h.add({'n_features': (32, int, (4, 128)),
+                     'activation': ('leaky_relu', str, set(ops.ACTIVATIONS))})        # helpers/tf_helpers.py:22-28 (compression.py:202)
         self._h.update(n_features=n_features, activation=activation)
         nf = self._h.n_features
+        act = self._h.activation
         if self.patch_size is None:
             self.latent_shape, self.n_latent = (None, None, nf), None
         else:
             self.latent_shape = (self.patch_size // 8, self.patch_size // 8, nf)
             self.n_latent = int(np.prod(self.latent_shape))
         L = OrderedDict()
-        L['e1'] = Conv5x5Stride2Image('e1', 5, 3, 64, 'leaky_relu', stride=2)
-        L['e2'] = Conv2D('e2', 5, 64, 128, None, stride=2)
+        L['e1'] = Conv5x5Stride2Image('e1', 5, 3, 64, act, stride=2)
+        L['e2'] = Conv2D('e2', 5, 64, 128, None, stride=2, mask_activation=act)
         for b in (1, 2, 3):
-            L['er{}a'.format(b)] = Conv2D('er{}a'.format(b), 3, 128, 128, 'leaky_relu')
-            L['er{}b'.format(b)] = Conv2D('er{}b'.format(b), 3, 128, 128, None)
+            L['er{}a'.format(b)] = Conv2D('er{}a'.format(b), 3, 128, 128, act)
+            L['er{}b'.format(b)] = Conv2D('er{}b'.format(b), 3, 128, 128, None, mask_activation=act)
         L['elat'] = Conv2D('elat', 5, 128, nf, None, stride=2)
         L['d512'] = Conv2D('d512', 3, nf, 512, None)
         for b in (1, 2, 3):
-            L['dr{}a'.format(b)] = Conv2D('dr{}a'.format(b), 3, 128, 128, 'leaky_relu')
-            L['dr{}b'.format(b)] = Conv2D('dr{}b'.format(b), 3, 128, 128, None)
-        L['d256'] = Conv2D('d256', 3, 128, 256, 'leaky_relu')
-        L['d12'] = Conv2D('d12', 3, 64, 12, None)
+            L['dr{}a'.format(b)] = Conv2D('dr{}a'.format(b), 3, 128, 128, act)
+            L['dr{}b'.format(b)] = Conv2D('dr{}b'.format(b), 3, 128, 128, None, mask_activation=act)
+        L['d256'] = Conv2D('d256', 3, 128, 256, act)
+        L['d12'] = Conv2D('d12', 3, 64, 12, None, mask_activation=act)
         self._layers = L
         specs = []
         for name in ('e1', 'e2', 'er1a', 'er1b', 'er2a', 'er2b', 'er3a', 'er3b', 'elat'):
@@ -226,8 +223,7 @@ class TwitterDCN(DCN):
         return '{}/{}'.format(super().model_code, '_'.join(s))
 
     # ------------------------------------------------------------------------------------------------------------
-    @staticmethod
-    def _bf16_inner():
+    def _bf16_inner(self):
         """Throughput mode: the tensors INSIDE a residual block - the activation between its two convolutions and that
         activation's gradient - live in HBM as bf16.  Their only consumers are convolution / weight-gradient operands (rounded to
         bf16 on the way to the matrix core anyway) and the LeakyReLU' sign test: the forward pass is bit-identical, the weight
@@ -240,7 +236,7 @@ class TwitterDCN(DCN):
         read and write the exact float32 tensor."""
         # the A/B switches that send the strided layers / depth-to-space epilogues down the unfused float32-output paths
         # (NIMG_NO_S2D_CONV, NIMG_NO_D2S_OUT) also switch the bf16 storage off: those paths hand back float32 tensors
-        return ops.COMPUTE == 'bf16' and ops.STORE_BF16 and ops.S2D_CONV and ops.D2S_EPILOGUE
+        return ops.COMPUTE == 'bf16' and ops.STORE_BF16 and ops.S2D_CONV and ops.D2S_EPILOGUE and self._h.activation == 'leaky_relu'
 
     @staticmethod
     def _operand(t, tb):
@@ -293,7 +289,9 @@ class TwitterDCN(DCN):
         count = t['zl'].numel()
         soft = self._h.rounding == 'soft-codebook'
         # (self._codebook is torch.arange(qmin, qmax + 1): consecutive integers - the unit_codebook promise of ops.latent_fwd)
+        rnd = 'identity' if soft else self._h.rounding            # identity | soft | sin (models/layers.py:118-134)
         lat, ent = ops.latent_fwd(t['zl'], P.p['latent_scaling'], self._codebook, self._lws, soft_codebook=soft, unit_codebook=True,
+                                  rounding=rnd,
                                   count_global=count * world, finalize=not dp)
         if dp:              # batch-global soft histogram: 2^bpf float64 sums are all-reduced (SURVEY 8e caveat 1)
             torch.distributed.all_reduce(self._lws.hist_sums())
@@ -360,7 +358,8 @@ class TwitterDCN(DCN):
         # ---- latent
         soft = self._h.rounding == 'soft-codebook'
         dzl = ops.latent_bwd(et['zl'], P.p['latent_scaling'], et['latent'], d_lat, entropy_coef, self._codebook,
-                             self._lws, dscale=P.g['latent_scaling'].view(1), soft_codebook=soft, unit_codebook=True)
+                             self._lws, dscale=P.g['latent_scaling'].view(1), soft_codebook=soft, unit_codebook=True,
+                             rounding='identity' if soft else self._h.rounding)
         # ---- encoder
         if 'n3s' in et:
             L['elat'].backward_params_s2d(P, et['n3s'], dzl)
@@ -376,7 +375,7 @@ class TwitterDCN(DCN):
             L['er{}a'.format(b)].backward_params(P, inp, dza)
             # block 1 was fed LeakyReLU(e2): its input gradient goes through that activation (mask by sign of e2)
             d_net = L['er{}a'.format(b)].backward_input(P, dza, hw(inp), act_mask=et['e2'] if b == 1 else None,
-                                                        residual=d_net, bf16_copy=bf)
+                                                        residual=d_net, bf16_copy=bf, mask_activation='leaky_relu')
             d_net, d_net_b = d_net if bf else (d_net, None)
         # e1's gradient only feeds matrix-core operands (e1's weight / input gradient): stored as bf16
         if 'e1s' in et:

@@ -33,7 +33,7 @@ class FAN(TFModel):
             'dropout': (0, float, (0, 1)),
             'use_gap': (False, bool, None),
             'n_dense': (2, int, (0, 16)),
-            'activation': ('leaky_relu', str, {'leaky_relu'}),
+            'activation': ('leaky_relu', str, set(ops.ACTIVATIONS)),          # helpers/tf_helpers.py:22-28 (forensics.py:55)
         })
         params = locals()
         self._h.update(**{k: params[k] for k in self._h.keys()})
@@ -56,17 +56,21 @@ class FAN(TFModel):
         self._convs = []
         cin, nf = 3, n_filters
         for i in range(self._h.n_convolutions):
-            self._convs.append(Conv2D('conv{}'.format(i + 1), self._h.kernel, cin, nf, 'leaky_relu'))
+            self._convs.append(Conv2D('conv{}'.format(i + 1), self._h.kernel, cin, nf, self._h.activation,
+                                      mask_activation=self._h.activation))
             cin, nf = nf, int(nf * self._h.n_fscale)
         nf = int(nf // self._h.n_fscale)
-        self._conv1x1 = Conv2D('conv1x1', 1, cin, nf, 'leaky_relu')
+        self._conv1x1 = Conv2D('conv1x1', 1, cin, nf, self._h.activation, mask_activation=self._h.activation)
+        # an activation the kernels do not fuse (relu, tanh, sigmoid, softsign): every layer runs unfused on float32 tensors -
+        # convolution, element-wise activation, MaxPool2D - and the backward pass takes the derivative from the stored outputs
+        self._generic_act = self._h.activation != 'leaky_relu'
         self._use_gap = bool(use_gap)
         feat = nf if use_gap else nf * (patch_size // 2 ** self._h.n_convolutions) ** 2
         # hidden Dense + LeakyReLU layers (Keras names dense, dense_1, ...; the classifier is the last Dense)
         self._hidden = []
         for i in range(self._h.n_dense):
             nf = int(nf // self._h.n_fscale)
-            self._hidden.append(Conv2D('dense' if i == 0 else 'dense_{}'.format(i), 1, feat, nf, 'leaky_relu'))
+            self._hidden.append(Conv2D('dense' if i == 0 else 'dense_{}'.format(i), 1, feat, nf, self._h.activation))
             feat = nf
         self._cls = 'dense' if self._h.n_dense == 0 else 'dense_{}'.format(self._h.n_dense)
         self._n_features = feat
@@ -145,7 +149,11 @@ class FAN(TFModel):
             rate = float(self._h.dropout)
             for li, d in enumerate(self._hidden):
                 w4 = P.p[d.name + '/kernel'].view(1, 1, d.cin, d.cout)
-                head_in = ops.conv2d(head_in, w4, P.p[d.name + '/bias'], act='leaky_relu')
+                if self._generic_act:
+                    head_in = ops.conv2d(head_in, w4, P.p[d.name + '/bias'])
+                    ops.activation(head_in, self._h.activation, out=head_in)
+                else:
+                    head_in = ops.conv2d(head_in, w4, P.p[d.name + '/bias'], act='leaky_relu')
                 t[d.name] = head_in                              # the activation (its sign gates LeakyReLU' backwards)
                 if training and rate > 0:
                     if self.dropout_masks is not None:
@@ -170,27 +178,35 @@ class FAN(TFModel):
         hw = lambda a: (a.shape[1], a.shape[2])
         a = t['conv1x1']
         # classifier backward; dz = gradient w.r.t. the PRE-activation of whatever fed the head (its LeakyReLU' applied)
+        gen = self._generic_act
+        act_bwd = (lambda g, y: ops.activation_bwd(g, y, self._h.activation, out=g)) if gen else ops.lrelu_bwd
         dz, loss = ops.fan_head_bwd(t['head_in'], t['gap'], P.p[self._cls + '/kernel'], t['dlogits'], t['loss_per'],
-                                    t['loss_scale'], P.g[self._cls + '/kernel'], P.g[self._cls + '/bias'])
+                                    t['loss_scale'], P.g[self._cls + '/kernel'], P.g[self._cls + '/bias'],
+                                    alpha=1.0 if gen else None)       # slope 1 = no derivative applied: done explicitly below
+        if gen and not ('feat' in t and self._hidden):
+            # the head was fed an activation (conv1x1's, directly or through Flatten): its derivative from the stored output
+            dz = act_bwd(dz.reshape(a.shape), a)
         if 'feat' in t:
             keep_scale = 1.0 / (1.0 - float(self._h.dropout))
             for i in range(len(self._hidden) - 1, -1, -1):
                 d = self._hidden[i]
                 if d.name + '/keep' in t:          # dz arrived w.r.t. the dropped tensor (x LeakyReLU' of its sign = the
                     dz = ops.mask_scale(dz.reshape(t[d.name].shape), t[d.name + '/keep'], keep_scale)   # activation's)
+                if gen:                            # derivative of this hidden layer's activation (the head / the layer above
+                    dz = act_bwd(dz.reshape(t[d.name].shape), t[d.name])                      # handed the plain gradient)
                 prev = self._hidden[i - 1].name if i > 0 else None
                 inp = t.get(prev + '/dropped', t[prev]) if i > 0 else t['feat']
                 ops.conv2d_wgrad(inp, dz, 1, dw=P.g[d.name + '/kernel'].view(1, 1, d.cin, d.cout),
                                  db=P.g[d.name + '/bias'])
                 w4 = P.p[d.name + '/kernel'].view(1, 1, d.cin, d.cout)
                 # hidden activations carry a LeakyReLU; the feature vector itself (GAP / Flatten output) does not
-                dz = ops.conv2d_dgrad(dz, w4, (1, 1), act_mask=t[prev] if i > 0 else None)
+                dz = ops.conv2d_dgrad(dz, w4, (1, 1), act_mask=t[prev] if (i > 0 and not gen) else None)
             if self._hidden:
                 # dz is now d loss / d feat (no activation applied yet): route it back into the 1x1-conv activation
                 if self._use_gap:
-                    dz = ops.lrelu_bwd(ops.avgpool_bwd(dz, a.shape[1]), a)
+                    dz = act_bwd(ops.avgpool_bwd(dz, a.shape[1]), a)
                 else:
-                    dz = ops.lrelu_bwd(dz.reshape(a.shape), a)
+                    dz = act_bwd(dz.reshape(a.shape).contiguous(), a)
             else:
                 dz = dz.reshape(a.shape)          # Flatten straight into the classifier: the head applied LReLU'(a)
         nconv = len(self._convs)
@@ -233,7 +249,9 @@ class FAN(TFModel):
                 as_bf16 = ops.COMPUTE == 'bf16' and ops.STORE_BF16 and conv.cout % 8 == 0 and conv.cin % 8 == 0
                 dz = ops.maxpool2_unpool(d_pool, t['idx{}'.format(i)], None, apply_mask=False, out_bf16=as_bf16)
             else:
-                dz = ops.maxpool2_bwd(d_pool, t['conv{}'.format(i)], None, apply_mask=True)
+                dz = ops.maxpool2_bwd(d_pool, t['conv{}'.format(i)], None, apply_mask=not gen)
+                if gen:
+                    dz = act_bwd(dz, t['conv{}'.format(i)])
             conv.backward_params(P, inp, dz)
             d_pool = conv.backward_input(P, dz, hw(inp), act_mask=prev_mask, out_bf16=g_bf16(i - 1))
         self._constrained.backward_params(P, t['x'], d_pool)

@@ -15,12 +15,27 @@ from .. import ops
 from ..helpers import kernels as hk
 
 
-class Conv2D(object):
-    """Conv2D(cout, ks, stride, 'SAME', activation) with (kh,kw,Cin,Cout) kernel + bias."""
+FUSED_ACTIVATIONS = (None, 'leaky_relu')       # what the convolution epilogues apply themselves; the other members of
+                                               # helpers/tf_helpers.activation_mapping (relu, tanh, sigmoid, softsign) run as an
+                                               # element-wise pass behind the (activation-free) convolution, on float32 tensors
 
-    def __init__(self, name, ks, cin, cout, activation=None, stride=1, cin2=0):
+
+def act_forward(y, activation):
+    """activation(y) in place for an activation the kernels do not fuse."""
+    if isinstance(y, tuple):                   # (out, bf16 copy): only the throughput-mode chains ask for copies
+        raise RuntimeError('a bf16 copy cannot be combined with activation {}'.format(activation))
+    return ops.activation(y, activation, out=y)
+
+
+class Conv2D(object):
+    """Conv2D(cout, ks, stride, 'SAME', activation) with (kh,kw,Cin,Cout) kernel + bias.
+    mask_activation: the activation of the layer that FEEDS this one - what an `act_mask` handed to backward_input stands for
+    (the models set it to their `activation` hyper-parameter; a call may override it)."""
+
+    def __init__(self, name, ks, cin, cout, activation=None, stride=1, cin2=0, mask_activation='leaky_relu'):
         self.name, self.ks, self.cin, self.cin2, self.cout = name, ks, cin, cin2, cout
         self.activation, self.stride = activation, stride
+        self.mask_activation = mask_activation
 
     def specs(self):
         return [(self.name + '/kernel', (self.ks, self.ks, self.cin + self.cin2, self.cout)),
@@ -39,13 +54,16 @@ class Conv2D(object):
         """residual: the skip tensor of a residual block, added to the layer's output in the same pass (ops.conv2d);
         bf16_copy: returns (out, bf16 copy of out or None); d2s_out / s2d_out: returns tf.nn.depth_to_space(out, 2) /
         tf.nn.space_to_depth(out, 2), see ops.conv2d."""
-        return ops.conv2d(x, store.p[self.name + '/kernel'], store.p[self.name + '/bias'], x2=x2,
-                          stride=self.stride, act=self.activation, out_bf16=out_bf16, residual=residual, bf16_copy=bf16_copy,
-                          d2s_out=d2s_out, copy_lrelu=copy_lrelu, s2d_out=s2d_out)
+        fused = self.activation in FUSED_ACTIVATIONS
+        y = ops.conv2d(x, store.p[self.name + '/kernel'], store.p[self.name + '/bias'], x2=x2,
+                       stride=self.stride, act=self.activation if fused else None, out_bf16=out_bf16, residual=residual,
+                       bf16_copy=bf16_copy, d2s_out=d2s_out, copy_lrelu=copy_lrelu, s2d_out=s2d_out)
+        # (an element-wise activation commutes with the depth_to_space / space_to_depth permutations of the output)
+        return y if fused else act_forward(y, self.activation)
 
     def can_pool(self, x):
         return self.stride == 1 and self.cin2 == 0 and self.ks in (3, 5) and self.cout % 4 == 0 and \
-            x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0
+            x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 and self.activation == 'leaky_relu'
 
     def forward_pool(self, store, x, want_idx=True, out_bf16=False):
         """conv -> activation -> MaxPool2D(2) in one pass; returns (pooled, argmax bytes)."""
@@ -67,7 +85,10 @@ class Conv2D(object):
 
     def forward_s2d(self, store, xs, bf16_copy=False, copy_lrelu=False):
         w3 = ops.s2d_conv_weights(store.p[self.name + '/kernel'])
-        return ops.conv2d(xs, w3, store.p[self.name + '/bias'], act=self.activation, bf16_copy=bf16_copy, copy_lrelu=copy_lrelu)
+        fused = self.activation in FUSED_ACTIVATIONS
+        y = ops.conv2d(xs, w3, store.p[self.name + '/bias'], act=self.activation if fused else None, bf16_copy=bf16_copy,
+                       copy_lrelu=copy_lrelu)
+        return y if fused else act_forward(y, self.activation)
 
     def backward_params_s2d(self, store, xs, dz):
         with ops.side_stream(xs, dz, key=store.g[self.name + '/kernel'].data_ptr()):
@@ -75,10 +96,24 @@ class Conv2D(object):
             ops.s2d_conv_weights_bwd(dw3, store.g[self.name + '/kernel'])
 
     def backward_input(self, store, dz, in_hw, act_mask=None, out=None, out2=None, out_bf16=False, residual=None,
-                       bf16_copy=False, s2d_out=False, mask_s2d=False):
+                       bf16_copy=False, s2d_out=False, mask_s2d=False, mask_activation=None):
         """residual: the gradient arriving over the block's skip connection, added in the same pass (stride-1 layers);
         bf16_copy: returns (gradient, bf16 copy of it or None); s2d_out: returns tf.nn.space_to_depth(gradient, 2) - the
-        gradient at the input of the depth_to_space layer that fed this one (stride-1 layers), see ops.conv2d."""
+        gradient at the input of the depth_to_space layer that fed this one (stride-1 layers), see ops.conv2d.
+        mask_activation: overrides the layer's (the codec's first block is fed tf.nn.leaky_relu whatever `activation` says)."""
+        kind = mask_activation or self.mask_activation
+        if act_mask is not None and kind not in FUSED_ACTIVATIONS:
+            # an activation the epilogues do not know: the plain gradient, its derivative taken from the stored output, then
+            # what the caller would have had fused behind it - float32 tensors (the models keep float32 storage in this case)
+            if out2 is not None or mask_s2d:
+                raise NotImplementedError('split / space-to-depth-stored masks with activation {}'.format(kind))
+            d = self.backward_input(store, dz, in_hw, out=out)
+            ops.activation_bwd(d, act_mask, kind, out=d)         # the mask = this layer's input activation, in d's layout
+            if residual is not None:
+                ops.add(residual, d, out=d)
+            if s2d_out:
+                d = ops.d2s_clip_bwd(d, 1.0)
+            return (d, None) if bf16_copy else d
         if self.stride == 2:
             d = ops.conv2d_dgrad_strided2(dz, store.p[self.name + '/kernel'], in_hw, act_mask=act_mask, out_bf16=out_bf16,
                                           mask_s2d=mask_s2d)
@@ -109,7 +144,10 @@ class Conv5x5Stride2Image(Conv2D):
             return self.forward(store, x0), x0
         xs = ops.s2d2_affine(x, a, b, cp=16)
         w3 = ops.s2d_conv_weights(store.p[self.name + '/kernel'], cp=16)
-        return ops.conv2d(xs, w3, store.p[self.name + '/bias'], act=self.activation, s2d_out=s2d_out, out_bf16=s2d_out), xs
+        fused = self.activation in FUSED_ACTIVATIONS
+        y = ops.conv2d(xs, w3, store.p[self.name + '/bias'], act=self.activation if fused else None, s2d_out=s2d_out,
+                       out_bf16=s2d_out)
+        return (y if fused else act_forward(y, self.activation)), xs
 
     def backward_params_image(self, store, ctx, dz):
         if ctx.dtype != torch.bfloat16:
@@ -146,7 +184,10 @@ class Conv2DTranspose2x2(object):
         ops.convt2x2_wgrad(x, dy, dw=store.g[self.name + '/kernel'], side=True)
         ops.bias_grad(dy, db=store.g[self.name + '/bias'], side=True)
 
-    def backward_input(self, store, dy, act_mask=None, out_bf16=False):
+    def backward_input(self, store, dy, act_mask=None, out_bf16=False, mask_activation='leaky_relu'):
+        if act_mask is not None and mask_activation not in FUSED_ACTIVATIONS:
+            d = ops.convt2x2_dgrad(dy, store.p[self.name + '/kernel'])
+            return ops.activation_bwd(d, act_mask, mask_activation, out=d)
         return ops.convt2x2_dgrad(dy, store.p[self.name + '/kernel'], act_mask=act_mask, out_bf16=out_bf16)
 
 

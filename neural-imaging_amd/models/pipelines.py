@@ -112,24 +112,25 @@ class UNet(NIPModel):
     def construct_model(self, **kwargs):
         self._h = paramspec.ParamSpec({
             'n_steps': (5, int, (2, 6)),
-            'activation': ('leaky_relu', str, {'leaky_relu'}),
+            'activation': ('leaky_relu', str, set(ops.ACTIVATIONS)),          # helpers/tf_helpers.py:22-28 (pipelines.py:179)
         })
         self._h.update(**kwargs)
         ns = self._h.n_steps
+        act = self._h.activation
         self._layers = OrderedDict()
         cin = self.in_channels
         for n in range(1, ns + 1):
             c = 32 * 2 ** (n - 1)
-            self._layers['ec{}1'.format(n)] = Conv2D('ec{}1'.format(n), 3, cin, c, 'leaky_relu')
-            self._layers['ec{}2'.format(n)] = Conv2D('ec{}2'.format(n), 3, c, c, 'leaky_relu')
+            self._layers['ec{}1'.format(n)] = Conv2D('ec{}1'.format(n), 3, cin, c, act, mask_activation=act)
+            self._layers['ec{}2'.format(n)] = Conv2D('ec{}2'.format(n), 3, c, c, act, mask_activation=act)
             cin = c
         for n in range(1, ns):
             c = 32 * 2 ** (ns - n - 1)
             self._layers['dct{}'.format(n)] = Conv2DTranspose2x2('dct{}'.format(n), cin, c)
-            self._layers['dc{}1'.format(n)] = Conv2D('dc{}1'.format(n), 3, c, c, 'leaky_relu', cin2=c)
-            self._layers['dc{}2'.format(n)] = Conv2D('dc{}2'.format(n), 3, c, c, 'leaky_relu')
+            self._layers['dc{}1'.format(n)] = Conv2D('dc{}1'.format(n), 3, c, c, act, cin2=c, mask_activation=act)
+            self._layers['dc{}2'.format(n)] = Conv2D('dc{}2'.format(n), 3, c, c, act, mask_activation=act)
             cin = c
-        self._layers['dc{}'.format(ns)] = Conv2D('dc{}'.format(ns), 3, cin, 12, None)
+        self._layers['dc{}'.format(ns)] = Conv2D('dc{}'.format(ns), 3, cin, 12, None, mask_activation=act)
         specs = [s for l in self._layers.values() for s in l.specs()]
         self._model = ParamStore(specs, self.device)
         gen = torch.Generator().manual_seed(self._seed)
@@ -142,8 +143,7 @@ class UNet(NIPModel):
     def model_code(self):
         return '{}_{}'.format(self.class_name, self._h.n_steps)
 
-    @staticmethod
-    def _store_bf16(x):
+    def _store_bf16(self, x):
         """Throughput mode keeps the UNet's internal activations and gradients in HBM as bf16 (like the FAN's): every consumer
         is a kernel that rounds them to bf16 MFMA operands, takes their sign (LeakyReLU') or their maximum (rounding is
         monotonic), so the FORWARD pass is bit-neutral and the level-1 / level-2 layers - HBM-bound at float32 - move half the
@@ -152,7 +152,8 @@ class UNet(NIPModel):
         have, so a few gradients take another window position than in the float32-stored path (and than tf's max-pool gradient);
         per-parameter cosine > 0.995 against the float32-stored run (tests/test_gpu_models.py::test_unet_bf16_storage).  The RAW input, the 12-channel output of the last convolution and the gradient that feeds the 4-channel
         weight-gradient kernel stay float32.  (forward() also asks for even sizes at every pooled level.)"""
-        return ops.COMPUTE == 'bf16' and ops.STORE_BF16 and x.is_cuda
+        return ops.COMPUTE == 'bf16' and ops.STORE_BF16 and x.is_cuda and self._h.activation == 'leaky_relu'
+        # (another activation runs as a float32 element-wise pass behind each convolution: float32 storage)
 
     writes_into = True            # forward(..., out=) develops straight into a caller's buffer (the workflow's class batch)
 
@@ -205,7 +206,8 @@ class UNet(NIPModel):
             d_skip[ns - n] = d_sk
             prev = t['dc{}2'.format(n - 1)]
             L['dct{}'.format(n)].backward_params(P, prev, d_up)
-            dz = L['dct{}'.format(n)].backward_input(P, d_up, act_mask=prev, out_bf16=sb)   # dZ of dc{n-1}2 / ec{ns}2
+            dz = L['dct{}'.format(n)].backward_input(P, d_up, act_mask=prev, out_bf16=sb,
+                                                     mask_activation=self._h.activation)          # dZ of dc{n-1}2 / ec{ns}2
         if on_decoder_done is not None:
             on_decoder_done()
         for n in range(ns, 0, -1):
@@ -217,7 +219,11 @@ class UNet(NIPModel):
             if n > 1:
                 d_pool = L['ec{}1'.format(n)].backward_input(P, dz1, hw(inp), out_bf16=sb)
                 prev = t['ec{}2'.format(n - 1)]
-                dz = ops.maxpool2_bwd(d_pool, prev, add=d_skip[n - 1], apply_mask=True, out=d_skip[n - 1])
+                if self._h.activation == 'leaky_relu':
+                    dz = ops.maxpool2_bwd(d_pool, prev, add=d_skip[n - 1], apply_mask=True, out=d_skip[n - 1])
+                else:           # route + skip sum, then the activation's derivative from its stored output
+                    dz = ops.maxpool2_bwd(d_pool, prev, add=d_skip[n - 1], apply_mask=False, out=d_skip[n - 1])
+                    ops.activation_bwd(dz, prev, self._h.activation, out=dz)
         ops.join_side_stream()
         return None
 

@@ -859,14 +859,15 @@ def fan_head_fwd(act, w, b, labels=None, loss_scale=1.0):
     return gap, probs, loss_per, dlogits
 
 
-def fan_head_bwd(act, gap, w, dlogits, loss_per, loss_scale, dw, db):
+def fan_head_bwd(act, gap, w, dlogits, loss_per, loss_scale, dw, db, alpha=None):
+    """alpha: slope of the LeakyReLU whose derivative the kernel applies to the gradient it returns (default 0.2; 1.0 = none)."""
     _f32(act, gap, w, dlogits, loss_per, dw, db)
     n, h, wd, c = act.shape
     k = w.shape[1]
     dact = torch.empty_like(act)
     loss = torch.empty((1,), dtype=torch.float32, device=act.device)
     _lib.call('nimg_fan_head_bwd', _p(act), _p(gap), _p(w), _p(dlogits), _p(loss_per), _p(dact), _p(dw), _p(db),
-              _p(loss), n, h * wd, c, k, float(loss_scale), LRELU_ALPHA, _stream())
+              _p(loss), n, h * wd, c, k, float(loss_scale), LRELU_ALPHA if alpha is None else float(alpha), _stream())
     return dact, loss
 
 
@@ -1214,15 +1215,25 @@ class LatentWorkspace(object):
         return self.buf.view(torch.float64)[1024 * self.k:1024 * self.k + self.k]
 
 
+LATENT_ROUNDING = {'identity': 0, 'soft': 1, 'sin': 2}       # bits 2-3 of the kernels' flag word when soft_codebook is off
+
+
+def _latent_flags(soft_codebook, unit_codebook, rounding):
+    if soft_codebook:
+        return 1 | (2 if unit_codebook else 0)
+    return (2 if unit_codebook else 0) | (LATENT_ROUNDING[rounding] << 2)
+
+
 def latent_fwd(z, scale, codebook, ws, v=50.0, gamma=25.0, soft_codebook=True, count_global=0, finalize=True,
-               unit_codebook=False):
+               unit_codebook=False, rounding='identity'):
     """unit_codebook: the caller's promise that codebook[k] = codebook[0] + k (include/nimg.h: the kernels then evaluate only
-    the centres whose weight can reach the float64 sums)."""
+    the centres whose weight can reach the float64 sums).  rounding (soft_codebook=False): identity | soft | sin
+    (models/layers.py:118-134)."""
     _f32(z, scale, codebook)
     latent = torch.empty_like(z)
     entropy = torch.empty((1,), dtype=torch.float32, device=z.device)
     _lib.call('nimg_latent_fwd', _p(z), _p(scale), _p(codebook), codebook.numel(), float(v), float(gamma),
-              (1 if soft_codebook else 0) | (2 if unit_codebook else 0), _p(latent), _p(entropy), z.numel(), int(count_global),
+              _latent_flags(soft_codebook, unit_codebook, rounding), _p(latent), _p(entropy), z.numel(), int(count_global),
               _p(ws.buf),
               ws.buf.numel(), 1 if finalize else 0, _stream())
     return latent, entropy
@@ -1233,11 +1244,11 @@ def latent_entropy_finalize(ws, count_global, entropy):
 
 
 def latent_bwd(z, scale, latent, dlatent, entropy_coef, codebook, ws, dscale=None, v=50.0, gamma=25.0,
-               soft_codebook=True, accumulate_dscale=False, unit_codebook=False):
+               soft_codebook=True, accumulate_dscale=False, unit_codebook=False, rounding='identity'):
     _f32(z, scale, latent, dlatent, codebook, dscale)
     dz = torch.empty_like(z)
     _lib.call('nimg_latent_bwd', _p(z), _p(scale), _p(latent), _p(dlatent), float(entropy_coef), _p(codebook),
-              codebook.numel(), float(v), float(gamma), (1 if soft_codebook else 0) | (2 if unit_codebook else 0), _p(dz),
+              codebook.numel(), float(v), float(gamma), _latent_flags(soft_codebook, unit_codebook, rounding), _p(dz),
               _p(dscale),
               1 if accumulate_dscale else 0, z.numel(), _p(ws.buf), ws.buf.numel(), _stream())
     return dz
@@ -1486,6 +1497,25 @@ def tanh_bwd(dy, y, out=None):
     _f32(dy, y, out)
     dx = torch.empty_like(dy) if out is None else out
     _lib.call('nimg_tanh_bwd', _p(dy), _p(y), _p(dx), dy.numel(), _stream())
+    return dx
+
+
+ACTIVATIONS = {'leaky_relu': 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3, 'softsign': 4}     # helpers/tf_helpers.py:22-28
+
+
+def activation(x, kind, out=None):
+    """activation_mapping[kind](x), element-wise (out may be x)."""
+    _f32(x, out)
+    y = torch.empty_like(x) if out is None else out
+    _lib.call('nimg_activation_fwd', _p(x), _p(y), x.numel(), ACTIVATIONS[kind], LRELU_ALPHA, _stream())
+    return y
+
+
+def activation_bwd(dy, y, kind, out=None):
+    """dy * activation'(.) taken from the stored output y (out may be dy)."""
+    _f32(dy, y, out)
+    dx = torch.empty_like(dy) if out is None else out
+    _lib.call('nimg_activation_bwd', _p(dy), _p(y), _p(dx), dy.numel(), ACTIVATIONS[kind], LRELU_ALPHA, _stream())
     return dx
 
 

@@ -50,13 +50,16 @@ def unet_init(seed=1234, in_channels=4, n_steps=5, dtype=torch.float64):
     return p
 
 
-def unet_forward(p, x, n_steps=5, return_tensors=False):
+def unet_forward(p, x, n_steps=5, return_tensors=False, activation='leaky_relu'):
+    """models/pipelines.py:175-226; `activation` is the constructor's (helpers/tf_helpers.py:22-28), applied behind every 3x3 layer
+    but the last."""
+    act = lambda v: T.activation(v, activation)
     t = OrderedDict()
     t['ep0'] = x
     for n in range(1, n_steps + 1):
-        a = T.leaky_relu(T.conv2d(t['ep{}'.format(n - 1)], p['ec{}1/kernel'.format(n)], p['ec{}1/bias'.format(n)]))
+        a = act(T.conv2d(t['ep{}'.format(n - 1)], p['ec{}1/kernel'.format(n)], p['ec{}1/bias'.format(n)]))
         t['ec{}1'.format(n)] = a
-        a = T.leaky_relu(T.conv2d(a, p['ec{}2/kernel'.format(n)], p['ec{}2/bias'.format(n)]))
+        a = act(T.conv2d(a, p['ec{}2/kernel'.format(n)], p['ec{}2/bias'.format(n)]))
         t['ec{}2'.format(n)] = a
         if n < n_steps:
             t['ep{}'.format(n)] = T.max_pool2(a)
@@ -65,9 +68,9 @@ def unet_forward(p, x, n_steps=5, return_tensors=False):
         up = T.conv2d_transpose_2x2(t['dc{}2'.format(n - 1)], p['dct{}/kernel'.format(n)], p['dct{}/bias'.format(n)])
         t['dct{}'.format(n)] = up
         cat = torch.cat([up, t['ec{}2'.format(n_steps - n)]], dim=-1)        # [upsampled, skip]  pipelines.py:211
-        a = T.leaky_relu(T.conv2d(cat, p['dc{}1/kernel'.format(n)], p['dc{}1/bias'.format(n)]))
+        a = act(T.conv2d(cat, p['dc{}1/kernel'.format(n)], p['dc{}1/bias'.format(n)]))
         t['dc{}1'.format(n)] = a
-        a = T.leaky_relu(T.conv2d(a, p['dc{}2/kernel'.format(n)], p['dc{}2/bias'.format(n)]))
+        a = act(T.conv2d(a, p['dc{}2/kernel'.format(n)], p['dc{}2/bias'.format(n)]))
         t['dc{}2'.format(n)] = a
     z = T.conv2d(t['dc{}2'.format(n_steps - 1)], p['dc{}/kernel'.format(n_steps)], p['dc{}/bias'.format(n_steps)])
     t['dc{}'.format(n_steps)] = z
@@ -98,25 +101,27 @@ def _dense_names(p):
     return sorted(names, key=lambda n: int(n.split('_')[1]) if '_' in n else 0)
 
 
-def fan_forward(p, x, n_convolutions=4, return_tensors=False, use_gap=True, dropout=0.0, dropout_masks=None):
+def fan_forward(p, x, n_convolutions=4, return_tensors=False, use_gap=True, dropout=0.0, dropout_masks=None,
+                activation='leaky_relu'):
     """models/forensics.py:62-90: constrained conv -> n x [conv + LReLU -> pool] -> 1x1 conv + LReLU -> GAP | Flatten ->
     hidden Dense + LReLU layers (n_dense) -> Dense softmax."""
+    act = lambda v: T.activation(v, activation)
     t = OrderedDict()
     mask = torch.tensor(tables.center_mask_2dfilter(5, 3), dtype=x.dtype)
     net = T.constrained_conv(x, p['constrained/kernel'], mask)
     t['constrained'] = net
     for i in range(n_convolutions):
-        net = T.leaky_relu(T.conv2d(net, p['conv{}/kernel'.format(i + 1)], p['conv{}/bias'.format(i + 1)]))
+        net = act(T.conv2d(net, p['conv{}/kernel'.format(i + 1)], p['conv{}/bias'.format(i + 1)]))
         t['conv{}'.format(i + 1)] = net
         net = T.max_pool2(net)
         t['pool{}'.format(i + 1)] = net
-    net = T.leaky_relu(T.conv2d(net, p['conv1x1/kernel'], p['conv1x1/bias']))
+    net = act(T.conv2d(net, p['conv1x1/kernel'], p['conv1x1/bias']))
     t['conv1x1'] = net
     feat = net.mean(dim=(1, 2)) if use_gap else net.reshape(net.shape[0], -1)       # Flatten is NHWC row-major
     t['gap'] = feat
     dn = _dense_names(p)
     for li, name in enumerate(dn[:-1]):
-        feat = T.leaky_relu(feat @ p[name + '/kernel'] + p[name + '/bias'])
+        feat = act(feat @ p[name + '/kernel'] + p[name + '/bias'])
         t[name] = feat
         if dropout_masks is not None:                    # Keras Dropout at training time (forensics.py:88), given mask
             feat = feat * dropout_masks[li].to(feat.dtype) / (1.0 - dropout)
@@ -146,17 +151,19 @@ def dcn_init(seed=777, n_features=32, dtype=torch.float64):
     return p
 
 
-def dcn_encode(p, x, latent_bpf=5, rounding='soft-codebook', v=50, gamma=25):
-    """compression.py:219-241. Returns (latent, entropy, pre-quantisation latent)."""
+def dcn_encode(p, x, latent_bpf=5, rounding='soft-codebook', v=50, gamma=25, activation='leaky_relu'):
+    """compression.py:219-241. Returns (latent, entropy, pre-quantisation latent).  `activation` replaces every layer activation
+    EXCEPT the tf.nn.leaky_relu in front of the first residual block (:224), which the reference hard-codes."""
+    act = lambda t_: T.activation(t_, activation)
     net = 2 * (x - 0.5)
-    net = T.leaky_relu(T.conv2d(net, p['e1/kernel'], p['e1/bias'], stride=2))
+    net = act(T.conv2d(net, p['e1/kernel'], p['e1/bias'], stride=2))
     net = T.conv2d(net, p['e2/kernel'], p['e2/bias'], stride=2)
     # block 1: fed LReLU(net), skip adds the PRE-activation net (compression.py:224-227)
-    r = T.leaky_relu(T.conv2d(T.leaky_relu(net), p['er1a/kernel'], p['er1a/bias']))
+    r = act(T.conv2d(T.leaky_relu(net), p['er1a/kernel'], p['er1a/bias']))
     r = T.conv2d(r, p['er1b/kernel'], p['er1b/bias'])
     net = net + r
     for b in (2, 3):
-        r = T.leaky_relu(T.conv2d(net, p['er{}a/kernel'.format(b)], p['er{}a/bias'.format(b)]))
+        r = act(T.conv2d(net, p['er{}a/kernel'.format(b)], p['er{}a/bias'.format(b)]))
         r = T.conv2d(r, p['er{}b/kernel'.format(b)], p['er{}b/bias'.format(b)])
         net = net + r
     z = T.conv2d(net, p['elat/kernel'], p['elat/bias'], stride=2)
@@ -170,21 +177,22 @@ def dcn_encode(p, x, latent_bpf=5, rounding='soft-codebook', v=50, gamma=25):
     return lat, ent, zs
 
 
-def dcn_decode(p, lat):
+def dcn_decode(p, lat, activation='leaky_relu'):
     """compression.py:245-271"""
+    act = lambda t_: T.activation(t_, activation)
     net = T.depth_to_space(T.conv2d(lat, p['d512/kernel'], p['d512/bias']), 2)
     for b in (1, 2, 3):
-        r = T.leaky_relu(T.conv2d(net, p['dr{}a/kernel'.format(b)], p['dr{}a/bias'.format(b)]))
+        r = act(T.conv2d(net, p['dr{}a/kernel'.format(b)], p['dr{}a/bias'.format(b)]))
         r = T.conv2d(r, p['dr{}b/kernel'.format(b)], p['dr{}b/bias'.format(b)])
         net = net + r
-    net = T.depth_to_space(T.leaky_relu(T.conv2d(net, p['d256/kernel'], p['d256/bias'])), 2)
+    net = T.depth_to_space(act(T.conv2d(net, p['d256/kernel'], p['d256/bias'])), 2)
     net = T.depth_to_space(T.conv2d(net, p['d12/kernel'], p['d12/bias']), 2)
     return T.clip_ste((net + 1) / 2)
 
 
 def dcn_forward(p, x, **kw):
     lat, ent, _ = dcn_encode(p, x, **kw)
-    return dcn_decode(p, lat), ent, lat
+    return dcn_decode(p, lat, activation=kw.get('activation', 'leaky_relu')), ent, lat
 
 
 def dcn_loss(x, y, ent, entropy_weight=250.0):

@@ -83,6 +83,21 @@ def leaky_relu(x, alpha=0.2):
     return torch.where(x > 0, x, alpha * x)
 
 
+def activation(x, kind='leaky_relu'):
+    """helpers/tf_helpers.py:22-28 `activation_mapping`: LeakyReLU(0.2) | relu | tanh | sigmoid | softsign (x / (1 + |x|))."""
+    if kind == 'leaky_relu':
+        return leaky_relu(x)
+    if kind == 'relu':
+        return torch.relu(x)
+    if kind == 'tanh':
+        return torch.tanh(x)
+    if kind == 'sigmoid':
+        return torch.sigmoid(x)
+    if kind == 'softsign':
+        return x / (1 + x.abs())
+    raise ValueError('unknown activation {}'.format(kind))
+
+
 def clip_ste(y):
     """stop_gradient(clip(y,0,1) - y) + y  (pipelines.py:223, compression.py:271)."""
     return (torch.clamp(y, 0, 1) - y).detach() + y

@@ -1490,3 +1490,159 @@ def test_full_channel_with_learned_codec_in_throughput_mode(dev):
                               (5, ('conv3/kernel', 'dense/kernel'))) for k in keys}
     floors = {'ec12/kernel': 0.7, 'dc42/kernel': 0.7}
     assert all(v > floors.get(k, 0.9) for k, v in found.items()), found
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the hyper-parameters the reference accepts beyond its defaults
+ACTS = ['relu', 'tanh', 'sigmoid', 'softsign']
+
+
+def test_activation_ops(dev):
+    """nimg_activation_fwd / _bwd: helpers/tf_helpers.py:22-28 `activation_mapping` element-wise, the derivative from the output."""
+    from neural_imaging_amd import ops
+    x = torch.from_numpy(np.random.RandomState(3).uniform(-3, 3, (2, 5, 7, 9)).astype(np.float32))       # 630 values: a scalar tail
+    gy = torch.from_numpy(np.random.RandomState(4).uniform(-1, 1, x.shape).astype(np.float32))
+    for kind in ['leaky_relu'] + ACTS:
+        xr = to64(x.numpy()).requires_grad_(True)
+        yr = T.activation(xr, kind)
+        (yr * to64(gy.numpy())).sum().backward()
+        y = ops.activation(x.to(dev), kind)
+        assert_close(y.cpu().numpy(), yr.detach().numpy(), 1e-6, 1e-6, what=kind)
+        dx = ops.activation_bwd(gy.to(dev), y, kind)
+        assert_close(dx.cpu().numpy(), xr.grad.numpy(), 2e-6, 1e-5, what=kind + ' derivative')
+        y2 = x.to(dev).clone()
+        assert ops.activation(y2, kind, out=y2) is y2 and torch.equal(y2, y)                 # in place
+    with pytest.raises(KeyError):
+        ops.activation(x.to(dev), 'gelu')
+
+
+@pytest.mark.parametrize('act', ACTS)
+def test_unet_activations(dev, act):
+    """UNet(activation=...) (models/pipelines.py:179-183): output, intermediate tensors and every parameter gradient against
+    the oracle for the four members of activation_mapping besides LeakyReLU."""
+    from neural_imaging_amd import ops
+    from neural_imaging_amd.models import pipelines
+    net = pipelines.UNet(patch_size=16, device=dev, n_steps=3, activation=act)
+    rgb = natural_images(2, 32, 32, seed=31)
+    raw = bayer_from_rgb(rgb)
+    p = oracle_params(net)
+    for v in p.values():
+        v.requires_grad_(True)
+    y_ref, t_ref = onets.unet_forward(p, to64(raw), n_steps=3, return_tensors=True, activation=act)
+    loss_ref = T.mse255(y_ref, to64(rgb))
+    g_ref = dict(zip(p.keys(), torch.autograd.grad(loss_ref, list(p.values()))))
+    for mode, tol_y, tol_g in (('f32', 1e-4, 3e-4), ('bf16', 3e-2, None)):
+        ops.set_compute(mode)
+        y, ctx = net.forward(torch.from_numpy(raw).to(dev), training=True)
+        assert_close(y.cpu().numpy(), y_ref.detach().numpy(), tol_y, what='UNet({}) output, {}'.format(act, mode))
+        loss, dy = ops.mse255(y, torch.from_numpy(rgb).to(dev), grad_scale=1.0)
+        net.backward(ctx, dy)
+        if tol_g is not None:
+            for name in ('ec11', 'ec22', 'dc11', 'dc22'):
+                assert_close(ctx[name].cpu().numpy(), t_ref[name].detach().numpy(), 1e-4, 1e-4, what=name)
+            check_grads(grads_of(net), g_ref, list(p.keys()), tol=tol_g)
+        else:           # throughput mode: float32-stored tensors, bf16 matrix operands - the gradients point the same way
+            got = grads_of(net)
+            for k in p:
+                a, b = got[k].ravel(), g_ref[k].numpy().ravel()
+                if np.linalg.norm(b) > 0 and a.size >= 16:
+                    assert float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)) > 0.98, (act, k)
+    with pytest.raises(ValueError):
+        pipelines.UNet(patch_size=16, device=dev, activation='gelu')
+
+
+@pytest.mark.parametrize('act', ACTS)
+@pytest.mark.parametrize('head', ['gap', 'dense'])
+def test_fan_activations(dev, act, head):
+    """FAN(activation=...) (models/forensics.py:55-59, 69, 76, 87) with the GAP head and with hidden Dense layers + dropout."""
+    from neural_imaging_amd.models import forensics
+    kw = dict(use_gap=True, n_dense=0) if head == 'gap' else dict(use_gap=False, n_dense=2, dropout=0.25)
+    fan = forensics.FAN(n_classes=5, patch_size=32, device=dev, n_convolutions=3, activation=act, **kw)
+    x = natural_images(5, 32, 32, seed=35)
+    labels = np.array([0, 1, 2, 3, 4], np.int32)
+    p = oracle_params(fan)
+    for v in p.values():
+        v.requires_grad_(True)
+    masks = None
+    if head == 'dense':
+        rng = np.random.RandomState(8)
+        masks = [torch.from_numpy((rng.uniform(size=(5, d.cout)) >= 0.25).astype(np.uint8)) for d in fan._hidden]
+        fan.dropout_masks = [m.clone() for m in masks]
+    xt = to64(x).requires_grad_(True)
+    probs_ref = onets.fan_forward(p, xt, n_convolutions=3, use_gap=kw['use_gap'], dropout=kw.get('dropout', 0.0),
+                                  dropout_masks=masks, activation=act)
+    loss_ref = T.sparse_ce_from_probs(probs_ref, labels)
+    gr = torch.autograd.grad(loss_ref, list(p.values()) + [xt])
+    g_ref = dict(zip(p.keys(), gr[:-1]))
+    probs, ctx = fan.forward(torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev), training=True)
+    assert_close(probs.cpu().numpy(), probs_ref.detach().numpy(), 1e-4, what='FAN({}) probabilities'.format(act))
+    loss, dx = fan.backward(ctx, need_input_grad=True)
+    assert abs(float(loss.item()) - float(loss_ref.detach())) < 1e-4
+    check_grads(grads_of(fan), g_ref, list(p.keys()), tol=1e-3)
+    assert_close(dx.cpu().numpy(), gr[-1].numpy(), 1e-7, 2e-3, what='FAN input gradient')
+
+
+@pytest.mark.parametrize('act', ACTS)
+def test_twitter_dcn_activations(dev, act):
+    """TwitterDCN(activation=...) (models/compression.py:197-215): every layer activation follows the hyper-parameter EXCEPT
+    the tf.nn.leaky_relu in front of the first residual block (:224)."""
+    from neural_imaging_amd import ops
+    from neural_imaging_amd.models import compression
+    dcn = compression.TwitterDCN(patch_size=32, device=dev, activation=act)
+    x = natural_images(2, 32, 32, seed=14)
+    p = onets.OrderedDict((k, to64(v)) for k, v in dcn.state_dict().items())
+    for v in p.values():
+        v.requires_grad_(True)
+    y_ref, ent_ref, lat_ref = onets.dcn_forward(p, to64(x), activation=act)
+    loss_ref = onets.dcn_loss(to64(x), y_ref, ent_ref, 250.0)
+    g_ref = dict(zip(p.keys(), torch.autograd.grad(loss_ref, list(p.values()))))
+    xt = torch.from_numpy(x).to(dev)
+    y, ent, ctx = dcn.forward(xt, training=True)
+    assert np.array_equal(np.round(ctx[0]['latent'].cpu().numpy()), np.round(lat_ref.detach().numpy()))
+    assert_close(y.cpu().numpy(), y_ref.detach().numpy(), 1e-4, what='DCN({}) reconstruction'.format(act))
+    assert abs(float(ent.item()) - float(ent_ref)) < 1e-5
+    _, dy = ops.l2_loss(xt, y, grad_scale=1.0)
+    dcn.backward(ctx, dy, entropy_coef=250.0)
+    check_grads(grads_of(dcn), g_ref, list(p.keys()), tol=1e-3)
+    ops.set_compute('bf16')                                    # throughput mode: runs (float32 storage), same reconstruction
+    yb, _, ctxb = dcn.forward(xt, training=True)
+    dcn.backward(ctxb, dy, entropy_coef=250.0)
+    assert float((yb - y).abs().max()) < 0.1 and all(torch.isfinite(v).all() for v in dcn._model.g.values())
+
+
+@pytest.mark.parametrize('rounding,bpf,nf', [('soft', 5, 32), ('sin', 5, 32), ('identity', 4, 16), ('soft-codebook', 7, 32),
+                                             ('soft-codebook', 8, 16), ('soft-codebook', 6, 64), ('soft', 8, 64),
+                                             ('soft-codebook', 3, 16)])
+def test_twitter_dcn_hyperparameters(dev, rounding, bpf, nf):
+    """The codec's hyper-parameter space (models/compression.py:53-59, config/twitter.csv: n_features 16 / 32 / 64): latent
+    rounding soft | sin | identity (models/layers.py:118-134) next to the soft codebook, codebooks of 3 .. 8 bits per feature
+    (8 .. 256 centres), 16 / 64 latent features - reconstruction, latent, entropy and all gradients against the oracle."""
+    from neural_imaging_amd import ops
+    from neural_imaging_amd.models import compression
+    dcn = compression.TwitterDCN(patch_size=32, device=dev, rounding=rounding, latent_bpf=bpf, n_features=nf)
+    assert dcn.get_codebook().size == 2 ** bpf and dcn.latent_shape == (4, 4, nf)
+    dcn._model.p['latent_scaling'].fill_(3.0)                  # spread the latent over several codebook entries
+    x = natural_images(2, 32, 32, seed=15)
+    p = onets.OrderedDict((k, to64(v)) for k, v in dcn.state_dict().items())
+    for v in p.values():
+        v.requires_grad_(True)
+    y_ref, ent_ref, lat_ref = onets.dcn_forward(p, to64(x), latent_bpf=bpf, rounding=rounding)
+    loss_ref = onets.dcn_loss(to64(x), y_ref, ent_ref, 250.0)
+    g_ref = dict(zip(p.keys(), torch.autograd.grad(loss_ref, list(p.values()))))
+    xt = torch.from_numpy(x).to(dev)
+    y, ent, ctx = dcn.forward(xt, training=True)
+    lat = ctx[0]['latent'].cpu().numpy()
+    if rounding in ('soft', 'soft-codebook'):
+        # hard values: equal wherever the float32 / float64 pre-quantisation values are not within 1e-4 of a rounding tie
+        zr = lat_ref.detach().numpy()
+        assert (np.round(lat) != np.round(zr)).mean() < 1e-3
+        keep = np.round(lat) == np.round(zr)
+    else:
+        assert_close(lat, lat_ref.detach().numpy(), 1e-4, 1e-4, what='latent ({})'.format(rounding))
+        keep = None
+    if keep is None or keep.all():
+        assert_close(y.cpu().numpy(), y_ref.detach().numpy(), 1e-4, what='reconstruction')
+        assert abs(float(ent.item()) - float(ent_ref)) < 2e-5
+        _, dy = ops.l2_loss(xt, y, grad_scale=1.0)
+        dcn.backward(ctx, dy, entropy_coef=250.0)
+        check_grads(grads_of(dcn), g_ref, list(p.keys()), tol=2e-3)
