@@ -419,9 +419,53 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
     // ---- epilogue, vector form: accumulators turned around through LDS so each lane stores 16 B along the channels
     if ((p.O1 & 3) == 0 && (p.O2 & 3) == 0) {
         float* elds = reinterpret_cast<float*>(smem_raw) + wave * (32 * (NI * 32 + EPI_PAD));
+        __syncthreads();                    // the scratch aliases the tiles: everyone is done reading them; from here on every
+                                            // wave works in its own region (wave-level ordering only)
+#ifndef NIMG_NO_EPI8
+        // bf16-stored outputs (and mask) in the plain layout - the UNet's and the codec's inner layers: eight channels per lane,
+        // 16-byte stores / mask loads (the store-issue rate, not the bytes, bounds a row-per-lane epilogue)
+        if ((p.flags & NIMG_BF16_OUT) && !(p.flags & (NIMG_D2S_OUT | NIMG_S2D_OUT)) && !p.res && !p.out1b &&
+            (!p.act1 || (p.flags & NIMG_BF16_MASK)) && (p.O1 & 7) == 0 && (p.O2 & 7) == 0) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                epilogue_via_lds8<NI>(acc[mi], elds, lane, [&](int row, int c, float4 lo, float4 hi) {
+                    const int co = co0 + wn * NI * 32 + c;
+                    if (co >= Cout) return;
+                    const int P = (wm * MI + mi) * 32 + row;
+                    const int img = P / (TH * TW), rem = P % (TH * TW);
+                    const int oy = ty0 + rem / TW, ox = tx0 + rem % TW, n = grp * NB + img;
+                    if (n >= p.N || oy >= p.Hout || ox >= p.Wout) return;
+                    const long pixoff = (KS == 1 && p.convt)
+                        ? ((long)n * 2 * p.Hout + 2 * oy + (phase >> 1)) * (2 * p.Wout) + 2 * ox + (phase & 1)
+                        : ((long)n * p.Hout + oy) * p.Wout + ox;
+                    float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    if (p.bias) {
+                        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + co), b1 = *reinterpret_cast<const float4*>(p.bias + co + 4);
+                        f[0] += b0.x; f[1] += b0.y; f[2] += b0.z; f[3] += b0.w; f[4] += b1.x; f[5] += b1.y; f[6] += b1.z; f[7] += b1.w;
+                    }
+                    if (p.act == 1) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] = lrelu(f[e], p.alpha);
+                    }
+                    if (co < p.O1) {
+                        const long o = pixoff * p.O1 + co;
+                        if (p.act1) {
+                            const bf16x8 m = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(p.act1) + o);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) f[e] *= (float)m[e] > 0.f ? 1.0f : p.alpha;
+                        }
+                        *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.out1) + o) = pack8(f);
+                    } else {
+                        *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.out2) + pixoff * p.O2 + (co - p.O1)) = pack8(f);
+                    }
+                });
+            }
+            return;
+        }
+#endif
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-            epilogue_via_lds<NI>(acc[mi], elds, lane, [&](int row, int c, float4 v) {
+            epilogue_via_lds<NI, false>(acc[mi], elds, lane, [&](int row, int c, float4 v) {
                 const int co = co0 + wn * NI * 32 + c;
                 if (co >= Cout) return;
                 const int P = (wm * MI + mi) * 32 + row;
