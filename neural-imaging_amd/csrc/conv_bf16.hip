@@ -154,6 +154,114 @@ __device__ __forceinline__ uint4 unp_route(uint4 g, unsigned k0, unsigned k1, un
                       g.z & __builtin_amdgcn_perm(m1, m1, 0x01010000u), g.w & __builtin_amdgcn_perm(m1, m1, 0x03030202u));
 }
 
+// Vector epilogue shared by the convolution kernels: the accumulators of a wave (MI x NI fragments of 32 pixels x 32 channels)
+// are turned around through the wave's LDS scratch so that each lane stores 16 B along the NHWC channel axis; bias, activation,
+// previous-layer LeakyReLU' mask, residual, bf16 copy and the depth_to_space / space_to_depth output layouts are applied on the
+// way (ConvParamsB).  Requires O1 % 4 == 0 and O2 % 4 == 0; contains one workgroup barrier (the scratch aliases the tiles).
+template <int KS, int TH, int TW, int NB, int MI, int NI>
+__device__ __forceinline__ void conv_epilogue_vec(const f32x16 (&acc)[MI][NI], const ConvParamsB& p, unsigned char* smem_raw,
+                                                  int wave, int lane, int wm, int wn, int co0, int Cout, int ty0, int tx0,
+                                                  int grp, int phase) {
+    float* elds = reinterpret_cast<float*>(smem_raw) + wave * (32 * (NI * 32 + EPI_PAD));
+    __syncthreads();                    // the scratch aliases the tiles: everyone is done reading them; from here on every
+                                        // wave works in its own region (wave-level ordering only)
+#ifndef NIMG_NO_EPI8
+    // bf16-stored outputs (and mask) in the plain layout - the UNet's and the codec's inner layers: eight channels per lane,
+    // 16-byte stores / mask loads (the store-issue rate, not the bytes, bounds a row-per-lane epilogue)
+    if ((p.flags & NIMG_BF16_OUT) && !(p.flags & (NIMG_D2S_OUT | NIMG_S2D_OUT)) && !p.res && !p.out1b &&
+        (!p.act1 || (p.flags & NIMG_BF16_MASK)) && (p.O1 & 7) == 0 && (p.O2 & 7) == 0) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            epilogue_via_lds8<NI>(acc[mi], elds, lane, [&](int row, int c, float4 lo, float4 hi) {
+                const int co = co0 + wn * NI * 32 + c;
+                if (co >= Cout) return;
+                const int P = (wm * MI + mi) * 32 + row;
+                const int img = P / (TH * TW), rem = P % (TH * TW);
+                const int oy = ty0 + rem / TW, ox = tx0 + rem % TW, n = grp * NB + img;
+                if (n >= p.N || oy >= p.Hout || ox >= p.Wout) return;
+                const long pixoff = (KS == 1 && p.convt)
+                    ? ((long)n * 2 * p.Hout + 2 * oy + (phase >> 1)) * (2 * p.Wout) + 2 * ox + (phase & 1)
+                    : ((long)n * p.Hout + oy) * p.Wout + ox;
+                float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                if (p.bias) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + co), b1 = *reinterpret_cast<const float4*>(p.bias + co + 4);
+                    f[0] += b0.x; f[1] += b0.y; f[2] += b0.z; f[3] += b0.w; f[4] += b1.x; f[5] += b1.y; f[6] += b1.z; f[7] += b1.w;
+                }
+                if (p.act == 1) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = lrelu(f[e], p.alpha);
+                }
+                if (co < p.O1) {
+                    const long o = pixoff * p.O1 + co;
+                    if (p.act1) {
+                        const bf16x8 m = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(p.act1) + o);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] *= (float)m[e] > 0.f ? 1.0f : p.alpha;
+                    }
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.out1) + o) = pack8(f);
+                } else {
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.out2) + pixoff * p.O2 + (co - p.O1)) = pack8(f);
+                }
+            });
+        }
+        return;
+    }
+#endif
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        epilogue_via_lds<NI, false>(acc[mi], elds, lane, [&](int row, int c, float4 v) {
+            const int co = co0 + wn * NI * 32 + c;
+            if (co >= Cout) return;
+            const int P = (wm * MI + mi) * 32 + row;
+            const int img = P / (TH * TW), rem = P % (TH * TW);
+            const int oy = ty0 + rem / TW, ox = tx0 + rem % TW, n = grp * NB + img;
+            if (n >= p.N || oy >= p.Hout || ox >= p.Wout) return;
+            const long pixoff = (KS == 1 && p.convt)
+                ? ((long)n * 2 * p.Hout + 2 * oy + (phase >> 1)) * (2 * p.Wout) + 2 * ox + (phase & 1)
+                : ((long)n * p.Hout + oy) * p.Wout + ox;
+            if (p.bias) {
+                const float4 b = *reinterpret_cast<const float4*>(p.bias + co);
+                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+            }
+            if (p.act == 1) {
+                v.x = lrelu(v.x, p.alpha); v.y = lrelu(v.y, p.alpha); v.z = lrelu(v.z, p.alpha); v.w = lrelu(v.w, p.alpha);
+            }
+            if (co < p.O1) {
+                long o = pixoff * p.O1 + co;
+                const long om_conv = o;            // NIMG_MASK_CONV: the mask keeps the convolution's own layout
+                if (p.flags & NIMG_D2S_OUT) {      // depth_to_space(2): channel block (2 dy + dx) of pixel (oy, ox) is pixel
+                    const int cd = p.O1 >> 2, blk = co / cd;                 // (2 oy + dy, 2 ox + dx) of the output
+                    o = (((long)n * 2 * p.Hout + 2 * oy + (blk >> 1)) * (2 * p.Wout) + 2 * ox + (blk & 1)) * cd + (co - blk * cd);
+                }
+                if (p.act1) {
+                    const long om = (p.flags & NIMG_MASK_CONV) ? om_conv : o;
+                    const float4 m = (p.flags & NIMG_BF16_MASK) ? load4_bf16(p.act1, om)
+                                                                : *reinterpret_cast<const float4*>(p.act1 + om);
+                    v.x *= m.x > 0.f ? 1.0f : p.alpha; v.y *= m.y > 0.f ? 1.0f : p.alpha;
+                    v.z *= m.z > 0.f ? 1.0f : p.alpha; v.w *= m.w > 0.f ? 1.0f : p.alpha;
+                }
+                if (p.res) {
+                    const float4 r = *reinterpret_cast<const float4*>(p.res + o);
+                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                }
+                if (p.flags & NIMG_S2D_OUT)        // space_to_depth(2): pixel (oy, ox) is channel block 2 (oy & 1) + (ox & 1) of
+                    o = (((long)n * (p.Hout >> 1) + (oy >> 1)) * (p.Wout >> 1) + (ox >> 1)) * (4 * p.O1) +    // pixel (oy/2, ox/2);
+                        (2 * (oy & 1) + (ox & 1)) * p.O1 + co;                  // mask and residual keep the convolution's layout
+                if (p.out1b) {
+                    float4 c = v;
+                    if (p.flags & NIMG_COPY_LRELU) { c.x = lrelu(c.x, p.alpha); c.y = lrelu(c.y, p.alpha); c.z = lrelu(c.z, p.alpha); c.w = lrelu(c.w, p.alpha); }
+                    store4_bf16(p.out1b, o, c);
+                }
+                if (p.flags & NIMG_BF16_OUT) store4_bf16(p.out1, o, v);
+                else *reinterpret_cast<float4*>(p.out1 + o) = v;
+            } else {
+                if (p.flags & NIMG_BF16_OUT) store4_bf16(p.out2, pixoff * p.O2 + (co - p.O1), v);
+                else *reinterpret_cast<float4*>(p.out2 + pixoff * p.O2 + (co - p.O1)) = v;
+            }
+        });
+    }
+}
+
 template <int KS, int STRIDE, int TH, int TW, int NB, int TN, bool INB, bool BUF = false, bool UNP = false, int CKT = 16>
 __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p) {
     // K chunk: 16 channels (one MFMA k-step per tap).  -DNIMG_CK32 stages 32 channels (two k-steps, half the barriers) for the
@@ -315,9 +423,16 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
                 preB[q] = *reinterpret_cast<const uint4*>(wchunk + (unsigned)((tap * Cout + co0 + j) * 16 + (h8 & 1) * 8));
         }
     };
+    // Diagnostic builds only (-DNIMG_GEN_ABLATE=<bits>, results are wrong): 1 no prefetch after the first chunk, 2 no commit (LDS
+    // writes) after the first chunk, 4 no barriers in the loop, 16 no epilogue stores.
+#ifndef NIMG_GEN_ABLATE
+#define NIMG_GEN_ABLATE 0
+#endif
+    constexpr int GABL = NIMG_GEN_ABLATE;
     fetch(0);
     for (int ci0 = 0; ci0 < Cin; ci0 += CK) {
-        __syncthreads();
+        if (!(GABL & 4) || ci0 == 0) __syncthreads();
+        if (!(GABL & 2) || ci0 == 0)
 #pragma unroll
         for (int q = 0; q < AP; ++q) {
             const int item = tid + q * 256;
@@ -340,6 +455,7 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
                                                                          // pixels, (pix >> 1) & 7 distinct inside each set
             }
         }
+        if (!(GABL & 2) || ci0 == 0)
 #pragma unroll
         for (int q = 0; q < BP; ++q) {
             const int item = tid + q * 256;
@@ -350,8 +466,8 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
                 else sB[row * 8 + (h8 ^ ((row >> 1) & 7))] = preB[q];
             }
         }
-        __syncthreads();
-        if (ci0 + CK < Cin) fetch(ci0 + CK);
+        if (!(GABL & 4) || ci0 == 0) __syncthreads();
+        if (ci0 + CK < Cin && !(GABL & 1)) fetch(ci0 + CK);
         // one kernel row unrolled: the next taps' ds_reads overlap the MFMAs.  The 32-channel tiles of the small kernels (the
         // UNet's deep and narrow layers: one or two workgroups per CU, nobody else to cover an LDS round trip) unroll ALL
         // taps - one exposed read latency per chunk instead of one per kernel row: ec42 / ec52 / dc11 -9 ... -13 %; the 64-channel
@@ -389,6 +505,17 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
             }
         }
     }
+    if constexpr ((GABL & 16) != 0) {          // keep the accumulators alive without storing them
+        float sacc = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) sacc += acc[mi][ni][j];
+        if (sacc == 123.456f) p.out1[0] = sacc;
+        return;
+    }
     // ---- epilogue, fused activation + 2x2 max-pool (16x16 tiles; the entry point guarantees even Hout/Wout, Cout % 4 == 0)
     if constexpr (TW == 16 && NB == 1 && STRIDE == 1) {
         if (p.pool_out) {
@@ -418,104 +545,7 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
     }
     // ---- epilogue, vector form: accumulators turned around through LDS so each lane stores 16 B along the channels
     if ((p.O1 & 3) == 0 && (p.O2 & 3) == 0) {
-        float* elds = reinterpret_cast<float*>(smem_raw) + wave * (32 * (NI * 32 + EPI_PAD));
-        __syncthreads();                    // the scratch aliases the tiles: everyone is done reading them; from here on every
-                                            // wave works in its own region (wave-level ordering only)
-#ifndef NIMG_NO_EPI8
-        // bf16-stored outputs (and mask) in the plain layout - the UNet's and the codec's inner layers: eight channels per lane,
-        // 16-byte stores / mask loads (the store-issue rate, not the bytes, bounds a row-per-lane epilogue)
-        if ((p.flags & NIMG_BF16_OUT) && !(p.flags & (NIMG_D2S_OUT | NIMG_S2D_OUT)) && !p.res && !p.out1b &&
-            (!p.act1 || (p.flags & NIMG_BF16_MASK)) && (p.O1 & 7) == 0 && (p.O2 & 7) == 0) {
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                epilogue_via_lds8<NI>(acc[mi], elds, lane, [&](int row, int c, float4 lo, float4 hi) {
-                    const int co = co0 + wn * NI * 32 + c;
-                    if (co >= Cout) return;
-                    const int P = (wm * MI + mi) * 32 + row;
-                    const int img = P / (TH * TW), rem = P % (TH * TW);
-                    const int oy = ty0 + rem / TW, ox = tx0 + rem % TW, n = grp * NB + img;
-                    if (n >= p.N || oy >= p.Hout || ox >= p.Wout) return;
-                    const long pixoff = (KS == 1 && p.convt)
-                        ? ((long)n * 2 * p.Hout + 2 * oy + (phase >> 1)) * (2 * p.Wout) + 2 * ox + (phase & 1)
-                        : ((long)n * p.Hout + oy) * p.Wout + ox;
-                    float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                    if (p.bias) {
-                        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + co), b1 = *reinterpret_cast<const float4*>(p.bias + co + 4);
-                        f[0] += b0.x; f[1] += b0.y; f[2] += b0.z; f[3] += b0.w; f[4] += b1.x; f[5] += b1.y; f[6] += b1.z; f[7] += b1.w;
-                    }
-                    if (p.act == 1) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) f[e] = lrelu(f[e], p.alpha);
-                    }
-                    if (co < p.O1) {
-                        const long o = pixoff * p.O1 + co;
-                        if (p.act1) {
-                            const bf16x8 m = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(p.act1) + o);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) f[e] *= (float)m[e] > 0.f ? 1.0f : p.alpha;
-                        }
-                        *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.out1) + o) = pack8(f);
-                    } else {
-                        *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.out2) + pixoff * p.O2 + (co - p.O1)) = pack8(f);
-                    }
-                });
-            }
-            return;
-        }
-#endif
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            epilogue_via_lds<NI, false>(acc[mi], elds, lane, [&](int row, int c, float4 v) {
-                const int co = co0 + wn * NI * 32 + c;
-                if (co >= Cout) return;
-                const int P = (wm * MI + mi) * 32 + row;
-                const int img = P / (TH * TW), rem = P % (TH * TW);
-                const int oy = ty0 + rem / TW, ox = tx0 + rem % TW, n = grp * NB + img;
-                if (n >= p.N || oy >= p.Hout || ox >= p.Wout) return;
-                const long pixoff = (KS == 1 && p.convt)
-                    ? ((long)n * 2 * p.Hout + 2 * oy + (phase >> 1)) * (2 * p.Wout) + 2 * ox + (phase & 1)
-                    : ((long)n * p.Hout + oy) * p.Wout + ox;
-                if (p.bias) {
-                    const float4 b = *reinterpret_cast<const float4*>(p.bias + co);
-                    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-                }
-                if (p.act == 1) {
-                    v.x = lrelu(v.x, p.alpha); v.y = lrelu(v.y, p.alpha); v.z = lrelu(v.z, p.alpha); v.w = lrelu(v.w, p.alpha);
-                }
-                if (co < p.O1) {
-                    long o = pixoff * p.O1 + co;
-                    const long om_conv = o;            // NIMG_MASK_CONV: the mask keeps the convolution's own layout
-                    if (p.flags & NIMG_D2S_OUT) {      // depth_to_space(2): channel block (2 dy + dx) of pixel (oy, ox) is pixel
-                        const int cd = p.O1 >> 2, blk = co / cd;                 // (2 oy + dy, 2 ox + dx) of the output
-                        o = (((long)n * 2 * p.Hout + 2 * oy + (blk >> 1)) * (2 * p.Wout) + 2 * ox + (blk & 1)) * cd + (co - blk * cd);
-                    }
-                    if (p.act1) {
-                        const long om = (p.flags & NIMG_MASK_CONV) ? om_conv : o;
-                        const float4 m = (p.flags & NIMG_BF16_MASK) ? load4_bf16(p.act1, om)
-                                                                    : *reinterpret_cast<const float4*>(p.act1 + om);
-                        v.x *= m.x > 0.f ? 1.0f : p.alpha; v.y *= m.y > 0.f ? 1.0f : p.alpha;
-                        v.z *= m.z > 0.f ? 1.0f : p.alpha; v.w *= m.w > 0.f ? 1.0f : p.alpha;
-                    }
-                    if (p.res) {
-                        const float4 r = *reinterpret_cast<const float4*>(p.res + o);
-                        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-                    }
-                    if (p.flags & NIMG_S2D_OUT)        // space_to_depth(2): pixel (oy, ox) is channel block 2 (oy & 1) + (ox & 1) of
-                        o = (((long)n * (p.Hout >> 1) + (oy >> 1)) * (p.Wout >> 1) + (ox >> 1)) * (4 * p.O1) +    // pixel (oy/2, ox/2);
-                            (2 * (oy & 1) + (ox & 1)) * p.O1 + co;                  // mask and residual keep the convolution's layout
-                    if (p.out1b) {
-                        float4 c = v;
-                        if (p.flags & NIMG_COPY_LRELU) { c.x = lrelu(c.x, p.alpha); c.y = lrelu(c.y, p.alpha); c.z = lrelu(c.z, p.alpha); c.w = lrelu(c.w, p.alpha); }
-                        store4_bf16(p.out1b, o, c);
-                    }
-                    if (p.flags & NIMG_BF16_OUT) store4_bf16(p.out1, o, v);
-                    else *reinterpret_cast<float4*>(p.out1 + o) = v;
-                } else {
-                    if (p.flags & NIMG_BF16_OUT) store4_bf16(p.out2, pixoff * p.O2 + (co - p.O1), v);
-                    else *reinterpret_cast<float4*>(p.out2 + pixoff * p.O2 + (co - p.O1)) = v;
-                }
-            });
-        }
+        conv_epilogue_vec<KS, TH, TW, NB, MI, NI>(acc, p, smem_raw, wave, lane, wm, wn, co0, Cout, ty0, tx0, grp, phase);
         return;
     }
 #pragma unroll
@@ -935,6 +965,170 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : (TN == 32 ? 3 : 2)) void con
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution over bf16-STORED activations (the UNet's and the codec's layers in throughput mode, forward and input
+// gradient) with BOTH operand tiles staged by LDS-DMA.  conv_fwd_bf16_kernel prefetches the next 16-channel chunk into registers
+// (3 + 5 ... 9 x 16 B per thread), writes it to LDS between two barriers per chunk and keeps ~40 VGPRs for it; on these layers
+// that staging is a quarter of the kernel's time (profiles/r04_j_conv3_ablation.txt: -24 % without prefetch / commit / barriers,
+// up to -42 % on the deep layers whose K loop is long and whose tiles are few).  Here the halo tile (16-byte items = one pixel's
+// 8 channels; padding = out-of-range offsets the hardware answers with zeros; the two tensors of a concatenated input are two
+// buffer descriptors chosen per chunk) and the weight tile ([tap][co] rows of 32 B, wb[chunk][tap][co][16]) of chunk c + 1 are
+// requested with buffer_load ... lds into the SECOND of two tile buffers while the matrix instructions of chunk c run: no staging
+// registers, no write pass, one barrier per chunk.  LDS images are lane-linear per 1 KB piece; the XOR swizzle of the 16-byte
+// halves (conflict-free ds_read_b128, as in the generic kernel) is applied on the source address.  Same tiles, fragment reads
+// and epilogue as conv_fwd_bf16_kernel<3, 1, TH, TW, NB, TN, true, ...>: the results are bit-identical.
+template <int TH, int TW, int NB, int TN>
+struct Dma3Geom {
+    static constexpr int THH = TH + 2, TWH = TW + 2, NPIXH = NB * THH * TWH;
+    static constexpr int A_PIECES = (NPIXH * 2 + 63) / 64, B_PIECES = 9 * TN * 2 / 64;
+    static constexpr int A_ENT = A_PIECES * 64, B_ENT = 9 * TN * 2;                     // uint4 entries of one buffer
+    static constexpr int APW = (A_PIECES + 3) / 4, BPW = (B_PIECES + 3) / 4;            // pieces per wave
+    static constexpr size_t LDS_TILES = (size_t)2 * (A_ENT + B_ENT) * sizeof(uint4);
+    static constexpr size_t LDS_EPI = (size_t)4 * 32 * (TN + EPI_PAD) * sizeof(float);
+    static constexpr size_t LDS = LDS_TILES > LDS_EPI ? LDS_TILES : LDS_EPI;
+};
+
+template <int TH, int TW, int NB, int TN>
+__global__ __launch_bounds__(256) void conv3_dma_kernel(const ConvParamsB p) {
+    using G = Dma3Geom<TH, TW, NB, TN>;
+    constexpr int THH = G::THH, TWH = G::TWH, NPIXH = G::NPIXH;
+    constexpr int MFRAGS = NB * TH * TW / 32, NFRAGS = TN / 32;
+    constexpr int WAVES_M = MFRAGS >= 4 ? 4 : MFRAGS, WAVES_N = 4 / WAVES_M;
+    constexpr int MI = MFRAGS / WAVES_M, NI = NFRAGS / WAVES_N;
+    static_assert(NI >= 1 && MFRAGS % WAVES_M == 0, "bad tile configuration");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint4* sA = reinterpret_cast<uint4*>(smem_raw);                  // [2][A_ENT] then [2][B_ENT]
+    uint4* sB = sA + 2 * G::A_ENT;
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)smem_raw;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+    const int Cin = p.C1 + p.C2, Cout = p.O1 + p.O2;
+    const int cot = (Cout + TN - 1) / TN;
+    int bid = xcd_order(blockIdx.x);
+    const int co0 = (bid % cot) * TN;
+    bid /= cot;
+    const int tiles = p.tiles_y * p.tiles_x;
+    const int tile = bid % tiles, grp = bid / tiles;
+    const int ty0 = (tile / p.tiles_x) * TH, tx0 = (tile % p.tiles_x) * TW;
+    const int iy0 = ty0 - p.pad_t, ix0 = tx0 - p.pad_l;
+    const int half = lane >> 5;
+
+    int abase[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int P = (wm * MI + mi) * 32 + (lane & 31);
+        const int img = P / (TH * TW), rem = P % (TH * TW);
+        abase[mi] = img * (THH * TWH) + (rem / TW) * TWH + (rem % TW);
+    }
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[mi][ni][j] = 0.0f;
+
+    // halo tile: piece k = wave + 4 j, lane l -> item 64 k + l = (pixel, 16-byte slot); the slot holds the channel half
+    // slot ^ (pixel >> 3 & 1).  The pixel's element index in the tensors is resolved once; per chunk only the scalar offset moves.
+    unsigned aoff1[G::APW], aoff2[G::APW];
+#pragma unroll
+    for (int j = 0; j < G::APW; ++j) {
+        const int item = (wave + 4 * j) * 64 + lane, pix = item >> 1;
+        const int h = (item & 1) ^ ((pix >> 3) & 1);
+        const int img = pix / (THH * TWH), rem = pix % (THH * TWH);
+        int gy = iy0 + rem / TWH, gx = ix0 + rem % TWH;
+        const int n = grp * NB + img;
+        const bool ok = (item < NPIXH * 2) & (n < p.N) & map_coord(gy, p.H, p.pad_mode) & map_coord(gx, p.W, p.pad_mode);
+        const unsigned apix = (unsigned)((n * p.H + gy) * p.W + gx);
+        aoff1[j] = ok ? (apix * (unsigned)p.C1 + 8u * h) * 2u : 0x80000000u;
+        aoff2[j] = ok ? (apix * (unsigned)p.C2 + 8u * h) * 2u : 0x80000000u;
+    }
+    const unsigned long a1 = (unsigned long)p.in1, a2 = (unsigned long)p.in2, wb_addr = (unsigned long)p.wb;
+    const long npx = (long)p.N * p.H * p.W;
+    const r_u32x4 ra1 = {(unsigned)a1, (unsigned)(a1 >> 32) & 0xffffu, (unsigned)(npx * p.C1 * 2), 0x00020000u};
+    const r_u32x4 ra2 = {(unsigned)a2, (unsigned)(a2 >> 32) & 0xffffu, (unsigned)(npx * p.C2 * 2), 0x00020000u};
+    const r_u32x4 rb = {(unsigned)wb_addr, (unsigned)(wb_addr >> 32) & 0xffffu,
+                        (unsigned)((long)(p.CinP >> 4) * 9 * 16 * Cout * 2), 0x00020000u};
+    // weights: piece k = (tap, 32-channel block) in tap-major order = rows 32 k .. 32 k + 31 of the [9 TN] x 32 B tile; lane l
+    // writes 16-byte position l: row l >> 1, which must hold half (l & 1) ^ (row >> 3 & 1)
+    const int bj = lane >> 1;
+    const unsigned bvoff = (unsigned)(((co0 + bj) * 16 + (((lane & 1) ^ ((lane >> 4) & 1)) * 8)) * 2);
+    constexpr int NB32 = TN / 32;
+    auto issue = [&](int c0, int buf) {
+        const bool first = c0 < p.C1;
+        const r_u32x4 ra = first ? ra1 : ra2;
+        const int soff = (first ? c0 : c0 - p.C1) * 2;
+#pragma unroll
+        for (int j = 0; j < G::APW; ++j) {
+            const int k = wave + 4 * j;
+            if (G::A_PIECES % 4 == 0 || k < G::A_PIECES)
+                glds16(ra, lds0 + (unsigned)((buf * G::A_ENT + k * 64) * 16), first ? aoff1[j] : aoff2[j], soff);
+        }
+        const int chunk = c0 >> 4;
+#pragma unroll
+        for (int j = 0; j < G::BPW; ++j) {
+            const int k = wave + 4 * j;
+            if (G::B_PIECES % 4 == 0 || k < G::B_PIECES) {
+                const int tap = k / NB32, nb = k % NB32;
+                // rows beyond Cout (a partial last channel tile) read the next tap's rows or run out of range (zeros): their
+                // products land in accumulator columns the epilogue never stores
+                glds16(rb, lds0 + (unsigned)((2 * G::A_ENT + buf * G::B_ENT + k * 64) * 16), bvoff,
+                       ((chunk * 9 + tap) * Cout + nb * 32) * 32);
+            }
+        }
+    };
+    issue(0, 0);
+    dma_wait();
+    __syncthreads();
+    for (int c0 = 0, buf = 0; c0 < Cin; c0 += 16, buf ^= 1) {
+        if (c0 + 16 < Cin) issue(c0 + 16, buf ^ 1);
+        const uint4* tA = sA + buf * G::A_ENT;
+        const uint4* tB = sB + buf * G::B_ENT;
+#pragma unroll(TN == 32 ? 3 : 1)
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tap = ky * 3 + kx, toff = ky * TWH + kx;
+                bf16x8 a[MI], b[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int pix = abase[mi] + toff;
+                    const uint4 v = tA[pix * 2 + (half ^ ((pix >> 3) & 1))];
+                    a[mi] = *reinterpret_cast<const bf16x8*>(&v);
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int row = tap * TN + (wn * NI + ni) * 32 + (lane & 31);
+                    const uint4 v = tB[row * 2 + (half ^ ((row >> 3) & 1))];
+                    b[ni] = *reinterpret_cast<const bf16x8*>(&v);
+                }
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            }
+        dma_wait();                                    // the next chunk has landed ...
+        __syncthreads();                               // ... and everyone is done with this one
+    }
+    conv_epilogue_vec<3, TH, TW, NB, MI, NI>(acc, p, smem_raw, wave, lane, wm, wn, co0, Cout, ty0, tx0, grp, 0);
+}
+
+template <int TH, int TW, int NB, int TN>
+int launch_conv3_dma(const ConvParamsB& p, hipStream_t stream) {
+    using G = Dma3Geom<TH, TW, NB, TN>;
+    ConvParamsB q = p;
+    q.tiles_y = cdiv(p.Hout, TH);
+    q.tiles_x = cdiv(p.Wout, TW);
+    const long blocks = (long)cdiv(p.O1 + p.O2, TN) * q.tiles_y * q.tiles_x * cdiv(p.N, NB);
+    auto kern = conv3_dma_kernel<TH, TW, NB, TN>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), G::LDS, stream, q);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
 template <int TN, int NW = 4>
 int launch_conv5_ring(const ConvParamsB& p, hipStream_t stream) {
     using G = RingGeom<TN, NW>;
@@ -963,6 +1157,23 @@ int launch_conv_b(const ConvParamsB& p, hipStream_t stream) {
         static const bool no_ck64 = getenv("NIMG_NO_CK64") != nullptr;
         if (!no_ck64 && (p.C1 + p.C2) % 64 == 0 && (p.C2 == 0 || p.C1 % 64 == 0))
             return launch_conv_b<KS, STRIDE, TH, TW, NB, TN, INB, false, 64>(p, stream);
+    }
+    if constexpr (INB && !BUF && KS == 3 && STRIDE == 1 && CKT == 16 && (TN == 32 || TN == 64)) {
+        // both tiles by LDS-DMA (conv3_dma_kernel): bf16-stored input(s) whose channel counts are whole 16-channel chunks, the
+        // vector epilogue's output shapes; descriptors cover < 2 GB tensors
+        static const bool no_dma = getenv("NIMG_NO_CONV3_DMA") != nullptr || getenv("NIMG_NO_BUFFER_LOADS") != nullptr;
+        const long px = (long)p.N * p.H * p.W;
+        const long w_bytes = (long)(p.CinP >> 4) * KS * KS * 16 * (p.O1 + p.O2) * 2;
+        // where it pays (profiles/r04_k_conv3_dma_ab.txt): the two-tensor inputs of the UNet's decoder (the register prefetch has
+        // no buffer-descriptor form for them) and the layers with a long K loop over small images (levels 3 - 5: -6 ... -13 %);
+        // the large-image layers with 2 - 4 chunks lose 10 - 20 % to the doubled LDS footprint (two instead of four
+        // workgroups per CU cover each other's prologue / epilogue)
+        static const long max_hw = getenv("NIMG_CONV3_DMA_MAXHW") ? atol(getenv("NIMG_CONV3_DMA_MAXHW")) : 1024;
+        const bool pays = p.C2 > 0 || (long)p.Hout * p.Wout <= max_hw;
+        if (!no_dma && pays && !p.convt && !p.in_idx && !p.pool_out && p.C1 % 16 == 0 && p.C2 % 16 == 0 && (p.O1 & 3) == 0 &&
+            (p.O2 & 3) == 0 && px * p.C1 * 2 < (1l << 31) - 65536 && px * p.C2 * 2 < (1l << 31) - 65536 &&
+            w_bytes < (1l << 31) - 65536)
+            return launch_conv3_dma<TH, TW, NB, TN>(p, stream);
     }
     if constexpr (INB && !BUF && (KS == 5 || KS == 3) && STRIDE == 1 && 128 % TN == 0) {
         static const bool no_buf = getenv("NIMG_NO_BUFFER_LOADS") != nullptr;
