@@ -164,6 +164,11 @@ class TrainDCN(Workload):
         self.x = torch.from_numpy(natural_images(self.batch, ps, ps, seed=1234 + rank)).to(dev)
         self.graph = False
         self.eager = lambda: self.dcn.training_step(self.x, learning_rate=1e-4, sync=False)
+        if self.args.graph and world_size() == 1 and not os.environ.get('NIMG_C3_EAGER'):
+            from neural_imaging_amd import graphs
+            self.runner = graphs.CapturedModelStep(self.dcn, self.x, learning_rate=1e-4)
+            self.graph = True
+            return self.runner.step
         return self.eager
 
     def dominant(self, dev):
@@ -184,6 +189,11 @@ class TrainNIP(Workload):
         self.bx, self.by = torch.from_numpy(raw).to(dev), torch.from_numpy(rgb).to(dev)
         self.graph = False
         self.eager = lambda: self.nip.training_step(self.bx, self.by, learning_rate=1e-4)
+        if self.args.graph and world_size() == 1:       # ~150 launches of 5 - 40 us: eager launches are bound by the host
+            from neural_imaging_amd import graphs
+            self.runner = graphs.CapturedModelStep(self.nip, self.bx, self.by, learning_rate=1e-4)
+            self.graph = True
+            return self.runner.step
         return self.eager
 
     def dominant(self, dev):
@@ -604,13 +614,15 @@ def main():
         # (profiles/r03_ae_graph_vs_eager.txt), on a loaded host it would be the other way round - so both are timed during the
         # warm-up (untimed part of the run) and the faster one runs the K timed steps
         launch_modes = {}
-        for name, fn in (('graph', step), ('eager', wl.eager)):
+        for name, fn in (('graph', step), ('eager', wl.eager)) * 2:      # twice, alternating; the better round of each counts
+            for _ in range(2):                                           # (the first eager steps after a capture re-grow scratch)
+                fn()
             torch.cuda.synchronize()
             t_m = time.perf_counter()
             for _ in range(max(args.warmup, 5)):
                 fn()
             torch.cuda.synchronize()
-            launch_modes[name] = 1e3 * (time.perf_counter() - t_m) / max(args.warmup, 5)
+            launch_modes[name] = min(launch_modes.get(name, 1e30), 1e3 * (time.perf_counter() - t_m) / max(args.warmup, 5))
         if launch_modes['eager'] < launch_modes['graph']:
             step, wl.graph = wl.eager, False
     nblk = 5 if args.steps >= 5 else 1
@@ -736,14 +748,22 @@ def main():
                     a2 = argparse.Namespace(**dict(vars(args), workload=key, batch=0))
                     w2 = WORKLOADS[key](a2)
                     step2 = w2.build(dev, rank)
-                    for _ in range(5):
-                        step2()
-                    torch.cuda.synchronize()
-                    t2 = time.perf_counter()
-                    for _ in range(30):
-                        step2()
-                    torch.cuda.synchronize()
-                    dt2 = (time.perf_counter() - t2) / 30
+
+                    def timed2(fn, n):
+                        for _ in range(5):
+                            fn()
+                        torch.cuda.synchronize()
+                        t2 = time.perf_counter()
+                        for _ in range(n):
+                            fn()
+                        torch.cuda.synchronize()
+                        return (time.perf_counter() - t2) / n
+                    dt2 = timed2(step2, 30)
+                    if getattr(w2, 'graph', False):          # both launch paths, the faster one is the figure (as for c4)
+                        dt2e = timed2(w2.eager, 30)
+                        line[key + '_eager_ms_per_step'] = 1e3 * dt2e
+                        line[key + '_graph_ms_per_step'] = 1e3 * dt2
+                        dt2 = min(dt2, dt2e)
                     w2.finish()
                     line[key + '_patches_per_s'] = w2.batch / dt2
                     line[key + '_ms_per_step'] = 1e3 * dt2

@@ -81,3 +81,61 @@ class CapturedStep(object):
         self.graph.replay()
         self.flow._step = self.t
         return self.out
+
+
+class CapturedModelStep(object):
+    """The stand-alone training step of ONE model - NIPModel.training_step(x, y) (train_nip.py -> training/pipeline.py:191-247),
+    DCN.training_step(x) (train_dcn.py), FAN.training_step(x, labels) - recorded into a HIP graph and replayed.  At the
+    reference's own batch sizes these steps are ~150 launches of 5 - 40 us: the host needs ~8 us per launch through Python +
+    ctypes, so the eager step is bound by the HOST (config 2: 1.8 ms per step for ~0.9 ms of kernel time); the replay is one call.
+
+    inputs: the positional batch tensors of training_step (device tensors; refill with load()).  kwargs go to training_step
+    unchanged (DCN: sync=False is forced - the captured step cannot read losses back).  Same restrictions as CapturedStep."""
+
+    def __init__(self, model, *inputs, learning_rate=1e-4, warmup=3, **kw):
+        if parallel.is_distributed():
+            raise RuntimeError('CapturedModelStep: the data-parallel step is not captured (RCCL launches stay eager)')
+        import inspect
+        if 'sync' in inspect.signature(model.training_step).parameters:
+            kw['sync'] = False
+        self.model, self.lr, self.kw = model, float(learning_rate), kw
+        dev = model.device
+        self.inputs = [t.detach().to(dev).clone().contiguous() for t in inputs]
+        self._rate_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        store = model._model
+        ops.begin_pin_log()
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            for _ in range(max(int(warmup), 1)):
+                model.training_step(*self.inputs, learning_rate=self.lr, **kw)
+        torch.cuda.current_stream(dev).wait_stream(s)
+        torch.cuda.synchronize(dev)
+        self.t = store.step
+        store.lr_t_dev = self._rate_dev
+        self.graph = torch.cuda.CUDAGraph()
+        try:
+            self._set_rate(self.t + 1)
+            with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
+                self.out = model.training_step(*self.inputs, learning_rate=self.lr, **kw)
+        finally:
+            store.lr_t_dev = None
+            self._pins = ops.end_pin_log()
+            lws = getattr(model, '_lws', None)
+            if lws is not None:
+                self._pins.append(lws)
+        store.step = self.t                   # the capture itself executed nothing
+
+    def _set_rate(self, t):
+        self._rate_dev.fill_(ops.adam_lr_t(self.lr, t))
+
+    def load(self, *inputs):
+        for dst, src in zip(self.inputs, inputs):
+            dst.copy_(src, non_blocking=True)
+
+    def step(self):
+        self.t += 1
+        self._set_rate(self.t)
+        self.graph.replay()
+        self.model._model.step = self.t
+        return self.out

@@ -43,6 +43,8 @@ class ParamStore(object):
             off += -(-n // align) * align
         self.m = self.v = None
         self.step = 0
+        self.lr_t_dev = None         # one-float device buffer with Keras Adam's bias-corrected rate: set by a captured step
+                                     # (graphs.CapturedModelStep) so that the recorded Adam launch never changes
         # bf16 images of every 4-D (convolution) kernel, rebuilt by one launch per step in throughput mode
         self.images = ops.WeightImages([t for t in self.p.values() if t.dim() == 4 and min(t.shape) > 0], device) \
             if torch.device(device).type == 'cuda' else None
@@ -71,7 +73,7 @@ class ParamStore(object):
             self.step += 1
             step = self.step
         ops.adam_step(self.flat, self.flat_grad, self.m, self.v, lr, step, grad_scale=grad_scale, skip_flag=skip_flag,
-                      lr_t_dev=lr_t_dev)
+                      lr_t_dev=lr_t_dev if lr_t_dev is not None else self.lr_t_dev)
 
 
 def glorot_uniform_(t, fan_in, fan_out, gen):

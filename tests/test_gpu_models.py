@@ -1270,6 +1270,42 @@ def test_captured_step_replays_the_eager_step(dev):
     assert captured._step == 5 and abs(float(runner._rate_dev.item()) - ops.adam_lr_t(1e-3, 5)) < 1e-10
 
 
+@pytest.mark.parametrize('family', ['nip', 'dcn'])
+def test_captured_model_step_replays_the_eager_step(dev, family):
+    """graphs.CapturedModelStep: NIPModel.training_step / DCN.training_step (configs 2 / 3) replayed from a HIP graph walk the
+    same weights as eager launches - same kernels in the same order (gradients bit-equal), Keras Adam's bias-corrected rate read
+    from device memory."""
+    from neural_imaging_amd import graphs, ops
+    from neural_imaging_amd.models import compression, pipelines
+    ops.set_compute('f32')
+    rgb = natural_images(2, 64, 64, seed=33)
+    if family == 'nip':
+        make = lambda: pipelines.UNet(patch_size=32, device=dev)
+        batch = (torch.from_numpy(bayer_from_rgb(rgb)).to(dev), torch.from_numpy(rgb).to(dev))
+    else:
+        make = lambda: compression.TwitterDCN(patch_size=64, device=dev)
+        batch = (torch.from_numpy(rgb).to(dev),)
+    eager, captured = make(), make()
+    kw = dict(sync=False) if family == 'dcn' else {}
+    for m in (eager, captured):
+        for _ in range(2):
+            m.training_step(*batch, learning_rate=1e-3, **kw)
+    assert torch.equal(eager._model.flat, captured._model.flat)
+    runner = graphs.CapturedModelStep(captured, *batch, learning_rate=1e-3, warmup=1)
+    eager.training_step(*batch, learning_rate=1e-3, **kw)                    # both: 3 eager steps so far
+    assert captured._model.step == 3 and (eager._model.flat - captured._model.flat).abs().max().item() <= 1e-7
+    eager.training_step(*batch, learning_rate=1e-3, **kw)
+    runner.step()
+    assert captured._model.step == 4
+    if family == 'nip':
+        assert torch.equal(eager._model.flat_grad, captured._model.flat_grad)
+    else:       # the codec's float64 histogram uses LDS atomics whose order is not fixed
+        assert (eager._model.flat_grad - captured._model.flat_grad).abs().max().item() <= 1e-5 * eager._model.flat_grad.abs().max().item()
+    assert (eager._model.flat - captured._model.flat).abs().max().item() <= 2e-6
+    runner.step()
+    assert captured._model.step == 5 and abs(float(runner._rate_dev.item()) - ops.adam_lr_t(1e-3, 5)) < 1e-10
+
+
 def test_captured_step_survives_workspace_regrowth(dev):
     """the graph holds raw addresses of buffers that live outside its pool (ops.Workspace scratch, the
     manipulations' filter-tap cache).  A LARGER eager step after the capture re-grows the workspaces and nine other strengths
