@@ -22,7 +22,7 @@ int nimg_internal_wgrad3_alltaps(const void* in1, int c1, const void* in2, int c
 // defined in conv_small.hip
 size_t nimg_internal_wgrad_tiny_bytes(int ks, int cin, int cout);
 int nimg_internal_conv_wgrad_tiny(const float* in, const float* dz, float* dw, int cin, int cout, int n, int h, int wd,
-                                  int ks, int pad, int pad_mode, int accumulate, void* workspace, hipStream_t s);
+                                  int ks, int pad, int pad_mode, int accumulate, void* workspace, hipStream_t s, bool bf16_ok);
 
 
 namespace {
@@ -1699,9 +1699,9 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
     const int cin = c1 + c2;
     if (workspace_bytes < nimg_conv2d_wgrad_bf16_workspace_bytes(cin, cout, ks, ks, n, hout, wout)) return NIMG_ERR_WORKSPACE;
     if (c2 == 0 && c1 == 3 && cout == 3 && stride == 1 && (ks == 3 || ks == 5) && hout == h && wout == wd &&
-        pad_t == (ks - 1) / 2 && pad_l == pad_t && !db)              // tiny filter: exact f32 VALU kernel in both modes
+        pad_t == (ks - 1) / 2 && pad_l == pad_t && !db)              // tiny filter: its own kernels (conv_small.hip)
         return nimg_internal_conv_wgrad_tiny(in1, dz, dw, c1, cout, n, h, wd, ks, pad_t, pad_mode, accumulate, workspace,
-                                             (hipStream_t)stream);
+                                             (hipStream_t)stream, true);          // throughput mode: bf16 matrix operands
     if (c2 == 0 && (c1 == 3 || c1 == 4) && stride == 1 && (ks == 3 || ks == 5)) {      // (tap, ci)-packed M dimension
         WgradParamsB q;
         q.in1 = in1; q.in2 = nullptr; q.dz = dz; q.dz_idx = dz_idx; q.partial = (float*)workspace; q.db_partial = nullptr;

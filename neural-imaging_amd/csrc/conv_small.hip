@@ -329,6 +329,139 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_c3k5_kernel(const TinyWPara
     }
 }
 
+// The same weight gradient on the matrix core (throughput mode).  The vector kernel above is VALU-bound: 225 FMAs per pixel,
+// 230 us for the 21 M pixels of a training step while its 504 MB would stream in ~100.  bf16 operands are what every other weight
+// gradient of the throughput mode multiplies (float32 accumulation; nothing here cancels like the filter's forward pass does).
+// All 225 weights are ONE 16 x 16 accumulator tile:
+//     D[m = (kx, ci)][n = (ky, co)] = sum over p = (v, x) of  A[m][p] B[p][n],
+//     A[(kx, ci)][(v, x)] = xp[v][x + kx][ci],   B[(v, x)][(ky, co)] = dz[v - ky][x][co]      (v = y + ky: padded row, 0 .. H + 3)
+// i.e. the kernel-row shift sits in the gradient operand (whole rows of a planar tile with a 4-row zero apron: aligned) and the
+// kernel-column shift in the input operand, which is staged as FIVE pre-shifted planar copies (a shift by one bf16 pixel would
+// otherwise misalign the 16-byte fragment reads): v_mfma_f32_16x16x32_bf16 with K = 32 consecutive pixels of a row, 15 x 15 of
+// the 16 x 16 tile used, one instruction per 32 pixels.  What is left is staging: float32 NHWC3 -> bf16 planes, two pixels per
+// lane packed into dwords (odd shifts take the neighbour lane's pixel by a wave shuffle).  A workgroup walks tiles of TR padded
+// rows x 64 columns; the next tile's loads are in flight during the current tile's staging + matrix work.
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    const __bf16 l = (__bf16)lo, h = (__bf16)hi;
+    return (unsigned)__builtin_bit_cast(unsigned short, l) | ((unsigned)__builtin_bit_cast(unsigned short, h) << 16);
+}
+
+template <int TR>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_c3k5_mfma_kernel(const TinyWParams p) {
+    constexpr int TC = 64, DR = TR + 4;                           // tile: TR padded rows x 64 columns; gradient rows incl. apron
+    constexpr int XROW = TC * 2, XPLANE = TR * XROW;              // bytes: one row / one (kx, ci) plane of the shifted input copies
+    constexpr int ZROW = TC * 2, ZPLANE = DR * ZROW;              // gradient planes (co)
+    constexpr int XBYTES = 15 * XPLANE, ZBYTES = 3 * ZPLANE;
+    constexpr int XQ = TR / 4, ZQ = (DR * 32 + 255) / 256, SPW = TR * 2 / 4;       // staging passes, matrix steps per wave
+    __shared__ __attribute__((aligned(16))) unsigned char smem[XBYTES + ZBYTES > 4096 ? XBYTES + ZBYTES : 4096];
+    unsigned char* sx = smem;
+    unsigned char* sz = smem + XBYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rows_p = p.H + 4;                                   // padded rows v
+    const int tiles_v = (rows_p + TR - 1) / TR, tiles_x = p.W / TC;
+    const long total = (long)p.N * tiles_v * tiles_x;
+
+    // staging roles.  Input: wave w stages padded rows w, w + 4, ... of the tile; lane j < 34 holds the pixel pair (2 j, 2 j + 1)
+    // of the 68 padded columns the five shifts need.  Gradient: DR rows x 32 pairs, item = tid + 256 q.
+    float px[XQ][6], pz[ZQ][6];
+    auto fetch = [&](long t) {
+        const int n = (int)(t / (tiles_v * tiles_x)), tile = (int)(t % (tiles_v * tiles_x));
+        const int v0 = (tile / tiles_x) * TR, x0 = (tile % tiles_x) * TC;
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int v = v0 + wave + 4 * q;
+            int gy = v - 2;
+            const bool oky = v < rows_p && lane < 34 && map_coord(gy, p.H, p.pad_mode);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                int gx = x0 + 2 * lane + e - 2;
+                const bool ok = oky && map_coord(gx, p.W, p.pad_mode);
+                const float* src = p.in + (((long)n * p.H + (ok ? gy : 0)) * p.W + (ok ? gx : 0)) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) px[q][3 * e + c] = ok ? src[c] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < ZQ; ++q) {
+            const int item = tid + 256 * q, r = item >> 5, j = item & 31;
+            const int gy = v0 - 4 + r, gx = x0 + 2 * j;
+            const bool ok = item < DR * 32 && (unsigned)gy < (unsigned)p.H;
+            const float* src = p.dz + (((long)n * p.H + (ok ? gy : 0)) * p.W + gx) * 3;      // the pair is 24 contiguous bytes
+#pragma unroll
+            for (int c = 0; c < 6; ++c) pz[q][c] = ok ? src[c] : 0.f;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int vr = wave + 4 * q;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const unsigned e = pack_bf16x2(px[q][c], px[q][3 + c]);              // padded columns 2 j, 2 j + 1
+                const unsigned nx = (unsigned)__shfl_down((int)e, 1, 64);            // the next pair (lane 33's is never used)
+                const unsigned o = (e >> 16) | (nx << 16);                            // padded columns 2 j + 1, 2 j + 2
+                // copy kx holds xp[..][x + kx]: tile column x = padded column - kx.  Even kx: pair j lands on dword j - kx / 2;
+                // odd kx: the (odd, even) pair starting at padded column 2 j + 1 lands on dword j - (kx - 1) / 2
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx) {
+                    const int d = lane - (kx >> 1);
+                    if (lane < 34 && d >= 0 && d < 32)
+                        *reinterpret_cast<unsigned*>(sx + (kx * 3 + c) * XPLANE + vr * XROW + d * 4) = (kx & 1) ? o : e;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < ZQ; ++q) {
+            const int item = tid + 256 * q, r = item >> 5, j = item & 31;
+            if (item < DR * 32) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    *reinterpret_cast<unsigned*>(sz + c * ZPLANE + r * ZROW + j * 4) = pack_bf16x2(pz[q][c], pz[q][3 + c]);
+            }
+        }
+    };
+    // fragment addresses: lane (i = lane & 15, kg = lane >> 4) reads the 8 pixels 8 kg .. 8 kg + 7 of a 32-pixel row segment of
+    // plane i (A: i = 3 kx + ci; B: i = 3 ky + co, i.e. gradient plane co at row vr - ky + 4).  i = 15 is the unused row / column
+    // of the tile: it reads plane 14's data, its products land in accumulator entries nobody stores.
+    const int fi = (lane & 15) < 15 ? (lane & 15) : 14, kg = lane >> 4;
+    const int a_lane = fi * XPLANE + kg * 16;
+    const int b_lane = (fi % 3) * ZPLANE + (4 - fi / 3) * ZROW + kg * 16;
+    f32x4w acc = {0.f, 0.f, 0.f, 0.f};
+    const long first = xcd_order(blockIdx.x);
+    if (first < total) fetch(first);
+    for (long t = first; t < total; t += gridDim.x) {
+        __syncthreads();                                   // the previous tile's fragment reads are done
+        commit();
+        __syncthreads();
+        if (t + gridDim.x < total) fetch(t + gridDim.x);
+        const int v0 = (int)((t % (tiles_v * tiles_x)) / tiles_x) * TR;
+#pragma unroll
+        for (int s8 = 0; s8 < SPW; ++s8) {                 // TR rows x 2 segments of 32 pixels, split over the four waves
+            const int step = wave * SPW + s8, vr = step >> 1, seg = step & 1;
+            if (v0 + vr < rows_p) {                        // wave-uniform: the last row tile of an image is partial
+                const bf16x8w a = *reinterpret_cast<const bf16x8w*>(sx + a_lane + vr * XROW + seg * 64);
+                const bf16x8w b = *reinterpret_cast<const bf16x8w*>(sz + b_lane + vr * ZROW + seg * 64);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+            }
+        }
+    }
+    // D[m][n]: lane holds rows m = 4 (lane >> 4) + r, column n = lane & 15.  The four waves' tiles are added in a fixed order.
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);           // [4 waves][16 m][16 n]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[r];
+    __syncthreads();
+    if (tid < 225) {
+        const int ky = tid / 45, rest = tid % 45, kx = rest / 9, ci = (rest / 3) % 3, co = rest % 3;
+        const int m = kx * 3 + ci, n = ky * 3 + co;
+        p.partial[(long)blockIdx.x * 225 + tid] = (red[m * 16 + n] + red[256 + m * 16 + n]) + (red[512 + m * 16 + n] + red[768 + m * 16 + n]);
+    }
+}
+
 // one wave per weight: lane l adds the partials l, l+64, ... in order, then a fixed-shape butterfly => deterministic
 __global__ __launch_bounds__(64) void tiny_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                          int count, int blocks, int accumulate) {
@@ -343,18 +476,28 @@ __global__ __launch_bounds__(64) void tiny_reduce_kernel(const float* __restrict
 
 constexpr int TINY_BLOCKS = 1024;
 
-size_t nimg_internal_wgrad_tiny_bytes(int ks, int cin, int cout) { return (size_t)TINY_BLOCKS * ks * ks * cin * cout * sizeof(float); }
+size_t nimg_internal_wgrad_tiny_bytes(int ks, int cin, int cout) { return (size_t)2 * TINY_BLOCKS * ks * ks * cin * cout * sizeof(float); }
 
 // internal entry used by the weight-gradient dispatchers; same-size output (stride 1, pad = (ks-1)/2), any pad mode
 int nimg_internal_conv_wgrad_tiny(const float* in, const float* dz, float* dw, int cin, int cout, int n, int h, int wd,
-                                  int ks, int pad, int pad_mode, int accumulate, void* workspace, hipStream_t s) {
+                                  int ks, int pad, int pad_mode, int accumulate, void* workspace, hipStream_t s, bool bf16_ok) {
     TinyWParams p;
     p.in = in; p.dz = dz; p.partial = (float*)workspace; p.N = n; p.H = h; p.W = wd; p.pad = pad; p.pad_mode = pad_mode;
     const bool c3k5 = ks == 5 && cin == 3 && cout == 3;
     p.tiles_y = cdiv(h, c3k5 ? 48 : 32); p.tiles_x = cdiv(wd, 32);
     const long total = (long)n * p.tiles_y * p.tiles_x;
-    const int blocks = (int)(total < TINY_BLOCKS ? total : TINY_BLOCKS);
-    if (c3k5) hipLaunchKernelGGL(conv_wgrad_c3k5_kernel, dim3(blocks), dim3(256), 0, s, p);
+    int blocks = (int)(total < TINY_BLOCKS ? total : TINY_BLOCKS);
+    // bf16_ok: the caller runs the throughput mode (bf16 matrix operands everywhere): the matrix-core form where the columns tile
+    static const bool no_mfma = getenv("NIMG_NO_C3K5_MFMA") != nullptr;
+    static const int tr8 = getenv("NIMG_C3K5_TR8") ? atoi(getenv("NIMG_C3K5_TR8")) : 0;
+    if (c3k5 && bf16_ok && !no_mfma && pad == 2 && wd % 64 == 0 && h >= 4) {
+        const int tr = tr8 ? 8 : 16;
+        const long tot2 = (long)n * ((h + 4 + tr - 1) / tr) * (wd / 64);
+        const long cap = tr8 ? 2 * TINY_BLOCKS : TINY_BLOCKS;
+        blocks = (int)(tot2 < cap ? tot2 : cap);
+        if (tr8) hipLaunchKernelGGL(conv_wgrad_c3k5_mfma_kernel<8>, dim3(blocks), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(conv_wgrad_c3k5_mfma_kernel<16>, dim3(blocks), dim3(256), 0, s, p);
+    } else if (c3k5) hipLaunchKernelGGL(conv_wgrad_c3k5_kernel, dim3(blocks), dim3(256), 0, s, p);
     else if (ks == 3 && cin == 3 && cout == 3) hipLaunchKernelGGL((conv_wgrad_tiny_kernel<3, 3, 3>), dim3(blocks), dim3(256), 0, s, p);
     else return NIMG_ERR_ARG;
     NIMG_CHECK_LAUNCH();

@@ -17,7 +17,7 @@
 // defined in conv_small.hip
 size_t nimg_internal_wgrad_tiny_bytes(int ks, int cin, int cout);
 int nimg_internal_conv_wgrad_tiny(const float* in, const float* dz, float* dw, int cin, int cout, int n, int h, int wd,
-                                  int ks, int pad, int pad_mode, int accumulate, void* workspace, hipStream_t s);
+                                  int ks, int pad, int pad_mode, int accumulate, void* workspace, hipStream_t s, bool bf16_ok);
 
 
 namespace {
@@ -407,7 +407,7 @@ int nimg_conv2d_wgrad(const float* in1, int c1, const float* in2, int c2, const 
     // tiny filters (Cin, Cout <= 4): one thread per weight, exact f32 (conv_small.hip)
     if (c2 == 0 && c1 == 3 && cout == 3 && stride == 1 && (ks == 3 || ks == 5) && hout == h && wout == wd &&
         pad_t == (ks - 1) / 2 && pad_l == pad_t && !db)
-        return nimg_internal_conv_wgrad_tiny(in1, dz, dw, c1, cout, n, h, wd, ks, pad_t, pad_mode, accumulate, workspace, s);
+        return nimg_internal_conv_wgrad_tiny(in1, dz, dw, c1, cout, n, h, wd, ks, pad_t, pad_mode, accumulate, workspace, s, false);
     // few input channels: (tap, ci)-packed M dimension
     if (c2 == 0 && (c1 == 3 || c1 == 4) && stride == 1 && (ks == 3 || ks == 5)) {
         const int ni = cout <= 32 ? 1 : 2;

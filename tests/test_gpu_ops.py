@@ -485,6 +485,33 @@ def test_cconv3_front_end_stencil(dev, shape):
     assert_close(dx.cpu().numpy(), ops.fold_pad(dpad, 2, 1).cpu().numpy(), 1e-3, 1e-5, what='vs pad-fold path')
 
 
+@pytest.mark.parametrize('shape', [(2, 64, 64), (1, 40, 128), (3, 13, 192), (2, 256, 256), (1, 6, 64)])
+def test_constrained_filter_wgrad_on_the_matrix_core(dev, shape):
+    """csrc/conv_small.hip conv_wgrad_c3k5_mfma_kernel (throughput mode): the 5x5x3x3 weight gradient of the ConstrainedConv2D
+    (SYMMETRIC pad, models/layers.py:56) as one 16 x 16 MFMA tile over bf16 operands - against the float64 oracle on the
+    bf16-rounded operands (only the float32 accumulation order differs) and against the exact float32 kernel of the parity mode."""
+    from neural_imaging_amd import ops
+    n, h, w = shape
+    x_np, dy_np = natural_images(n, h, w, seed=6), rnd((n, h, w, 3), 7)
+    xr, dr = _bf16_round(x_np), _bf16_round(dy_np)
+    k = to64(rnd((5, 5, 3, 3), 1)).requires_grad_(True)
+    y = T.conv2d(T.pad2d(xr, 2, 'SYMMETRIC'), k, None, 1, 'VALID')
+    (y * dr).sum().backward()
+    ref = k.grad.numpy()
+    ops.set_compute('bf16')
+    try:
+        dw = ops.conv2d_wgrad(g(x_np, dev), g(dy_np, dev), 5, pads=(2, 2), pad_mode=1)
+        assert_close(dw.cpu().numpy(), ref, 1e-6, 2e-5, what='c3k5 wgrad, matrix core')
+        dw2 = torch.full_like(dw, 1.0)
+        ops.conv2d_wgrad(g(x_np, dev), g(dy_np, dev), 5, pads=(2, 2), pad_mode=1, dw=dw2, accumulate=True)
+        assert_close((dw2 - 1.0).cpu().numpy(), ref, 1e-5, 2e-5, what='accumulate')
+    finally:
+        ops.set_compute('f32')
+    exact = ops.conv2d_wgrad(g(x_np, dev), g(dy_np, dev), 5, pads=(2, 2), pad_mode=1)          # float32 operands, VALU
+    scale = np.abs(exact.cpu().numpy()).max()
+    assert np.abs(dw.cpu().numpy() - exact.cpu().numpy()).max() <= 1.5e-2 * scale
+
+
 def _bf16_round(a):
     return torch.from_numpy(np.asarray(a, np.float32)).to(torch.bfloat16).double()
 
