@@ -352,7 +352,10 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 template <int TR>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_c3k5_mfma_kernel(const TinyWParams p) {
     constexpr int TC = 64, DR = TR + 4;                           // tile: TR padded rows x 64 columns; gradient rows incl. apron
-    constexpr int XROW = TC * 2, XPLANE = TR * XROW;              // bytes: one row / one (kx, ci) plane of the shifted input copies
+    // bytes: one row / one (kx, ci) plane of the shifted input copies.  A row carries 16 B in front of and behind its 64 pixels:
+    // the shifted copies of the 34 staged pairs land on dwords -2 .. 33 of a row - with the margin every store is in bounds
+    // and needs no predicate of its own (the margins are never read)
+    constexpr int XMARGIN = 16, XROW = TC * 2 + 2 * XMARGIN, XPLANE = TR * XROW;
     constexpr int ZROW = TC * 2, ZPLANE = DR * ZROW;              // gradient planes (co)
     constexpr int XBYTES = 15 * XPLANE, ZBYTES = 3 * ZPLANE;
     constexpr int XQ = TR / 4, ZQ = (DR * 32 + 255) / 256, SPW = TR * 2 / 4;       // staging passes, matrix steps per wave
@@ -399,19 +402,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_c3k5_mfma_kernel(const Tiny
 #pragma unroll
         for (int q = 0; q < XQ; ++q) {
             const int vr = wave + 4 * q;
+            unsigned e[3], o[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const unsigned e = pack_bf16x2(px[q][c], px[q][3 + c]);              // padded columns 2 j, 2 j + 1
-                const unsigned nx = (unsigned)__shfl_down((int)e, 1, 64);            // the next pair (lane 33's is never used)
-                const unsigned o = (e >> 16) | (nx << 16);                            // padded columns 2 j + 1, 2 j + 2
-                // copy kx holds xp[..][x + kx]: tile column x = padded column - kx.  Even kx: pair j lands on dword j - kx / 2;
-                // odd kx: the (odd, even) pair starting at padded column 2 j + 1 lands on dword j - (kx - 1) / 2
+                e[c] = pack_bf16x2(px[q][c], px[q][3 + c]);                           // padded columns 2 j, 2 j + 1
+                const unsigned nx = (unsigned)__shfl_down((int)e[c], 1, 64);          // the next pair (lane 33's is never used)
+                o[c] = (e[c] >> 16) | (nx << 16);                                      // padded columns 2 j + 1, 2 j + 2
+            }
+            // copy kx holds xp[..][x + kx]: tile column x = padded column - kx.  Even kx: pair j lands on dword j - kx / 2;
+            // odd kx: the (odd, even) pair starting at padded column 2 j + 1 lands on dword j - (kx - 1) / 2
+            if (lane < 34) {
+                unsigned char* row = sx + vr * XROW + XMARGIN + lane * 4;
 #pragma unroll
-                for (int kx = 0; kx < 5; ++kx) {
-                    const int d = lane - (kx >> 1);
-                    if (lane < 34 && d >= 0 && d < 32)
-                        *reinterpret_cast<unsigned*>(sx + (kx * 3 + c) * XPLANE + vr * XROW + d * 4) = (kx & 1) ? o : e;
-                }
+                for (int kx = 0; kx < 5; ++kx)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        *reinterpret_cast<unsigned*>(row + (kx * 3 + c) * XPLANE - (kx >> 1) * 4) = (kx & 1) ? o[c] : e[c];
             }
         }
 #pragma unroll
@@ -428,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_c3k5_mfma_kernel(const Tiny
     // plane i (A: i = 3 kx + ci; B: i = 3 ky + co, i.e. gradient plane co at row vr - ky + 4).  i = 15 is the unused row / column
     // of the tile: it reads plane 14's data, its products land in accumulator entries nobody stores.
     const int fi = (lane & 15) < 15 ? (lane & 15) : 14, kg = lane >> 4;
-    const int a_lane = fi * XPLANE + kg * 16;
+    const int a_lane = fi * XPLANE + XMARGIN + kg * 16;
     const int b_lane = (fi % 3) * ZPLANE + (4 - fi / 3) * ZROW + kg * 16;
     f32x4w acc = {0.f, 0.f, 0.f, 0.f};
     const long first = xcd_order(blockIdx.x);
@@ -489,7 +495,8 @@ int nimg_internal_conv_wgrad_tiny(const float* in, const float* dz, float* dw, i
     int blocks = (int)(total < TINY_BLOCKS ? total : TINY_BLOCKS);
     // bf16_ok: the caller runs the throughput mode (bf16 matrix operands everywhere): the matrix-core form where the columns tile
     static const bool no_mfma = getenv("NIMG_NO_C3K5_MFMA") != nullptr;
-    static const int tr8 = getenv("NIMG_C3K5_TR8") ? atoi(getenv("NIMG_C3K5_TR8")) : 0;
+    // 8-row tiles: 24 KB of LDS, six workgroups per CU cover each other's load latency (16-row tiles, three per CU: 180 us)
+    static const int tr8 = getenv("NIMG_C3K5_TR8") ? atoi(getenv("NIMG_C3K5_TR8")) : 1;
     if (c3k5 && bf16_ok && !no_mfma && pad == 2 && wd % 64 == 0 && h >= 4) {
         const int tr = tr8 ? 8 : 16;
         const long tot2 = (long)n * ((h + 4 + tr - 1) / tr) * (wd / 64);
