@@ -339,6 +339,10 @@ int nimg_conv2d_wgrad_bf16_unpool(const void* in, int cin, const void* g, const 
                                   int n, int h, int w_, int ks, int accumulate, void* workspace, size_t workspace_bytes,
                                   void* stream);
 
+/* The same 5x5, 3 -> 3 convolution with ZERO padding and bf16 matrix-core operands (float32 accumulation, float32 output): the
+ * main term of the ConstrainedConv2D input gradient in throughput mode (models/layers.py:56-57 backward; w = the flipped /
+ * transposed filter, nimg_conv_flip_weights).  wd % 64 == 0 (else NIMG_ERR_ARG: use nimg_cconv3). */
+int nimg_conv5c3_bf16(const float* in, const float* w, float* out, int n, int h, int wd, void* stream);
 /* ------------------------------------------------------------------------------------------------------------------
  * FAN front end (csrc/frontend.hip): ConstrainedConv2D, models/layers.py:56-57 (tf.pad SYMMETRIC + VALID conv2d) and the
  * first FAN convolution, models/forensics.py:69-70, as row-band kernels (float32 VALU stencil / bf16 MFMA).

@@ -117,6 +117,7 @@ PROTOTYPES = {
                                             c_int, c_int, c_float, c_int, P]),
     'nimg_conv2d_wgrad_bf16_unpool': (c_int, [P, c_int, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'nimg_cconv3': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    'nimg_conv5c3_bf16': (c_int, [P, P, P, c_int, c_int, c_int, P]),
     'nimg_cconv3_dgrad_border': (c_int, [P, P, P, c_int, c_int, c_int, P]),
     'nimg_conv1_pool_fwd_c4': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_float, c_int, P]),
     'nimg_conv1_wgrad_c4_workspace_bytes': (c_size_t, []),

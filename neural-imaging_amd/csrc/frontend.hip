@@ -799,6 +799,87 @@ int launch_conv1_pool(const void* c4, const float* w, const float* bias, void* p
     return NIMG_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// The zero-padded 5x5, 3 -> 3 convolution on the matrix core - the main term of the ConstrainedConv2D's input gradient in
+// throughput mode (bf16 operands, float32 accumulation, like every other input gradient there; the FORWARD filter stays on the
+// float32 stencil above: its -100 centre taps cancel against the rest, which bf16 inputs cannot carry).  cconv_kernel is bound
+// by VALU issue (225 FMAs per pixel, 168 us for the 21 M pixels of a step, 2.9 TB/s); here four horizontally adjacent output
+// pixels x 3 channels are the N dimension of v_mfma_f32_16x16x32_bf16 (12 of 16 columns), 16 such groups = 64 pixels of an
+// image row are M, and K = one window row: 8 input pixels x 4 channels ({c0, c1, c2, 0} bf16 pixels, 8 bytes) - the window of
+// group g starts at the even column 4 g - 2, so a lane's 8 K values are ONE aligned 16-byte LDS read.  The weights become five
+// banded (Toeplitz) 32 x 16 operands, one per kernel row, built once per wave in registers: five reads + five matrix
+// instructions per 64 output pixels; the result tile turns around through a 768-byte LDS row so that every lane stores one
+// pixel's 12 bytes.  What remains is the byte stream: 12 B in + 12 B out per pixel.
+typedef float f32x4c __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8c __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void conv5c3_mfma_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                           float* __restrict__ out, int N, int H, int W, int tiles_y) {
+    constexpr int TR = 16, TC = 64, HR = TR + 4, HC = TC + 8;            // halo tile: 20 rows x 72 c4 pixels (68 used)
+    __shared__ __attribute__((aligned(16))) uint2 tile[HR * HC];
+    __shared__ __attribute__((aligned(16))) float orow[4][TC * 3];       // per-wave output row
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = xcd_order(blockIdx.x);
+    const int tiles_x = W / TC;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y, n = bid / tiles_y;
+    const int y0 = ty * TR, x0 = tx * TC;
+    // stage the halo tile: float32 NHWC3 -> {c0, c1, c2, 0} bf16 pixels, zeros outside the image
+    for (int i = tid; i < HR * (TC + 4); i += 256) {
+        const int r = i / (TC + 4), c = i % (TC + 4);
+        const int gy = y0 - 2 + r, gx = x0 - 2 + c;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+            const float* src = in + (((long)n * H + gy) * W + gx) * 3;
+            v0 = src[0]; v1 = src[1]; v2 = src[2];
+        }
+        const __bf16 b0 = (__bf16)v0, b1 = (__bf16)v1, b2 = (__bf16)v2;
+        tile[r * HC + c] = make_uint2((unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16),
+                                      (unsigned)__builtin_bit_cast(unsigned short, b2));
+    }
+    // banded weight operands: lane (col = lane & 15 = 3 j + co, kg = lane >> 4) holds k = 8 kg .. 8 kg + 7 = window columns 2 kg,
+    // 2 kg + 1 x 4 channels; output pixel j of a group reads window column wc with tap kx = wc - j
+    const int col = lane & 15, kg = lane >> 4;
+    const int j = col / 3, co = col % 3;
+    bf16x8c bw[5];
+#pragma unroll
+    for (int wr = 0; wr < 5; ++wr)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int wc = 2 * kg + (e >> 2), ci = e & 3, kx = wc - j;
+            float v = 0.f;
+            if (col < 12 && ci < 3 && kx >= 0 && kx < 5) v = w[((wr * 5 + kx) * 3 + ci) * 3 + co];
+            bw[wr][e] = (__bf16)v;
+        }
+    __syncthreads();
+    const int g = lane & 15;                                               // A operand: pixel group g, window columns 2 kg, 2 kg + 1
+    const uint2* abase = tile + 4 * g + 2 * kg;
+#pragma unroll
+    for (int q = 0; q < TR / 4; ++q) {
+        const int r = wave + 4 * q;                                        // output row of the tile
+        f32x4c acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int wr = 0; wr < 5; ++wr) {
+            const uint4 v = *reinterpret_cast<const uint4*>(abase + (r + wr) * HC);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8c*>(&v), bw[wr], acc, 0, 0, 0);
+        }
+        // D[m = group][n = 3 j + co]: lane holds rows 4 (lane >> 4) + e, column lane & 15 -> float index 12 m + n of the row
+        __builtin_amdgcn_wave_barrier();
+        if (col < 12) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) orow[wave][12 * (4 * kg + e) + col] = acc[e];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int gy = y0 + r;
+        if (gy < H && lane < 48)               // the row's 64 pixels = 768 contiguous, 16-byte aligned bytes: 48 float4 stores
+            *reinterpret_cast<float4*>(out + (((long)n * H + gy) * W + x0) * 3 + 4 * lane) =
+                *reinterpret_cast<const float4*>(&orow[wave][4 * lane]);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -891,6 +972,17 @@ int nimg_cconv3(const float* in, const float* w, float* out_f32, void* out_c4, i
                                     : launch_cconv<64, 2>(p, (hipStream_t)stream);
         if (rc != NIMG_OK) return rc;
     }
+    return NIMG_OK;
+}
+
+int nimg_conv5c3_bf16(const float* in, const float* w, float* out, int n, int h, int wd, void* stream) {
+    if (n == 0) return NIMG_OK;
+    if (!in || !w || !out || n < 0 || h < 1 || wd < 64 || (wd & 63)) return NIMG_ERR_ARG;
+    const int tiles_y = (h + 15) / 16;
+    const long blocks = (long)n * tiles_y * (wd / 64);
+    if (blocks > 0x7fffffffL) return NIMG_ERR_ARG;
+    hipLaunchKernelGGL(conv5c3_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, w, out, n, h, wd, tiles_y);
+    NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }
 

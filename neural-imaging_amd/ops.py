@@ -930,6 +930,7 @@ def cconv3(x, w, pad_mode=1, out=None, want_f32=True, want_c4=False):
 # The row-band front-end kernels (csrc/frontend.hip) serve the FAN's standard first layer in throughput mode; NIMG_OLD_FRONTEND=1
 # keeps the generic small-channel kernels (A/B runs).
 FRONT_END = _os.environ.get('NIMG_OLD_FRONTEND') is None
+CCONV_DGRAD_MFMA = _os.environ.get('NIMG_NO_CCONV_DGRAD_MFMA') is None       # A/B switch
 # 5x5 stride-2 layers as 3x3 stride-1 layers over the space-to-depth image (throughput mode); NIMG_NO_S2D_CONV=1: the strided kernels
 S2D_CONV = _os.environ.get('NIMG_NO_S2D_CONV') is None
 # 5x5 input gradients of the fused conv + pool layers on the sparse matrix instruction (csrc/dgrad5s.hip): correct, but at
@@ -999,7 +1000,11 @@ def cconv3_dgrad(dy, nf):
     filter plus the mirror terms of the two outermost rows / columns."""
     _f32(dy, nf)
     n, h, wd, _ = dy.shape
-    dx, _ = cconv3(dy, flip_weights(nf), pad_mode=0)
+    if COMPUTE == 'bf16' and wd % 64 == 0 and CCONV_DGRAD_MFMA:      # throughput mode: the main term on the matrix core
+        dx = torch.empty_like(dy)
+        _lib.call('nimg_conv5c3_bf16', _p(dy), _p(flip_weights(nf)), _p(dx), n, h, wd, _stream())
+    else:
+        dx, _ = cconv3(dy, flip_weights(nf), pad_mode=0)
     _lib.call('nimg_cconv3_dgrad_border', _p(dy), _p(nf), _p(dx), n, h, wd, _stream())
     return dx
 

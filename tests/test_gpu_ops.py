@@ -512,6 +512,34 @@ def test_constrained_filter_wgrad_on_the_matrix_core(dev, shape):
     assert np.abs(dw.cpu().numpy() - exact.cpu().numpy()).max() <= 1.5e-2 * scale
 
 
+@pytest.mark.parametrize('shape', [(2, 24, 64), (1, 37, 128), (2, 256, 256), (1, 5, 192)])
+def test_cconv3_input_gradient_on_the_matrix_core(dev, shape):
+    """csrc/frontend.hip conv5c3_mfma_kernel (throughput mode): the main term of the ConstrainedConv2D input gradient as a banded
+    bf16 matrix product - against the float64 oracle of the whole gradient (SYMMETRIC-pad fold included) evaluated on the
+    bf16-rounded operands, and against the float32 stencil of the parity mode."""
+    from neural_imaging_amd import ops
+    n, h, w = shape
+    k = to64(ot.fan_residual_init() + 0.05 * rnd((5, 5, 3, 3), 1))
+    m = to64(ot.center_mask_2dfilter(5, 3))
+    nf64 = T.constrained_kernel(k, m)
+    nf = g(nf64.numpy(), dev)
+    dy_np = rnd((n, h, w, 3), 2)
+    x = to64(natural_images(n, h, w, seed=4)).requires_grad_(True)
+    y = T.conv2d(T.pad2d(x, 2, 'SYMMETRIC'), _bf16_round(nf64.numpy()), None, 1, 'VALID')
+    (y * _bf16_round(dy_np)).sum().backward()
+    exact = ops.cconv3_dgrad(g(dy_np, dev), nf)                    # float32 stencil
+    ops.set_compute('bf16')
+    try:
+        dx = ops.cconv3_dgrad(g(dy_np, dev), nf)
+    finally:
+        ops.set_compute('f32')
+    # interior: bf16 operands on both sides; the 2-pixel border adds the float32 mirror terms (nimg_cconv3_dgrad_border)
+    ref = x.grad.numpy()
+    assert_close(dx.cpu().numpy()[:, 2:-2, 2:-2], ref[:, 2:-2, 2:-2], 1e-4, 1e-5, what='matrix-core dgrad, interior')
+    scale = np.abs(exact.cpu().numpy()).max()
+    assert np.abs(dx.cpu().numpy() - exact.cpu().numpy()).max() <= 1.5e-2 * scale
+
+
 def _bf16_round(a):
     return torch.from_numpy(np.asarray(a, np.float32)).to(torch.bfloat16).double()
 
