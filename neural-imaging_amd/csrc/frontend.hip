@@ -814,6 +814,7 @@ int launch_conv1_pool(const void* c4, const float* w, const float* bias, void* p
 typedef float f32x4c __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8c __attribute__((ext_vector_type(8)));
 
+template <int ABL>      // diagnostic bits (wrong results): 1 no staging loads, 2 no output stores, 4 no matrix work
 __global__ __launch_bounds__(256) void conv5c3_mfma_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                            float* __restrict__ out, int N, int H, int W, int tiles_y) {
     constexpr int TR = 16, TC = 64, HR = TR + 4, HC = TC + 8;            // halo tile: 20 rows x 72 c4 pixels (68 used)
@@ -827,40 +828,56 @@ __global__ __launch_bounds__(256) void conv5c3_mfma_kernel(const float* __restri
     bid /= tiles_x;
     const int ty = bid % tiles_y, n = bid / tiles_y;
     const int y0 = ty * TR, x0 = tx * TC;
-    // stage the halo tile: float32 NHWC3 -> {c0, c1, c2, 0} bf16 pixels, zeros outside the image
-    for (int i = tid; i < HR * (TC + 4); i += 256) {
-        const int r = i / (TC + 4), c = i % (TC + 4);
+    // stage the halo tile: float32 NHWC3 -> {c0, c1, c2, 0} bf16 pixels, zeros outside the image.  All loads of a thread are issued
+    // before the first is used, from clamped addresses and without branches around them (a guarded load in a rolled loop makes
+    // hipcc wait for every element before it requests the next: the 252 MB input then costs 76 us on top of the rest)
+    constexpr int ITEMS = HR * (TC + 4), SQ = (ITEMS + 255) / 256;
+    float sv[SQ][3];
+    bool sok[SQ];
+#pragma unroll
+    for (int q = 0; q < SQ; ++q) {
+        const int i = tid + 256 * q, r = i / (TC + 4), c = i % (TC + 4);
         const int gy = y0 - 2 + r, gx = x0 - 2 + c;
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
-            const float* src = in + (((long)n * H + gy) * W + gx) * 3;
-            v0 = src[0]; v1 = src[1]; v2 = src[2];
+        sok[q] = !(ABL & 1) && i < ITEMS && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const float* src = in + (sok[q] ? (((long)n * H + gy) * W + gx) * 3 : 0L);
+        sv[q][0] = src[0]; sv[q][1] = src[1]; sv[q][2] = src[2];
+    }
+#pragma unroll
+    for (int q = 0; q < SQ; ++q) {
+        const int i = tid + 256 * q, r = i / (TC + 4), c = i % (TC + 4);
+        if (i < ITEMS) {
+            const __bf16 b0 = (__bf16)(sok[q] ? sv[q][0] : 0.f), b1 = (__bf16)(sok[q] ? sv[q][1] : 0.f), b2 = (__bf16)(sok[q] ? sv[q][2] : 0.f);
+            tile[r * HC + c] = make_uint2((unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16),
+                                          (unsigned)__builtin_bit_cast(unsigned short, b2));
         }
-        const __bf16 b0 = (__bf16)v0, b1 = (__bf16)v1, b2 = (__bf16)v2;
-        tile[r * HC + c] = make_uint2((unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16),
-                                      (unsigned)__builtin_bit_cast(unsigned short, b2));
     }
     // banded weight operands: lane (col = lane & 15 = 3 j + co, kg = lane >> 4) holds k = 8 kg .. 8 kg + 7 = window columns 2 kg,
-    // 2 kg + 1 x 4 channels; output pixel j of a group reads window column wc with tap kx = wc - j
+    // 2 kg + 1 x 4 channels; output pixel j of a group reads window column wc with tap kx = wc - j.  The 225 weights go through
+    // LDS (one coalesced load), the operands are built from there with clamped indices and selects - 40 guarded global loads
+    // per lane were 40 dependent round trips in front of every tile
+    __shared__ float sw[232];
+    if (tid < 225) sw[tid] = w[tid];
+    if (tid >= 225 && tid < 232) sw[tid] = 0.f;
     const int col = lane & 15, kg = lane >> 4;
     const int j = col / 3, co = col % 3;
+    __syncthreads();
     bf16x8c bw[5];
 #pragma unroll
     for (int wr = 0; wr < 5; ++wr)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int wc = 2 * kg + (e >> 2), ci = e & 3, kx = wc - j;
-            float v = 0.f;
-            if (col < 12 && ci < 3 && kx >= 0 && kx < 5) v = w[((wr * 5 + kx) * 3 + ci) * 3 + co];
+            const bool on = col < 12 && ci < 3 && kx >= 0 && kx < 5;
+            const float v = sw[on ? ((wr * 5 + kx) * 3 + ci) * 3 + co : 225];
             bw[wr][e] = (__bf16)v;
         }
-    __syncthreads();
     const int g = lane & 15;                                               // A operand: pixel group g, window columns 2 kg, 2 kg + 1
     const uint2* abase = tile + 4 * g + 2 * kg;
 #pragma unroll
     for (int q = 0; q < TR / 4; ++q) {
         const int r = wave + 4 * q;                                        // output row of the tile
         f32x4c acc = {0.f, 0.f, 0.f, 0.f};
+        if (!(ABL & 4))
 #pragma unroll
         for (int wr = 0; wr < 5; ++wr) {
             const uint4 v = *reinterpret_cast<const uint4*>(abase + (r + wr) * HC);
@@ -874,7 +891,7 @@ __global__ __launch_bounds__(256) void conv5c3_mfma_kernel(const float* __restri
         }
         __builtin_amdgcn_wave_barrier();
         const int gy = y0 + r;
-        if (gy < H && lane < 48)               // the row's 64 pixels = 768 contiguous, 16-byte aligned bytes: 48 float4 stores
+        if (!(ABL & 2) && gy < H && lane < 48) // the row's 64 pixels = 768 contiguous, 16-byte aligned bytes: 48 float4 stores
             *reinterpret_cast<float4*>(out + (((long)n * H + gy) * W + x0) * 3 + 4 * lane) =
                 *reinterpret_cast<const float4*>(&orow[wave][4 * lane]);
     }
@@ -981,7 +998,10 @@ int nimg_conv5c3_bf16(const float* in, const float* w, float* out, int n, int h,
     const int tiles_y = (h + 15) / 16;
     const long blocks = (long)n * tiles_y * (wd / 64);
     if (blocks > 0x7fffffffL) return NIMG_ERR_ARG;
-    hipLaunchKernelGGL(conv5c3_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, w, out, n, h, wd, tiles_y);
+    static const int abl = getenv("NIMG_C5C3_ABL") ? atoi(getenv("NIMG_C5C3_ABL")) : 0;
+    auto kern = abl == 1 ? conv5c3_mfma_kernel<1> : abl == 2 ? conv5c3_mfma_kernel<2> : abl == 4 ? conv5c3_mfma_kernel<4>
+              : abl == 3 ? conv5c3_mfma_kernel<3> : conv5c3_mfma_kernel<0>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, w, out, n, h, wd, tiles_y);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }
