@@ -383,9 +383,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_c3k5_mfma_kernel(const Tiny
             for (int e = 0; e < 2; ++e) {
                 int gx = x0 + 2 * lane + e - 2;
                 const bool ok = oky && map_coord(gx, p.W, p.pad_mode);
-                const float* src = p.in + (((long)n * p.H + (ok ? gy : 0)) * p.W + (ok ? gx : 0)) * 3;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) px[q][3 * e + c] = ok ? src[c] : 0.f;
+                // (clamped address, unconditional loads, select afterwards: a guarded load makes hipcc wait per element)
+                const float* src = p.in + (ok ? (((long)n * p.H + gy) * p.W + gx) * 3 : 0L);
+                const float l0 = src[0], l1 = src[1], l2 = src[2];
+                px[q][3 * e] = ok ? l0 : 0.f; px[q][3 * e + 1] = ok ? l1 : 0.f; px[q][3 * e + 2] = ok ? l2 : 0.f;
             }
         }
 #pragma unroll
@@ -393,9 +394,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_c3k5_mfma_kernel(const Tiny
             const int item = tid + 256 * q, r = item >> 5, j = item & 31;
             const int gy = v0 - 4 + r, gx = x0 + 2 * j;
             const bool ok = item < DR * 32 && (unsigned)gy < (unsigned)p.H;
-            const float* src = p.dz + (((long)n * p.H + (ok ? gy : 0)) * p.W + gx) * 3;      // the pair is 24 contiguous bytes
+            const float* src = p.dz + (ok ? (((long)n * p.H + gy) * p.W + gx) * 3 : 0L);      // the pair is 24 contiguous bytes
+            float l[6];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) pz[q][c] = ok ? src[c] : 0.f;
+            for (int c = 0; c < 6; ++c) l[c] = src[c];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) pz[q][c] = ok ? l[c] : 0.f;
         }
     };
     auto commit = [&]() {
