@@ -243,6 +243,21 @@ __device__ __forceinline__ void reduce_slabs(const float* __restrict__ partial, 
             if (i < c4) {
                 const float4* src = reinterpret_cast<const float4*>(partial) + i;
                 int k = seg;
+                // eight slabs requested before the first is added (two per round trip left the reduction waiting on memory
+                // latency: 16 dependent round trips for 512 slabs); the additions keep their order - a0 takes slabs k, k + 32,
+                // ..., a1 the ones in between - so the sums are bit-identical to the two-at-a-time loop
+#ifndef NIMG_SLABS_PIPE_OFF
+                for (; k + 112 < splits; k += 128) {
+                    float4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = src[(long)(k + 16 * u) * c4];
+#pragma unroll
+                    for (int u = 0; u < 8; u += 2) {
+                        a0.x += v[u].x; a0.y += v[u].y; a0.z += v[u].z; a0.w += v[u].w;
+                        a1.x += v[u + 1].x; a1.y += v[u + 1].y; a1.z += v[u + 1].z; a1.w += v[u + 1].w;
+                    }
+                }
+#endif
                 for (; k + 16 < splits; k += 32) {
                     const float4 v0 = src[(long)k * c4], v1 = src[(long)(k + 16) * c4];
                     a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
