@@ -623,33 +623,34 @@ __device__ __forceinline__ void dma_wait_leave() { asm volatile("s_waitcnt vmcnt
 // ALL of them from L2, and the stream is what the main loop loses most to (profiles/r04_b_ring_ablation.txt: without the
 // weight DMA the TN = 128 layers run 20 - 26 % faster, without the input fetch 6 %): doubling the pixels per workgroup halves
 // the DMA pieces and the L2 bytes per matrix instruction.
-template <int TN, int NW = 4>
+template <int TN, int NW = 4, int KS = 5>
 struct RingGeom {
     static constexpr int NI = TN / 32, MI = NI == 1 ? 4 : 8 / NI;   // fragment block of a wave (NW waves stacked along the pixels)
     static constexpr int NT = 64 * NW;
-    static constexpr int TH = 2 * NW * MI, TW = 16, THH = TH + 4, TWH = TW + 4;
+    static constexpr int TH = 2 * NW * MI, TW = 16, THH = TH + KS - 1, TWH = TW + KS - 1;
     static constexpr int NPIXH = THH * TWH, AP = (NPIXH * 2 + NT - 1) / NT;
     static constexpr int PLSZ = THH * 32;                    // uint4 entries of one k-half plane of the halo tile
     static constexpr int ABUF = 2 * PLSZ;                    // one A buffer
     static constexpr bool ADBL = TN == 128;                  // two A buffers
-    static constexpr int SLOT = 5 * TN * 2;                  // one ring slot: [5 taps x TN co][2 halves]
-    static constexpr int PIECES = 5 * NI, NPW = (PIECES + NW - 1) / NW;   // 1 KB DMA pieces per kernel row, per wave
+    static constexpr int SLOT = KS * TN * 2;                 // one ring slot: [KS taps x TN co][2 halves]
+    static constexpr int PIECES = KS * NI, NPW = (PIECES + NW - 1) / NW;   // 1 KB DMA pieces per kernel row, per wave
     // ring depth.  3 (with NW = 8, where the LDS of the one resident workgroup has the room): the row requested in phase r is
     // needed in phase r + 2, so the wait at the end of a phase leaves the youngest row's transfers in flight (counted vmcnt)
     // instead of draining the queue - a weight row gets two phases to arrive from L2 instead of one.
 #ifdef NIMG_RING_SLOTS2
     static constexpr int NSLOT = 2;
 #else
-    static constexpr int NSLOT = NW == 8 ? 3 : 2;
+    static constexpr int NSLOT = (NW == 8 && KS == 5) ? 3 : 2;
 #endif
     static constexpr size_t LDS_TILES = (size_t)(NSLOT * SLOT + (ADBL ? 2 : 1) * ABUF) * sizeof(uint4);
     static constexpr size_t LDS_EPI = (size_t)NW * 32 * (TN + EPI_PAD) * sizeof(float);
     static constexpr size_t LDS = LDS_TILES > LDS_EPI ? LDS_TILES : LDS_EPI;
 };
 
-template <int TN, bool UNP, int NW = 4>
+template <int TN, bool UNP, int NW = 4, int KS = 5>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : (TN == 32 ? 3 : 2)) void conv5_ring_kernel(const ConvParamsB p) {
-    using G = RingGeom<TN, NW>;
+    using G = RingGeom<TN, NW, KS>;
+    static_assert(KS == 5 || (KS == 3 && !UNP && NW == 4), "kernel size 3: plain input, four waves");
     constexpr int NT = G::NT;
     constexpr int NI = G::NI, MI = G::MI, TH = G::TH, TW = G::TW, TWH = G::TWH, NPIXH = G::NPIXH, AP = G::AP;
     constexpr int PLSZ = G::PLSZ, ABUF = G::ABUF, SLOT = G::SLOT;
@@ -709,7 +710,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : (TN == 32 ? 3 : 2)) void con
         const_cast<float*>(p.in1), 0, (int)(((long)p.N * p.H * p.W * p.C1 * 2) >> (UNP ? 2 : 0)), 0x00020000);
     const unsigned long wb_addr = (unsigned long)p.wb;
     const r_u32x4 rb = {(unsigned)wb_addr, (unsigned)(wb_addr >> 32) & 0xffffu,
-                        (unsigned)((long)(p.CinP >> 4) * 25 * 16 * Cout * 2), 0x00020000u};
+                        (unsigned)((long)(p.CinP >> 4) * KS * KS * 16 * Cout * 2), 0x00020000u};
     const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned char*>(UNP ? p.in_idx : reinterpret_cast<const unsigned char*>(p.in1)), 0,
         (int)(((long)p.N * p.H * p.W * p.C1) >> 2), 0x00020000);
@@ -744,7 +745,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : (TN == 32 ? 3 : 2)) void con
         for (int j = 0; j < G::NPW; ++j) {
             const int k = wave + NW * j;
             if (G::PIECES % NW == 0 || k < G::PIECES) {
-                const int soff = ((chunk * 25 + ky * 5 + k / NI) * Cout + (k % NI) * 32) * 32;
+                const int soff = ((chunk * KS * KS + ky * KS + k / NI) * Cout + (k % NI) * 32) * 32;
                 glds16(rb, sB_addr + (unsigned)((slot * SLOT + k * 64) * 16), bvoff, soff);
             }
         }
@@ -822,16 +823,16 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : (TN == 32 ? 3 : 2)) void con
         const int ab = G::ADBL ? (c & 1) * ABUF : 0;
         const bool more = c + 1 < chunks;
 #pragma unroll
-        for (int ky = 0; ky < 5; ++ky) {
-            const int slot = (c + ky) & 1;                 // (5 c + ky) & 1
+        for (int ky = 0; ky < KS; ++ky) {
+            const int slot = (c + ky) & 1;                 // (KS c + ky) & 1, KS odd
             if constexpr (!(ABL & 1)) {
-                if (ky < 4) gldsB(c, ky + 1, slot ^ 1);
+                if (ky < KS - 1) gldsB(c, ky + 1, slot ^ 1);
                 else if (more) gldsB(c + 1, 0, slot ^ 1);
             }
             if constexpr (!(ABL & 2)) if (ky == 0 && more) fetchA((c + 1) * 16);
             const uint4* sBs = sB + slot * SLOT + bbase;
 #pragma unroll
-            for (int kx = 0; kx < 5; ++kx) {
+            for (int kx = 0; kx < KS; ++kx) {
                 bf16x8 a[MI], b[NI];
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
@@ -851,12 +852,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : (TN == 32 ? 3 : 2)) void con
                     for (int ni = 0; ni < NI; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
             }
-            if constexpr (!(ABL & 2)) if (G::ADBL && ky == 4 && more) commitA(ab ^ ABUF);
+            if constexpr (!(ABL & 2)) if (G::ADBL && ky == KS - 1 && more) commitA(ab ^ ABUF);
             if constexpr (!(ABL & 4)) {
                 dma_wait();                                // the next kernel row has landed ...
                 __syncthreads();                           // ... and everyone is done with this one (slot and A buffer free)
             }
-            if constexpr (!(ABL & 2)) if (!G::ADBL && ky == 4 && more) {
+            if constexpr (!(ABL & 2)) if (!G::ADBL && ky == KS - 1 && more) {
                 commitA(0);
                 if constexpr (!(ABL & 4)) __syncthreads();
             }
@@ -872,6 +873,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : (TN == 32 ? 3 : 2)) void con
 #pragma unroll
                 for (int j = 0; j < 16; ++j) sacc += acc[mi][ni][j];
         if (sacc == 123.456f) p.out1[0] = sacc;
+        return;
+    }
+    if constexpr (KS == 3) {        // the 3x3 layers (codec, UNet): every epilogue option of conv_fwd_bf16_kernel, same code
+        conv_epilogue_vec<3, TH, TW, 1, MI, NI>(acc, p, smem_raw, wave, lane, wave, 0, co0, Cout, ty0, tx0, grp, 0);
         return;
     }
     // epilogue: per-wave private LDS scratch (the loop's last barrier released the tiles) -> wave-level ordering only
@@ -1129,10 +1134,10 @@ int launch_conv3_dma(const ConvParamsB& p, hipStream_t stream) {
     return NIMG_OK;
 }
 
-template <int TN, int NW = 4>
+template <int TN, int NW = 4, int KS = 5>
 int launch_conv5_ring(const ConvParamsB& p, hipStream_t stream) {
-    using G = RingGeom<TN, NW>;
-    if constexpr (NW == 4 && TN == 128) {
+    using G = RingGeom<TN, NW, KS>;
+    if constexpr (NW == 4 && TN == 128 && KS == 5) {
         // NIMG_RING_NW8=1 (A/B switch, not the product path): eight waves on a 32 x 16 tile against one three-slot weight ring.
         // Measured (profiles/r04_ring_*.txt): half the weight DMA per matrix instruction raises the clock the chip sustains
         // (1.81 -> 1.94 GHz on conv3) but the single resident workgroup loses more to its lock-step phases (MFMA pipe busy
@@ -1144,7 +1149,8 @@ int launch_conv5_ring(const ConvParamsB& p, hipStream_t stream) {
     q.tiles_y = cdiv(p.Hout, G::TH);
     q.tiles_x = cdiv(p.Wout, G::TW);
     const long blocks = (long)(p.O1 / TN) * q.tiles_y * q.tiles_x * p.N;
-    auto kern = p.in_idx ? conv5_ring_kernel<TN, true, NW> : conv5_ring_kernel<TN, false, NW>;
+    auto kern = conv5_ring_kernel<TN, false, NW, KS>;
+    if constexpr (KS == 5) { if (p.in_idx) kern = conv5_ring_kernel<TN, true, NW, KS>; }
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(G::NT), G::LDS, stream, q);
     NIMG_CHECK_LAUNCH();
@@ -1182,6 +1188,19 @@ int launch_conv_b(const ConvParamsB& p, hipStream_t stream) {
         const long w_bytes = (long)(p.CinP >> 4) * KS * KS * 16 * Cout * 2;
         if (!no_buf && p.C2 == 0 && Cin % 16 == 0 && Cout % TN == 0 && !p.convt && in_bytes < (1l << 31) - 65536 &&
             w_bytes < (1l << 31) - 65536) {
+            if constexpr (KS == 3 && TH == 16 && TW == 16 && NB == 1 && TN == 64) {
+                // ring form at kernel size 3 (conv5_ring_kernel<128, false, 4, 3>: 16 x 16 pixels x 128 channels, 2 x 4 fragments
+                // per wave, weights by LDS-DMA one kernel row at a time): the big 3x3 layers - the codec's 128 -> 128 residual
+                // blocks at 64 x 64 - where the generic kernel's 2 x 2 fragment block reads as many operands as it multiplies.
+                // OPT-IN (NIMG_CONV3_RING_MIN=<workgroups>, default off): stand-alone the 128 -> 128 layer gains 4 - 7 % at B = 48 ... 80
+                // (profiles/r04_p_conv3_ring_codec.txt), but the config-3 step LOSES 5 % (5.02 -> 5.27 ms): two 67 KB workgroups per
+                // CU leave the side streams' weight-gradient kernels no LDS to run beside them.
+                static const long ring3_min = getenv("NIMG_CONV3_RING_MIN") ? atol(getenv("NIMG_CONV3_RING_MIN")) : -1;
+                const long rblocks = (long)(Cout / 128) * cdiv(p.Hout, 16) * cdiv(p.Wout, 16) * p.N;
+                if (ring3_min >= 0 && Cout % 128 == 0 && p.O2 == 0 && (p.O1 & 7) == 0 && p.pad_t == 1 && p.pad_l == 1 && p.Hout == p.H &&
+                    p.Wout == p.W && !p.pool_out && !p.in_idx && rblocks >= ring3_min)
+                    return launch_conv5_ring<128, 4, 3>(p, stream);
+            }
             if constexpr (KS == 5 && TH == 16 && TW == 16 && NB == 1 && TN == 64) {
                 static const bool no_ring = getenv("NIMG_NO_CONV5_RING") != nullptr;
                 static const bool no_ring64 = getenv("NIMG_NO_CONV5_RING64") != nullptr;
