@@ -203,14 +203,25 @@ __device__ __forceinline__ void pool_in_regs8(const nimg_f32x16 (&acc)[NI], floa
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int pc = (q & 1) + 4 * (q >> 1) + 2 * half;
+            // the window is pooled on the raw sums, bias + activation go to the winner: x -> lrelu(x + b) is non-decreasing, so the
+            // pooled VALUE is bit-identical to pooling the activated values (12 instead of 21 VALU per window); the arg-max can
+            // differ only where two unequal sums round to the same activated value (the gradient then takes another, equal, entry)
+#ifdef NIMG_POOL_ACT_FIRST                 // A/B: the activated values compared (the form of pool_in_regs)
             const float v0 = lrelu(acc[ni][2 * q] + b, alpha), v1 = lrelu(acc[ni][2 * q + 1] + b, alpha);
             const float v2 = lrelu(acc[ni][2 * q + 8] + b, alpha), v3 = lrelu(acc[ni][2 * q + 9] + b, alpha);
+#else
+            const float v0 = acc[ni][2 * q], v1 = acc[ni][2 * q + 1], v2 = acc[ni][2 * q + 8], v3 = acc[ni][2 * q + 9];
+#endif
             float m = v0;
             unsigned char k = 0;
             if (v1 > m) { m = v1; k = 1; }
             if (v2 > m) { m = v2; k = 2; }
             if (v3 > m) { m = v3; k = 3; }
+#ifdef NIMG_POOL_ACT_FIRST
             lds[pc * RS + ni * 32 + n] = m;
+#else
+            lds[pc * RS + ni * 32 + n] = lrelu(m + b, alpha);
+#endif
             lidx[pc * (NI * 32) + ni * 32 + n] = k;
         }
     }

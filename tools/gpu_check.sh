@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box session, made of the stages named on the command line; everything lands under gpurun_out/<tag>/.
 #   gpurun --timeout 900 -- 'bash tools/gpu_check.sh r02_b tests c4 prof'
-# stages: tests | tests:<pytest -k expression> | c4 | c4nocpu | c4eager | c3 | c5 | n2 | prof | trace | pmc:<counter> | py:<script and args>
+# stages: tests | tests:<pytest -k expression> | c4 | c4nocpu | c4eager | c3 | c5 | n2 | prof | trace | pmc:<counter> | pmcstep | pmcring | py:<script and args>
 TAG=${1:-r02}
 shift
 OUT=gpurun_out/$TAG
@@ -32,6 +32,16 @@ for ST in "$@"; do
           (cd /tmp && timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $ROOT/$OUT/pmc_$C -o p -- \
             python $ROOT/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-parity-mode > $ROOT/$OUT/pmc_$C.log 2>&1)
           note "pmc $C done" ;;
+    pmcstep) # counter-based HBM bytes of one whole C4 step on THIS build: two separate passes + tools/pmc_step_total.py (stamped)
+          for C in FETCH_SIZE WRITE_SIZE; do
+            (cd /tmp && timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $ROOT/$OUT/pmc_$C -o p -- \
+              python $ROOT/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-parity-mode > $ROOT/$OUT/pmc_$C.log 2>&1)
+            find $OUT/pmc_$C -name '*counter_collection.csv' | head -1 | xargs -I{} cp {} $OUT/pmc_$C.csv; rm -rf $OUT/pmc_$C
+          done
+          python tools/pmc_step_total.py $OUT/pmc_FETCH_SIZE.csv $OUT/pmc_WRITE_SIZE.csv 64 c4 > $OUT/pmc_step_total.json 2> $OUT/pmc_step_total.err
+          note "pmcstep rc=$?"; head -c 600 $OUT/pmc_step_total.json; rm -f $OUT/pmc_FETCH_SIZE.csv $OUT/pmc_WRITE_SIZE.csv ;;
+    pmcring) bash tools/pmc_ring.sh > $OUT/pmc_ring.log 2>&1; cp gpurun_out/pmc_ring/summary.json $OUT/pmc_ring_kernel.json; note "pmcring rc=$?"
+          tail -c 900 $OUT/pmc_ring_kernel.json ;;
     py:*) timeout 600 python ${ST#py:} > $OUT/py_$(echo "${ST#py:}" | tr ' /' '__' | cut -c1-40).log 2>&1; note "py ${ST#py:} rc=$?"
           tail -40 $OUT/py_$(echo "${ST#py:}" | tr ' /' '__' | cut -c1-40).log ;;
     *) note "unknown stage $ST" ;;
