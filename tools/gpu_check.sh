@@ -32,6 +32,10 @@ for ST in "$@"; do
           (cd /tmp && timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $ROOT/$OUT/pmc_$C -o p -- \
             python $ROOT/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-parity-mode > $ROOT/$OUT/pmc_$C.log 2>&1)
           note "pmc $C done" ;;
+    ltrace) (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $ROOT/$OUT/ltrace -o c4 -- \
+            python $ROOT/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-parity-mode > $ROOT/$OUT/ltrace.log 2>&1)
+          find $OUT/ltrace -name '*kernel_trace.csv' | head -1 | xargs -I{} python tools/launch_trace.py {} > $OUT/launch_trace.txt
+          rm -rf $OUT/ltrace; note "ltrace done"; tail -1 $OUT/launch_trace.txt ;;
     pmcstep) # counter-based HBM bytes of one whole C4 step on THIS build: two separate passes + tools/pmc_step_total.py (stamped)
           for C in FETCH_SIZE WRITE_SIZE; do
             (cd /tmp && timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $ROOT/$OUT/pmc_$C -o p -- \
