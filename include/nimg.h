@@ -47,6 +47,7 @@ extern "C" {
                            * space_to_depth(2) image (n, hout / 2, wout / 2, 4 o1) of the result - the gradient of a depth_to_space
                            * layer, written by the input-gradient pass that produces it (models/compression.py:233,245 backward);
                            * act_mask and residual keep the convolution's own (n, hout, wout, o1) layout */
+#define NIMG_POOL_ALSO 256 /* internal to nimg_conv2d_fwd_pool_also_bf16: the pooled tensor is written next to out1, not instead of it */
 
 /* library / ABI version, bumped on any signature change of an existing entry point (3: nimg_conv2d_fwd_bf16_res gained
  * out_bf16_copy and stride).  A binding compares nimg_abi_version() with the NIMG_ABI_VERSION it was written against. */
@@ -462,6 +463,11 @@ int nimg_conv2d_wgrad_bf16_ex(const float* in1, int c1, const float* in2, int c2
 int nimg_conv2d_pool_fwd_bf16_ex(const float* in, int cin, const float* w, const void* wb, const float* bias,
                                  float* pool_out, unsigned char* pool_idx, int cout, int n, int h, int wd, int ks,
                                  int act, float alpha, int flags, void* stream);
+/* 3x3 SAME stride-1 convolution + bias + activation storing BOTH the full output and its 2x2 max-pooled tensor (bf16 in and out;
+ * cin % 8 == 0, cout % 8 == 0, even h / wd > 8; pool_idx - the arg-max bytes - optional).  The second convolution of a UNet
+ * encoder level + its max_pool2d (models/pipelines.py:160-173): the full tensor is the skip connection. */
+int nimg_conv2d_fwd_pool_also_bf16(const float* in, int cin, const void* wb, const float* bias, float* out, float* pool_out,
+                                   unsigned char* pool_idx, int cout, int n, int h, int wd, int act, float alpha, void* stream);
 int nimg_conv2d_wgrad_pooled_bf16_ex(const float* in, int cin, const float* g, const unsigned char* idx, int cout,
                                      float* dw, float* db, int n, int h, int wd, int ks, int accumulate, void* workspace,
                                      size_t workspace_bytes, int flags, void* stream);     /* NIMG_BF16_DZ: g is bf16 */

@@ -203,6 +203,22 @@ __device__ __forceinline__ void conv_epilogue_vec(const f32x16 (&acc)[MI][NI], c
                     *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.out2) + pixoff * p.O2 + (co - p.O1)) = pack8(f);
                 }
             });
+            // NIMG_POOL_ALSO: the 2x2 max-pooled tensor next to the full one (the UNet's encoder keeps the full tensor for its skip
+            // connection and feeds the pooled one to the next level): a fragment = two rows of 16 pixels = 8 windows per channel
+            if constexpr (TW == 16 && NB == 1)
+                if (p.pool_out) {
+                    const int Hp = p.Hout >> 1, Wp = p.Wout >> 1, py = (ty0 >> 1) + wm * MI + mi;
+                    pool_in_regs8<NI>(acc[mi], elds, lane, p.act == 1 ? p.alpha : 1.0f,
+                        [&](int c) { const int co = co0 + wn * NI * 32 + c; return (p.bias && co < Cout) ? p.bias[co] : 0.f; },
+                        [&](int pc, int c, float4 lo, float4 hi, uint2 k) {
+                            const int co = co0 + wn * NI * 32 + c, px = (tx0 >> 1) + pc;
+                            if (co >= Cout || grp >= p.N || py >= Hp || px >= Wp) return;
+                            const long o = (((long)grp * Hp + py) * Wp + px) * Cout + co;
+                            const float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                            *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.pool_out) + o) = pack8(f);
+                            if (p.pool_idx) *reinterpret_cast<uint2*>(p.pool_idx + o) = k;
+                        });
+                }
         }
         return;
     }
@@ -518,7 +534,7 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
     }
     // ---- epilogue, fused activation + 2x2 max-pool (16x16 tiles; the entry point guarantees even Hout/Wout, Cout % 4 == 0)
     if constexpr (TW == 16 && NB == 1 && STRIDE == 1) {
-        if (p.pool_out) {
+        if (p.pool_out && !(p.flags & NIMG_POOL_ALSO)) {
             float* elds = reinterpret_cast<float*>(smem_raw) + wave * (32 * (NI * 32 + EPI_PAD));
             const int Hp = p.Hout >> 1, Wp = p.Wout >> 1;
             const float al = p.act == 1 ? p.alpha : 1.0f;
@@ -1176,7 +1192,7 @@ int launch_conv_b(const ConvParamsB& p, hipStream_t stream) {
         // workgroups per CU cover each other's prologue / epilogue)
         static const long max_hw = getenv("NIMG_CONV3_DMA_MAXHW") ? atol(getenv("NIMG_CONV3_DMA_MAXHW")) : 1024;
         const bool pays = p.C2 > 0 || (long)p.Hout * p.Wout <= max_hw;
-        if (!no_dma && pays && !p.convt && !p.in_idx && !p.pool_out && p.C1 % 16 == 0 && p.C2 % 16 == 0 && (p.O1 & 3) == 0 &&
+        if (!no_dma && pays && !p.convt && !p.in_idx && (!p.pool_out || (p.flags & NIMG_POOL_ALSO)) && p.C1 % 16 == 0 && p.C2 % 16 == 0 && (p.O1 & 3) == 0 &&
             (p.O2 & 3) == 0 && px * p.C1 * 2 < (1l << 31) - 65536 && px * p.C2 * 2 < (1l << 31) - 65536 &&
             w_bytes < (1l << 31) - 65536)
             return launch_conv3_dma<TH, TW, NB, TN>(p, stream);
@@ -1580,7 +1596,8 @@ static int conv2d_fwd_bf16_impl(const float* in1, int c1, const float* in2, int 
                          float* out1, int o1, float* out2, int o2, const float* act_mask, int n, int h, int wd,
                          int ks, int stride, int pad_t, int pad_l, int pad_mode, int hout, int wout, int act,
                          float alpha, int flags, void* stream, const unsigned char* in_idx = nullptr,
-                         const float* res = nullptr, void* out1b = nullptr) {
+                         const float* res = nullptr, void* out1b = nullptr, float* pool_out = nullptr,
+                         unsigned char* pool_idx = nullptr) {
     if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
     if (!in1 || !wb || !out1 || c1 <= 0 || c2 < 0 || o1 <= 0 || o2 < 0 || n < 0 || h <= 0 || wd <= 0) return NIMG_ERR_ARG;
     if ((c2 > 0 && !in2) || (o2 > 0 && !out2) || hout <= 0 || wout <= 0 || pad_t < 0 || pad_l < 0) return NIMG_ERR_ARG;
@@ -1590,8 +1607,9 @@ static int conv2d_fwd_bf16_impl(const float* in1, int c1, const float* in2, int 
     if (n == 0) return NIMG_OK;
     ConvParamsB p;
     p.in1 = in1; p.in2 = in2; p.wb = (const __bf16*)wb; p.bias = bias; p.out1 = out1; p.out2 = out2; p.act1 = act_mask;
-    p.pool_out = nullptr; p.pool_idx = nullptr; p.convt = 0; p.flags = flags; p.in_idx = in_idx; p.res = res;
+    p.pool_out = pool_out; p.pool_idx = pool_idx; p.convt = 0; p.flags = flags; p.in_idx = in_idx; p.res = res;
     p.out1b = (float*)out1b;
+    if (((flags & NIMG_POOL_ALSO) != 0) != (pool_out != nullptr)) return NIMG_ERR_ARG;
     if (res && (ks != 3 || stride != 1)) return NIMG_ERR_ARG;
     if ((res || out1b) && (o2 != 0 || (o1 & 3))) return NIMG_ERR_ARG;
     if (out1b && (flags & NIMG_BF16_OUT)) return NIMG_ERR_ARG;
@@ -1629,6 +1647,18 @@ int nimg_conv2d_fwd_bf16_ex(const float* in1, int c1, const float* in2, int c2, 
                             float alpha, int flags, void* stream) {
     return conv2d_fwd_bf16_impl(in1, c1, in2, c2, wb, bias, out1, o1, out2, o2, act_mask, n, h, wd, ks, stride, pad_t, pad_l,
                                 pad_mode, hout, wout, act, alpha, flags, stream);
+}
+
+/* A SAME stride-1 3x3 convolution (+ bias + activation) that stores BOTH its output and the 2x2 max-pooled output, bf16 in
+ * and out: the UNet's second encoder convolutions (models/pipelines.py:160-173 - the full tensor is the skip connection, the
+ * pooled one the next level's input).  cin % 8 == 0, cout % 8 == 0, even h / wd > 8 (the 16x16-pixel tiles); pool_idx optional. */
+int nimg_conv2d_fwd_pool_also_bf16(const float* in, int cin, const void* wb, const float* bias, float* out, float* pool_out,
+                                   unsigned char* pool_idx, int cout, int n, int h, int wd, int act, float alpha, void* stream) {
+    if (n == 0) return NIMG_OK;
+    if (!pool_out || (h & 1) || (wd & 1) || h <= 8 || wd <= 8 || (cout & 7) || (cin & 7)) return NIMG_ERR_ARG;
+    return conv2d_fwd_bf16_impl(in, cin, nullptr, 0, wb, bias, out, cout, nullptr, 0, nullptr, n, h, wd, 3, 1, 1, 1, 0, h, wd, act,
+                                alpha, NIMG_BF16_IN | NIMG_BF16_OUT | NIMG_POOL_ALSO, stream, nullptr, nullptr, nullptr, pool_out,
+                                pool_idx);
 }
 
 /* nimg_conv2d_fwd_bf16_ex for the layers of a residual block (models/compression.py:224-227, 240-243): `residual` (float32, the

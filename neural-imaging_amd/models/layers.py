@@ -70,6 +70,14 @@ class Conv2D(object):
         return ops.conv2d_pool(x, store.p[self.name + '/kernel'], store.p[self.name + '/bias'], act=self.activation,
                                want_idx=want_idx, out_bf16=out_bf16)
 
+    def forward_and_pool(self, store, x, out_bf16=False):
+        """-> (activation, MaxPool2D(2) of it): one pass where the bf16 epilogue can write both (ops.conv2d_and_pool)."""
+        w = store.p[self.name + '/kernel']
+        if out_bf16 and self.can_pool(x) and ops.conv2d_and_pool_ok(x, w):
+            return ops.conv2d_and_pool(x, w, store.p[self.name + '/bias'], act=self.activation)
+        y = self.forward(store, x, out_bf16=out_bf16)
+        return y, ops.maxpool2(y)
+
     def backward_params(self, store, x, dz, x2=None):
         # on the side stream: it only needs (x, dz), which the input gradient on the launch stream reads as well
         ops.conv2d_wgrad(x, dz, self.ks, x2=x2, stride=self.stride, dw=store.g[self.name + '/kernel'],

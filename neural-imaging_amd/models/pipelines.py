@@ -165,9 +165,11 @@ class UNet(NIPModel):
         t['ep0'] = x
         for n in range(1, ns + 1):
             t['ec{}1'.format(n)] = L['ec{}1'.format(n)].forward(P, t['ep{}'.format(n - 1)], out_bf16=sb)
-            t['ec{}2'.format(n)] = L['ec{}2'.format(n)].forward(P, t['ec{}1'.format(n)], out_bf16=sb)
-            if n < ns:
-                t['ep{}'.format(n)] = ops.maxpool2(t['ec{}2'.format(n)])
+            if n < ns:          # the skip tensor and the next level's input (bf16 storage: both from the same epilogue)
+                t['ec{}2'.format(n)], t['ep{}'.format(n)] = L['ec{}2'.format(n)].forward_and_pool(P, t['ec{}1'.format(n)],
+                                                                                                   out_bf16=sb)
+            else:
+                t['ec{}2'.format(n)] = L['ec{}2'.format(n)].forward(P, t['ec{}1'.format(n)], out_bf16=sb)
         t['dc02'] = t['ec{}2'.format(ns)]
         for n in range(1, ns):
             t['dct{}'.format(n)] = L['dct{}'.format(n)].forward(P, t['dc{}2'.format(n - 1)], out_bf16=sb)

@@ -643,6 +643,32 @@ def conv2d_pool(x, w, bias=None, act='leaky_relu', want_idx=True, out_bf16=False
     return pooled, idx
 
 
+# The UNet's encoder levels write the pooled tensor from the second convolution's epilogue (NIMG_NO_POOL_ALSO=1: a separate
+# max-pool pass over the stored activation, A/B runs).
+POOL_ALSO = _os.environ.get('NIMG_NO_POOL_ALSO') is None
+
+
+def conv2d_and_pool_ok(x, w):
+    n, h, wd, cin = x.shape
+    return POOL_ALSO and COMPUTE == 'bf16' and _is_bf16(x) and w.shape[0] == 3 and w.shape[1] == 3 and cin % 8 == 0 and \
+        w.shape[3] % 8 == 0 and h % 2 == 0 and wd % 2 == 0 and h > 8 and wd > 8
+
+
+def conv2d_and_pool(x, w, bias=None, act='leaky_relu'):
+    """3x3 SAME Conv2D -> [LeakyReLU] stored as bf16 AND its MaxPool2D(2), one pass (where conv2d_and_pool_ok): returns
+    (activation, pooled activation) - bit-identical to conv2d(..., out_bf16=True) followed by maxpool2."""
+    _f32(w, bias)
+    if not conv2d_and_pool_ok(x, w):
+        raise ValueError('conv2d_and_pool: unsupported shape / mode')
+    n, h, wd, cin = x.shape
+    cout = w.shape[3]
+    y = torch.empty((n, h, wd, cout), dtype=torch.bfloat16, device=x.device)
+    pooled = torch.empty((n, h // 2, wd // 2, cout), dtype=torch.bfloat16, device=x.device)
+    _lib.call('nimg_conv2d_fwd_pool_also_bf16', _p(x), cin, _p(weights_bf16(w, 0)), _p(bias), _p(y), _p(pooled), None, cout,
+              n, h, wd, 1 if act == 'leaky_relu' else 0, LRELU_ALPHA, _stream())
+    return y, pooled
+
+
 def maxpool2_unpool(dp, idx, pooled, apply_mask=True, out=None, out_bf16=False):
     """Backward of conv2d_pool's epilogue: the pre-activation gradient at full resolution (optionally stored as bf16:
     its consumers - the bf16 weight / input gradient kernels - round it to bf16 anyway)."""

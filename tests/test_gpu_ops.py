@@ -298,6 +298,30 @@ def test_conv_pool_fused_epilogue(dev, mode, cin, cout, ks, h, w):
         ops.set_compute('f32')
 
 
+@pytest.mark.parametrize('n,cin,cout,h,w', [(3, 32, 32, 128, 128), (3, 64, 64, 64, 64), (5, 128, 128, 32, 32), (5, 256, 256, 16, 16),
+                                            (2, 16, 24, 24, 40), (1, 8, 72, 10, 18)])
+def test_conv_writes_activation_and_pooled_tensor(dev, n, cin, cout, h, w):
+    """The UNet encoder's second convolutions store the skip tensor AND its max-pool from one epilogue (ops.conv2d_and_pool):
+    both equal the two separate passes bit for bit - the generic and the LDS-DMA 3x3 kernels, ragged tiles, ragged channels."""
+    from neural_imaging_amd import ops
+    ops.set_compute('bf16')
+    try:
+        x = g(rnd((n, h, w, cin), 1), dev).to(torch.bfloat16)
+        wt, b = g(rnd((3, 3, cin, cout), 2, -0.2, 0.2), dev), g(rnd((cout,), 3, -0.1, 0.1), dev)
+        assert ops.conv2d_and_pool_ok(x, wt)
+        for act in ('leaky_relu', None):
+            full = ops.conv2d(x, wt, b, act=act, out_bf16=True)
+            y, pooled = ops.conv2d_and_pool(x, wt, b, act=act)
+            assert y.dtype == torch.bfloat16 and pooled.dtype == torch.bfloat16
+            assert torch.equal(y, full)
+            assert torch.equal(pooled, ops.maxpool2(full))
+        assert not ops.conv2d_and_pool_ok(x[:, :8, :8], wt)          # 8 x 8 images take the four-image tiles: separate passes
+        with pytest.raises(ValueError):
+            ops.conv2d_and_pool(x[:, :8, :8].contiguous(), wt, b)
+    finally:
+        ops.set_compute('f32')
+
+
 @pytest.mark.parametrize('shape', [(3, 40, 56, 3), (2, 64, 64, 1), (1, 11, 11, 3)])
 def test_ssim_both_flavours(dev, shape):
     """Device SSIM against the restated skimage (7x7 uniform, sample covariance) and tf.image.ssim (11x11 Gaussian)."""
