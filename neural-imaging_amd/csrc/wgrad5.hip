@@ -565,6 +565,207 @@ __global__ __launch_bounds__(256, 1) void conv5_wgrad_sparse_kernel(const Wg5Par
     }
 }
 
+// Eight-wave form of conv5_wgrad_sparse_kernel: TWO waves per SIMD.  The four-wave form above leaves one wave per SIMD to issue a
+// tile's ~1000 instructions - fetch, arg-max pieces, fragment reads, 208 matrix instructions - strictly one behind the other:
+// 37 % of its cycles on the matrix pipe (profiles/r03_pmc_wgrad5_sparse_v3.json), 40 % of its time in the staging in front of the
+// tap pipeline (profiles/r03_ab_wgrad5_sparse_ablation.txt).  Here a wave owns 16 input x 64 output channels x a QUARTER of the
+// taps (7 | 6 | 6 | 6: 112 accumulator registers), keeps the gradient fragments of ONE step of four rows at a time (20 registers,
+// the next step's requested under the current one's matrix instructions) and stages half as much per thread - everything fits
+// the 256 registers two waves per SIMD leave each, and one wave's staging / LDS round trips run under the partner's matrix work.
+// Waves w and w + 4 share a SIMD: tap quarters (0, 2) = 13 taps and (1, 3) = 12.  Same LDS layout, same tile loop, same slabs.
+template <int TH>
+__global__ __launch_bounds__(512, 1) void conv5_wgrad_sparse8_kernel(const Wg5Params p) {
+    using G = Wg5SGeom<TH>;
+    constexpr int XP = G::XP, XR = G::XR, GP = G::GP, GR = G::GR;
+    constexpr int IP = (G::THH + 5) / 6, ZP = G::ZITEMS / 512;
+    static_assert(G::ZITEMS % 512 == 0, "pooled tile divides over the threads");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ai = wave & 1, tg = wave >> 1;                       // this wave's 16 input channels, its quarter of the taps
+    const int tap0 = tg == 0 ? 0 : 1 + 6 * tg;                     // taps 0..6 | 7..12 | 13..18 | 19..24
+    const int cib = p.Cin / 32, cob = p.Cout / 64;
+    int bid = xcd_order(blockIdx.x);
+    const int ci0 = (bid % cib) * 32;
+    bid /= cib;
+    const int co0 = (bid % cob) * 64;
+    const int split = bid / cob;
+    const int q = lane >> 4, g = lane & 15;
+    const int Hp = p.H >> 1, Wp = p.W >> 1;
+
+    constexpr int NF = 4, NTAP = 7;
+    f32x4 acc[NF][NTAP];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) acc[f][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum[NF] = {0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = p.db_partial && ci0 == 0 && wave == 0;
+
+    const int tiles = p.tiles_y * p.tiles_x;
+    const int work_total = p.N * tiles;
+    const int w_begin = split * p.work_per_split;
+    const int w_end = min(work_total, w_begin + p.work_per_split);
+
+    // ---- staging maps: 480 threads cover six halo rows of 20 pixels x four 16-byte pieces per pass; one pooled pixel piece each
+    const int ihy0 = tid < 480 ? tid / 80 : 100000, ihx = (tid % 80) >> 2;
+    const int ic8 = (tid & 3) * 8;
+    const int icommit = ihx * XP + (tid & 3) * 16;
+    const int zc8 = (tid & 7) * 8;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.in), 0, (int)((long)p.N * p.H * p.W * p.Cin * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.g), 0, (int)((long)p.N * Hp * Wp * p.Cout * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(p.idx), 0, (int)((long)p.N * Hp * Wp * p.Cout), 0x00020000);
+    u32x4 preI[IP], preZ[ZP];
+    u32x2 preK[ZP];
+    auto fetch = [&](int wk) {
+        const int n = wk / tiles, tile = wk - n * tiles;
+        const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+        const int iy0 = ty * TH - 2, ix0 = tx * 16 - 2;
+        const int gx = ix0 + ihx;
+        const bool okx = (unsigned)gx < (unsigned)p.W;
+#pragma unroll
+        for (int i = 0; i < IP; ++i) {
+            const int gy = iy0 + ihy0 + 6 * i;
+            const bool ok = okx & ((unsigned)gy < (unsigned)p.H) & (ihy0 + 6 * i < G::THH);
+            const unsigned off = ok ? (unsigned)((((n * p.H + gy) * p.W + gx) * p.Cin + ci0 + ic8) * 2) : 0x80000000u;
+            preI[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < ZP; ++i) {
+            const int ppix = (tid + i * 512) >> 3;
+            const unsigned e = (unsigned)(((n * Hp + ty * (TH / 2) + (ppix >> 3)) * Wp + tx * 8 + (ppix & 7)) * p.Cout + co0 + zc8);
+            preZ[i] = __builtin_amdgcn_raw_buffer_load_b128(rz, e * 2, 0, 0);
+            preK[i] = __builtin_amdgcn_raw_buffer_load_b64(rk, e, 0, 0);
+        }
+    };
+    auto commit = [&](unsigned char* buf) {
+#pragma unroll
+        for (int i = 0; i < IP; ++i)
+            if (ihy0 + 6 * i < G::THH) *reinterpret_cast<u32x4*>(buf + (ihy0 + 6 * i) * XR + icommit) = preI[i];
+        unsigned char* gb = buf + G::IBYTES;
+#pragma unroll
+        for (int i = 0; i < ZP; ++i) {
+            const int ppix = (tid + i * 512) >> 3, pr = ppix >> 3, pc = ppix & 7;
+            const int o = pr * GR + pc * GP + zc8 * 2;
+            *reinterpret_cast<u32x4*>(gb + o) = preZ[i];
+            const unsigned u = (unsigned)(pr & 1), s8 = 8u * (unsigned)((pc >> 1) & 1);     // the pieces of conv5_wgrad_sparse_kernel
+            u32x4 m16, x16;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const unsigned e2 = __builtin_amdgcn_perm(0u, preK[i][d >> 1], (d & 1) ? 0x0c030c02u : 0x0c010c00u);
+                m16[d] = (e2 & 0x00010001u) * 0xffffu;
+                const unsigned val = ((e2 >> 1) & 0x00010001u) + u * 0x00020002u;
+                x16[d] = ((val << (2 * u)) | (val << (2 * u + 4))) << s8;
+            }
+            *reinterpret_cast<u32x4*>(gb + G::GBYTES + o) = m16;
+            *reinterpret_cast<u32x4*>(gb + 2 * G::GBYTES + o) = x16;
+        }
+    };
+    const int jx = g >> 2;
+    const int x_lane = jx * XR + 4 * q * XP + ai * 32 + (g & 3) * 8;
+    const int pcA = (q & 1) * 4 + (q >> 1);
+    const int z_lane = (jx & 1) * GR + (pcA + 2 * (jx >> 1)) * GP + (g & 3) * 8;
+    auto tr2 = [](const unsigned char* a) {
+        const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)a);
+        return *reinterpret_cast<const u32x2*>(&v);
+    };
+    auto trl = [](unsigned lds_addr) {
+        const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(unsigned long)lds_addr);
+        return *reinterpret_cast<const u32x2*>(&v);
+    };
+
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)smem_raw;
+    if (w_begin < w_end) {
+        fetch(w_begin);
+        commit(smem_raw);
+    }
+    __syncthreads();
+    for (int wk = w_begin; wk < w_end; ++wk) {
+#ifndef NIMG_W8_ABL
+#define NIMG_W8_ABL 0
+#endif
+        constexpr int ABL = NIMG_W8_ABL;        // diagnostic builds: 1 = stage the first tile only, 2 = no tap pipeline, 4 = one B operand
+        const int par = (ABL & 1) ? 0 : (wk - w_begin) & 1;
+        const bool more = wk + 1 < w_end && !(ABL & 1);
+        if (more) fetch(wk + 1);
+        const unsigned char* sG = smem_raw + par * G::BUF + G::IBYTES;
+        auto readB = [&](unsigned xr) {
+            asm volatile("" : "+v"(xr));                   // one opaque address per tap: see conv5_wgrad_sparse_kernel
+            const u32x2 r0 = trl(xr), r1 = trl(xr + XP), r2 = trl(xr + 2 * XP), r3 = trl(xr + 3 * XP);
+            const u32x4 q0 = __builtin_shufflevector(r0, r1, 0, 1, 2, 3), q1 = __builtin_shufflevector(r2, r3, 0, 1, 2, 3);
+            const u32x8 b8 = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7);
+            return *reinterpret_cast<const bf16x16*>(&b8);
+        };
+        auto readA = [&](const unsigned char* zr, unsigned (&a)[NF][4], unsigned (&ix)[NF]) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const u32x2 v = tr2(zr + f * 32), m = tr2(zr + G::GBYTES + f * 32), k = tr2(zr + 2 * G::GBYTES + f * 32);
+                a[f][0] = v[0] & ~m[0]; a[f][1] = v[0] & m[0];
+                a[f][2] = v[1] & ~m[1]; a[f][3] = v[1] & m[1];
+                const unsigned t = k[0] | k[1];
+                ix[f] = t | (t >> 16);
+                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                const unsigned ones = 0x3f803f80u, v0 = v[0], v1 = v[1];
+                bsum[f] = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const bf16x2*>(&v0), *reinterpret_cast<const bf16x2*>(&ones), bsum[f], false);
+                bsum[f] = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const bf16x2*>(&v1), *reinterpret_cast<const bf16x2*>(&ones), bsum[f], false);
+            }
+        };
+#ifndef NIMG_W8_DIST
+#define NIMG_W8_DIST 2
+#endif
+        constexpr int STEPS = TH / 4, NT = STEPS * NTAP, DIST = NIMG_W8_DIST;
+        const unsigned x0 = lds0 + (unsigned)(par * G::BUF + x_lane);
+        auto tap_addr = [&](int T) {
+            const int tap = tap0 + T % NTAP;                        // wave-uniform: scalar arithmetic
+            return x0 + (unsigned)((T / NTAP) * (4 * XR) + (tap / 5) * XR + (tap % 5) * XP);
+        };
+        const bool seven = tg == 0;                                 // the first quarter owns a seventh tap
+        if constexpr ((ABL & 2) == 0) {
+        unsigned a4[2][NF][4], ix[2][NF];
+        readA(sG + z_lane, a4[0], ix[0]);
+        bf16x16 ring[DIST + 1];
+#pragma unroll
+        for (int d = 0; d < DIST; ++d) ring[d] = readB(tap_addr(d));
+#pragma unroll
+        for (int T = 0; T < NT; ++T) {
+            const int st = T / NTAP, t = T % NTAP;
+            if (t == 1 && st + 1 < STEPS) readA(sG + z_lane + (st + 1) * (2 * GR), a4[(st + 1) & 1], ix[(st + 1) & 1]);
+            if (T + DIST < NT && !(ABL & 4)) {
+                if ((T + DIST) % NTAP < 6 || seven) ring[(T + DIST) % (DIST + 1)] = readB(tap_addr(T + DIST));
+            }
+            if (t < 6 || seven) {
+#pragma unroll
+                for (int f = 0; f < NF; ++f)
+                    acc[f][t] = __builtin_amdgcn_smfmac_f32_16x16x64_bf16(*reinterpret_cast<const bf16x8*>(a4[st & 1][f]),
+                                                                          ring[(ABL & 4) ? 0 : T % (DIST + 1)], acc[f][t], (int)ix[st & 1][f], 0, 0);
+            }
+        }
+        }
+        if (more) commit(smem_raw + (par ^ 1) * G::BUF);
+        __syncthreads();
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            float v = bsum[f];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lane < 16) p.db_partial[(long)split * p.Cout + co0 + f * 16 + lane] = v;
+        }
+    }
+    float* slab = p.partial + (long)split * 25 * p.Cin * p.Cout;
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
+        if (t == 6 && tg != 0) continue;
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+            *reinterpret_cast<f32x4*>(slab + ((long)(tap0 + t) * p.Cin + ci0 + 16 * ai + g) * p.Cout + co0 + f * 16 + 4 * q) = acc[f][t];
+    }
+}
+
 template <int TH>
 int launch_sparse(Wg5Params p, int max_slabs, hipStream_t stream) {
     using G = Wg5SGeom<TH>;
@@ -580,9 +781,11 @@ int launch_sparse(Wg5Params p, int max_slabs, hipStream_t stream) {
     const long wps = (work + splits - 1) / splits;
     splits = (work + wps - 1) / wps;
     p.work_per_split = (int)wps;
-    auto kern = conv5_wgrad_sparse_kernel<TH>;
+    // NIMG_WGRAD5_W4: the four-wave form (one wave per SIMD), A/B runs; read per call
+    const bool w8 = getenv("NIMG_WGRAD5_W4") == nullptr;
+    auto kern = w8 ? conv5_wgrad_sparse8_kernel<TH> : conv5_wgrad_sparse_kernel<TH>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(blocks_io * splits)), dim3(256), G::LDS, stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(blocks_io * splits)), dim3(w8 ? 512 : 256), G::LDS, stream, p);
     if (hipGetLastError() != hipSuccess) return -1;
     return (int)splits;
 }
