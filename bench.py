@@ -441,6 +441,24 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+class RunAhead(object):
+    """Bounds how far the launching thread runs ahead of the GPU in an eager-launch loop: call it after every step; it waits for the
+    step issued `depth` steps earlier.  Without a bound the host (~3 ms of launches per 8 ms step) gets ~16 steps ahead, every step
+    in flight holds its temporaries, and the caching allocator has to hipMalloc new segments in the middle of the timed loop - a
+    0.3 - 0.75 s stall on boxes where hipMalloc is slow (profiles/r04_zc_stall_probe.txt: always at step 16, inside torch.empty).
+    Two or three steps in flight keep the GPU fed and the pool at its warm-up size."""
+
+    def __init__(self, depth=3):
+        self.depth, self.events = depth, []
+
+    def __call__(self):
+        e = torch.cuda.Event()
+        e.record()
+        self.events.append(e)
+        if len(self.events) > self.depth:
+            self.events.pop(0).synchronize()
+
+
 def dp1_nccl_leg(wl, n=20):
     """Eager C4 steps with the data-parallel path live on ONE rank: `nccl` (= RCCL) process group of world size 1,
     parallel.force_collectives() -> the FAN / UNet-decoder / UNet-encoder gradient buckets are launched as asynchronous
@@ -452,8 +470,10 @@ def dp1_nccl_leg(wl, n=20):
             fn()
         torch.cuda.synchronize()
         t, c = time.perf_counter(), time.thread_time()
+        pace = RunAhead()
         for _ in range(n):
             fn()
+            pace()
         host = 1e3 * (time.thread_time() - c) / n
         torch.cuda.synchronize()
         return 1e3 * (time.perf_counter() - t) / n, host
@@ -559,6 +579,10 @@ def main():
                     help='joint training steps of the trained-parity leg (0 = skip); the NIP is pre-trained for 2.5 x as many '
                          'steps first and each mode trains a quarter as many more from the checkpoint')
     ap.add_argument('--no-side-workloads', action='store_true', help='skip the short c2 / c3 / c5 runs of the default c4 line')
+    ap.add_argument('--run-ahead', type=int, default=3,
+                    help='steps the launching thread may be ahead of the GPU in the timed loop (0 = unbounded), see RunAhead')
+    ap.add_argument('--stall-probe', action='store_true',
+                    help='diagnostic: per-step host times of the timed loop + a Python stack dump of any step that takes > 150 ms')
     ap.add_argument('--no-dp1-nccl', action='store_true', help='skip the one-rank RCCL leg (dp1_nccl_*) of the default c4 line')
     ap.add_argument('--no-graph', dest='graph', action='store_false',
                     help='launch every kernel of the timed steps eagerly (default at N = 1: the step is ALSO captured into a HIP '
@@ -619,8 +643,10 @@ def main():
                 fn()
             torch.cuda.synchronize()
             t_m = time.perf_counter()
+            pace = RunAhead()
             for _ in range(max(args.warmup, 5)):
                 fn()
+                pace()
             torch.cuda.synchronize()
             launch_modes[name] = min(launch_modes.get(name, 1e30), 1e3 * (time.perf_counter() - t_m) / max(args.warmup, 5))
         if launch_modes['eager'] < launch_modes['graph']:
@@ -632,10 +658,21 @@ def main():
     t0 = time.perf_counter()
     c0 = time.thread_time()                    # CPU time this thread spends issuing the steps (host cost of the launch path)
     last = None
+    host_step_ms = []
+    pace = RunAhead(args.run_ahead) if args.run_ahead > 0 else (lambda: None)
+    if args.stall_probe:
+        import faulthandler
     for i in range(args.steps):
         if i in edges:
             marks[edges.index(i)].record()
+        if args.stall_probe:
+            faulthandler.dump_traceback_later(0.15, file=sys.stderr)
+            t_s = time.perf_counter()
         last = step()
+        pace()
+        if args.stall_probe:
+            faulthandler.cancel_dump_traceback_later()
+            host_step_ms.append(1e3 * (time.perf_counter() - t_s))
     marks[nblk].record()
     host_cpu_ms = 1e3 * (time.thread_time() - c0) / max(args.steps, 1)
     barrier()
@@ -665,6 +702,9 @@ def main():
                'hip_graph': bool(getattr(wl, 'graph', False)), 'host_cpu_ms_per_step': host_cpu_ms, 'loss': loss,
                'achieved_tflops_whole_step': value * wl.gflop_per_unit / 1e3,
                'block_ms_per_step': [round(v, 4) for v in blocks], 'median_block_ms_per_step': float(np.median(blocks))}
+        if host_step_ms:
+            order = np.argsort(host_step_ms)[::-1][:5]
+            cfg['stall_probe_slowest_host_steps'] = [[int(j), round(host_step_ms[j], 2)] for j in order]
         if launch_modes is not None:
             cfg['launch_mode_warmup_ms_per_step'] = {k: round(v, 4) for k, v in launch_modes.items()}
         if world == 1 and getattr(wl, 'graph', False):
@@ -754,8 +794,10 @@ def main():
                             fn()
                         torch.cuda.synchronize()
                         t2 = time.perf_counter()
+                        pace2 = RunAhead()
                         for _ in range(n):
                             fn()
+                            pace2()
                         torch.cuda.synchronize()
                         return (time.perf_counter() - t2) / n
                     dt2 = timed2(step2, 30)

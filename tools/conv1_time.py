@@ -25,6 +25,8 @@ w = torch.randn((5, 5, 3, 32), device=dev) * 0.1
 b = torch.zeros((32,), device=dev)
 pooled, idx = ops.conv2d_pool(x, w, b)
 g = torch.randn_like(pooled)
+if args.dtype == 'bf16':
+    g = g.to(torch.bfloat16)            # the product path hands the pooled gradient over as bf16
 dw = torch.empty_like(w)
 db = torch.empty_like(b)
 
