@@ -441,30 +441,13 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-class RunAhead(object):
-    """Bounds how far the launching thread runs ahead of the GPU in an eager-launch loop: call it after every step; it waits for the
-    step issued `depth` steps earlier.  Without a bound the host (~3 ms of launches per 8 ms step) gets ~16 steps ahead, every step
-    in flight holds its temporaries, and the caching allocator has to hipMalloc new segments in the middle of the timed loop - a
-    0.3 - 0.75 s stall on boxes where hipMalloc is slow (profiles/r04_zc_stall_probe.txt: always at step 16, inside torch.empty).
-    Two or three steps in flight keep the GPU fed and the pool at its warm-up size."""
-
-    def __init__(self, depth=3):
-        self.depth, self.events = depth, []
-
-    def __call__(self):
-        e = torch.cuda.Event()
-        e.record()
-        self.events.append(e)
-        if len(self.events) > self.depth:
-            self.events.pop(0).synchronize()
-
-
 def dp1_nccl_leg(wl, n=20):
     """Eager C4 steps with the data-parallel path live on ONE rank: `nccl` (= RCCL) process group of world size 1,
     parallel.force_collectives() -> the FAN / UNet-decoder / UNet-encoder gradient buckets are launched as asynchronous
     all-reduces while the backward pass continues, the NaN flag is MAX-reduced, Adam waits for the buckets.  Reported next to
     the plain eager step timed the same way in the same process."""
     from neural_imaging_amd import parallel
+    from neural_imaging_amd.graphs import RunAhead
     def timed(fn):
         for _ in range(3):
             fn()
@@ -603,6 +586,7 @@ def main():
 
     importlib.import_module('neural-imaging_amd')
     from neural_imaging_amd import _lib, parallel
+    from neural_imaging_amd.graphs import RunAhead
 
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU; there is no CPU fallback')

@@ -139,3 +139,22 @@ class CapturedModelStep(object):
         self.graph.replay()
         self.model._model.step = self.t
         return self.out
+
+
+class RunAhead(object):
+    """Bounds how far the launching thread runs ahead of the GPU in an eager-launch loop: call it after every step; it waits for the
+    step issued `depth` steps earlier.  Without a bound the host (~3 ms of launches per 8 ms step) gets ~16 steps ahead, every step
+    in flight holds its temporaries, and the caching allocator has to hipMalloc new segments in the middle of the timed loop - a
+    0.3 - 0.75 s stall on boxes where hipMalloc is slow (profiles/r04_zc_stall_probe.txt: always at step 16, inside torch.empty);
+    a training loop that reads a loss every step is paced by that read and does not need it.
+    Two or three steps in flight keep the GPU fed and the pool at its warm-up size."""
+
+    def __init__(self, depth=3):
+        self.depth, self.events = depth, []
+
+    def __call__(self):
+        e = torch.cuda.Event()
+        e.record()
+        self.events.append(e)
+        if len(self.events) > self.depth:
+            self.events.pop(0).synchronize()

@@ -1270,6 +1270,21 @@ def test_captured_step_replays_the_eager_step(dev):
     assert captured._step == 5 and abs(float(runner._rate_dev.item()) - ops.adam_lr_t(1e-3, 5)) < 1e-10
 
 
+def test_run_ahead_bounds_the_steps_in_flight(dev):
+    """graphs.RunAhead(depth): after every call at most `depth` recorded steps are still unfinished on the host side."""
+    from neural_imaging_amd import graphs
+    pace = graphs.RunAhead(2)
+    x = torch.zeros((1 << 22,), device=dev)
+    for k in range(6):
+        x.add_(1.0)
+        pace()
+        assert len(pace.events) <= 2
+        if k >= 2:                                  # the step issued two calls ago has been waited for
+            assert float(x[0].item()) >= k - 1
+    torch.cuda.synchronize()
+    assert float(x[0].item()) == 6.0
+
+
 @pytest.mark.parametrize('family', ['nip', 'dcn'])
 def test_captured_model_step_replays_the_eager_step(dev, family):
     """graphs.CapturedModelStep: NIPModel.training_step / DCN.training_step (configs 2 / 3) replayed from a HIP graph walk the
