@@ -656,13 +656,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_pooled_kernel(const void* __r
 // dc[y][x][i] = sum_kx P[(kx,i)][x+2-kx] is a shift-add through a 4 KB per-wave LDS strip.  The gradient tile is un-pooled
 // and arg-max-masked once per tile by the staging pass (packed bit operations), then read five times (once per ky).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-#ifndef NIMG_E_TR
-#define NIMG_E_TR 8
-#endif
-#ifndef NIMG_E_GRID
-#define NIMG_E_GRID 512
-#endif
-constexpr int E_TR = NIMG_E_TR, E_TW = 64, E_HR = E_TR + 4, E_HC = E_TW + 4;
+constexpr int E_TR = 8, E_TW = 64, E_HR = E_TR + 4, E_HC = E_TW + 4;
 constexpr int E_DZ_BYTES = E_HR * E_HC * 64 + 12 * 64;                       // + slack: the last fragment over-reads 12 pixels
 constexpr int E_PS = E_HC;                                                   // floats per P row: (4 kg + reg) * 68 = 16 kg + 4 reg
 constexpr int E_P_BYTES = 16 * E_PS * 4;                                     // (mod 32 banks) -> both accesses conflict-free
@@ -936,7 +930,7 @@ int nimg_conv1_dgrad_pooled(const void* g, const unsigned char* pool_idx, const 
     if ((long)n * (h / 2) * (wd / 2) * 32 * (g_bf16 ? 2 : 4) > 0x7fffffffL) return NIMG_ERR_ARG;      // one descriptor, < 2 GB
     const int tiles_y = cdiv(h, E_TR), tiles_x = cdiv(wd, E_TW);
     const long total = (long)n * tiles_y * tiles_x;
-    const dim3 grid((unsigned)(total < NIMG_E_GRID ? total : NIMG_E_GRID));              // persistent: two 70 KB workgroups per CU
+    const dim3 grid((unsigned)(total < 512 ? total : 512));              // persistent: two 70 KB workgroups per CU
     if (g_bf16)
         hipLaunchKernelGGL((conv1_dgrad_pooled_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, g, pool_idx, w, dc, n, h, wd,
                            tiles_y, tiles_x);
