@@ -7,9 +7,11 @@ quirk 6): ConstrainedConv2D -> 4 x [Conv5x5 SAME (32,64,128,256) + LeakyReLU(0.2
 Also built: use_gap=False (Flatten) and n_dense > 0 hidden Dense + LeakyReLU layers (forensics.py:79-87), as 1x1
 convolutions on (N,1,1,F) tensors, with Keras Dropout after each of them at training time (masks from a device generator).
 """
+import os
 from collections import OrderedDict
 
 import numpy as np
+
 import torch
 
 from .. import ops, parallel
@@ -17,6 +19,11 @@ from ..device import DeviceArray, to_device
 from ..helpers import paramspec
 from .layers import ConstrainedConv2D, Conv2D
 from .tfmodel import ParamStore, TFModel, glorot_uniform_
+
+
+# The FAN's weight gradients issued behind its input-gradient chain when the caller keeps launching (the workflow's codec /
+# manipulation / UNet backward): NIMG_NO_LATE_PARAMS=1 = beside the input gradients, as rounds 1 - 3 (A/B runs).
+LATE_PARAMS = os.environ.get('NIMG_NO_LATE_PARAMS') is None
 
 
 class FAN(TFModel):
@@ -172,8 +179,17 @@ class FAN(TFModel):
         t['gap'], t['probs'], t['loss_per'], t['dlogits'], t['loss_scale'] = gap, probs, loss_per, dlogits, ls
         return probs, (t if training else None)
 
-    def backward(self, t, need_input_grad=False):
-        """Fills the gradient buffer; returns (loss[1], d loss / d x or None)."""
+    def backward(self, t, need_input_grad=False, join=True):
+        """Fills the gradient buffer; returns (loss[1], d loss / d x or None).
+        join=False: the caller joins the side streams itself (ops.join_side_stream / ops.nan_flag / the Adam step) - with
+        LATE_PARAMS the weight gradients of the fused conv + pool layers are ISSUED behind the whole input-gradient chain, so
+        they run beside whatever the caller launches next instead of beside the (equally chip-filling) input-gradient kernels."""
+        late = [] if (LATE_PARAMS and not join) else None
+        def params(fn):                    # a parameter-gradient launch: now, or behind the input-gradient chain
+            if late is None:
+                fn()
+            else:
+                late.append(fn)
         P = self._model
         hw = lambda a: (a.shape[1], a.shape[2])
         a = t['conv1x1']
@@ -228,19 +244,20 @@ class FAN(TFModel):
             if fused(i) and ops.pooled_backward_ok(conv.cin, conv.cout, conv.ks) and prev_mask is None:
                 # the pooled gradient feeds the weight / input gradient kernels directly (un-pooled while staging)
                 if t.get('front'):     # row-band front end: `inp` is the filtered image as 8-byte bf16 pixels
-                    ops.conv1_wgrad_c4(inp, d_pool, t['idx{}'.format(i)], dw=P.g[conv.name + '/kernel'],
-                                       db=P.g[conv.name + '/bias'], side=True)
+                    params(lambda inp=inp, g=d_pool, i=i, conv=conv: ops.conv1_wgrad_c4(
+                        inp, g, t['idx{}'.format(i)], dw=P.g[conv.name + '/kernel'], db=P.g[conv.name + '/bias'], side=True))
                     d_pool = ops.conv1_dgrad_pooled(d_pool, t['idx{}'.format(i)], P.p[conv.name + '/kernel'])
                 else:
-                    ops.conv2d_wgrad_pooled(inp, d_pool, t['idx{}'.format(i)], conv.ks, dw=P.g[conv.name + '/kernel'],
-                                            db=P.g[conv.name + '/bias'], side=True)
+                    params(lambda inp=inp, g=d_pool, i=i, conv=conv: ops.conv2d_wgrad_pooled(
+                        inp, g, t['idx{}'.format(i)], conv.ks, dw=P.g[conv.name + '/kernel'], db=P.g[conv.name + '/bias'],
+                        side=True))
                     d_pool = ops.conv2d_dgrad_pooled(d_pool, t['idx{}'.format(i)], P.p[conv.name + '/kernel'])
                 continue
             if fused(i) and ops.unpool_fold_ok(inp, d_pool, conv.cin, conv.cout, conv.ks):
                 # throughput mode, 5x5 layers: both gradient kernels read (pooled gradient, arg-max bytes) and route while
                 # staging - the full-resolution gradient (4x the bytes, 3/4 zeros) is never written nor re-read
-                ops.conv2d_wgrad_unpool(inp, d_pool, t['idx{}'.format(i)], conv.ks, dw=P.g[conv.name + '/kernel'],
-                                        db=P.g[conv.name + '/bias'], side=True)
+                params(lambda inp=inp, g=d_pool, i=i, conv=conv: ops.conv2d_wgrad_unpool(
+                    inp, g, t['idx{}'.format(i)], conv.ks, dw=P.g[conv.name + '/kernel'], db=P.g[conv.name + '/bias'], side=True))
                 d_pool = ops.conv2d_dgrad_unpool(d_pool, t['idx{}'.format(i)], P.p[conv.name + '/kernel'], act_mask=prev_mask,
                                                  out_bf16=g_bf16(i - 1))
                 continue
@@ -252,11 +269,14 @@ class FAN(TFModel):
                 dz = ops.maxpool2_bwd(d_pool, t['conv{}'.format(i)], None, apply_mask=not gen)
                 if gen:
                     dz = act_bwd(dz, t['conv{}'.format(i)])
-            conv.backward_params(P, inp, dz)
+            params(lambda conv=conv, inp=inp, dz=dz: conv.backward_params(P, inp, dz))
             d_pool = conv.backward_input(P, dz, hw(inp), act_mask=prev_mask, out_bf16=g_bf16(i - 1))
-        self._constrained.backward_params(P, t['x'], d_pool)
+        params(lambda g=d_pool: self._constrained.backward_params(P, t['x'], g))
         dx = self._constrained.backward_input(t['nf'], d_pool) if need_input_grad else None
-        ops.join_side_stream()
+        for fn in late or ():
+            fn()
+        if join:
+            ops.join_side_stream()
         return loss, dx
 
     # -- reference surface ---------------------------------------------------------------------------------------

@@ -266,9 +266,15 @@ class ManipulationClassification(object):
 
         # ---- backward
         self._nan_flag.zero_()
-        loss_ce, dC = self.fan.backward(fctx, need_input_grad=need_upstream)
-        ops.nan_flag(self.fan._model.flat_grad, self._nan_flag)
-        self._bucket.launch(self.fan._model.flat_grad)              # overlaps with the rest of the backward pass
+        # one process, gradients flowing on upstream: the FAN's weight gradients are issued BEHIND its input-gradient chain and
+        # run beside the codec / manipulation / UNet backward (HBM- and latency-bound kernels that leave the matrix cores idle)
+        # instead of beside the FAN's own input gradients (which fill the chip themselves); their NaN flag is taken at the end.
+        # With ranks to talk to, the FAN bucket has to leave early instead: the old order.
+        late_fan = forensics.LATE_PARAMS and need_upstream and not parallel.is_distributed()
+        loss_ce, dC = self.fan.backward(fctx, need_input_grad=need_upstream, join=not late_fan)
+        if not late_fan:
+            ops.nan_flag(self.fan._model.flat_grad, self._nan_flag)
+            self._bucket.launch(self.fan._model.flat_grad)          # overlaps with the rest of the backward pass
         loss_dcn = None
         dc = None
         if need_upstream:
@@ -338,6 +344,9 @@ class ManipulationClassification(object):
                 self._bucket.launch(self.nip._model.flat_grad)
         else:
             loss_nip, _ = self.nip._loss_fn(Y, target)
+        if late_fan:
+            ops.nan_flag(self.fan._model.flat_grad, self._nan_flag)         # joins the side streams
+            self._bucket.launch(self.fan._model.flat_grad)
         parallel.all_reduce_flag(self._nan_flag)
         torch.maximum(self._nan_seen, self._nan_flag, out=self._nan_seen)
         if self._nan_check == 'eager' and int(self._nan_flag.item()) != 0:       # host sync, like the reference
