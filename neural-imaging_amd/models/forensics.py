@@ -24,6 +24,8 @@ from .tfmodel import ParamStore, TFModel, glorot_uniform_
 # The FAN's weight gradients issued behind its input-gradient chain when the caller keeps launching (the workflow's codec /
 # manipulation / UNet backward): NIMG_NO_LATE_PARAMS=1 = beside the input gradients, as rounds 1 - 3 (A/B runs).
 LATE_PARAMS = os.environ.get('NIMG_NO_LATE_PARAMS') is None
+LATE_MIN_IMAGES = int(os.environ.get('NIMG_LATE_MIN_IMAGES', '160'))      # FAN batch from which the late order pays
+LATE_MASK = int(os.environ.get('NIMG_LATE_MASK', '255'))      # bit 0: constrained filter, bit i: convolution i (A/B runs)
 
 
 class FAN(TFModel):
@@ -185,8 +187,8 @@ class FAN(TFModel):
         LATE_PARAMS the weight gradients of the fused conv + pool layers are ISSUED behind the whole input-gradient chain, so
         they run beside whatever the caller launches next instead of beside the (equally chip-filling) input-gradient kernels."""
         late = [] if (LATE_PARAMS and not join) else None
-        def params(fn):                    # a parameter-gradient launch: now, or behind the input-gradient chain
-            if late is None:
+        def params(fn, layer=0):           # a parameter-gradient launch: now, or behind the input-gradient chain
+            if late is None or not (LATE_MASK >> layer) & 1:
                 fn()
             else:
                 late.append(fn)
@@ -245,19 +247,19 @@ class FAN(TFModel):
                 # the pooled gradient feeds the weight / input gradient kernels directly (un-pooled while staging)
                 if t.get('front'):     # row-band front end: `inp` is the filtered image as 8-byte bf16 pixels
                     params(lambda inp=inp, g=d_pool, i=i, conv=conv: ops.conv1_wgrad_c4(
-                        inp, g, t['idx{}'.format(i)], dw=P.g[conv.name + '/kernel'], db=P.g[conv.name + '/bias'], side=True))
+                        inp, g, t['idx{}'.format(i)], dw=P.g[conv.name + '/kernel'], db=P.g[conv.name + '/bias'], side=True), i)
                     d_pool = ops.conv1_dgrad_pooled(d_pool, t['idx{}'.format(i)], P.p[conv.name + '/kernel'])
                 else:
                     params(lambda inp=inp, g=d_pool, i=i, conv=conv: ops.conv2d_wgrad_pooled(
                         inp, g, t['idx{}'.format(i)], conv.ks, dw=P.g[conv.name + '/kernel'], db=P.g[conv.name + '/bias'],
-                        side=True))
+                        side=True), i)
                     d_pool = ops.conv2d_dgrad_pooled(d_pool, t['idx{}'.format(i)], P.p[conv.name + '/kernel'])
                 continue
             if fused(i) and ops.unpool_fold_ok(inp, d_pool, conv.cin, conv.cout, conv.ks):
                 # throughput mode, 5x5 layers: both gradient kernels read (pooled gradient, arg-max bytes) and route while
                 # staging - the full-resolution gradient (4x the bytes, 3/4 zeros) is never written nor re-read
                 params(lambda inp=inp, g=d_pool, i=i, conv=conv: ops.conv2d_wgrad_unpool(
-                    inp, g, t['idx{}'.format(i)], conv.ks, dw=P.g[conv.name + '/kernel'], db=P.g[conv.name + '/bias'], side=True))
+                    inp, g, t['idx{}'.format(i)], conv.ks, dw=P.g[conv.name + '/kernel'], db=P.g[conv.name + '/bias'], side=True), i)
                 d_pool = ops.conv2d_dgrad_unpool(d_pool, t['idx{}'.format(i)], P.p[conv.name + '/kernel'], act_mask=prev_mask,
                                                  out_bf16=g_bf16(i - 1))
                 continue
@@ -269,7 +271,7 @@ class FAN(TFModel):
                 dz = ops.maxpool2_bwd(d_pool, t['conv{}'.format(i)], None, apply_mask=not gen)
                 if gen:
                     dz = act_bwd(dz, t['conv{}'.format(i)])
-            params(lambda conv=conv, inp=inp, dz=dz: conv.backward_params(P, inp, dz))
+            params(lambda conv=conv, inp=inp, dz=dz: conv.backward_params(P, inp, dz), i)
             d_pool = conv.backward_input(P, dz, hw(inp), act_mask=prev_mask, out_bf16=g_bf16(i - 1))
         params(lambda g=d_pool: self._constrained.backward_params(P, t['x'], g))
         dx = self._constrained.backward_input(t['nf'], d_pool) if need_input_grad else None
