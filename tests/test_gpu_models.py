@@ -1234,6 +1234,38 @@ def test_data_parallel_step_nccl_world1(dev, codec, mode):
             assert np.abs(p0[k] - p1[k]).max() <= 1e-6, ('parameters after 3 Adam steps', k)
 
 
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+def test_late_fan_weight_gradients_are_the_same_gradients(dev, mode, monkeypatch):
+    """The workflow issues the FAN's weight gradients behind its input-gradient chain (forensics.LATE_PARAMS, from
+    LATE_MIN_IMAGES FAN images): same kernels on the same operands - gradients, NaN flag and the Adam step are bit-identical to
+    the order that launches them beside the input gradients."""
+    from neural_imaging_amd import ops
+    from neural_imaging_amd.models import forensics
+    from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
+    ops.set_compute(mode)
+    try:
+        dist = {'downsampling': 'none', 'compression': 'jpeg', 'compression_params': {'quality': 80, 'codec': 'soft'}}
+        rgb = natural_images(2, 64, 64, seed=33)
+        raw = bayer_from_rgb(rgb)
+        bx, by = torch.from_numpy(raw).to(dev), torch.from_numpy(rgb).to(dev)
+        monkeypatch.setattr(forensics, 'LATE_MIN_IMAGES', 0)
+        state = []
+        for late in (True, False):
+            monkeypatch.setattr(forensics, 'LATE_PARAMS', late)
+            wf = ManipulationClassification('UNet', distribution=dist, trainable={'nip'}, raw_patch_size=32, device=dev,
+                                            nan_check='deferred')
+            for _ in range(2):
+                loss, _ = wf.training_step(bx, by, lambda_nip=0.1, learning_rate=1e-3)
+            wf.check_nan()
+            state.append((float(loss), wf.fan._model.flat_grad.clone(), wf.nip._model.flat_grad.clone(),
+                          wf.fan._model.flat.clone(), wf.nip._model.flat.clone()))
+        assert state[0][0] == state[1][0]
+        for a, b in zip(state[0][1:], state[1][1:]):
+            assert torch.equal(a, b)
+    finally:
+        ops.set_compute('f32')
+
+
 def test_captured_step_replays_the_eager_step(dev):
     """graphs.CapturedStep: the hipGraph replay of the training step walks the same weights trajectory as eager launches
     (including Keras Adam's per-step bias correction, which the replay reads from device memory)."""
