@@ -54,6 +54,7 @@ def evaluate(wf, raw, rgb, batch=64):
     n = raw.shape[0]
     mse, nll, hits, decs, count = 0.0, 0.0, 0, [], 0
     per_class = torch.zeros(wf.n_classes, device=raw.device)
+    pair_hits = 0                    # first / last class ('native' / 'jpeg:80' in C4) taken as ONE class
     for i in range(0, n - batch + 1, batch):
         res = wf.run_workflow(raw[i:i + batch])
         Y, probs = res[0].t.float(), res[-1].t.float()
@@ -62,12 +63,15 @@ def evaluate(wf, raw, rgb, batch=64):
         decs.append(d)
         hits += int((d == labels).sum().item())
         per_class += (d == labels).float().view(wf.n_classes, batch).sum(dim=1)
+        dm = d.view(wf.n_classes, batch)[[0, wf.n_classes - 1]]
+        pair_hits += int(((dm == 0) | (dm == wf.n_classes - 1)).sum().item())
         nll += float((-probs.gather(1, labels[:, None]).clamp_min(1e-7).log()).sum().item())
         mse += float(((Y - rgb[i:i + batch]) ** 2).mean().item())
         count += 1
     nd = count * batch * wf.n_classes
     return {'fan_accuracy': hits / nd, 'ce': nll / nd, 'isp_psnr_db': float(10 * np.log10(1.0 / (mse / count))),
-            'per_class_accuracy': [round(float(v), 4) for v in (per_class / (count * batch)).tolist()]}, torch.cat(decs)
+            'per_class_accuracy': [round(float(v), 4) for v in (per_class / (count * batch)).tolist()],
+            'first_or_last_class_accuracy': pair_hits / (2.0 * count * batch)}, torch.cat(decs)
 
 
 def pretrain_nip(wf, pool, steps, lr, batch, seed):
