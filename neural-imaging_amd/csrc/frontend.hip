@@ -743,6 +743,52 @@ __global__ __launch_bounds__(256) void conv1_dgrad_pooled_kernel(const void* __r
         __syncthreads();
         if (t + (int)gridDim.x < total) fetch(t + gridDim.x);
 
+#ifndef NIMG_E_NO_PAIR
+        // a wave owns two ADJACENT output rows: their taps read the tile rows r0 .. r0 + 5, each fragment ONCE for both rows (30
+        // operand reads per 50 matrix instructions instead of 50; every accumulator still sums ky = 0 .. 4 in that order: same bits)
+        static_assert(E_TR == 8, "four waves x two adjacent rows");
+        {
+            const int r0 = 2 * wave;
+            f32x4 acc2[2][5];
+#pragma unroll
+            for (int fq = 0; fq < 5; ++fq) {
+                const int q = 16 * fq + nl;
+                const int slot = (kg ^ (((q >> 3) & 1) << 1)) * 16;
+                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {                            // tile row r0 + 5 - j: ky = j for row r0 + 1, j - 1 for row r0
+                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(sZ + ((r0 + 5 - j) * E_HC + q) * 64 + slot);
+                    if (j < 5) a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j], b, a1, 0, 0, 0);
+                    if (j >= 1) a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j - 1], b, a0, 0, 0, 0);
+                }
+                acc2[0][fq] = a0;
+                acc2[1][fq] = a1;
+            }
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+#pragma unroll
+                for (int fq = 0; fq < 5; ++fq) {
+                    const int q = 16 * fq + nl;
+                    if (q < E_HC) {
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) sP[(4 * kg + reg) * E_PS + q] = acc2[rr][fq][reg];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                const int oy = y0 + r0 + rr;
+                float o3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx)
+#pragma unroll
+                    for (int ci = 0; ci < 3; ++ci) o3[ci] += sP[(kx * 3 + ci) * E_PS + lane + 4 - kx];
+                if (oy < H && x0 + lane < W) {
+                    float* d = dc + ((long)(n * H + oy) * W + x0 + lane) * 3;
+                    d[0] = o3[0]; d[1] = o3[1]; d[2] = o3[2];
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+#else
         for (int r = wave; r < E_TR; r += 4) {
             // output row y0 + r, tap ky reads gradient row y0 + r + 2 - ky = tile row r + 4 - ky; position q = tile column
 #pragma unroll
@@ -776,6 +822,7 @@ __global__ __launch_bounds__(256) void conv1_dgrad_pooled_kernel(const void* __r
             }
             __builtin_amdgcn_wave_barrier();
         }
+#endif
     }
 }
 
