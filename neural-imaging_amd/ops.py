@@ -195,14 +195,17 @@ _ws = Workspace()
 # streams so the kernels share the machine.  A side stream first waits for everything queued on the launch stream,
 # the tensors it reads are pinned against early reuse by the caching allocator (record_stream), and every consumer of
 # the gradient buffers (optimiser, all-reduce, NaN check, end of each model's backward) joins them.
-# NIMG_SIDE_STREAMS=n (default 3): the parameter gradients of different layers are independent of each other as well - on
+# NIMG_SIDE_STREAMS=n (default 2): the parameter gradients of different layers are independent of each other as well - on
 # ONE side stream the UNet's ~25 weight-gradient + slab-reduction pairs (20 - 70 us each, a dependent launch gap between
-# them) finish ~0.25 ms after the input-gradient chain they run beside (profiles/r03_ao_c4_launch_trace.txt); spread over three
-# they end with it.  A gradient buffer always goes to the same stream (`key`), so accumulating launches stay ordered; each
-# stream has its own split-K scratch.  NIMG_NO_SIDE_STREAM=1 keeps everything on one stream.
+# them) finish ~0.25 ms after the input-gradient chain they run beside (profiles/r03_ao_c4_launch_trace.txt).  Round 3 spread
+# them over three; since the FAN's weight gradients are issued late (models/forensics.py LATE_PARAMS) three streams put three
+# chip-filling 5x5 weight gradients beside the launch stream at once (profiles/r04_final_c4_launch_trace.txt: djpeg_bwd waits
+# 1.2 ms for a CU) - with two, every workload is 1 - 4 % faster and the captured two-branch graph replays as fast as eager
+# launches (profiles/r04_side_streams_2_vs_3.txt).  A gradient buffer always goes to the same stream (`key`), so accumulating
+# launches stay ordered; each stream has its own split-K scratch.  NIMG_NO_SIDE_STREAM=1 keeps everything on one stream.
 import os as _os
 
-_SIDE = {'streams': [], 'ws': [Workspace()], 'n': max(1, int(_os.environ.get('NIMG_SIDE_STREAMS', '3'))), 'next': 0, 'keys': {},
+_SIDE = {'streams': [], 'ws': [Workspace()], 'n': max(1, int(_os.environ.get('NIMG_SIDE_STREAMS', '2'))), 'next': 0, 'keys': {},
          'enabled': _os.environ.get('NIMG_NO_SIDE_STREAM') is None, 'dirty': set()}
 _ws_side = _SIDE['ws'][0]       # split-K scratch of the kernels that run on the (first) side stream
 
