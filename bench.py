@@ -452,12 +452,13 @@ def dp1_nccl_leg(wl, n=20):
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
-        t, c = time.perf_counter(), time.thread_time()
+        t, host = time.perf_counter(), 0.0
         pace = RunAhead()
         for _ in range(n):
+            c = time.thread_time()
             fn()
+            host += 1e3 * (time.thread_time() - c) / n       # issuing the step only: the pacing wait below spins on an event
             pace()
-        host = 1e3 * (time.thread_time() - c) / n
         torch.cuda.synchronize()
         return 1e3 * (time.perf_counter() - t) / n, host
     plain_ms, plain_host = timed(wl.eager)
@@ -642,8 +643,8 @@ def main():
     edges = [round(i * args.steps / nblk) for i in range(nblk + 1)]
     barrier()
     t0 = time.perf_counter()
-    c0 = time.thread_time()                    # CPU time this thread spends issuing the steps (host cost of the launch path)
-    last = None
+    host_cpu = 0.0                             # CPU time this thread spends ISSUING the steps (host cost of the launch path; the
+    last = None                                # run-ahead wait spins on an event and is not counted)
     host_step_ms = []
     pace = RunAhead(args.run_ahead) if args.run_ahead > 0 else (lambda: None)
     if args.stall_probe:
@@ -654,13 +655,15 @@ def main():
         if args.stall_probe:
             faulthandler.dump_traceback_later(0.15, file=sys.stderr)
             t_s = time.perf_counter()
+        c0 = time.thread_time()
         last = step()
+        host_cpu += time.thread_time() - c0
         pace()
         if args.stall_probe:
             faulthandler.cancel_dump_traceback_later()
             host_step_ms.append(1e3 * (time.perf_counter() - t_s))
     marks[nblk].record()
-    host_cpu_ms = 1e3 * (time.thread_time() - c0) / max(args.steps, 1)
+    host_cpu_ms = 1e3 * host_cpu / max(args.steps, 1)
     barrier()
     dt = time.perf_counter() - t0
     wl.finish()
