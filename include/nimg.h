@@ -193,7 +193,8 @@ int nimg_ssim(const float* a, const float* b, float* out, int n, int h, int w, i
               const float* gauss_win, void* workspace, size_t workspace_bytes, void* stream);
 /* FAN head, models/forensics.py:80-94: GAP -> Dense(k, softmax) -> SparseCategoricalCrossentropy on probabilities
  * (Keras eager semantics: clip to [1e-7, 1-1e-7], renormalise).  act (n,hw,c) is the 1x1-conv output AFTER LeakyReLU.
- * labels may be NULL (inference: only gap/probs are written).  loss_scale = 1/batch (mean reduction). */
+ * labels may be NULL (inference: only gap/probs are written).  loss_scale = 1/batch (mean reduction).  k <= 256 classes (the
+ * reference's own bound, models/forensics.py:37): one lane sums up to 16 classes, from 17 on the wave's lanes own the classes. */
 int nimg_fan_head_fwd(const float* act, const float* w, const float* b, const int* labels, float* gap, float* probs,
                       float* loss_per, float* dlogits, int n, int hw, int c, int k, float loss_scale, void* stream);
 /* dact = gradient wrt the 1x1 conv PRE-activation (LeakyReLU' fused), dw (c,k), db (k), loss (1) */

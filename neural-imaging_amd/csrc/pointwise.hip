@@ -550,6 +550,110 @@ __global__ __launch_bounds__(64) void dense_softmax_ce_kernel(const float* __res
     for (int j = 0; j < k; ++j) dlogits[(long)im * k + j] = loss_scale * pr[j] * (g[j] - dot);
 }
 
+// The same head for 16 < k <= 256 classes (models/forensics.py:37 allows n_classes up to 256): the lanes of the image's wave own
+// the classes (lane j: classes j, j + 64, ...), the softmax / clip / renormalise sums are wave reductions.
+__global__ __launch_bounds__(64) void dense_softmax_ce_wide_kernel(const float* __restrict__ gap, const float* __restrict__ w,
+                                        const float* __restrict__ b, const int* __restrict__ labels,
+                                        float* __restrict__ probs, float* __restrict__ loss_per,
+                                        float* __restrict__ dlogits, int n, int c, int k, float loss_scale) {
+    const int im = blockIdx.x, lane = threadIdx.x;
+    if (im >= n) return;
+    float z[4], pr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) z[q] = 0.f;
+    for (int ch = 0; ch < c; ++ch) {
+        const float g = gap[(long)im * c + ch];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = lane + 64 * q;
+            if (j < k) z[q] = fmaf(g, w[ch * k + j], z[q]);
+        }
+    }
+    float m = -3.0e38f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = lane + 64 * q;
+        if (j < k) { z[q] += b[j]; m = fmaxf(m, z[q]); }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = lane + 64 * q;
+        pr[q] = j < k ? expf(z[q] - m) : 0.f;
+        s += pr[q];
+    }
+    s = wave_sum(s);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = lane + 64 * q;
+        pr[q] /= s;
+        if (j < k) probs[(long)im * k + j] = pr[q];
+    }
+    if (!labels) return;
+    const float eps = 1e-7f;
+    const int lab = labels[im];
+    float pc[4], S = 0.f, pl = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = lane + 64 * q;
+        pc[q] = j < k ? fminf(fmaxf(pr[q], eps), 1.0f - eps) : 0.f;
+        S += pc[q];
+        if (j == lab) pl = pc[q];
+    }
+    S = wave_sum(S);
+    pl = wave_sum(pl);                         // exactly one lane holds the label's clipped probability
+    if (lane == 0) loss_per[im] = -logf(pl) + logf(S);
+    float g[4], dot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = lane + 64 * q;
+        const bool inside = j < k && pr[q] >= eps && pr[q] <= 1.0f - eps;
+        g[q] = inside ? (1.0f / S - (j == lab ? 1.0f / pl : 0.f)) : 0.f;
+        dot += g[q] * pr[q];
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = lane + 64 * q;
+        if (j < k) dlogits[(long)im * k + j] = loss_scale * pr[q] * (g[q] - dot);
+    }
+}
+
+// ... and its parameter gradients: one wave per feature channel (block c: bias, block c + 1: the loss), lanes over the classes,
+// the images summed in order
+__global__ __launch_bounds__(64) void dense_bwd_params_wide_kernel(const float* __restrict__ gap,
+                                        const float* __restrict__ dlogits, const float* __restrict__ loss_per,
+                                        float* __restrict__ dw, float* __restrict__ db, float* __restrict__ loss, int n, int c,
+                                        int k, float loss_scale) {
+    const int ch = blockIdx.x, lane = threadIdx.x;
+    if (ch == c + 1) {
+        double sd = 0.0;
+        for (int im = lane; im < n; im += 64) sd += (double)loss_per[im];
+        sd = wave_sum_d(sd);
+        if (lane == 0) loss[0] = (float)(sd * (double)loss_scale);
+        return;
+    }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int im = 0; im < n; ++im) {
+        const float g = ch < c ? gap[(long)im * c + ch] : 1.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = lane + 64 * q;
+            if (j < k) acc[q] = fmaf(g, dlogits[(long)im * k + j], acc[q]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = lane + 64 * q;
+        if (j < k) {
+            if (ch < c) dw[ch * k + j] = acc[q];
+            else db[j] = acc[q];
+        }
+    }
+}
+
 // dW[c][j] = sum_n gap[n][c] dlogits[n][j];  db[j] = sum_n dlogits[n][j];  loss = scale * sum loss_per
 // one wave per feature channel (block c: bias gradient, block c + 1: the loss); lanes over the images
 __global__ __launch_bounds__(64) void dense_bwd_params_kernel(const float* __restrict__ gap,
@@ -967,12 +1071,16 @@ int nimg_ssim(const float* a, const float* b, float* out, int n, int h, int w, i
 int nimg_fan_head_fwd(const float* act, const float* w, const float* b, const int* labels, float* gap, float* probs,
                       float* loss_per, float* dlogits, int n, int hw, int c, int k, float loss_scale, void* stream) {
     if (n == 0) return NIMG_OK;        /* empty batch: nothing to do (its buffers may be null) */
-    if (!act || !w || !b || !gap || !probs || n < 0 || hw <= 0 || c <= 0 || k <= 0 || k > 16) return NIMG_ERR_ARG;
+    if (!act || !w || !b || !gap || !probs || n < 0 || hw <= 0 || c <= 0 || k <= 0 || k > 256) return NIMG_ERR_ARG;
     if (labels && (!loss_per || !dlogits)) return NIMG_ERR_ARG;
     if (n == 0) return NIMG_OK;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(gap_fwd_kernel, dim3(n), dim3(256), 0, s, act, gap, hw, c);
     NIMG_CHECK_LAUNCH();
+    if (k > 16)
+        hipLaunchKernelGGL(dense_softmax_ce_wide_kernel, dim3(n), dim3(64), 0, s, gap, w, b, labels, probs, loss_per, dlogits, n,
+                           c, k, loss_scale);
+    else
     hipLaunchKernelGGL(dense_softmax_ce_kernel, dim3(n), dim3(64), 0, s, gap, w, b, labels, probs, loss_per, dlogits, n, c,
                        k, loss_scale);
     NIMG_CHECK_LAUNCH();
@@ -983,8 +1091,12 @@ int nimg_fan_head_bwd(const float* act, const float* gap, const float* w, const 
                       const float* loss_per, float* dact, float* dw, float* db, float* loss, int n, int hw, int c,
                       int k, float loss_scale, float alpha, void* stream) {
     if (!act || !gap || !w || !dlogits || !loss_per || !dact || !dw || !db || !loss) return NIMG_ERR_ARG;
-    if (n <= 0 || hw <= 0 || c <= 0 || k <= 0 || k > 16) return NIMG_ERR_ARG;
+    if (n <= 0 || hw <= 0 || c <= 0 || k <= 0 || k > 256) return NIMG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    if (k > 16)
+        hipLaunchKernelGGL(dense_bwd_params_wide_kernel, dim3(c + 2), dim3(64), 0, s, gap, dlogits, loss_per, dw, db, loss, n, c,
+                           k, loss_scale);
+    else
     hipLaunchKernelGGL(dense_bwd_params_kernel, dim3(c + 2), dim3(64), 0, s, gap, dlogits, loss_per, dw, db, loss, n, c, k,
                        loss_scale);
     NIMG_CHECK_LAUNCH();

@@ -55,8 +55,8 @@ class FAN(TFModel):
         self.dropout_masks = None
         if not use_gap and patch_size is None:
             raise ValueError('the Flatten head (use_gap=False) needs a fixed patch_size')
-        if self._h.kernel not in (3, 5) or self._h.n_classes > 16:
-            raise NotImplementedError('kernel size {} / {} classes not built'.format(self._h.kernel, self._h.n_classes))
+        if self._h.kernel not in (3, 5):
+            raise NotImplementedError('kernel size {} not built'.format(self._h.kernel))
         self.patch_size = patch_size
         self.x = _Shape((None, patch_size, patch_size, 3))
         self.y = _Shape((None, n_classes))

@@ -126,6 +126,30 @@ def test_fan_forward_backward(dev):
     assert dec.shape == (5,) and (dec == probs_ref.detach().numpy().argmax(axis=1)).all()
 
 
+@pytest.mark.parametrize('n_classes', [24, 200])
+def test_fan_with_many_classes(dev, n_classes):
+    """FAN(n_classes) beyond the 16 classes one lane of the fused head holds (the reference allows up to 256, forensics.py:37):
+    probabilities, loss, every parameter gradient and the input gradient against the float64 oracle."""
+    from neural_imaging_amd.models import forensics
+    fan = forensics.FAN(n_classes=n_classes, patch_size=32, device=dev)
+    x = natural_images(6, 32, 32, seed=35)
+    labels = np.array([0, n_classes - 1, 7, 16, 17, n_classes // 2], np.int32)
+    p = oracle_params(fan)
+    for v in p.values():
+        v.requires_grad_(True)
+    xt = to64(x).requires_grad_(True)
+    probs_ref = onets.fan_forward(p, xt)
+    loss_ref = T.sparse_ce_from_probs(probs_ref, labels)
+    gr = torch.autograd.grad(loss_ref, list(p.values()) + [xt])
+    probs, ctx = fan.forward(torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev), training=True)
+    assert probs.shape == (6, n_classes)
+    assert_close(probs.cpu().numpy(), probs_ref.detach().numpy(), 1e-4, what='FAN probabilities')
+    loss, dx = fan.backward(ctx, need_input_grad=True)
+    assert abs(float(loss.item()) - float(loss_ref.detach())) < 1e-4
+    check_grads(grads_of(fan), dict(zip(p.keys(), gr[:-1])), list(p.keys()), tol=3e-4)
+    assert_close(dx.cpu().numpy(), gr[-1].numpy(), 1e-7, 3e-4, what='FAN input gradient')
+
+
 @pytest.mark.parametrize('fused', [True, False])
 @pytest.mark.parametrize('patch', [32, 48])
 def test_fan_small_patch_fused_vs_separate_pool(dev, fused, patch, monkeypatch):

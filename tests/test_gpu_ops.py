@@ -437,13 +437,16 @@ def test_mse255_and_adam_and_nanflag(dev):
     assert torch.equal(torch.nan_to_num(pg), torch.nan_to_num(before))
 
 
-def test_fan_head(dev):
+@pytest.mark.parametrize('k', [5, 16, 17, 100, 256])
+def test_fan_head(dev, k):
+    """GAP -> Dense(k, softmax) -> Keras sparse CE on probabilities, forward and backward: k <= 16 in one lane's registers, from
+    17 classes on the lanes of the image's wave own the classes (the reference allows n_classes up to 256, forensics.py:37)."""
     from neural_imaging_amd import ops
-    n, h, w, c, k = 6, 4, 4, 32, 5
+    n, h, w, c = 6, 4, 4, 32
     act = to64(rnd((n, h, w, c), 1)).requires_grad_(True)
     wt = to64(rnd((c, k), 2)).requires_grad_(True)
     b = to64(rnd((k,), 3)).requires_grad_(True)
-    labels = np.array([0, 1, 2, 3, 4, 1], np.int32)
+    labels = (np.array([0, 1, 2, 3, 4, 1], np.int32) * 53 + (k - 1) * np.array([0, 0, 1, 0, 0, 1], np.int32)) % k
     a = T.leaky_relu(act)
     probs = torch.softmax(a.mean(dim=(1, 2)) @ wt + b, dim=1)
     loss = T.sparse_ce_from_probs(probs, labels)
