@@ -188,6 +188,14 @@ int nimg_ssim_loss(const float* y, const float* t, float* loss, float* grad_y, i
  *   mode 0 = skimage.metrics.structural_similarity(multichannel=True, data_range=max_val) as helpers/metrics.py:9-25 uses
  *            it (7x7 uniform window, sample covariance);   mode 1 = tf.image.ssim(max_val) as models/compression.py:89
  *            uses it (11x11 Gaussian window sigma 1.5 passed by the caller in gauss_win[121], population moments). */
+/* The workflow's hand-over to the UNet backward in one pass (workflows/manipulation_classification.py:265-283 under the tape:
+ * d loss / d Y = the manipulations' input gradients + lambda_nip * d mse255(Y, target) / d Y, then the gradient of
+ * depth_to_space + clip, models/pipelines.py:203-205): dz (n,h,w,12) = space_to_depth of [parts[0] + ... + parts[n_parts-1] +
+ * grad_scale * d mse255(y, target) / d y] with parts / y / target (n,2h,2w,3), 1 <= n_parts <= 6; loss (1) = mse255(y, target).
+ * Same additions in the same order as nimg_add_n -> nimg_mse255(accumulate) -> nimg_d2s_clip_bwd(scale 1): same bits.
+ * workspace: nimg_mse255_workspace_bytes(). */
+int nimg_mse255_sum_s2d3(const float* const* parts, int n_parts, const float* y, const float* target, float* loss, float* dz,
+                         int n, int h, int w, float grad_scale, void* workspace, size_t workspace_bytes, void* stream);
 size_t nimg_ssim_workspace_bytes(int n);
 int nimg_ssim(const float* a, const float* b, float* out, int n, int h, int w, int c, int mode, float max_val,
               const float* gauss_win, void* workspace, size_t workspace_bytes, void* stream);

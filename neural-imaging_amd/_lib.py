@@ -48,6 +48,7 @@ PROTOTYPES = {
     'nimg_avgpool_bwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'nimg_mse255_workspace_bytes': (c_size_t, []),
     'nimg_mse255': (c_int, [P, P, P, P, c_long, c_float, c_int, P, c_size_t, P]),
+    'nimg_mse255_sum_s2d3': (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_float, P, c_size_t, P]),
     'nimg_fan_head_fwd': (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     'nimg_fan_head_bwd': (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P]),
     'nimg_adam_step': (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_int, c_float, P, P]),

@@ -465,6 +465,56 @@ __global__ __launch_bounds__(256) void mse255_kernel(const float* __restrict__ a
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
+// The head of the UNet's backward pass in the workflow, one pass instead of three (add_n -> mse255 with accumulate ->
+// d2s_clip3_bwd): element (n, y, x, ch) of the result's depth_to_space image = parts[0] + parts[1] + ... + gk (a - b), the
+// additions in that order with the same single rounding per step as the three kernels (the last one contracted to an fma, as
+// mse255_kernel's accumulate form compiles) - written as (n, h, w, 12); the loss partials as mse255_kernel.
+struct SumS2dParts { const float* p[6]; };
+__global__ __launch_bounds__(256) void mse255_sum_s2d3_kernel(SumS2dParts parts, int n_parts, const float* __restrict__ a,
+                                                              const float* __restrict__ b, float* __restrict__ dz,
+                                                              double* __restrict__ partial, long npix, int h, int w, float gscale) {
+    __shared__ double red[4];
+    double s = 0.0;
+    const long count = npix * 12;
+    const float gk = gscale * 2.0f * 255.0f * 255.0f / (float)count;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % w);
+        const long r = i / w;
+        const int yy = (int)(r % h);
+        const long im = r / h;
+        const long top = ((im * 2 * h + 2 * yy) * (2L * w) + 2 * xx) * 3, bot = top + 2L * w * 3;
+        float v[12];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const long o = half ? bot : top;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                float2 acc = reinterpret_cast<const float2*>(parts.p[0] + o)[q];
+#pragma unroll
+                for (int k = 1; k < 6; ++k)
+                    if (k < n_parts) {
+                        const float2 t = reinterpret_cast<const float2*>(parts.p[k] + o)[q];
+                        acc.x += t.x; acc.y += t.y;
+                    }
+                const float2 va = reinterpret_cast<const float2*>(a + o)[q], vb = reinterpret_cast<const float2*>(b + o)[q];
+                const float d0 = va.x - vb.x, d1 = va.y - vb.y;
+                const float e0 = 255.0f * d0, e1 = 255.0f * d1;
+                s += (double)e0 * (double)e0;
+                s += (double)e1 * (double)e1;
+                v[half * 6 + 2 * q] = fmaf(gk, d0, acc.x);
+                v[half * 6 + 2 * q + 1] = fmaf(gk, d1, acc.y);
+            }
+        }
+        float4* dst = reinterpret_cast<float4*>(dz + i * 12);
+        dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+        dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+        dst[2] = make_float4(v[8], v[9], v[10], v[11]);
+    }
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
 __global__ void mse255_final_kernel(const double* __restrict__ partial, int nblocks, long count, float* loss) {
     double s = 0.0;                                      // one wave: strided partials, then a fixed-shape butterfly
     for (int k = threadIdx.x; k < nblocks; k += 64) s += partial[k];
@@ -1039,6 +1089,29 @@ int nimg_mse255(const float* a, const float* b, float* loss, float* grad_a, long
                        grad_scale, accumulate);
     NIMG_CHECK_LAUNCH();
     hipLaunchKernelGGL(mse255_final_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, grid, count, loss);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_mse255_sum_s2d3(const float* const* parts, int n_parts, const float* y, const float* target, float* loss, float* dz,
+                         int n, int h, int w, float grad_scale, void* workspace, size_t workspace_bytes, void* stream) {
+    if (n == 0) return NIMG_OK;
+    if (!parts || n_parts < 1 || n_parts > 6 || !y || !target || !loss || !dz || !workspace || n < 0 || h <= 0 || w <= 0)
+        return NIMG_ERR_ARG;
+    if (workspace_bytes < nimg_mse255_workspace_bytes()) return NIMG_ERR_WORKSPACE;
+    SumS2dParts sp;
+    for (int i = 0; i < 6; ++i) {
+        sp.p[i] = i < n_parts ? parts[i] : nullptr;
+        if (i < n_parts && (!parts[i] || ((size_t)parts[i] & 7))) return NIMG_ERR_ARG;
+    }
+    if (((size_t)y & 7) || ((size_t)target & 7) || ((size_t)dz & 15)) return NIMG_ERR_ARG;
+    const long npix = (long)n * h * w;
+    const int grid = grid_for(npix);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(mse255_sum_s2d3_kernel, dim3(grid), dim3(256), 0, s, sp, n_parts, y, target, dz, (double*)workspace, npix,
+                       h, w, grad_scale);
+    NIMG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(mse255_final_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, grid, npix * 12, loss);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }

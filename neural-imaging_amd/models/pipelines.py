@@ -184,15 +184,23 @@ class UNet(NIPModel):
         """The decoder's slice of the flat gradient buffer (complete when the decoder backward is done), the encoder's."""
         return self._model.grad_range(first='dct1/kernel'), self._model.grad_range(before='dct1/kernel')
 
-    def backward(self, t, dy, on_decoder_done=None):
+    def head_gradient(self, parts, y, target, grad_scale):
+        """The workflow's hand-over in one pass (where it applies, else None): -> (L2 loss[1], dz_head) with dz_head = the gradient
+        behind depth_to_space + clip of sum(parts) + grad_scale * d L2 / d y, to be passed to backward(dz_head=)."""
+        if not ops.FUSED_HEAD_GRAD or self.loss_metric != 'L2' or not 1 <= len(parts) <= 6 or y.dtype != torch.float32 or \
+                any(p.dtype != torch.float32 or not p.is_contiguous() or p.data_ptr() % 8 for p in parts):
+            return None
+        return ops.mse255_sum_s2d3(parts, y, target, grad_scale)
+
+    def backward(self, t, dy, on_decoder_done=None, dz_head=None):
         """dy = d loss / d y (N,2h,2w,3).  Fills the gradient buffer; the RAW input needs no gradient.
         on_decoder_done(): called once every decoder gradient has been queued (data parallelism all-reduces that slice
-        while the encoder backward runs)."""
+        while the encoder backward runs).  dz_head: head_gradient()'s result instead of dy."""
         L, P, ns = self._layers, self._model, self._h.n_steps
         hw = lambda a: (a.shape[1], a.shape[2])
         sb = t['ec12'].dtype == torch.bfloat16              # the forward pass stored its activations as bf16: so are the gradients
         # head: d2s + clip are straight-through
-        dz = ops.d2s_clip_bwd(dy, 1.0)
+        dz = ops.d2s_clip_bwd(dy, 1.0) if dz_head is None else dz_head
         last = 'dc{}2'.format(ns - 1)
         L['dc{}'.format(ns)].backward_params(P, t[last], dz)
         dz = L['dc{}'.format(ns)].backward_input(P, dz, hw(t[last]), act_mask=t[last], out_bf16=sb)   # dZ of dc{ns-1}2

@@ -869,6 +869,30 @@ def mse255(a, b, grad_scale=None, grad_out=None, accumulate=False):
     return loss, g
 
 
+# The workflow hands the UNet its output gradient as (manipulation gradients..., L2 term): one pass that sums them and writes
+# the gradient behind depth_to_space + clip (NIMG_NO_FUSED_HEAD_GRAD=1: the three separate passes, A/B runs).
+FUSED_HEAD_GRAD = _os.environ.get('NIMG_NO_FUSED_HEAD_GRAD') is None
+
+
+def mse255_sum_s2d3(parts, y, target, grad_scale):
+    """(mse255(y, target)[1], space_to_depth(sum(parts) + grad_scale * d mse255 / d y)) - parts, y, target (n,2h,2w,3) float32;
+    bit-identical to add_n -> mse255(accumulate=True) -> d2s_clip_bwd(scale 1)."""
+    import ctypes
+    _f32(y, target, *parts)
+    n, h2, w2, c = y.shape
+    if c != 3 or (h2 & 1) or (w2 & 1) or not 1 <= len(parts) <= 6 or any(t.shape != y.shape for t in parts) or \
+            target.shape != y.shape:
+        raise ValueError('mse255_sum_s2d3: unsupported shapes')
+    loss = torch.empty((1,), dtype=torch.float32, device=y.device)
+    dz = torch.empty((n, h2 // 2, w2 // 2, 12), dtype=torch.float32, device=y.device)
+    need = _lib.load().nimg_mse255_workspace_bytes()
+    ws = _ws.get(need, y.device)
+    ptrs = (ctypes.c_void_p * len(parts))(*[t.data_ptr() for t in parts])
+    _lib.call('nimg_mse255_sum_s2d3', ptrs, len(parts), _p(y), _p(target), _p(loss), _p(dz), n, h2 // 2, w2 // 2,
+              float(grad_scale), _p(ws), ws.numel(), _stream())
+    return loss, dz
+
+
 def fan_head_fwd(act, w, b, labels=None, loss_scale=1.0):
     _f32(act, w, b)
     n, h, wd, c = act.shape

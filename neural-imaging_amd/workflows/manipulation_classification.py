@@ -328,10 +328,15 @@ class ManipulationClassification(object):
             parts_dY = [dm[:b]] + [op.backward(mctxs[k], dm[(k + 1) * b:(k + 2) * b])
                                    for k, (name, op) in enumerate(self._operations.items())]
             dY = dm[:b]
-            for i in range(0, len(parts_dY) - 1, 5):            # nimg_add_n takes up to 6 tensors per launch
-                chunk = ([dY] if i else [parts_dY[0]]) + parts_dY[i + 1:i + 6]
-                ops.add_n(chunk, out=dY)
-            loss_nip, _ = self.nip.loss_and_grad(Y, target, grad_scale=float(lambda_nip), grad_out=dY, accumulate=True)
+            head = self.nip.head_gradient(parts_dY, Y, target, float(lambda_nip)) if hasattr(self.nip, 'head_gradient') else None
+            nip_kw = {}
+            if head is not None:        # sum + L2 term + the gradient of depth_to_space / clip in one pass (UNet, L2 loss)
+                loss_nip, nip_kw['dz_head'] = head
+            else:
+                for i in range(0, len(parts_dY) - 1, 5):            # nimg_add_n takes up to 6 tensors per launch
+                    chunk = ([dY] if i else [parts_dY[0]]) + parts_dY[i + 1:i + 6]
+                    ops.add_n(chunk, out=dY)
+                loss_nip, _ = self.nip.loss_and_grad(Y, target, grad_scale=float(lambda_nip), grad_out=dY, accumulate=True)
             if parallel.is_distributed() and hasattr(self.nip, 'decoder_grads'):
                 # two buckets: the decoder's gradients (its backward runs first) travel while the encoder backward
                 # computes; only the encoder's slice is exposed at the end of the step
@@ -339,11 +344,11 @@ class ManipulationClassification(object):
                 def decoder_done():
                     ops.nan_flag(dec, self._nan_flag)
                     self._bucket.launch(dec)
-                self.nip.backward(nctx, dY, on_decoder_done=decoder_done)
+                self.nip.backward(nctx, dY, on_decoder_done=decoder_done, **nip_kw)
                 ops.nan_flag(enc, self._nan_flag)
                 self._bucket.launch(enc)
             else:
-                self.nip.backward(nctx, dY)
+                self.nip.backward(nctx, dY, **nip_kw)
                 ops.nan_flag(self.nip._model.flat_grad, self._nan_flag)
                 self._bucket.launch(self.nip._model.flat_grad)
         else:

@@ -1290,6 +1290,30 @@ def test_late_fan_weight_gradients_are_the_same_gradients(dev, mode, monkeypatch
         ops.set_compute('f32')
 
 
+def test_fused_head_gradient_gives_the_same_step(dev, monkeypatch):
+    """The workflow's one-pass hand-over to the UNet backward (UNet.head_gradient) against the three separate passes: same
+    loss, bit-identical gradients and parameters after two steps."""
+    from neural_imaging_amd import ops
+    from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
+    dist = {'downsampling': 'none', 'compression': 'jpeg', 'compression_params': {'quality': 80, 'codec': 'soft'}}
+    rgb = natural_images(2, 64, 64, seed=37)
+    raw = bayer_from_rgb(rgb)
+    bx, by = torch.from_numpy(raw).to(dev), torch.from_numpy(rgb).to(dev)
+    state = []
+    for fused in (True, False):
+        monkeypatch.setattr(ops, 'FUSED_HEAD_GRAD', fused)
+        wf = ManipulationClassification('UNet', distribution=dist, trainable={'nip'}, raw_patch_size=32, device=dev,
+                                        nan_check='deferred')
+        for _ in range(2):
+            loss, comp = wf.training_step(bx, by, lambda_nip=0.1, learning_rate=1e-3)
+        wf.check_nan()
+        state.append((float(comp['nip']), wf.nip._model.flat_grad.clone(), wf.fan._model.flat_grad.clone(),
+                      wf.nip._model.flat.clone()))
+    assert abs(state[0][0] - state[1][0]) <= 1e-6 * abs(state[1][0])
+    for a, b in zip(state[0][1:], state[1][1:]):
+        assert torch.equal(a, b)
+
+
 def test_captured_step_replays_the_eager_step(dev):
     """graphs.CapturedStep: the hipGraph replay of the training step walks the same weights trajectory as eager launches
     (including Keras Adam's per-step bias correction, which the replay reads from device memory)."""

@@ -322,6 +322,26 @@ def test_conv_writes_activation_and_pooled_tensor(dev, n, cin, cout, h, w):
         ops.set_compute('f32')
 
 
+@pytest.mark.parametrize('n_parts', [1, 2, 5, 6])
+def test_head_gradient_in_one_pass(dev, n_parts):
+    """ops.mse255_sum_s2d3 = add_n -> mse255(accumulate) -> d2s_clip_bwd(scale 1) in one pass: the same additions in the same
+    order (bit-identical gradient), the loss to float32 rounding of its float64 sum."""
+    from neural_imaging_amd import ops
+    n, h2, w2 = 3, 24, 40
+    parts = [g(rnd((n, h2, w2, 3), 10 + k, -0.1, 0.1), dev) for k in range(n_parts)]
+    y, t = g(rnd((n, h2, w2, 3), 1, 0, 1), dev), g(rnd((n, h2, w2, 3), 2, 0, 1), dev)
+    s = ops.add_n(parts) if n_parts > 1 else parts[0].clone()
+    loss_ref, _ = ops.mse255(y, t, grad_scale=0.1, grad_out=s, accumulate=True)
+    dz_ref = ops.d2s_clip_bwd(s, 1.0)
+    loss, dz = ops.mse255_sum_s2d3(parts, y, t, 0.1)
+    assert dz.shape == (n, h2 // 2, w2 // 2, 12) and torch.equal(dz, dz_ref)
+    assert abs(float(loss) - float(loss_ref)) <= 1e-6 * abs(float(loss_ref))
+    ref64 = float((((to64(y.cpu().numpy()) - to64(t.cpu().numpy())) * 255.0) ** 2).mean())
+    assert abs(float(loss) - ref64) <= 1e-6 * ref64
+    with pytest.raises(ValueError):
+        ops.mse255_sum_s2d3(parts + parts + parts + parts + parts + parts + parts, y, t, 0.1)
+
+
 @pytest.mark.parametrize('shape', [(3, 40, 56, 3), (2, 64, 64, 1), (1, 11, 11, 3)])
 def test_ssim_both_flavours(dev, shape):
     """Device SSIM against the restated skimage (7x7 uniform, sample covariance) and tf.image.ssim (11x11 Gaussian)."""
