@@ -47,6 +47,7 @@ extern "C" {
                            * space_to_depth(2) image (n, hout / 2, wout / 2, 4 o1) of the result - the gradient of a depth_to_space
                            * layer, written by the input-gradient pass that produces it (models/compression.py:233,245 backward);
                            * act_mask and residual keep the convolution's own (n, hout, wout, o1) layout */
+#define NIMG_UNPOOL_OUT 512 /* internal to nimg_conv2d_dgrad_unpool_out_bf16: the result is routed through a 2x2 max-pool's backward */
 #define NIMG_POOL_ALSO 256 /* internal to nimg_conv2d_fwd_pool_also_bf16: the pooled tensor is written next to out1, not instead of it */
 
 /* library / ABI version, bumped on any signature change of an existing entry point (3: nimg_conv2d_fwd_bf16_res gained
@@ -477,6 +478,14 @@ int nimg_conv2d_pool_fwd_bf16_ex(const float* in, int cin, const float* w, const
  * encoder level + its max_pool2d (models/pipelines.py:160-173): the full tensor is the skip connection. */
 int nimg_conv2d_fwd_pool_also_bf16(const float* in, int cin, const void* wb, const float* bias, float* out, float* pool_out,
                                    unsigned char* pool_idx, int cout, int n, int h, int wd, int act, float alpha, void* stream);
+/* Input gradient of a 3x3 SAME stride-1 convolution whose input was a 2x2 max-pool, written THROUGH that pool (the first
+ * convolution of a UNet encoder level, models/pipelines.py:160-173 under the tape), all tensors bf16: dz (n,h,wd,c1) = the
+ * convolution's output gradient, wb = its weights in input-gradient form (nimg_conv_weights_bf16 mode 1), act (n,2h,2wd,cout) =
+ * the activation the pool read, skip (same shape, optional, may be `out`) = the gradient arriving over the level's skip
+ * connection, out (n,2h,2wd,cout) = [route to the first maximum of each window + skip] x LeakyReLU'(act) (apply_mask) - the
+ * arithmetic of nimg_conv2d_fwd_bf16_ex(bf16 out) followed by nimg_maxpool2_bwd_bf16, same bits.  c1 % 8 == 0, cout % 8 == 0. */
+int nimg_conv2d_dgrad_unpool_out_bf16(const float* dz, int c1, const void* wb, const float* act, const float* skip, float* out,
+                                      int cout, int n, int h, int wd, int apply_mask, float alpha, void* stream);
 int nimg_conv2d_wgrad_pooled_bf16_ex(const float* in, int cin, const float* g, const unsigned char* idx, int cout,
                                      float* dw, float* db, int n, int h, int wd, int ks, int accumulate, void* workspace,
                                      size_t workspace_bytes, int flags, void* stream);     /* NIMG_BF16_DZ: g is bf16 */

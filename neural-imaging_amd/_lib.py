@@ -136,6 +136,7 @@ PROTOTYPES = {
                                           c_int, c_int, c_int, c_int, c_int, P, c_size_t, c_int, P]),
     'nimg_conv2d_pool_fwd_bf16_ex': (c_int, [P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                              c_int, P]),
+    'nimg_conv2d_dgrad_unpool_out_bf16': (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, P]),
     'nimg_conv2d_fwd_pool_also_bf16': (c_int, [P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, P]),
     'nimg_conv2d_wgrad_pooled_bf16_ex': (c_int, [P, c_int, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, P,
                                                  c_size_t, c_int, P]),

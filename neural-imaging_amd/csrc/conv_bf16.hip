@@ -168,6 +168,54 @@ __device__ __forceinline__ void conv_epilogue_vec(const f32x16 (&acc)[MI][NI], c
 #ifndef NIMG_NO_EPI8
     // bf16-stored outputs (and mask) in the plain layout - the UNet's and the codec's inner layers: eight channels per lane,
     // 16-byte stores / mask loads (the store-issue rate, not the bytes, bounds a row-per-lane epilogue)
+    // NIMG_UNPOOL_OUT: the result is the gradient of a 2x2 max-pool's OUTPUT (the UNet's encoder levels, pipelines.py:160-173
+    // backward): every value goes to the first maximum of its window of the stored activation act1 (n, 2 hout, 2 wout, o1), the
+    // skip gradient `res` (same shape, bf16, optional; may be out1 itself) is added to all four positions, LeakyReLU'(act1)
+    // applied (act == 1) - maxpool2_bwd_bf16_kernel's arithmetic on the value this kernel would have stored as bf16
+    if (p.flags & NIMG_UNPOOL_OUT) {
+        const __bf16* ya = reinterpret_cast<const __bf16*>(p.act1);
+        const __bf16* sk = reinterpret_cast<const __bf16*>(p.res);
+        __bf16* dzo = reinterpret_cast<__bf16*>(p.out1);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            epilogue_via_lds8<NI>(acc[mi], elds, lane, [&](int row, int c, float4 lo, float4 hi) {
+                const int co = co0 + wn * NI * 32 + c;
+                if (co >= Cout) return;
+                const int P = (wm * MI + mi) * 32 + row;
+                const int img = P / (TH * TW), rem = P % (TH * TW);
+                const int oy = ty0 + rem / TW, ox = tx0 + rem % TW, n = grp * NB + img;
+                if (n >= p.N || oy >= p.Hout || ox >= p.Wout) return;
+                const float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                const long W2 = 2L * p.Wout;
+                const long base = (((long)n * 2 * p.Hout + 2 * oy) * W2 + 2 * ox) * p.O1 + co;
+                const long offs[4] = {0, (long)p.O1, W2 * p.O1, W2 * p.O1 + p.O1};
+                bf16x8 v[4], a[4], o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[q] = *reinterpret_cast<const bf16x8*>(ya + base + offs[q]);
+                    if (sk) a[q] = *reinterpret_cast<const bf16x8*>(sk + base + offs[q]);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float g = (float)(__bf16)f[e];
+                    const float v0 = (float)v[0][e], v1 = (float)v[1][e], v2 = (float)v[2][e], v3 = (float)v[3][e];
+                    const float m = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+                    const int sel = v0 == m ? 0 : (v1 == m ? 1 : (v2 == m ? 2 : 3));
+                    const float vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float t = (q == sel) ? g : 0.f;
+                        if (sk) t += (float)a[q][e];
+                        if (p.act == 1) t *= (vv[q] > 0.f ? 1.0f : p.alpha);
+                        o[q][e] = (__bf16)t;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<bf16x8*>(dzo + base + offs[q]) = o[q];
+            });
+        }
+        return;
+    }
     if ((p.flags & NIMG_BF16_OUT) && !(p.flags & (NIMG_D2S_OUT | NIMG_S2D_OUT)) && !p.res && !p.out1b &&
         (!p.act1 || (p.flags & NIMG_BF16_MASK)) && (p.O1 & 7) == 0 && (p.O2 & 7) == 0) {
 #pragma unroll
@@ -1659,6 +1707,23 @@ int nimg_conv2d_fwd_pool_also_bf16(const float* in, int cin, const void* wb, con
     return conv2d_fwd_bf16_impl(in, cin, nullptr, 0, wb, bias, out, cout, nullptr, 0, nullptr, n, h, wd, 3, 1, 1, 1, 0, h, wd, act,
                                 alpha, NIMG_BF16_IN | NIMG_BF16_OUT | NIMG_POOL_ALSO, stream, nullptr, nullptr, nullptr, pool_out,
                                 pool_idx);
+}
+
+/* The input gradient of the first convolution of a UNet encoder level, written THROUGH the 2x2 max-pool in front of it
+ * (models/pipelines.py:160-173 backward): dz (bf16, n x cin... see include/nimg.h). */
+int nimg_conv2d_dgrad_unpool_out_bf16(const float* dz, int c1, const void* wb, const float* act, const float* skip, float* out,
+                                      int cout, int n, int h, int wd, int apply_mask, float alpha, void* stream) {
+    if (n == 0) return NIMG_OK;
+    if (!dz || !wb || !act || !out || (c1 & 7) || (cout & 7) || h <= 0 || wd <= 0) return NIMG_ERR_ARG;
+    if ((long)n * 4 * h * wd * cout * 2 >= (1l << 40)) return NIMG_ERR_ARG;
+    ConvParamsB p;
+    p.in1 = dz; p.in2 = nullptr; p.wb = (const __bf16*)wb; p.bias = nullptr; p.out1 = out; p.out2 = nullptr; p.act1 = act;
+    p.pool_out = nullptr; p.pool_idx = nullptr; p.convt = 0; p.flags = NIMG_BF16_IN | NIMG_BF16_OUT | NIMG_BF16_MASK | NIMG_UNPOOL_OUT;
+    p.in_idx = nullptr; p.res = skip; p.out1b = nullptr;
+    p.C1 = c1; p.C2 = 0; p.O1 = cout; p.O2 = 0; p.CinP = (c1 + 15) / 16 * 16;
+    p.N = n; p.H = h; p.W = wd; p.Hout = h; p.Wout = wd; p.pad_t = p.pad_l = 1;
+    p.tiles_y = p.tiles_x = 0; p.act = apply_mask ? 1 : 0; p.pad_mode = 0; p.alpha = alpha;
+    return dispatch_b<3, 1>(p, (hipStream_t)stream);
 }
 
 /* nimg_conv2d_fwd_bf16_ex for the layers of a residual block (models/compression.py:224-227, 240-243): `residual` (float32, the

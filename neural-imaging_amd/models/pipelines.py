@@ -227,8 +227,13 @@ class UNet(NIPModel):
             dz1 = L['ec{}2'.format(n)].backward_input(P, dz, hw(a1), act_mask=a1, out_bf16=sb and n > 1)
             L['ec{}1'.format(n)].backward_params(P, inp, dz1)
             if n > 1:
-                d_pool = L['ec{}1'.format(n)].backward_input(P, dz1, hw(inp), out_bf16=sb)
                 prev = t['ec{}2'.format(n - 1)]
+                w1 = P.p['ec{}1/kernel'.format(n)]
+                if sb and self._h.activation == 'leaky_relu' and ops.conv2d_dgrad_unpool_out_ok(dz1, w1, prev, d_skip[n - 1]):
+                    # the input gradient written through the max-pool: route + skip sum + LeakyReLU' in the epilogue (bf16 storage)
+                    dz = ops.conv2d_dgrad_unpool_out(dz1, w1, prev, skip=d_skip[n - 1], apply_mask=True, out=d_skip[n - 1])
+                    continue
+                d_pool = L['ec{}1'.format(n)].backward_input(P, dz1, hw(inp), out_bf16=sb)
                 if self._h.activation == 'leaky_relu':
                     dz = ops.maxpool2_bwd(d_pool, prev, add=d_skip[n - 1], apply_mask=True, out=d_skip[n - 1])
                 else:           # route + skip sum, then the activation's derivative from its stored output

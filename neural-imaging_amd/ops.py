@@ -672,6 +672,33 @@ def conv2d_and_pool(x, w, bias=None, act='leaky_relu'):
     return y, pooled
 
 
+# ... and their backward: the input gradient of the NEXT level's first convolution written through the max-pool
+# (NIMG_NO_DGRAD_UNPOOL_OUT=1: input gradient, then maxpool2_bwd; A/B runs)
+DGRAD_UNPOOL_OUT = _os.environ.get('NIMG_NO_DGRAD_UNPOOL_OUT') is None
+
+
+def conv2d_dgrad_unpool_out_ok(dz, w, act, skip):
+    return DGRAD_UNPOOL_OUT and COMPUTE == 'bf16' and _is_bf16(dz) and _is_bf16(act) and (skip is None or _is_bf16(skip)) and \
+        w.shape[0] == 3 and w.shape[1] == 3 and w.shape[2] % 8 == 0 and w.shape[3] % 8 == 0 and \
+        act.shape[1] == 2 * dz.shape[1] and act.shape[2] == 2 * dz.shape[2] and act.shape[3] == w.shape[2]
+
+
+def conv2d_dgrad_unpool_out(dz, w, act, skip=None, apply_mask=True, out=None):
+    """maxpool2_bwd(conv2d_dgrad(dz, w) stored as bf16, act, add=skip, apply_mask) in one pass: the gradient at the INPUT of the
+    2x2 max-pool that fed a 3x3 SAME convolution with kernel w (k,k,cin,cout); dz (n,h,w,cout), act / skip / result
+    (n,2h,2w,cin), all bf16; out may be skip.  Same bits as the two passes."""
+    if not conv2d_dgrad_unpool_out_ok(dz, w, act, skip):
+        raise ValueError('conv2d_dgrad_unpool_out: unsupported shape / mode')
+    _f32(w)
+    n, h, wd, cz = dz.shape
+    cin = w.shape[2]
+    if out is None:
+        out = torch.empty_like(act)
+    _lib.call('nimg_conv2d_dgrad_unpool_out_bf16', _p(dz), cz, _p(weights_bf16(w, 1)), _p(act), _p(skip), _p(out), cin, n, h, wd,
+              1 if apply_mask else 0, LRELU_ALPHA, _stream())
+    return out
+
+
 def maxpool2_unpool(dp, idx, pooled, apply_mask=True, out=None, out_bf16=False):
     """Backward of conv2d_pool's epilogue: the pre-activation gradient at full resolution (optionally stored as bf16:
     its consumers - the bf16 weight / input gradient kernels - round it to bf16 anyway)."""

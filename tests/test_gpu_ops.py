@@ -322,6 +322,35 @@ def test_conv_writes_activation_and_pooled_tensor(dev, n, cin, cout, h, w):
         ops.set_compute('f32')
 
 
+@pytest.mark.parametrize('n,cin,cout,h,w', [(3, 32, 64, 64, 64), (3, 64, 128, 32, 32), (5, 128, 256, 16, 16), (5, 256, 512, 8, 8),
+                                            (2, 16, 24, 12, 20), (1, 8, 72, 6, 10)])
+@pytest.mark.parametrize('with_skip', [True, False])
+def test_input_gradient_written_through_the_max_pool(dev, n, cin, cout, h, w, with_skip):
+    """ops.conv2d_dgrad_unpool_out = conv2d_dgrad (stored as bf16) -> maxpool2_bwd (route to the first maximum + skip gradient +
+    LeakyReLU') in the convolution's epilogue: bit-identical, in place on the skip buffer, for the generic and the LDS-DMA
+    kernels, the four-image 8 x 8 tiles and ragged shapes."""
+    from neural_imaging_amd import ops
+    ops.set_compute('bf16')
+    try:
+        bf = torch.bfloat16
+        dz = g(rnd((n, h, w, cout), 1), dev).to(bf)
+        wt = g(rnd((3, 3, cin, cout), 2, -0.2, 0.2), dev)
+        act = (torch.round(g(rnd((n, 2 * h, 2 * w, cin), 3), dev) * 4) / 4).to(bf)        # coarse values: ties inside the windows
+        skip = g(rnd((n, 2 * h, 2 * w, cin), 4), dev).to(bf) if with_skip else None
+        assert ops.conv2d_dgrad_unpool_out_ok(dz, wt, act, skip)
+        for mask in (True, False):
+            d_pool = ops.conv2d_dgrad(dz, wt, (h, w), out_bf16=True)
+            ref = ops.maxpool2_bwd(d_pool, act, add=skip, apply_mask=mask)
+            out = ops.conv2d_dgrad_unpool_out(dz, wt, act, skip=skip, apply_mask=mask)
+            assert out.dtype == bf and torch.equal(out, ref)
+        if with_skip:
+            buf = skip.clone()
+            res = ops.conv2d_dgrad_unpool_out(dz, wt, act, skip=buf, apply_mask=True, out=buf)
+            assert res.data_ptr() == buf.data_ptr() and torch.equal(buf, ops.maxpool2_bwd(d_pool, act, add=skip, apply_mask=True))
+    finally:
+        ops.set_compute('f32')
+
+
 @pytest.mark.parametrize('n_parts', [1, 2, 5, 6])
 def test_head_gradient_in_one_pass(dev, n_parts):
     """ops.mse255_sum_s2d3 = add_n -> mse255(accumulate) -> d2s_clip_bwd(scale 1) in one pass: the same additions in the same
