@@ -138,6 +138,41 @@ def test_hsv_roundtrip_and_sharpen_quirk():
     assert (y0 - torch.clamp(T.hsv_to_rgb(shifted), 0, 1)).abs().max() < 1e-12
 
 
+def test_hsv_known_answers_against_colorsys():
+    """Third-party KAT for oracle/tfops.py rgb_to_hsv / hsv_to_rgb (tf.image.rgb_to_hsv, helpers/tf_helpers.py:133-160): the
+    standard library's colorsys on every pixel of a random batch plus the branch corners (grey, black, white, pure and
+    two-channel-tied colours, where tf's and colorsys' selection order could differ)."""
+    import colorsys
+    rng = np.random.default_rng(5)
+    px = rng.random((400, 3))
+    corners = [(0, 0, 0), (1, 1, 1), (.5, .5, .5), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (0, 1, 1), (1, 0, 1),
+               (.3, .3, .7), (.7, .3, .3), (.3, .7, .3), (.7, .7, .3), (.3, .7, .7), (.7, .3, .7), (.2, .2, .2000001)]
+    px = np.concatenate([px, np.array(corners, np.float64)])
+    hsv = T.rgb_to_hsv(torch.tensor(px)).numpy()
+    want = np.array([colorsys.rgb_to_hsv(*p) for p in px])
+    assert np.abs(hsv - want).max() < 1e-12
+    back = T.hsv_to_rgb(torch.tensor(want)).numpy()
+    want_rgb = np.array([colorsys.hsv_to_rgb(*p) for p in want])
+    assert np.abs(back - want_rgb).max() < 1e-12 and np.abs(back - px).max() < 1e-12
+    # hue wheel: colorsys.hsv_to_rgb over a grid of (h, s, v), including h = 0 and the sector borders k / 6
+    grid = np.array([(h, s, v) for h in np.linspace(0, 1, 25)[:-1] for s in (0., .25, 1.) for v in (0., .6, 1.)])
+    assert np.abs(T.hsv_to_rgb(torch.tensor(grid)).numpy() - np.array([colorsys.hsv_to_rgb(*p) for p in grid])).max() < 1e-12
+
+
+def test_pad_modes_against_numpy_and_explicit_indices():
+    """tf.pad SYMMETRIC (edge repeated: helpers/tf_helpers.py:84,151) vs REFLECT (edge not repeated: tf_helpers.py:110,
+    pipelines.py:276): explicit index tables for the 1-D case and numpy's np.pad (same two definitions) on images."""
+    v = torch.arange(5, dtype=torch.float64).view(1, 5, 1, 1).expand(1, 5, 5, 1).contiguous()
+    assert T.pad2d(v, 2, 'SYMMETRIC')[0, :, 2, 0].tolist() == [1, 0, 0, 1, 2, 3, 4, 4, 3]
+    assert T.pad2d(v, 2, 'REFLECT')[0, :, 2, 0].tolist() == [2, 1, 0, 1, 2, 3, 4, 3, 2]
+    rng = np.random.default_rng(11)
+    x = rng.random((2, 7, 9, 3))
+    for p in (1, 2, 3, 5):
+        for mode, npmode in (('SYMMETRIC', 'symmetric'), ('REFLECT', 'reflect')):
+            want = np.pad(x, ((0, 0), (p, p), (p, p), (0, 0)), mode=npmode)
+            assert np.array_equal(T.pad2d(torch.tensor(x), p, mode).numpy(), want), (mode, p)
+
+
 def test_keras_adam_first_step():
     p = [torch.ones(3, dtype=torch.float64)]
     g = [torch.tensor([0.5, -2.0, 0.0], dtype=torch.float64)]
