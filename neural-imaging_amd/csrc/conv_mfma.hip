@@ -487,6 +487,11 @@ int nimg_conv2d_fwd(const float* in1, int c1, const float* in2, int c2, const fl
         if (ks == 1) return dispatch_tiles<1, 1, 16>(p, vec, s);
         if (ks == 3) return dispatch_tiles<3, 1, 16>(p, vec, s);
         if (ks == 5) return dispatch_tiles<5, 1, 8>(p, vec, s);
+        // 7x7 ... 11x11 (FAN `kernel`, forensics.py:51; the demosaicing filters, pipelines.py:242,419): the same kernel with a
+        // 4-channel K chunk - the weight tile of a chunk is KS^2 x 4 x TN floats (11x11, TN = 64: 121 KB of LDS)
+        if (ks == 7) return dispatch_tiles<7, 1, 4>(p, vec, s);
+        if (ks == 9) return dispatch_tiles<9, 1, 4>(p, vec, s);
+        if (ks == 11) return dispatch_tiles<11, 1, 4>(p, vec, s);
     } else if (stride == 2) {
         if (ks == 2) return dispatch_tiles<2, 2, 16>(p, vec, s);
         if (ks == 5) return dispatch_tiles<5, 2, 8>(p, vec, s);

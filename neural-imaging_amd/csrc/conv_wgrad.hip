@@ -34,6 +34,7 @@ struct WgradParams {
     int C1, C2, Cout;
     int N, H, W, Hout, Wout, pad_t, pad_l;
     int tiles_y, tiles_x, splits, work_per_split, pad_mode;
+    int tap0;             // first tap of this launch (kernels above 5x5 take their taps in passes of TCH)
 };
 
 constexpr int WG_TH = 8, WG_TW = 16;     // output-pixel tile per K iteration
@@ -41,10 +42,15 @@ constexpr int CI_T = 32, CO_T = 64;      // dw block per workgroup
 
 // NW waves share the taps (4, or 8 for 5x5: 4 waves would each hold 7 taps x 32 = 224 accumulator registers and run
 // alone on their SIMD; with 8 it is 128 and two waves per SIMD hide each other's LDS / global latency)
-template <int KS, int STRIDE, bool VEC, int NW>
+// TCH < KS * KS (7x7 ... 11x11): the launch covers taps [p.tap0, p.tap0 + TCH) only - 49 ... 121 taps x 2 x 16 accumulators do
+// not fit the register file, so the host walks the taps in passes over the same tiles (each pass its own part of the slabs;
+// the bias sums come from pass 0)
+template <int KS, int STRIDE, bool VEC, int NW, int TCH = KS * KS>
 __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_kernel(const WgradParams p) {
     constexpr int TAPS = KS * KS, NTHR = NW * 64;
-    constexpr int NT = (TAPS + NW - 1) / NW;           // taps per wave
+    constexpr int NT = (TCH + NW - 1) / NW;            // taps per wave
+    constexpr bool PASSES = TCH < TAPS;
+    const int tap_first = PASSES ? p.tap0 : 0, tap_end = PASSES ? min(TAPS, p.tap0 + TCH) : TAPS;
     constexpr int THH = (WG_TH - 1) * STRIDE + KS, TWH = (WG_TW - 1) * STRIDE + KS;
     constexpr int NPIXH = THH * TWH, NPIX = WG_TH * WG_TW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -73,7 +79,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_kernel(const WgradParam
     const int work_total = p.N * tiles;                 // < 2^31 (checked by the entry point)
     const int w_begin = split * p.work_per_split;
     const int w_end = min(work_total, w_begin + p.work_per_split);
-    const bool do_bias = p.db_partial && ci0 == 0;
+    const bool do_bias = p.db_partial && ci0 == 0 && tap_first == 0;
     float bsum = 0.f;
 
     for (int wk = w_begin; wk < w_end; ++wk) {
@@ -139,8 +145,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_kernel(const WgradParam
                 const int ibase = (r * STRIDE * TWH + 2 * cp * STRIDE) * CI_T;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const int tap = wave + NW * t;
-                    if (tap < TAPS) {
+                    const int tap = tap_first + wave + NW * t;
+                    if (tap < tap_end) {
                         const float a = iL[ibase + ((tap / KS) * TWH + (tap % KS)) * CI_T];
                         acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[t][0], 0, 0, 0);
                         acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[t][1], 0, 0, 0);
@@ -155,8 +161,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_kernel(const WgradParam
     float* slab = p.partial + (long)split * TAPS * Cin * p.Cout;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int tap = wave + NW * t;
-        if (tap >= TAPS) continue;
+        const int tap = tap_first + wave + NW * t;
+        if (tap >= tap_end) continue;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             const int co = co0 + ni * 32 + (lane & 31);
@@ -451,13 +457,37 @@ int nimg_conv2d_wgrad(const float* in1, int c1, const float* in2, int c2, const 
         }                                                                                                     \
     } while (0)
 
+    // 7x7 ... 11x11: ceil(taps / 32) passes of <= 32 taps (8 waves x 4 taps: the register footprint of the 5x5 kernel)
+#define NIMG_WG_BIG(KS_)                                                                                      \
+    do {                                                                                                      \
+        constexpr int THH = WG_TH - 1 + KS_, TWH = WG_TW - 1 + KS_;                                           \
+        constexpr size_t lds = (size_t)(THH * TWH * CI_T + WG_TH * WG_TW * CO_T) * sizeof(float);             \
+        constexpr int PASSES_ = (KS_ * KS_ + 31) / 32, TCH_ = (KS_ * KS_ + PASSES_ - 1) / PASSES_;            \
+        for (int ps = 0; ps < PASSES_; ++ps) {                                                                \
+            p.tap0 = ps * TCH_;                                                                               \
+            if (vec) {                                                                                        \
+                auto k = conv_wgrad_kernel<KS_, 1, true, 8, TCH_>;                                            \
+                (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+                hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(512), lds, s, p);                          \
+            } else {                                                                                          \
+                auto k = conv_wgrad_kernel<KS_, 1, false, 8, TCH_>;                                           \
+                (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+                hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(512), lds, s, p);                          \
+            }                                                                                                 \
+        }                                                                                                     \
+    } while (0)
+    p.tap0 = 0;
     if (stride == 1 && ks == 1) NIMG_WG(1, 1);
     else if (stride == 1 && ks == 3) NIMG_WG(3, 1);
     else if (stride == 1 && ks == 5) NIMG_WG(5, 1);
     else if (stride == 2 && ks == 2) NIMG_WG(2, 2);
     else if (stride == 2 && ks == 5) NIMG_WG(5, 2);
+    else if (stride == 1 && ks == 7) NIMG_WG_BIG(7);
+    else if (stride == 1 && ks == 9) NIMG_WG_BIG(9);
+    else if (stride == 1 && ks == 11) NIMG_WG_BIG(11);
     else return NIMG_ERR_ARG;
 #undef NIMG_WG
+#undef NIMG_WG_BIG
     NIMG_CHECK_LAUNCH();
     nimg::launch_reduce2((const float*)workspace, dw, count, p.splits, db ? (const float*)p.db_partial : nullptr, db,
                          (long)cout, p.splits, accumulate, s);

@@ -55,8 +55,9 @@ class FAN(TFModel):
         self.dropout_masks = None
         if not use_gap and patch_size is None:
             raise ValueError('the Flatten head (use_gap=False) needs a fixed patch_size')
-        if self._h.kernel not in (3, 5):
-            raise NotImplementedError('kernel size {} not built'.format(self._h.kernel))
+        if self._h.kernel % 2 == 0:
+            # the reference's range is any integer 3 .. 11 (forensics.py:51); TF's SAME padding of an even kernel is asymmetric
+            raise NotImplementedError('even kernel size {} not built (3, 5, 7, 9, 11)'.format(self._h.kernel))
         self.patch_size = patch_size
         self.x = _Shape((None, patch_size, patch_size, 3))
         self.y = _Shape((None, n_classes))

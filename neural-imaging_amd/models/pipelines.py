@@ -259,8 +259,8 @@ class INet(NIPModel):
         })
         self._h.update(random_init=random_init, kernel=kernel, trainable_upsampling=trainable_upsampling,
                        cfa_pattern=cfa_pattern)
-        if self._h.kernel not in (3, 5):
-            raise NotImplementedError('demosaicing kernel {} not built (3 | 5)'.format(self._h.kernel))
+        if self._h.kernel % 2 == 0:
+            raise NotImplementedError('even demosaicing kernel {} not built (3, 5, 7, 9, 11)'.format(self._h.kernel))
         if self.in_channels != 4:
             raise ValueError('INet develops 4-plane RAW input')
         k = self._h.kernel
@@ -442,8 +442,8 @@ class ClassicISP(NIPModel):
             'residual': (True, bool, None),
         })
         self._h.update(kernel=kernel, c_filters=tuple(c_filters), cfa_pattern=cfa_pattern, residual=residual)
-        if self._h.kernel not in (3, 5):
-            raise NotImplementedError('demosaicing kernel {} not built (3 | 5)'.format(self._h.kernel))
+        if self._h.kernel % 2 == 0:
+            raise NotImplementedError('even demosaicing kernel {} not built (3, 5, 7, 9, 11)'.format(self._h.kernel))
         if self.in_channels != 4:
             raise ValueError('ClassicISP develops 4-plane RAW input')
         k, res = self._h.kernel, self._h.residual

@@ -126,6 +126,56 @@ def test_fan_forward_backward(dev):
     assert dec.shape == (5,) and (dec == probs_ref.detach().numpy().argmax(axis=1)).all()
 
 
+@pytest.mark.parametrize('kernel', [7, 9, 11])
+def test_fan_large_kernels(dev, kernel):
+    """FAN(kernel = 7 | 9 | 11) (forensics.py:51 allows 3 .. 11): the generic float32 matrix-core kernels (conv_mfma.hip with a
+    4-channel K chunk, conv_wgrad.hip in tap passes) behind the same layer code; probabilities, every parameter gradient and
+    the input gradient against the float64 oracle, then the same model in throughput mode (the large kernels stay float32
+    there) and one training step."""
+    from neural_imaging_amd import ops
+    from neural_imaging_amd.models import forensics
+    fan = forensics.FAN(n_classes=4, patch_size=64, kernel=kernel, n_filters=8, device=dev)
+    assert fan.count_parameters() == sum(int(np.prod(v.shape)) for v in fan.state_dict().values())
+    assert fan.summary().startswith('{0}x{0} CNN'.format(kernel))
+    x = natural_images(4, 64, 64, seed=35)
+    labels = np.array([0, 1, 2, 3], np.int32)
+    p = oracle_params(fan)
+    assert p['conv2/kernel'].shape == (kernel, kernel, 8, 16)
+    for v in p.values():
+        v.requires_grad_(True)
+    xt = to64(x).requires_grad_(True)
+    probs_ref = onets.fan_forward(p, xt)
+    loss_ref = T.sparse_ce_from_probs(probs_ref, labels)
+    gr = torch.autograd.grad(loss_ref, list(p.values()) + [xt])
+    g_ref = dict(zip(p.keys(), gr[:-1]))
+    probs, ctx = fan.forward(torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev), training=True)
+    assert_close(probs.cpu().numpy(), probs_ref.detach().numpy(), 1e-4, what='FAN probabilities')
+    loss, dx = fan.backward(ctx, need_input_grad=True)
+    assert abs(float(loss.item()) - float(loss_ref.detach())) < 1e-4
+    check_grads(grads_of(fan), g_ref, list(p.keys()), tol=3e-4)
+    assert_close(dx.cpu().numpy(), gr[-1].numpy(), 1e-7, 3e-4, what='FAN input gradient')
+    try:
+        ops.set_compute('bf16')
+        probs_b, ctx_b = fan.forward(torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev), training=True)
+        fan.backward(ctx_b, need_input_grad=True)
+        # only the constrained front filter and the 1x1 layer see bf16 operands here
+        assert_close(probs_b.cpu().numpy(), probs_ref.detach().numpy(), 3e-2, what='FAN probabilities, throughput mode')
+        l0 = float(fan.training_step(x, labels, learning_rate=1e-3))
+        for _ in range(10):
+            l1 = float(fan.training_step(x, labels, learning_rate=1e-3))
+        assert l1 < l0
+    finally:
+        ops.set_compute('f32')
+
+
+def test_even_kernel_sizes_are_refused_loudly(dev):
+    from neural_imaging_amd.models import forensics, pipelines
+    with pytest.raises(NotImplementedError):
+        forensics.FAN(n_classes=4, patch_size=64, kernel=6, device=dev)
+    with pytest.raises(NotImplementedError):
+        pipelines.INet(patch_size=24, kernel=8, device=dev)
+
+
 @pytest.mark.parametrize('n_classes', [24, 200])
 def test_fan_with_many_classes(dev, n_classes):
     """FAN(n_classes) beyond the 16 classes one lane of the fused head holds (the reference allows up to 256, forensics.py:37):
@@ -245,7 +295,7 @@ def test_fan_dropout(dev, use_gap):
     assert float(fan.training_step(x, labels, learning_rate=1e-3)) > 0
 
 
-@pytest.mark.parametrize('kernel,cfa', [(5, 'gbrg'), (3, 'rggb')])
+@pytest.mark.parametrize('kernel,cfa', [(5, 'gbrg'), (3, 'rggb'), (7, 'gbrg'), (9, 'bggr'), (11, 'gbrg')])
 def test_inet_forward_backward_and_training(dev, kernel, cfa):
     """INet (models/pipelines.py:233-295), the NIP the reference's own framework tests train (config/tests/framework.json):
     output and every trainable gradient against the float64 oracle, frozen up-sampling, then Keras-Adam steps."""
@@ -304,7 +354,7 @@ def test_inet_trainable_upsampling(dev):
 
 
 @pytest.mark.parametrize('kernel,c_filters,residual', [(5, (8, 8), True), (3, (16,), True), (5, (), True), (3, (8,), False),
-                                                       (5, (), False)])
+                                                       (5, (), False), (7, (8,), True), (11, (), True), (9, (8, 8), False)])
 def test_classic_isp_forward_backward_and_training(dev, kernel, c_filters, residual):
     """ClassicISP (models/pipelines.py:416-514) with its DemosaicingLayer (models/layers.py:206-258): output, the gradient
     of alpha and of every CNN parameter against the float64 oracle, camera setters, constants stay frozen."""
