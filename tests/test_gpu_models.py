@@ -937,15 +937,38 @@ def test_default_channel_parity_outside_flipped_blocks(dev):
     assert clean is not None, 'no batch without a rounding flip in 16 seeds: rates {}'.format(rates)
     seed, raw, rgb = clean
     loss_ref, parts_ref, params, grads, _ = ref.loss_and_grads(to64(raw), to64(rgb), 0.1)
+    # the same restatement evaluated in float32 - the arithmetic the reference itself runs in (TF2 CPU, float32): how far ITS
+    # gradients sit from the exact ones bounds what any float32 implementation can be asked for.  On this channel that is not
+    # small everywhere: the FAN's x100 prediction-error filter is ~0 on smooth content, the first LeakyReLU / MaxPool2D behind it
+    # then decide on rounding noise, and conv1/bias, constrained/kernel (sums over those pixels) move by 1 - 30 % between float32
+    # and float64 while every other tensor agrees to < 1e-3 (profiles/r05_default_channel_parity.txt).
+    ref32 = owf.Workflow(trainable=('nip',), jpeg_quality=80, dtype=torch.float32)
+    ref32.nip = onets.OrderedDict((k, v.to(torch.float32)) for k, v in ref.nip.items())
+    ref32.fan = onets.OrderedDict((k, v.to(torch.float32)) for k, v in ref.fan.items())
+    _, _, _, grads32, _ = ref32.loss_and_grads(torch.tensor(raw), torch.tensor(rgb), 0.1)
     loss, parts = wf.training_step(raw, rgb, lambda_nip=0.1, learning_rate=1e-4)
     assert abs(float(parts['ce']) - parts_ref['ce']) < 1e-4, (float(parts['ce']), parts_ref['ce'])
     assert abs(float(parts['nip']) - parts_ref['nip']) / parts_ref['nip'] < 1e-4
     names = list(ref.fan.keys()) + list(ref.nip.keys())
     got = grads_of(wf.fan)
     got.update(grads_of(wf.nip))
-    worst = check_grads(got, dict(zip(names, grads)), names, tol=GRAD_TOL)
-    print('default channel, seed {} (no flipped tie): worst gradient {:.2e} rel-to-max at {}; flip rates walked {}'.format(
-        seed, worst[0], worst[1], ['%.1e' % r for r in rates]))
+    rows, loose = [], []
+    for k, g64, g32 in zip(names, grads, grads32):
+        b = g64.numpy()
+        scale = max(np.abs(b).max(), 1e-12)
+        e_prod = np.abs(got[k].astype(np.float64) - b).max() / scale
+        e_ref32 = np.abs(g32.numpy().astype(np.float64) - b).max() / scale
+        rows.append((e_prod, e_ref32, k))
+        if e_ref32 > GRAD_TOL / 1.5:
+            loose.append(k)
+        assert e_prod <= max(GRAD_TOL, 1.5 * e_ref32), (k, e_prod, e_ref32)
+    rows.sort(reverse=True)
+    # the ill-conditioned ones are the FAN's front end (and, by seed, a bias or two behind it) - never the bulk of the tensors
+    assert len(loose) <= 6 and all(k.split('/')[0] in ('constrained', 'conv1', 'conv2', 'conv3') or k.endswith('/bias')
+                                   for k in loose), loose
+    print('default channel, seed {} (no flipped tie), flip rates walked {}'.format(seed, ['%.1e' % r for r in rates]))
+    for e_prod, e_ref32, k in rows[:8]:
+        print('   {:22s} product vs float64 {:.2e}   float32 restatement vs float64 {:.2e}'.format(k, e_prod, e_ref32))
 
 
 def test_twitter_dcn_forward_backward(dev):
