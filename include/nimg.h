@@ -48,11 +48,13 @@ extern "C" {
                            * layer, written by the input-gradient pass that produces it (models/compression.py:233,245 backward);
                            * act_mask and residual keep the convolution's own (n, hout, wout, o1) layout */
 #define NIMG_UNPOOL_OUT 512 /* internal to nimg_conv2d_dgrad_unpool_out_bf16: the result is routed through a 2x2 max-pool's backward */
+#define NIMG_D2S_CONVT 1024 /* internal to nimg_convt2x2_fwd_bf16_ex: the transposed convolution as ONE 1x1 product with 4 cout columns, phase
+                              3 - b = channel block b written to pixel (2 y + dy, 2 x + dx); the bias repeats per block */
 #define NIMG_POOL_ALSO 256 /* internal to nimg_conv2d_fwd_pool_also_bf16: the pooled tensor is written next to out1, not instead of it */
 
 /* library / ABI version, bumped on any signature change of an existing entry point (3: nimg_conv2d_fwd_bf16_res gained
  * out_bf16_copy and stride).  A binding compares nimg_abi_version() with the NIMG_ABI_VERSION it was written against. */
-#define NIMG_ABI_VERSION 3
+#define NIMG_ABI_VERSION 4
 int nimg_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -221,6 +223,11 @@ int nimg_adam_step_dev(float* params, const float* grads, float* m, float* v, lo
                        float beta2, float eps, float grad_scale, const int* skip_flag, void* stream);
 /* flag[0] |= 1 if any gradient is NaN (device-side version of workflows/manipulation_classification.py:281-282) */
 int nimg_nan_flag(const float* g, long count, int* flag, void* stream);
+/* flag / scalar bookkeeping of a training step on the library's own kernels: mode 0 dst[0 .. n) = value, mode 1 dst[i] =
+ * max(dst[i], src[i]) (the "NaN seen since the last check" word);  nimg_float_fill: dst[0 .. n) = value (a captured step's
+ * device-resident learning rate) */
+int nimg_int_words(int* dst, const int* src, long n, int value, int mode, void* stream);
+int nimg_float_fill(float* dst, long n, float value, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * ConstrainedConv2D kernel re-normalisation, models/layers.py:45-53 (ks=5, channels=3, strength=100) */

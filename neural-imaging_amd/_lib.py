@@ -54,6 +54,8 @@ PROTOTYPES = {
     'nimg_adam_step': (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_int, c_float, P, P]),
     'nimg_adam_step_dev': (c_int, [P, P, P, P, c_long, P, c_float, c_float, c_float, c_float, P, P]),
     'nimg_nan_flag': (c_int, [P, c_long, P, P]),
+    'nimg_int_words': (c_int, [P, P, c_long, c_int, c_int, P]),
+    'nimg_float_fill': (c_int, [P, c_long, c_float, P]),
     'nimg_constrained_kernel_fwd': (c_int, [P, P, c_int, c_int, c_float, P]),
     'nimg_constrained_kernel_bwd': (c_int, [P, P, P, c_int, c_int, c_float, P]),
     'nimg_fold_pad': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
@@ -166,7 +168,7 @@ ERRORS = {-1: 'NIMG_ERR_ARG (invalid argument / unsupported configuration)',
 _lib = None
 
 
-ABI_VERSION = 3         # include/nimg.h NIMG_ABI_VERSION
+ABI_VERSION = 4         # include/nimg.h NIMG_ABI_VERSION
 
 
 def load():

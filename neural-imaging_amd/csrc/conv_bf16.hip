@@ -216,6 +216,31 @@ __device__ __forceinline__ void conv_epilogue_vec(const f32x16 (&acc)[MI][NI], c
         }
         return;
     }
+    // NIMG_D2S_CONVT: Conv2DTranspose(2x2, stride 2) as one 1x1 product over 4 x cout columns (nimg_convt2x2_fwd_bf16_ex) - column
+    // block b holds output phase 3 - b (the weight image lists the taps flipped), which goes to pixel (2 y + dy, 2 x + dx)
+    if (p.flags & NIMG_D2S_CONVT) {
+        const int cd = p.O1 >> 2;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            epilogue_via_lds8<NI>(acc[mi], elds, lane, [&](int row, int c, float4 lo, float4 hi) {
+                const int co = co0 + wn * NI * 32 + c;
+                if (co >= Cout) return;
+                const int P = (wm * MI + mi) * 32 + row;
+                const int img = P / (TH * TW), rem = P % (TH * TW);
+                const int oy = ty0 + rem / TW, ox = tx0 + rem % TW, n = grp * NB + img;
+                if (n >= p.N || oy >= p.Hout || ox >= p.Wout) return;
+                const int blk = co / cd, cc = co - blk * cd, ph = 3 - blk;
+                const long o = (((long)n * 2 * p.Hout + 2 * oy + (ph >> 1)) * (2 * p.Wout) + 2 * ox + (ph & 1)) * cd + cc;
+                float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                if (p.bias) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + cc), b1 = *reinterpret_cast<const float4*>(p.bias + cc + 4);
+                    f[0] += b0.x; f[1] += b0.y; f[2] += b0.z; f[3] += b0.w; f[4] += b1.x; f[5] += b1.y; f[6] += b1.z; f[7] += b1.w;
+                }
+                *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.out1) + o) = pack8(f);
+            });
+        }
+        return;
+    }
     if ((p.flags & NIMG_BF16_OUT) && !(p.flags & (NIMG_D2S_OUT | NIMG_S2D_OUT)) && !p.res && !p.out1b &&
         (!p.act1 || (p.flags & NIMG_BF16_MASK)) && (p.O1 & 7) == 0 && (p.O2 & 7) == 0) {
 #pragma unroll
@@ -1702,6 +1727,9 @@ int nimg_conv2d_fwd_bf16_ex(const float* in1, int c1, const float* in2, int c2, 
  * pooled one the next level's input).  cin % 8 == 0, cout % 8 == 0, even h / wd > 8 (the 16x16-pixel tiles); pool_idx optional. */
 int nimg_conv2d_fwd_pool_also_bf16(const float* in, int cin, const void* wb, const float* bias, float* out, float* pool_out,
                                    unsigned char* pool_idx, int cout, int n, int h, int wd, int act, float alpha, void* stream) {
+#ifdef NIMG_NO_EPI8
+    return NIMG_ERR_ARG;           /* A/B build without the 8-wide epilogue: the NIMG_POOL_ALSO branch lives there (ops probes with n = 0) */
+#endif
     if (n == 0) return NIMG_OK;
     if (!pool_out || (h & 1) || (wd & 1) || h <= 8 || wd <= 8 || (cout & 7) || (cin & 7)) return NIMG_ERR_ARG;
     return conv2d_fwd_bf16_impl(in, cin, nullptr, 0, wb, bias, out, cout, nullptr, 0, nullptr, n, h, wd, 3, 1, 1, 1, 0, h, wd, act,
@@ -1713,6 +1741,9 @@ int nimg_conv2d_fwd_pool_also_bf16(const float* in, int cin, const void* wb, con
  * (models/pipelines.py:160-173 backward): dz (bf16, n x cin... see include/nimg.h). */
 int nimg_conv2d_dgrad_unpool_out_bf16(const float* dz, int c1, const void* wb, const float* act, const float* skip, float* out,
                                       int cout, int n, int h, int wd, int apply_mask, float alpha, void* stream) {
+#ifdef NIMG_NO_EPI8
+    return NIMG_ERR_ARG;           /* A/B build without the 8-wide epilogue: the NIMG_UNPOOL_OUT branch lives there (ops probes with n = 0) */
+#endif
     if (n == 0) return NIMG_OK;
     if (!dz || !wb || !act || !out || (c1 & 7) || (cout & 7) || h <= 0 || wd <= 0) return NIMG_ERR_ARG;
     if ((long)n * 4 * h * wd * cout * 2 >= (1l << 40)) return NIMG_ERR_ARG;
@@ -1775,6 +1806,15 @@ int nimg_convt2x2_fwd_bf16_ex(const float* x, const void* wb, const float* bias,
     p.C1 = cin; p.C2 = 0; p.O1 = cout; p.O2 = 0; p.CinP = (cin + 15) / 16 * 16;
     p.N = n; p.H = h; p.W = wd; p.Hout = h; p.Wout = wd; p.pad_t = 0; p.pad_l = 0;
     p.tiles_y = p.tiles_x = 0; p.act = 0; p.pad_mode = 0; p.alpha = 0.f;
+#ifndef NIMG_NO_EPI8
+    // bf16-stored output, cout % 8 == 0 (the UNet's four layers): ONE 1x1 product with N = 4 cout columns - the input tile is
+    // staged once for the four output phases instead of once per phase, a quarter of the workgroups pay prologue and epilogue -
+    // and the phase is a pixel offset of the 16-byte store (NIMG_D2S_CONVT).  Same products in the same order: bit-identical.
+    static const bool no_fat = getenv("NIMG_NO_CONVT_FAT") != nullptr;
+    if (!no_fat && (flags & NIMG_BF16_OUT) && (cout & 7) == 0) {
+        p.convt = 0; p.O1 = 4 * cout; p.flags = flags | NIMG_D2S_CONVT;
+    }
+#endif
     return dispatch_b<1, 1>(p, (hipStream_t)stream);
 }
 

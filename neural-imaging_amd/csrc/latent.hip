@@ -197,17 +197,23 @@ __global__ void d2s2_scale3_kernel(const float4* __restrict__ xs, float* __restr
 // constant 2 * np.pi becomes a float32 tensor constant next to a float32 operand).
 __device__ __forceinline__ float round_mode_fwd(float zs, int mode) {
     const float tp = 6.2831855f;
-    if (mode == 1) return rintf(zs);
-    if (mode == 2) return zs - sinf(tp * zs) / tp;
-    return zs;
+    if (mode == 0) return zs;
+    const float xs = zs - sinf(tp * zs) / tp;
+    // 'soft': stop_gradient(round(x) - x_) + x_ with x_ the sinusoidal approximation (layers.py:126-128) - evaluated as written,
+    // in float32: the sum can sit one ulp off round(x), exactly as the soft-codebook branch's (hard - soft) + soft below
+    if (mode == 1) return (rintf(zs) - xs) + xs;
+    return xs;
 }
 __device__ __forceinline__ double round_mode_bwd(float zs, int mode) {
     return mode ? (double)(1.0f - cosf(6.2831855f * zs)) : 1.0;
 }
 
+// KB = array bucket of the generic kernels (64 | 128 | 256 centres): a per-thread `double w[256]` is 6 KB of scratch, four times
+// what the K <= 64 codebooks (bpf <= 6) need - the bucket is picked per launch (launch_generic below)
+template <int KB>
 struct KernelW {
-    double w[MAXK];
-    double dw[MAXK];
+    double w[KB];
+    double dw[KB];
     double S, dS;
 };
 
@@ -226,8 +232,9 @@ __device__ __forceinline__ double pow_neg_half_int(double base, int m) {
 }
 
 // kernel weights (+eps) and their derivative w.r.t. u, for all K centres
+template <int KB>
 __device__ __forceinline__ void eval_weights(double u, const float* __restrict__ cb, int K, double v, double gamma,
-                                             KernelW& o, bool need_grad) {
+                                             KernelW<KB>& o, bool need_grad) {
     o.S = 0.0;
     o.dS = 0.0;
     const double m_real = v + 1.0;
@@ -252,6 +259,7 @@ __device__ __forceinline__ void eval_weights(double u, const float* __restrict__
 }
 
 // forward: latent = STE(hard, soft)(scale * z); hist partial (float64) of the normalised weights AT THE LATENT values
+template <int KB>
 __global__ __launch_bounds__(256) void soft_codebook_fwd_kernel(const float* __restrict__ z,
                                                                 const float* __restrict__ scale,
                                                                 const float* __restrict__ cb, int K, double v,
@@ -262,9 +270,9 @@ __global__ __launch_bounds__(256) void soft_codebook_fwd_kernel(const float* __r
     if (threadIdx.x < MAXK) sh[threadIdx.x] = 0.0;
     __syncthreads();
     const float s = scale ? scale[0] : 1.0f;
-    double hacc[MAXK];
+    double hacc[KB];
     for (int k = 0; k < K; ++k) hacc[k] = 0.0;
-    KernelW kw;
+    KernelW<KB> kw;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
         const float zs = z[i] * s;                                           // layers.py:197-198 (float32 product)
         float lat = round_mode_fwd(zs, soft_codebook >> 2);
@@ -627,6 +635,7 @@ __global__ void entropy_finalize_kernel(const double* __restrict__ hist_sum, int
 }
 
 // backward: dz = scale * dsoft/du(zs) * [ dlat + coef * sum_k dH_dsum[k] * dwn_k/du(lat) ];  dscale partial = sum z * (...)
+template <int KB>
 __global__ __launch_bounds__(256) void soft_codebook_bwd_kernel(const float* __restrict__ z,
                                                                 const float* __restrict__ scale,
                                                                 const float* __restrict__ latent,
@@ -639,7 +648,7 @@ __global__ __launch_bounds__(256) void soft_codebook_bwd_kernel(const float* __r
     __shared__ double red[4];
     const float s = scale ? scale[0] : 1.0f;
     double dsum = 0.0;
-    KernelW kw;
+    KernelW<KB> kw;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
         double g = dlat ? (double)dlat[i] : 0.0;
         if (coef != 0.f) {
@@ -864,8 +873,14 @@ int nimg_latent_fwd(const float* z, const float* scale, const float* codebook, i
     else if (m && K == 16) NIMG_SCB_FWD(16, 0);
     else if (m && K == 8) NIMG_SCB_FWD(8, 0);
 #undef NIMG_SCB_FWD
+    else if (K <= 64)
+        hipLaunchKernelGGL(soft_codebook_fwd_kernel<64>, dim3(grid), dim3(256), 0, s, z, scale, codebook, K, vd, (double)gamma,
+                           latent, part, count, soft_codebook);
+    else if (K <= 128)
+        hipLaunchKernelGGL(soft_codebook_fwd_kernel<128>, dim3(grid), dim3(256), 0, s, z, scale, codebook, K, vd, (double)gamma,
+                           latent, part, count, soft_codebook);
     else
-        hipLaunchKernelGGL(soft_codebook_fwd_kernel, dim3(grid), dim3(256), 0, s, z, scale, codebook, K, vd, (double)gamma,
+        hipLaunchKernelGGL(soft_codebook_fwd_kernel<MAXK>, dim3(grid), dim3(256), 0, s, z, scale, codebook, K, vd, (double)gamma,
                            latent, part, count, soft_codebook);
     NIMG_CHECK_LAUNCH();
     hipLaunchKernelGGL(hist_reduce_kernel, dim3(1), dim3(1024), 0, s, (const double*)part, grid, K, hsum);
@@ -922,8 +937,14 @@ int nimg_latent_bwd(const float* z, const float* scale, const float* latent, con
     else if (m && K == 16) NIMG_SCB_BWD(16, 0);
     else if (m && K == 8) NIMG_SCB_BWD(8, 0);
 #undef NIMG_SCB_BWD
+    else if (K <= 64)
+        hipLaunchKernelGGL(soft_codebook_bwd_kernel<64>, dim3(grid), dim3(256), 0, s, z, scale, latent, dlatent,
+                           (const double*)dH, entropy_coef, codebook, K, vd, (double)gamma, dz, dsp, count, soft_codebook);
+    else if (K <= 128)
+        hipLaunchKernelGGL(soft_codebook_bwd_kernel<128>, dim3(grid), dim3(256), 0, s, z, scale, latent, dlatent,
+                           (const double*)dH, entropy_coef, codebook, K, vd, (double)gamma, dz, dsp, count, soft_codebook);
     else
-        hipLaunchKernelGGL(soft_codebook_bwd_kernel, dim3(grid), dim3(256), 0, s, z, scale, latent, dlatent,
+        hipLaunchKernelGGL(soft_codebook_bwd_kernel<MAXK>, dim3(grid), dim3(256), 0, s, z, scale, latent, dlatent,
                            (const double*)dH, entropy_coef, codebook, K, vd, (double)gamma, dz, dsp, count, soft_codebook);
     NIMG_CHECK_LAUNCH();
     if (dscale) {

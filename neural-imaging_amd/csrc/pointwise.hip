@@ -7,6 +7,8 @@
 //   mse on 255-scaled images (loss + gradient)            helpers/tf_helpers.py:31-32
 //   GAP + Dense + softmax + sparse CE head, fwd + bwd     models/forensics.py:80-94
 //   Keras Adam over a flat parameter buffer               tf.keras.optimizers.Adam (pipelines.py:51 etc.)
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -465,6 +467,13 @@ __global__ __launch_bounds__(256) void mse255_kernel(const float* __restrict__ a
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
+__global__ void int_words_kernel(int* __restrict__ dst, const int* __restrict__ src, long n, int value, int mode) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dst[i] = mode == 0 ? value : max(dst[i], src[i]);
+}
+__global__ void float_fill_kernel(float* __restrict__ dst, long n, float value) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = value;
+}
 // The head of the UNet's backward pass in the workflow, one pass instead of three (add_n -> mse255 with accumulate ->
 // d2s_clip3_bwd): element (n, y, x, ch) of the result's depth_to_space image = parts[0] + parts[1] + ... + gk (a - b), the
 // additions in that order with the same single rounding per step as the three kernels (the last one contracted to an fma, as
@@ -514,6 +523,69 @@ __global__ __launch_bounds__(256) void mse255_sum_s2d3_kernel(SumS2dParts parts,
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// Row form of the kernel above (w even, w <= 512): a workgroup takes one OUTPUT row = two input rows of 6 w floats.  The pixel-pair
+// form reads 24-byte runs at 8 bytes per lane - every 64-byte line of the seven input tensors is requested three times by
+// neighbouring lanes (counters: 1.04 GB fetched per launch for 0.4 GB of operands, 150 us at B = 64); here the two rows are read
+// as linear 16-byte items, summed in the same order (parts[0] + parts[1] + ..., then the fma with gk (a - b)), turned around
+// through LDS and written as linear 16-byte items of the (n, h, w, 12) row.  Same values, same bits; the loss partials are per
+// workgroup as before.
+__global__ __launch_bounds__(256) void mse255_sum_s2d3_rows_kernel(SumS2dParts parts, int n_parts, const float* __restrict__ a,
+                                                                   const float* __restrict__ b, float* __restrict__ dz,
+                                                                   double* __restrict__ partial, long nrows, int h, int w,
+                                                                   float gscale) {
+    __shared__ double red[4];
+    __shared__ __attribute__((aligned(16))) float sh[2 * 6 * 512];            // [top | bottom][6 w]
+    double s = 0.0;
+    const long count = nrows * w * 12;
+    const float gk = gscale * 2.0f * 255.0f * 255.0f / (float)count;
+    const int rq = (6 * w) >> 2;                                               // float4 items of one input row (w even)
+    const int tid = threadIdx.x;
+    for (long row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const long im = row / h;
+        const int yy = (int)(row - im * h);
+        const long top = ((im * 2 * h + 2 * yy) * (2L * w)) * 3;              // float offset of the upper input row (the lower one follows)
+        __syncthreads();
+        for (int item = tid; item < 2 * rq; item += 256) {
+            const long o = top + 4L * item;
+            float4 acc = *reinterpret_cast<const float4*>(parts.p[0] + o);
+#pragma unroll
+            for (int k = 1; k < 6; ++k)
+                if (k < n_parts) {
+                    const float4 t = *reinterpret_cast<const float4*>(parts.p[k] + o);
+                    acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+                }
+            const float4 va = *reinterpret_cast<const float4*>(a + o), vb = *reinterpret_cast<const float4*>(b + o);
+            const float d0 = va.x - vb.x, d1 = va.y - vb.y, d2 = va.z - vb.z, d3 = va.w - vb.w;
+            const float e0 = 255.0f * d0, e1 = 255.0f * d1, e2 = 255.0f * d2, e3 = 255.0f * d3;
+            s += (double)e0 * (double)e0;
+            s += (double)e1 * (double)e1;
+            s += (double)e2 * (double)e2;
+            s += (double)e3 * (double)e3;
+            *reinterpret_cast<float4*>(sh + 4 * item) = make_float4(fmaf(gk, d0, acc.x), fmaf(gk, d1, acc.y), fmaf(gk, d2, acc.z),
+                                                                     fmaf(gk, d3, acc.w));
+        }
+        __syncthreads();
+        // output pixel px = [top 6 px .. + 5 | bottom 6 px .. + 5]: item j = (px, third t) -> t 0: top 0..3; 1: top 4, 5 + bottom 0, 1;
+        // 2: bottom 2..5
+        const float* st = sh;
+        const float* sb = sh + 6 * w;
+        float4* dst = reinterpret_cast<float4*>(dz + row * (long)w * 12);
+        for (int j = tid; j < 3 * w; j += 256) {
+            const int px = j / 3, third = j - 3 * px;
+            float f[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 4 * third + e;                                   // channel of the (n, h, w, 12) pixel
+                f[e] = k < 6 ? st[6 * px + k] : sb[6 * px + k - 6];
+            }
+            dst[j] = make_float4(f[0], f[1], f[2], f[3]);
+        }
+    }
+    s = wave_sum_d(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 __global__ void mse255_final_kernel(const double* __restrict__ partial, int nblocks, long count, float* loss) {
     double s = 0.0;                                      // one wave: strided partials, then a fixed-shape butterfly
@@ -1106,10 +1178,20 @@ int nimg_mse255_sum_s2d3(const float* const* parts, int n_parts, const float* y,
     }
     if (((size_t)y & 7) || ((size_t)target & 7) || ((size_t)dz & 15)) return NIMG_ERR_ARG;
     const long npix = (long)n * h * w;
-    const int grid = grid_for(npix);
+    int grid = grid_for(npix);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(mse255_sum_s2d3_kernel, dim3(grid), dim3(256), 0, s, sp, n_parts, y, target, dz, (double*)workspace, npix,
-                       h, w, grad_scale);
+    bool a16 = (((size_t)y | (size_t)target) & 15) == 0;
+    for (int i = 0; i < n_parts; ++i) a16 = a16 && ((size_t)parts[i] & 15) == 0;
+    static const bool no_rows = getenv("NIMG_NO_S2D3_ROWS") != nullptr;
+    if (!no_rows && a16 && (w & 1) == 0 && w <= 512) {          // row form: linear 16-byte items on both sides
+        const long nrows = (long)n * h;
+        grid = (int)(nrows < 2048 ? nrows : 2048);
+        hipLaunchKernelGGL(mse255_sum_s2d3_rows_kernel, dim3(grid), dim3(256), 0, s, sp, n_parts, y, target, dz, (double*)workspace,
+                           nrows, h, w, grad_scale);
+    } else {
+        hipLaunchKernelGGL(mse255_sum_s2d3_kernel, dim3(grid), dim3(256), 0, s, sp, n_parts, y, target, dz, (double*)workspace, npix,
+                           h, w, grad_scale);
+    }
     NIMG_CHECK_LAUNCH();
     hipLaunchKernelGGL(mse255_final_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, grid, npix * 12, loss);
     NIMG_CHECK_LAUNCH();
@@ -1198,6 +1280,24 @@ int nimg_adam_step_dev(float* params, const float* grads, float* m, float* v, lo
     if (count == 0) return NIMG_OK;
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v,
                        count, 0.f, beta1, beta2, eps, grad_scale, skip_flag, lr_t);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+/* The step's flag / scalar bookkeeping as kernels of this library (no framework-native launch inside a training step):
+ * mode 0: dst[0 .. n) = value;  mode 1: dst[i] = max(dst[i], src[i]) (the workflow's "NaN seen since the last check" word) */
+int nimg_int_words(int* dst, const int* src, long n, int value, int mode, void* stream) {
+    if (!dst || n < 0 || mode < 0 || mode > 1 || (mode == 1 && !src)) return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    hipLaunchKernelGGL(int_words_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dst, src, n, value, mode);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_float_fill(float* dst, long n, float value, void* stream) {
+    if (!dst || n < 0) return NIMG_ERR_ARG;
+    if (n == 0) return NIMG_OK;
+    hipLaunchKernelGGL(float_fill_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dst, n, value);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }

@@ -68,7 +68,7 @@ class CapturedStep(object):
         flow._step = self.t                 # the capture itself executed nothing
 
     def _set_rate(self, t):
-        self._rate_dev.fill_(ops.adam_lr_t(self.lr, t))     # a scalar-argument fill launch, ordered before the replay
+        ops.float_fill(self._rate_dev, ops.adam_lr_t(self.lr, t))     # a scalar-argument fill launch, ordered before the replay
 
     def load(self, batch_x, batch_y):
         """Next batch into the captured step's input buffers (device-to-device or pinned host-to-device copy)."""
@@ -127,7 +127,7 @@ class CapturedModelStep(object):
         store.step = self.t                   # the capture itself executed nothing
 
     def _set_rate(self, t):
-        self._rate_dev.fill_(ops.adam_lr_t(self.lr, t))
+        ops.float_fill(self._rate_dev, ops.adam_lr_t(self.lr, t))
 
     def load(self, *inputs):
         for dst, src in zip(self.inputs, inputs):

@@ -660,9 +660,25 @@ def conv2d_pool(x, w, bias=None, act='leaky_relu', want_idx=True, out_bf16=False
 POOL_ALSO = _os.environ.get('NIMG_NO_POOL_ALSO') is None
 
 
+_EPI8 = {}
+
+
+def _epi8_built(entry):
+    """Does the bound library carry the 8-wide epilogue branch `entry` needs?  An A/B build with -DNIMG_NO_EPI8 answers an empty
+    call (n = 0) with NIMG_ERR_ARG instead of NIMG_OK, and the callers fall back to the two-pass forms."""
+    if entry not in _EPI8:
+        lib = _lib.load()
+        if entry == 'nimg_conv2d_fwd_pool_also_bf16':
+            rc = lib.nimg_conv2d_fwd_pool_also_bf16(None, 8, None, None, None, None, None, 8, 0, 16, 16, 1, LRELU_ALPHA, None)
+        else:
+            rc = lib.nimg_conv2d_dgrad_unpool_out_bf16(None, 8, None, None, None, None, 8, 0, 16, 16, 1, LRELU_ALPHA, None)
+        _EPI8[entry] = rc == 0
+    return _EPI8[entry]
+
+
 def conv2d_and_pool_ok(x, w):
     n, h, wd, cin = x.shape
-    return POOL_ALSO and COMPUTE == 'bf16' and _is_bf16(x) and w.shape[0] == 3 and w.shape[1] == 3 and cin % 8 == 0 and \
+    return POOL_ALSO and _epi8_built('nimg_conv2d_fwd_pool_also_bf16') and COMPUTE == 'bf16' and _is_bf16(x) and w.shape[0] == 3 and w.shape[1] == 3 and cin % 8 == 0 and \
         w.shape[3] % 8 == 0 and h % 2 == 0 and wd % 2 == 0 and h > 8 and wd > 8
 
 
@@ -687,7 +703,7 @@ DGRAD_UNPOOL_OUT = _os.environ.get('NIMG_NO_DGRAD_UNPOOL_OUT') is None
 
 
 def conv2d_dgrad_unpool_out_ok(dz, w, act, skip):
-    return DGRAD_UNPOOL_OUT and COMPUTE == 'bf16' and _is_bf16(dz) and _is_bf16(act) and (skip is None or _is_bf16(skip)) and \
+    return DGRAD_UNPOOL_OUT and _epi8_built('nimg_conv2d_dgrad_unpool_out_bf16') and COMPUTE == 'bf16' and _is_bf16(dz) and _is_bf16(act) and (skip is None or _is_bf16(skip)) and \
         w.shape[0] == 3 and w.shape[1] == 3 and w.shape[2] % 8 == 0 and w.shape[3] % 8 == 0 and \
         act.shape[1] == 2 * dz.shape[1] and act.shape[2] == 2 * dz.shape[2] and act.shape[3] == w.shape[2]
 
@@ -978,6 +994,30 @@ def adam_step(params, grads, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-7, g
         return
     _lib.call('nimg_adam_step', _p(params), _p(grads), _p(m), _p(v), params.numel(), float(lr), float(beta1),
               float(beta2), float(eps), int(step), float(grad_scale), _p(skip_flag), _stream())
+
+
+def int_fill(t, value=0):
+    """t[...] = value for an int32 device tensor (the step's flag words) on the library's own kernel."""
+    _chk(t)
+    if t.dtype != torch.int32 or not t.is_contiguous():
+        raise ValueError('int_fill: contiguous int32 tensor expected')
+    _lib.call('nimg_int_words', _p(t), None, t.numel(), int(value), 0, _stream())
+    return t
+
+
+def int_max_(dst, src):
+    """dst = max(dst, src) element-wise, int32, in place."""
+    _chk(dst, src)
+    if dst.dtype != torch.int32 or src.dtype != torch.int32 or dst.numel() != src.numel():
+        raise ValueError('int_max_: two int32 tensors of one size expected')
+    _lib.call('nimg_int_words', _p(dst), _p(src), dst.numel(), 0, 1, _stream())
+    return dst
+
+
+def float_fill(t, value):
+    _f32(t)
+    _lib.call('nimg_float_fill', _p(t), t.numel(), float(value), _stream())
+    return t
 
 
 def nan_flag(g, flag):

@@ -265,7 +265,7 @@ class ManipulationClassification(object):
         _, fctx = self.fan.forward(C, self._device_labels(b), training=True)
 
         # ---- backward
-        self._nan_flag.zero_()
+        ops.int_fill(self._nan_flag, 0)
         # one process, gradients flowing on upstream: the FAN's weight gradients are issued BEHIND its input-gradient chain and
         # run beside the codec / manipulation / UNet backward (HBM- and latency-bound kernels that leave the matrix cores idle)
         # instead of beside the FAN's own input gradients (which fill the chip themselves); their NaN flag is taken at the end.
@@ -357,7 +357,7 @@ class ManipulationClassification(object):
             ops.nan_flag(self.fan._model.flat_grad, self._nan_flag)         # joins the side streams
             self._bucket.launch(self.fan._model.flat_grad)
         parallel.all_reduce_flag(self._nan_flag)
-        torch.maximum(self._nan_seen, self._nan_flag, out=self._nan_seen)
+        ops.int_max_(self._nan_seen, self._nan_flag)
         if self._nan_check == 'eager' and int(self._nan_flag.item()) != 0:       # host sync, like the reference
             self._nan_seen.zero_()
             self._bucket.wait()
