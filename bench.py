@@ -527,6 +527,13 @@ def trained_parity(wl, dev, pre, joint, tail):
     # chunks of 50 steps (at most 8) until no manipulation class sits at zero - 'native' and 'jpeg:80' (indistinguishable from each
     # other) count as one class: round 4's final build reaches step 600 with both of them answered 'gaussian' (2 % / 0 %, CE 5.7)
     # in BOTH modes and is back at 0.78 / 0.78 150 steps later.  `joint_steps_added_to_leave_a_collapse` says what was added.
+    # the checkpoint below is therefore selected on a held-out probe; the metrics AT THE NOMINAL STEP COUNT (fixed
+    # protocol, no selection), in both modes, are reported next to it as `at_nominal_steps`.
+    nominal = {}
+    for mode in ('bf16', 'f32'):
+        ops.set_compute(mode)
+        nominal[mode] = tp.evaluate(wf, held[0], held[1], b)[0]
+    ops.set_compute('bf16')
     extra = 0
     while extra < 400:
         probe, _ = tp.evaluate(wf, held[0], held[1], b)
@@ -538,7 +545,10 @@ def trained_parity(wl, dev, pre, joint, tail):
     out = {'recipe': {'nip_pretraining_steps': pre, 'nip_pretraining_lr': 3e-4, 'joint_steps': joint, 'joint_lr': 1e-4,
                       'joint_steps_added_to_leave_a_collapse': extra,
                       'tail_steps_per_mode': tail, 'batch': b, 'training_pool': 512, 'held_out_patches': 256,
-                      'data': 'tests/util.scene_images (synthetic scenes)', 'checkpoint_trained_in': 'bf16'}}
+                      'data': 'tests/util.scene_images (synthetic scenes)', 'checkpoint_trained_in': 'bf16'},
+           'at_nominal_steps': {'joint_steps': joint - extra, 'bf16': nominal['bf16'], 'f32': nominal['f32'],
+                                'fan_accuracy_delta': nominal['bf16']['fan_accuracy'] - nominal['f32']['fan_accuracy'],
+                                'isp_psnr_delta_db': nominal['bf16']['isp_psnr_db'] - nominal['f32']['isp_psnr_db']}}
     merge = lambda d: torch.where(d == wf.n_classes - 1, torch.zeros_like(d), d)       # 'jpeg:80' -> 'native'
     ev, dec = {}, {}
     for mode in ('bf16', 'f32'):

@@ -280,6 +280,11 @@ class FAN(TFModel):
             fn()
         if join:
             ops.join_side_stream()
+            P.grads_pending = False
+        else:
+            # the weight gradients are still in flight on the side streams - whoever reads the gradient buffer next
+            # (ParamStore.adam, GradientBucket.launch, a test) has to join first; ops.nan_flag / ops.join_side_stream clear the mark
+            P.grads_pending = True
         return loss, dx
 
     # -- reference surface ---------------------------------------------------------------------------------------
