@@ -1664,3 +1664,80 @@ def test_torch_library_custom_ops(dev):
     assert torch.ops.nimg.cconv3(img, nf, 1).shape == (1, 16, 16, 3)
     with pytest.raises(NotImplementedError):
         torch.ops.nimg.cconv3(img.clone().requires_grad_(True), nf, 1)
+
+
+def test_torch_ops_autograd_matches_the_explicit_backward(dev):
+    """torch.ops.nimg.* (neural-imaging_amd/torch_ops.py, round 5): a channel assembled from dispatcher ops alone -
+    manipulations -> dJPEG -> constrained filter -> conv + LeakyReLU -> max-pool -> GAP / Dense / softmax / CE, plus the NIP
+    loss - differentiated by torch.autograd on the GPU, against autograd of the float64 oracle on the CPU."""
+    import neural_imaging_amd.torch_ops  # noqa: F401  (registers the ops)
+    from neural_imaging_amd import ops
+    from oracle import nets as onets
+    nimg = torch.ops.nimg
+    n, h = 4, 32
+    x0 = natural_images(n, h, h, seed=61)
+    tgt = natural_images(n, h, h, seed=62)
+    noise = rnd((n, h, h, 3), 63)
+    kern = ot.fan_residual_init().astype(np.float32)
+    w1, b1 = (0.1 * rnd((5, 5, 3, 8), 64)), 0.05 * rnd((8,), 65)
+    wd, bd = 0.3 * rnd((8, 4), 66), 0.1 * rnd((4,), 67)
+    labels = np.array([0, 1, 2, 3], np.int64)
+    qt = ops.qtables_device(80, dev)
+
+    def chain(P, lib):
+        x = P['x']
+        parts = [lib['sharpen'](x), lib['gaussian'](x), lib['resample'](x), lib['gamma'](x), lib['awgn'](x)]
+        m = (parts[0] + parts[1] + parts[2] + parts[3] + parts[4]) / 5
+        c = lib['djpeg'](m)
+        r = lib['cconv'](c, P['kern'])
+        a = lib['conv'](r, P['w1'], P['b1'])
+        pl = lib['pool'](a)
+        loss_ce = lib['head'](pl, P['wd'], P['bd'])
+        return loss_ce + 0.01 * lib['mse'](m)
+
+    mk = lambda a, d, t: torch.tensor(a, dtype=t, device=d, requires_grad=True)
+    names = ('x', 'kern', 'w1', 'b1', 'wd', 'bd')
+    vals = (x0, kern, w1, b1, wd, bd)
+    Pg = {k: mk(v, dev, torch.float32) for k, v in zip(names, vals)}
+    lab_g, tgt_g, noise_g = torch.tensor(labels, device=dev), g(tgt, dev), g(noise, dev)
+    gpu = {'sharpen': lambda x: nimg.manipulation_sharpen(x, 1.0), 'gaussian': lambda x: nimg.manipulation_gaussian(x, 0.83),
+           'resample': lambda x: nimg.manipulation_resample(x, 50.0), 'gamma': lambda x: nimg.manipulation_gamma(x, 3.0),
+           'awgn': lambda x: nimg.manipulation_awgn(x, noise_g, 5.1 / 255), 'djpeg': lambda m: nimg.djpeg(m, qt, 'sin'),
+           'cconv': lambda c, k: nimg.constrained_conv(c, k, 100.0), 'conv': lambda r, w, b: nimg.conv2d(r, w, b, 1, 'leaky_relu'),
+           'pool': nimg.max_pool2, 'head': lambda a, w, b: nimg.fan_head(a, w, b, lab_g)[0], 'mse': lambda m: nimg.mse255(m, tgt_g)}
+    loss_g = chain(Pg, gpu)
+    grads_g = torch.autograd.grad(loss_g, [Pg[k] for k in names])
+
+    Pc = {k: mk(v, 'cpu', torch.float64) for k, v in zip(names, vals)}
+    mask = torch.tensor(ot.center_mask_2dfilter(5, 3), dtype=torch.float64)
+    tgt_c, noise_c = to64(tgt), to64(noise)
+
+    def head_c(a, w, b):
+        probs = torch.softmax(a.mean(dim=(1, 2)) @ w + b, dim=1)
+        return T.sparse_ce_from_probs(probs, labels)
+    cpu = {'sharpen': lambda x: om.manipulation_sharpen(x, 1, hsv=True), 'gaussian': lambda x: om.manipulation_gaussian(x, 5, 0.83),
+           'resample': lambda x: om.manipulation_resample(x, 50), 'gamma': lambda x: om.manipulation_gamma(x, 3.0),
+           'awgn': lambda x: om.manipulation_awgn(x, 5.1 / 255, noise_c), 'djpeg': lambda m: odj.djpeg_torch(m, 80, 'sin')[0],
+           'cconv': lambda c, k: T.constrained_conv(c, k, mask), 'conv': lambda r, w, b: T.leaky_relu(T.conv2d(r, w, b)),
+           'pool': T.max_pool2, 'head': head_c, 'mse': lambda m: T.mse255(m, tgt_c)}
+    loss_c = chain(Pc, cpu)
+    grads_c = torch.autograd.grad(loss_c, [Pc[k] for k in names])
+    assert abs(float(loss_g) - float(loss_c)) <= 1e-4 * max(1.0, abs(float(loss_c)))
+    for k, a, b in zip(names, grads_g, grads_c):
+        assert_close(a.cpu().numpy(), b.numpy(), 1e-7, 2e-3, what='torch.ops.nimg autograd: d loss / d ' + k)
+
+    # the decoder tail of the UNet: Conv2DTranspose(2x2, stride 2) -> depth_to_space(2) + straight-through clip
+    xt, wt, bt = rnd((2, 6, 6, 8), 70), 0.3 * rnd((2, 2, 12, 8), 71), 0.1 * rnd((12,), 72)
+    tg = natural_images(2, 24, 24, seed=73)
+    Qg = [mk(v, dev, torch.float32) for v in (xt, wt, bt)]
+    lg = nimg.mse255(nimg.depth_to_space_clip(nimg.conv_transpose2x2(*Qg)), g(tg, dev))
+    gg = torch.autograd.grad(lg, Qg)
+    Qc = [mk(v, 'cpu', torch.float64) for v in (xt, wt, bt)]
+    lc = T.mse255(T.clip_ste(T.depth_to_space(T.conv2d_transpose_2x2(*Qc), 2)), to64(tg))
+    gc = torch.autograd.grad(lc, Qc)
+    assert abs(float(lg) - float(lc)) <= 1e-5 * float(lc)
+    for a, b, k in zip(gg, gc, ('x', 'kernel', 'bias')):
+        assert_close(a.cpu().numpy(), b.numpy(), 1e-7, 2e-4, what='conv_transpose2x2 -> depth_to_space_clip: d loss / d ' + k)
+    # inference mode reaches the kernels through the backend key
+    with torch.inference_mode():
+        assert nimg.max_pool2(g(rnd((1, 8, 8, 8), 74), dev)).shape == (1, 4, 4, 8)
