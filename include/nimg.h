@@ -485,6 +485,16 @@ int nimg_conv2d_pool_fwd_bf16_ex(const float* in, int cin, const float* w, const
  * encoder level + its max_pool2d (models/pipelines.py:160-173): the full tensor is the skip connection. */
 int nimg_conv2d_fwd_pool_also_bf16(const float* in, int cin, const void* wb, const float* bias, float* out, float* pool_out,
                                    unsigned char* pool_idx, int cout, int n, int h, int wd, int act, float alpha, void* stream);
+/* Row-band STREAMING form of the 3x3 / stride 1 / SAME convolution over bf16-stored activations with 32 output channels
+ * (csrc/conv3_rows.hip; the UNet's level-1 layers, models/pipelines.py:190-216, throughput mode): in1 (n, h, wd, c1) [+ in2
+ * (n, h, wd, c2)], wb = nimg_conv_weights_bf16 image (mode 0 forward, mode 1 input gradient), bias (32) or null, mask = optional
+ * (n, h, wd, 32) bf16 activation whose LeakyReLU' multiplies the result, out (n, h, wd, 32) bf16, pool_out = optional
+ * (n, h / 2, wd / 2, 32) bf16 2x2 max-pool of out.  Results are bit-identical to nimg_conv2d_fwd_bf16_ex (+ nimg_maxpool2_fwd_bf16).
+ * Shapes: wd == 128, h % 4 == 0, cout == 32, (c1, c2) in {(32, 0), (64, 0), (32, 32)}; anything else NIMG_ERR_ARG (use the tile
+ * kernels). */
+int nimg_conv3_rows_bf16(const void* in1, int c1, const void* in2, int c2, const void* wb, const float* bias, const void* mask,
+                         void* out, void* pool_out, int n, int h, int wd, int cout, int act, float alpha, void* stream);
+
 /* Input gradient of a 3x3 SAME stride-1 convolution whose input was a 2x2 max-pool, written THROUGH that pool (the first
  * convolution of a UNet encoder level, models/pipelines.py:160-173 under the tape), all tensors bf16: dz (n,h,wd,c1) = the
  * convolution's output gradient, wb = its weights in input-gradient form (nimg_conv_weights_bf16 mode 1), act (n,2h,2wd,cout) =

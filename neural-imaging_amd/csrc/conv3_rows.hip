@@ -1,0 +1,343 @@
+// Row-band STREAMING form of the 3x3 / stride 1 / SAME convolution over bf16-stored activations with 32 output channels - the UNet's
+// level-1 layers (models/pipelines.py:190-216: ec12, dc41, dc42 forward; dc42 / dc5 input gradients), throughput mode.
+//
+// Why another form.  At 128 x 128 x 32 channels these layers are byte-bound (9 x 32 x 32 MACs per 128 B moved) and the tile
+// kernels (conv_fwd_bf16_kernel / conv3_dma_kernel: one 16 x 16 tile per workgroup, prologue - two 16-channel chunks - epilogue)
+// reach ~3 TB/s: a workgroup has ONE tile's bytes in flight, its neighbours on the CU are in other phases, and every tile pays a
+// halo (18 x 18 for 16 x 16: 1.27 x the reads), an address prologue and a drained pipeline.  Here a workgroup is PERSISTENT over a
+// band of image rows of full width:
+//   * the input arrives one image row at a time by LDS-DMA (buffer_load_dwordx4 ... lds, no staging registers, no write pass)
+//     into a ring of 2 RB + 2 row slots; the RB rows of step s + 1 are requested at the top of step s and land under its
+//     matrix work and its stores - a steady stream instead of load / compute / store phases;
+//   * no horizontal halo (the slot carries one zero pixel left and right), one row of vertical halo per band side;
+//   * the whole weight set (9 x Cin x 32 bf16 = 18 / 36 KB) is staged ONCE per workgroup;
+//   * a wave owns one 32-pixel column block of the RB rows of a step: accumulators stay in registers across the 9 taps and all
+//     input channels, summed in the tile kernels' order (16-channel chunk, then ky, then kx) - the results are BIT-IDENTICAL;
+//   * output rows leave as whole 2 KB runs (32 pixels x 32 channels x bf16), 16 bytes per lane, optionally with the 2x2 max-pool of
+//     the row pair next to them (NIMG_POOL_ALSO semantics: pooled on the raw sums, bias + LeakyReLU on the winner).
+// LDS image of a row slot: per 32-channel plane (W + 2) pixels x 64 B; the four 16-byte pieces of a pixel are XOR-swizzled by
+// (pixel >> 2) & 3 - applied on the SOURCE address of the DMA (which writes lane-linear) - so a ds_read_b128 of 16 consecutive
+// pixels covers all 64 banks.  Inputs with 64 channels (a decoder layer's [up, skip] pair, or one 64-channel tensor) are two planes.
+#include <stdlib.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "common.h"
+
+namespace {
+
+using namespace nimg;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int r_u32x4 __attribute__((ext_vector_type(4)));
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>) - the operand ring below must be indexed
+// with constants whatever the unroller decides (a 36-tap pipeline left rolled puts the ring into scratch memory)
+template <int... I, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+struct RowsParams {
+    const void* in1;              // (N, H, W, C1) bf16
+    const void* in2;              // (N, H, W, C2) bf16 or null
+    const __bf16* wb;             // [Cin / 16][9][32][16] (nimg_conv_weights_bf16, mode 0 forward / mode 1 input gradient)
+    const float* bias;            // 32 or null
+    const void* mask;             // optional (N, H, W, 32) bf16: out *= mask > 0 ? 1 : alpha (the previous layer's LeakyReLU')
+    void* out;                    // (N, H, W, 32) bf16
+    void* pool_out;               // optional (N, H / 2, W / 2, 32) bf16
+    int C1, C2, N, H;
+    int units, bands, BH;         // work units = N x bands, a band = BH rows (BH % RB == 0)
+    int act;                      // 1: LeakyReLU(alpha) on the output
+    int ablate;                   // diagnostics (NIMG_ROWS_ABLATE, results are wrong): 1 no stores, 2 no matrix loop, 4 no row requests after a unit's first
+    float alpha;
+};
+
+__device__ __forceinline__ void glds16(r_u32x4 rsrc, unsigned lds_addr, unsigned voff, int soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+template <int NP, int W, int RB, int PFD, int NCW>
+struct RowsGeom {
+    static constexpr int NR = (PFD + 1) * RB + 2;               // ring slots: the step's window + PFD steps of rows in flight
+    static constexpr int PLANE = (W + 2) * 64;                  // bytes of one 32-channel plane of a row slot
+    static constexpr int SLOT = NP * PLANE;
+    static constexpr int WBYTES = NP * 2 * 9 * 32 * 32;         // weights: [k-step][tap][co][2 x 16 B]
+    static constexpr int EPI = 32 * (32 + EPI_PAD) * 4;         // per-wave epilogue scratch
+    static constexpr size_t LDS = (size_t)NR * SLOT + WBYTES + NCW * EPI;
+};
+
+// NCW = computing waves: 4 (one per SIMD) or 8 (two per SIMD: one wave's epilogue - LDS turn-around, conversions, stores - runs
+// under its partner's matrix instructions); wave NCW is the loader
+template <int NP, int W, int RB, int PFD, int NCW>
+__global__ __launch_bounds__(64 * (NCW + 1)) __attribute__((amdgpu_waves_per_eu(1, NCW == 8 ? 3 : 2))) void conv3_rows_kernel(const RowsParams p) {
+    using G = RowsGeom<NP, W, RB, PFD, NCW>;
+    constexpr int NR = G::NR, PLANE = G::PLANE, SLOT = G::SLOT;
+    constexpr int KSTEPS = 2 * NP;                              // 16-channel MFMA k-steps
+    constexpr int MF = W / 32, RG = NCW / MF, RW = RB / RG;     // column blocks, row groups of the computing waves, rows per wave
+    constexpr int PIECES = W / 16;                              // 1 KB DMA pieces per plane row
+    constexpr int NTHR = 64 * (NCW + 1);                        // the computing waves + the loader wave
+    static_assert(W % 64 == 0 && MF <= 4 && NCW % MF == 0 && RB % RG == 0 && RW >= 1, "geometry");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sA = smem;                                   // ring first: DMA addresses stay small
+    uint4* sW = reinterpret_cast<uint4*>(smem + NR * SLOT);
+    const unsigned sA_addr = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* elds = reinterpret_cast<float*>(smem + NR * SLOT + G::WBYTES + (wave % NCW) * G::EPI);
+    const int half = lane >> 5, co = lane & 31;
+    const int pf = wave % MF, rg = wave / MF;
+
+    // ---- DMA source offsets of this wave's pieces inside a plane row: LDS position q (16 B units from pixel 1) holds pixel
+    //      x = q / 4, piece s' = q % 4 of the swizzled image = piece s = s' ^ (((x + 1) >> 2) & 3) of the source pixel
+    unsigned voff[NP][PIECES];                                  // (only the loader wave uses them)
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) {
+        const bool second = p.in2 && pl * 32 >= p.C1;
+        const int ct = second ? p.C2 : p.C1, c0 = second ? pl * 32 - p.C1 : pl * 32;
+#pragma unroll
+        for (int k = 0; k < PIECES; ++k) {
+            const int q = k * 64 + lane, x = q >> 2, sp = (q & 3) ^ (((x + 1) >> 2) & 3);
+            voff[pl][k] = (unsigned)(x * ct * 2 + c0 * 2 + sp * 16);
+        }
+    }
+    const long row_bytes1 = (long)W * p.C1 * 2, row_bytes2 = (long)W * p.C2 * 2;
+    const unsigned long a1 = (unsigned long)p.in1, a2 = (unsigned long)(p.in2 ? p.in2 : p.in1);
+    const r_u32x4 rs1 = {(unsigned)a1, (unsigned)(a1 >> 32) & 0xffffu, (unsigned)((long)p.N * p.H * row_bytes1), 0x00020000u};
+    const r_u32x4 rs2 = {(unsigned)a2, (unsigned)(a2 >> 32) & 0xffffu,
+                         (unsigned)((long)p.N * p.H * (p.in2 ? row_bytes2 : row_bytes1)), 0x00020000u};
+
+    // loader wave: request image row y of image n into ring position pos.  A row outside the image is requested too, at
+    // out-of-range offsets: the buffer descriptor answers with zeros, which land in the slot like any other row - the number
+    // of transfers per batch is then a constant and the loader can wait with a COUNTED s_waitcnt
+    auto request = [&](int n, int y, int pos) {
+        const bool inside = (unsigned)y < (unsigned)p.H;
+        static_for<NP>([&](auto PL) {
+            constexpr int pl = decltype(PL)::value;
+            const bool second = p.in2 && pl * 32 >= p.C1;
+            const long rb = second ? row_bytes2 : row_bytes1;
+            // (wave-uniform by construction; readfirstlane makes it provable for the "s" operands of the asm statement)
+            const int soff = __builtin_amdgcn_readfirstlane(inside ? (int)(((long)n * p.H + y) * rb) : 0);
+            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(sA_addr + (unsigned)(pos * SLOT + pl * PLANE + 64)));
+            r_u32x4 rs = second ? rs2 : rs1;
+            rs[0] = (unsigned)__builtin_amdgcn_readfirstlane((int)rs[0]);
+            rs[1] = (unsigned)__builtin_amdgcn_readfirstlane((int)rs[1]);
+            rs[2] = (unsigned)__builtin_amdgcn_readfirstlane((int)rs[2]);
+            rs[3] = (unsigned)__builtin_amdgcn_readfirstlane((int)rs[3]);
+            static_for<PIECES>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                glds16(rs, dst + k * 1024, inside ? voff[pl][k] : 0x80000000u, soff);
+            });
+        });
+    };
+
+    // the first unit's rows are requested BEFORE the weights are staged: their flight covers the staging
+    constexpr int DPB = RB * NP * PIECES;                        // transfers of one step's batch of new rows
+    const int steps = p.BH / RB;
+    auto request_unit = [&](int unit) {
+        const int n = unit / p.bands, y0 = (unit % p.bands) * p.BH;
+        for (int i = 0; i < RB + 2; ++i) request(n, y0 - 1 + i, i);
+        if (PFD == 2 && steps > 1)
+            for (int i = 0; i < RB; ++i) request(n, y0 + RB + 1 + i, (RB + 2 + i) % NR);
+    };
+    if (wave == NCW && (int)blockIdx.x < p.units) request_unit(blockIdx.x);
+    // ---- once per workgroup: weights -> LDS ([k-step][tap][co] rows of two 16-byte halves, XOR-swizzled by (co >> 3) & 1),
+    //      the zero pixels left and right of every slot
+    for (int item = tid; item < KSTEPS * 9 * 32 * 2; item += NTHR) {
+        const int h8 = item & 1, row = item >> 1;               // row = (ks * 9 + tap) * 32 + co
+        const uint4 v = *reinterpret_cast<const uint4*>(p.wb + (long)row * 16 + h8 * 8);
+        sW[row * 2 + (h8 ^ ((row >> 3) & 1))] = v;
+    }
+    for (int item = tid; item < NR * NP * 2 * 4; item += NTHR) {
+        const int q = item & 3, side = (item >> 2) & 1, pl = item >> 3;      // pl = slot * NP + plane
+        *reinterpret_cast<uint4*>(sA + pl * PLANE + (side ? (W + 1) * 64 : 0) + q * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    const __bf16* maskp = reinterpret_cast<const __bf16*>(p.mask);
+    __bf16* outp = reinterpret_cast<__bf16*>(p.out);
+    __bf16* poolp = reinterpret_cast<__bf16*>(p.pool_out);
+    float bias_l = 0.f, bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+        bias_l = p.bias[co];
+        // the epilogue hands lane l the channels 8 (l & 3) .. + 7 of a pixel on every call: their biases live in registers (a global
+        // load inside the epilogue is a full memory round trip per row for a wave that has its SIMD to itself)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bias8[e] = p.bias[(lane & 3) * 8 + e];
+    }
+    const int b_lane = co * 2 + (half ^ ((co >> 3) & 1));       // + (ks * 9 + tap) * 64
+    const bool loader = wave == NCW;
+    for (int unit = blockIdx.x; unit < p.units; unit += gridDim.x) {
+        const int n = unit / p.bands, y0 = (unit % p.bands) * p.BH;
+        __syncthreads();                                         // the previous unit's reads are done
+        if (loader) {
+            if (unit != (int)blockIdx.x) request_unit(unit);
+            if (PFD == 2 && steps > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPB) : "memory");          // transfers complete in order
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();                                         // rows of step 0 landed
+        for (int s = 0; s < steps; ++s) {
+            if (loader) {
+                // the rows of steps s + 1 .. s + PFD travel while the four computing waves work on step s; only THIS wave waits for
+                // them - the computing waves never wait on the vector-memory counter (their stores would be in it)
+                if (s + PFD < steps && !(p.ablate & 4))
+                    for (int i = 0; i < RB; ++i) request(n, y0 + (s + PFD) * RB + 1 + i, ((s + PFD) * RB + 2 + i) % NR);
+                if (PFD == 2 && s + 2 < steps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPB) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                continue;
+            }
+            const int base = (s * RB + rg * RW) % NR;            // ring position of input row (first output row of the wave) - 1
+            f32x16 acc[RW];
+#pragma unroll
+            for (int r = 0; r < RW; ++r)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[r][j] = 0.f;
+            int slot_off[RW + 2];
+#pragma unroll
+            for (int i = 0; i < RW + 2; ++i) slot_off[i] = ((base + i) % NR) * SLOT;
+            // One software pipeline over the step's taps (k-step, ky, kx - the tile kernels' summation order): with one computing wave
+            // per SIMD nobody else covers an LDS round trip, so the operands of tap t + DIST are requested in front of the matrix
+            // instructions of tap t (a ring of DIST + 1 operand sets, everything unrolled, the order pinned per tap).
+            constexpr int NT = KSTEPS * 9, DIST = 2;
+            uint4 ra[DIST + 1][RW], rbw[DIST + 1];
+            auto fetch_tap = [&](auto T, auto S) {
+                constexpr int t = decltype(T)::value, slot = decltype(S)::value;
+                constexpr int ks = t / 9, ky = (t % 9) / 3, kx = t % 3;
+                constexpr int pl = ks >> 1;
+                const int sub = (ks & 1) * 2 + half;
+                rbw[slot] = sW[t * 64 + b_lane];
+                const int px = pf * 32 + co + kx;                // slot pixel index of output pixel (pf * 32 + lane) under tap kx
+                const int a_off = pl * PLANE + px * 64 + ((sub ^ ((px >> 2) & 3)) << 4);
+#pragma unroll
+                for (int r = 0; r < RW; ++r) ra[slot][r] = *reinterpret_cast<const uint4*>(sA + slot_off[r + ky] + a_off);
+            };
+            if (!(p.ablate & 2)) {
+                static_for<DIST>([&](auto D) { fetch_tap(D, D); });
+                __builtin_amdgcn_sched_group_barrier(0x100, DIST * (RW + 1), 0);
+                static_for<NT>([&](auto T) {
+                    constexpr int t = decltype(T)::value;
+                    if constexpr (t + DIST < NT)
+                        fetch_tap(std::integral_constant<int, t + DIST>{}, std::integral_constant<int, (t + DIST) % (DIST + 1)>{});
+#pragma unroll
+                    for (int r = 0; r < RW; ++r)
+                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&ra[t % (DIST + 1)][r]),
+                                                                         *reinterpret_cast<const bf16x8*>(&rbw[t % (DIST + 1)]), acc[r], 0, 0, 0);
+                    if constexpr (t + DIST < NT) __builtin_amdgcn_sched_group_barrier(0x100, RW + 1, 0);     // DS reads of tap t + DIST
+                    __builtin_amdgcn_sched_group_barrier(0x008, RW, 0);                                      // the matrix instructions of tap t
+                });
+            }
+            // ---- epilogue: bias, activation, mask, 16-byte stores; then the pooled row pairs
+            const int yw = y0 + s * RB + rg * RW;
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const long rowbase = (((long)n * p.H + yw + r) * W + pf * 32) * 32;
+                epilogue_via_lds8<1>(reinterpret_cast<const f32x16(&)[1]>(acc[r]), elds, lane, [&](int row, int c, float4 lo, float4 hi) {
+                    float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += bias8[e];          // c == 8 (lane & 3) on every call (NI = 1)
+                    if (p.act == 1) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] = lrelu(f[e], p.alpha);
+                    }
+                    const long o = rowbase + row * 32 + c;
+                    if (maskp) {
+                        const bf16x8 m = *reinterpret_cast<const bf16x8*>(maskp + o);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] *= (float)m[e] > 0.f ? 1.0f : p.alpha;
+                    }
+                    bf16x8 ov;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ov[e] = (__bf16)f[e];
+                    if (!(p.ablate & 1)) *reinterpret_cast<bf16x8*>(outp + o) = ov;
+                });
+            }
+            if (poolp) {
+                // rows (r, r + 1), pixels (2 i, 2 i + 1): registers j, j + 1 of one lane (j even) - the window of pooled pixel
+                // {0, 1, 4, 5, 8, 9, 12, 13}[j / 2] + 2 half; pooled on the raw sums, bias + LeakyReLU on the winner
+                constexpr int RS = 32 + EPI_PAD;
+#pragma unroll
+                for (int r = 0; r + 1 < RW; r += 2) {
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int j = 2 * q;
+                        const float m = fmaxf(fmaxf(acc[r][j], acc[r][j + 1]), fmaxf(acc[r + 1][j], acc[r + 1][j + 1]));
+                        const int pp = ((j & 3) >> 1) + 4 * (j >> 2) + 2 * half;       // pooled pixel inside the block (0..15)
+                        elds[pp * RS + co] = p.act == 1 ? lrelu(m + bias_l, p.alpha) : m + bias_l;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    const int pp = lane >> 2, c = (lane & 3) * 8;
+                    const float4 lo = *reinterpret_cast<const float4*>(elds + pp * RS + c);
+                    const float4 hi = *reinterpret_cast<const float4*>(elds + pp * RS + c + 4);
+                    bf16x8 ov;
+                    ov[0] = (__bf16)lo.x; ov[1] = (__bf16)lo.y; ov[2] = (__bf16)lo.z; ov[3] = (__bf16)lo.w;
+                    ov[4] = (__bf16)hi.x; ov[5] = (__bf16)hi.y; ov[6] = (__bf16)hi.z; ov[7] = (__bf16)hi.w;
+                    const long o = ((((long)n * (p.H >> 1) + ((yw + r) >> 1)) * (W >> 1)) + pf * 16 + pp) * 32 + c;
+                    *reinterpret_cast<bf16x8*>(poolp + o) = ov;
+                }
+            }
+            __syncthreads();                                     // step s is read out; the loader's rows of step s + 1 have landed
+        }
+    }
+}
+
+template <int NP, int W, int RB, int PFD, int NCW>
+int launch_rows(const RowsParams& p, hipStream_t s) {
+    using G = RowsGeom<NP, W, RB, PFD, NCW>;
+    static_assert(G::LDS <= 160 * 1024, "LDS");
+    auto k = conv3_rows_kernel<NP, W, RB, PFD, NCW>;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+        attr = true;
+    }
+    static const int max_wg = getenv("NIMG_ROWS_WGS") ? atoi(getenv("NIMG_ROWS_WGS")) : 256;
+    const int grid = p.units < max_wg ? p.units : max_wg;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * (NCW + 1)), G::LDS, s, p);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* see include/nimg.h */
+int nimg_conv3_rows_bf16(const void* in1, int c1, const void* in2, int c2, const void* wb, const float* bias, const void* mask,
+                         void* out, void* pool_out, int n, int h, int wd, int cout, int act, float alpha, void* stream) {
+    if (n == 0) return NIMG_OK;
+    if (!in1 || !wb || !out || n < 0 || cout != 32 || wd != 128 || h < 4 || (h & 3)) return NIMG_ERR_ARG;
+    if (!((c1 == 32 && c2 == 0 && !in2) || (c1 == 64 && c2 == 0 && !in2) || (c1 == 32 && c2 == 32 && in2))) return NIMG_ERR_ARG;
+    if (pool_out && (h & 1)) return NIMG_ERR_ARG;
+    if ((long)n * h * wd * (c1 > c2 ? c1 : c2) * 2 >= (1l << 31) - 65536) return NIMG_ERR_ARG;
+    RowsParams p;
+    p.in1 = in1; p.in2 = in2; p.wb = (const __bf16*)wb; p.bias = bias; p.mask = mask; p.out = out; p.pool_out = pool_out;
+    p.C1 = c1; p.C2 = c2; p.N = n; p.H = h; p.act = act ? 1 : 0; p.alpha = alpha;
+    static const int ablate = getenv("NIMG_ROWS_ABLATE") ? atoi(getenv("NIMG_ROWS_ABLATE")) : 0;
+    p.ablate = ablate;
+    // bands: the largest power-of-two band height that still gives every CU a unit (256 units at 64 images x 128 rows: 32 rows)
+    static const int bh_env = getenv("NIMG_ROWS_BH") ? atoi(getenv("NIMG_ROWS_BH")) : 0;
+    int bh = bh_env > 0 ? bh_env : 32;
+    while (bh > 4 && (h % bh != 0 || (long)n * (h / bh) < 256)) bh >>= 1;
+    if (h % bh != 0) return NIMG_ERR_ARG;
+    p.BH = bh; p.bands = h / bh; p.units = n * p.bands;
+    hipStream_t s = (hipStream_t)stream;
+    // rows per step: 4 where the ring (2 RB + 2 slots) fits, 2 for the 64-channel inputs (a slot is 16.6 KB there)
+    static const int rb_env = getenv("NIMG_ROWS_RB") ? atoi(getenv("NIMG_ROWS_RB")) : 0;
+    static const int pfd_env = getenv("NIMG_ROWS_PFD") ? atoi(getenv("NIMG_ROWS_PFD")) : 2;
+    static const int ncw_env = getenv("NIMG_ROWS_NCW") ? atoi(getenv("NIMG_ROWS_NCW")) : 8;
+    (void)rb_env;
+    if (c1 + c2 == 32) {
+        if (ncw_env == 4) return pfd_env == 1 ? launch_rows<1, 128, 4, 1, 4>(p, s) : launch_rows<1, 128, 4, 2, 4>(p, s);
+        return launch_rows<1, 128, 4, 1, 8>(p, s);
+    }
+    return launch_rows<2, 128, 2, 1, 4>(p, s);            // (a 64-channel slot is 16.6 KB: eight scratch areas do not fit beside the ring)
+}
+
+}  // extern "C"

@@ -357,7 +357,13 @@ def _register_round5():
     return lib, auto, cuda
 
 
-_HANDLES = _register() + _register_round5()          # keep the Library objects alive: dropping them de-registers the ops
+# keep the Library objects alive (dropping them de-registers the ops) - and register ONCE per process: the package is importable
+# under two names ('neural-imaging_amd' and its alias 'neural_imaging_amd'), a second execution of this module must not
+# define the namespace again
+_HANDLES = getattr(torch, '_nimg_torch_ops_handles', None)
+if _HANDLES is None:
+    _HANDLES = _register() + _register_round5()
+    torch._nimg_torch_ops_handles = _HANDLES
 
 
 def conv2d(x, w, bias=None, stride=1, act=''):

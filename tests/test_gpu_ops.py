@@ -1670,8 +1670,7 @@ def test_torch_ops_autograd_matches_the_explicit_backward(dev):
     """torch.ops.nimg.* (neural-imaging_amd/torch_ops.py, round 5): a channel assembled from dispatcher ops alone -
     manipulations -> dJPEG -> constrained filter -> conv + LeakyReLU -> max-pool -> GAP / Dense / softmax / CE, plus the NIP
     loss - differentiated by torch.autograd on the GPU, against autograd of the float64 oracle on the CPU."""
-    import neural_imaging_amd.torch_ops  # noqa: F401  (registers the ops)
-    from neural_imaging_amd import ops
+    from neural_imaging_amd import ops, torch_ops  # noqa: F401  (importing torch_ops registers the ops)
     from oracle import nets as onets
     nimg = torch.ops.nimg
     n, h = 4, 32
