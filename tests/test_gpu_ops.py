@@ -1740,3 +1740,40 @@ def test_torch_ops_autograd_matches_the_explicit_backward(dev):
     # inference mode reaches the kernels through the backend key
     with torch.inference_mode():
         assert nimg.max_pool2(g(rnd((1, 8, 8, 8), 74), dev)).shape == (1, 4, 4, 8)
+
+
+@pytest.mark.parametrize('n,h', [(3, 128), (2, 20), (5, 64)])
+def test_row_streaming_convolution_equals_the_tile_kernels(dev, n, h, monkeypatch):
+    """csrc/conv3_rows.hip (the UNet's level-1 layers in throughput mode: 3x3, 32 output channels, 128-pixel rows, bf16 storage):
+    forward with and without the pooled tensor, two-tensor and 64-channel inputs, the input-gradient form with the previous
+    layer's LeakyReLU' - the same bits as the tile kernels (same products, same summation order), whatever the band split."""
+    from neural_imaging_amd import ops
+    wd = 128
+    bf = lambda a: g(a, dev).to(torch.bfloat16)
+    same = lambda a, b: torch.equal(a.view(torch.int16), b.view(torch.int16))
+    try:
+        ops.set_compute('bf16')
+        for c1, c2 in ((32, 0), (32, 32), (64, 0)):
+            x = bf(rnd((n, h, wd, c1), 80 + c1))
+            x2 = bf(rnd((n, h, wd, c2), 81)) if c2 else None
+            w, b = g(0.1 * rnd((3, 3, c1 + c2, 32), 82), dev), g(0.1 * rnd((32,), 83), dev)
+            for act in ('leaky_relu', None):
+                monkeypatch.setattr(ops, 'ROWS_CONV', False)
+                ref = ops.conv2d(x, w, b, x2=x2, act=act, out_bf16=True)
+                monkeypatch.setattr(ops, 'ROWS_CONV', True)
+                assert ops.rows_conv_ok(x, x2, 3, 1, 32, (h, wd), (1, 1), 0, ref, None, None, act)
+                assert same(ops.conv2d(x, w, b, x2=x2, act=act, out_bf16=True), ref), (c1, c2, act)
+        x = bf(rnd((n, h, wd, 32), 84))
+        w, b = g(0.1 * rnd((3, 3, 32, 32), 85), dev), g(0.1 * rnd((32,), 86), dev)
+        monkeypatch.setattr(ops, 'ROWS_CONV', False)
+        ra, rp = ops.conv2d_and_pool(x, w, b)
+        dz, prev = bf(rnd((n, h, wd, 32), 87)), bf(rnd((n, h, wd, 32), 88))
+        rd = ops.conv2d_dgrad(dz, w, (h, wd), act_mask=prev, out_bf16=True)
+        monkeypatch.setattr(ops, 'ROWS_CONV', True)
+        ga, gp = ops.conv2d_and_pool(x, w, b)
+        assert same(ga, ra) and same(gp, rp)
+        assert same(ops.conv2d_dgrad(dz, w, (h, wd), act_mask=prev, out_bf16=True), rd)
+        # shapes the streaming form does not take fall through to the tile kernels
+        assert not ops.rows_conv_ok(bf(rnd((1, 16, 64, 32), 89)), None, 3, 1, 32, (16, 64), (1, 1), 0, ref, None, None, None)
+    finally:
+        ops.set_compute('f32')
