@@ -494,6 +494,11 @@ int nimg_conv2d_fwd_pool_also_bf16(const float* in, int cin, const void* wb, con
  * kernels). */
 int nimg_conv3_rows_bf16(const void* in1, int c1, const void* in2, int c2, const void* wb, const float* bias, const void* mask,
                          void* out, void* pool_out, int n, int h, int wd, int cout, int act, float alpha, void* stream);
+/* The UNet's last layer in the same form: 3x3 convolution 32 -> 12 channels + bias, written as clip(depth_to_space(., 2), 0, 1)
+ * (models/pipelines.py:216-223; the clip is straight-through, this is its forward value): in (n, h, wd, 32) bf16, wb the mode-0
+ * weight image of the (3, 3, 32, 12) kernel, bias (12) or null, y (n, 2 h, 2 wd, 3) float32.  Bit-identical to
+ * nimg_conv2d_fwd_bf16_ex + nimg_d2s_clip_fwd(scale 1, shift 0, clip).  wd == 128, h % 4 == 0. */
+int nimg_conv3_rows_d2s_bf16(const void* in, int c1, const void* wb, const float* bias, float* y, int n, int h, int wd, void* stream);
 
 /* Input gradient of a 3x3 SAME stride-1 convolution whose input was a 2x2 max-pool, written THROUGH that pool (the first
  * convolution of a UNet encoder level, models/pipelines.py:160-173 under the tape), all tensors bf16: dz (n,h,wd,c1) = the

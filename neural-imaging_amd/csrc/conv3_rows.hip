@@ -51,6 +51,8 @@ struct RowsParams {
     const void* mask;             // optional (N, H, W, 32) bf16: out *= mask > 0 ? 1 : alpha (the previous layer's LeakyReLU')
     void* out;                    // (N, H, W, 32) bf16
     void* pool_out;               // optional (N, H / 2, W / 2, 32) bf16
+    float* d2s;                   // optional (N, 2 H, 2 W, 3) float32: the layer has 12 output channels and leaves as clip(depth_to_space(.., 2), 0, 1)
+    int cout;                     // 32, or 12 with d2s
     int C1, C2, N, H;
     int units, bands, BH;         // work units = N x bands, a band = BH rows (BH % RB == 0)
     int act;                      // 1: LeakyReLU(alpha) on the output
@@ -152,7 +154,9 @@ __global__ __launch_bounds__(64 * (NCW + 1)) __attribute__((amdgpu_waves_per_eu(
     //      the zero pixels left and right of every slot
     for (int item = tid; item < KSTEPS * 9 * 32 * 2; item += NTHR) {
         const int h8 = item & 1, row = item >> 1;               // row = (ks * 9 + tap) * 32 + co
-        const uint4 v = *reinterpret_cast<const uint4*>(p.wb + (long)row * 16 + h8 * 8);
+        const int cow = row & 31, kt = row >> 5;                 // the image in HBM has p.cout rows per (k-step, tap)
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (cow < p.cout) v = *reinterpret_cast<const uint4*>(p.wb + ((long)kt * p.cout + cow) * 16 + h8 * 8);
         sW[row * 2 + (h8 ^ ((row >> 3) & 1))] = v;
     }
     for (int item = tid; item < NR * NP * 2 * 4; item += NTHR) {
@@ -163,7 +167,11 @@ __global__ __launch_bounds__(64 * (NCW + 1)) __attribute__((amdgpu_waves_per_eu(
     __bf16* outp = reinterpret_cast<__bf16*>(p.out);
     __bf16* poolp = reinterpret_cast<__bf16*>(p.pool_out);
     float bias_l = 0.f, bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
+    float bias_d[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};         // d2s: lane = (pixel, output row parity dy) takes channels 6 dy .. + 5
+    if (p.bias && p.d2s) {
+#pragma unroll
+        for (int e = 0; e < 6; ++e) bias_d[e] = p.bias[half * 6 + e];
+    } else if (p.bias) {
         bias_l = p.bias[co];
         // the epilogue hands lane l the channels 8 (l & 3) .. + 7 of a pixel on every call: their biases live in registers (a global
         // load inside the epilogue is a full memory round trip per row for a wave that has its SIMD to itself)
@@ -234,6 +242,29 @@ __global__ __launch_bounds__(64 * (NCW + 1)) __attribute__((amdgpu_waves_per_eu(
             }
             // ---- epilogue: bias, activation, mask, 16-byte stores; then the pooled row pairs
             const int yw = y0 + s * RB + rg * RW;
+            if (p.d2s) {
+                // last layer of the UNet (pipelines.py:216-223): 12 channels = the 2 x 2 x 3 values of depth_to_space(2); lane (pixel,
+                // dy) writes the six floats of output row 2 y + dy, pixels 2 x and 2 x + 1, clipped to [0, 1] (the straight-through
+                // clip's forward value) - 768 contiguous bytes per wave and row; the 12-channel tensor never exists in HBM
+                constexpr int RS = 32 + EPI_PAD;
+#pragma unroll
+                for (int r = 0; r < RW; ++r) {
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) elds[((j & 3) + 8 * (j >> 2) + 4 * half) * RS + co] = acc[r][j];
+                    __builtin_amdgcn_wave_barrier();
+                    float2* dst = reinterpret_cast<float2*>(
+                        p.d2s + ((((long)n * 2 * p.H + 2 * (yw + r) + half) * (2L * W)) + 2 * (pf * 32 + co)) * 3);
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) {
+                        const float2 v = *reinterpret_cast<const float2*>(elds + co * RS + half * 6 + 2 * e);
+                        const float a = fminf(fmaxf(v.x + bias_d[2 * e], 0.f), 1.f), b = fminf(fmaxf(v.y + bias_d[2 * e + 1], 0.f), 1.f);
+                        if (!(p.ablate & 1)) dst[e] = make_float2(a, b);
+                    }
+                }
+                __syncthreads();
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < RW; ++r) {
                 const long rowbase = (((long)n * p.H + yw + r) * W + pf * 32) * 32;
@@ -318,7 +349,7 @@ int nimg_conv3_rows_bf16(const void* in1, int c1, const void* in2, int c2, const
     if ((long)n * h * wd * (c1 > c2 ? c1 : c2) * 2 >= (1l << 31) - 65536) return NIMG_ERR_ARG;
     RowsParams p;
     p.in1 = in1; p.in2 = in2; p.wb = (const __bf16*)wb; p.bias = bias; p.mask = mask; p.out = out; p.pool_out = pool_out;
-    p.C1 = c1; p.C2 = c2; p.N = n; p.H = h; p.act = act ? 1 : 0; p.alpha = alpha;
+    p.C1 = c1; p.C2 = c2; p.N = n; p.H = h; p.act = act ? 1 : 0; p.alpha = alpha; p.d2s = nullptr; p.cout = 32;
     static const int ablate = getenv("NIMG_ROWS_ABLATE") ? atoi(getenv("NIMG_ROWS_ABLATE")) : 0;
     p.ablate = ablate;
     // bands: the largest power-of-two band height that still gives every CU a unit (256 units at 64 images x 128 rows: 32 rows)
@@ -338,6 +369,22 @@ int nimg_conv3_rows_bf16(const void* in1, int c1, const void* in2, int c2, const
         return launch_rows<1, 128, 4, 1, 8>(p, s);
     }
     return launch_rows<2, 128, 2, 1, 4>(p, s);            // (a 64-channel slot is 16.6 KB: eight scratch areas do not fit beside the ring)
+}
+
+/* see include/nimg.h */
+int nimg_conv3_rows_d2s_bf16(const void* in, int c1, const void* wb, const float* bias, float* y, int n, int h, int wd, void* stream) {
+    if (n == 0) return NIMG_OK;
+    if (!in || !wb || !y || n < 0 || c1 != 32 || wd != 128 || h < 4 || (h & 3)) return NIMG_ERR_ARG;
+    if ((long)n * h * wd * c1 * 2 >= (1l << 31) - 65536) return NIMG_ERR_ARG;
+    RowsParams p;
+    p.in1 = in; p.in2 = nullptr; p.wb = (const __bf16*)wb; p.bias = bias; p.mask = nullptr; p.out = nullptr; p.pool_out = nullptr;
+    p.d2s = y; p.cout = 12;
+    p.C1 = c1; p.C2 = 0; p.N = n; p.H = h; p.act = 0; p.alpha = 0.f; p.ablate = 0;
+    int bh = 32;
+    while (bh > 4 && (h % bh != 0 || (long)n * (h / bh) < 256)) bh >>= 1;
+    if (h % bh != 0) return NIMG_ERR_ARG;
+    p.BH = bh; p.bands = h / bh; p.units = n * p.bands;
+    return launch_rows<1, 128, 4, 1, 8>(p, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -158,10 +158,34 @@ __device__ __forceinline__ uint4 unp_route(uint4 g, unsigned k0, unsigned k1, un
 // are turned around through the wave's LDS scratch so that each lane stores 16 B along the NHWC channel axis; bias, activation,
 // previous-layer LeakyReLU' mask, residual, bf16 copy and the depth_to_space / space_to_depth output layouts are applied on the
 // way (ConvParamsB).  Requires O1 % 4 == 0 and O2 % 4 == 0; contains one workgroup barrier (the scratch aliases the tiles).
+// The eight biases a lane adds in the 8-wide epilogue below are the same on every call (channels 8 (lane % (4 NI)) .. + 7 of the
+// wave's strip): the kernels request them at their START (EpiBias), so the epilogue of a workgroup that has its SIMDs to itself
+// does not open with a memory round trip (conv3_rows.hip: that round trip was 20 % of a byte-bound layer).
+struct EpiBias { float b[8]; };
+template <int NI>
+__device__ __forceinline__ EpiBias epi_bias_preload(const ConvParamsB& p, int lane, int wn, int co0, int Cout) {
+    EpiBias r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r.b[e] = 0.f;
+    const int co = co0 + wn * NI * 32 + (lane % (NI * 4)) * 8;
+    if (p.bias && co + 7 < Cout) {
+        const int cb = (p.flags & NIMG_D2S_CONVT) ? co % (p.O1 >> 2) : co;
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + cb), b1 = *reinterpret_cast<const float4*>(p.bias + cb + 4);
+        r.b[0] = b0.x; r.b[1] = b0.y; r.b[2] = b0.z; r.b[3] = b0.w; r.b[4] = b1.x; r.b[5] = b1.y; r.b[6] = b1.z; r.b[7] = b1.w;
+    }
+    return r;
+}
+
 template <int KS, int TH, int TW, int NB, int MI, int NI>
 __device__ __forceinline__ void conv_epilogue_vec(const f32x16 (&acc)[MI][NI], const ConvParamsB& p, unsigned char* smem_raw,
                                                   int wave, int lane, int wm, int wn, int co0, int Cout, int ty0, int tx0,
-                                                  int grp, int phase) {
+                                                  int grp, int phase, const EpiBias& pre_) {
+#ifdef NIMG_NO_EPI_PRELOAD                      // A/B: the biases requested where the epilogue starts, as before round 5
+    const EpiBias pre = epi_bias_preload<NI>(p, lane, wn, co0, Cout);
+    (void)pre_;
+#else
+    const EpiBias& pre = pre_;
+#endif
     float* elds = reinterpret_cast<float*>(smem_raw) + wave * (32 * (NI * 32 + EPI_PAD));
     __syncthreads();                    // the scratch aliases the tiles: everyone is done reading them; from here on every
                                         // wave works in its own region (wave-level ordering only)
@@ -233,8 +257,8 @@ __device__ __forceinline__ void conv_epilogue_vec(const f32x16 (&acc)[MI][NI], c
                 const long o = (((long)n * 2 * p.Hout + 2 * oy + (ph >> 1)) * (2 * p.Wout) + 2 * ox + (ph & 1)) * cd + cc;
                 float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                 if (p.bias) {
-                    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + cc), b1 = *reinterpret_cast<const float4*>(p.bias + cc + 4);
-                    f[0] += b0.x; f[1] += b0.y; f[2] += b0.z; f[3] += b0.w; f[4] += b1.x; f[5] += b1.y; f[6] += b1.z; f[7] += b1.w;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += pre.b[e];
                 }
                 *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.out1) + o) = pack8(f);
             });
@@ -257,8 +281,8 @@ __device__ __forceinline__ void conv_epilogue_vec(const f32x16 (&acc)[MI][NI], c
                     : ((long)n * p.Hout + oy) * p.Wout + ox;
                 float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                 if (p.bias) {
-                    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + co), b1 = *reinterpret_cast<const float4*>(p.bias + co + 4);
-                    f[0] += b0.x; f[1] += b0.y; f[2] += b0.z; f[3] += b0.w; f[4] += b1.x; f[5] += b1.y; f[6] += b1.z; f[7] += b1.w;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += pre.b[e];
                 }
                 if (p.act == 1) {
 #pragma unroll
@@ -398,6 +422,7 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
     const int ty0 = (tile / p.tiles_x) * TH, tx0 = (tile % p.tiles_x) * TW;
     const int iy0 = ty0 * STRIDE - p.pad_t, ix0 = tx0 * STRIDE - p.pad_l;
     const int half = lane >> 5;
+    const EpiBias epi_pre = epi_bias_preload<NI>(p, lane, wn, co0, Cout);       // in flight under the whole main loop
 
     int abase[MI];
 #pragma unroll
@@ -634,7 +659,7 @@ __global__ __launch_bounds__(256) void conv_fwd_bf16_kernel(const ConvParamsB p)
     }
     // ---- epilogue, vector form: accumulators turned around through LDS so each lane stores 16 B along the channels
     if ((p.O1 & 3) == 0 && (p.O2 & 3) == 0) {
-        conv_epilogue_vec<KS, TH, TW, NB, MI, NI>(acc, p, smem_raw, wave, lane, wm, wn, co0, Cout, ty0, tx0, grp, phase);
+        conv_epilogue_vec<KS, TH, TW, NB, MI, NI>(acc, p, smem_raw, wave, lane, wm, wn, co0, Cout, ty0, tx0, grp, phase, epi_pre);
         return;
     }
 #pragma unroll
@@ -965,7 +990,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : (TN == 32 ? 3 : 2)) void con
         return;
     }
     if constexpr (KS == 3) {        // the 3x3 layers (codec, UNet): every epilogue option of conv_fwd_bf16_kernel, same code
-        conv_epilogue_vec<3, TH, TW, 1, MI, NI>(acc, p, smem_raw, wave, lane, wave, 0, co0, Cout, ty0, tx0, grp, 0);
+        conv_epilogue_vec<3, TH, TW, 1, MI, NI>(acc, p, smem_raw, wave, lane, wave, 0, co0, Cout, ty0, tx0, grp, 0,
+                                                epi_bias_preload<NI>(p, lane, 0, co0, Cout));
         return;
     }
     // epilogue: per-wave private LDS scratch (the loop's last barrier released the tiles) -> wave-level ordering only
@@ -1107,6 +1133,7 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const ConvParamsB p) {
     const int ty0 = (tile / p.tiles_x) * TH, tx0 = (tile % p.tiles_x) * TW;
     const int iy0 = ty0 - p.pad_t, ix0 = tx0 - p.pad_l;
     const int half = lane >> 5;
+    const EpiBias epi_pre = epi_bias_preload<NI>(p, lane, wn, co0, Cout);       // older than every DMA request: retires first
 
     int abase[MI];
 #pragma unroll
@@ -1206,7 +1233,7 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const ConvParamsB p) {
         dma_wait();                                    // the next chunk has landed ...
         __syncthreads();                               // ... and everyone is done with this one
     }
-    conv_epilogue_vec<3, TH, TW, NB, MI, NI>(acc, p, smem_raw, wave, lane, wm, wn, co0, Cout, ty0, tx0, grp, 0);
+    conv_epilogue_vec<3, TH, TW, NB, MI, NI>(acc, p, smem_raw, wave, lane, wm, wn, co0, Cout, ty0, tx0, grp, 0, epi_pre);
 }
 
 template <int TH, int TW, int NB, int TN>

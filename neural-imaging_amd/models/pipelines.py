@@ -176,8 +176,15 @@ class UNet(NIPModel):
             t['dc{}1'.format(n)] = L['dc{}1'.format(n)].forward(P, t['dct{}'.format(n)], t['ec{}2'.format(ns - n)],
                                                               out_bf16=sb)
             t['dc{}2'.format(n)] = L['dc{}2'.format(n)].forward(P, t['dc{}1'.format(n)], out_bf16=sb)
-        t['dc{}'.format(ns)] = L['dc{}'.format(ns)].forward(P, t['dc{}2'.format(ns - 1)])
-        y = ops.d2s_clip(t['dc{}'.format(ns)], 1.0, 0.0, True, out=out)
+        last, xin = L['dc{}'.format(ns)], t['dc{}2'.format(ns - 1)]
+        if ops.rows_d2s_ok(xin, P.p[last.name + '/kernel']):
+            # throughput mode at 128-pixel rows: the 12-channel tensor is written as its clipped depth_to_space image by the
+            # convolution itself (csrc/conv3_rows.hip); the backward pass never reads it (the clip is straight-through)
+            t['dc{}'.format(ns)] = None
+            y = ops.conv3_rows_d2s(xin, P.p[last.name + '/kernel'], P.p[last.name + '/bias'], out=out)
+        else:
+            t['dc{}'.format(ns)] = last.forward(P, xin)
+            y = ops.d2s_clip(t['dc{}'.format(ns)], 1.0, 0.0, True, out=out)
         return y, (t if training else None)
 
     def decoder_grads(self):

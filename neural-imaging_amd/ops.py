@@ -502,6 +502,26 @@ def rows_conv_ok(x, x2, ks, stride, cout, out_hw, pads, pad_mode, out, out2, act
         n * h * wd * max(c1, c2) * 2 < (1 << 31) - 65536
 
 
+def rows_d2s_ok(x, w):
+    n, h, wd, c = x.shape
+    return ROWS_CONV and COMPUTE == 'bf16' and _is_bf16(x) and tuple(w.shape) == (3, 3, 32, 12) and c == 32 and wd == 128 and \
+        h % 4 == 0 and h >= 4 and n * h * wd * 64 < (1 << 31) - 65536
+
+
+def conv3_rows_d2s(x, w, bias, out=None):
+    """clip(depth_to_space(conv2d(x, w, bias), 2), 0, 1) in one pass (the UNet's last layer, where rows_d2s_ok): x (n, h, 128, 32)
+    bf16 -> (n, 2 h, 256, 3) float32; the same bits as conv2d + d2s_clip."""
+    if not rows_d2s_ok(x, w):
+        raise ValueError('conv3_rows_d2s: unsupported shape / mode')
+    _f32(w, bias, out)
+    n, h, wd, _ = x.shape
+    if out is not None and (tuple(out.shape) != (n, 2 * h, 2 * wd, 3) or not out.is_contiguous()):
+        raise ValueError('conv3_rows_d2s: output shape mismatch')
+    y = torch.empty((n, 2 * h, 2 * wd, 3), dtype=torch.float32, device=x.device) if out is None else out
+    _lib.call('nimg_conv3_rows_d2s_bf16', _p(x), 32, _p(weights_bf16(w, 0)), _p(bias), _p(y), n, h, wd, _stream())
+    return y
+
+
 def flip_weights(w, out=None):
     """(k,k,Cin,Cout) -> spatially flipped (k,k,Cout,Cin) for the input-gradient pass."""
     _f32(w, out)

@@ -1773,6 +1773,12 @@ def test_row_streaming_convolution_equals_the_tile_kernels(dev, n, h, monkeypatc
         ga, gp = ops.conv2d_and_pool(x, w, b)
         assert same(ga, ra) and same(gp, rp)
         assert same(ops.conv2d_dgrad(dz, w, (h, wd), act_mask=prev, out_bf16=True), rd)
+        # the UNet's last layer: 32 -> 12 channels written as the clipped depth_to_space image
+        w12, b12 = g(0.3 * rnd((3, 3, 32, 12), 90), dev), g(0.2 * rnd((12,), 91), dev)
+        want = ops.d2s_clip(ops.conv2d(x, w12, b12), 1.0, 0.0, True)
+        assert ops.rows_d2s_ok(x, w12)
+        got = ops.conv3_rows_d2s(x, w12, b12)
+        assert torch.equal(got, want) and float(got.min()) == 0.0 and float(got.max()) == 1.0
         # shapes the streaming form does not take fall through to the tile kernels
         assert not ops.rows_conv_ok(bf(rnd((1, 16, 64, 32), 89)), None, 3, 1, 32, (16, 64), (1, 1), 0, ref, None, None, None)
     finally:
