@@ -490,10 +490,13 @@ int nimg_conv2d_fwd_pool_also_bf16(const float* in, int cin, const void* wb, con
  * (n, h, wd, c2)], wb = nimg_conv_weights_bf16 image (mode 0 forward, mode 1 input gradient), bias (32) or null, mask = optional
  * (n, h, wd, 32) bf16 activation whose LeakyReLU' multiplies the result, out (n, h, wd, 32) bf16, pool_out = optional
  * (n, h / 2, wd / 2, 32) bf16 2x2 max-pool of out.  Results are bit-identical to nimg_conv2d_fwd_bf16_ex (+ nimg_maxpool2_fwd_bf16).
- * Shapes: wd == 128, h % 4 == 0, cout == 32, (c1, c2) in {(32, 0), (64, 0), (32, 32)}; anything else NIMG_ERR_ARG (use the tile
- * kernels). */
+ * Shapes: wd == 128, h % 4 == 0, cout == 32, (c1, c2) in {(32, 0), (64, 0), (32, 32)}; or cout == 64 from c1 == 32 as TWO 32-channel
+ * tensors out / out2 (a decoder layer's input gradient, no bias / mask / pool).  flags: NIMG_ROWS_F32_OUT = out holds float32.
+ * Anything else NIMG_ERR_ARG (use the tile kernels). */
+#define NIMG_ROWS_F32_OUT 1
 int nimg_conv3_rows_bf16(const void* in1, int c1, const void* in2, int c2, const void* wb, const float* bias, const void* mask,
-                         void* out, void* pool_out, int n, int h, int wd, int cout, int act, float alpha, void* stream);
+                         void* out, void* out2, void* pool_out, int n, int h, int wd, int cout, int act, float alpha, int flags,
+                         void* stream);
 /* The UNet's last layer in the same form: 3x3 convolution 32 -> 12 channels + bias, written as clip(depth_to_space(., 2), 0, 1)
  * (models/pipelines.py:216-223; the clip is straight-through, this is its forward value): in (n, h, wd, 32) bf16, wb the mode-0
  * weight image of the (3, 3, 32, 12) kernel, bias (12) or null, y (n, 2 h, 2 wd, 3) float32.  Bit-identical to

@@ -53,7 +53,7 @@ PROTOTYPES = {
     'nimg_fan_head_bwd': (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P]),
     'nimg_adam_step': (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_int, c_float, P, P]),
     'nimg_adam_step_dev': (c_int, [P, P, P, P, c_long, P, c_float, c_float, c_float, c_float, P, P]),
-    'nimg_conv3_rows_bf16': (c_int, [P, c_int, P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, P]),
+    'nimg_conv3_rows_bf16': (c_int, [P, c_int, P, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),
     'nimg_conv3_rows_d2s_bf16': (c_int, [P, c_int, P, P, P, c_int, c_int, c_int, P]),
     'nimg_nan_flag': (c_int, [P, c_long, P, P]),
     'nimg_int_words': (c_int, [P, P, c_long, c_int, c_int, P]),

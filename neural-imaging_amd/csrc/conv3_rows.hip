@@ -49,7 +49,9 @@ struct RowsParams {
     const __bf16* wb;             // [Cin / 16][9][32][16] (nimg_conv_weights_bf16, mode 0 forward / mode 1 input gradient)
     const float* bias;            // 32 or null
     const void* mask;             // optional (N, H, W, 32) bf16: out *= mask > 0 ? 1 : alpha (the previous layer's LeakyReLU')
-    void* out;                    // (N, H, W, 32) bf16
+    void* out;                    // (N, H, W, 32) bf16 (float32 with out_f32)
+    void* out2;                   // second 32-channel output (64 output channels split over two tensors) or null
+    int out_f32;                  // out holds float32
     void* pool_out;               // optional (N, H / 2, W / 2, 32) bf16
     float* d2s;                   // optional (N, 2 H, 2 W, 3) float32: the layer has 12 output channels and leaves as clip(depth_to_space(.., 2), 0, 1)
     int cout;                     // 32, or 12 with d2s
@@ -66,21 +68,22 @@ __device__ __forceinline__ void glds16(r_u32x4 rsrc, unsigned lds_addr, unsigned
                  : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 
-template <int NP, int W, int RB, int PFD, int NCW>
+template <int NP, int W, int RB, int PFD, int NCW, int NO>
 struct RowsGeom {
     static constexpr int NR = (PFD + 1) * RB + 2;               // ring slots: the step's window + PFD steps of rows in flight
     static constexpr int PLANE = (W + 2) * 64;                  // bytes of one 32-channel plane of a row slot
     static constexpr int SLOT = NP * PLANE;
-    static constexpr int WBYTES = NP * 2 * 9 * 32 * 32;         // weights: [k-step][tap][co][2 x 16 B]
+    static constexpr int WBYTES = NP * 2 * 9 * (32 * NO) * 32;  // weights: [k-step][tap][co][2 x 16 B]
     static constexpr int EPI = 32 * (32 + EPI_PAD) * 4;         // per-wave epilogue scratch
     static constexpr size_t LDS = (size_t)NR * SLOT + WBYTES + NCW * EPI;
 };
 
 // NCW = computing waves: 4 (one per SIMD) or 8 (two per SIMD: one wave's epilogue - LDS turn-around, conversions, stores - runs
 // under its partner's matrix instructions); wave NCW is the loader
-template <int NP, int W, int RB, int PFD, int NCW>
+// NO = 32-channel output blocks: 1, or 2 for an input gradient that leaves as two 32-channel tensors (a decoder layer's [up, skip])
+template <int NP, int W, int RB, int PFD, int NCW, int NO>
 __global__ __launch_bounds__(64 * (NCW + 1)) __attribute__((amdgpu_waves_per_eu(1, NCW == 8 ? 3 : 2))) void conv3_rows_kernel(const RowsParams p) {
-    using G = RowsGeom<NP, W, RB, PFD, NCW>;
+    using G = RowsGeom<NP, W, RB, PFD, NCW, NO>;
     constexpr int NR = G::NR, PLANE = G::PLANE, SLOT = G::SLOT;
     constexpr int KSTEPS = 2 * NP;                              // 16-channel MFMA k-steps
     constexpr int MF = W / 32, RG = NCW / MF, RW = RB / RG;     // column blocks, row groups of the computing waves, rows per wave
@@ -152,9 +155,9 @@ __global__ __launch_bounds__(64 * (NCW + 1)) __attribute__((amdgpu_waves_per_eu(
     if (wave == NCW && (int)blockIdx.x < p.units) request_unit(blockIdx.x);
     // ---- once per workgroup: weights -> LDS ([k-step][tap][co] rows of two 16-byte halves, XOR-swizzled by (co >> 3) & 1),
     //      the zero pixels left and right of every slot
-    for (int item = tid; item < KSTEPS * 9 * 32 * 2; item += NTHR) {
-        const int h8 = item & 1, row = item >> 1;               // row = (ks * 9 + tap) * 32 + co
-        const int cow = row & 31, kt = row >> 5;                 // the image in HBM has p.cout rows per (k-step, tap)
+    for (int item = tid; item < KSTEPS * 9 * (32 * NO) * 2; item += NTHR) {
+        const int h8 = item & 1, row = item >> 1;               // row = (ks * 9 + tap) * 32 NO + co
+        const int cow = row % (32 * NO), kt = row / (32 * NO);   // the image in HBM has p.cout rows per (k-step, tap)
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (cow < p.cout) v = *reinterpret_cast<const uint4*>(p.wb + ((long)kt * p.cout + cow) * 16 + h8 * 8);
         sW[row * 2 + (h8 ^ ((row >> 3) & 1))] = v;
@@ -166,7 +169,11 @@ __global__ __launch_bounds__(64 * (NCW + 1)) __attribute__((amdgpu_waves_per_eu(
     const __bf16* maskp = reinterpret_cast<const __bf16*>(p.mask);
     __bf16* outp = reinterpret_cast<__bf16*>(p.out);
     __bf16* poolp = reinterpret_cast<__bf16*>(p.pool_out);
-    float bias_l = 0.f, bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float bias_l = 0.f, bias8[NO][8];
+#pragma unroll
+    for (int ni = 0; ni < NO; ++ni)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bias8[ni][e] = 0.f;
     float bias_d[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};         // d2s: lane = (pixel, output row parity dy) takes channels 6 dy .. + 5
     if (p.bias && p.d2s) {
 #pragma unroll
@@ -176,9 +183,11 @@ __global__ __launch_bounds__(64 * (NCW + 1)) __attribute__((amdgpu_waves_per_eu(
         // the epilogue hands lane l the channels 8 (l & 3) .. + 7 of a pixel on every call: their biases live in registers (a global
         // load inside the epilogue is a full memory round trip per row for a wave that has its SIMD to itself)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bias8[e] = p.bias[(lane & 3) * 8 + e];
+        for (int ni = 0; ni < NO; ++ni)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bias8[ni][e] = p.bias[ni * 32 + (lane & 3) * 8 + e];
     }
-    const int b_lane = co * 2 + (half ^ ((co >> 3) & 1));       // + (ks * 9 + tap) * 64
+    const int b_lane = co * 2 + (half ^ ((co >> 3) & 1));       // + ((ks * 9 + tap) * NO + ni) * 64
     const bool loader = wave == NCW;
     for (int unit = blockIdx.x; unit < p.units; unit += gridDim.x) {
         const int n = unit / p.bands, y0 = (unit % p.bands) * p.BH;
@@ -201,11 +210,13 @@ __global__ __launch_bounds__(64 * (NCW + 1)) __attribute__((amdgpu_waves_per_eu(
                 continue;
             }
             const int base = (s * RB + rg * RW) % NR;            // ring position of input row (first output row of the wave) - 1
-            f32x16 acc[RW];
+            f32x16 acc[RW][NO];
 #pragma unroll
             for (int r = 0; r < RW; ++r)
 #pragma unroll
-                for (int j = 0; j < 16; ++j) acc[r][j] = 0.f;
+                for (int ni = 0; ni < NO; ++ni)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) acc[r][ni][j] = 0.f;
             int slot_off[RW + 2];
 #pragma unroll
             for (int i = 0; i < RW + 2; ++i) slot_off[i] = ((base + i) % NR) * SLOT;
@@ -213,13 +224,14 @@ __global__ __launch_bounds__(64 * (NCW + 1)) __attribute__((amdgpu_waves_per_eu(
             // per SIMD nobody else covers an LDS round trip, so the operands of tap t + DIST are requested in front of the matrix
             // instructions of tap t (a ring of DIST + 1 operand sets, everything unrolled, the order pinned per tap).
             constexpr int NT = KSTEPS * 9, DIST = 2;
-            uint4 ra[DIST + 1][RW], rbw[DIST + 1];
+            uint4 ra[DIST + 1][RW], rbw[DIST + 1][NO];
             auto fetch_tap = [&](auto T, auto S) {
                 constexpr int t = decltype(T)::value, slot = decltype(S)::value;
                 constexpr int ks = t / 9, ky = (t % 9) / 3, kx = t % 3;
                 constexpr int pl = ks >> 1;
                 const int sub = (ks & 1) * 2 + half;
-                rbw[slot] = sW[t * 64 + b_lane];
+#pragma unroll
+                for (int ni = 0; ni < NO; ++ni) rbw[slot][ni] = sW[(t * NO + ni) * 64 + b_lane];
                 const int px = pf * 32 + co + kx;                // slot pixel index of output pixel (pf * 32 + lane) under tap kx
                 const int a_off = pl * PLANE + px * 64 + ((sub ^ ((px >> 2) & 3)) << 4);
 #pragma unroll
@@ -227,22 +239,25 @@ __global__ __launch_bounds__(64 * (NCW + 1)) __attribute__((amdgpu_waves_per_eu(
             };
             if (!(p.ablate & 2)) {
                 static_for<DIST>([&](auto D) { fetch_tap(D, D); });
-                __builtin_amdgcn_sched_group_barrier(0x100, DIST * (RW + 1), 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, DIST * (RW + NO), 0);
                 static_for<NT>([&](auto T) {
                     constexpr int t = decltype(T)::value;
                     if constexpr (t + DIST < NT)
                         fetch_tap(std::integral_constant<int, t + DIST>{}, std::integral_constant<int, (t + DIST) % (DIST + 1)>{});
 #pragma unroll
                     for (int r = 0; r < RW; ++r)
-                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&ra[t % (DIST + 1)][r]),
-                                                                         *reinterpret_cast<const bf16x8*>(&rbw[t % (DIST + 1)]), acc[r], 0, 0, 0);
-                    if constexpr (t + DIST < NT) __builtin_amdgcn_sched_group_barrier(0x100, RW + 1, 0);     // DS reads of tap t + DIST
-                    __builtin_amdgcn_sched_group_barrier(0x008, RW, 0);                                      // the matrix instructions of tap t
+#pragma unroll
+                        for (int ni = 0; ni < NO; ++ni)
+                            acc[r][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                *reinterpret_cast<const bf16x8*>(&ra[t % (DIST + 1)][r]),
+                                *reinterpret_cast<const bf16x8*>(&rbw[t % (DIST + 1)][ni]), acc[r][ni], 0, 0, 0);
+                    if constexpr (t + DIST < NT) __builtin_amdgcn_sched_group_barrier(0x100, RW + NO, 0);    // DS reads of tap t + DIST
+                    __builtin_amdgcn_sched_group_barrier(0x008, RW * NO, 0);                                 // the matrix instructions of tap t
                 });
             }
             // ---- epilogue: bias, activation, mask, 16-byte stores; then the pooled row pairs
             const int yw = y0 + s * RB + rg * RW;
-            if (p.d2s) {
+            if (NO == 1 && p.d2s) {
                 // last layer of the UNet (pipelines.py:216-223): 12 channels = the 2 x 2 x 3 values of depth_to_space(2); lane (pixel,
                 // dy) writes the six floats of output row 2 y + dy, pixels 2 x and 2 x + 1, clipped to [0, 1] (the straight-through
                 // clip's forward value) - 768 contiguous bytes per wave and row; the 12-channel tensor never exists in HBM
@@ -251,7 +266,7 @@ __global__ __launch_bounds__(64 * (NCW + 1)) __attribute__((amdgpu_waves_per_eu(
                 for (int r = 0; r < RW; ++r) {
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) elds[((j & 3) + 8 * (j >> 2) + 4 * half) * RS + co] = acc[r][j];
+                    for (int j = 0; j < 16; ++j) elds[((j & 3) + 8 * (j >> 2) + 4 * half) * RS + co] = acc[r][0][j];
                     __builtin_amdgcn_wave_barrier();
                     float2* dst = reinterpret_cast<float2*>(
                         p.d2s + ((((long)n * 2 * p.H + 2 * (yw + r) + half) * (2L * W)) + 2 * (pf * 32 + co)) * 3);
@@ -268,27 +283,38 @@ __global__ __launch_bounds__(64 * (NCW + 1)) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
             for (int r = 0; r < RW; ++r) {
                 const long rowbase = (((long)n * p.H + yw + r) * W + pf * 32) * 32;
-                epilogue_via_lds8<1>(reinterpret_cast<const f32x16(&)[1]>(acc[r]), elds, lane, [&](int row, int c, float4 lo, float4 hi) {
-                    float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] += bias8[e];          // c == 8 (lane & 3) on every call (NI = 1)
-                    if (p.act == 1) {
+                for (int ni = 0; ni < NO; ++ni) {
+                    void* dstp = ni == 0 ? p.out : p.out2;
+                    epilogue_via_lds8<1>(reinterpret_cast<const f32x16(&)[1]>(acc[r][ni]), elds, lane, [&](int row, int c, float4 lo, float4 hi) {
+                        float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) f[e] = lrelu(f[e], p.alpha);
-                    }
-                    const long o = rowbase + row * 32 + c;
-                    if (maskp) {
-                        const bf16x8 m = *reinterpret_cast<const bf16x8*>(maskp + o);
+                        for (int e = 0; e < 8; ++e) f[e] += bias8[ni][e];      // c == 8 (lane & 3) on every call
+                        if (p.act == 1) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) f[e] *= (float)m[e] > 0.f ? 1.0f : p.alpha;
-                    }
-                    bf16x8 ov;
+                            for (int e = 0; e < 8; ++e) f[e] = lrelu(f[e], p.alpha);
+                        }
+                        const long o = rowbase + row * 32 + c;
+                        if (maskp) {
+                            const bf16x8 m = *reinterpret_cast<const bf16x8*>(maskp + o);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) ov[e] = (__bf16)f[e];
-                    if (!(p.ablate & 1)) *reinterpret_cast<bf16x8*>(outp + o) = ov;
-                });
+                            for (int e = 0; e < 8; ++e) f[e] *= (float)m[e] > 0.f ? 1.0f : p.alpha;
+                        }
+                        if (p.ablate & 1) return;
+                        if (p.out_f32) {
+                            float4* d4 = reinterpret_cast<float4*>(reinterpret_cast<float*>(dstp) + o);
+                            d4[0] = make_float4(f[0], f[1], f[2], f[3]);
+                            d4[1] = make_float4(f[4], f[5], f[6], f[7]);
+                        } else {
+                            bf16x8 ov;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) ov[e] = (__bf16)f[e];
+                            *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(dstp) + o) = ov;
+                        }
+                    });
+                }
             }
-            if (poolp) {
+            if (NO == 1 && poolp) {
                 // rows (r, r + 1), pixels (2 i, 2 i + 1): registers j, j + 1 of one lane (j even) - the window of pooled pixel
                 // {0, 1, 4, 5, 8, 9, 12, 13}[j / 2] + 2 half; pooled on the raw sums, bias + LeakyReLU on the winner
                 constexpr int RS = 32 + EPI_PAD;
@@ -298,7 +324,7 @@ __global__ __launch_bounds__(64 * (NCW + 1)) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         const int j = 2 * q;
-                        const float m = fmaxf(fmaxf(acc[r][j], acc[r][j + 1]), fmaxf(acc[r + 1][j], acc[r + 1][j + 1]));
+                        const float m = fmaxf(fmaxf(acc[r][0][j], acc[r][0][j + 1]), fmaxf(acc[r + 1][0][j], acc[r + 1][0][j + 1]));
                         const int pp = ((j & 3) >> 1) + 4 * (j >> 2) + 2 * half;       // pooled pixel inside the block (0..15)
                         elds[pp * RS + co] = p.act == 1 ? lrelu(m + bias_l, p.alpha) : m + bias_l;
                     }
@@ -318,11 +344,11 @@ __global__ __launch_bounds__(64 * (NCW + 1)) __attribute__((amdgpu_waves_per_eu(
     }
 }
 
-template <int NP, int W, int RB, int PFD, int NCW>
+template <int NP, int W, int RB, int PFD, int NCW, int NO = 1>
 int launch_rows(const RowsParams& p, hipStream_t s) {
-    using G = RowsGeom<NP, W, RB, PFD, NCW>;
+    using G = RowsGeom<NP, W, RB, PFD, NCW, NO>;
     static_assert(G::LDS <= 160 * 1024, "LDS");
-    auto k = conv3_rows_kernel<NP, W, RB, PFD, NCW>;
+    auto k = conv3_rows_kernel<NP, W, RB, PFD, NCW, NO>;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
@@ -341,15 +367,18 @@ extern "C" {
 
 /* see include/nimg.h */
 int nimg_conv3_rows_bf16(const void* in1, int c1, const void* in2, int c2, const void* wb, const float* bias, const void* mask,
-                         void* out, void* pool_out, int n, int h, int wd, int cout, int act, float alpha, void* stream) {
+                         void* out, void* out2, void* pool_out, int n, int h, int wd, int cout, int act, float alpha, int flags,
+                         void* stream) {
     if (n == 0) return NIMG_OK;
-    if (!in1 || !wb || !out || n < 0 || cout != 32 || wd != 128 || h < 4 || (h & 3)) return NIMG_ERR_ARG;
+    if (!in1 || !wb || !out || n < 0 || wd != 128 || h < 4 || (h & 3) || (flags & ~NIMG_ROWS_F32_OUT)) return NIMG_ERR_ARG;
+    if (!((cout == 32 && !out2) || (cout == 64 && out2 && c1 == 32 && c2 == 0 && !pool_out && !mask && !flags))) return NIMG_ERR_ARG;
     if (!((c1 == 32 && c2 == 0 && !in2) || (c1 == 64 && c2 == 0 && !in2) || (c1 == 32 && c2 == 32 && in2))) return NIMG_ERR_ARG;
     if (pool_out && (h & 1)) return NIMG_ERR_ARG;
     if ((long)n * h * wd * (c1 > c2 ? c1 : c2) * 2 >= (1l << 31) - 65536) return NIMG_ERR_ARG;
     RowsParams p;
     p.in1 = in1; p.in2 = in2; p.wb = (const __bf16*)wb; p.bias = bias; p.mask = mask; p.out = out; p.pool_out = pool_out;
-    p.C1 = c1; p.C2 = c2; p.N = n; p.H = h; p.act = act ? 1 : 0; p.alpha = alpha; p.d2s = nullptr; p.cout = 32;
+    p.out2 = out2; p.out_f32 = (flags & NIMG_ROWS_F32_OUT) ? 1 : 0;
+    p.C1 = c1; p.C2 = c2; p.N = n; p.H = h; p.act = act ? 1 : 0; p.alpha = alpha; p.d2s = nullptr; p.cout = cout;
     static const int ablate = getenv("NIMG_ROWS_ABLATE") ? atoi(getenv("NIMG_ROWS_ABLATE")) : 0;
     p.ablate = ablate;
     // bands: the largest power-of-two band height that still gives every CU a unit (256 units at 64 images x 128 rows: 32 rows)
@@ -364,6 +393,7 @@ int nimg_conv3_rows_bf16(const void* in1, int c1, const void* in2, int c2, const
     static const int pfd_env = getenv("NIMG_ROWS_PFD") ? atoi(getenv("NIMG_ROWS_PFD")) : 2;
     static const int ncw_env = getenv("NIMG_ROWS_NCW") ? atoi(getenv("NIMG_ROWS_NCW")) : 8;
     (void)rb_env;
+    if (cout == 64) return launch_rows<1, 128, 4, 1, 8, 2>(p, s);
     if (c1 + c2 == 32) {
         if (ncw_env == 4) return pfd_env == 1 ? launch_rows<1, 128, 4, 1, 4>(p, s) : launch_rows<1, 128, 4, 2, 4>(p, s);
         return launch_rows<1, 128, 4, 1, 8>(p, s);
@@ -378,7 +408,7 @@ int nimg_conv3_rows_d2s_bf16(const void* in, int c1, const void* wb, const float
     if ((long)n * h * wd * c1 * 2 >= (1l << 31) - 65536) return NIMG_ERR_ARG;
     RowsParams p;
     p.in1 = in; p.in2 = nullptr; p.wb = (const __bf16*)wb; p.bias = bias; p.mask = nullptr; p.out = nullptr; p.pool_out = nullptr;
-    p.d2s = y; p.cout = 12;
+    p.out2 = nullptr; p.out_f32 = 0; p.d2s = y; p.cout = 12;
     p.C1 = c1; p.C2 = 0; p.N = n; p.H = h; p.act = 0; p.alpha = 0.f; p.ablate = 0;
     int bh = 32;
     while (bh > 4 && (h % bh != 0 || (long)n * (h / bh) < 256)) bh >>= 1;

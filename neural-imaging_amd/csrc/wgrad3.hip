@@ -315,7 +315,12 @@ int nimg_internal_wgrad3_alltaps(const void* in1, int c1, const void* in2, int c
     p.in1 = in1; p.in2 = in2; p.dz = dz; p.partial = partial; p.db_partial = db_partial;
     p.C1 = c1; p.C2 = c2; p.Cout = cout; p.N = n; p.H = h; p.W = wd;
     p.tiles_y = p.tiles_x = p.work_per_split = 0;
-    if (cout % 128 == 0) return launch<4, 8>(p, max_slabs, stream);
-    if (cout % 64 == 0) return launch<2, 8>(p, max_slabs, stream);
+    // output channels per workgroup: 32 NB.  A/B: NIMG_WGRAD3_NB = 1 | 2 | 4 forces the block width (read per call)
+    const char* nb_env = getenv("NIMG_WGRAD3_NB");
+    int nb = nb_env ? atoi(nb_env) : 0;
+    if (nb != 1 && nb != 2 && nb != 4) nb = cout % 128 == 0 ? 4 : (cout % 64 == 0 ? 2 : 1);
+    while (nb > 1 && cout % (32 * nb)) nb >>= 1;
+    if (nb == 4) return launch<4, 8>(p, max_slabs, stream);
+    if (nb == 2) return launch<2, 8>(p, max_slabs, stream);
     return (h % 16 == 0) ? launch<1, 16>(p, max_slabs, stream) : launch<1, 8>(p, max_slabs, stream);
 }

@@ -455,11 +455,11 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
         _lib.call('nimg_conv2d_dgrad_fewin_bf16', _p(x), _p(w), _p(out), 3, 32, n, h, wd, 5, _stream())
         return out
     if COMPUTE == 'bf16' and not _f32_only and residual is None and not bf16_copy and not d2s_out and not s2d_out and \
-            rows_conv_ok(x, x2, ks, stride, cout, (ho, wo), (pt, pl), pad_mode, out, out2, act_mask, act):
+            rows_conv_ok(x, x2, ks, stride, cout, (ho, wo), (pt, pl), pad_mode, out, out2, act_mask, act, bias):
         # the UNet's level-1 layers: row-band streaming kernel (csrc/conv3_rows.hip), same bits as the tile kernels
-        _lib.call('nimg_conv3_rows_bf16', _p(x), c1, _p(x2), c2, _p(weights_bf16(w, _wmode)), _p(bias), _p(act_mask), _p(out), None,
-                  n, h, wd, cout, act_id, alpha, _stream())
-        return out
+        _lib.call('nimg_conv3_rows_bf16', _p(x), c1, _p(x2), c2, _p(weights_bf16(w, _wmode)), _p(bias), _p(act_mask), _p(out),
+                  _p(out2), None, n, h, wd, cout, act_id, alpha, 0 if _is_bf16(out) else 1, _stream())
+        return out if out2 is None else (out, out2)
     if COMPUTE == 'bf16' and not _f32_only and c2 % 8 == 0 and cout >= 8 and \
             (c1 % 8 == 0 or (c2 == 0 and c1 % 4 == 0 and c1 >= 8 and not _is_bf16(x))):
         wb = weights_bf16(w, _wmode)
@@ -492,14 +492,18 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
 ROWS_CONV = _os.environ.get('NIMG_NO_ROWS_CONV') is None
 
 
-def rows_conv_ok(x, x2, ks, stride, cout, out_hw, pads, pad_mode, out, out2, act_mask, act):
+def rows_conv_ok(x, x2, ks, stride, cout, out_hw, pads, pad_mode, out, out2, act_mask, act, bias=None):
     n, h, wd, c1 = x.shape
     c2 = 0 if x2 is None else x2.shape[3]
-    return ROWS_CONV and ks == 3 and stride == 1 and cout == 32 and wd == 128 and h % 4 == 0 and h >= 4 and \
-        tuple(out_hw) == (h, wd) and tuple(pads) == (1, 1) and pad_mode == 0 and out2 is None and \
-        (c1, c2) in ((32, 0), (64, 0), (32, 32)) and _is_bf16(x) and (x2 is None or _is_bf16(x2)) and _is_bf16(out) and \
-        (act_mask is None or (_is_bf16(act_mask) and tuple(act_mask.shape) == (n, h, wd, 32))) and act in (None, 'leaky_relu') and \
-        n * h * wd * max(c1, c2) * 2 < (1 << 31) - 65536
+    if not (ROWS_CONV and ks == 3 and stride == 1 and wd == 128 and h % 4 == 0 and h >= 4 and tuple(out_hw) == (h, wd) and
+            tuple(pads) == (1, 1) and pad_mode == 0 and _is_bf16(x) and (x2 is None or _is_bf16(x2)) and
+            act in (None, 'leaky_relu') and n * h * wd * max(c1, c2) * 2 < (1 << 31) - 65536):
+        return False
+    if cout == 64:      # an input gradient that leaves as two 32-channel tensors (a decoder layer's [up, skip])
+        return (c1, c2) == (32, 0) and out2 is not None and _is_bf16(out) and _is_bf16(out2) and out.shape[3] == 32 and \
+            out2.shape[3] == 32 and act_mask is None and bias is None and act is None
+    return cout == 32 and out2 is None and (c1, c2) in ((32, 0), (64, 0), (32, 32)) and \
+        (act_mask is None or (_is_bf16(act_mask) and tuple(act_mask.shape) == (n, h, wd, 32)))      # out: bf16 or float32
 
 
 def rows_d2s_ok(x, w):
@@ -734,8 +738,8 @@ def conv2d_and_pool(x, w, bias=None, act='leaky_relu'):
     y = torch.empty((n, h, wd, cout), dtype=torch.bfloat16, device=x.device)
     pooled = torch.empty((n, h // 2, wd // 2, cout), dtype=torch.bfloat16, device=x.device)
     if rows_conv_ok(x, None, 3, 1, cout, (h, wd), (1, 1), 0, y, None, None, act):
-        _lib.call('nimg_conv3_rows_bf16', _p(x), cin, None, 0, _p(weights_bf16(w, 0)), _p(bias), None, _p(y), _p(pooled), n, h, wd,
-                  cout, 1 if act == 'leaky_relu' else 0, LRELU_ALPHA, _stream())
+        _lib.call('nimg_conv3_rows_bf16', _p(x), cin, None, 0, _p(weights_bf16(w, 0)), _p(bias), None, _p(y), None, _p(pooled), n, h,
+                  wd, cout, 1 if act == 'leaky_relu' else 0, LRELU_ALPHA, 0, _stream())
         return y, pooled
     _lib.call('nimg_conv2d_fwd_pool_also_bf16', _p(x), cin, _p(weights_bf16(w, 0)), _p(bias), _p(y), _p(pooled), None, cout,
               n, h, wd, 1 if act == 'leaky_relu' else 0, LRELU_ALPHA, _stream())

@@ -1773,6 +1773,17 @@ def test_row_streaming_convolution_equals_the_tile_kernels(dev, n, h, monkeypatc
         ga, gp = ops.conv2d_and_pool(x, w, b)
         assert same(ga, ra) and same(gp, rp)
         assert same(ops.conv2d_dgrad(dz, w, (h, wd), act_mask=prev, out_bf16=True), rd)
+        # float32 result (ec12's input gradient) and a 64-channel gradient that leaves as two tensors (dc41's [up, skip])
+        w64 = g(0.1 * rnd((3, 3, 64, 32), 92), dev)
+
+        def grads(on):
+            monkeypatch.setattr(ops, 'ROWS_CONV', on)
+            o1 = torch.empty((n, h, wd, 32), dtype=torch.bfloat16, device=dev)
+            o2 = torch.empty_like(o1)
+            ops.conv2d_dgrad(dz, w64, (h, wd), out=o1, out2=o2)
+            return ops.conv2d_dgrad(dz, w, (h, wd), act_mask=prev, out_bf16=False), o1, o2
+        (f0, a0, b0), (f1, a1, b1) = grads(False), grads(True)
+        assert f1.dtype == torch.float32 and torch.equal(f0, f1) and same(a0, a1) and same(b0, b1)
         # the UNet's last layer: 32 -> 12 channels written as the clipped depth_to_space image
         w12, b12 = g(0.3 * rnd((3, 3, 32, 12), 90), dev), g(0.2 * rnd((12,), 91), dev)
         want = ops.d2s_clip(ops.conv2d(x, w12, b12), 1.0, 0.0, True)

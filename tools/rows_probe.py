@@ -38,8 +38,8 @@ def rows(x, w, b, x2=None, mode=0, mask=None, pool=False, act=True):
     po = torch.empty((n, h // 2, h // 2, 32), dtype=torch.bfloat16, device=dev) if pool else None
     wb = ops.weights_bf16(w, mode)
     P = lambda t: None if t is None else t.data_ptr()
-    _lib.call('nimg_conv3_rows_bf16', P(x), c1, P(x2), c2, P(wb), P(b), P(mask), P(out), P(po), n, h, h, 32, 1 if act else 0, 0.2,
-              ops._stream())
+    _lib.call('nimg_conv3_rows_bf16', P(x), c1, P(x2), c2, P(wb), P(b), P(mask), P(out), None, P(po), n, h, h, 32, 1 if act else 0, 0.2,
+              0, ops._stream())
     return out, po
 
 
@@ -72,3 +72,23 @@ for name, c1, c2 in (('ec12 / dc42 (32 -> 32)', 32, 0), ('dc41 (32 + 32 -> 32)',
         t_new = timed(lambda: rows(dz, w, None, mode=1, mask=act_prev, act=False))
         print('%-26s dgrad    : tile %6.1f us  rows %6.1f us  identical %s' % (
             name, t_ref, t_new, torch.equal(ref.view(torch.int16), got.view(torch.int16))))
+        # the same with a float32 result (ec12's input gradient feeds the 4-channel weight-gradient kernel, which stages float32)
+        def via_ops(rows_on, f32):
+            ops.ROWS_CONV = rows_on
+            return ops.conv2d_dgrad(dz, w, (h, h), act_mask=act_prev, out_bf16=not f32)
+        ref, got = via_ops(False, True), via_ops(True, True)
+        print('%-26s dgrad f32: tile %6.1f us  rows %6.1f us  identical %s' % (
+            name, timed(lambda: via_ops(False, True)), timed(lambda: via_ops(True, True)), torch.equal(ref, got)))
+        # decoder layer's input gradient: 32 -> 32 + 32 channels as two tensors
+        w2 = rnd(3, 3, 64, 32) * 0.1
+        def two(rows_on):
+            ops.ROWS_CONV = rows_on
+            o1 = torch.empty((n, h, h, 32), dtype=torch.bfloat16, device=dev)
+            o2 = torch.empty_like(o1)
+            ops.conv2d_dgrad(dz, w2, (h, h), out=o1, out2=o2)
+            return o1, o2
+        (r1, r2), (g1, g2) = two(False), two(True)
+        print('%-26s dgrad 2x : tile %6.1f us  rows %6.1f us  identical %s / %s' % (
+            'dc41 (32 -> 32 + 32)', timed(lambda: two(False)), timed(lambda: two(True)),
+            torch.equal(r1.view(torch.int16), g1.view(torch.int16)), torch.equal(r2.view(torch.int16), g2.view(torch.int16))))
+        ops.ROWS_CONV = True

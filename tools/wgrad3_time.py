@@ -19,7 +19,8 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 N = 64
 LAYERS = [('ec12 / dc42', 128, 32, 0, 32), ('dc41', 128, 32, 32, 32), ('ec21', 64, 32, 0, 64), ('ec22 / dc32', 64, 64, 0, 64),
           ('dc31', 64, 64, 64, 64), ('ec31', 32, 64, 0, 128), ('ec32 / dc22', 32, 128, 0, 128), ('dc21', 32, 128, 128, 128),
-          ('ec41', 16, 128, 0, 256), ('ec42 / dc12', 16, 256, 0, 256), ('dc11', 16, 256, 256, 256)]
+          ('ec41', 16, 128, 0, 256), ('ec42 / dc12', 16, 256, 0, 256), ('dc11', 16, 256, 256, 256), ('ec51', 8, 256, 0, 512),
+          ('ec52', 8, 512, 0, 512)]
 tot = {'new': 0.0, 'old': 0.0}
 for name, h, c1, c2, cout in LAYERS:
     x1 = torch.randn((N, h, h, c1), device=dev).to(torch.bfloat16)
@@ -28,10 +29,12 @@ for name, h, c1, c2, cout in LAYERS:
     dw, db = torch.empty((3, 3, c1 + c2, cout), device=dev), torch.empty((cout,), device=dev)
     res = {}
     for tag in ('new', 'old', 'new', 'old'):
+        # 'old' = the comparison arm: NIMG_WGRAD3_ALT='NAME=VALUE' sets that variable for it (default: the tile-at-a-time kernel)
+        alt = os.environ.get('NIMG_WGRAD3_ALT', 'NIMG_NO_WGRAD3_ALLTAPS=1').split('=')
         if tag == 'old':
-            os.environ['NIMG_NO_WGRAD3_ALLTAPS'] = '1'
+            os.environ[alt[0]] = alt[1]
         else:
-            os.environ.pop('NIMG_NO_WGRAD3_ALLTAPS', None)
+            os.environ.pop(alt[0], None)
         fn = lambda: ops.conv2d_wgrad(x1, dz, 3, x2=x2, dw=dw, db=db)
         fn()
         torch.cuda.synchronize()
@@ -42,7 +45,7 @@ for name, h, c1, c2, cout in LAYERS:
         e1.record()
         torch.cuda.synchronize()
         res[tag] = (e0.elapsed_time(e1) / reps, float(dw.double().abs().sum()))
-    os.environ.pop('NIMG_NO_WGRAD3_ALLTAPS', None)
+    os.environ.pop(alt[0], None)
     fl = 2.0 * 9 * (c1 + c2) * cout * N * h * h
     mb = N * h * h * (c1 + c2 + cout) * 2 / 1e6
     print('{:12s} {:3d}+{:3d}->{:3d} @{:3d}^2: new {:6.1f} us ({:6.1f} TFLOP/s, {:5.2f} TB/s)   old {:6.1f} us   checksums {:.5e} / {:.5e}'.format(
