@@ -1446,14 +1446,18 @@ constexpr int B_ZS = 192;      // dz tile row stride in bytes (64 co bf16 = 128 
 // NCO = 32-channel output fragments per workgroup: 2 (a 64-wide dz tile) or 1 for layers with Cout <= 32 (UNet level 1), where
 // half of the 64-wide tile would be zeros: half the MFMAs, 4 instead of 5 operand reads per pixel row, and the unpadded 64-byte
 // tile rows already spread four consecutive pixels over the four bank quarters.
-template <int KS, int STRIDE, int NW, bool INB, bool DZB, int TH, bool UNP = false, int NCO = 2>
+// PAIR (3x3, stride 1, 8 x 8 images - the UNet's bottleneck level): the 8 x 16 tile would be half outside the image (every second
+// matrix instruction multiplying zeros).  A tile is then TWO images side by side: columns 0 - 7 = image 2 u, 8 - 15 = image 2 u + 1,
+// each with its own zero halo in the input tile ([10][2 x 10] pixels) - the lanes of the second K half read 2 pixels further on.
+template <int KS, int STRIDE, int NW, bool INB, bool DZB, int TH, bool UNP = false, int NCO = 2, bool PAIR = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const WgradParamsB p) {
     constexpr int TCO = 32 * NCO, ZS = NCO == 2 ? B_ZS : 64, ZI = 4 * NCO;      // dz tile: channels, row stride, 16-byte items per pixel
     static_assert(NCO == 1 || NCO == 2, "one or two output fragments");
     static_assert(!UNP || NCO == 2, "un-pooling dz: 64-wide tile");
     static_assert(!UNP || (DZB && STRIDE == 1), "un-pooling dz: bf16-stored pooled gradient, stride 1");
     constexpr int TAPS = KS * KS, NT = (TAPS + NW - 1) / NW, NTHR = NW * 64;
-    constexpr int THH = (TH - 1) * STRIDE + KS, TWH = (B_TW - 1) * STRIDE + KS;
+    static_assert(!PAIR || (KS == 3 && STRIDE == 1 && TH == 8 && INB && DZB && !UNP), "image pairs: the 3x3 layers over 8 x 8 bf16 images");
+    constexpr int THH = (TH - 1) * STRIDE + KS, TWH = PAIR ? 20 : (B_TW - 1) * STRIDE + KS;
     constexpr int NPIXH = THH * TWH, NPIX = TH * B_TW;
     static_assert(STRIDE == 1 || STRIDE == 2, "stride");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1478,13 +1482,13 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const Wgrad
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[t][ni][j] = 0.0f;
     const int tiles = p.tiles_y * p.tiles_x;
-    const int work_total = p.N * tiles;                 // < 2^31 (checked by the entry point)
+    const int work_total = PAIR ? (p.N + 1) / 2 : p.N * tiles;       // < 2^31 (checked by the entry point); PAIR: image pairs
     const int w_begin = split * p.work_per_split;
     const int w_end = min(work_total, w_begin + p.work_per_split);
     const bool do_bias = p.db_partial && ci0 == 0;
     float bacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // per-lane constant parts of the transpose-read addresses
-    const int a_lane = ((half * 8 + (g >> 2)) * STRIDE) * 64 + (sub * 16 + (g & 3) * 4) * 2;   // + pixel terms
+    const int a_lane = ((half * (PAIR ? 10 : 8) + (g >> 2)) * STRIDE) * 64 + (sub * 16 + (g & 3) * 4) * 2;   // + pixel terms
     const int z_lane = (half * 8 + (g >> 2)) * ZS + (sub * 16 + (g & 3) * 4) * 2;
     // async-stage split: tile t+1 travels HBM -> registers while tile t is multiplied
     constexpr int IP = (NPIXH * 4 + NTHR - 1) / NTHR, ZP = (NPIX * ZI) / NTHR;
@@ -1500,9 +1504,16 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const Wgrad
             const int item = tid + q * NTHR;
             const int pix = item >> 2, c = ci0 + (item & 3) * 8;
             int gy = iy_ + pix / TWH, gx = ix_ + pix % TWH;
+            int ni_ = n_;
+            if constexpr (PAIR) {                    // wk_ = image pair: halo columns 0 - 9 image 2 wk_, 10 - 19 image 2 wk_ + 1
+                const int hx = pix % TWH;
+                ni_ = 2 * wk_ + (hx >= 10 ? 1 : 0);
+                gx = (hx >= 10 ? hx - 10 : hx) - 1;
+                gy = pix / TWH - 1;
+            }
             preI[q][0] = preI[q][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (item < NPIXH * 4 && c < Cin && map_coord(gy, p.H, p.pad_mode) && map_coord(gx, p.W, p.pad_mode)) {
-                const long pixoff = ((long)n_ * p.H + gy) * p.W + gx;
+            if (item < NPIXH * 4 && c < Cin && (!PAIR || ni_ < p.N) && map_coord(gy, p.H, p.pad_mode) && map_coord(gx, p.W, p.pad_mode)) {
+                const long pixoff = ((long)ni_ * p.H + gy) * p.W + gx;
                 if constexpr (INB) {                 // C1 % 8 == 0, C2 % 8 == 0 (entry point): the 8 channels are one 16-byte load
                     const __bf16* src = c < p.C1 ? reinterpret_cast<const __bf16*>(p.in1) + pixoff * p.C1 + c
                                                  : reinterpret_cast<const __bf16*>(p.in2) + pixoff * p.C2 + (c - p.C1);
@@ -1518,12 +1529,17 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const Wgrad
         for (int q = 0; q < ZP; ++q) {
             const int item = tid + q * NTHR;
             const int pix = item / ZI, c = co0 + (item % ZI) * 8;
-            const int oy = ty_ + pix / B_TW, ox = tx_ + pix % B_TW;
+            int oy = ty_ + pix / B_TW, ox = tx_ + pix % B_TW, nz_ = n_;
+            if constexpr (PAIR) {
+                nz_ = 2 * wk_ + ((pix % B_TW) >> 3);
+                ox = pix & 7;
+                oy = pix / B_TW;
+            }
             preZ[q][0] = preZ[q][1] = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (UNP) preZK[q] = make_uint2(0xffffffffu, 0xffffffffu);
-            if (oy < p.Hout && ox < p.Wout && c < p.Cout) {
+            if (oy < p.Hout && ox < p.Wout && c < p.Cout && (!PAIR || nz_ < p.N)) {
                 const long zo = UNP ? (((long)n_ * (p.Hout >> 1) + (oy >> 1)) * (p.Wout >> 1) + (ox >> 1)) * p.Cout + c
-                                    : (((long)n_ * p.Hout + oy) * p.Wout + ox) * p.Cout + c;
+                                    : (((long)nz_ * p.Hout + oy) * p.Wout + ox) * p.Cout + c;
                 if constexpr (UNP) preZK[q] = *reinterpret_cast<const uint2*>(p.dz_idx + zo);
                 if constexpr (DZB) {                 // Cout % 8 == 0 (entry point)
                     preZ[q][0] = *reinterpret_cast<const float4*>(reinterpret_cast<const __bf16*>(p.dz) + zo);
@@ -1969,6 +1985,27 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
             NIMG_CHECK_LAUNCH();
             return NIMG_OK;
         }
+    }
+    // 8 x 8 images (the UNet's bottleneck level): tiles of two images side by side instead of 8 x 16 tiles that are half empty
+    static const bool no_pair = getenv("NIMG_NO_WGRAD_PAIR8") != nullptr;
+    if (!no_pair && !dz_idx && ks == 3 && stride == 1 && h == 8 && wd == 8 && hout == 8 && wout == 8 && pad_t == 1 && pad_l == 1 &&
+        pad_mode == 0 && flags == (NIMG_BF16_IN | NIMG_BF16_DZ) && n >= 2) {
+        const long pairs = (n + 1) / 2;
+        long sp = p.splits < pairs ? p.splits : pairs;
+        const long wps = (pairs + sp - 1) / sp;
+        sp = (pairs + wps - 1) / wps;
+        p.splits = (int)sp; p.work_per_split = (int)wps; p.tiles_y = p.tiles_x = 1;
+        if (db) p.db_partial = p.partial + (size_t)p.splits * count;
+        const long pblocks = (long)cdiv(cin, B_CI) * cdiv(cout, B_CO) * p.splits;
+        constexpr size_t lds = (size_t)10 * 20 * 64 + (size_t)B_TH * B_TW * B_ZS;
+        auto k = conv_wgrad_bf16_kernel<3, 1, 4, true, true, B_TH, false, 2, true>;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, dim3((unsigned)pblocks), dim3(256), lds, s, p);
+        NIMG_CHECK_LAUNCH();
+        launch_reduce2((const float*)workspace, dw, count, p.splits, db ? (const float*)p.db_partial : nullptr, db, (long)cout,
+                       p.splits, accumulate, s);
+        NIMG_CHECK_LAUNCH();
+        return NIMG_OK;
     }
     if (db) p.db_partial = p.partial + (size_t)p.splits * count;
     const long blocks = (long)cdiv(cin, B_CI) * cdiv(cout, B_CO) * p.splits;
