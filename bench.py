@@ -248,6 +248,57 @@ def _event_time(run, reps):
     return e0.elapsed_time(e1) / reps
 
 
+def _power_under(run, ms_per_launch, seconds=0.6):
+    """Socket power and shader clock WHILE the dominant kernel runs back to back for ~`seconds` (tools/ring_power.Sampler: amdsmi
+    gpu_metrics at ~5 ms cadence, sysfs hwmon as a fall-back): the roofline fraction of a bf16 MFMA kernel on this part is bounded
+    by the board's power limit, not by pipe occupancy (profiles/r05_ring_power.txt) - the line says how close to the cap this run
+    was.  None where no power interface is readable."""
+    try:
+        from ring_power import Sampler
+        smp = Sampler()
+        if smp.smi is None and not smp.hwmon:
+            return None
+        n = max(200, int(seconds * 1e3 / max(ms_per_launch, 1e-3)))
+        torch.cuda.synchronize()
+        smp.start()
+        t0 = time.perf_counter()
+        ev = None
+        for i in range(n):
+            run()
+            if (i + 1) % 400 == 0:                       # bound the launch queue (allocator), never drain it
+                if ev is not None:
+                    ev.synchronize()
+                ev = torch.cuda.Event()
+                ev.record()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        smp.stop_flag = True
+        smp.join()
+        load = [x for x in smp.samples if t0 + 0.15 <= x['t'] <= t1 - 0.02]
+        pw = [x['current_socket_power'] for x in load if isinstance(x.get('current_socket_power'), (int, float)) and 0 < x['current_socket_power'] < 5000]
+        if not pw:
+            pw = [x[k] * 1e-6 for x in load for k in ('power1_input', 'power1_average') if isinstance(x.get(k), int) and x[k] > 0]
+        ck = []
+        for x in load:
+            c = [v for v in (x.get('current_gfxclks') or []) if isinstance(v, (int, float)) and 0 < v < 10000]
+            if c:
+                ck.append(sum(c) / len(c))
+        cap = None
+        pc = smp.info.get('power_cap', {})
+        for k in ('power_cap', 'default_power_cap', 'max_power_cap'):
+            if isinstance(pc.get(k), int) and pc[k] > 0:
+                cap = pc[k] / (1e6 if pc[k] > 100000 else 1.0)
+                break
+        out = {'launches': n, 'samples': len(load), 'ms_per_launch_sustained': 1e3 * (t1 - t0) / n,
+               'socket_power_w_mean': sum(pw) / len(pw) if pw else None, 'power_cap_w': cap,
+               'gfx_clock_mhz_mean': sum(ck) / len(ck) if ck else None, 'gfx_clock_mhz_max': 2400}
+        if pw and cap:
+            out['frac_of_power_cap'] = out['socket_power_w_mean'] / cap
+        return out
+    except Exception as e:                                 # noqa: a measurement extra must never take the bench line down
+        return {'error': repr(e)[:200]}
+
+
 def _pmc_traffic(fname, key, n, stamped=False):
     """HBM bytes per launch from a committed counter profile (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes, see
     profiles/README.md), scaled to n images.  stamped: the file carries the hash of the kernel sources it was taken on
@@ -270,8 +321,8 @@ def _pmc_traffic(fname, key, n, stamped=False):
         return None, {'file': 'profiles/' + fname, 'status': 'missing'}
 
 
-PMC_RING = 'r04_pmc_ring_kernel.json'            # tools/pmc_ring.sh on the final build of the round
-PMC_STEP = 'r04_pmc_step_total.json'             # tools/pmc_step_total.py, same
+PMC_RING = 'r05_pmc_ring_kernel.json'            # tools/pmc_ring.sh on the final build of the round
+PMC_STEP = 'r05_pmc_step_total.json'             # tools/pmc_step_total.py, same
 
 
 def time_conv5_dominant(dev, n, reps=20):
@@ -290,13 +341,15 @@ def time_conv5_dominant(dev, n, reps=20):
     run = (lambda: ops.conv2d_pool(x, w, b, out_bf16=True)) if stored_bf16 else \
         (lambda: ops.conv2d(x, w, b, act='leaky_relu', out=out))
     ms = _event_time(run, reps)
+    power = _power_under(run, ms) if stored_bf16 else None
     flops = 2.0 * 25 * 64 * 128 * 64 * 64 * n
     kname = 'conv_fwd_kernel<5,1,16,16,1,64,8>' if ops.COMPUTE == 'f32' else (
         'conv5_ring_kernel<128>' if stored_bf16 else 'conv_fwd_bf16_kernel<5,1,16,16,1,64>')
     traffic, tsrc = _pmc_traffic(PMC_RING, 'bf16_stored_input_pooled', n, stamped=True) if stored_bf16 else \
         _pmc_traffic('r01_pmc_dominant_kernel.json', ops.COMPUTE, n)
     return {'kernel': kname + ' (FAN conv3 fwd{}, {}x64x64x64->128)'.format(' + LReLU + pool' if stored_bf16 else '', n),
-            'traffic': traffic, 'traffic_source': tsrc, 'flops_per_launch': flops, 'ms_per_launch': ms, 'tflops': flops / (ms * 1e-3) / 1e12}
+            'traffic': traffic, 'traffic_source': tsrc, 'flops_per_launch': flops, 'ms_per_launch': ms, 'tflops': flops / (ms * 1e-3) / 1e12,
+            'power': power}
 
 
 def time_conv3_dominant(dev, n, reps=20):
@@ -764,7 +817,7 @@ def main():
             'roofline': {'bound': 'mfma', 'achieved': dom['tflops'], 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': dom['tflops'] / peak, 'traffic': dom['traffic'], 'kernel': dom['kernel'],
                          'ms_per_launch': dom['ms_per_launch'], 'flops_per_launch': dom['flops_per_launch'],
-                         'traffic_source': dom.get('traffic_source')},
+                         'traffic_source': dom.get('traffic_source'), 'power': dom.get('power')},
         }
         if world == 1 and args.dtype == 'bf16' and not args.no_parity_mode and wl.key in ('c4', 'c5'):
             _ops.set_compute('f32')                           # same step, exact float32 MFMA (the parity-test mode), eager
