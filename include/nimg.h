@@ -356,6 +356,19 @@ int nimg_conv2d_fwd_bf16_unpool(const void* in_pooled, const unsigned char* in_i
 int nimg_conv2d_wgrad_bf16_unpool(const void* in, int cin, const void* g, const unsigned char* idx, int cout, float* dw, float* db,
                                   int n, int h, int w_, int ks, int accumulate, void* workspace, size_t workspace_bytes,
                                   void* stream);
+/* DEFERRED slab reduction (round 5): nimg_conv2d_wgrad_bf16_deferred = nimg_conv2d_wgrad_bf16_ex (idx == null) or
+ * nimg_conv2d_wgrad_bf16_unpool (idx != null) with accumulate = 0, except that the reduction of the split-K partial sums is not
+ * launched but described in *entry (nimg_reduce_entry_bytes() bytes of HOST memory); the workspace must stay untouched until
+ * nimg_reduce_slabs_batch(entries, n, stream) has been issued on the same stream.  One batch launch runs the reductions of up to
+ * nimg_reduce_batch_max() weight gradients (the entries travel as kernel arguments: nothing is copied to the device, the launch
+ * can be captured); every sum is bit-identical to the per-layer reduction of the non-deferred entry points. */
+int nimg_conv2d_wgrad_bf16_deferred(const void* in1, int c1, const void* in2, int c2, const void* dz, const unsigned char* idx,
+                                    int cout, float* dw, float* db, int n, int h, int wd, int ks, int stride, int pad_t, int pad_l,
+                                    int pad_mode, int hout, int wout, void* workspace, size_t workspace_bytes, int flags,
+                                    void* entry, void* stream);
+size_t nimg_reduce_entry_bytes(void);
+int nimg_reduce_batch_max(void);
+int nimg_reduce_slabs_batch(const void* entries, int n, void* stream);
 
 /* The same 5x5, 3 -> 3 convolution with ZERO padding and bf16 matrix-core operands (float32 accumulation, float32 output): the
  * main term of the ConstrainedConv2D input gradient in throughput mode (models/layers.py:56-57 backward; w = the flipped /

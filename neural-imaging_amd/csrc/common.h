@@ -326,6 +326,40 @@ static inline void launch_reduce2(const float* p1, float* d1, long n1, int split
                        accumulate);
 }
 
+// ---- batched form: the slab reductions of MANY weight gradients in one launch (~30 launches of 4 - 19 us per
+// training step, most of them latency, not bytes).  A weight-gradient entry point called in DEFERRED mode launches its partial-sum
+// kernel only and describes the reduction it still owes in a ReduceEntry (host memory); nimg_reduce_slabs_batch() later runs up to
+// REDUCE_BATCH_MAX of them as one grid - the entries travel BY VALUE as kernel arguments (no device table, nothing to copy,
+// capturable in a HIP graph), every workgroup finds its entry in a prefix table and runs reduce_slabs() exactly as
+// reduce_slabs2_kernel would: the sums are bit-identical to the per-layer launches.
+struct ReduceEntry {
+    const float* p1; float* d1; long n1;          // dw slabs -> dw
+    const float* p2; float* d2; long n2;          // db partials -> db (or null)
+    int splits1, splits2, accumulate, blocks1;    // blocks1 = reduce_grid(n1) (filled by the producer)
+};
+static_assert(sizeof(ReduceEntry) == 64, "ReduceEntry is part of the C ABI (nimg_reduce_entry_bytes)");
+constexpr int REDUCE_BATCH_MAX = 40;
+struct ReduceBatch {
+    ReduceEntry e[REDUCE_BATCH_MAX];
+    int first_block[REDUCE_BATCH_MAX + 1];
+    int n;
+};
+static __global__ __launch_bounds__(256) void reduce_slabs_batch_kernel(const ReduceBatch b) {
+    int k = 0;
+    while (k + 1 < b.n && (int)blockIdx.x >= b.first_block[k + 1]) ++k;       // <= 40 scalar compares
+    const ReduceEntry& e = b.e[k];
+    const int blk = (int)blockIdx.x - b.first_block[k], total = b.first_block[k + 1] - b.first_block[k];
+    if (blk < e.blocks1) reduce_slabs(e.p1, e.d1, e.n1, e.splits1, e.accumulate, blk, e.blocks1);
+    else reduce_slabs(e.p2, e.d2, e.n2, e.splits2, e.accumulate, blk - e.blocks1, total - e.blocks1);
+}
+static inline void fill_reduce_entry(ReduceEntry* e, const float* p1, float* d1, long n1, int splits1, const float* p2, float* d2,
+                                     long n2, int splits2, int accumulate) {
+    e->p1 = p1; e->d1 = d1; e->n1 = n1; e->splits1 = splits1;
+    const bool two = p2 && d2;
+    e->p2 = two ? p2 : nullptr; e->d2 = two ? d2 : nullptr; e->n2 = two ? n2 : 0; e->splits2 = two ? splits2 : 0;
+    e->accumulate = accumulate; e->blocks1 = reduce_grid(n1);
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace nimg

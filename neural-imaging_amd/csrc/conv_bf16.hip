@@ -1881,6 +1881,15 @@ size_t nimg_conv2d_wgrad_bf16_workspace_bytes(int cin, int cout, int ks_h, int k
     return m > tiny ? m : tiny;
 }
 
+// deferred mode (nimg_conv2d_wgrad_bf16_deferred): the partial-sum kernel is launched, the reduction it owes is described in
+// *g_defer instead of being launched (common.h ReduceEntry); one thread-local pointer, set around the call
+static thread_local nimg::ReduceEntry* g_defer = nullptr;
+static inline void finish_reduce2(const float* p1, float* d1, long n1, int splits1, const float* p2, float* d2, long n2,
+                                  int splits2, int accumulate, hipStream_t s) {
+    if (g_defer) nimg::fill_reduce_entry(g_defer, p1, d1, n1, splits1, p2, d2, n2, splits2, accumulate);
+    else launch_reduce2(p1, d1, n1, splits1, p2, d2, n2, splits2, accumulate, s);
+}
+
 static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, const float* dz,
                            const unsigned char* dz_idx, int cout, float* dw, float* db, int n, int h, int wd, int ks,
                            int stride, int pad_t, int pad_l, int pad_mode, int hout, int wout, int accumulate,
@@ -1940,7 +1949,7 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
         else { if (ni == 1) NIMG_WGPB(3, 4, 1); else NIMG_WGPB(3, 4, 2); }
 #undef NIMG_WGPB
         NIMG_CHECK_LAUNCH();
-        launch_reduce2((const float*)workspace, dw, cnt, slabs_per_wg * q.splits, db ? (const float*)q.db_partial : nullptr, db,
+        finish_reduce2((const float*)workspace, dw, cnt, slabs_per_wg * q.splits, db ? (const float*)q.db_partial : nullptr, db,
                        (long)cout, q.splits, accumulate, s_);
         NIMG_CHECK_LAUNCH();
         return NIMG_OK;
@@ -1968,7 +1977,7 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
         const int slabs = nimg_internal_wgrad5_alltaps(in1, cin, dz, dz_idx, cout, (float*)workspace, dbp, n, h, wd, max_slabs, s);
         if (slabs < 0) return NIMG_ERR_LAUNCH;
         if (slabs > 0) {
-            launch_reduce2((const float*)workspace, dw, count, slabs, dbp, db, (long)cout, slabs, accumulate, s);
+            finish_reduce2((const float*)workspace, dw, count, slabs, dbp, db, (long)cout, slabs, accumulate, s);
             NIMG_CHECK_LAUNCH();
             return NIMG_OK;
         }
@@ -1981,7 +1990,7 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
         const int slabs = nimg_internal_wgrad3_alltaps(in1, c1, in2, c2, dz, cout, (float*)workspace, dbp, n, h, wd, max_slabs, s);
         if (slabs < 0) return NIMG_ERR_LAUNCH;
         if (slabs > 0) {
-            launch_reduce2((const float*)workspace, dw, count, slabs, dbp, db, (long)cout, slabs, accumulate, s);
+            finish_reduce2((const float*)workspace, dw, count, slabs, dbp, db, (long)cout, slabs, accumulate, s);
             NIMG_CHECK_LAUNCH();
             return NIMG_OK;
         }
@@ -2002,7 +2011,7 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, dim3((unsigned)pblocks), dim3(256), lds, s, p);
         NIMG_CHECK_LAUNCH();
-        launch_reduce2((const float*)workspace, dw, count, p.splits, db ? (const float*)p.db_partial : nullptr, db, (long)cout,
+        finish_reduce2((const float*)workspace, dw, count, p.splits, db ? (const float*)p.db_partial : nullptr, db, (long)cout,
                        p.splits, accumulate, s);
         NIMG_CHECK_LAUNCH();
         return NIMG_OK;
@@ -2049,7 +2058,7 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
 #undef NIMG_WGB
 #undef NIMG_WGB1
     NIMG_CHECK_LAUNCH();
-    launch_reduce2((const float*)workspace, dw, count, p.splits, db ? (const float*)p.db_partial : nullptr, db, (long)cout,
+    finish_reduce2((const float*)workspace, dw, count, p.splits, db ? (const float*)p.db_partial : nullptr, db, (long)cout,
                    p.splits, accumulate, s);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
@@ -2079,6 +2088,50 @@ int nimg_conv2d_wgrad_bf16_unpool(const void* in, int cin, const void* g, const 
     if (!idx || ks != 5 || (h & 1) || (wd & 1)) return NIMG_ERR_ARG;
     return wgrad_bf16_impl((const float*)in, cin, nullptr, 0, (const float*)g, idx, cout, dw, db, n, h, wd, ks, 1, 2, 2, 0, h, wd,
                            accumulate, workspace, workspace_bytes, NIMG_BF16_IN | NIMG_BF16_DZ, stream);
+}
+
+/* DEFERRED forms of nimg_conv2d_wgrad_bf16_ex / _unpool (idx != null): the split-K partial sums are written to `workspace`, the
+ * slab reduction is NOT launched - it is described in *entry (nimg_reduce_entry_bytes() bytes of host memory) for a later
+ * nimg_reduce_slabs_batch() on the same stream.  The workspace must stay untouched until then.  accumulate must be 0. */
+int nimg_conv2d_wgrad_bf16_deferred(const void* in1, int c1, const void* in2, int c2, const void* dz, const unsigned char* idx,
+                                    int cout, float* dw, float* db, int n, int h, int wd, int ks, int stride, int pad_t, int pad_l,
+                                    int pad_mode, int hout, int wout, void* workspace, size_t workspace_bytes, int flags,
+                                    void* entry, void* stream) {
+    if (!entry) return NIMG_ERR_ARG;
+    nimg::ReduceEntry* e = reinterpret_cast<nimg::ReduceEntry*>(entry);
+    nimg::fill_reduce_entry(e, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, 0, 0);          // n1 == 0: nothing owed (paths that reduce themselves)
+    e->blocks1 = 0;
+    g_defer = e;
+    const int rc = wgrad_bf16_impl((const float*)in1, c1, (const float*)in2, c2, (const float*)dz, idx, cout, dw, db, n, h, wd, ks,
+                                   stride, pad_t, pad_l, pad_mode, hout, wout, 0, workspace, workspace_bytes, flags, stream);
+    g_defer = nullptr;
+    return rc;
+}
+
+size_t nimg_reduce_entry_bytes(void) { return sizeof(nimg::ReduceEntry); }
+int nimg_reduce_batch_max(void) { return nimg::REDUCE_BATCH_MAX; }
+
+/* The reductions owed by up to nimg_reduce_batch_max() deferred weight gradients, one launch; entries = n x
+ * nimg_reduce_entry_bytes() bytes of HOST memory as the deferred calls filled them (entries that owe nothing are skipped). */
+int nimg_reduce_slabs_batch(const void* entries, int n, void* stream) {
+    if (n == 0) return NIMG_OK;
+    if (!entries || n < 0 || n > nimg::REDUCE_BATCH_MAX) return NIMG_ERR_ARG;
+    const nimg::ReduceEntry* src = reinterpret_cast<const nimg::ReduceEntry*>(entries);
+    nimg::ReduceBatch b;
+    b.n = 0;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        if (src[i].n1 <= 0 || !src[i].p1 || !src[i].d1) continue;
+        b.e[b.n] = src[i];
+        b.first_block[b.n] = blocks;
+        blocks += src[i].blocks1 + ((src[i].p2 && src[i].d2) ? nimg::reduce_grid(src[i].n2) : 0);
+        ++b.n;
+    }
+    b.first_block[b.n] = blocks;
+    if (b.n == 0) return NIMG_OK;
+    hipLaunchKernelGGL(nimg::reduce_slabs_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, b);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
 }
 
 /* Weight (+bias) gradient of a fused conv+pool layer (nimg_conv2d_pool_fwd_bf16) with few input channels (cin 3|4):

@@ -187,6 +187,26 @@ class Workspace(object):
             self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
         return pin(self.buf)
 
+    # deferred slab reductions (DEFER_REDUCE): every pending weight gradient keeps its OWN piece of an arena until the batched
+    # reduction has been issued; the arena grows by replacement (the pending pieces hold the old one alive) and is re-used from
+    # the start after each flush
+    arena, used, pending = None, 0, ()
+
+    def claim(self, nbytes, device):
+        nbytes = (max(int(nbytes), 256) + 255) // 256 * 256
+        if self.arena is None or self.arena.device != device or self.used + nbytes > self.arena.numel():
+            size = max(2 * nbytes, 64 << 20, 0 if self.arena is None else 2 * self.arena.numel())
+            if self.arena is not None:
+                self.pending = self.pending + (self.arena,)
+            self.arena, self.used = torch.empty(size, dtype=torch.uint8, device=device), 0
+        piece = self.arena[self.used:self.used + nbytes]
+        self.used += nbytes
+        pin(self.arena)
+        return piece
+
+    def release(self):
+        self.used, self.pending = 0, ()
+
 
 _ws = Workspace()
 
@@ -274,11 +294,52 @@ class side_stream(object):
         return self.ctx.__exit__(*exc) if self.ctx is not None else False
 
 
+# The split-K slab reductions of the weight gradients issued with side=True are DEFERRED: the partial-sum kernels run where they
+# were issued, the reductions they owe are collected per side stream and run as ONE batched launch when somebody joins the side
+# streams (or the batch is full) - ~30 launches of 4 - 19 us per training step become 2 - 4, with the same sums to the bit
+# (csrc/common.h ReduceEntry).  OPT-IN (NIMG_DEFER_REDUCE=1), because it LOSES: UNet backward 1690 -> 1744 us, C4 step 8.06 -> 8.21 ms
+# (profiles/r05_deferred_reduce_ab.txt).  A reduction issued right behind its producer finds the ~38 MB of slabs in the 256 MB
+# Infinity Cache and overlaps with the next layers; the batched one reads ~1 GB of slabs from HBM at the tail of the side stream,
+# on the step's critical path.  The launches were never the cost - VERDICT r04 item 4 is answered by measurement, not by count.
+DEFER_REDUCE = _os.environ.get('NIMG_DEFER_REDUCE') is not None
+_DEFER = {}
+
+
+def _defer_state(k):
+    st = _DEFER.get(k)
+    if st is None:
+        import ctypes
+        lib = _lib.load()
+        nb, cap = int(lib.nimg_reduce_entry_bytes()), int(lib.nimg_reduce_batch_max())
+        st = _DEFER[k] = {'buf': (ctypes.c_char * (nb * cap))(), 'n': 0, 'nb': nb, 'cap': cap}
+    return st
+
+
+def _flush_deferred(k, on_its_stream=True):
+    """Issue the batched reduction owed on side stream k (on that stream) and hand its scratch arena back."""
+    st = _DEFER.get(k)
+    if st is None or st['n'] == 0:
+        return
+    side = _SIDE['streams'][k]
+    if on_its_stream and side is not None and torch.cuda.current_stream(side.device) != side:
+        prev = torch.cuda.current_stream(side.device)
+        torch.cuda.set_stream(side)
+        try:
+            _lib.call('nimg_reduce_slabs_batch', st['buf'], st['n'], _stream())
+        finally:
+            torch.cuda.set_stream(prev)
+    else:
+        _lib.call('nimg_reduce_slabs_batch', st['buf'], st['n'], _stream())
+    st['n'] = 0
+    _SIDE['ws'][k].release()
+
+
 def join_side_stream():
     """Make the current stream wait for the parameter-gradient kernels launched on the side streams."""
     for k in sorted(_SIDE['dirty']):
         st = _SIDE['streams'][k]
         if st is not None:
+            _flush_deferred(k)
             torch.cuda.current_stream(st.device).wait_stream(st)
     _SIDE['dirty'].clear()
 
@@ -554,13 +615,14 @@ def conv2d_dgrad(dz, w, in_hw, stride=1, padding='SAME', act_mask=None, out=None
 
 
 def conv2d_wgrad(x, dz, ks, x2=None, stride=1, padding='SAME', pad_mode=0, pads=None, dw=None, accumulate=False,
-                 db=None, side=False):
+                 db=None, side=False, _defer_k=None):
     """dw (k,k,C1+C2,Cout) = sum over pixels of x (x) dz;  db (optional, Cout) = fused bias gradient.
     side=True: launch on the side stream (see _on_side_stream); dw / db must then be persistent buffers."""
     if side and _SIDE['enabled'] and dw is not None:
-        with _on_side_stream(x, dz, x2, key=dw.data_ptr()):
+        ctx = _on_side_stream(x, dz, x2, key=dw.data_ptr())
+        with ctx:
             return conv2d_wgrad(x, dz, ks, x2=x2, stride=stride, padding=padding, pad_mode=pad_mode, pads=pads, dw=dw,
-                                accumulate=accumulate, db=db, side=False)
+                                accumulate=accumulate, db=db, side=False, _defer_k=ctx.k)
     _f32(dw, db)
     _fb(x, x2, dz)
     if x2 is not None and x2.dtype != x.dtype:
@@ -583,8 +645,13 @@ def conv2d_wgrad(x, dz, ks, x2=None, stride=1, padding='SAME', pad_mode=0, pads=
     if COMPUTE == 'bf16' and ks <= 5 and (packed_ok or (c1 % 4 == 0 and c2 % 4 == 0 and cout % 4 == 0 and c1 + c2 >= 8 and
                                             (c2 == 0 or c1 % 8 == 0))):
         need = _lib.load().nimg_conv2d_wgrad_bf16_workspace_bytes(c1 + c2, cout, ks, ks, n, ho, wo)
-        ws = _ws_current(x.device).get(need, x.device)
         flags = (BF16_IN if _is_bf16(x) else 0) | (BF16_DZ if _is_bf16(dz) else 0)
+        if _defer_k is not None and DEFER_REDUCE and not accumulate:
+            _wgrad_deferred(_defer_k, x, c1, x2, c2, dz, None, cout, dw, db, n, h, wd, ks, stride, pt, pl, pad_mode, ho, wo, need, flags)
+            return dw
+        if _defer_k is not None:
+            _flush_deferred(_defer_k, on_its_stream=False)      # an accumulating launch follows the pending ones of its stream
+        ws = _ws_current(x.device).get(need, x.device)
         _lib.call('nimg_conv2d_wgrad_bf16_ex', _p(x), c1, _p(x2), c2, _p(dz), cout, _p(dw), _p(db), n, h, wd, ks, stride,
                   pt, pl, pad_mode, ho, wo, 1 if accumulate else 0, _p(ws), ws.numel(), flags, _stream())
         return dw
@@ -595,6 +662,19 @@ def conv2d_wgrad(x, dz, ks, x2=None, stride=1, padding='SAME', pad_mode=0, pads=
     _lib.call('nimg_conv2d_wgrad', _p(x), c1, _p(x2), c2, _p(dz), cout, _p(dw), _p(db), n, h, wd, ks, stride, pt, pl,
               pad_mode, ho, wo, 1 if accumulate else 0, _p(ws), ws.numel(), _stream())
     return dw
+
+
+def _wgrad_deferred(k, x, c1, x2, c2, dz, idx, cout, dw, db, n, h, wd, ks, stride, pt, pl, pad_mode, ho, wo, need, flags):
+    """One weight gradient whose slab reduction joins side stream k's pending batch (the caller is ON that stream)."""
+    import ctypes
+    st = _defer_state(k)
+    if st['n'] == st['cap']:
+        _flush_deferred(k, on_its_stream=False)
+    ws = _SIDE['ws'][k].claim(need, x.device)
+    entry = ctypes.byref(st['buf'], st['n'] * st['nb'])
+    _lib.call('nimg_conv2d_wgrad_bf16_deferred', _p(x), c1, _p(x2), c2, _p(dz), _p(idx), cout, _p(dw), _p(db), n, h, wd, ks, stride,
+              pt, pl, pad_mode, ho, wo, _p(ws), ws.numel(), flags, entry, _stream())
+    st['n'] += 1
 
 
 def bias_grad(dz, db=None, accumulate=False, side=False):
@@ -825,17 +905,21 @@ def conv2d_dgrad_unpool(g, idx, w, act_mask=None, out_bf16=False):
     return out
 
 
-def conv2d_wgrad_unpool(x, g, idx, ks, dw, db=None, side=False):
+def conv2d_wgrad_unpool(x, g, idx, ks, dw, db=None, side=False, _defer_k=None):
     """Weight / bias gradient of a fused 5x5 conv + pool layer from its bf16 input x and the pooled gradient + arg-max bytes."""
     if side and _SIDE['enabled'] and dw is not None:
-        with _on_side_stream(x, g, idx, key=dw.data_ptr()):
-            return conv2d_wgrad_unpool(x, g, idx, ks, dw, db=db, side=False)
+        ctx = _on_side_stream(x, g, idx, key=dw.data_ptr())
+        with ctx:
+            return conv2d_wgrad_unpool(x, g, idx, ks, dw, db=db, side=False, _defer_k=ctx.k)
     _f32(dw, db)
     _fb(x, g)
     _chk(idx)
     n, h, wd, cin = x.shape
     cout = g.shape[3]
     need = _lib.load().nimg_conv2d_wgrad_bf16_workspace_bytes(cin, cout, ks, ks, n, h, wd)
+    if _defer_k is not None and DEFER_REDUCE and ks == 5 and h % 2 == 0 and wd % 2 == 0:
+        _wgrad_deferred(_defer_k, x, cin, None, 0, g, idx, cout, dw, db, n, h, wd, ks, 1, 2, 2, 0, h, wd, need, BF16_IN | BF16_DZ)
+        return dw
     ws = _ws_current(x.device).get(need, x.device)
     _lib.call('nimg_conv2d_wgrad_bf16_unpool', _p(x), cin, _p(g), _p(idx), cout, _p(dw), _p(db), n, h, wd, ks, 0, _p(ws),
               ws.numel(), _stream())

@@ -971,6 +971,33 @@ def test_default_channel_parity_outside_flipped_blocks(dev):
         print('   {:22s} product vs float64 {:.2e}   float32 restatement vs float64 {:.2e}'.format(k, e_prod, e_ref32))
 
 
+def test_deferred_slab_reductions_give_the_same_gradients(dev, monkeypatch):
+    """ops.DEFER_REDUCE (opt-in): the split-K reductions of every side-stream weight gradient of a step in one batched launch per
+    side stream (nimg_conv2d_wgrad_bf16_deferred + nimg_reduce_slabs_batch) - the same sums to the bit as one reduction per layer."""
+    from neural_imaging_amd import ops
+    from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
+    dist = {'downsampling': 'none', 'compression': 'jpeg', 'compression_params': {'quality': 80, 'codec': 'soft'}}
+    rgb = natural_images(4, 64, 64, seed=77)
+    raw = bayer_from_rgb(rgb)
+    res = {}
+    try:
+        ops.set_compute('bf16')
+        for defer in (False, True):
+            monkeypatch.setattr(ops, 'DEFER_REDUCE', defer)
+            wf = ManipulationClassification('UNet', distribution=dist, trainable={'nip'}, raw_patch_size=32, device=dev)
+            for _ in range(2):
+                loss, _ = wf.training_step(raw, rgb, lambda_nip=0.1, learning_rate=1e-4)
+            torch.cuda.synchronize()
+            res[defer] = (float(loss), {k: v.copy() for k, v in grads_of(wf.nip).items()}, {k: v.copy() for k, v in grads_of(wf.fan).items()},
+                          wf.nip.state_dict(), wf.fan.state_dict())
+    finally:
+        ops.set_compute('f32')
+    assert res[False][0] == res[True][0]
+    for part in (1, 2, 3, 4):
+        for k in res[False][part]:
+            assert np.array_equal(res[False][part][k], res[True][part][k]), (part, k)
+
+
 def test_twitter_dcn_forward_backward(dev):
     """TwitterDCN-32C (models/compression.py:197-279): reconstruction, hard latent indices (exact), entropy, loss and
     every parameter gradient against the float64 oracle; then the reference's training_step contract."""
