@@ -515,6 +515,11 @@ int nimg_conv3_rows_bf16(const void* in1, int c1, const void* in2, int c2, const
  * weight image of the (3, 3, 32, 12) kernel, bias (12) or null, y (n, 2 h, 2 wd, 3) float32.  Bit-identical to
  * nimg_conv2d_fwd_bf16_ex + nimg_d2s_clip_fwd(scale 1, shift 0, clip).  wd == 128, h % 4 == 0. */
 int nimg_conv3_rows_d2s_bf16(const void* in, int c1, const void* wb, const float* bias, float* y, int n, int h, int wd, void* stream);
+/* The UNet's first layer in the same form: Conv2D(32, 3x3, SAME) + bias [+ LeakyReLU(alpha)] on the float32 4-plane RAW stack
+ * (models/pipelines.py:190): in (n, h, wd, 4) float32, w (3, 3, 4, 32) float32 HWIO, out (n, h, wd, 32) bf16.  Bit-identical to
+ * nimg_conv2d_fwd_smallc_bf16_ex.  wd == 128, h % 4 == 0. */
+int nimg_conv3_rows_c4_bf16(const float* in, const float* w, const float* bias, void* out, int n, int h, int wd, int act, float alpha,
+                            void* stream);
 
 /* Input gradient of a 3x3 SAME stride-1 convolution whose input was a 2x2 max-pool, written THROUGH that pool (the first
  * convolution of a UNet encoder level, models/pipelines.py:160-173 under the tape), all tensors bf16: dz (n,h,wd,c1) = the

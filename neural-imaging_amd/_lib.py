@@ -60,6 +60,7 @@ PROTOTYPES = {
     'nimg_reduce_entry_bytes': (c_size_t, []),
     'nimg_reduce_batch_max': (c_int, []),
     'nimg_reduce_slabs_batch': (c_int, [P, c_int, P]),
+    'nimg_conv3_rows_c4_bf16': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     'nimg_nan_flag': (c_int, [P, c_long, P, P]),
     'nimg_int_words': (c_int, [P, P, c_long, c_int, c_int, P]),
     'nimg_float_fill': (c_int, [P, c_long, c_float, P]),

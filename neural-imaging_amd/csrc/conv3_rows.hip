@@ -344,6 +344,138 @@ __global__ __launch_bounds__(64 * (NCW + 1)) __attribute__((amdgpu_waves_per_eu(
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The UNet's FIRST layer in the same streaming form (pipelines.py:190: Conv2D(32, 3x3) on the 4-plane RAW stack, float32 input):
+// K = (tap, ci) packed - 36 of 48 slots in three 16-wide k-steps, the order of conv_fwd_packed_bf16_kernel (k = 4 tap + ci, padded
+// slots meet zero weights), so the results are bit-identical to it.  A row slot is (W + 2) pixels x 16 B of float32; a lane builds
+// its operand from two 16-byte reads (the four channels of two taps) converted to bf16; the three weight fragments live in
+// registers.  The layer is 3 matrix instructions per 32 pixels - the kernel is its output stream (2 KB runs, 16 bytes per lane).
+struct RowsC4Params {
+    const float* in;              // (N, H, W, 4) float32
+    const float* w;               // (3, 3, 4, 32) float32 HWIO
+    const float* bias;            // 32 or null
+    void* out;                    // (N, H, W, 32) bf16
+    int N, H, units, bands, BH, act;
+    float alpha;
+};
+
+template <int W, int RB, int NCW>
+__global__ __launch_bounds__(64 * (NCW + 1)) __attribute__((amdgpu_waves_per_eu(1, 3))) void conv3_rows_c4_kernel(const RowsC4Params p) {
+    constexpr int NR = 2 * RB + 2, SLOT = (W + 2) * 16;
+    constexpr int MF = W / 32, RG = NCW / MF, RW = RB / RG, PIECES = W / 64, NTHR = 64 * (NCW + 1);
+    static_assert(W % 64 == 0 && NCW % MF == 0 && RB % RG == 0 && RW >= 1, "geometry");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sA = smem;
+    const unsigned sA_addr = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* elds = reinterpret_cast<float*>(smem + NR * SLOT + (wave % NCW) * (32 * (32 + EPI_PAD) * 4));
+    const int half = lane >> 5, co = lane & 31;
+    const int pf = wave % MF, rg = wave / MF;
+    const unsigned long a1 = (unsigned long)p.in;
+    const long row_bytes = (long)W * 16;
+    const r_u32x4 rs1 = {(unsigned)a1, (unsigned)(a1 >> 32) & 0xffffu, (unsigned)((long)p.N * p.H * row_bytes), 0x00020000u};
+    auto request = [&](int n, int y, int pos) {
+        const bool inside = (unsigned)y < (unsigned)p.H;
+        const int soff = __builtin_amdgcn_readfirstlane(inside ? (int)(((long)n * p.H + y) * row_bytes) : 0);
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(sA_addr + (unsigned)(pos * SLOT + 16)));
+        r_u32x4 rs = rs1;
+        rs[0] = (unsigned)__builtin_amdgcn_readfirstlane((int)rs[0]);
+        rs[1] = (unsigned)__builtin_amdgcn_readfirstlane((int)rs[1]);
+        rs[2] = (unsigned)__builtin_amdgcn_readfirstlane((int)rs[2]);
+        rs[3] = (unsigned)__builtin_amdgcn_readfirstlane((int)rs[3]);
+        static_for<PIECES>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            glds16(rs, dst + k * 1024, inside ? (unsigned)((k * 64 + lane) * 16) : 0x80000000u, soff);
+        });
+    };
+    const int steps = p.BH / RB;
+    auto request_unit = [&](int unit) {
+        const int n = unit / p.bands, y0 = (unit % p.bands) * p.BH;
+        for (int i = 0; i < RB + 2; ++i) request(n, y0 - 1 + i, i);
+    };
+    if (wave == NCW && (int)blockIdx.x < p.units) request_unit(blockIdx.x);
+    for (int item = tid; item < NR * 2; item += NTHR)          // the zero pixel left and right of every slot
+        *reinterpret_cast<uint4*>(sA + (item >> 1) * SLOT + ((item & 1) ? (W + 1) * 16 : 0)) = make_uint4(0u, 0u, 0u, 0u);
+    // weight fragments: lane (co, half) holds k = 16 s + 8 half .. + 7 of output channel co
+    bf16x8 wf[3];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = ks * 16 + half * 8 + j;
+            wf[ks][j] = (__bf16)(k < 36 ? p.w[k * 32 + co] : 0.f);
+        }
+    float bias8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias8[e] = p.bias ? p.bias[(lane & 3) * 8 + e] : 0.f;
+    __bf16* outp = reinterpret_cast<__bf16*>(p.out);
+    const bool loader = wave == NCW;
+    for (int unit = blockIdx.x; unit < p.units; unit += gridDim.x) {
+        const int n = unit / p.bands, y0 = (unit % p.bands) * p.BH;
+        __syncthreads();
+        if (loader) {
+            if (unit != (int)blockIdx.x) request_unit(unit);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        for (int s = 0; s < steps; ++s) {
+            if (loader) {
+                if (s + 1 < steps)
+                    for (int i = 0; i < RB; ++i) request(n, y0 + (s + 1) * RB + 1 + i, ((s + 1) * RB + 2 + i) % NR);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                continue;
+            }
+            const int base = (s * RB + rg * RW) % NR;
+            int slot_off[RW + 2];
+#pragma unroll
+            for (int i = 0; i < RW + 2; ++i) slot_off[i] = ((base + i) % NR) * SLOT;
+            const int yw = y0 + s * RB + rg * RW;
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                f32x16 acc;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {
+                    float f[8];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        // the lane's tap of this k-step: 4 ks + u (lanes 0 - 31) or 4 ks + 2 + u (lanes 32 - 63); a padded slot
+                        // (tap >= 9) meets zero weights, any finite data will do: tap 0.  Both candidates are compile-time taps -
+                        // a select between two addresses, no register array indexed at run time
+                        constexpr int NTAP = 9;
+                        const int t0 = ks * 4 + u < NTAP ? ks * 4 + u : 0, t1 = ks * 4 + 2 + u < NTAP ? ks * 4 + 2 + u : 0;
+                        const int o0 = slot_off[r + t0 / 3] + (t0 % 3) * 16, o1 = slot_off[r + t1 / 3] + (t1 % 3) * 16;
+                        const float4 v = *reinterpret_cast<const float4*>(sA + (half ? o1 : o0) + (pf * 32 + co) * 16);
+                        f[4 * u] = v.x; f[4 * u + 1] = v.y; f[4 * u + 2] = v.z; f[4 * u + 3] = v.w;
+                    }
+                    bf16x8 a;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a[e] = (__bf16)f[e];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wf[ks], acc, 0, 0, 0);
+                }
+                const long rowbase = (((long)n * p.H + yw + r) * W + pf * 32) * 32;
+                epilogue_via_lds8<1>(reinterpret_cast<const f32x16(&)[1]>(acc), elds, lane, [&](int row, int c, float4 lo, float4 hi) {
+                    float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += bias8[e];
+                    if (p.act == 1) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] = lrelu(f[e], p.alpha);
+                    }
+                    bf16x8 ov;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ov[e] = (__bf16)f[e];
+                    *reinterpret_cast<bf16x8*>(outp + rowbase + row * 32 + c) = ov;
+                });
+            }
+            __syncthreads();
+        }
+    }
+}
+
 template <int NP, int W, int RB, int PFD, int NCW, int NO = 1>
 int launch_rows(const RowsParams& p, hipStream_t s) {
     using G = RowsGeom<NP, W, RB, PFD, NCW, NO>;
@@ -399,6 +531,27 @@ int nimg_conv3_rows_bf16(const void* in1, int c1, const void* in2, int c2, const
         return launch_rows<1, 128, 4, 1, 8>(p, s);
     }
     return launch_rows<2, 128, 2, 1, 4>(p, s);            // (a 64-channel slot is 16.6 KB: eight scratch areas do not fit beside the ring)
+}
+
+/* see include/nimg.h */
+int nimg_conv3_rows_c4_bf16(const float* in, const float* w, const float* bias, void* out, int n, int h, int wd, int act, float alpha,
+                            void* stream) {
+    if (n == 0) return NIMG_OK;
+    if (!in || !w || !out || n < 0 || wd != 128 || h < 4 || (h & 3)) return NIMG_ERR_ARG;
+    if ((long)n * h * wd * 16 >= (1l << 31) - 65536) return NIMG_ERR_ARG;
+    RowsC4Params p;
+    p.in = in; p.w = w; p.bias = bias; p.out = out; p.N = n; p.H = h; p.act = act ? 1 : 0; p.alpha = alpha;
+    int bh = 32;
+    while (bh > 4 && (h % bh != 0 || (long)n * (h / bh) < 256)) bh >>= 1;
+    if (h % bh != 0) return NIMG_ERR_ARG;
+    p.BH = bh; p.bands = h / bh; p.units = n * p.bands;
+    constexpr int RB = 4, NCW = 8;
+    constexpr size_t lds = (size_t)(2 * RB + 2) * (128 + 2) * 16 + (size_t)NCW * 32 * (32 + nimg::EPI_PAD) * 4;
+    auto k = conv3_rows_c4_kernel<128, RB, NCW>;
+    const int grid = p.units < 512 ? p.units : 512;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * (NCW + 1)), lds, (hipStream_t)stream, p);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
 }
 
 /* see include/nimg.h */

@@ -507,6 +507,11 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
             c1 in (3, 4) and ks in (3, 5) and stride == 1 and cout >= 8 and (ho, wo) == (h, wd) and \
             (pt, pl) == ((ks - 1) // 2, (ks - 1) // 2):
         _f32(x)
+        if ROWS_CONV and c1 == 4 and ks == 3 and cout == 32 and wd == 128 and h % 4 == 0 and h >= 4 and pad_mode == 0 and \
+                _is_bf16(out) and act in (None, 'leaky_relu') and n * h * wd * 16 < (1 << 31) - 65536:
+            # the UNet's first layer at 128-pixel rows: row-streaming form (csrc/conv3_rows.hip), same bits
+            _lib.call('nimg_conv3_rows_c4_bf16', _p(x), _p(w), _p(bias), _p(out), n, h, wd, act_id, alpha, _stream())
+            return out
         _lib.call('nimg_conv2d_fwd_smallc_bf16_ex', _p(x), c1, _p(w), _p(bias), _p(out), cout, n, h, wd, ks, pad_mode,
                   act_id, alpha, BF16_OUT if _is_bf16(out) else 0, _stream())
         return out

@@ -1784,6 +1784,13 @@ def test_row_streaming_convolution_equals_the_tile_kernels(dev, n, h, monkeypatc
             return ops.conv2d_dgrad(dz, w, (h, wd), act_mask=prev, out_bf16=False), o1, o2
         (f0, a0, b0), (f1, a1, b1) = grads(False), grads(True)
         assert f1.dtype == torch.float32 and torch.equal(f0, f1) and same(a0, a1) and same(b0, b1)
+        # the UNet's first layer: 4 float32 RAW planes -> 32 channels
+        x4, w4 = g(rnd((n, h, wd, 4), 93, 0, 1), dev), g(0.2 * rnd((3, 3, 4, 32), 94), dev)
+        for act in ('leaky_relu', None):
+            monkeypatch.setattr(ops, 'ROWS_CONV', False)
+            ref4 = ops.conv2d(x4, w4, b, act=act, out_bf16=True)
+            monkeypatch.setattr(ops, 'ROWS_CONV', True)
+            assert same(ops.conv2d(x4, w4, b, act=act, out_bf16=True), ref4), act
         # the UNet's last layer: 32 -> 12 channels written as the clipped depth_to_space image
         w12, b12 = g(0.3 * rnd((3, 3, 32, 12), 90), dev), g(0.2 * rnd((12,), 91), dev)
         want = ops.d2s_clip(ops.conv2d(x, w12, b12), 1.0, 0.0, True)
