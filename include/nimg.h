@@ -505,6 +505,7 @@ int nimg_conv2d_fwd_pool_also_bf16(const float* in, int cin, const void* wb, con
  * (n, h / 2, wd / 2, 32) bf16 2x2 max-pool of out.  Results are bit-identical to nimg_conv2d_fwd_bf16_ex (+ nimg_maxpool2_fwd_bf16).
  * Shapes: wd == 128, h % 4 == 0, cout == 32, (c1, c2) in {(32, 0), (64, 0), (32, 32)}; or cout == 64 from c1 == 32 as TWO 32-channel
  * tensors out / out2 (a decoder layer's input gradient, no bias / mask / pool).  flags: NIMG_ROWS_F32_OUT = out holds float32.
+ * Second level of the UNet: wd == 64, (c1, c2, cout) in {(32, 0, 64), (64, 0, 64)}, out (n, h, wd, 64) bf16 (mask likewise), no pool.
  * Anything else NIMG_ERR_ARG (use the tile kernels). */
 #define NIMG_ROWS_F32_OUT 1
 int nimg_conv3_rows_bf16(const void* in1, int c1, const void* in2, int c2, const void* wb, const float* bias, const void* mask,

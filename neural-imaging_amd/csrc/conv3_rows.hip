@@ -52,6 +52,7 @@ struct RowsParams {
     void* out;                    // (N, H, W, 32) bf16 (float32 with out_f32)
     void* out2;                   // second 32-channel output (64 output channels split over two tensors) or null
     int out_f32;                  // out holds float32
+    int ostride;                  // channels per pixel of out (and mask): 32, or 64 when both output blocks go to ONE tensor
     void* pool_out;               // optional (N, H / 2, W / 2, 32) bf16
     float* d2s;                   // optional (N, 2 H, 2 W, 3) float32: the layer has 12 output channels and leaves as clip(depth_to_space(.., 2), 0, 1)
     int cout;                     // 32, or 12 with d2s
@@ -282,10 +283,11 @@ __global__ __launch_bounds__(64 * (NCW + 1)) __attribute__((amdgpu_waves_per_eu(
             }
 #pragma unroll
             for (int r = 0; r < RW; ++r) {
-                const long rowbase = (((long)n * p.H + yw + r) * W + pf * 32) * 32;
+                const long rowbase = (((long)n * p.H + yw + r) * W + pf * 32) * p.ostride;
 #pragma unroll
                 for (int ni = 0; ni < NO; ++ni) {
-                    void* dstp = ni == 0 ? p.out : p.out2;
+                    void* dstp = (ni == 0 || p.ostride == 64) ? p.out : p.out2;
+                    const int cofs = p.ostride == 64 ? ni * 32 : 0;
                     epilogue_via_lds8<1>(reinterpret_cast<const f32x16(&)[1]>(acc[r][ni]), elds, lane, [&](int row, int c, float4 lo, float4 hi) {
                         float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(64 * (NCW + 1)) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
                             for (int e = 0; e < 8; ++e) f[e] = lrelu(f[e], p.alpha);
                         }
-                        const long o = rowbase + row * 32 + c;
+                        const long o = rowbase + (long)row * p.ostride + cofs + c;
                         if (maskp) {
                             const bf16x8 m = *reinterpret_cast<const bf16x8*>(maskp + o);
 #pragma unroll
@@ -502,14 +504,19 @@ int nimg_conv3_rows_bf16(const void* in1, int c1, const void* in2, int c2, const
                          void* out, void* out2, void* pool_out, int n, int h, int wd, int cout, int act, float alpha, int flags,
                          void* stream) {
     if (n == 0) return NIMG_OK;
-    if (!in1 || !wb || !out || n < 0 || wd != 128 || h < 4 || (h & 3) || (flags & ~NIMG_ROWS_F32_OUT)) return NIMG_ERR_ARG;
-    if (!((cout == 32 && !out2) || (cout == 64 && out2 && c1 == 32 && c2 == 0 && !pool_out && !mask && !flags))) return NIMG_ERR_ARG;
-    if (!((c1 == 32 && c2 == 0 && !in2) || (c1 == 64 && c2 == 0 && !in2) || (c1 == 32 && c2 == 32 && in2))) return NIMG_ERR_ARG;
+    if (!in1 || !wb || !out || n < 0 || (wd != 128 && wd != 64) || h < 4 || (h & 3) || (flags & ~NIMG_ROWS_F32_OUT)) return NIMG_ERR_ARG;
+    const bool level2 = wd == 64;              // 64-pixel rows: 32 | 64 -> 64 channels in one tensor (the UNet's second level)
+    if (level2) {
+        if (cout != 64 || out2 || pool_out || flags || c2 != 0 || in2 || (c1 != 32 && c1 != 64)) return NIMG_ERR_ARG;
+    } else {
+        if (!((cout == 32 && !out2) || (cout == 64 && out2 && c1 == 32 && c2 == 0 && !pool_out && !mask && !flags))) return NIMG_ERR_ARG;
+        if (!((c1 == 32 && c2 == 0 && !in2) || (c1 == 64 && c2 == 0 && !in2) || (c1 == 32 && c2 == 32 && in2))) return NIMG_ERR_ARG;
+    }
     if (pool_out && (h & 1)) return NIMG_ERR_ARG;
     if ((long)n * h * wd * (c1 > c2 ? c1 : c2) * 2 >= (1l << 31) - 65536) return NIMG_ERR_ARG;
     RowsParams p;
     p.in1 = in1; p.in2 = in2; p.wb = (const __bf16*)wb; p.bias = bias; p.mask = mask; p.out = out; p.pool_out = pool_out;
-    p.out2 = out2; p.out_f32 = (flags & NIMG_ROWS_F32_OUT) ? 1 : 0;
+    p.out2 = out2; p.out_f32 = (flags & NIMG_ROWS_F32_OUT) ? 1 : 0; p.ostride = level2 ? 64 : 32;
     p.C1 = c1; p.C2 = c2; p.N = n; p.H = h; p.act = act ? 1 : 0; p.alpha = alpha; p.d2s = nullptr; p.cout = cout;
     static const int ablate = getenv("NIMG_ROWS_ABLATE") ? atoi(getenv("NIMG_ROWS_ABLATE")) : 0;
     p.ablate = ablate;
@@ -525,6 +532,7 @@ int nimg_conv3_rows_bf16(const void* in1, int c1, const void* in2, int c2, const
     static const int pfd_env = getenv("NIMG_ROWS_PFD") ? atoi(getenv("NIMG_ROWS_PFD")) : 2;
     static const int ncw_env = getenv("NIMG_ROWS_NCW") ? atoi(getenv("NIMG_ROWS_NCW")) : 8;
     (void)rb_env;
+    if (level2) return c1 == 32 ? launch_rows<1, 64, 4, 1, 8, 2>(p, s) : launch_rows<2, 64, 2, 1, 4, 2>(p, s);
     if (cout == 64) return launch_rows<1, 128, 4, 1, 8, 2>(p, s);
     if (c1 + c2 == 32) {
         if (ncw_env == 4) return pfd_env == 1 ? launch_rows<1, 128, 4, 1, 4>(p, s) : launch_rows<1, 128, 4, 2, 4>(p, s);
@@ -561,7 +569,7 @@ int nimg_conv3_rows_d2s_bf16(const void* in, int c1, const void* wb, const float
     if ((long)n * h * wd * c1 * 2 >= (1l << 31) - 65536) return NIMG_ERR_ARG;
     RowsParams p;
     p.in1 = in; p.in2 = nullptr; p.wb = (const __bf16*)wb; p.bias = bias; p.mask = nullptr; p.out = nullptr; p.pool_out = nullptr;
-    p.out2 = nullptr; p.out_f32 = 0; p.d2s = y; p.cout = 12;
+    p.out2 = nullptr; p.out_f32 = 0; p.ostride = 32; p.d2s = y; p.cout = 12;
     p.C1 = c1; p.C2 = 0; p.N = n; p.H = h; p.act = 0; p.alpha = 0.f; p.ablate = 0;
     int bh = 32;
     while (bh > 4 && (h % bh != 0 || (long)n * (h / bh) < 256)) bh >>= 1;

@@ -556,11 +556,21 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
 # Row-band streaming form of the 3x3 convolutions with 32 output channels over 128-pixel-wide bf16-stored images - the UNet's
 # level-1 layers at the channel's 128 x 128 RAW patches (NIMG_NO_ROWS_CONV=1: the tile kernels, A/B runs)
 ROWS_CONV = _os.environ.get('NIMG_NO_ROWS_CONV') is None
+# ... and the 64-pixel-wide, 64-channel second level: OPT-IN (NIMG_ROWS_LEVEL2=1).  Stand-alone the streaming form wins there too
+# (32 -> 64: 27 -> 22 us, 64 -> 64: 39 -> 34 us at B = 64) but the UNet step does not move (forward 755 vs 761 us, step 2354 vs 2347 us):
+# these layers are no longer byte-bound (73 KB of weights staged per workgroup, one 143 KB workgroup per CU leaves the side
+# streams' weight gradients no room) - profiles/r05_unet_rows_ab.txt section 6
+ROWS_LEVEL2 = _os.environ.get('NIMG_ROWS_LEVEL2') is not None
 
 
 def rows_conv_ok(x, x2, ks, stride, cout, out_hw, pads, pad_mode, out, out2, act_mask, act, bias=None):
     n, h, wd, c1 = x.shape
     c2 = 0 if x2 is None else x2.shape[3]
+    if ROWS_CONV and ROWS_LEVEL2 and ks == 3 and stride == 1 and wd == 64 and h % 4 == 0 and h >= 4 and tuple(out_hw) == (h, wd) and \
+            tuple(pads) == (1, 1) and pad_mode == 0 and _is_bf16(x) and x2 is None and act in (None, 'leaky_relu'):
+        # the UNet's second level: 32 | 64 -> 64 channels at 64-pixel rows, one bf16 tensor out
+        return cout == 64 and c1 in (32, 64) and out2 is None and _is_bf16(out) and out.shape[3] == 64 and \
+            (act_mask is None or (_is_bf16(act_mask) and tuple(act_mask.shape) == (n, h, wd, 64)))
     if not (ROWS_CONV and ks == 3 and stride == 1 and wd == 128 and h % 4 == 0 and h >= 4 and tuple(out_hw) == (h, wd) and
             tuple(pads) == (1, 1) and pad_mode == 0 and _is_bf16(x) and (x2 is None or _is_bf16(x2)) and
             act in (None, 'leaky_relu') and n * h * wd * max(c1, c2) * 2 < (1 << 31) - 65536):
@@ -822,7 +832,7 @@ def conv2d_and_pool(x, w, bias=None, act='leaky_relu'):
     cout = w.shape[3]
     y = torch.empty((n, h, wd, cout), dtype=torch.bfloat16, device=x.device)
     pooled = torch.empty((n, h // 2, wd // 2, cout), dtype=torch.bfloat16, device=x.device)
-    if rows_conv_ok(x, None, 3, 1, cout, (h, wd), (1, 1), 0, y, None, None, act):
+    if wd == 128 and rows_conv_ok(x, None, 3, 1, cout, (h, wd), (1, 1), 0, y, None, None, act):       # (the pooled tensor: level 1 only)
         _lib.call('nimg_conv3_rows_bf16', _p(x), cin, None, 0, _p(weights_bf16(w, 0)), _p(bias), None, _p(y), None, _p(pooled), n, h,
                   wd, cout, 1 if act == 'leaky_relu' else 0, LRELU_ALPHA, 0, _stream())
         return y, pooled

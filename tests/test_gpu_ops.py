@@ -1797,7 +1797,24 @@ def test_row_streaming_convolution_equals_the_tile_kernels(dev, n, h, monkeypatc
         assert ops.rows_d2s_ok(x, w12)
         got = ops.conv3_rows_d2s(x, w12, b12)
         assert torch.equal(got, want) and float(got.min()) == 0.0 and float(got.max()) == 1.0
+        # second level of the UNet (opt-in form): 64-pixel rows, 32 | 64 -> 64 channels, forward and the input-gradient form with a mask
+        monkeypatch.setattr(ops, 'ROWS_LEVEL2', True)
+        h2 = 64 if h >= 64 else (h // 4) * 4
+        for c1 in (32, 64):
+            x2l = bf(rnd((n, h2, 64, c1), 95 + c1))
+            wl, bl = g(0.1 * rnd((3, 3, c1, 64), 96), dev), g(0.1 * rnd((64,), 97), dev)
+            prevl = bf(rnd((n, h2, 64, 64), 98))
+            wg = g(0.1 * rnd((3, 3, 64, c1), 99), dev)             # a layer c1... whose gradient w.r.t. its 64-channel input is taken
+            res = {}
+            for on in (False, True):
+                monkeypatch.setattr(ops, 'ROWS_CONV', on)
+                res[on] = (ops.conv2d(x2l, wl, bl, act='leaky_relu', out_bf16=True),
+                           ops.conv2d_dgrad(x2l, wg, (h2, 64), act_mask=prevl, out_bf16=True) if c1 == 64 else None)
+            assert ops.rows_conv_ok(x2l, None, 3, 1, 64, (h2, 64), (1, 1), 0, res[True][0], None, None, 'leaky_relu')
+            assert same(res[False][0], res[True][0]), c1
+            if c1 == 64:
+                assert same(res[False][1], res[True][1])
         # shapes the streaming form does not take fall through to the tile kernels
-        assert not ops.rows_conv_ok(bf(rnd((1, 16, 64, 32), 89)), None, 3, 1, 32, (16, 64), (1, 1), 0, ref, None, None, None)
+        assert not ops.rows_conv_ok(bf(rnd((1, 16, 32, 32), 89)), None, 3, 1, 32, (16, 32), (1, 1), 0, ref, None, None, None)
     finally:
         ops.set_compute('f32')
