@@ -971,6 +971,86 @@ def test_default_channel_parity_outside_flipped_blocks(dev):
         print('   {:22s} product vs float64 {:.2e}   float32 restatement vs float64 {:.2e}'.format(k, e_prod, e_ref32))
 
 
+def test_full_patch_size_channel_against_the_oracle(dev):
+    """BASELINE.json configs[3] at its FULL patch size (RAW 128 x 128 -> 256 x 256 x 3 images; the reference's
+    workflows/manipulation_classification.py:260-285 with hard rounding in both JPEG stages) against the float64 oracle, at a
+    batch the oracle finishes in seconds (B = 2 -> ten FAN images): the 128-pixel-wide UNet level, the 256-pixel image chain and
+    the 32 x 32 blocks-per-plane dJPEG are the launch shapes of the bench line, which the reduced-size tests do not reach.
+    Forward to the 1e-4 contract outside 8 x 8 blocks with a flipped rounding tie; losses; gradient directions (at ~4 M coefficients
+    a batch without any flip does not exist - the per-tensor 1e-3 check is test_default_channel_parity_outside_flipped_blocks)."""
+    from neural_imaging_amd import ops
+    from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
+    from oracle import djpeg as odj
+    dist = {'downsampling': 'none', 'compression': 'jpeg', 'compression_params': {'quality': 80, 'codec': 'soft'}}
+    wf = ManipulationClassification('UNet', distribution=dist, trainable={'nip'}, raw_patch_size=128, device=dev)
+    ref = owf.Workflow(trainable=('nip',), jpeg_quality=80)
+    _sync_oracle(wf, ref)
+    qt = ops.qtables_device(80, dev)
+    jpeg_class = 1 + ref.operations.index('jpeg')
+    rgb = natural_images(2, 256, 256, seed=8)
+    raw = bayer_from_rgb(rgb)
+    b = raw.shape[0]
+    Y, c, C, ent, probs = wf.run_workflow(raw)
+    Yr, cr, Cr, _, pr = ref.run_workflow(to64(raw))
+    assert Y.shape == (b, 256, 256, 3) and C.shape == (5 * b, 256, 256, 3)
+    assert_close(Y.numpy(), Yr.numpy(), 1e-4, what='UNet output at 256 x 256')
+    i1 = ops.djpeg_fwd(torch.as_tensor(Y.numpy()).to(dev), qt, 'soft', want_idx=True)[2].cpu().numpy()
+    i2 = ops.djpeg_fwd(torch.as_tensor(c.numpy()).to(dev), qt, 'soft', want_idx=True)[2].cpu().numpy()
+    f1 = i1 != np.rint(odj.djpeg_torch(Yr, 80, 'soft')[2].numpy())
+    f2 = i2 != np.rint(odj.djpeg_torch(cr, 80, 'soft')[2].numpy())
+    rate = (f1.sum() + f2.sum()) / float(f1.size + f2.size)
+    assert rate < 1e-4, rate
+    # the five manipulated classes: only the 'jpeg' class has a rounding stage behind it
+    bad1 = np.zeros((5 * b, 32, 32), bool)
+    bad1[jpeg_class * b:(jpeg_class + 1) * b] = f1.any(axis=(1, 4, 5))
+    dc = np.abs(c.numpy().astype(np.float64) - cr.numpy()) * ~np.kron(bad1, np.ones((1, 8, 8), bool))[..., None]
+    assert dc.max() <= 1e-4, float(dc.max())
+    bad = f2.any(axis=(1, 4, 5)) | bad1
+    keep = ~np.kron(bad, np.ones((1, 8, 8), bool))[..., None]
+    dC = np.abs(C.numpy().astype(np.float64) - Cr.numpy()) * keep
+    assert dC.max() <= 1e-4, (float(dC.max()), int(bad.sum()))
+    assert keep.mean() > 0.99                                         # the mask hides a handful of blocks, not the image
+    loss_ref, parts_ref, params, grads, _ = ref.loss_and_grads(to64(raw), to64(rgb), 0.1)
+    loss, parts = wf.training_step(raw, rgb, lambda_nip=0.1, learning_rate=1e-4)
+    assert abs(float(parts['nip']) - parts_ref['nip']) / parts_ref['nip'] < 1e-4
+    assert abs(float(parts['ce']) - parts_ref['ce']) < 5e-3, (float(parts['ce']), parts_ref['ce'])
+    names = list(ref.fan.keys()) + list(ref.nip.keys())
+    got = grads_of(wf.fan)
+    got.update(grads_of(wf.nip))
+    for k, gr in zip(names, grads):
+        a, g = got[k].ravel().astype(np.float64), gr.numpy().ravel()
+        cos = float(a @ g / (np.linalg.norm(a) * np.linalg.norm(g) + 1e-300))
+        assert cos > 0.98, (k, cos)
+    print('full patch size: flip rate {:.1e}, {} of {} blocks masked, max |dC| outside {:.2e}'.format(
+        rate, int(bad.sum()), bad.size, float(dC.max())))
+    # the throughput mode of the bench line (bf16 MFMA operands, bf16-stored activations, the row-streaming level-1 kernels at
+    # their 128-pixel width) against the SAME float64 oracle, judged as BASELINE.json judges it: PSNR, losses, directions
+    ops.set_compute('bf16')
+    try:
+        wb = ManipulationClassification('UNet', distribution=dist, trainable={'nip'}, raw_patch_size=128, device=dev)
+        wb.nip.load_state_dict({k: v.numpy() for k, v in ref.nip.items()})      # the weights the oracle was given
+        wb.fan.load_state_dict({k: v.numpy() for k, v in ref.fan.items()})
+        Yb = wb.run_workflow(raw)[0].numpy()
+        lb, pb = wb.training_step(raw, rgb, lambda_nip=0.1, learning_rate=1e-4)
+        gb = grads_of(wb.fan)
+        gb.update(grads_of(wb.nip))
+    finally:
+        ops.set_compute('f32')
+    psnr = 10 * np.log10(1.0 / np.mean((Yb.astype(np.float64) - Yr.numpy()) ** 2))
+    assert psnr > 45, psnr
+    assert abs(float(pb['nip']) - parts_ref['nip']) / parts_ref['nip'] < 1e-2
+    assert abs(float(pb['ce']) - parts_ref['ce']) < 3e-2, (float(pb['ce']), parts_ref['ce'])
+    worst = 1.0
+    for k, gr in zip(names, grads):
+        if k.endswith('/kernel') and k.split('/')[0] not in ('constrained', 'conv1'):      # the ill-conditioned front end: see above
+            a, g = gb[k].ravel().astype(np.float64), gr.numpy().ravel()
+            cos = float(a @ g / (np.linalg.norm(a) * np.linalg.norm(g) + 1e-300))
+            worst = min(worst, cos)
+            assert cos > 0.9, (k, cos)
+    print('   throughput mode vs the oracle: PSNR {:.1f} dB, ce {:.4f} vs {:.4f}, worst kernel-gradient cosine {:.4f}'.format(
+        psnr, float(pb['ce']), parts_ref['ce'], worst))
+
+
 def test_deferred_slab_reductions_give_the_same_gradients(dev, monkeypatch):
     """ops.DEFER_REDUCE (opt-in): the split-K reductions of every side-stream weight gradient of a step in one batched launch per
     side stream (nimg_conv2d_wgrad_bf16_deferred + nimg_reduce_slabs_batch) - the same sums to the bit as one reduction per layer."""
