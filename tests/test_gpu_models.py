@@ -73,14 +73,15 @@ def test_unet_forward_backward(dev):
     assert out.shape == (1, 64, 64, 3) and np.abs(out.numpy()[0] - y_ref.detach().numpy()[0]).max() < 1e-4
 
 
-def test_unet_at_the_full_patch_size(dev):
+@pytest.mark.parametrize('n', [2, 1])
+def test_unet_at_the_full_patch_size(dev, n):
     """BASELINE.json configs[1] at its real patch size (train_nip.py: RAW 128 x 128 x 4 -> 256 x 256 x 3; models/pipelines.py:190-218)
     at a batch the float64 oracle finishes in seconds: the launch shapes of the bench lines - 128 x 128 level 1 (the row-streaming
     kernels in throughput mode), 8 x 8 level 5 - against the oracle.  Parity mode to the 1e-4 contract, forward and every
     parameter gradient; throughput mode by PSNR and gradient direction."""
     from neural_imaging_amd.models import pipelines
     from neural_imaging_amd import ops
-    rgb = natural_images(2, 256, 256, seed=23)
+    rgb = natural_images(n, 256, 256, seed=23)
     raw = bayer_from_rgb(rgb)
     net = pipelines.UNet(patch_size=128, device=dev)
     p = oracle_params(net)
@@ -91,7 +92,7 @@ def test_unet_at_the_full_patch_size(dev):
     g_ref = dict(zip(p.keys(), torch.autograd.grad(loss_ref, list(p.values()))))
     x, tgt = torch.from_numpy(raw).to(dev), torch.from_numpy(rgb).to(dev)
     y, ctx = net.forward(x, training=True)
-    assert y.shape == (2, 256, 256, 3)
+    assert y.shape == (n, 256, 256, 3)
     assert_close(y.cpu().numpy(), y_ref.detach().numpy(), 1e-4, what='UNet output at 256 x 256')
     loss, dy = ops.mse255(y, tgt, grad_scale=1.0)
     assert abs(float(loss.item()) - float(loss_ref.detach())) / float(loss_ref.detach()) < 1e-4
@@ -110,13 +111,14 @@ def test_unet_at_the_full_patch_size(dev):
     psnr = 10 * np.log10(1.0 / np.mean((yb.float().cpu().numpy().astype(np.float64) - y_ref.detach().numpy()) ** 2))
     assert psnr > 45, psnr
     assert abs(float(lb.item()) - float(loss_ref.detach())) / float(loss_ref.detach()) < 1e-2
-    lo = 1.0
+    cosines = []
     for k in p:
         if k.endswith('/kernel'):
             a, g = gb[k].ravel().astype(np.float64), g_ref[k].numpy().ravel()
-            cos = float(a @ g / (np.linalg.norm(a) * np.linalg.norm(g) + 1e-300))
-            lo = min(lo, cos)
-            assert cos > 0.97, (k, cos)
+            cosines.append((float(a @ g / (np.linalg.norm(a) * np.linalg.norm(g) + 1e-300)), k))
+    cosines.sort()
+    lo = cosines[0][0]
+    assert lo > 0.97, cosines[:8]
     print('UNet at 128 x 128 RAW: worst parity-mode gradient {:.2e} ({}), throughput mode PSNR {:.1f} dB, worst cosine {:.4f}'.format(
         worst[0], worst[1], psnr, lo))
 
@@ -1262,6 +1264,73 @@ def test_workflow_with_learned_codec_joint_training(dev):
         worst = min(worst, cos)
         assert cos > 0.99, (k, cos)
     assert wf.is_trainable('dcn') and 'TwitterDCN' in wf.summary()
+
+
+def test_learned_codec_channel_at_the_full_patch_size(dev):
+    """BASELINE.json configs[4] at its real patch size - UNet (RAW 128 x 128) -> manipulations -> TwitterDCN-32C on 256 x 256 -> FAN,
+    trainable = {nip, dcn} (workflows/manipulation_classification.py:267-277) - at B = 1 raw patch (five codec / FAN images), which
+    the float64 oracle finishes in seconds: losses and gradient directions in parity mode, and the throughput mode of the bench line
+    against the same oracle."""
+    from neural_imaging_amd import ops
+    from neural_imaging_amd.models import compression
+    from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
+    rgb = natural_images(1, 256, 256, seed=9)
+    raw = bayer_from_rgb(rgb)
+    ref = owf.Workflow(codec='dcn', trainable=('nip', 'dcn'))
+    res = {}
+    for mode in ('f32', 'bf16'):
+        ops.set_compute(mode)
+        try:
+            dcn = compression.TwitterDCN(patch_size=256, device=dev)
+            dist = {'downsampling': 'none', 'compression': 'dcn', 'compression_params': {'model': dcn}}
+            wf = ManipulationClassification('UNet', distribution=dist, trainable={'nip', 'dcn'}, raw_patch_size=128, device=dev)
+            if mode == 'f32':
+                _sync_oracle(wf, ref)
+                ref.dcn = onets.OrderedDict((k, to64(v)) for k, v in dcn.state_dict().items())
+                loss_ref, parts_ref, params, grads, _ = ref.loss_and_grads(to64(raw), to64(rgb), 0.1, 0.01)
+            else:
+                wf.nip.load_state_dict({k: v.numpy() for k, v in ref.nip.items()})
+                wf.fan.load_state_dict({k: v.numpy() for k, v in ref.fan.items()})
+                dcn.load_state_dict({k: v.numpy() for k, v in ref.dcn.items()})
+            loss, parts = wf.training_step(raw, rgb, lambda_nip=0.1, lambda_dcn=0.01, learning_rate=1e-4)
+            got = grads_of(wf.fan)
+            got.update(grads_of(wf.nip))
+            got.update(grads_of(dcn))
+            res[mode] = (float(loss), {k: float(v) for k, v in parts.items()}, got)
+        finally:
+            ops.set_compute('f32')
+    names = list(ref.fan.keys()) + list(ref.nip.keys()) + list(ref.dcn.keys())
+    lref = float(loss_ref.detach())
+    deep = ('ec41', 'ec42', 'ec51', 'ec52', 'dct1', 'dct2', 'dc11', 'dc12')       # UNet levels 4 - 5 and the way back up
+    for mode, tol_ce, tol_rel, lo in (('f32', 2e-3, 1e-3, 0.98), ('bf16', 3e-2, 3e-2, 0.9)):
+        loss, parts, got = res[mode]
+        assert abs(parts['ce'] - parts_ref['ce']) < tol_ce, (mode, parts['ce'], parts_ref['ce'])
+        assert abs(parts['nip'] - parts_ref['nip']) / parts_ref['nip'] < tol_rel, mode
+        assert abs(parts['dcn'] - parts_ref['dcn']) / parts_ref['dcn'] < tol_rel, mode
+        assert abs(loss - lref) / lref < tol_rel, (mode, loss, lref)
+        cosines = {}
+        for k, gr in zip(names, grads):
+            a, b = got[k].ravel().astype(np.float64), gr.numpy().ravel()
+            cosines[k] = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
+        if mode == 'f32':
+            assert min(cosines.values()) > lo, sorted((c, k) for k, c in cosines.items())[:8]
+        else:
+            # throughput mode: the FAN's and the codec's kernels point the oracle's way to 3 digits.  The UNet's gradient arrives
+            # through the (randomly initialised) codec, whose l2 term dominates this loss: bf16 WEIGHTS are a spatially coherent
+            # ~0.4 % perturbation of that linear map, i.e. a low-frequency error on a gradient image whose low-frequency content
+            # nearly cancels - the deeper the level the less of the oracle's direction survives (measured: level 1 0.997, level 2
+            # 0.96, level 3 0.92 - 0.94, level 4 0.66 - 0.69, level 5 0.36 - 0.45; the same UNet under its own loss: 0.9995 at every
+            # level, test_unet_at_the_full_patch_size).  The yardstick is tests/test_oracle.py::
+            # test_codec_channel_gradient_conditioning_under_bf16_weights: the float64 oracle ITSELF with its weights rounded to bf16
+            # keeps 0.09 - 0.30 at levels 4 - 5.  Levels 1 - 3 are held to the floor; 4 - 5 only to the right half-space.
+            kern = {k: c for k, c in cosines.items() if k.endswith('/kernel') and k.split('/')[0] not in ('constrained', 'conv1')}
+            for k, c in kern.items():
+                own = k in ref.nip
+                floor = 0.25 if (own and k.split('/')[0] in deep) else (lo if own else 0.99)
+                assert c > floor, (k, c, sorted((c2, k2) for k2, c2 in kern.items())[:12])
+        worst = min((c, k) for k, c in cosines.items() if mode == 'f32' or k.endswith('/kernel'))
+        print('learned-codec channel at full patch size, {}: loss {:.5f} vs {:.5f}, worst gradient cosine {:.4f} ({})'.format(
+            mode, loss, lref, *worst))
 
 
 def test_channel_learns_and_compute_modes_agree(dev):

@@ -319,3 +319,32 @@ def test_stride2_conv_is_a_conv_over_the_space_to_depth_image():
         gx2, gw2 = torch.autograd.grad((got * dy).sum(), (x, w5))
         assert float((gx - gx2).abs().max()) < 1e-12 and float((gw - gw2).abs().max()) < 1e-12
 
+
+
+def test_codec_channel_gradient_conditioning_under_bf16_weights():
+    """What a bf16-operand implementation can be asked for on configs[4] at random initialisation (the yardstick behind the UNet
+    floors of tests/test_gpu_models.py::test_learned_codec_channel_at_the_full_patch_size).  The float64 oracle itself, exact
+    arithmetic throughout, evaluated once with its weights as they are and once with every weight rounded to bf16: the codec's l2
+    term dominates the loss, the UNet's deep levels only see the nearly cancelling low-frequency part of the gradient image, and a
+    coherent 2^-9 perturbation of the linear maps in front of it leaves little of their direction (levels 4 - 5: cosine < 0.5) while
+    the FAN / codec kernels and UNet level 1 keep theirs.  The product keeps float32 master weights and rounds operands only; it
+    measures 0.36 - 0.69 on the same tensors."""
+    from util import bayer_from_rgb
+    rgb = natural_images(1, 256, 256, seed=9)
+    raw = bayer_from_rgb(rgb)
+    ref = owf.Workflow(codec='dcn', trainable=('nip', 'dcn'))
+    names = list(ref.fan.keys()) + list(ref.nip.keys()) + list(ref.dcn.keys())
+    g0 = dict(zip(names, [g.numpy().copy() for g in ref.loss_and_grads(to64(raw), to64(rgb), 0.1, 0.01)[3]]))
+    rb = lambda v: v.to(torch.bfloat16).to(torch.float64)
+    r2 = owf.Workflow(codec='dcn', trainable=('nip', 'dcn'))
+    r2.nip = onets.OrderedDict((k, rb(v)) for k, v in ref.nip.items())
+    r2.fan = onets.OrderedDict((k, rb(v)) for k, v in ref.fan.items())
+    r2.dcn = onets.OrderedDict((k, rb(v)) for k, v in ref.dcn.items())
+    g2 = dict(zip(names, [g.numpy() for g in r2.loss_and_grads(to64(raw), to64(rgb), 0.1, 0.01)[3]]))
+    cos = {}
+    for k in names:
+        if k.endswith('/kernel'):
+            a, b = g2[k].ravel(), g0[k].ravel()
+            cos[k.split('/')[0]] = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
+    assert all(cos[k] < 0.5 for k in ('ec51', 'ec52', 'dct1', 'ec41')), cos
+    assert all(cos[k] > 0.9 for k in ('dc42', 'ec11', 'conv3', 'conv4', 'dense', 'e2', 'er2a', 'd256')), cos
