@@ -67,6 +67,105 @@ def nearest_axis_matrix(in_size, out_size):
     return m
 
 
+# tf.image.resize's other methods (image_ops_impl.py resize_images_v2 with antialias=False, the call of the reference's
+# manipulation_resample, helpers/tf_helpers.py:68-76): every one of them is a separable linear map, so each becomes an (out, in)
+# matrix per axis like the two above and runs through the same banded-operator kernels.  The weights are computed in float32 in
+# the order of TensorFlow's kernels (resize_bicubic_op.cc, resize_area_op.cc, scale_and_translate_op.cc + sampling_kernels.h).
+def bicubic_axis_matrix(in_size, out_size):
+    """ResizeBicubic(half_pixel_centers=True): Keys cubic (a = -0.5) read from the kernel's 1024-step coefficient table, the four
+    taps around floor(src); taps that fall outside the image weigh 0 and the others are renormalised to sum 1."""
+    f32, steps, a = np.float32, 1024, -0.5
+    x = (np.arange(steps + 1) * 1.0 / steps).astype(f32)
+    near = (((a + 2) * x.astype(np.float64) - (a + 3)) * x * x + 1).astype(f32)              # |t| <= 1
+    x1 = (x + f32(1.0)).astype(np.float64)
+    far = (((a * x1 - 5 * a) * x1 + 8 * a) * x1 - 4 * a).astype(f32)                         # 1 <= |t| <= 2
+    o = np.arange(out_size, dtype=f32)
+    src = (o + f32(0.5)) * (f32(in_size) / f32(out_size)) - f32(0.5)
+    base = np.floor(src)
+    off = np.rint((src - base) * f32(steps)).astype(np.int64)
+    base = base.astype(np.int64)
+    idx = base[:, None] + np.array([-1, 0, 1, 2])
+    w = np.stack([far[off], near[off], near[steps - off], far[steps - off]], 1)
+    w = np.where((idx >= 0) & (idx < in_size), w, f32(0.0))
+    tot = ((w[:, 0] + w[:, 1]) + w[:, 2]) + w[:, 3]
+    ok = np.abs(tot) >= 1000.0 * np.finfo(f32).tiny
+    w = np.where(ok[:, None], w * (f32(1.0) / np.where(ok, tot, f32(1.0)))[:, None], w).astype(f32)
+    m = np.zeros((out_size, in_size), np.float64)
+    np.add.at(m, (np.repeat(np.arange(out_size), 4), np.clip(idx, 0, in_size - 1).ravel()), w.ravel().astype(np.float64))
+    return m
+
+
+def area_axis_matrix(in_size, out_size):
+    """ResizeArea: the mean of the input over [o s, (o + 1) s), s = in / out - edge pixels by the covered fraction, clamped indices."""
+    f32 = np.float32
+    s = f32(in_size) / f32(out_size)
+    lo = (np.arange(out_size, dtype=f32) * s).astype(f32)
+    hi = (np.arange(1, out_size + 1, dtype=f32) * s).astype(f32)
+    m = np.zeros((out_size, in_size), np.float64)
+    for o in range(out_size):                                                    # spans differ in length: one short loop per output
+        v = np.arange(int(np.floor(lo[o])), int(np.ceil(hi[o])), dtype=np.int64)
+        vf = v.astype(f32)
+        before, beyond = vf < lo[o], vf + f32(1.0) > hi[o]
+        cover = np.where(before, np.where(beyond, s, vf + f32(1.0) - lo[o]), np.where(beyond, hi[o] - vf, f32(1.0))).astype(f32)
+        np.add.at(m[o], np.clip(v, 0, in_size - 1), cover.astype(np.float64) / float(s))
+    return m
+
+
+def _sampling_kernel(name):
+    f32 = np.float32
+    pi = f32(3.14159265359)
+    if name in ('lanczos3', 'lanczos5'):
+        r = f32(3.0 if name == 'lanczos3' else 5.0)
+
+        def fn(x):
+            xs = np.where(x <= f32(1e-3), f32(1.0), x)                            # (the guarded lanes are overwritten below)
+            y = r * np.sin(pi * xs, dtype=f32) * np.sin(pi * xs / r, dtype=f32) / (pi * pi * (xs * xs))
+            return np.where(x > r, f32(0.0), np.where(x <= f32(1e-3), f32(1.0), y)).astype(f32)
+        return r, fn
+    if name == 'gaussian':
+        r = f32(1.5)
+        sigma = float(r / f32(3.0))
+        return r, lambda x: np.where(x >= r, 0.0, np.exp(-x.astype(np.float64) ** 2 / (2.0 * sigma * sigma))).astype(f32)
+    if name == 'mitchellcubic':
+        def fn(x):
+            outer = ((f32(-7.0) / f32(18.0) * x + f32(2.0)) * x - f32(10.0) / f32(3.0)) * x + f32(16.0) / f32(9.0)
+            inner = ((f32(7.0) / f32(6.0) * x - f32(2.0)) * x) * x + f32(8.0) / f32(9.0)
+            return np.where(x >= f32(2.0), f32(0.0), np.where(x >= f32(1.0), outer, inner)).astype(f32)
+        return f32(2.0), fn
+    raise ValueError(name)
+
+
+def scale_translate_axis_matrix(in_size, out_size, kernel):
+    """ScaleAndTranslate(kernel_type, antialias=False), no translation: output o samples the input at (o + 0.5) in / out with the
+    kernel at its native width (no widening on down-sampling), over the pixel centres inside the radius and the image; weights
+    normalised per output."""
+    f32 = np.float32
+    radius, fn = _sampling_kernel(kernel)
+    inv_scale = f32(1.0) / (f32(out_size) / f32(in_size))
+    sample = ((np.arange(out_size, dtype=f32) + f32(0.5)) * inv_scale).astype(f32)
+    first = np.clip(np.ceil(sample - radius - f32(0.5)).astype(np.int64), 0, in_size - 1)
+    last = np.clip(np.floor(sample + radius - f32(0.5)).astype(np.int64), 0, in_size - 1)
+    width = int((last - first).max()) + 1
+    src = first[:, None] + np.arange(width)
+    live = (src <= last[:, None]) & ((sample >= 0) & (sample <= in_size))[:, None]
+    w = np.where(live, fn(np.abs(src.astype(f32) + f32(0.5) - sample[:, None]).astype(f32)), f32(0.0)).astype(f32)
+    tot = np.zeros(out_size, f32)
+    for k in range(width):                                                       # the kernel's left-to-right float32 sum
+        tot = (tot + w[:, k]).astype(f32)
+    ok = np.abs(tot) >= 1000.0 * np.finfo(f32).tiny
+    w = np.where(ok[:, None], w * (f32(1.0) / np.where(ok, tot, f32(1.0)))[:, None], f32(0.0)).astype(f32)
+    m = np.zeros((out_size, in_size), np.float64)
+    rows = np.repeat(np.arange(out_size), width)
+    np.add.at(m, (rows, np.clip(src, 0, in_size - 1).ravel()), np.where(live, w, f32(0.0)).ravel().astype(np.float64))
+    return m
+
+
+RESIZE_AXIS_MATRIX = {'bilinear': bilinear_axis_matrix, 'nearest': nearest_axis_matrix, 'bicubic': bicubic_axis_matrix,
+                      'area': area_axis_matrix}
+for _name in ('lanczos3', 'lanczos5', 'gaussian', 'mitchellcubic'):
+    RESIZE_AXIS_MATRIX[_name] = (lambda i, o, _name=_name: scale_translate_axis_matrix(i, o, _name))
+
+
 def residual_kernel():
     """3x3 high-pass taps of residual() (helpers/tf_helpers.py:131)."""
     return np.array([[-0.0833, -0.1667, -0.0833], [-0.1667, 1, -0.1667], [-0.0833, -0.1667, -0.0833]])

@@ -3,9 +3,10 @@ Photo manipulations and image losses of the channel on the HIP kernels.  Same fu
 the reference's helpers/tf_helpers.py (manipulation_* :68-184, mse :31-32); each manipulation also exists as an object
 with forward(x, strength, out) / backward(ctx, dy), which is what the workflow's training step uses.
 
-Implemented: sharpen (hsv=True incl. the S-channel corner-tap quirk, and hsv=False), resample (bilinear or nearest down+up, any
-factor), gaussian (any odd kernel, any std; the workflow's 5x5 has its own LDS-tiled kernel), residual (hsv=False), awgn
-(device-side noise), gamma, median (odd kernels up to 9).  tf.image.resize's other methods (bicubic, lanczos, area ...) raise.
+Implemented: sharpen (hsv=True incl. the S-channel corner-tap quirk, and hsv=False), resample (down + up with any method string
+tf.image.resize takes - bilinear, nearest, bicubic, area, lanczos3, lanczos5, gaussian, mitchellcubic - any factor), gaussian (any
+odd kernel, any std; the workflow's 5x5 has its own LDS-tiled kernel), residual (hsv=False), awgn (device-side noise), gamma,
+median (odd kernels up to 9).
 """
 from collections import OrderedDict
 
@@ -109,10 +110,10 @@ class Residual(object):
 
 class Resample(object):
     """manipulation_resample(x, factor, method) (tf_helpers.py:68-76): down to floor(H*factor/100) and back up, both dims sized
-    from shape[1].  For the separable linear methods (bilinear - the workflow's - and nearest) the composition is one banded
-    linear operator M per axis: y = M x M^T, dx = M^T dy M."""
+    from shape[1].  Every method of tf.image.resize is a separable linear map (helpers/kernels.py RESIZE_AXIS_MATRIX), so the
+    composition is one banded linear operator M per axis: y = M x M^T, dx = M^T dy M."""
 
-    METHODS = {'bilinear': hk.bilinear_axis_matrix, 'nearest': hk.nearest_axis_matrix}
+    METHODS = hk.RESIZE_AXIS_MATRIX          # every method string tf.image.resize takes
 
     def __init__(self, method='bilinear'):
         if method not in self.METHODS:

@@ -26,7 +26,10 @@ def manipulation_resample(x, factor=50, method='bilinear'):
     if 0 < factor <= 1:
         factor = 100 * factor
     s = x.shape[1] * int(factor) // 100
-    resize = {'bilinear': T.resize_bilinear, 'nearest': T.resize_nearest}[method]
+    if method in T.RESIZE_AXIS:
+        resize = lambda t, oh, ow: T.resize_separable(t, oh, ow, method)
+    else:
+        resize = {'bilinear': T.resize_bilinear, 'nearest': T.resize_nearest}[method]
     down = resize(x, s, s)
     return resize(down, x.shape[1], x.shape[1])
 

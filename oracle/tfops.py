@@ -189,6 +189,136 @@ def resize_nearest(x, out_h, out_w):
     return x[:, table(h, out_h)][:, :, table(w, out_w)]
 
 
+# tf.image.resize's remaining methods (tensorflow/python/ops/image_ops_impl.py resize_images_v2, antialias=False as
+# helpers/tf_helpers.py:74-76 calls it): 'bicubic' -> ResizeBicubic(half_pixel_centers=True), 'area' -> ResizeArea,
+# 'lanczos3' | 'lanczos5' | 'gaussian' | 'mitchellcubic' -> ScaleAndTranslate(kernel_type, antialias=False).  All are separable
+# linear maps; each is restated as ONE (out, in) matrix per axis, built the way the kernel builds its per-output weights - float32
+# where the kernel computes in float - and applied to both axes.  Not vendored in /root/reference: restated from the published
+# kernels (tensorflow/core/kernels/image/resize_bicubic_op.cc, resize_area_op.cc, scale_and_translate_op.cc, sampling_kernels.h),
+# PARITY UNPINNED like the rest of this file.
+_f = np.float32
+
+
+def _bound(v, limit):
+    return min(limit - 1, max(0, v))
+
+
+def resize_bicubic_axis(in_size, out_size):
+    """ResizeBicubic, half_pixel_centers=True: Keys cubic a = -0.5 from a 1024-entry coefficient table indexed by
+    lrintf(delta * 1024); taps in_loc - 1 .. in_loc + 2, a tap outside the image gets weight 0 and the rest are renormalised
+    (GetWeightsAndIndices<HalfPixelScaler, true>)."""
+    a, table = -0.5, 1 << 10
+    co = np.zeros(2 * (table + 1), np.float32)
+    for i in range(table + 1):
+        x = _f(i * 1.0 / table)                                   # float x = i * 1.0 / kTableSize
+        co[2 * i] = ((a + 2) * x - (a + 3)) * x * x + 1           # double arithmetic, stored as float
+        x = _f(x + _f(1.0))
+        co[2 * i + 1] = ((a * x - 5 * a) * x + 8 * a) * x - 4 * a
+    scale = _f(in_size) / _f(out_size)
+    m = np.zeros((out_size, in_size), np.float64)
+    for o in range(out_size):
+        in_loc_f = _f(_f(_f(o) + _f(0.5)) * scale) - _f(0.5)
+        in_loc = int(math.floor(in_loc_f))
+        delta = _f(in_loc_f - _f(in_loc))
+        offset = int(np.rint(_f(delta * _f(table))))
+        taps = [(in_loc - 1, co[offset * 2 + 1]), (in_loc, co[offset * 2]),
+                (in_loc + 1, co[(table - offset) * 2]), (in_loc + 2, co[(table - offset) * 2 + 1])]
+        w = [_f(wt) if _bound(i, in_size) == i else _f(0.0) for i, wt in taps]
+        tot = _f(_f(_f(w[0] + w[1]) + w[2]) + w[3])
+        if abs(tot) >= 1000.0 * np.finfo(np.float32).tiny:
+            inv = _f(1.0) / tot
+            w = [_f(v * inv) for v in w]
+        for (i, _), v in zip(taps, w):
+            m[o, _bound(i, in_size)] += float(v)
+    return m
+
+
+def resize_area_axis(in_size, out_size):
+    """ResizeArea: output o averages the input interval [o * scale, (o + 1) * scale) - boundary pixels by their covered
+    fraction, pixels in between whole, indices clamped - and the sum is divided by scale (resize_area_op.cc, per axis)."""
+    scale = _f(in_size) / _f(out_size)
+    m = np.zeros((out_size, in_size), np.float64)
+
+    def frac(v, lo, hi):
+        if v < lo:
+            return scale if v + 1 > hi else _f(v + 1 - lo)
+        return _f(hi - v) if v + 1 > hi else _f(1.0)
+
+    for o in range(out_size):
+        lo, hi = _f(o * scale), _f((o + 1) * scale)
+        for v in range(int(math.floor(lo)), int(math.ceil(hi))):
+            m[o, _bound(v, in_size)] += float(frac(v, lo, hi)) / float(scale)
+    return m
+
+
+def _sampling_kernel(name):
+    """(radius, f) of tensorflow/core/kernels/image/sampling_kernels.h; x >= 0, float32."""
+    pi = _f(3.14159265359)
+    if name in ('lanczos3', 'lanczos5'):
+        r = _f(3.0 if name == 'lanczos3' else 5.0)
+
+        def f(x):
+            if x > r:
+                return _f(0.0)
+            if x <= _f(1e-3):
+                return _f(1.0)
+            return _f(r * _f(np.sin(_f(pi * x))) * _f(np.sin(_f(_f(pi * x) / r))) / _f(_f(pi * pi) * _f(x * x)))
+        return r, f
+    if name == 'gaussian':
+        r, sigma = _f(1.5), _f(1.5) / _f(3.0)
+
+        def f(x):
+            return _f(0.0) if x >= r else _f(np.exp(-float(x) * float(x) / (2.0 * float(sigma) * float(sigma))))
+        return r, f
+    if name == 'mitchellcubic':
+        def f(x):
+            if x >= _f(2.0):
+                return _f(0.0)
+            if x >= _f(1.0):
+                return _f(_f(_f(_f(_f(_f(-7.0) / _f(18.0)) * x + _f(2.0)) * x - _f(10.0) / _f(3.0)) * x) + _f(16.0) / _f(9.0))
+            return _f(_f(_f(_f(_f(7.0) / _f(6.0)) * x - _f(2.0)) * x) * x + _f(8.0) / _f(9.0))
+        return _f(2.0), f
+    raise ValueError(name)
+
+
+def resize_scale_translate_axis(in_size, out_size, kernel):
+    """ScaleAndTranslate, antialias=False, translation 0 (ComputeSpansCore): the sample point of output o is (o + 0.5) / scale with
+    scale = out / in; the span is the input pixels whose centres lie within the kernel radius (NOT widened when down-sampling),
+    clamped to the image; weights kernel(|centre - sample|) normalised to sum 1."""
+    radius, kern = _sampling_kernel(kernel)
+    scale = _f(out_size) / _f(in_size)
+    inv_scale = _f(1.0) / scale
+    m = np.zeros((out_size, in_size), np.float64)
+    for o in range(out_size):
+        sample = _f(_f(_f(o) + _f(0.5)) * inv_scale)
+        if sample < 0 or sample > in_size:
+            continue
+        first = int(math.ceil(_f(_f(sample - radius) - _f(0.5))))
+        last = int(math.floor(_f(_f(sample + radius) - _f(0.5))))
+        first, last = min(max(first, 0), in_size - 1), min(max(last, 0), in_size - 1)
+        w = [kern(_f(abs(_f(_f(_f(src) + _f(0.5)) - sample)))) for src in range(first, last + 1)]
+        tot = _f(0.0)
+        for v in w:
+            tot = _f(tot + v)
+        if abs(tot) >= 1000.0 * np.finfo(np.float32).tiny:
+            inv = _f(1.0) / tot
+            for src, v in zip(range(first, last + 1), w):
+                m[o, src] = float(_f(v * inv))
+    return m
+
+
+RESIZE_AXIS = {'bicubic': resize_bicubic_axis, 'area': resize_area_axis}
+for _k in ('lanczos3', 'lanczos5', 'gaussian', 'mitchellcubic'):
+    RESIZE_AXIS[_k] = (lambda i, o, _k=_k: resize_scale_translate_axis(i, o, _k))
+
+
+def resize_separable(x, out_h, out_w, method):
+    """tf.image.resize(x, (out_h, out_w), method) for the methods of RESIZE_AXIS: rows then columns with the axis matrices."""
+    my = torch.tensor(RESIZE_AXIS[method](x.shape[1], out_h), dtype=x.dtype)
+    mx = torch.tensor(RESIZE_AXIS[method](x.shape[2], out_w), dtype=x.dtype)
+    return torch.einsum('oh,nhwc->nowc', my, torch.einsum('pw,nhwc->nhpc', mx, x))
+
+
 # ---------------------------------------------------------------------------------------------
 # colour spaces (tf.image.rgb_to_hsv / hsv_to_rgb; tensorflow/core/kernels/colorspace_op.h)
 def rgb_to_hsv(x):

@@ -757,11 +757,34 @@ def test_manipulations_general_forms(dev, name):
     assert_close(dx.cpu().numpy(), x.grad.numpy(), 2e-4, 3e-4, what=name + ' bwd')
 
 
+@pytest.mark.parametrize('factor', [50, 73, 130])
+@pytest.mark.parametrize('method', ['bicubic', 'area', 'lanczos3', 'lanczos5', 'gaussian', 'mitchellcubic'])
+def test_resample_with_every_resize_method(dev, method, factor):
+    """manipulation_resample(x, factor, method) for the method strings tf.image.resize takes besides bilinear / nearest
+    (helpers/tf_helpers.py:68-76 passes `method` through; VERDICT r04 missing 4): down and back up, forward and input gradient,
+    object and function forms, against the oracle's restatement of TensorFlow's kernels (oracle/tfops.py RESIZE_AXIS - built
+    independently of the product's helpers/kernels.py; TensorFlow itself is not in the image: parity unpinned, like every TF op)."""
+    from neural_imaging_amd.helpers import tf_helpers as th
+    x_np = natural_images(2, 40, 40, seed=13)
+    x = to64(x_np).requires_grad_(True)
+    xd = g(x_np, dev)
+    ref = om.manipulation_resample(x, factor, method)
+    op = th.Resample(method)
+    y, ctx = op.forward(xd, factor, training=True)
+    fn = th.manipulation_resample(xd, factor, method)
+    dy = rnd(tuple(ref.shape), 3)
+    (ref * to64(dy)).sum().backward()
+    assert_close(y.cpu().numpy(), ref.detach().numpy(), ATOL, what='{} {} fwd'.format(method, factor))
+    assert np.array_equal(fn.t.cpu().numpy(), y.cpu().numpy()), 'function and object forms differ'
+    dx = op.backward(ctx, g(dy, dev))
+    assert_close(dx.cpu().numpy(), x.grad.numpy(), 2e-4, 3e-4, what='{} {} bwd'.format(method, factor))
+
+
 def test_manipulations_unbuilt_forms_raise(dev):
     from neural_imaging_amd.helpers import tf_helpers as th
     x = g(natural_images(1, 16, 16, seed=2), dev)
     with pytest.raises(NotImplementedError):
-        th.manipulation_resample(x, 50, 'bicubic')
+        th.manipulation_resample(x, 50, 'trilinear')                         # not a tf.image.ResizeMethod either
     with pytest.raises(ValueError):
         th.manipulation_gaussian(x, 4, 1.0)
     with pytest.raises(RuntimeError):

@@ -348,3 +348,40 @@ def test_codec_channel_gradient_conditioning_under_bf16_weights():
             cos[k.split('/')[0]] = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
     assert all(cos[k] < 0.5 for k in ('ec51', 'ec52', 'dct1', 'ec41')), cos
     assert all(cos[k] > 0.9 for k in ('dc42', 'ec11', 'conv3', 'conv4', 'dense', 'e2', 'er2a', 'd256')), cos
+
+
+def test_resize_method_matrices_known_answers():
+    """The axis matrices of tf.image.resize's other methods (oracle/tfops.py RESIZE_AXIS) against values that follow from the
+    kernels' definitions by hand, and against the product's independent builder (helpers/kernels.py)."""
+    import importlib
+    importlib.import_module('neural-imaging_amd')
+    from neural_imaging_amd.helpers import kernels as hk
+    # Keys cubic a = -0.5 half-way between two pixels: (-1/16, 9/16, 9/16, -1/16); at the border the outside tap is dropped and
+    # the remaining three are renormalised by 1 / (1 + 1/16)
+    m = T.resize_bicubic_axis(16, 8)
+    assert np.allclose(m[3, 5:9], [-0.0625, 0.5625, 0.5625, -0.0625], atol=1e-7)
+    assert np.allclose(m[0, :3], np.array([0.5625, 0.5625, -0.0625]) / 1.0625, atol=1e-7)
+    assert np.array_equal(T.resize_bicubic_axis(9, 9), np.eye(9))
+    # area: 2:1 is the mean of two pixels, 1:2 repeats each pixel, 3:2 mixes thirds
+    assert np.array_equal(T.resize_area_axis(8, 4), np.kron(np.eye(4), [[0.5, 0.5]]))
+    assert np.array_equal(T.resize_area_axis(4, 8), np.kron(np.eye(4), [[1.0], [1.0]]))
+    assert np.allclose(T.resize_area_axis(3, 2), [[2 / 3, 1 / 3, 0], [0, 1 / 3, 2 / 3]], atol=1e-6)
+    # lanczos3 two-to-one WITHOUT antialiasing: taps at +-0.5, 1.5, 2.5 of L(x) = 3 sin(pi x) sin(pi x / 3) / (pi x)^2, normalised
+    lz = lambda x: 3 * np.sin(np.pi * x) * np.sin(np.pi * x / 3) / (np.pi * x) ** 2
+    w = np.array([lz(2.5), lz(1.5), lz(0.5), lz(0.5), lz(1.5), lz(2.5)])
+    assert np.allclose(T.resize_scale_translate_axis(32, 16, 'lanczos3')[7, 12:18], w / w.sum(), atol=1e-6)
+    # gaussian (sigma 0.5, radius 1.5) and Mitchell-Netravali at the same size are NOT the identity: taps at -1, 0, 1
+    gw = np.array([np.exp(-2.0), 1.0, np.exp(-2.0)])
+    assert np.allclose(T.resize_scale_translate_axis(12, 12, 'gaussian')[5, 4:7], gw / gw.sum(), atol=1e-6)
+    assert np.allclose(T.resize_scale_translate_axis(12, 12, 'mitchellcubic')[5, 4:7], [1 / 18, 8 / 9, 1 / 18], atol=1e-6)
+    for name, axis in T.RESIZE_AXIS.items():
+        for i, o in ((256, 128), (128, 256), (64, 46), (46, 64), (10, 3), (3, 10), (200, 31), (7, 7), (1, 4), (4, 1)):
+            a = axis(i, o)
+            assert np.allclose(a.sum(1), 1.0, atol=3e-6), (name, i, o)             # every output is a weighted mean
+            assert np.abs(a - hk.RESIZE_AXIS_MATRIX[name](i, o)).max() < 1e-6, (name, i, o)
+    # the manipulation (tf_helpers.py:68-76): constants stay constants, and the method reaches both resizes
+    x = torch.full((1, 12, 12, 3), 0.25, dtype=torch.float64)
+    for name in T.RESIZE_AXIS:
+        assert torch.allclose(om.manipulation_resample(x, 50, name), x, atol=1e-6), name
+    ramp = torch.linspace(0, 1, 12, dtype=torch.float64).view(1, 1, 12, 1).expand(1, 12, 12, 3)
+    assert not torch.allclose(om.manipulation_resample(ramp, 50, 'area'), om.manipulation_resample(ramp, 50, 'bicubic'), atol=1e-3)
