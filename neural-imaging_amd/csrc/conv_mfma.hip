@@ -492,6 +492,12 @@ int nimg_conv2d_fwd(const float* in1, int c1, const float* in2, int c2, const fl
         if (ks == 7) return dispatch_tiles<7, 1, 4>(p, vec, s);
         if (ks == 9) return dispatch_tiles<9, 1, 4>(p, vec, s);
         if (ks == 11) return dispatch_tiles<11, 1, 4>(p, vec, s);
+        // even sizes (the FAN's `kernel` is any integer 3 .. 11): TF's SAME padding puts the extra row / column AFTER the image -
+        // the pads are explicit arguments here, so it is the same kernel (the input gradient takes pads KS - 1 - pad)
+        if (ks == 4) return dispatch_tiles<4, 1, 8>(p, vec, s);
+        if (ks == 6) return dispatch_tiles<6, 1, 4>(p, vec, s);
+        if (ks == 8) return dispatch_tiles<8, 1, 4>(p, vec, s);
+        if (ks == 10) return dispatch_tiles<10, 1, 4>(p, vec, s);
     } else if (stride == 2) {
         if (ks == 2) return dispatch_tiles<2, 2, 16>(p, vec, s);
         if (ks == 5) return dispatch_tiles<5, 2, 8>(p, vec, s);

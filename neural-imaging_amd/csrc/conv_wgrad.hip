@@ -482,6 +482,10 @@ int nimg_conv2d_wgrad(const float* in1, int c1, const float* in2, int c2, const 
     else if (stride == 1 && ks == 5) NIMG_WG(5, 1);
     else if (stride == 2 && ks == 2) NIMG_WG(2, 2);
     else if (stride == 2 && ks == 5) NIMG_WG(5, 2);
+    else if (stride == 1 && ks == 4) NIMG_WG(4, 1);
+    else if (stride == 1 && ks == 6) NIMG_WG_BIG(6);
+    else if (stride == 1 && ks == 8) NIMG_WG_BIG(8);
+    else if (stride == 1 && ks == 10) NIMG_WG_BIG(10);
     else if (stride == 1 && ks == 7) NIMG_WG_BIG(7);
     else if (stride == 1 && ks == 9) NIMG_WG_BIG(9);
     else if (stride == 1 && ks == 11) NIMG_WG_BIG(11);

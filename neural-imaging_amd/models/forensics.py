@@ -55,9 +55,8 @@ class FAN(TFModel):
         self.dropout_masks = None
         if not use_gap and patch_size is None:
             raise ValueError('the Flatten head (use_gap=False) needs a fixed patch_size')
-        if self._h.kernel % 2 == 0:
-            # the reference's range is any integer 3 .. 11 (forensics.py:51); TF's SAME padding of an even kernel is asymmetric
-            raise NotImplementedError('even kernel size {} not built (3, 5, 7, 9, 11)'.format(self._h.kernel))
+        # the reference's range is any integer 3 .. 11 (forensics.py:51): 3 and 5 have the throughput-mode kernels, the others run on
+        # the generic float32 ones; an even kernel's SAME padding is TF's (the extra row / column after the image)
         self.patch_size = patch_size
         self.x = _Shape((None, patch_size, patch_size, 3))
         self.y = _Shape((None, n_classes))

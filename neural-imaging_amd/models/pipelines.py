@@ -267,7 +267,8 @@ class INet(NIPModel):
         self._h.update(random_init=random_init, kernel=kernel, trainable_upsampling=trainable_upsampling,
                        cfa_pattern=cfa_pattern)
         if self._h.kernel % 2 == 0:
-            raise NotImplementedError('even demosaicing kernel {} not built (3, 5, 7, 9, 11)'.format(self._h.kernel))
+            raise NotImplementedError('even demosaicing kernel {}: the reference pads (k - 1) // 2 and convolves VALID - its output '
+                                      'is one pixel short of the target; 3, 5, 7, 9, 11 are built'.format(self._h.kernel))
         if self.in_channels != 4:
             raise ValueError('INet develops 4-plane RAW input')
         k = self._h.kernel
@@ -450,7 +451,8 @@ class ClassicISP(NIPModel):
         })
         self._h.update(kernel=kernel, c_filters=tuple(c_filters), cfa_pattern=cfa_pattern, residual=residual)
         if self._h.kernel % 2 == 0:
-            raise NotImplementedError('even demosaicing kernel {} not built (3, 5, 7, 9, 11)'.format(self._h.kernel))
+            raise NotImplementedError('even demosaicing kernel {}: the reference pads (k - 1) // 2 and convolves VALID - its output '
+                                      'is one pixel short of the target; 3, 5, 7, 9, 11 are built'.format(self._h.kernel))
         if self.in_channels != 4:
             raise ValueError('ClassicISP develops 4-plane RAW input')
         k, res = self._h.kernel, self._h.residual

@@ -416,11 +416,11 @@ def conv2d(x, w, bias=None, x2=None, stride=1, padding='SAME', act=None, pad_mod
     copy = None
     if mask_conv_layout and not d2s_out:
         raise ValueError('mask_conv_layout only has a meaning with d2s_out')
-    if w.shape[0] > 5:
-        # 7x7 ... 11x11 (FAN `kernel`, forensics.py:51; demosaicing filters, pipelines.py:242,419): the float32 matrix-core kernels
-        # in either compute mode - the throughput-mode kernels are built for the channel's own 1x1 / 2x2 / 3x3 / 5x5 layers
+    if w.shape[0] not in (1, 2, 3, 5):
+        # 4x4, 6x6 ... 11x11 (FAN `kernel`, forensics.py:51; demosaicing filters, pipelines.py:242,419): the float32 matrix-core
+        # kernels in either compute mode - the throughput-mode kernels are built for the channel's own 1x1 / 2x2 / 3x3 / 5x5 layers
         if w.shape[0] not in BIG_KERNELS or stride != 1:
-            raise NotImplementedError('convolution kernel size {} (stride {}) is not built: 1, 2, 3, 5, 7, 9, 11'.format(
+            raise NotImplementedError('convolution kernel size {} (stride {}) is not built: 1 ... 11 at stride 1'.format(
                 w.shape[0], stride))
         _f32_only = True
     if s2d_out:
@@ -655,9 +655,9 @@ def conv2d_wgrad(x, dz, ks, x2=None, stride=1, padding='SAME', pad_mode=0, pads=
     if dw is None:
         dw = torch.empty((ks, ks, c1 + c2, cout), dtype=torch.float32, device=x.device)
     packed_ok = c2 == 0 and c1 in (3, 4) and stride == 1 and ks in (3, 5)
-    if ks > 5 and (ks not in BIG_KERNELS or stride != 1):
+    if ks not in (1, 2, 3, 5) and (ks not in BIG_KERNELS or stride != 1):
         raise NotImplementedError('weight gradient for kernel size {} (stride {}) is not built'.format(ks, stride))
-    if COMPUTE == 'bf16' and ks <= 5 and (packed_ok or (c1 % 4 == 0 and c2 % 4 == 0 and cout % 4 == 0 and c1 + c2 >= 8 and
+    if COMPUTE == 'bf16' and ks in (1, 2, 3, 5) and (packed_ok or (c1 % 4 == 0 and c2 % 4 == 0 and cout % 4 == 0 and c1 + c2 >= 8 and
                                             (c2 == 0 or c1 % 8 == 0))):
         need = _lib.load().nimg_conv2d_wgrad_bf16_workspace_bytes(c1 + c2, cout, ks, ks, n, ho, wo)
         flags = (BF16_IN if _is_bf16(x) else 0) | (BF16_DZ if _is_bf16(dz) else 0)
@@ -1783,7 +1783,7 @@ def tanh_bwd(dy, y, out=None):
 
 
 ACTIVATIONS = {'leaky_relu': 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3, 'softsign': 4}     # helpers/tf_helpers.py:22-28
-BIG_KERNELS = (7, 9, 11)           # kernel sizes above 5x5 served by the generic float32 kernels (conv_mfma.hip / conv_wgrad.hip)
+BIG_KERNELS = (4, 6, 7, 8, 9, 10, 11)    # kernel sizes served by the generic float32 kernels only (conv_mfma.hip / conv_wgrad.hip)
 
 
 def activation(x, kind, out=None):

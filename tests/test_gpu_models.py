@@ -176,12 +176,13 @@ def test_fan_forward_backward(dev):
     assert dec.shape == (5,) and (dec == probs_ref.detach().numpy().argmax(axis=1)).all()
 
 
-@pytest.mark.parametrize('kernel', [7, 9, 11])
+@pytest.mark.parametrize('kernel', [7, 9, 11, 4, 6, 8, 10])
 def test_fan_large_kernels(dev, kernel):
-    """FAN(kernel = 7 | 9 | 11) (forensics.py:51 allows 3 .. 11): the generic float32 matrix-core kernels (conv_mfma.hip with a
-    4-channel K chunk, conv_wgrad.hip in tap passes) behind the same layer code; probabilities, every parameter gradient and
-    the input gradient against the float64 oracle, then the same model in throughput mode (the large kernels stay float32
-    there) and one training step."""
+    """FAN(kernel = 4, 6 ... 11) (forensics.py:51 allows any integer 3 .. 11): the generic float32 matrix-core kernels
+    (conv_mfma.hip with a 4-channel K chunk, conv_wgrad.hip in tap passes) behind the same layer code; probabilities, every
+    parameter gradient and the input gradient against the float64 oracle, then the same model in throughput mode (these kernel
+    sizes stay float32 there) and one training step.  Even sizes: Keras' SAME padding puts the extra row / column after the image
+    (oracle/tfops.py same_pads), the input gradient pads the other way round."""
     from neural_imaging_amd import ops
     from neural_imaging_amd.models import forensics
     fan = forensics.FAN(n_classes=4, patch_size=64, kernel=kernel, n_filters=8, device=dev)
@@ -219,11 +220,13 @@ def test_fan_large_kernels(dev, kernel):
 
 
 def test_even_kernel_sizes_are_refused_loudly(dev):
-    from neural_imaging_amd.models import forensics, pipelines
-    with pytest.raises(NotImplementedError):
-        forensics.FAN(n_classes=4, patch_size=64, kernel=6, device=dev)
+    """INet / ClassicISP pad REFLECT by (kernel - 1) // 2 and convolve VALID (models/pipelines.py:277-280 of the reference): an even
+    kernel returns images one pixel short of the targets the reference's own loss compares them with - nothing to match, refused."""
+    from neural_imaging_amd.models import pipelines
     with pytest.raises(NotImplementedError):
         pipelines.INet(patch_size=24, kernel=8, device=dev)
+    with pytest.raises(NotImplementedError):
+        pipelines.ClassicISP(patch_size=24, kernel=4, device=dev)
 
 
 @pytest.mark.parametrize('n_classes', [24, 200])
