@@ -48,9 +48,21 @@ def init_from_env(backend=None):
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     if ws <= 1:                               # forced one-rank group: no launcher has set the rendezvous variables
-        os.environ.setdefault('MASTER_PORT', str(_free_port()))
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
+        if 'MASTER_PORT' not in os.environ:
+            # the port is OURS to pick: between _free_port() closing its probe socket and the store listening on the number,
+            # another process can take it (seen on a GPU box: EADDRINUSE) - pick again instead of failing the run
+            for attempt in range(8):
+                os.environ['MASTER_PORT'] = str(_free_port())
+                try:
+                    dist.init_process_group(backend=backend)
+                    return ws
+                except Exception as e:                                    # noqa (DistNetworkError is a RuntimeError subclass)
+                    in_use = 'EADDRINUSE' in str(e) or 'address already in use' in str(e).lower()
+                    if not in_use or attempt == 7:
+                        del os.environ['MASTER_PORT']
+                        raise
     dist.init_process_group(backend=backend)
     return ws
 

@@ -11,7 +11,7 @@ from oracle import nets as onets
 from oracle import tfops as T
 from oracle import workflow as owf
 
-from util import assert_close, bayer_from_rgb, natural_images, to64
+from util import assert_close, bayer_from_rgb, collect_from_workers, natural_images, to64
 
 pytestmark = pytest.mark.gpu
 
@@ -1559,19 +1559,10 @@ def test_data_parallel_step_equals_global_batch(dev, codec):
     g_ref, p_ref = channel_state(wf)
     ref = (float(parts['ce']), float(parts['nip']), float(parts['dcn']))
     del wf
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    procs = [ctx.Process(target=dp_step_worker, args=(r, 2, port, q, codec, raw, rgb)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted((q.get(timeout=600) for _ in range(2)), key=lambda r: r[0])
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    res, procs = collect_from_workers(
+        lambda ctx, port, q: [ctx.Process(target=dp_step_worker, args=(r, 2, port, q, codec, raw, rgb)) for r in range(2)], 2, 600)
+    res = sorted(res, key=lambda r: r[0])
+    assert all(p.exitcode == 0 for p in procs)
     # CE and the NIP loss are means over the rank's shard: their rank average is the global-batch value
     assert abs(0.5 * (res[0][1] + res[1][1]) - ref[0]) < 1e-5 * max(1.0, abs(ref[0]))
     assert abs(0.5 * (res[0][2] + res[1][2]) - ref[1]) < 1e-5 * max(1.0, abs(ref[1]))
@@ -1596,13 +1587,9 @@ def test_data_parallel_step_nccl_world1(dev, codec, mode):
     from dp_worker import dp_nccl_world1_worker
     rgb = natural_images(4, 64, 64, seed=22)
     raw = bayer_from_rgb(rgb)
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    p = ctx.Process(target=dp_nccl_world1_worker, args=(q, codec, raw, rgb, mode))
-    p.start()
-    out = q.get(timeout=600)
-    p.join(timeout=120)
-    assert p.exitcode == 0
+    (out,), procs = collect_from_workers(
+        lambda ctx, port, q: [ctx.Process(target=dp_nccl_world1_worker, args=(q, codec, raw, rgb, mode))], 1, 600)
+    assert procs[0].exitcode == 0
     (l0, g0, p0), (l1, g1, p1) = out['plain'], out['nccl']
     exact = codec == 'jpeg'
     for a, b in zip(l0, l1):

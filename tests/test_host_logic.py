@@ -14,6 +14,7 @@ import torch
 from oracle import tfops as T
 
 from neural_imaging_amd import ops, parallel
+from util import collect_from_workers
 from neural_imaging_amd.helpers import kernels as hk
 from neural_imaging_amd.helpers.paramspec import ParamSpec
 from neural_imaging_amd.models import forensics, jpeg, pipelines
@@ -352,20 +353,10 @@ def test_host_dataset_from_directory_and_arrays(tmp_path):
 def _run_dp_workers(world):
     import torch.multiprocessing as mp
     from dp_worker import dp_worker
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    procs = [ctx.Process(target=dp_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=180) for _ in range(world))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    return res
+    res, procs = collect_from_workers(
+        lambda ctx, port, q: [ctx.Process(target=dp_worker, args=(r, world, port, q)) for r in range(world)], world, 180)
+    assert all(p.exitcode == 0 for p in procs)
+    return sorted(res)
 
 
 @pytest.mark.parametrize('world', [2, 8])
@@ -391,12 +382,43 @@ def test_forced_collectives_at_world_size_one():
     """parallel.force_collectives(): a one-rank group whose collectives really run (the hook the nccl world-1 GPU test and
     bench.py's dp1_nccl leg use) - sum over one rank is the identity, the world size stays 1 (Adam scale 1)."""
     import torch.multiprocessing as mp
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
     from dp_worker import forced_world1_worker
-    p = ctx.Process(target=forced_world1_worker, args=(q,))
-    p.start()
-    ok, flat, flag, drawn, world = q.get(timeout=120)
-    p.join(timeout=60)
-    assert p.exitcode == 0 and ok
+    ((ok, flat, flag, drawn, world),), procs = collect_from_workers(
+        lambda ctx, port, q: [ctx.Process(target=forced_world1_worker, args=(q,))], 1, 120)
+    assert procs[0].exitcode == 0 and ok
     assert flat == [float(i) for i in range(10)] and flag == 1 and drawn == [0.5, 2.0] and world == 1
+
+
+def test_forced_one_rank_group_picks_another_port_when_its_pick_is_taken(monkeypatch):
+    """parallel.init_from_env for a forced one-rank group chooses the rendezvous port itself; between probing a free number and the
+    store listening on it another process can take it (EADDRINUSE, seen on a GPU box during test_data_parallel_step_nccl_world1):
+    it picks again.  A port the LAUNCHER set is never second-guessed, and any other error passes through."""
+    calls = []
+
+    def fake_init(backend=None):
+        calls.append(os.environ['MASTER_PORT'])
+        if len(calls) < 3:
+            raise RuntimeError('The server socket has failed to listen on any local network address. port: {}, useIpv6: false, '
+                               'code: -98, name: EADDRINUSE, message: address already in use'.format(calls[-1]))
+
+    for k in ('MASTER_PORT', 'RANK', 'WORLD_SIZE'):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(parallel.dist, 'init_process_group', fake_init)
+    monkeypatch.setattr(parallel, '_FORCE', True)
+    assert parallel.init_from_env('gloo') == 1
+    assert len(calls) == 3 and os.environ['MASTER_PORT'] == calls[-1]
+    # a port given by the launcher: one attempt, the error is the caller's
+    calls.clear()
+    monkeypatch.setenv('MASTER_PORT', '29500')
+    with pytest.raises(RuntimeError):
+        parallel.init_from_env('gloo')
+    assert calls == ['29500']
+    # an error that is not about the port: no retry
+    monkeypatch.delenv('MASTER_PORT')
+    calls.clear()
+    monkeypatch.setattr(parallel.dist, 'init_process_group', lambda backend=None: (_ for _ in ()).throw(ValueError('bad backend')))
+    with pytest.raises(ValueError):
+        parallel.init_from_env('gloo')
+    assert 'MASTER_PORT' not in os.environ
+    for k in ('RANK', 'WORLD_SIZE'):
+        os.environ.pop(k, None)

@@ -100,3 +100,50 @@ def bayer_from_rgb_t(rgb):
     """bayer_from_rgb() for a torch tensor (N,h,w,3) on any device."""
     return torch.stack([rgb[:, 0::2, 0::2, 1], rgb[:, 0::2, 1::2, 2], rgb[:, 1::2, 0::2, 0], rgb[:, 1::2, 1::2, 1]],
                        dim=-1).contiguous()
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def collect_from_workers(make_procs, n_results, timeout, attempts=3):
+    """Start the processes make_procs(port, queue) returns and collect n_results answers from the queue.  A worker that dies
+    without answering ends the wait at once (not after `timeout`), and - because the rendezvous port is probed, released and only
+    then listened on by rank 0, so another process can take it in between - the whole group is started again on a fresh port, up to
+    `attempts` times.  Returns (results, procs) with every process joined."""
+    import queue
+    import time
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    last = None
+    for _ in range(attempts):
+        q = ctx.Queue()
+        procs = make_procs(ctx, free_port(), q)
+        for p in procs:
+            p.start()
+        res, deadline = [], time.monotonic() + timeout
+        while len(res) < n_results:
+            try:
+                res.append(q.get(timeout=1.0))
+            except queue.Empty:
+                if any(p.exitcode not in (None, 0) for p in procs):
+                    try:                                                   # an answer put just before the exit
+                        res.append(q.get(timeout=0.5))
+                        continue
+                    except queue.Empty:
+                        break
+                if time.monotonic() > deadline:
+                    break
+        if len(res) == n_results:
+            for p in procs:
+                p.join(timeout=120)
+            return res, procs
+        last = [p.exitcode for p in procs]
+        for p in procs:                                                    # exactly the processes started here
+            if p.is_alive():
+                p.kill()
+            p.join(timeout=30)
+    raise RuntimeError('workers did not answer in {} attempt(s); exit codes of the last one: {}'.format(attempts, last))
