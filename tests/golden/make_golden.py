@@ -64,8 +64,8 @@ def main():
     # 3. constant kernels (helpers/kernels.py)
     for cfa in ('gbrg', 'rggb', 'bggr'):
         g['upk_' + cfa] = kernels.upsampling_kernel(cfa).astype(np.float64)
-    g['bilin3'] = kernels.bilin_kernel(3).astype(np.float64)
-    g['bilin5'] = kernels.bilin_kernel(5).astype(np.float64)
+    for k in (3, 5, 7, 9, 11):                                     # INet / ClassicISP `kernel` (models/pipelines.py:242,419)
+        g['bilin%d' % k] = kernels.bilin_kernel(k).astype(np.float64)
     d1k, d1b, d2k, d2b = kernels.gamma_kernels()
     g['gamma_d1k'], g['gamma_d1b'], g['gamma_d2k'], g['gamma_d2b'] = d1k, d1b, d2k, d2b
     for std in (0.5, 0.83, 1.0, 3.0, 7.0):
