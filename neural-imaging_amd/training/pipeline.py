@@ -2,7 +2,9 @@
 NIP pre-training loop - counterpart of the reference's training/pipeline.py:105-256: lr schedule
 dict {epoch: lr} (default {0: 1e-4}), per-batch model.training_step(bx, by, lr), validation every
 `validation_schedule` epochs (PSNR / loss), lr x0.95 when the validation loss exceeds 1.2 x its best (:224-227), early
-stop on a converged validation loss (:230-238), progress.json + checkpoint, `resume` reloads weights + progress.
+stop on a converged validation loss (:230-238), progress.json + checkpoint, `resume` reloads weights + progress (and continues
+with the epoch AFTER the recorded one - the reference restarts at the recorded epoch itself and logs it twice, :155).
+train_nip_bare (:259-302): the same loop without validation, logging or files.
 """
 import json
 import os
@@ -39,7 +41,9 @@ def train_nip_model(model, camera_name, n_epochs=10000, lr_schedule=None, valida
     if os.path.exists(out_directory) and not resume:
         return out_directory
     start_epoch = 0
-    if resume and os.path.isfile(os.path.join(out_directory, 'progress.json')):
+    if resume:
+        if not os.path.isfile(os.path.join(out_directory, 'progress.json')):
+            raise FileNotFoundError('Could not open file {}'.format(os.path.join(out_directory, 'progress.json')))
         model.load_model(out_directory)
         with open(os.path.join(out_directory, 'progress.json')) as f:
             prog = json.load(f)
@@ -93,7 +97,33 @@ def train_nip_model(model, camera_name, n_epochs=10000, lr_schedule=None, valida
                 if abs((current - previous) / previous) < validation_loss_threshold:
                     break
     summary['Epoch'] = epoch
+    vl = model.performance['loss']['validation']
+    keep = not save_best or (len(vl) > 0 and vl[-1] <= min(vl))
+    if keep:
+        summary['Saved checkpoint'] = epoch
     if rank == 0:
-        model.save_model(out_directory, epoch, quiet=True)
+        if keep:
+            model.save_model(out_directory, epoch, quiet=True)
         save_progress(model, summary, out_directory)
+    return out_directory
+
+
+def train_nip_bare(model, camera_name, n_epochs=10000, lr_schedule=None, validation_loss_threshold=1e-3,
+                   validation_schedule=100, resume=False, patch_size=64, batch_size=20, data=None,
+                   out_directory_root='./data/models/nip', save_best=False, discard='flat'):
+    """The bare loop of the reference (training/pipeline.py:259-302): training steps only, at a learning rate of 1e-3 (the
+    schedule argument is accepted and, as there, never consulted), from a Dataset or from any iterable of (x, y) batches."""
+    out_directory = os.path.join(out_directory_root, camera_name, model.model_code, model.scoped_name)
+    learning_rate = 1e-3
+    world, rank = parallel.world_size(), parallel.rank()
+    for _ in range(n_epochs):
+        if hasattr(data, 'next_training_batch'):
+            batches = (data.next_training_batch(b, batch_size, patch_size, discard=discard)
+                       for b in range(data.count_training // batch_size))
+        else:
+            batches = iter(data)
+        for bx, by in batches:
+            if world > 1:
+                bx, by = parallel.shard_batch(bx, rank, world), parallel.shard_batch(by, rank, world)
+            model.training_step(bx, by, learning_rate)
     return out_directory

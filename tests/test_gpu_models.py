@@ -1503,6 +1503,17 @@ def test_nip_pretraining_harness(dev, tmp_path, feed):
     assert prog2['performance']['loss']['training'][6] < perf['loss']['training'][0]            # resumed, not restarted
     with pytest.raises(ValueError):
         tp.train_nip_model(net, 'synthetic', patch_size=32, batch_size=16, data=data, out_directory_root=str(tmp_path))
+    with pytest.raises(FileNotFoundError):              # resume without a progress.json to resume from (training/pipeline.py:141-142)
+        tp.train_nip_model(net, 'nowhere', n_epochs=1, patch_size=32, batch_size=4, data=data, resume=True,
+                           out_directory_root=str(tmp_path))
+    # the bare loop (:259-302): steps only, from the Dataset and from an iterable of batches
+    net3 = pipelines.UNet(patch_size=16, device=dev)
+    bx, by = data.next_training_batch(0, 4, 32, discard=None)
+    l0 = float(net3.training_step(bx, by, 0.0))
+    assert tp.train_nip_bare(net3, 'synthetic', n_epochs=3, patch_size=32, batch_size=4, data=data, discard=None,
+                             out_directory_root=str(tmp_path)).endswith(os.path.join('synthetic', net3.model_code, 'unet'))
+    tp.train_nip_bare(net3, 'synthetic', n_epochs=2, data=[(bx, by)] * 2)
+    assert float(net3.training_step(bx, by, 0.0)) < l0
 
 
 @pytest.mark.parametrize('feed', ['host', 'device'])
