@@ -14,7 +14,7 @@ from collections import OrderedDict, deque
 import numpy as np
 
 from .. import parallel
-from ..models import compression
+from ..models import compression, jpeg
 from . import validation
 
 
@@ -153,6 +153,11 @@ def train_manipulation_nip(flow, training, data, directories=None, overwrite=Fal
         if codec_is_dcn:
             for metric, value in validation.validate_dcn(flow.codec, data, save_dir, epoch=epoch).items():
                 flow.codec.log_metric(metric, 'validation', value)
+        elif flow.is_trainable('dcn') and isinstance(flow.codec, jpeg.JPEG) and not final:      # trainable tables (:241-242)
+            for metric, value in validation.validate_jpeg(flow.codec, data).items():
+                flow.codec.log_metric(metric, 'validation', value)
+        elif flow.is_trainable('dcn') and not final:
+            raise NotImplementedError('Validation for {} codec doesn\'t seem to be implemented'.format(flow.codec))
         if rank != 0:
             return
         validation.save_training_progress(summary, flow, save_dir, quiet=True)

@@ -9,6 +9,7 @@ kernels - and reads the results back ONCE at the end of the pass.  What callers 
   validate_fan(flow, data[, get_labels]) -> (accuracy, confusion / n_patches[, predicted labels])       (:163-202)
   validate_nip(model, data, ...)         -> (ssims, psnrs, losses), one value per validation patch        (:96-160)
   validate_dcn(dcn, data, ...)           -> {'ssim', 'psnr', 'loss', 'entropy'} over the whole validation set (:44-93)
+  validate_jpeg(jpeg, data[, batch_size])-> {'psnr', 'ssim', 'entropy'}: the differentiable JPEG codec (trainable tables) (:19-41)
   save_training_progress(...)            -> <root>/training.json with the reference's keys               (:301-352)
 The matplotlib dashboards of the reference (figures per epoch) are not produced.
 """
@@ -92,6 +93,28 @@ def validate_dcn(dcn, data, out_directory=None, savefig=False, epoch=0, show_ref
     packed = torch.stack([ssim, psnr, l2, ent.t.double().reshape(())]).cpu().numpy()
     return {'ssim': float(packed[0]), 'psnr': float(packed[1]),
             'loss': float(packed[2] + dcn._h.entropy_weight * packed[3]), 'entropy': float(packed[3])}
+
+
+def validate_jpeg(jpeg, data, batch_size=1):
+    """Mean SSIM / PSNR of the differentiable JPEG codec over the validation images, `batch_size` at a time (the tail dropped);
+    the entropy is NaN, as JPEG.process reports it (models/jpeg.py:245-249)."""
+    from ..models.jpeg import JPEG
+    if not isinstance(jpeg, JPEG):
+        raise ValueError('Codec needs to be as instance of {} but is {}'.format(JPEG, getattr(jpeg, 'class_name', type(jpeg))))
+    batch_size = int(min(batch_size, data.count_validation))
+    ssims, psnrs, ents = [], [], []
+    for b in range(data.count_validation // batch_size):
+        bx = data.next_validation_batch(b, batch_size)
+        target = to_device(bx[-1] if isinstance(bx, tuple) else bx, jpeg.device)
+        y, ent = jpeg.process(target, return_entropy=True)
+        y = y.t
+        ssims.append(ops.ssim(y.clamp(0.0, 1.0).contiguous(), target, mode='skimage', max_val=1.0).double())
+        psnrs.append(_psnr_device(y, target))
+        ents.append(ent)
+    if not ssims:
+        return {'psnr': float('nan'), 'ssim': float('nan'), 'entropy': float('nan')}
+    packed = torch.stack([torch.cat(ssims).mean(), torch.cat(psnrs).mean()]).cpu().numpy()
+    return {'psnr': float(packed[1]), 'ssim': float(packed[0]), 'entropy': float(np.mean(ents))}
 
 
 def _model_record(model, with_args=True):
