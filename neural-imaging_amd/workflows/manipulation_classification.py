@@ -214,6 +214,21 @@ class ManipulationClassification(object):
     def run_manipulations(self, batch_y, randomize=False, override=None):
         return DeviceArray(self._manipulations(to_device(batch_y, self.device), randomize, override)[0])
 
+    def manipulations_timing(self, batch_y):
+        """{operation: seconds} of one application of every manipulation at its default strength (workflows/...:210-221).  The
+        launches are asynchronous here: the device is drained before and after each one, so the figures are kernel time, not
+        the time to queue a launch."""
+        from datetime import datetime
+        Y = to_device(batch_y, self.device)
+        times = {}
+        for name, op in self._operations.items():
+            torch.cuda.synchronize(self.device)
+            d1 = datetime.now()
+            op.forward(Y, self._strengths[name])
+            torch.cuda.synchronize(self.device)
+            times[name] = (datetime.now() - d1).total_seconds()
+        return times
+
     def run_downsampling(self, batch_y):
         return DeviceArray(self._downsampling(to_device(batch_y, self.device)))
 

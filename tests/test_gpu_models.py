@@ -589,6 +589,8 @@ def test_workflow_augmentation_strengths(dev):
     np.random.seed(5)
     loss, _ = wf.training_step(raw, rgb, lambda_nip=0.1, augment=True, learning_rate=1e-4)
     assert np.isfinite(float(loss))
+    times = wf.manipulations_timing(wf.nip.process(raw))                  # workflows/...:210-221
+    assert list(times.keys()) == list(wf._operations.keys()) and all(0 < t < 5 for t in times.values())
 
 
 def test_workflow_augmentation_draws_match_the_reference_order(dev):
