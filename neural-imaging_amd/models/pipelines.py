@@ -7,6 +7,7 @@ UNet graph (pipelines.py:190-223): encoder n=1..5: 2 x [Conv3x3 SAME, 32*2^(n-1)
 n=5); decoder n=1..4: ConvT 2x2 s2 -> concat(up, skip) [never materialised: the conv reads two tensors] -> 2 x
 Conv3x3+LReLU; Conv3x3 -> 12 (linear) -> depth_to_space(2) -> straight-through clip.
 """
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -95,9 +96,26 @@ class NIPModel(TFModel):
     def patch_size_rgb(self):
         return self.y.shape[1:]
 
+    @property
+    def _input_description(self):
+        return utils.format_patch_shape(self.patch_size_raw)
+
+    @property
+    def _output_description(self):
+        return utils.format_patch_shape(self.patch_size_rgb)
+
     def summary(self):
-        return '{:s} : {} -> {}'.format(super().summary(), utils.format_patch_shape(self.patch_size_raw),
-                                        utils.format_patch_shape(self.patch_size_rgb))
+        return '{:s} : {} -> {}'.format(super().summary(), self._input_description, self._output_description)
+
+    def load_model(self, dirname, quiet=False):
+        if '/' not in dirname:                           # a bare camera / model name lives under the NIP snapshot root (:133-136)
+            dirname = os.path.join('data/models/nip', dirname)
+        super().load_model(dirname, quiet=quiet)
+
+    def save_model(self, dirname, epoch=0, save_args=False, quiet=False):
+        if '/' not in dirname:
+            dirname = os.path.join('data/models/nip', dirname)
+        super().save_model(dirname, epoch=epoch, save_args=save_args, quiet=quiet)
 
 
 class _Placeholder(object):
@@ -450,9 +468,10 @@ class ClassicISP(NIPModel):
             'residual': (True, bool, None),
         })
         self._h.update(kernel=kernel, c_filters=tuple(c_filters), cfa_pattern=cfa_pattern, residual=residual)
-        if self._h.kernel % 2 == 0:
-            raise NotImplementedError('even demosaicing kernel {}: the reference pads (k - 1) // 2 and convolves VALID - its output '
-                                      'is one pixel short of the target; 3, 5, 7, 9, 11 are built'.format(self._h.kernel))
+        if self._h.kernel % 2 == 0 and self._h.residual:
+            # (residual=False has no bilinear branch: its k x k layers are Keras 'same' convolutions, models/layers.py:229 - built)
+            raise NotImplementedError('even demosaicing kernel {} with the bilinear residual: the reference pads (k - 1) // 2 and '
+                                      'convolves VALID - its output is one pixel short of the target'.format(self._h.kernel))
         if self.in_channels != 4:
             raise ValueError('ClassicISP develops 4-plane RAW input')
         k, res = self._h.kernel, self._h.residual
@@ -527,6 +546,18 @@ class ClassicISP(NIPModel):
         return 'ClassicISP_{cfa}_{k}x{k}_{fs}-{of}{r}'.format(
             fs='-'.join(['{:d}'.format(x) for x in self._h.c_filters]), of=3, k=self._h.kernel,
             cfa=self._h.cfa_pattern, r='R' if self._h.residual else '')
+
+    def summary(self):                                   # pipelines.py:529-533
+        nf = len(self._h.c_filters)
+        fs = self._h.c_filters[0] if len(set(self._h.c_filters)) == 1 else '*'
+        k = self._h.kernel
+        return '{}[{}] + CNN demosaicing [{}+1 layers : {k}x{k}x{} -> 1x1x3]'.format(self.class_name, self._h.cfa_pattern, nf, fs, k=k)
+
+    def summary_compact(self):                           # pipelines.py:535-539
+        nf = len(self._h.c_filters)
+        fs = self._h.c_filters[0] if len(set(self._h.c_filters)) == 1 else '*'
+        k = self._h.kernel
+        return '{}[{}, {}+1 conv2D {k}x{k}x{} > 1x1x3]'.format(self.class_name, self._h.cfa_pattern, nf, fs, k=k)
 
     @classmethod
     def restore(cls, dir_name='data/models/isp/ClassicISP_auto_3x3_32-32-32-32-3R/', *, camera=None, cfa=None, srgb=None,

@@ -130,6 +130,13 @@ class TFModel(object):
     def count_parameters(self):
         return int(sum(int(p.numel()) for p in self.parameters))
 
+    def count_parameters_breakdown(self):
+        """One row per parameter tensor: name, shape, number of values, share of the total in per cent (tfmodel.py:144-148)."""
+        import pandas as pd
+        total = max(self.count_parameters(), 1)
+        rows = [(k, tuple(v.shape), int(v.numel()), round(100 * int(v.numel()) / total, 1)) for k, v in self._model.p.items()]
+        return pd.DataFrame(rows, columns=['name', 'shape', 'parameters', 'total'])
+
     def state_dict(self):
         return OrderedDict((k, v.detach().cpu().numpy()) for k, v in self._model.p.items())
 
@@ -206,6 +213,14 @@ class TFModel(object):
             with np.load(legacy) as data:
                 self.load_state_dict({k: data[k] for k in data.files})
         self.reset_performance_stats()
+
+    def migrate_model(self, dirname, mapping=None, verbose=False):
+        """The reference reads variables out of a TensorFlow CHECKPOINT by name (tf.train.list_variables / load_variable,
+        tfmodel.py:184-230); no TensorFlow here to parse one - Keras .h5 weight files load through load_model."""
+        raise NotImplementedError('TensorFlow checkpoints cannot be read here (no TensorFlow); load_model reads the .h5 weights')
+
+    def deploy_model(self, dirname):
+        raise NotImplementedError()                      # as in the reference (tfmodel.py:292-294: a TODO there)
 
     @classmethod
     def restore(cls, dir_name, *, key=None, patch_size=None, **kwargs):

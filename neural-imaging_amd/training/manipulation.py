@@ -14,6 +14,7 @@ from collections import OrderedDict, deque
 import numpy as np
 
 from .. import parallel
+from ..helpers import utils
 from ..models import compression, jpeg
 from . import validation
 
@@ -121,17 +122,26 @@ def train_manipulation_nip(flow, training, data, directories=None, overwrite=Fal
     summary['NIP model'] = flow.nip.summary()
     summary['Channel Downsampling'] = flow._distribution['downsampling']
     summary['Channel Compression'] = flow.codec.summary() if flow.codec is not None else 'n/a'
+    summary['Channel Compression Parameters'] = str(flow._distribution['compression_params'])
     summary['Joint optimization'] = '{}'.format(flow.trainable_models)
-    summary['NIP Regularization'] = training['lambda_nip']
-    summary['DCN Regularization'] = training['lambda_dcn']
-    summary['# Epochs'] = training['n_epochs']
-    summary['Patch size'] = ps
-    summary['Batch size'] = training['batch_size']
-    summary['Learning rate'] = training['learning_rate']
-    summary['Learning rate decay schedule'] = decay_schedule
-    summary['Learning rate decay rate'] = decay_rate
+    summary['NIP Regularization'] = utils.format_number(training['lambda_nip'])                  # (:171-186: the reference's formats)
+    summary['DCN Regularization'] = utils.format_number(training['lambda_dcn'])
+    summary['NIP loss'] = '{}'.format(flow.nip.loss_metric)
+    summary['Use pre-trained NIP'] = str(training['use_pretrained_nip'])
+    summary['# Epochs'] = utils.format_number(training['n_epochs'])
+    summary['Patch size'] = utils.format_number(ps)
+    summary['Batch size'] = utils.format_number(training['batch_size'])
+    summary['Learning rate'] = utils.format_number(training['learning_rate'])
+    summary['Learning rate decay schedule'] = utils.format_number(decay_schedule)
+    summary['Learning rate decay rate'] = utils.format_number(decay_rate)
     summary['Validation schedule'] = training['validation_schedule']
     summary['Augmentation'] = str(training['augment'])
+    summary['# train. images'] = utils.format_number(data.count_training)
+    summary['# valid. images'] = utils.format_number(data.count_validation)
+    summary['Batch shape'] = '{}'.format(tuple(bx.shape))
+    summary['NIP input patch'] = '{}'.format(flow.nip.x.shape)
+    summary['NIP output patch'] = '{}'.format(flow.nip.y.shape)
+    summary['FAN input patch'] = '{}'.format(flow.fan.x.shape)
 
     world, rank = parallel.world_size(), parallel.rank()
     if training['batch_size'] % world:

@@ -90,6 +90,32 @@ def main():
     g['batch_gamma_in'] = xb
     g['batch_gamma_out'] = image.batch_gamma(xb, 2.2)
 
+    # 6. helpers/utils.py: number formats, labels, argument lists (strings; np.int is shimmed above as in the reference's numpy)
+    from helpers import utils
+    import json
+    from collections import OrderedDict
+    numbers = [0.1, 0.0001, 12.345, 1234.5678, 0.05, 1e-4, 250.0, 1.0, 0.0, 1001, 64, float('nan'), float('inf'), -0.25, 3]
+    orders = [0, 7, 999, 1000, 1234, 2.5e6, 7763820, 3e9, 4e12, 5e15, -12000]
+    shapes = [None, (64, 64, 4), (128, 128, 3), (None, None, 3), (None, None, 4), (1, 2)]
+    args = [OrderedDict(), OrderedDict([('quality', 80), ('codec', 'soft'), ('trainable', False)]),
+            OrderedDict([('kernel', 3), ('c_filters', (32, 32)), ('cfa_pattern', 'rggb'), ('alpha', 0.5)])]
+    nested = {'nip': {'performance': {'psnr': {'validation': [30.0, 31.5]}}}, 'x': 1}
+    keys = ['nip.performance.psnr.validation', 'nip.performance.ssim', 'missing.level', 'x']
+    opts = ['sharpen', 'resample', 'gaussian', 'jpeg', 'awgn', 'gamma', 'median']
+    g['utils_json'] = np.array(json.dumps({
+        'format_number_in': [repr(v) for v in numbers], 'format_number': [utils.format_number(v) for v in numbers],
+        'format_number_d2': [utils.format_number(v, 2) for v in numbers[:6]],
+        'format_number_order_in': orders, 'format_number_order': [utils.format_number_order(v) for v in orders],
+        'format_patch_shape_in': shapes, 'format_patch_shape': [utils.format_patch_shape(v) for v in shapes],
+        'join_args_in': [list(a.items()) for a in args], 'join_args': [utils.join_args(a) for a in args],
+        'get_keys': keys, 'get': [utils.get(nested, k, 'dflt') for k in keys],
+        'is_nan': [bool(utils.is_nan(v)) for v in (None, float('nan'), 1.0, 'x', np.float32('nan'))],
+        'is_vector': [bool(utils.is_vector(v)) for v in ([1, 2.0], [1, 'a'], np.zeros(3), np.zeros((2, 2)), (1, 2))],
+        'match_option_in': ['sharp', 'gaus', 'resamp', 'jpeg:80'],       # (the edit-distance branch needs the absent Levenshtein)
+        'match_option': [utils.match_option(v, opts) for v in ['sharp', 'gaus', 'resamp', 'jpeg:80']],
+        'match_option_regexp': utils.match_option('^ga.s', opts, regexp=True),
+    }))
+
     np.savez_compressed(OUT, **g)
     print('wrote', OUT, {k: v.shape for k, v in g.items()})
 

@@ -226,7 +226,8 @@ def test_even_kernel_sizes_are_refused_loudly(dev):
     with pytest.raises(NotImplementedError):
         pipelines.INet(patch_size=24, kernel=8, device=dev)
     with pytest.raises(NotImplementedError):
-        pipelines.ClassicISP(patch_size=24, kernel=4, device=dev)
+        pipelines.ClassicISP(patch_size=24, kernel=4, device=dev)            # residual=True: the bilinear branch
+    assert pipelines.ClassicISP(patch_size=24, kernel=4, c_filters=(8,), residual=False, device=dev).model_code.endswith('4x4_8-3')
 
 
 @pytest.mark.parametrize('n_classes', [24, 200])
@@ -407,7 +408,8 @@ def test_inet_trainable_upsampling(dev):
 
 
 @pytest.mark.parametrize('kernel,c_filters,residual', [(5, (8, 8), True), (3, (16,), True), (5, (), True), (3, (8,), False),
-                                                       (5, (), False), (7, (8,), True), (11, (), True), (9, (8, 8), False)])
+                                                       (5, (), False), (7, (8,), True), (11, (), True), (9, (8, 8), False),
+                                                       (4, (8,), False), (6, (8, 8), False)])
 def test_classic_isp_forward_backward_and_training(dev, kernel, c_filters, residual):
     """ClassicISP (models/pipelines.py:416-514) with its DemosaicingLayer (models/layers.py:206-258): output, the gradient
     of alpha and of every CNN parameter against the float64 oracle, camera setters, constants stay frozen."""
@@ -1447,6 +1449,10 @@ def test_training_harness_outputs(dev, tmp_path):
     prog = json.load(open(os.path.join(run_dir, 'training.json')))
     assert set(prog.keys()) >= {'summary', 'distribution', 'manipulations', 'nip', 'forensics', 'codec'}
     assert prog['manipulations'] == ['native', 'sharpen:1.0', 'gaussian:1.0']
+    sm = prog['summary']                                  # the reference's keys and number formats (training/manipulation.py:159-190)
+    assert sm['NIP Regularization'] == '0.100' and sm['Learning rate'] == '0.000100' and sm['# Epochs'] == '3'
+    assert sm['Learning rate decay rate'] == '0.900' and sm['Batch shape'] == '(1, 16, 16, 4)' and sm['NIP loss'] == 'L2'
+    assert list(sm.keys())[:3] == ['Problem', 'Dataset', 'Camera name'] and 'FAN input patch' in sm and len(sm) == 28
     assert len(prog['forensics']['performance']['accuracy']['validation']) == 3        # epochs 0 and 2 + the final pass
     conf = np.asarray(prog['forensics']['performance']['confusion'])
     assert conf.shape == (3, 3) and np.allclose(conf.sum(axis=1), 1.0)                 # rows = true class, normalised

@@ -188,6 +188,33 @@ def test_model_surface_and_checkpoint_roundtrip(tmp_path):
     assert fan._loss([0, 1], np.full((2, 5), 0.2)) == pytest.approx(np.log(5))
     with pytest.raises(ValueError):
         forensics.FAN(1, device='cpu')
+    # tfmodel.py:144-148: one row per tensor, shares in per cent
+    table = net.count_parameters_breakdown()
+    assert list(table.columns) == ['name', 'shape', 'parameters', 'total'] and len(table) == 46
+    assert int(table['parameters'].sum()) == net.count_parameters() and table['name'][0] == 'ec11/kernel'
+    assert abs(float(table['total'].sum()) - 100.0) < 1.0
+    with pytest.raises(NotImplementedError):
+        net.deploy_model(str(tmp_path))
+    with pytest.raises(NotImplementedError):
+        net.migrate_model(str(tmp_path))
+    # pipelines.py:114-141: patch descriptions; a bare name is a sub-directory of the NIP snapshot root
+    assert net._input_description == '32\u00d732\u00d74' and net._output_description == '64\u00d764\u00d73'
+    assert net.summary().endswith('32\u00d732\u00d74 -> 64\u00d764\u00d73')
+    assert pipelines.UNet(device='cpu').summary().endswith('(raw) -> (rgb)')            # no fixed patch size (helpers/utils.py:257-263)
+    cwd = os.getcwd()
+    os.chdir(str(tmp_path))
+    try:
+        net.save_model('D90')
+        assert os.path.isfile(os.path.join('data', 'models', 'nip', 'D90', 'unet', 'unet.h5'))
+        net3 = pipelines.UNet(patch_size=32, device='cpu', seed=5)
+        net3.load_model('D90')
+        assert all(torch.equal(a, b) for a, b in zip(net.parameters, net3.parameters))
+    finally:
+        os.chdir(cwd)
+    isp = pipelines.ClassicISP(patch_size=16, kernel=3, c_filters=(32, 32), cfa_pattern='rggb', device='cpu')
+    assert isp.summary() == 'ClassicISP[rggb] + CNN demosaicing [2+1 layers : 3x3x32 -> 1x1x3]'                # pipelines.py:529-539
+    assert isp.summary_compact() == 'ClassicISP[rggb, 2+1 conv2D 3x3x32 > 1x1x3]'
+    assert pipelines.ClassicISP(patch_size=16, c_filters=(8, 16), device='cpu').summary_compact() == 'ClassicISP[gbrg, 2+1 conv2D 5x5x* > 1x1x3]'
 
 
 def test_hdf5_reader_against_libhdf5_bytes():
