@@ -2,7 +2,8 @@
 Hyper-parameter records of the models: a schema {name: (default, type, rule)} plus the values that differ from it.
 
 Same contract as the reference's helpers/paramspec.py:33-178 (callers read attributes, call `update`, `to_dict`,
-`to_json`, `changed_params`, `keys`, `add`, `get_dtype`, `get_default`, `get_value`; assignment is refused; every failure is
+`to_json`, `changed_params`, `keys`, `add`, `get_dtype`, `get_default`, `get_value`, `get_min` / `get_max` / `get_enum` /
+`get_regex`; assignment is refused; every failure is
 a ValueError).  A rule is None, a (low, high) range with open ends as None, a set of allowed values, a substring a string
 value must contain, or a predicate.  `update` casts each value to the field's type first; None leaves a field as it is.
 """
@@ -20,6 +21,11 @@ def numbers_in_range(dtype, min_value=None, max_value=None):
             return False
         return (min_value is None or item >= min_value) and (max_value is None or item <= max_value)
     return lambda items: all(inside(i) for i in items)
+
+
+def item_passes(check):
+    """Rule for tuple-valued fields: `check` holds for every item (paramspec.py:11-17)."""
+    return lambda items: all(check(i) for i in items)
 
 
 class _Field(object):
@@ -83,6 +89,25 @@ class ParamSpec(object):
 
     def get_default(self, name):
         return self._fields[name].default
+
+    def _rule_of_kind(self, name, kind):
+        rule = self._fields[name].rule
+        return rule if type(rule) is kind and (kind is not tuple or len(rule) == 2) else None
+
+    def get_min(self, name):                             # paramspec.py:75-103: what a rule of the matching kind says, else None
+        rule = self._rule_of_kind(name, tuple)
+        return None if rule is None else rule[0]
+
+    def get_max(self, name):
+        rule = self._rule_of_kind(name, tuple)
+        return None if rule is None else rule[1]
+
+    def get_enum(self, name):
+        rule = self._rule_of_kind(name, set)
+        return None if rule is None else set(rule)
+
+    def get_regex(self, name):
+        return self._rule_of_kind(name, str)
 
     # -- values -------------------------------------------------------------------------------------------------------
     def __getattr__(self, name):

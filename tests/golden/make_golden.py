@@ -116,6 +116,12 @@ def main():
         'match_option_regexp': utils.match_option('^ga.s', opts, regexp=True),
     }))
 
+    # 7. helpers/paramspec.py: a scripted session (values, casts, every validation error with its message)
+    from helpers import paramspec
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import paramspec_script
+    g['paramspec_transcript'] = np.array(json.dumps(paramspec_script.session(paramspec)))
+
     np.savez_compressed(OUT, **g)
     print('wrote', OUT, {k: v.shape for k, v in g.items()})
 
