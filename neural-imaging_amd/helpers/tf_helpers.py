@@ -249,3 +249,21 @@ def mse(a, b):
     """mean((255a - 255b)^2)  (tf_helpers.py:31-32)"""
     d = _dev(a)
     return DeviceArray(ops.mse255(to_device(a, d), to_device(b, d))[0])
+
+
+def mae(a, b):
+    """mean(|255a - 255b|)  (tf_helpers.py:35-36)"""
+    d = _dev(a)
+    return DeviceArray(ops.mae255(to_device(a, d), to_device(b, d))[0])
+
+
+def ssim_loss(a, b):
+    """mean(255 (1 - tf.image.ssim(a, b, 1.0)))  (tf_helpers.py:39-40)"""
+    d = _dev(a)
+    return DeviceArray(ops.ssim_loss(to_device(a, d), to_device(b, d))[0])
+
+
+def msssim_loss(a, b):
+    """mean(255 (1 - tf.image.ssim_multiscale(a, b, 1.0)))  (tf_helpers.py:43-44)"""
+    d = _dev(a)
+    return DeviceArray(ops.msssim_loss(to_device(a, d), to_device(b, d))[0])

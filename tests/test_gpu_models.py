@@ -489,6 +489,9 @@ def test_nip_loss_metrics(dev, metric):
     loss, dy = net.loss_and_grad(y, torch.from_numpy(rgb).to(dev))
     assert abs(float(loss.item()) - float(loss_ref.detach())) / float(loss_ref.detach()) < 1e-5
     assert abs(float(net.loss(y, rgb)) - float(loss_ref.detach())) / float(loss_ref.detach()) < 1e-5
+    from neural_imaging_amd.helpers import tf_helpers as th        # the same values under the reference's function names (:31-44)
+    named = {'L1': th.mae, 'SSIM': th.ssim_loss, 'MS-SSIM': th.msssim_loss}[metric]
+    assert abs(float(named(y, rgb)) - float(loss_ref.detach())) / float(loss_ref.detach()) < 1e-5
     net.backward(ctx, dy)
     # 192 x 192: the float32 sums of the UNet's deepest layers alone are off by 4e-4 (L2) .. 1.1e-3 (SSIM) of the layer's
     # largest gradient at this size (measured); the loss gradient itself matches to 1e-5 (test_image_losses_with_gradient)
