@@ -43,6 +43,16 @@ def _unit_range(kind, a):
     return (a.astype(np.float64) / _FULL_SCALE[kind]).astype(np.float32)
 
 
+class _Pipeline(object):
+    """Iterable over the batches a generator factory yields; iterating again starts again."""
+
+    def __init__(self, factory):
+        self._factory = factory
+
+    def __iter__(self):
+        return iter(self._factory())
+
+
 class Dataset(object):
     """Host-side training data with the reference's interface (helpers/dataset.py:50-189): `data[split][kind]` holds the
     full-resolution training images and the pre-cut validation patches, kind 'x' = RAW (n, H/2, W/2, 4) uint16, 'y' = RGB
@@ -139,6 +149,14 @@ class Dataset(object):
     def get_validation_generator(self, batch_size):
         for batch_id in range(self.count_validation // batch_size):
             yield self.next_validation_batch(batch_id, batch_size)
+
+    def get_training_pipeline(self, batch_size, rgb_patch_size, discard='flat'):
+        """A re-iterable stream of training batches - the role tf.data.Dataset.from_generator plays in the reference
+        (helpers/dataset.py:247-255): every `for batch in pipeline` starts a fresh pass of get_training_generator."""
+        return _Pipeline(lambda: self.get_training_generator(batch_size, rgb_patch_size, discard))
+
+    def get_validation_pipeline(self, batch_size):
+        return _Pipeline(lambda: self.get_validation_generator(batch_size))
 
     # ---- descriptions ----------------------------------------------------------------------------------------------------
     def is_raw_and_rgb(self):
@@ -277,3 +295,11 @@ class DeviceDataset(object):
     def get_validation_generator(self, batch_size):
         for batch_id in range(self.host.count_validation // batch_size):
             yield self.next_validation_batch(batch_id, batch_size)
+
+    def get_training_pipeline(self, batch_size, rgb_patch_size, discard='flat'):
+        """A re-iterable stream of training batches - the role tf.data.Dataset.from_generator plays in the reference
+        (helpers/dataset.py:247-255): every `for batch in pipeline` starts a fresh pass of get_training_generator."""
+        return _Pipeline(lambda: self.get_training_generator(batch_size, rgb_patch_size, discard))
+
+    def get_validation_pipeline(self, batch_size):
+        return _Pipeline(lambda: self.get_validation_generator(batch_size))

@@ -375,6 +375,12 @@ def test_host_dataset_from_directory_and_arrays(tmp_path):
         dataset.Dataset.from_arrays({'y': rgb[:4].astype(np.float32)}, {'y': rgb[4:]})
     with pytest.raises(RuntimeError):
         dataset.DeviceDataset(arr, device='cpu')
+    # helpers/dataset.py:247-255: the batch streams (tf.data pipelines there) - re-iterable, one pass = count // batch batches
+    pipe = arr.get_training_pipeline(2, 48, discard=None)
+    for _ in range(2):
+        passes = [b for b in pipe]
+        assert len(passes) == 2 and all(b.shape == (2, 48, 48, 3) for b in passes)
+    assert [b.shape for b in arr.get_validation_pipeline(1)] == [(1, 32, 32, 3)] * arr.count_validation
 
 
 def _run_dp_workers(world):
