@@ -229,6 +229,18 @@ int nimg_nan_flag(const float* g, long count, int* flag, void* stream);
 int nimg_int_words(int* dst, const int* src, long n, int value, int mode, void* stream);
 int nimg_float_fill(float* dst, long n, float value, void* stream);
 
+/* In-kernel finish of the split-K weight-gradient sums (throughput-mode kernels: nimg_conv2d_wgrad_bf16*, nimg_conv1_wgrad_*,
+ * nimg_conv_wgrad_c3k5 ...; replaces the separate fixed-order reduction launch behind tape.gradient(loss, weights),
+ * workflows/manipulation_classification.py:280).  The workgroups that contribute to one tile of dw share arrival counters and
+ * the last to arrive sums the tile's slabs in a fixed order (deterministic).  The counters are the CALLER's memory: bind `bytes`
+ * (a multiple of 4, >= NIMG_TICKET_BYTES recommended) of device memory that is ZERO to a stream; every launch on that stream
+ * may use them and leaves them zero.  One buffer per stream that launches weight gradients concurrently; a stream without a
+ * binding (or buf = NULL: unbind) keeps the separate reduction launch - results differ from the ticketed ones only in the order
+ * of the additions.  The binding table holds NIMG_TICKET_STREAMS streams.  Host-side call, no device work. */
+#define NIMG_TICKET_BYTES (64 * 1024)
+#define NIMG_TICKET_STREAMS 16
+int nimg_bind_tickets(void* stream, void* buf, size_t bytes);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * ConstrainedConv2D kernel re-normalisation, models/layers.py:45-53 (ks=5, channels=3, strength=100) */
 int nimg_constrained_kernel_fwd(const float* kernel, float* nf, int ks, int channels, float strength, void* stream);

@@ -64,6 +64,7 @@ PROTOTYPES = {
     'nimg_nan_flag': (c_int, [P, c_long, P, P]),
     'nimg_int_words': (c_int, [P, P, c_long, c_int, c_int, P]),
     'nimg_float_fill': (c_int, [P, c_long, c_float, P]),
+    'nimg_bind_tickets': (c_int, [P, P, c_size_t]),
     'nimg_constrained_kernel_fwd': (c_int, [P, P, c_int, c_int, c_float, P]),
     'nimg_constrained_kernel_bwd': (c_int, [P, P, P, c_int, c_int, c_float, P]),
     'nimg_fold_pad': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
@@ -177,6 +178,7 @@ _lib = None
 
 
 ABI_VERSION = 4         # include/nimg.h NIMG_ABI_VERSION
+TICKET_BYTES = 64 * 1024        # include/nimg.h NIMG_TICKET_BYTES
 
 
 def load():

@@ -360,6 +360,101 @@ static inline void fill_reduce_entry(ReduceEntry* e, const float* p1, float* d1,
     e->accumulate = accumulate; e->blocks1 = reduce_grid(n1);
 }
 
+// ---- in-kernel finish of a split-K sum by the LAST-ARRIVING workgroup.  The separate
+// reduce_slabs2 launch behind every weight gradient (~32 per training step) read slabs that were still in the Infinity Cache,
+// but each cost a launch on the side stream and a pass over every slab by a handful of workgroups.  Here the workgroups
+// that contribute to one dw TILE share arrival counters: a workgroup writes its slab tile, publishes it (agent-scope release),
+// draws a ticket; the one that draws the last ticket of its GROUP of `group` consecutive splits sums the group's slabs in split
+// order (into the final tensor when there is one group, else in place into the group's first slab), and the last group to finish
+// sums the group sums in group order.  Every sum has ONE fixed order => deterministic, whoever arrives last.  The hand-off is
+// the recipe of cdna_hip_programming.md section 6 G16 (counter form): every storing wave drains vmcnt, workgroup barrier, ONE
+// lane: release fence + asm wait + relaxed agent fetch_add; the reducer: ONE lane acquire fence, barrier, plain loads - correct
+// for any placement of a tile's splits on XCDs / CUs.  Counters: caller-provided, zero before the first launch, and the last
+// arriver stores 0 again (nimg_bind_tickets); a tile owns 1 + NG words: [0] = arrivals of groups, [1 + g] = arrivals in group g.
+struct TicketJob {
+    unsigned* cnt;                 // this TILE's counters (null: no in-kernel finish)
+    float* slab[2];                // 0: dw slabs, 1: db partials (may be null); slab k at slab[i] + k * stride[i]
+    long stride[2];
+    float* dst[2];                 // dw, db (item offsets inside a slab = offsets inside the destination)
+    int splits, group, accumulate;
+};
+struct TicketItem { int which; long off; };          // `which` 0 / 1 as above, `off` in floats, a multiple of 4 (one float4 per item)
+
+// every thread of the workgroup calls this after its last slab store; flag_word: 4 bytes of the kernel's LDS array nobody reads
+// any more.  True in every thread of the workgroup that drew ticket `expected - 1`.
+__device__ __forceinline__ bool ticket_arrive(unsigned* cnt, unsigned expected, unsigned* flag_word) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = t + 1 == expected;
+        if (last) {
+            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // zero again for the next launch
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        *reinterpret_cast<volatile unsigned*>(flag_word) = last ? 1u : 0u;
+    }
+    __syncthreads();
+    return *reinterpret_cast<volatile unsigned*>(flag_word) != 0u;
+}
+
+// items [0, items) of this tile: sum of slabs k0, k0 + kstep, ... (n of them), ascending, 8 loads in flight per thread
+template <int NT, typename Map>
+__device__ __forceinline__ void ticket_sum(const TicketJob& j, int k0, int kstep, int n, bool final, int items, Map map) {
+    for (int it = threadIdx.x; it < items; it += NT) {
+        const TicketItem m = map(it);
+        const long st = j.stride[m.which] * kstep;
+        float* src = j.slab[m.which] + (long)k0 * j.stride[m.which] + m.off;
+        float4 a = *reinterpret_cast<const float4*>(src);
+        int k = 1;
+        for (; k + 8 <= n; k += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(src + (long)(k + u) * st);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+        }
+        for (; k < n; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (long)k * st);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        if (final) {
+            float4* d = reinterpret_cast<float4*>(j.dst[m.which] + m.off);
+            if (j.accumulate) { const float4 o = *d; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
+            *d = a;
+        } else {
+            *reinterpret_cast<float4*>(src) = a;
+        }
+    }
+}
+
+// the whole finish: call with every thread of the workgroup (NT threads) after the workgroup's slab stores
+template <int NT, typename Map>
+__device__ __forceinline__ void ticket_finish(const TicketJob& j, int split, int items, Map map, unsigned* flag_word) {
+    const int G = j.group, NG = (j.splits + G - 1) / G, g = split / G;
+    const int members = j.splits - g * G < G ? j.splits - g * G : G;
+    if (!ticket_arrive(j.cnt + 1 + g, (unsigned)members, flag_word)) return;
+    ticket_sum<NT>(j, g * G, 1, members, NG == 1, items, map);
+    if (NG == 1) return;
+    if (!ticket_arrive(j.cnt, (unsigned)NG, flag_word)) return;
+    ticket_sum<NT>(j, 0, G, NG, true, items, map);
+}
+
+// group size for `splits` slabs: one level up to 24, else ~sqrt (two levels of <= 16 .. 23 reads per item)
+static inline int ticket_group(int splits) {
+    if (splits <= 24) return splits < 1 ? 1 : splits;
+    int g = 1;
+    while (g * g < splits) ++g;
+    return g;
+}
+__device__ __forceinline__ int ticket_words_per_tile_dev(int splits, int group) { return 1 + (splits + group - 1) / group; }
+static inline int ticket_words_per_tile(int splits) { const int g = ticket_group(splits); return 1 + (splits + g - 1) / g; }
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace nimg
+
+// zeroed counter words bound to `stream` by nimg_bind_tickets (pointwise.hip), or null when fewer than `words` are bound
+extern "C" unsigned* nimg_internal_tickets(hipStream_t stream, size_t words);

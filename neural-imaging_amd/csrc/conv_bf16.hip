@@ -18,7 +18,8 @@ int nimg_internal_wgrad5_alltaps(const void* in, int cin, const void* g, const u
                                  float* db_partial, int n, int h, int wd, int max_slabs, hipStream_t stream);
 // defined in wgrad3.hip: same contract for the UNet's 3x3 layers (bf16 input(s) and output gradient)
 int nimg_internal_wgrad3_alltaps(const void* in1, int c1, const void* in2, int c2, const void* dz, int cout, float* partial,
-                                 float* db_partial, int n, int h, int wd, int max_slabs, hipStream_t stream);
+                                 float* db_partial, int n, int h, int wd, int max_slabs, hipStream_t stream, float* dw, float* db,
+                                 int accumulate);
 // defined in conv_small.hip
 size_t nimg_internal_wgrad_tiny_bytes(int ks, int cin, int cout);
 int nimg_internal_conv_wgrad_tiny(const float* in, const float* dz, float* dw, int cin, int cout, int n, int h, int wd,
@@ -1412,6 +1413,11 @@ struct WgradParamsB {
     int N, H, W, Hout, Wout, pad_t, pad_l;
     int tiles_y, tiles_x, splits, work_per_split, pad_mode;
     int flags;                     // NIMG_BF16_IN: in1 (and in2) hold bf16; NIMG_BF16_DZ: dz holds bf16
+    // in-kernel finish of the split-K sums by the last-arriving workgroup of a dw tile (common.h ticket_finish); null: slabs only
+    unsigned* tickets;
+    float* dw;
+    float* db;
+    int group, accumulate;
 };
 
 constexpr int B_TH = 8, B_TW = 16, B_CI = 32, B_CO = 64;
@@ -1642,19 +1648,20 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const Wgrad
                 for (int j = 0; j < 16; ++j) red[(((wave - 1) * 2 + ni) * 16 + j) * 64 + lane] = acc[0][ni][j];
         }
         __syncthreads();
-        if (wave > 0) return;
+        if (wave == 0) {
 #pragma unroll
-        for (int w = 1; w < NW; ++w)
+            for (int w = 1; w < NW; ++w)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+                for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                for (int j = 0; j < 16; ++j) acc[0][ni][j] += red[(((w - 1) * 2 + ni) * 16 + j) * 64 + lane];
+                    for (int j = 0; j < 16; ++j) acc[0][ni][j] += red[(((w - 1) * 2 + ni) * 16 + j) * 64 + lane];
+        }
     }
     float* slab = p.partial + (long)split * TAPS * Cin * p.Cout;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int tap = KS == 1 ? 0 : wave + NW * t;
-        if (tap >= TAPS) continue;
+        if (tap >= TAPS || (KS == 1 && wave > 0)) continue;
 #pragma unroll
         for (int ni = 0; ni < NCO; ++ni) {
             const int co = co0 + ni * 32 + (lane & 31);
@@ -1666,6 +1673,24 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const Wgrad
             }
         }
     }
+    if (p.tickets == nullptr) return;
+    // ---- the last workgroup of this (ci block, co block) tile to get here sums the tile over the splits, in a fixed order
+    TicketJob job;
+    job.cnt = p.tickets + (long)(xcd_order(blockIdx.x) % (cib * cob)) * ticket_words_per_tile_dev(p.splits, p.group);
+    job.slab[0] = p.partial; job.stride[0] = (long)TAPS * Cin * p.Cout; job.dst[0] = p.dw;
+    job.slab[1] = p.db_partial; job.stride[1] = p.Cout; job.dst[1] = p.db;
+    job.splits = p.splits; job.group = p.group; job.accumulate = p.accumulate;
+    const int rows = min(B_CI, Cin - ci0), c4n = min(TCO, p.Cout - co0) >> 2, Cout = p.Cout;
+    const int witems = TAPS * rows * c4n;
+    const int items = witems + ((p.db_partial && ci0 == 0) ? c4n : 0);
+    ticket_finish<NTHR>(job, split, items, [=](int it) {
+        TicketItem m;
+        if (it >= witems) { m.which = 1; m.off = co0 + (it - witems) * 4; return m; }
+        const int c4 = it % c4n, row = it / c4n;                 // row = tap * rows + r
+        m.which = 0;
+        m.off = ((long)(row / rows) * Cin + ci0 + row % rows) * Cout + co0 + c4 * 4;
+        return m;
+    }, reinterpret_cast<unsigned*>(smem_raw));
 }
 
 int splits_for(int cin, int cout, int n, int hout, int wout, int th = B_TH, int target_blocks = 512) {
@@ -1912,6 +1937,7 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
         WgradParamsB q;
         q.in1 = in1; q.in2 = nullptr; q.dz = dz; q.dz_idx = dz_idx; q.partial = (float*)workspace; q.db_partial = nullptr;
         q.flags = flags;
+        q.tickets = nullptr; q.dw = nullptr; q.db = nullptr; q.group = 1; q.accumulate = accumulate;
         q.C1 = c1; q.C2 = 0; q.Cout = cout; q.N = n; q.H = h; q.W = wd; q.Hout = hout; q.Wout = wout;
         q.pad_t = pad_t; q.pad_l = pad_l; q.pad_mode = pad_mode;
         q.tiles_y = cdiv(hout, B_TH); q.tiles_x = cdiv(wout, B_TW);
@@ -1958,8 +1984,15 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
     WgradParamsB p;
     p.in1 = in1; p.in2 = in2; p.dz = dz; p.dz_idx = dz_idx; p.partial = (float*)workspace; p.db_partial = nullptr;
     p.flags = flags;
+    p.tickets = nullptr; p.dw = dw; p.db = db; p.group = 1; p.accumulate = accumulate;
     p.C1 = c1; p.C2 = c2; p.Cout = cout; p.N = n; p.H = h; p.W = wd; p.Hout = hout; p.Wout = wout;
     p.pad_t = pad_t; p.pad_l = pad_l; p.pad_mode = pad_mode;
+    // arrival counters for the in-kernel finish of the generic kernel's split-K sums (set once p.splits is final)
+    auto want_tickets = [&](WgradParamsB& w) {
+        if (g_defer || (((uintptr_t)dw | (uintptr_t)db) & 15)) return;
+        w.group = ticket_group(w.splits);
+        w.tickets = nimg_internal_tickets((hipStream_t)stream, (size_t)cdiv(cin, B_CI) * cdiv(cout, B_CO) * ticket_words_per_tile(w.splits));
+    };
     const int th = (stride == 1 && ks == 5) ? 16 : B_TH;
     p.tiles_y = cdiv(hout, th); p.tiles_x = cdiv(wout, B_TW);
     // the 8-wave 5x5 kernel runs ONE workgroup per CU: 256 workgroups are one full round, and half the slabs to write and reduce
@@ -1987,8 +2020,10 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
         // the UNet's 3x3 layers with bf16-stored tensors: all 9 taps in one wave, double-buffered tiles (wgrad3.hip)
         const int max_slabs = splits_for(cin, cout, n, hout, wout);
         float* dbp = db ? (float*)workspace + (size_t)max_slabs * count : nullptr;
-        const int slabs = nimg_internal_wgrad3_alltaps(in1, c1, in2, c2, dz, cout, (float*)workspace, dbp, n, h, wd, max_slabs, s);
-        if (slabs < 0) return NIMG_ERR_LAUNCH;
+        const int slabs = nimg_internal_wgrad3_alltaps(in1, c1, in2, c2, dz, cout, (float*)workspace, dbp, n, h, wd, max_slabs, s,
+                                                       g_defer ? nullptr : dw, db, accumulate);
+        if (slabs == -1) return NIMG_ERR_LAUNCH;
+        if (slabs < -1) return NIMG_OK;                       // finished in the kernel by the last-arriving workgroups
         if (slabs > 0) {
             finish_reduce2((const float*)workspace, dw, count, slabs, dbp, db, (long)cout, slabs, accumulate, s);
             NIMG_CHECK_LAUNCH();
@@ -2009,8 +2044,10 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
         constexpr size_t lds = (size_t)10 * 20 * 64 + (size_t)B_TH * B_TW * B_ZS;
         auto k = conv_wgrad_bf16_kernel<3, 1, 4, true, true, B_TH, false, 2, true>;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        want_tickets(p);
         hipLaunchKernelGGL(k, dim3((unsigned)pblocks), dim3(256), lds, s, p);
         NIMG_CHECK_LAUNCH();
+        if (p.tickets) return NIMG_OK;
         finish_reduce2((const float*)workspace, dw, count, p.splits, db ? (const float*)p.db_partial : nullptr, db, (long)cout,
                        p.splits, accumulate, s);
         NIMG_CHECK_LAUNCH();
@@ -2018,6 +2055,7 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
     }
     if (db) p.db_partial = p.partial + (size_t)p.splits * count;
     const long blocks = (long)cdiv(cin, B_CI) * cdiv(cout, B_CO) * p.splits;
+    want_tickets(p);
 #define NIMG_WGB1(KS_, ST_, NW_, INB_, DZB_, TH_)                                                               \
     do {                                                                                                      \
         constexpr int THH = (TH_ - 1) * ST_ + KS_, TWH = (B_TW - 1) * ST_ + KS_;                              \
@@ -2058,6 +2096,7 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
 #undef NIMG_WGB
 #undef NIMG_WGB1
     NIMG_CHECK_LAUNCH();
+    if (p.tickets) return NIMG_OK;
     finish_reduce2((const float*)workspace, dw, count, p.splits, db ? (const float*)p.db_partial : nullptr, db, (long)cout,
                    p.splits, accumulate, s);
     NIMG_CHECK_LAUNCH();

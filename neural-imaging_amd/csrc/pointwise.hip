@@ -8,6 +8,7 @@
 //   GAP + Dense + softmax + sparse CE head, fwd + bwd     models/forensics.py:80-94
 //   Keras Adam over a flat parameter buffer               tf.keras.optimizers.Adam (pipelines.py:51 etc.)
 #include <stdlib.h>
+#include <mutex>
 
 #include "common.h"
 
@@ -1292,6 +1293,40 @@ int nimg_int_words(int* dst, const int* src, long n, int value, int mode, void* 
     hipLaunchKernelGGL(int_words_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dst, src, n, value, mode);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
+}
+
+// ---- arrival counters of the in-kernel split-K finish (common.h ticket_finish): caller-owned zeroed device memory per stream
+namespace {
+struct TicketBinding { hipStream_t stream; unsigned* buf; size_t words; bool used; };
+TicketBinding g_tickets[NIMG_TICKET_STREAMS];
+std::mutex g_tickets_mutex;
+}  // namespace
+
+int nimg_bind_tickets(void* stream, void* buf, size_t bytes) {
+    if ((buf && (bytes < 4 || (bytes & 3))) || ((uintptr_t)buf & 3)) return NIMG_ERR_ARG;
+    std::lock_guard<std::mutex> lock(g_tickets_mutex);
+    int free_slot = -1;
+    for (int i = 0; i < NIMG_TICKET_STREAMS; ++i) {
+        if (g_tickets[i].used && g_tickets[i].stream == (hipStream_t)stream) {
+            if (buf) { g_tickets[i].buf = (unsigned*)buf; g_tickets[i].words = bytes / 4; }
+            else g_tickets[i].used = false;
+            return NIMG_OK;
+        }
+        if (!g_tickets[i].used && free_slot < 0) free_slot = i;
+    }
+    if (!buf) return NIMG_OK;
+    if (free_slot < 0) return NIMG_ERR_ARG;
+    g_tickets[free_slot] = TicketBinding{(hipStream_t)stream, (unsigned*)buf, bytes / 4, true};
+    return NIMG_OK;
+}
+
+unsigned* nimg_internal_tickets(hipStream_t stream, size_t words) {
+    static const bool off = getenv("NIMG_NO_TICKETS") != nullptr;
+    if (off) return nullptr;
+    std::lock_guard<std::mutex> lock(g_tickets_mutex);
+    for (int i = 0; i < NIMG_TICKET_STREAMS; ++i)
+        if (g_tickets[i].used && g_tickets[i].stream == stream) return g_tickets[i].words >= words ? g_tickets[i].buf : nullptr;
+    return nullptr;
 }
 
 int nimg_float_fill(float* dst, long n, float value, void* stream) {

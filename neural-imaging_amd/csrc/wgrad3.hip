@@ -38,6 +38,11 @@ struct Wg3Params {
     float* db_partial;             // [slabs][Cout] or null
     int C1, C2, Cout, N, H, W;
     int tiles_y, tiles_x, work_per_split;
+    // in-kernel finish by the last-arriving workgroup of a dw tile (common.h ticket_finish); tickets == null: slabs only
+    unsigned* tickets;
+    float* dw;
+    float* db;
+    int splits, group, accumulate;
 };
 
 template <int NB, int TH>
@@ -68,6 +73,7 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_alltaps_kernel(const Wg3Pa
     const int Cin = p.C1 + p.C2;
     const int cib = Cin / 32, cob = p.Cout / CB;
     int bid = xcd_order(blockIdx.x);
+    const int tile_id = bid % (cib * cob);
     const int ci0 = (bid % cib) * 32;
     bid /= cib;
     const int co0 = (bid % cob) * CB;
@@ -256,9 +262,9 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_alltaps_kernel(const Wg3Pa
             }
             __syncthreads();
         }
-        if (kg != 0) return;
     }
-    if (do_bias) {                              // lanes g, g + 16, g + 32, g + 48 hold the four pixel groups of one channel
+    const bool writer = KG == 1 || kg == 0;
+    if (writer && do_bias) {                    // lanes g, g + 16, g + 32, g + 48 hold the four pixel groups of one channel
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
             float v = bsum[f];
@@ -268,13 +274,33 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_alltaps_kernel(const Wg3Pa
         }
     }
     float* slab = p.partial + (long)split * 9 * Cin * p.Cout;
+    if (writer) {
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
+        for (int f = 0; f < 2; ++f)
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+            for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                slab[((long)t * Cin + ci0 + 16 * ai + 4 * q + j) * p.Cout + co0 + bj * 32 + f * 16 + g] = acc[f][t][j];
+                for (int j = 0; j < 4; ++j)
+                    slab[((long)t * Cin + ci0 + 16 * ai + 4 * q + j) * p.Cout + co0 + bj * 32 + f * 16 + g] = acc[f][t][j];
+    }
+    if (p.tickets == nullptr) return;
+    // ---- the last workgroup of this (ci block, co block) tile to get here sums the tile over the splits, in a fixed order
+    TicketJob job;
+    job.cnt = p.tickets + (long)tile_id * ticket_words_per_tile_dev(p.splits, p.group);
+    job.slab[0] = p.partial; job.stride[0] = (long)9 * Cin * p.Cout; job.dst[0] = p.dw;
+    job.slab[1] = p.db_partial; job.stride[1] = p.Cout; job.dst[1] = p.db;
+    job.splits = p.splits; job.group = p.group; job.accumulate = p.accumulate;
+    constexpr int C4 = CB / 4;
+    const int items = 9 * 32 * C4 + ((p.db_partial && ci0 == 0) ? C4 : 0);
+    const int Cout = p.Cout;
+    ticket_finish<512>(job, split, items, [=](int it) {
+        TicketItem m;
+        if (it >= 9 * 32 * C4) { m.which = 1; m.off = co0 + (it - 9 * 32 * C4) * 4; return m; }
+        const int c4 = it % C4, row = it / C4;                   // row = t * 32 + r
+        m.which = 0;
+        m.off = ((long)(row >> 5) * Cin + ci0 + (row & 31)) * Cout + co0 + c4 * 4;
+        return m;
+    }, reinterpret_cast<unsigned*>(smem_raw));
 }
 
 template <int NB, int TH>
@@ -293,20 +319,27 @@ int launch(Wg3Params p, int max_slabs, hipStream_t stream) {
     const long wps = (work + splits - 1) / splits;
     splits = (work + wps - 1) / wps;
     p.work_per_split = (int)wps;
+    // in-kernel finish: counters bound to this stream (nimg_bind_tickets), 16-byte aligned destinations
+    p.splits = (int)splits;
+    p.group = ticket_group((int)splits);
+    const size_t words = (size_t)blocks_io * ticket_words_per_tile((int)splits);
+    if (p.dw && !(((uintptr_t)p.dw | (uintptr_t)p.db) & 15)) p.tickets = nimg_internal_tickets(stream, words);
     auto kern = conv3_wgrad_alltaps_kernel<NB, TH>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
     hipLaunchKernelGGL(kern, dim3((unsigned)(blocks_io * splits)), dim3(512), G::LDS, stream, p);
     if (hipGetLastError() != hipSuccess) return -1;
-    return (int)splits;
+    return p.tickets ? -2 - (int)splits : (int)splits;            // <= -3: finished in-kernel, nothing left to reduce
 }
 
 }  // namespace
 
 // Weight-gradient slabs (+ bias partials) of a 3x3 / stride 1 / SAME (zero padding) layer from its bf16 input(s) and bf16 output
 // gradient.  Returns the number of slabs written to partial[slab][9][c1 + c2][cout] (db_partial[slab][cout]), 0 when the shape is
-// not this kernel's (the caller falls back to conv_wgrad_bf16_kernel), -1 on a launch error.
+// not this kernel's (the caller falls back to conv_wgrad_bf16_kernel), -1 on a launch error.  With dw != null and arrival
+// counters bound to the stream the sums are FINISHED in the kernel (dw / db written or accumulated into): returns -2 - slabs.
 int nimg_internal_wgrad3_alltaps(const void* in1, int c1, const void* in2, int c2, const void* dz, int cout, float* partial,
-                                 float* db_partial, int n, int h, int wd, int max_slabs, hipStream_t stream) {
+                                 float* db_partial, int n, int h, int wd, int max_slabs, hipStream_t stream, float* dw, float* db,
+                                 int accumulate) {
     if (getenv("NIMG_NO_WGRAD3_ALLTAPS") != nullptr) return 0;
     if ((c1 % 32) || (c2 % 32) || (cout % 32) || (wd % 16) || (h % 8) || max_slabs < 1 || (c2 > 0 && !in2)) return 0;
     const long px = (long)n * h * wd;
@@ -315,6 +348,7 @@ int nimg_internal_wgrad3_alltaps(const void* in1, int c1, const void* in2, int c
     p.in1 = in1; p.in2 = in2; p.dz = dz; p.partial = partial; p.db_partial = db_partial;
     p.C1 = c1; p.C2 = c2; p.Cout = cout; p.N = n; p.H = h; p.W = wd;
     p.tiles_y = p.tiles_x = p.work_per_split = 0;
+    p.tickets = nullptr; p.dw = dw; p.db = db_partial ? db : nullptr; p.splits = p.group = 0; p.accumulate = accumulate;
     // output channels per workgroup: 32 NB.  A/B: NIMG_WGRAD3_NB = 1 | 2 | 4 forces the block width (read per call)
     const char* nb_env = getenv("NIMG_WGRAD3_NB");
     int nb = nb_env ? atoi(nb_env) : 0;

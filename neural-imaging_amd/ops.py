@@ -241,10 +241,29 @@ def _side_index(key):
     return k
 
 
+# Arrival counters of the in-kernel split-K finish (include/nimg.h nimg_bind_tickets, csrc/common.h ticket_finish): one zeroed
+# 64 KB buffer per (device, stream) that launches weight gradients, bound the first time that stream asks for its scratch buffer.
+# The library leaves the counters zero after every launch.  NIMG_NO_TICKETS=1: nothing is bound, every weight gradient keeps its
+# separate reduction launch (the A/B switch; the sums then differ in the order of the additions only).
+_TICKETS = {}
+TICKETS = _os.environ.get('NIMG_NO_TICKETS') is None
+
+
+def _bind_tickets(device, handle):
+    key = (device.index, handle)
+    buf = _TICKETS.get(key)
+    if buf is None:
+        buf = _TICKETS[key] = torch.zeros(_lib.TICKET_BYTES, dtype=torch.uint8, device=device)
+        _lib.call('nimg_bind_tickets', handle, buf.data_ptr(), buf.numel())
+    pin(buf)
+
+
 def _ws_current(device):
     """The scratch buffer of the stream the caller launches on."""
     cur = _stream() if (_raw_device is not None and device.index in (None, _raw_device())) else \
         torch.cuda.current_stream(device).cuda_stream
+    if TICKETS:
+        _bind_tickets(device, cur)
     for k, st in enumerate(_SIDE['streams']):
         if st is not None and st.device == device and cur == st.cuda_stream:
             return _SIDE['ws'][k]

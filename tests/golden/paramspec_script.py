@@ -28,7 +28,7 @@ def session(ps):
         ('above_max', lambda: h.update(n=7)),
         ('open_range_ok', lambda: (h.update(lo=1e9), h.lo)[1]),
         ('open_range_low', lambda: h.update(lo=-0.1)),
-        ('enum_str', lambda: _head(lambda: h.update(act='gelu'), 42)),      # (the set's print order depends on the hash seed)
+        ('enum_str', lambda: _head(lambda: h.update(act='gelu'), 35)),      # (the set's print order depends on the hash seed: keep the stable prefix only)
         ('substring_ok', lambda: (h.update(tag='rggb'), h.tag)[1]),
         ('substring_bad', lambda: h.update(tag='xyz')),
         ('custom_bad_type', lambda: h.update(filters=(32, 2.5))),
