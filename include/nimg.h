@@ -241,6 +241,14 @@ int nimg_float_fill(float* dst, long n, float value, void* stream);
 #define NIMG_TICKET_STREAMS 16
 int nimg_bind_tickets(void* stream, void* buf, size_t bytes);
 
+/* A HIP stream whose kernels run on `n_cus` compute units only (hipExtStreamCreateWithCUMask, mask = the low n_cus bits: the
+ * driver deals mask bits round-robin over the 8 XCDs, so any n is balanced to within one CU per XCD).  For partitioning the chip
+ * between kernel classes that only evict each other when interleaved workgroup by workgroup - the matrix-core-bound weight
+ * gradients of the FAN beside the byte-bound backward pass of the image chain (workflows/manipulation_classification.py:260-285
+ * under the tape).  *stream is a hipStream_t the caller owns (nimg_stream_destroy). */
+int nimg_stream_create_cu_mask(int n_cus, void** stream);
+int nimg_stream_destroy(void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * ConstrainedConv2D kernel re-normalisation, models/layers.py:45-53 (ks=5, channels=3, strength=100) */
 int nimg_constrained_kernel_fwd(const float* kernel, float* nf, int ks, int channels, float strength, void* stream);

@@ -65,6 +65,8 @@ PROTOTYPES = {
     'nimg_int_words': (c_int, [P, P, c_long, c_int, c_int, P]),
     'nimg_float_fill': (c_int, [P, c_long, c_float, P]),
     'nimg_bind_tickets': (c_int, [P, P, c_size_t]),
+    'nimg_stream_create_cu_mask': (c_int, [c_int, P]),
+    'nimg_stream_destroy': (c_int, [P]),
     'nimg_constrained_kernel_fwd': (c_int, [P, P, c_int, c_int, c_float, P]),
     'nimg_constrained_kernel_bwd': (c_int, [P, P, P, c_int, c_int, c_float, P]),
     'nimg_fold_pad': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),

@@ -1320,6 +1320,21 @@ int nimg_bind_tickets(void* stream, void* buf, size_t bytes) {
     return NIMG_OK;
 }
 
+int nimg_stream_create_cu_mask(int n_cus, void** stream) {
+    if (!stream || n_cus < 1 || n_cus > 1024) return NIMG_ERR_ARG;
+    uint32_t mask[32] = {0};
+    for (int i = 0; i < n_cus; ++i) mask[i >> 5] |= 1u << (i & 31);
+    hipStream_t s = nullptr;
+    if (hipExtStreamCreateWithCUMask(&s, (uint32_t)((n_cus + 31) / 32), mask) != hipSuccess) return NIMG_ERR_LAUNCH;
+    *stream = (void*)s;
+    return NIMG_OK;
+}
+
+int nimg_stream_destroy(void* stream) {
+    if (!stream) return NIMG_ERR_ARG;
+    return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? NIMG_OK : NIMG_ERR_LAUNCH;
+}
+
 unsigned* nimg_internal_tickets(hipStream_t stream, size_t words) {
     static const bool off = getenv("NIMG_NO_TICKETS") != nullptr;
     if (off) return nullptr;

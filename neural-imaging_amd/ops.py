@@ -243,10 +243,13 @@ def _side_index(key):
 
 # Arrival counters of the in-kernel split-K finish (include/nimg.h nimg_bind_tickets, csrc/common.h ticket_finish): one zeroed
 # 64 KB buffer per (device, stream) that launches weight gradients, bound the first time that stream asks for its scratch buffer.
-# The library leaves the counters zero after every launch.  NIMG_NO_TICKETS=1: nothing is bound, every weight gradient keeps its
-# separate reduction launch (the A/B switch; the sums then differ in the order of the additions only).
+# The library leaves the counters zero after every launch.  OPT-IN (NIMG_TICKETS=1) because it LOSES (profiles/r06_tickets_ab.txt:
+# UNet backward 1667 -> 2304 us, C4 step 8.02 -> 8.68 ms): the last-arriving workgroup of a dw tile reads splits x tile bytes
+# (2.4 MB for a 256 -> 256 layer) ALONE at ~100 GB/s while the rest of the chip has nothing left to do - a serial 20 - 30 us tail per
+# launch - where the separate reduction spreads the same 38 MB over every CU in ~10 us.  Without it every weight gradient keeps its
+# separate reduction launch; the sums differ in the order of the additions only.
 _TICKETS = {}
-TICKETS = _os.environ.get('NIMG_NO_TICKETS') is None
+TICKETS = _os.environ.get('NIMG_TICKETS') is not None
 
 
 def _bind_tickets(device, handle):
@@ -270,6 +273,21 @@ def _ws_current(device):
     return _ws
 
 
+# NIMG_SIDE_CUS=n: the side streams run on n compute units only (nimg_stream_create_cu_mask) - partitions the chip between the
+# parameter-gradient kernels and the launch stream's kernels instead of interleaving them workgroup by workgroup.
+SIDE_CUS = int(_os.environ.get('NIMG_SIDE_CUS', '0'))
+
+
+def _new_side_stream(dev):
+    if SIDE_CUS <= 0:
+        return torch.cuda.Stream(device=dev)
+    import ctypes
+    h = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        _lib.call('nimg_stream_create_cu_mask', SIDE_CUS, ctypes.byref(h))
+    return torch.cuda.ExternalStream(h.value, device=dev)
+
+
 class _on_side_stream(object):
     def __init__(self, *tensors, key=None):
         self.tensors = [t for t in tensors if t is not None]
@@ -283,7 +301,7 @@ class _on_side_stream(object):
             if len(_SIDE['ws']) < len(streams):
                 _SIDE['ws'].append(Workspace())
         if streams[k] is None or streams[k].device != dev:
-            streams[k] = torch.cuda.Stream(device=dev)
+            streams[k] = _new_side_stream(dev)
         side = streams[k]
         self.prev = torch.cuda.current_stream(dev)
         side.wait_stream(self.prev)
