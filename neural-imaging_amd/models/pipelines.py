@@ -368,8 +368,10 @@ class DNet(NIPModel):
             'n_features': (64, int, (4, 128)),
         })
         self._h.update(n_layers=n_layers, kernel=kernel, n_features=n_features)
-        if self._h.kernel not in (3, 5) or self.in_channels != 4:
-            raise NotImplementedError('DNet is built for 3x3 / 5x5 kernels on 4-plane RAW input')
+        if self._h.kernel % 2 == 0 or self.in_channels != 4:
+            # an even kernel has no working behaviour in the reference: VALID k x k followed by a REFLECT re-pad of (k - 1) // 2
+            # (pipelines.py:319-322) returns images one pixel short per layer of what the loss compares them with
+            raise NotImplementedError('DNet is built for odd kernels 3 .. 11 on 4-plane RAW input')
         k, nf, nl = self._h.kernel, self._h.n_features, self._h.n_layers
         self._convs = []
         cin = 4

@@ -649,15 +649,17 @@ def test_jpeg_process_with_another_quality(dev):
     assert np.abs(codec.process(x).numpy() - odj.djpeg_torch(to64(x), 50, 'soft')[0].numpy()).max() < 0.1
 
 
-@pytest.mark.parametrize('n_layers,nf', [(4, 16), (3, 24)])
-def test_dnet_forward_backward(dev, n_layers, nf):
+@pytest.mark.parametrize('n_layers,nf,kernel', [(4, 16, 3), (3, 24, 3), (3, 16, 5), (3, 16, 7), (2, 8, 9), (2, 8, 11)])
+def test_dnet_forward_backward(dev, n_layers, nf, kernel):
     """DNet (models/pipelines.py:298-349): VALID conv + ReLU + REFLECT re-pad chains, two-tensor projection, frozen
-    up-sampling; output and every trainable gradient against the float64 oracle."""
+    up-sampling; output and every trainable gradient against the float64 oracle - for every odd kernel size the reference's
+    ParamSpec admits (pipelines.py:308: 3 .. 11; 7 / 9 / 11 through the generic float32 matrix-core kernels)."""
     from neural_imaging_amd import ops
     from neural_imaging_amd.models import pipelines
-    net = pipelines.DNet(patch_size=16, n_layers=n_layers, n_features=nf, device=dev)
-    assert net.model_code == 'DNet_3x3_{}x{}f'.format(n_layers, nf)
-    rgb = natural_images(3, 32, 32, seed=23)
+    ps = 16 if kernel < 9 else 24          # (the re-pad's gradient folds at most two sources per pixel: size > 2 x pad)
+    net = pipelines.DNet(patch_size=ps, n_layers=n_layers, n_features=nf, kernel=kernel, device=dev)
+    assert net.model_code == 'DNet_{0}x{0}_{1}x{2}f'.format(kernel, n_layers, nf)
+    rgb = natural_images(3, 2 * ps, 2 * ps, seed=23)
     raw = bayer_from_rgb(rgb)
     p = oracle_params(net)
     train = [k for k in p if not k.startswith('up/')]
@@ -667,7 +669,7 @@ def test_dnet_forward_backward(dev, n_layers, nf):
     loss_ref = T.mse255(y_ref, to64(rgb))
     g_ref = dict(zip(train, torch.autograd.grad(loss_ref, [p[k] for k in train])))
     y, ctx = net.forward(torch.from_numpy(raw).to(dev), training=True)
-    assert y.shape == (3, 32, 32, 3)
+    assert y.shape == (3, 2 * ps, 2 * ps, 3)
     assert_close(y.cpu().numpy(), y_ref.detach().numpy(), 2e-5, what='DNet output')
     loss, dy = ops.mse255(y, torch.from_numpy(rgb).to(dev), grad_scale=1.0)
     net.backward(ctx, dy)
