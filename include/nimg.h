@@ -250,6 +250,30 @@ int nimg_stream_create_cu_mask(int n_cus, void** stream);
 int nimg_stream_destroy(void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * The FAN's head in throughput mode - Conv2D(nf, 1x1, leaky_relu) -> GlobalAveragePooling2D -> Dense(softmax),
+ * models/forensics.py:76-94 - with the pooling fused into the 1x1 layer (csrc/head.hip).  hw = pixels per image (64 | 128 | 256),
+ * c = channels in = channels out (64 | 128 | 256): nimg_head_fused_ok.  x (n * hw, c) bf16; wimg / wimg_t the 1x1 kernel's bf16
+ * images (nimg_conv_weights_bf16 mode 0 / mode 1).
+ *   nimg_head_fwd:   gap (n, c) = mean over the image of LeakyReLU(x W + b); mask (n * hw, c / 32) words, bit j of word f = the
+ *                    activation of channel 32 f + j is > 0 (NULL at inference) - the activation tensor itself is not written.
+ *   nimg_fan_dense_fwd / _bwd: the Dense softmax / sparse-CE classifier on a pooled feature (the two halves of nimg_fan_head_fwd /
+ *                    _bwd that do not touch the activation tensor).
+ *   nimg_head_dgrad: dx (n * hw, c) bf16 = ((g (x) (bit ? 1 : alpha)) W^T) * LeakyReLU'(in_mask) with g[n] = wdense dlogits[n] / hw:
+ *                    the gradient at the INPUT of the 1x1 layer straight from the classifier's dlogits (n, k); in_mask bf16 or NULL.
+ *   nimg_head_dact:  the gradient at the 1x1 layer's pre-activation as bf16 (n * hw, c), for its weight gradient. */
+int nimg_head_fused_ok(int hw, int c);
+int nimg_head_fwd(const void* x, const void* wimg, const float* bias, unsigned* mask, float* gap, int n, int hw, int c,
+                  float alpha, void* stream);
+int nimg_head_dgrad(const unsigned* mask, const float* dlogits, const float* wdense, int k, const void* wimg_t,
+                    const void* in_mask, void* dx, int n, int hw, int c, float alpha, void* stream);
+int nimg_head_dact(const unsigned* mask, const float* dlogits, const float* wdense, int k, void* dact, int n, int hw, int c,
+                   float alpha, void* stream);
+int nimg_fan_dense_fwd(const float* gap, const float* w, const float* b, const int* labels, float* probs, float* loss_per,
+                       float* dlogits, int n, int c, int k, float loss_scale, void* stream);
+int nimg_fan_dense_bwd(const float* gap, const float* dlogits, const float* loss_per, float* dw, float* db, float* loss, int n,
+                       int c, int k, float loss_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * ConstrainedConv2D kernel re-normalisation, models/layers.py:45-53 (ks=5, channels=3, strength=100) */
 int nimg_constrained_kernel_fwd(const float* kernel, float* nf, int ks, int channels, float strength, void* stream);
 int nimg_constrained_kernel_bwd(const float* kernel, const float* dnf, float* dkernel, int ks, int channels,

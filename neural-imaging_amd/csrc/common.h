@@ -405,8 +405,11 @@ template <int NT, typename Map>
 __device__ __forceinline__ void ticket_sum(const TicketJob& j, int k0, int kstep, int n, bool final, int items, Map map) {
     for (int it = threadIdx.x; it < items; it += NT) {
         const TicketItem m = map(it);
-        const long st = j.stride[m.which] * kstep;
-        float* src = j.slab[m.which] + (long)k0 * j.stride[m.which] + m.off;
+        // (selects, not j.slab[m.which]: a dynamically indexed member array puts the whole struct on the stack - 80 bytes of scratch
+        //  per lane and the scratch set-up of every launch, used or not)
+        const long stride = m.which ? j.stride[1] : j.stride[0];
+        const long st = stride * kstep;
+        float* src = (m.which ? j.slab[1] : j.slab[0]) + (long)k0 * stride + m.off;
         float4 a = *reinterpret_cast<const float4*>(src);
         int k = 1;
         for (; k + 8 <= n; k += 8) {
@@ -421,7 +424,7 @@ __device__ __forceinline__ void ticket_sum(const TicketJob& j, int k0, int kstep
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
         if (final) {
-            float4* d = reinterpret_cast<float4*>(j.dst[m.which] + m.off);
+            float4* d = reinterpret_cast<float4*>((m.which ? j.dst[1] : j.dst[0]) + m.off);
             if (j.accumulate) { const float4 o = *d; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
             *d = a;
         } else {

@@ -1263,6 +1263,36 @@ int nimg_fan_head_bwd(const float* act, const float* gap, const float* w, const 
     return NIMG_OK;
 }
 
+int nimg_fan_dense_fwd(const float* gap, const float* w, const float* b, const int* labels, float* probs, float* loss_per,
+                       float* dlogits, int n, int c, int k, float loss_scale, void* stream) {
+    if (n == 0) return NIMG_OK;
+    if (!gap || !w || !b || !probs || n < 0 || c <= 0 || k <= 0 || k > 256) return NIMG_ERR_ARG;
+    if (labels && (!loss_per || !dlogits)) return NIMG_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (k > 16)
+        hipLaunchKernelGGL(dense_softmax_ce_wide_kernel, dim3(n), dim3(64), 0, s, gap, w, b, labels, probs, loss_per, dlogits, n,
+                           c, k, loss_scale);
+    else
+        hipLaunchKernelGGL(dense_softmax_ce_kernel, dim3(n), dim3(64), 0, s, gap, w, b, labels, probs, loss_per, dlogits, n, c,
+                           k, loss_scale);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
+int nimg_fan_dense_bwd(const float* gap, const float* dlogits, const float* loss_per, float* dw, float* db, float* loss, int n,
+                       int c, int k, float loss_scale, void* stream) {
+    if (!gap || !dlogits || !loss_per || !dw || !db || !loss || n <= 0 || c <= 0 || k <= 0 || k > 256) return NIMG_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (k > 16)
+        hipLaunchKernelGGL(dense_bwd_params_wide_kernel, dim3(c + 2), dim3(64), 0, s, gap, dlogits, loss_per, dw, db, loss, n, c,
+                           k, loss_scale);
+    else
+        hipLaunchKernelGGL(dense_bwd_params_kernel, dim3(c + 2), dim3(64), 0, s, gap, dlogits, loss_per, dw, db, loss, n, c, k,
+                           loss_scale);
+    NIMG_CHECK_LAUNCH();
+    return NIMG_OK;
+}
+
 int nimg_adam_step(float* params, const float* grads, float* m, float* v, long count, float lr, float beta1,
                    float beta2, float eps, int step, float grad_scale, const int* skip_flag, void* stream) {
     if (!params || !grads || !m || !v || count < 0 || step < 1) return NIMG_ERR_ARG;

@@ -141,10 +141,18 @@ class FAN(TFModel):
                 t['conv{}'.format(i + 1)] = a
                 net = ops.maxpool2(a)
             t['pool{}'.format(i + 1)] = net
-        a = self._conv1x1.forward(P, net)
-        t['conv1x1'] = a
         n = x.shape[0]
         ls = (1.0 / n) if loss_scale is None else loss_scale
+        c5 = self._conv1x1
+        if self._use_gap and not self._hidden and not self._generic_act and c5.cin == c5.cout and ops.head_fused_ok(net, c5.cout):
+            # throughput mode: 1x1 conv + LeakyReLU + global average pooling in ONE pass (csrc/head.hip); the activation leaves as
+            # one sign bit per value, all the backward pass needs of it
+            gap, mask = ops.head_fwd(net, P.p[c5.name + '/kernel'], P.p[c5.name + '/bias'], want_mask=training)
+            probs, loss_per, dlogits = ops.fan_dense_fwd(gap, P.p[self._cls + '/kernel'], P.p[self._cls + '/bias'], labels, ls)
+            t['head_mask'], t['gap'], t['probs'], t['loss_per'], t['dlogits'], t['loss_scale'] = mask, gap, probs, loss_per, dlogits, ls
+            return probs, (t if training else None)
+        a = self._conv1x1.forward(P, net)
+        t['conv1x1'] = a
         head_in = a
         if self._hidden or not self._use_gap:
             # general head: features as an (N,1,1,F) tensor, hidden Dense layers as 1x1 convolutions
@@ -194,6 +202,38 @@ class FAN(TFModel):
                 late.append(fn)
         P = self._model
         hw = lambda a: (a.shape[1], a.shape[2])
+        nconv = len(self._convs)
+        fused = lambda i: i >= 1 and t.get('idx{}'.format(i)) is not None
+        pooled_path = lambda i: fused(i) and not fused(i - 1) and ops.pooled_backward_ok(
+            self._convs[i - 1].cin, self._convs[i - 1].cout, self._convs[i - 1].ks)
+        # a pooled gradient that is only un-pooled into a bf16 tensor can itself be stored as bf16 (throughput mode)
+        g_bf16 = lambda i: (ops.COMPUTE == 'bf16' and ops.STORE_BF16 and fused(i) and self._convs[i - 1].cout % 8 == 0 and
+                            (pooled_path(i) or self._convs[i - 1].cin % 8 == 0))
+        if 'head_mask' in t:
+            d_pool, loss = self._fused_head_backward(t)
+        else:
+            d_pool, loss = self._head_backward(t, fused, g_bf16)
+        return self._conv_backward(t, d_pool, loss, fused, g_bf16, params, late, need_input_grad, join)
+
+    def _fused_head_backward(self, t):
+        """Backward of the fused head (forward above): classifier gradients, then the gradient at the INPUT of the 1x1 layer straight
+        from dlogits and the activation's sign bits; the 1x1 layer's weight gradient on the side stream from the same bits."""
+        P, c5 = self._model, self._conv1x1
+        pool = t['pool{}'.format(len(self._convs))]
+        wd = P.p[self._cls + '/kernel']
+        loss = ops.fan_dense_bwd(t['gap'], t['dlogits'], t['loss_per'], t['loss_scale'], P.g[self._cls + '/kernel'],
+                                 P.g[self._cls + '/bias'])
+        dw = P.g[c5.name + '/kernel']
+        with ops.side_stream(pool, t['head_mask'], t['dlogits'], wd, key=dw.data_ptr()):
+            dact = ops.head_dact(t['head_mask'], t['dlogits'], wd, pool.shape)
+            ops.conv2d_wgrad(pool, dact, 1, dw=dw, db=P.g[c5.name + '/bias'])
+        d_pool = ops.head_dgrad(t['head_mask'], t['dlogits'], wd, P.p[c5.name + '/kernel'],
+                                pool if t.get('idx{}'.format(len(self._convs))) is not None else None, pool.shape)
+        return d_pool, loss
+
+    def _head_backward(self, t, fused, g_bf16):
+        P = self._model
+        hw = lambda a: (a.shape[1], a.shape[2])
         a = t['conv1x1']
         # classifier backward; dz = gradient w.r.t. the PRE-activation of whatever fed the head (its LeakyReLU' applied)
         gen = self._generic_act
@@ -231,14 +271,16 @@ class FAN(TFModel):
         pool = t['pool{}'.format(nconv)]
         self._conv1x1.backward_params(P, pool, dz)
         # fused layers: the producer of d_pool applies LeakyReLU'(pooled) in its epilogue (sign(window max) = sign(pooled))
-        fused = lambda i: i >= 1 and t.get('idx{}'.format(i)) is not None
-        pooled_path = lambda i: fused(i) and not fused(i - 1) and ops.pooled_backward_ok(
-            self._convs[i - 1].cin, self._convs[i - 1].cout, self._convs[i - 1].ks)
-        # a pooled gradient that is only un-pooled into a bf16 tensor can itself be stored as bf16 (throughput mode)
-        g_bf16 = lambda i: (ops.COMPUTE == 'bf16' and ops.STORE_BF16 and fused(i) and self._convs[i - 1].cout % 8 == 0 and
-                            (pooled_path(i) or self._convs[i - 1].cin % 8 == 0))
         d_pool = self._conv1x1.backward_input(P, dz, hw(pool), act_mask=pool if fused(nconv) else None,
                                               out_bf16=g_bf16(nconv))
+        return d_pool, loss
+
+    def _conv_backward(self, t, d_pool, loss, fused, g_bf16, params, late, need_input_grad, join):
+        P = self._model
+        hw = lambda a: (a.shape[1], a.shape[2])
+        gen = self._generic_act
+        act_bwd = (lambda g, y: ops.activation_bwd(g, y, self._h.activation, out=g)) if gen else ops.lrelu_bwd
+        nconv = len(self._convs)
         for i in range(nconv, 0, -1):
             conv = self._convs[i - 1]
             inp = t['pool{}'.format(i - 1)] if i > 1 else t['constrained']

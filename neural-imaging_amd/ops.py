@@ -1161,6 +1161,78 @@ def fan_head_bwd(act, gap, w, dlogits, loss_per, loss_scale, dw, db, alpha=None)
     return dact, loss
 
 
+# ---- fused FAN head, throughput mode (csrc/head.hip): 1x1 conv + LeakyReLU + global average pooling in one pass; the backward
+# pass builds the pooled gradient's spread-out form inside the 1x1 layer's input-gradient kernel from one bit per activation.
+# NIMG_NO_HEAD_FUSED=1 keeps the generic 1x1 / pooling kernels (A/B switch).
+HEAD_FUSED = _os.environ.get('NIMG_NO_HEAD_FUSED') is None
+
+
+def head_fused_ok(x, cout):
+    """The fused head applies: throughput mode, bf16-stored input (N, H, W, C) with C = cout in {64, 128, 256} and
+    H * W in {64, 128, 256}."""
+    return bool(HEAD_FUSED and COMPUTE == 'bf16' and STORE_BF16 and x.dim() == 4 and _is_bf16(x) and x.shape[3] == cout and
+                x.shape[0] > 0 and _lib.load().nimg_head_fused_ok(int(x.shape[1] * x.shape[2]), int(cout)))
+
+
+def head_fwd(x, w, b, want_mask=True):
+    """x (N,H,W,C) bf16, w (1,1,C,C), b (C) -> gap (N,C) float32, mask (N*H*W, C/32) int32 sign bits of the activation (or None)."""
+    _chk(x, w, b)
+    n, h, wd, c = x.shape
+    gap = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    mask = torch.empty((n * h * wd, c // 32), dtype=torch.int32, device=x.device) if want_mask else None
+    _lib.call('nimg_head_fwd', _p(x), _p(weights_bf16(w, 0)), _p(b), _p(mask), _p(gap), n, h * wd, c, LRELU_ALPHA, _stream())
+    return gap, mask
+
+
+def fan_dense_fwd(gap, w, b, labels=None, loss_scale=1.0):
+    """The classifier on a pooled feature: probs (+ per-image loss and dlogits with labels)."""
+    _f32(gap, w, b)
+    n, c = gap.shape
+    k = w.shape[1]
+    probs = torch.empty((n, k), dtype=torch.float32, device=gap.device)
+    loss_per = dlogits = None
+    if labels is not None:
+        _chk(labels)
+        if labels.dtype != torch.int32:
+            raise RuntimeError('labels must be int32')
+        loss_per = torch.empty((n,), dtype=torch.float32, device=gap.device)
+        dlogits = torch.empty((n, k), dtype=torch.float32, device=gap.device)
+    _lib.call('nimg_fan_dense_fwd', _p(gap), _p(w), _p(b), _p(labels), _p(probs), _p(loss_per), _p(dlogits), n, c, k,
+              float(loss_scale), _stream())
+    return probs, loss_per, dlogits
+
+
+def fan_dense_bwd(gap, dlogits, loss_per, loss_scale, dw, db):
+    _f32(gap, dlogits, loss_per, dw, db)
+    n, c = gap.shape
+    loss = torch.empty((1,), dtype=torch.float32, device=gap.device)
+    _lib.call('nimg_fan_dense_bwd', _p(gap), _p(dlogits), _p(loss_per), _p(dw), _p(db), _p(loss), n, c, dlogits.shape[1],
+              float(loss_scale), _stream())
+    return loss
+
+
+def head_dgrad(mask, dlogits, wdense, w, in_mask, shape):
+    """Gradient at the INPUT of the fused head's 1x1 layer, bf16 (N,H,W,C): from the classifier's dlogits, the activation's sign
+    bits and (optionally) the bf16 tensor whose sign gates the LeakyReLU of the layer below."""
+    _chk(mask, dlogits, wdense, w, in_mask)
+    n, h, wd, c = shape
+    dx = torch.empty((n, h, wd, c), dtype=torch.bfloat16, device=mask.device)
+    if in_mask is not None and (not _is_bf16(in_mask) or tuple(in_mask.shape) != tuple(shape)):
+        raise RuntimeError('head_dgrad: the mask tensor is the bf16-stored input of the 1x1 layer')
+    _lib.call('nimg_head_dgrad', _p(mask), _p(dlogits), _p(wdense), dlogits.shape[1], _p(weights_bf16(w, 1)), _p(in_mask), _p(dx),
+              n, h * wd, c, LRELU_ALPHA, _stream())
+    return dx
+
+
+def head_dact(mask, dlogits, wdense, shape):
+    """Gradient at the fused head's 1x1 pre-activation as a bf16 tensor (N,H,W,C) - what its weight gradient reads."""
+    _chk(mask, dlogits, wdense)
+    n, h, wd, c = shape
+    dact = torch.empty((n, h, wd, c), dtype=torch.bfloat16, device=mask.device)
+    _lib.call('nimg_head_dact', _p(mask), _p(dlogits), _p(wdense), dlogits.shape[1], _p(dact), n, h * wd, c, LRELU_ALPHA, _stream())
+    return dact
+
+
 def adam_lr_t(lr, step, beta1=0.9, beta2=0.999):
     """Keras Adam's bias-corrected rate of iteration `step` (1-based), exactly as nimg_adam_step computes it: double
     arithmetic on the float32 values of lr / beta1 / beta2 that cross the C ABI."""

@@ -2226,3 +2226,87 @@ def test_twitter_dcn_hyperparameters(dev, rounding, bpf, nf):
         _, dy = ops.l2_loss(xt, y, grad_scale=1.0)
         dcn.backward(ctx, dy, entropy_coef=250.0)
         check_grads(grads_of(dcn), g_ref, list(p.keys()), tol=2e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('hw,c', [((16, 16), 256), ((8, 8), 256), ((8, 16), 128), ((8, 8), 64)])
+def test_fused_head_kernels_against_the_generic_path(dev, hw, c):
+    """csrc/head.hip (throughput mode): 1x1 conv + LeakyReLU + global average pooling in one pass, the activation kept as ONE SIGN
+    BIT per value; the input gradient of the 1x1 layer built from those bits and the classifier's dlogits.  Against the generic
+    kernels on the same bf16 operands (1x1 convolution -> pooling; pooling backward -> 1x1 input gradient): the same products, other
+    summation orders."""
+    from neural_imaging_amd import ops
+    n, k = 7, 5
+    g = torch.Generator(device='cpu').manual_seed(3)
+    x = (torch.randn((n, hw[0], hw[1], c), generator=g) * 0.7).to(dev).to(torch.bfloat16)
+    w = (torch.randn((1, 1, c, c), generator=g) * (1.0 / np.sqrt(c))).to(dev)
+    b = (torch.randn((c,), generator=g) * 0.1).to(dev)
+    wd = (torch.randn((c, k), generator=g) * 0.1).to(dev)
+    dlogits = (torch.randn((n, k), generator=g) * 0.3).to(dev)
+    ops.set_compute('bf16')
+    try:
+        assert ops.head_fused_ok(x, c)
+        gap, mask = ops.head_fwd(x, w, b)
+        a = ops.conv2d(x, w, b, act='leaky_relu').float()                     # generic 1x1 kernel, float32 result
+        assert_close(gap.cpu().numpy(), a.mean(dim=(1, 2)).cpu().numpy(), 1e-5, 1e-4, what='pooled feature')
+        bits = (mask.view(n, hw[0], hw[1], c // 32, 1) >> torch.arange(32, device=dev, dtype=torch.int32)) & 1
+        want = (a > 0).view(n, hw[0], hw[1], c // 32, 32).to(torch.int32)
+        # (a value within float32 rounding of zero may fall on either side in another summation order: none in this draw)
+        assert int((bits != want).sum().item()) <= 2
+        # backward: the generic path = pooling backward (float32 gradient tensor) -> 1x1 input gradient with the mask of the input
+        dact_ref = (dlogits @ wd.t() / float(hw[0] * hw[1]))[:, None, None, :] * torch.where(a > 0, 1.0, ops.LRELU_ALPHA)
+        dact = ops.head_dact(mask, dlogits, wd, x.shape)
+        assert_close(dact.float().cpu().numpy(), dact_ref.to(torch.bfloat16).float().cpu().numpy(), 1e-6, 1e-2, what='dAct')
+        dx_ref = ops.conv2d_dgrad(dact_ref.contiguous(), w, hw, act_mask=x, out_bf16=True).float().cpu().numpy()
+        dx = ops.head_dgrad(mask, dlogits, wd, w, x, x.shape).float().cpu().numpy()
+        scale = np.abs(dx_ref).max()
+        assert np.abs(dx - dx_ref).max() <= 1e-2 * scale                      # one bf16 ulp of the largest entry
+        assert np.mean(np.abs(dx - dx_ref) > 1e-3 * scale) < 0.02
+        dx0 = ops.head_dgrad(mask, dlogits, wd, w, None, x.shape).float().cpu().numpy()        # no mask below
+        dx0_ref = ops.conv2d_dgrad(dact_ref.contiguous(), w, hw, out_bf16=True).float().cpu().numpy()
+        assert np.abs(dx0 - dx0_ref).max() <= 1e-2 * np.abs(dx0_ref).max()
+    finally:
+        ops.set_compute('f32')
+
+
+@pytest.mark.gpu
+def test_fan_with_the_fused_head(dev, monkeypatch):
+    """A FAN whose last feature map has 64 pixels (patch 128): throughput mode takes the fused head (csrc/head.hip).  Same
+    probabilities / loss / gradients as with the generic head kernels (NIMG_NO_HEAD_FUSED path) up to bf16 rounding, and the float64
+    oracle within the throughput mode's usual tolerances."""
+    from neural_imaging_amd import ops
+    from neural_imaging_amd.models import forensics
+    x = natural_images(5, 128, 128, seed=41)
+    labels = np.array([0, 1, 2, 3, 4], np.int32)
+    xd, ld = torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev)
+    res = {}
+    ops.set_compute('bf16')
+    try:
+        for fused in (True, False):
+            monkeypatch.setattr(ops, 'HEAD_FUSED', fused)
+            fan = forensics.FAN(n_classes=5, patch_size=128, device=dev)
+            probs, ctx = fan.forward(xd, ld, training=True)
+            assert ('head_mask' in ctx) == fused
+            loss, dx = fan.backward(ctx, need_input_grad=True)
+            res[fused] = (probs.cpu().numpy(), float(loss.item()), dx.cpu().numpy(), grads_of(fan))
+            assert np.array_equal(fan.forward(xd)[0].cpu().numpy(), probs.cpu().numpy())     # inference: no mask, same numbers
+    finally:
+        ops.set_compute('f32')
+    a, b = res[True], res[False]
+    assert_close(a[0], b[0], 1e-5, 1e-4, what='probabilities, fused vs generic head')
+    assert abs(a[1] - b[1]) < 1e-5
+    cos = lambda u, v: float((u * v).sum() / (np.linalg.norm(u) * np.linalg.norm(v) + 1e-30))
+    assert cos(a[2], b[2]) > 0.999, cos(a[2], b[2])
+    for k in a[3]:
+        assert cos(a[3][k].ravel(), b[3][k].ravel()) > 0.999, (k, cos(a[3][k].ravel(), b[3][k].ravel()))
+    # the float64 oracle
+    fan = forensics.FAN(n_classes=5, patch_size=128, device=dev)
+    p = oracle_params(fan)
+    for v in p.values():
+        v.requires_grad_(True)
+    probs_ref = onets.fan_forward(p, to64(x))
+    loss_ref = T.sparse_ce_from_probs(probs_ref, labels)
+    g_ref = dict(zip(p.keys(), torch.autograd.grad(loss_ref, list(p.values()))))
+    assert np.abs(a[0] - probs_ref.detach().numpy()).max() < 2e-2
+    for k in ('conv1x1/kernel', 'conv4/kernel', 'conv3/kernel', 'dense/kernel' if 'dense/kernel' in g_ref else list(g_ref)[-2]):
+        assert cos(a[3][k].ravel(), g_ref[k].numpy().ravel()) > 0.98, k
