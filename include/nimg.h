@@ -262,8 +262,16 @@ int nimg_stream_destroy(void* stream);
  *                    the gradient at the INPUT of the 1x1 layer straight from the classifier's dlogits (n, k); in_mask bf16 or NULL.
  *   nimg_head_dact:  the gradient at the 1x1 layer's pre-activation as bf16 (n * hw, c), for its weight gradient. */
 int nimg_head_fused_ok(int hw, int c);
-int nimg_head_fwd(const void* x, const void* wimg, const float* bias, unsigned* mask, float* gap, int n, int hw, int c,
-                  float alpha, void* stream);
+int nimg_head_fwd(const void* x, const void* wimg, const float* bias, unsigned* mask, unsigned* mask_p, float* gap, int n, int hw,
+                  int c, float alpha, void* stream);
+/*   nimg_head_wgrad: weight + bias gradient of the 1x1 layer from its bf16 input x and the PIXEL-MAJOR sign words mask_p
+ *                    (n, hw / 32, c): bit j of word [n][b][co] = the activation of channel co at pixel 32 b + j is > 0 (written by
+ *                    nimg_head_fwd next to mask) - the gradient at the pre-activation is built inside the kernel.  dw (c, c) in the
+ *                    Keras (1, 1, cin, cout) layout, db (c) or NULL; split over the images, fixed-order reduction through
+ *                    `workspace` (nimg_head_wgrad_workspace_bytes). */
+size_t nimg_head_wgrad_workspace_bytes(int n, int c);
+int nimg_head_wgrad(const void* x, const unsigned* mask_p, const float* dlogits, const float* wdense, int k, float* dw, float* db,
+                    int n, int hw, int c, float alpha, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 int nimg_head_dgrad(const unsigned* mask, const float* dlogits, const float* wdense, int k, const void* wimg_t,
                     const void* in_mask, void* dx, int n, int hw, int c, float alpha, void* stream);
 int nimg_head_dact(const unsigned* mask, const float* dlogits, const float* wdense, int k, void* dact, int n, int hw, int c,

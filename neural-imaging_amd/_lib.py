@@ -68,7 +68,9 @@ PROTOTYPES = {
     'nimg_stream_create_cu_mask': (c_int, [c_int, P]),
     'nimg_stream_destroy': (c_int, [P]),
     'nimg_head_fused_ok': (c_int, [c_int, c_int]),
-    'nimg_head_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_float, P]),
+    'nimg_head_fwd': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_float, P]),
+    'nimg_head_wgrad_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'nimg_head_wgrad': (c_int, [P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_float, c_int, P, c_size_t, P]),
     'nimg_head_dgrad': (c_int, [P, P, P, c_int, P, P, P, c_int, c_int, c_int, c_float, P]),
     'nimg_head_dact': (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_float, P]),
     'nimg_fan_dense_fwd': (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_float, P]),

@@ -147,7 +147,8 @@ class FAN(TFModel):
         if self._use_gap and not self._hidden and not self._generic_act and c5.cin == c5.cout and ops.head_fused_ok(net, c5.cout):
             # throughput mode: 1x1 conv + LeakyReLU + global average pooling in ONE pass (csrc/head.hip); the activation leaves as
             # one sign bit per value, all the backward pass needs of it
-            gap, mask = ops.head_fwd(net, P.p[c5.name + '/kernel'], P.p[c5.name + '/bias'], want_mask=training)
+            gap, mask, mask_p = ops.head_fwd(net, P.p[c5.name + '/kernel'], P.p[c5.name + '/bias'], want_mask=training)
+            t['head_mask_p'] = mask_p
             probs, loss_per, dlogits = ops.fan_dense_fwd(gap, P.p[self._cls + '/kernel'], P.p[self._cls + '/bias'], labels, ls)
             t['head_mask'], t['gap'], t['probs'], t['loss_per'], t['dlogits'], t['loss_scale'] = mask, gap, probs, loss_per, dlogits, ls
             return probs, (t if training else None)
@@ -224,9 +225,8 @@ class FAN(TFModel):
         loss = ops.fan_dense_bwd(t['gap'], t['dlogits'], t['loss_per'], t['loss_scale'], P.g[self._cls + '/kernel'],
                                  P.g[self._cls + '/bias'])
         dw = P.g[c5.name + '/kernel']
-        with ops.side_stream(pool, t['head_mask'], t['dlogits'], wd, key=dw.data_ptr()):
-            dact = ops.head_dact(t['head_mask'], t['dlogits'], wd, pool.shape)
-            ops.conv2d_wgrad(pool, dact, 1, dw=dw, db=P.g[c5.name + '/bias'])
+        with ops.side_stream(pool, t['head_mask_p'], t['dlogits'], wd, key=dw.data_ptr()):
+            ops.head_wgrad(pool, t['head_mask_p'], t['dlogits'], wd, dw.view(dw.shape[2], dw.shape[3]), P.g[c5.name + '/bias'])
         d_pool = ops.head_dgrad(t['head_mask'], t['dlogits'], wd, P.p[c5.name + '/kernel'],
                                 pool if t.get('idx{}'.format(len(self._convs))) is not None else None, pool.shape)
         return d_pool, loss

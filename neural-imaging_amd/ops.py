@@ -1175,13 +1175,30 @@ def head_fused_ok(x, cout):
 
 
 def head_fwd(x, w, b, want_mask=True):
-    """x (N,H,W,C) bf16, w (1,1,C,C), b (C) -> gap (N,C) float32, mask (N*H*W, C/32) int32 sign bits of the activation (or None)."""
+    """x (N,H,W,C) bf16, w (1,1,C,C), b (C) -> gap (N,C) float32, mask (N*H*W, C/32), mask_p (N, H*W/32, C): int32 sign bits of
+    the activation in the two layouts the backward kernels read (or None, None)."""
     _chk(x, w, b)
     n, h, wd, c = x.shape
     gap = torch.empty((n, c), dtype=torch.float32, device=x.device)
-    mask = torch.empty((n * h * wd, c // 32), dtype=torch.int32, device=x.device) if want_mask else None
-    _lib.call('nimg_head_fwd', _p(x), _p(weights_bf16(w, 0)), _p(b), _p(mask), _p(gap), n, h * wd, c, LRELU_ALPHA, _stream())
-    return gap, mask
+    mask = mask_p = None
+    if want_mask:           # the same sign bits twice: channel-major words per pixel (input gradient), pixel-major per channel (weights)
+        mask = torch.empty((n * h * wd, c // 32), dtype=torch.int32, device=x.device)
+        mask_p = torch.empty((n, h * wd // 32, c), dtype=torch.int32, device=x.device)
+    _lib.call('nimg_head_fwd', _p(x), _p(weights_bf16(w, 0)), _p(b), _p(mask), _p(mask_p), _p(gap), n, h * wd, c, LRELU_ALPHA,
+              _stream())
+    return gap, mask, mask_p
+
+
+def head_wgrad(x, mask_p, dlogits, wdense, dw, db=None, accumulate=False):
+    """Weight (+ bias) gradient of the fused head's 1x1 layer from its bf16 input and the pixel-major sign words."""
+    _chk(x, mask_p, dlogits, wdense)
+    _f32(dw, db)
+    n, h, wd, c = x.shape
+    need = _lib.load().nimg_head_wgrad_workspace_bytes(n, c)
+    ws = _ws_current(x.device).get(need, x.device)
+    _lib.call('nimg_head_wgrad', _p(x), _p(mask_p), _p(dlogits), _p(wdense), dlogits.shape[1], _p(dw), _p(db), n, h * wd, c,
+              LRELU_ALPHA, 1 if accumulate else 0, _p(ws), ws.numel(), _stream())
+    return dw
 
 
 def fan_dense_fwd(gap, w, b, labels=None, loss_scale=1.0):

@@ -2246,7 +2246,7 @@ def test_fused_head_kernels_against_the_generic_path(dev, hw, c):
     ops.set_compute('bf16')
     try:
         assert ops.head_fused_ok(x, c)
-        gap, mask = ops.head_fwd(x, w, b)
+        gap, mask, mask_p = ops.head_fwd(x, w, b)
         a = ops.conv2d(x, w, b, act='leaky_relu').float()                     # generic 1x1 kernel, float32 result
         assert_close(gap.cpu().numpy(), a.mean(dim=(1, 2)).cpu().numpy(), 1e-5, 1e-4, what='pooled feature')
         bits = (mask.view(n, hw[0], hw[1], c // 32, 1) >> torch.arange(32, device=dev, dtype=torch.int32)) & 1
@@ -2262,6 +2262,17 @@ def test_fused_head_kernels_against_the_generic_path(dev, hw, c):
         scale = np.abs(dx_ref).max()
         assert np.abs(dx - dx_ref).max() <= 1e-2 * scale                      # one bf16 ulp of the largest entry
         assert np.mean(np.abs(dx - dx_ref) > 1e-3 * scale) < 0.02
+        # the same bits, pixel-major
+        bits_p = (mask_p.view(n, hw[0] * hw[1] // 32, 1, c) >> torch.arange(32, device=dev, dtype=torch.int32).view(1, 1, 32, 1)) & 1
+        assert torch.equal(bits_p.reshape(n, hw[0], hw[1], c), bits.reshape(n, hw[0], hw[1], c))
+        # weight + bias gradient of the 1x1 layer: the generic kernel on the materialised gradient
+        dw_ref, db_ref = torch.empty_like(w), torch.empty_like(b)
+        ops.conv2d_wgrad(x, dact, 1, dw=dw_ref, db=db_ref)
+        dw, db = torch.empty_like(w), torch.empty_like(b)
+        ops.head_wgrad(x, mask_p, dlogits, wd, dw.view(c, c), db)
+        assert_close(dw.cpu().numpy(), dw_ref.cpu().numpy(), 1e-7, 1e-4, what='head dW')
+        assert_close(db_ref.cpu().numpy(), dact_ref.sum(dim=(0, 1, 2)).cpu().numpy(), 1e-7, 1e-2, what='generic db')   # (bf16-rounded tensor)
+        assert_close(db.cpu().numpy(), dact_ref.sum(dim=(0, 1, 2)).cpu().numpy(), 1e-7, 1e-4, what='head db')      # (exact g)
         dx0 = ops.head_dgrad(mask, dlogits, wd, w, None, x.shape).float().cpu().numpy()        # no mask below
         dx0_ref = ops.conv2d_dgrad(dact_ref.contiguous(), w, hw, out_bf16=True).float().cpu().numpy()
         assert np.abs(dx0 - dx0_ref).max() <= 1e-2 * np.abs(dx0_ref).max()

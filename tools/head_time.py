@@ -43,7 +43,11 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         return 1e3 * e0.elapsed_time(e1) / args.reps
-    gap, mask = ops.head_fwd(x, w, b)
+    gap, mask, mask_p = ops.head_fwd(x, w, b)
+    dw, db = torch.empty_like(w), torch.empty_like(b)
+    print('head_wgrad           %7.1f us' % timed(lambda: ops.head_wgrad(x, mask_p, dlogits, wd, dw.view(c, c), db)))
+    dact = ops.head_dact(mask, dlogits, wd, x.shape)
+    print('generic 1x1 wgrad    %7.1f us' % timed(lambda: ops.conv2d_wgrad(x, dact, 1, dw=dw, db=db)))
     print('head_fwd (mask)      %7.1f us' % timed(lambda: ops.head_fwd(x, w, b)))
     print('head_fwd (no mask)   %7.1f us' % timed(lambda: ops.head_fwd(x, w, b, want_mask=False)))
     print('head_dgrad (mask)    %7.1f us' % timed(lambda: ops.head_dgrad(mask, dlogits, wd, w, x, x.shape)))
