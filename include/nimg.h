@@ -443,7 +443,8 @@ int nimg_cconv3_dgrad_border(const float* dc, const float* nf, float* dx, int n,
 /* First FAN convolution in throughput mode, models/forensics.py:69-70: Conv2D(32, 5x5, SAME) + bias + LeakyReLU(alpha) +
  * MaxPool2D(2) in one pass over the bf16 {c0,c1,c2,1} pixels of nimg_cconv3 (bf16 MFMA operands, float32 accumulation).
  * c4 (n,h,w,4) bf16; w (5,5,3,32) float32 HWIO; bias (32) or NULL; pooled (n,h/2,w/2,32) bf16 (out_bf16 = 1) or float32;
- * pool_idx (n,h/2,w/2,32) uint8 arg-max position inside the window (row-major, first maximum wins) or NULL.
+ * pool_idx (n,h/2,w/2,8) uint8 or NULL: the arg-max position inside the window (row-major, first maximum wins) as 2 bits per
+ * channel - channel c in byte c >> 2, bits 2 (c & 3) .. 2 (c & 3) + 1 (the layout nimg_conv1_wgrad_c4 / nimg_conv1_dgrad_pooled read).
  * h, w even; 0 < alpha <= 1 (1 = no activation). */
 int nimg_conv1_pool_fwd_c4(const void* c4, const float* w, const float* bias, void* pooled, unsigned char* pool_idx, int n,
                            int h, int w_, float alpha, int out_bf16, void* stream);

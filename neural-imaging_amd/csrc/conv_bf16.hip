@@ -1098,28 +1098,28 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : (TN == 32 ? 3 : 2)) void con
 // registers, no write pass, one barrier per chunk.  LDS images are lane-linear per 1 KB piece; the XOR swizzle of the 16-byte
 // halves (conflict-free ds_read_b128, as in the generic kernel) is applied on the source address.  Same tiles, fragment reads
 // and epilogue as conv_fwd_bf16_kernel<3, 1, TH, TW, NB, TN, true, ...>: the results are bit-identical.
-template <int TH, int TW, int NB, int TN>
+template <int TH, int TW, int NB, int TN, int NS = 2>
 struct Dma3Geom {
     static constexpr int THH = TH + 2, TWH = TW + 2, NPIXH = NB * THH * TWH;
     static constexpr int A_PIECES = (NPIXH * 2 + 63) / 64, B_PIECES = 9 * TN * 2 / 64;
     static constexpr int A_ENT = A_PIECES * 64, B_ENT = 9 * TN * 2;                     // uint4 entries of one buffer
     static constexpr int APW = (A_PIECES + 3) / 4, BPW = (B_PIECES + 3) / 4;            // pieces per wave
-    static constexpr size_t LDS_TILES = (size_t)2 * (A_ENT + B_ENT) * sizeof(uint4);
+    static constexpr size_t LDS_TILES = (size_t)NS * (A_ENT + B_ENT) * sizeof(uint4);
     static constexpr size_t LDS_EPI = (size_t)4 * 32 * (TN + EPI_PAD) * sizeof(float);
     static constexpr size_t LDS = LDS_TILES > LDS_EPI ? LDS_TILES : LDS_EPI;
 };
 
-template <int TH, int TW, int NB, int TN>
+template <int TH, int TW, int NB, int TN, int NS = 2, bool PIPE = false>
 __global__ __launch_bounds__(256) void conv3_dma_kernel(const ConvParamsB p) {
-    using G = Dma3Geom<TH, TW, NB, TN>;
+    using G = Dma3Geom<TH, TW, NB, TN, NS>;
     constexpr int THH = G::THH, TWH = G::TWH, NPIXH = G::NPIXH;
     constexpr int MFRAGS = NB * TH * TW / 32, NFRAGS = TN / 32;
     constexpr int WAVES_M = MFRAGS >= 4 ? 4 : MFRAGS, WAVES_N = 4 / WAVES_M;
     constexpr int MI = MFRAGS / WAVES_M, NI = NFRAGS / WAVES_N;
     static_assert(NI >= 1 && MFRAGS % WAVES_M == 0, "bad tile configuration");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    uint4* sA = reinterpret_cast<uint4*>(smem_raw);                  // [2][A_ENT] then [2][B_ENT]
-    uint4* sB = sA + 2 * G::A_ENT;
+    uint4* sA = reinterpret_cast<uint4*>(smem_raw);                  // [NS][A_ENT] then [NS][B_ENT]
+    uint4* sB = sA + NS * G::A_ENT;
     const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)smem_raw;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1135,6 +1135,9 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const ConvParamsB p) {
     const int iy0 = ty0 - p.pad_t, ix0 = tx0 - p.pad_l;
     const int half = lane >> 5;
     const EpiBias epi_pre = epi_bias_preload<NI>(p, lane, wn, co0, Cout);       // older than every DMA request: retires first
+    // DMA pieces THIS wave requests per chunk (the wave's vmcnt sees only its own): the partial waits of the deeper rings count them
+    constexpr int AREM = G::A_PIECES % 4, BREM = G::B_PIECES % 4;
+    const int short_by = ((AREM && wave >= AREM) ? 1 : 0) + ((BREM && wave >= BREM) ? 1 : 0);
 
     int abase[MI];
 #pragma unroll
@@ -1195,18 +1198,54 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const ConvParamsB p) {
                 const int tap = k / NB32, nb = k % NB32;
                 // rows beyond Cout (a partial last channel tile) read the next tap's rows or run out of range (zeros): their
                 // products land in accumulator columns the epilogue never stores
-                glds16(rb, lds0 + (unsigned)((2 * G::A_ENT + buf * G::B_ENT + k * 64) * 16), bvoff,
+                glds16(rb, lds0 + (unsigned)((NS * G::A_ENT + buf * G::B_ENT + k * 64) * 16), bvoff,
                        ((chunk * 9 + tap) * Cout + nb * 32) * 32);
             }
         }
     };
-    issue(0, 0);
+    // NS-slot ring, chunk c + NS - 1 requested while chunk c multiplies: a request has NS - 1 chunks' worth of matrix
+    // instructions (18 ... 36 per wave and chunk) to come back from L2 / HBM instead of one.  NS = 2 is the original double buffer.
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s * 16 < Cin) issue(s * 16, s);
     dma_wait();
     __syncthreads();
-    for (int c0 = 0, buf = 0; c0 < Cin; c0 += 16, buf ^= 1) {
-        if (c0 + 16 < Cin) issue(c0 + 16, buf ^ 1);
+    for (int c0 = 0, buf = 0, nbuf = NS - 1; c0 < Cin; c0 += 16) {
+        const bool more = c0 + (NS - 1) * 16 < Cin;
+        if (more) issue(c0 + (NS - 1) * 16, nbuf);
         const uint4* tA = sA + buf * G::A_ENT;
         const uint4* tB = sB + buf * G::B_ENT;
+        if constexpr (PIPE) {
+            // every operand fragment of the chunk is requested from LDS BEFORE the first matrix instruction (9 (MI + NI) x 4
+            // registers); the waits in front of the matrix instructions then count down one queue instead of each tap paying
+            // an LDS round trip: with one or two waves per SIMD nothing else covers that latency (profiles/r06_conv3_pipe.txt)
+            bf16x8 a[9][MI], b[9][NI];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int toff = (tap / 3) * TWH + tap % 3;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int row = tap * TN + (wn * NI + ni) * 32 + (lane & 31);
+                    const uint4 v = tB[row * 2 + (half ^ ((row >> 3) & 1))];
+                    b[tap][ni] = *reinterpret_cast<const bf16x8*>(&v);
+                }
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int pix = abase[mi] + toff;
+                    const uint4 v = tA[pix * 2 + (half ^ ((pix >> 3) & 1))];
+                    a[tap][mi] = *reinterpret_cast<const bf16x8*>(&v);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tap][mi], b[tap][ni], acc[mi][ni], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        } else
 #pragma unroll(TN == 32 ? 3 : 1)
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -1231,20 +1270,40 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const ConvParamsB p) {
                     for (int ni = 0; ni < NI; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
             }
-        dma_wait();                                    // the next chunk has landed ...
+        // chunk c + 1 has landed (the NS - 2 younger ones may still be in flight: loads retire in order) ...
+        if constexpr (NS == 2) dma_wait();
+        else {
+            constexpr int FULL = (NS - 2) * (G::APW + G::BPW);
+            if (!more) dma_wait();
+            else if (short_by == 0) dma_wait_leave<FULL>();
+            else if (short_by == 1) dma_wait_leave<FULL - (NS - 2)>();
+            else dma_wait_leave<FULL - 2 * (NS - 2)>();
+        }
         __syncthreads();                               // ... and everyone is done with this one
+        buf = buf + 1 == NS ? 0 : buf + 1;
+        nbuf = nbuf + 1 == NS ? 0 : nbuf + 1;
     }
     conv_epilogue_vec<3, TH, TW, NB, MI, NI>(acc, p, smem_raw, wave, lane, wm, wn, co0, Cout, ty0, tx0, grp, 0, epi_pre);
 }
 
-template <int TH, int TW, int NB, int TN>
+template <int TH, int TW, int NB, int TN, int NS = 2, bool PIPE = false>
 int launch_conv3_dma(const ConvParamsB& p, hipStream_t stream) {
-    using G = Dma3Geom<TH, TW, NB, TN>;
+    using G = Dma3Geom<TH, TW, NB, TN, NS>;
+    if constexpr (NS == 2 && !PIPE) {
+        // NIMG_CONV3_STAGES=3 (three-slot ring: a chunk's transfers get two chunks of matrix work to land), NIMG_CONV3_PIPE=1 (all
+        // operand fragments of a chunk requested from LDS before its first matrix instruction): A/B switches, both measured
+        // NEGATIVE on the UNet's layers (profiles/r06_conv3_stages_pipe.txt: the layers are bound by neither latency:
+        // the LDS bank conflicts of the pixel-major halo tile and the 2 x 1 fragment block of the 32-channel tiles are)
+        static const int stages = getenv("NIMG_CONV3_STAGES") ? atoi(getenv("NIMG_CONV3_STAGES")) : 2;
+        static const int pipe = getenv("NIMG_CONV3_PIPE") ? atoi(getenv("NIMG_CONV3_PIPE")) : 0;
+        if (stages == 3) return pipe ? launch_conv3_dma<TH, TW, NB, TN, 3, true>(p, stream) : launch_conv3_dma<TH, TW, NB, TN, 3, false>(p, stream);
+        if (pipe) return launch_conv3_dma<TH, TW, NB, TN, 2, true>(p, stream);
+    }
     ConvParamsB q = p;
     q.tiles_y = cdiv(p.Hout, TH);
     q.tiles_x = cdiv(p.Wout, TW);
     const long blocks = (long)cdiv(p.O1 + p.O2, TN) * q.tiles_y * q.tiles_x * cdiv(p.N, NB);
-    auto kern = conv3_dma_kernel<TH, TW, NB, TN>;
+    auto kern = conv3_dma_kernel<TH, TW, NB, TN, NS, PIPE>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), G::LDS, stream, q);
     NIMG_CHECK_LAUNCH();

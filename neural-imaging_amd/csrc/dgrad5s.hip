@@ -80,14 +80,19 @@ constexpr int S_LDS_TILES = 2 * S_SLAB + 2 * S_ABUF;
 constexpr int S_LDS_EPI = 4 * 32 * (128 + EPI_PAD) * 4;
 constexpr int S_LDS = S_LDS_TILES > S_LDS_EPI ? S_LDS_TILES : S_LDS_EPI;
 
+// MI x NI = the fragment block of a wave (8 accumulators): 2 x 4 = four waves stacked along the pixels, each across all four parity
+// classes; 4 x 2 = two pixel halves x two class pairs - the dense operand (2 KB per fragment) is read half as often per matrix
+// instruction (8 KB of LDS reads per 8 instructions instead of 10) and is 2 % SLOWER (profiles/r06_dgrad5s_block.txt): opt-in
+template <int MI>
 __global__ __launch_bounds__(256, 2) void conv5_dgrad_sparse_kernel(const Dg5sParams p) {
-    constexpr int MI = 2, NI = 4;
+    constexpr int NI = 8 / MI, WAVES_M = 8 / MI;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned char* sB = smem_raw;                                   // ring first: the LDS-DMA base (M0) stays below 64 KB
     unsigned char* sA = smem_raw + 2 * S_SLAB;
     const unsigned sB_addr = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)smem_raw;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
     const int h = lane >> 5, nl = lane & 31;
     const int nts = p.Ci / 32, chunks = p.Cz / 8;
     int bid = xcd_order(blockIdx.x);
@@ -161,10 +166,10 @@ __global__ __launch_bounds__(256, 2) void conv5_dgrad_sparse_kernel(const Dg5sPa
     int abase[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-        const int P = (wave * MI + mi) * 32 + nl;
+        const int P = (wm * MI + mi) * 32 + nl;
         abase[mi] = (P / S_TP) * S_HP + (P % S_TP);                 // halo pixel of the tile pixel's (wy, wx) = (0, 0) neighbour
     }
-    const int bbase = h * 2 * 2048 + nl * 16;
+    const int bbase = h * 2 * 2048 + nl * 16 + wn * NI * 512;
 
     gldsB(0, 0, 0);
     fetchA(0);
@@ -216,8 +221,8 @@ __global__ __launch_bounds__(256, 2) void conv5_dgrad_sparse_kernel(const Dg5sPa
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         epilogue_via_lds<NI, false>(acc[mi], elds, lane, [&](int row, int c, float4 v) {
-            const int P = (wave * MI + mi) * 32 + row;
-            const int a_ = ty0 + P / S_TP, b_ = tx0 + P % S_TP, cls = c >> 5;
+            const int P = (wm * MI + mi) * 32 + row;
+            const int a_ = ty0 + P / S_TP, b_ = tx0 + P % S_TP, cls = wn * NI + (c >> 5);
             if (a_ >= p.Hp || b_ >= p.Wp) return;
             const long o = (((long)n * H + 2 * a_ + (cls >> 1)) * W + 2 * b_ + (cls & 1)) * p.Ci + nt * 32 + (c & 31);
             if (p.act) {
@@ -275,8 +280,10 @@ int nimg_conv5_dgrad_sparse(const void* g, const unsigned char* idx, int cout, c
     p.tiles_y = nimg::cdiv(p.Hp, S_TP);
     p.tiles_x = nimg::cdiv(p.Wp, S_TP);
     const long blocks = (long)(cin / 32) * p.tiles_y * p.tiles_x * n;
-    (void)hipFuncSetAttribute((const void*)conv5_dgrad_sparse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS);
-    hipLaunchKernelGGL(conv5_dgrad_sparse_kernel, dim3((unsigned)blocks), dim3(256), S_LDS, (hipStream_t)stream, p);
+    static const bool block42 = getenv("NIMG_DGRAD5S_BLOCK42") != nullptr;        // A/B: the 4 x 2 fragment block (round 6, slower)
+    auto kern = block42 ? conv5_dgrad_sparse_kernel<4> : conv5_dgrad_sparse_kernel<2>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), S_LDS, (hipStream_t)stream, p);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }

@@ -424,11 +424,11 @@ __global__ __launch_bounds__(256, CONV1_WGS) void conv1_pool_fwd_kernel(const vo
             const int py = (y0 + 2 * ur) >> 1, px = ((x0 + 64 * uc) >> 1) + nl;
             if (py < Hp && px < Wp) {
                 const long po = ((long)(n * Hp + py) * Wp + px) * 32 + 16 * h;
-                if (pidx) {
-                    unsigned ib[4];
+                if (pidx) {                       // 2 bits per channel: byte c >> 2 of the pixel's 8, bits 2 (c & 3)
+                    unsigned ib = 0;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) ib[g] = kk[4 * g] | (kk[4 * g + 1] << 8) | (kk[4 * g + 2] << 16) | (kk[4 * g + 3] << 24);
-                    *reinterpret_cast<uint4*>(pidx + po) = make_uint4(ib[0], ib[1], ib[2], ib[3]);
+                    for (int r = 0; r < 16; ++r) ib |= kk[r] << (2 * r);
+                    *reinterpret_cast<unsigned*>(pidx + (po >> 2)) = ib;
                 }
                 if constexpr (OUT_BF16) {
                     unsigned pb[8];
@@ -487,6 +487,21 @@ __device__ __forceinline__ bf16x8 tr_read8(const unsigned char* p0, const unsign
     return *reinterpret_cast<bf16x8*>(&r);
 }
 
+// The arg-max of the first pooling layer is stored as 2 bits per value (8 bytes per pooled pixel of 32 channels instead of 32:
+// -0.38 GB per step over conv1_pool_fwd / conv1_wgrad_pooled / conv1_dgrad_pooled, whose traffic bounds them).  The 16 bits of
+// an 8-channel chunk -> the two words of byte-per-channel codes the routing below works on.
+__device__ __forceinline__ u32x2 argmax2_bytes(unsigned short k16) {
+    const unsigned k = k16;
+    auto spread = [](unsigned x) {                        // x = 4 fields of 2 bits -> one field per byte
+        const unsigned t = (x | (x << 12)) & 0x000F000Fu;
+        return (t | (t << 6)) & 0x03030303u;
+    };
+    u32x2 r;
+    r[0] = spread(k & 0xFFu);
+    r[1] = spread(k >> 8);
+    return r;
+}
+
 // 4 arg-max bytes (values 0..3) -> 0xFF in every byte that equals pos
 __device__ __forceinline__ unsigned eq_bytes(unsigned k, unsigned pos) {
     const unsigned x = k ^ (pos * 0x01010101u);
@@ -517,7 +532,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_pooled_kernel(const void* __r
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(gp), 0,
                                                                         (int)((long)N * Hp * Wp * 32 * (GB ? 2 : 4)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(pidx), 0,
-                                                                        (int)((long)N * Hp * Wp * 32), 0x00020000);
+                                                                        (int)((long)N * Hp * Wp * 8), 0x00020000);
     // per-lane parts of the transpose-read addresses
     const int tl = 4 * q1 + (g16 & 3);                               // this lane's tap inside an 8-tap M fragment
     int a_off[4];
@@ -561,7 +576,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_pooled_kernel(const void* __r
                 pg[q][0] = __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? e * 4 : OOB, 0, 0);
                 pg[q][1] = __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? e * 4 + 16 : OOB, 0, 0);
             }
-            pk[q] = __builtin_amdgcn_raw_buffer_load_b64(rk, ok ? e : OOB, 0, 0);
+            pk[q] = argmax2_bytes(__builtin_amdgcn_raw_buffer_load_b16(rk, ok ? e >> 2 : OOB, 0, 0));
         }
     };
     if (w_begin < w_end) fetch(w_begin);
@@ -677,7 +692,7 @@ __global__ __launch_bounds__(256) void conv1_dgrad_pooled_kernel(const void* __r
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(gp), 0,
                                                                         (int)((long)N * Hp * Wp * 32 * (GB ? 2 : 4)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(pidx), 0,
-                                                                        (int)((long)N * Hp * Wp * 32), 0x00020000);
+                                                                        (int)((long)N * Hp * Wp * 8), 0x00020000);
     // A operand: row m = (kx, i) = nl (row 15 is empty), K values o = 8 kg .. 8 kg + 7, one fragment per ky
     bf16x8 wa[5];
 #pragma unroll
@@ -704,7 +719,7 @@ __global__ __launch_bounds__(256) void conv1_dgrad_pooled_kernel(const void* __r
                 pg[q][0] = __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? e * 4 : OOB, 0, 0);
                 pg[q][1] = __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? e * 4 + 16 : OOB, 0, 0);
             }
-            pk[q] = __builtin_amdgcn_raw_buffer_load_b64(rk, ok ? e : OOB, 0, 0);
+            pk[q] = argmax2_bytes(__builtin_amdgcn_raw_buffer_load_b16(rk, ok ? e >> 2 : OOB, 0, 0));
         }
     };
     const int first = xcd_order(blockIdx.x);
@@ -962,7 +977,7 @@ int nimg_conv1_pool_fwd_c4(const void* c4, const float* w, const float* bias, vo
         const long px0 = (long)n0 * h * wd, pp0 = (long)n0 * (h / 2) * (wd / 2) * 32;
         const void* src = (const char*)c4 + px0 * 8;
         void* dst = (char*)pooled + pp0 * esz;
-        unsigned char* di = pool_idx ? pool_idx + pp0 : nullptr;
+        unsigned char* di = pool_idx ? pool_idx + (pp0 >> 2) : nullptr;       // 2 bits per value
         const int rc = wd > 96 ? launch_conv1_pool<256>(src, w, bias, dst, di, nn, h, wd, alpha, out_bf16, (hipStream_t)stream)
                                : launch_conv1_pool<64>(src, w, bias, dst, di, nn, h, wd, alpha, out_bf16, (hipStream_t)stream);
         if (rc != NIMG_OK) return rc;

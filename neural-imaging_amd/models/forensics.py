@@ -285,17 +285,19 @@ class FAN(TFModel):
             conv = self._convs[i - 1]
             inp = t['pool{}'.format(i - 1)] if i > 1 else t['constrained']
             prev_mask = inp if fused(i - 1) else None
+            if i == 1 and t.get('front'):
+                # row-band front end: `inp` is the filtered image as 8-byte bf16 pixels, idx1 the 2-bit arg-max codes only these
+                # two kernels read (ops.conv1_pool_c4)
+                params(lambda inp=inp, g=d_pool, i=i, conv=conv: ops.conv1_wgrad_c4(
+                    inp, g, t['idx{}'.format(i)], dw=P.g[conv.name + '/kernel'], db=P.g[conv.name + '/bias'], side=True), i)
+                d_pool = ops.conv1_dgrad_pooled(d_pool, t['idx{}'.format(i)], P.p[conv.name + '/kernel'])
+                continue
             if fused(i) and ops.pooled_backward_ok(conv.cin, conv.cout, conv.ks) and prev_mask is None:
                 # the pooled gradient feeds the weight / input gradient kernels directly (un-pooled while staging)
-                if t.get('front'):     # row-band front end: `inp` is the filtered image as 8-byte bf16 pixels
-                    params(lambda inp=inp, g=d_pool, i=i, conv=conv: ops.conv1_wgrad_c4(
-                        inp, g, t['idx{}'.format(i)], dw=P.g[conv.name + '/kernel'], db=P.g[conv.name + '/bias'], side=True), i)
-                    d_pool = ops.conv1_dgrad_pooled(d_pool, t['idx{}'.format(i)], P.p[conv.name + '/kernel'])
-                else:
-                    params(lambda inp=inp, g=d_pool, i=i, conv=conv: ops.conv2d_wgrad_pooled(
-                        inp, g, t['idx{}'.format(i)], conv.ks, dw=P.g[conv.name + '/kernel'], db=P.g[conv.name + '/bias'],
-                        side=True), i)
-                    d_pool = ops.conv2d_dgrad_pooled(d_pool, t['idx{}'.format(i)], P.p[conv.name + '/kernel'])
+                params(lambda inp=inp, g=d_pool, i=i, conv=conv: ops.conv2d_wgrad_pooled(
+                    inp, g, t['idx{}'.format(i)], conv.ks, dw=P.g[conv.name + '/kernel'], db=P.g[conv.name + '/bias'],
+                    side=True), i)
+                d_pool = ops.conv2d_dgrad_pooled(d_pool, t['idx{}'.format(i)], P.p[conv.name + '/kernel'])
                 continue
             if fused(i) and ops.unpool_fold_ok(inp, d_pool, conv.cin, conv.cout, conv.ks):
                 # throughput mode, 5x5 layers: both gradient kernels read (pooled gradient, arg-max bytes) and route while

@@ -985,7 +985,7 @@ def pooled_backward_ok(cin, cout, ks):
 
 
 def conv2d_wgrad_pooled(x, g, idx, ks, dw=None, db=None, side=False):
-    """Weight / bias gradient of conv2d_pool from the pooled gradient g (already x LeakyReLU') and the arg-max bytes."""
+    """Weight / bias gradient of conv2d_pool from the pooled gradient g (already x LeakyReLU') and the 2-bit arg-max codes."""
     if side and _SIDE['enabled'] and dw is not None:
         with _on_side_stream(x, g, idx, key=dw.data_ptr()):
             return conv2d_wgrad_pooled(x, g, idx, ks, dw=dw, db=db, side=False)
@@ -1351,21 +1351,22 @@ def front_end_ok(cin, cout, ks, h, w, n=None):
 
 def conv1_pool_c4(c4, w, bias, act='leaky_relu', want_idx=True, out_bf16=True):
     """Conv2D(32, 5x5, SAME) + bias + activation + MaxPool2D(2) over the bf16 {c0,c1,c2,1} pixels written by cconv3 (the FAN's
-    first convolution, throughput mode).  Returns (pooled (N,H/2,W/2,32), arg-max bytes | None)."""
+    first convolution, throughput mode).  Returns (pooled (N,H/2,W/2,32), arg-max codes (N,H/2,W/2,8) uint8 | None): 2 bits per
+    channel, channel c in byte c >> 2 at bits 2 (c & 3) (include/nimg.h nimg_conv1_pool_fwd_c4)."""
     _f32(w, bias)
     _chk(c4)
     n, h, wd, c = c4.shape
     if c4.dtype != torch.bfloat16 or c != 4 or tuple(w.shape) != (5, 5, 3, 32) or (h & 1) or (wd & 1):
         raise ValueError('conv1_pool_c4: (N,H,W,4) bf16 pixels, a (5,5,3,32) kernel and even sizes expected')
     pooled = torch.empty((n, h // 2, wd // 2, 32), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=c4.device)
-    idx = torch.empty((n, h // 2, wd // 2, 32), dtype=torch.uint8, device=c4.device) if want_idx else None
+    idx = torch.empty((n, h // 2, wd // 2, 8), dtype=torch.uint8, device=c4.device) if want_idx else None
     _lib.call('nimg_conv1_pool_fwd_c4', _p(c4), _p(w), _p(bias), _p(pooled), _p(idx), n, h, wd,
               LRELU_ALPHA if act == 'leaky_relu' else 1.0, 1 if out_bf16 else 0, _stream())
     return pooled, idx
 
 
 def conv1_wgrad_c4(c4, g, idx, dw=None, db=None, accumulate=False, side=False):
-    """Weight / bias gradient of conv1_pool_c4 from the pooled gradient g (already x LeakyReLU') and the arg-max bytes."""
+    """Weight / bias gradient of conv1_pool_c4 from the pooled gradient g (already x LeakyReLU') and the 2-bit arg-max codes."""
     if side and _SIDE['enabled'] and dw is not None:
         with _on_side_stream(c4, g, idx, key=dw.data_ptr()):
             return conv1_wgrad_c4(c4, g, idx, dw=dw, db=db, accumulate=accumulate, side=False)
@@ -1373,8 +1374,9 @@ def conv1_wgrad_c4(c4, g, idx, dw=None, db=None, accumulate=False, side=False):
     _fb(g)
     _chk(c4, idx)
     n, h, wd, _ = c4.shape
-    if c4.dtype != torch.bfloat16 or tuple(g.shape) != (n, h // 2, wd // 2, 32) or tuple(idx.shape) != tuple(g.shape):
-        raise ValueError('conv1_wgrad_c4: (N,H,W,4) bf16 pixels and (N,H/2,W/2,32) gradient / arg-max tensors expected')
+    if c4.dtype != torch.bfloat16 or tuple(g.shape) != (n, h // 2, wd // 2, 32) or tuple(idx.shape) != (n, h // 2, wd // 2, 8) or \
+            idx.dtype != torch.uint8:
+        raise ValueError('conv1_wgrad_c4: (N,H,W,4) bf16 pixels, a (N,H/2,W/2,32) gradient and (N,H/2,W/2,8) arg-max codes expected')
     if dw is None:
         dw = torch.empty((5, 5, 3, 32), dtype=torch.float32, device=c4.device)
     need = _lib.load().nimg_conv1_wgrad_c4_workspace_bytes()
@@ -1385,13 +1387,13 @@ def conv1_wgrad_c4(c4, g, idx, dw=None, db=None, accumulate=False, side=False):
 
 
 def conv1_dgrad_pooled(g, idx, w, out=None):
-    """Input gradient (N,H,W,3) of conv1_pool_c4 from the pooled gradient g (N,H/2,W/2,32) and the arg-max bytes."""
+    """Input gradient (N,H,W,3) of conv1_pool_c4 from the pooled gradient g (N,H/2,W/2,32) and the 2-bit arg-max codes."""
     _f32(w, out)
     _fb(g)
     _chk(idx)
     n, hp, wp, c = g.shape
-    if c != 32 or tuple(w.shape) != (5, 5, 3, 32) or tuple(idx.shape) != tuple(g.shape):
-        raise ValueError('conv1_dgrad_pooled: (N,H/2,W/2,32) gradient / arg-max tensors and a (5,5,3,32) kernel expected')
+    if c != 32 or tuple(w.shape) != (5, 5, 3, 32) or tuple(idx.shape) != (n, hp, wp, 8) or idx.dtype != torch.uint8:
+        raise ValueError('conv1_dgrad_pooled: a (N,H/2,W/2,32) gradient, (N,H/2,W/2,8) arg-max codes and a (5,5,3,32) kernel expected')
     if out is None:
         out = torch.empty((n, 2 * hp, 2 * wp, 3), dtype=torch.float32, device=g.device)
     _lib.call('nimg_conv1_dgrad_pooled', _p(g), _p(idx), _p(w), _p(out), n, 2 * hp, 2 * wp, 1 if _is_bf16(g) else 0, _stream())

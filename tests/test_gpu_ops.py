@@ -620,6 +620,19 @@ def _bf16_round(a):
     return torch.from_numpy(np.asarray(a, np.float32)).to(torch.bfloat16).double()
 
 
+def unpack_argmax2(p):
+    """(..., 8) uint8 codes of nimg_conv1_pool_fwd_c4 -> (..., 32) arg-max positions: channel c = byte c >> 2, bits 2 (c & 3)."""
+    c = np.arange(32)
+    return (p[..., c >> 2] >> (2 * (c & 3))) & 3
+
+
+def pack_argmax2(k):
+    p = np.zeros(k.shape[:-1] + (8,), np.uint8)
+    for c in range(32):
+        p[..., c >> 2] |= (k[..., c].astype(np.uint8) & 3) << (2 * (c & 3))
+    return p
+
+
 @pytest.mark.parametrize('shape,out_bf16', [((2, 16, 32), False), ((1, 24, 72), True), ((3, 64, 64), True), ((1, 10, 256), False),
                                             ((2, 256, 256), True)])
 def test_conv1_pool_front_end(dev, shape, out_bf16):
@@ -644,7 +657,8 @@ def test_conv1_pool_front_end(dev, shape, out_bf16):
     win = act.numpy().reshape(n, h // 2, 2, w // 2, 2, 32).transpose(0, 1, 3, 5, 2, 4).reshape(n, h // 2, w // 2, 32, 4)
     srt = np.sort(win, axis=-1)
     clear = (srt[..., 3] - srt[..., 2]) > 1e-4 * (1.0 + np.abs(srt[..., 3]))
-    k = idx.cpu().numpy()
+    assert tuple(idx.shape) == (n, h // 2, w // 2, 8)
+    k = unpack_argmax2(idx.cpu().numpy())
     assert clear.mean() > 0.99 and np.array_equal(k[clear], win.argmax(axis=-1)[clear]) and k.max() <= 3
     # same kernel, no activation (alpha = 1) and no bias / no arg-max output
     p2, i2 = ops.conv1_pool_c4(c4.contiguous(), g(wk, dev), None, act=None, want_idx=False, out_bf16=out_bf16)
@@ -672,16 +686,16 @@ def test_conv1_wgrad_front_end(dev, shape, g_bf16):
     gd = gp.to(torch.bfloat16 if g_bf16 else torch.float32).to(dev).contiguous()
     dw = torch.full((5, 5, 3, 32), 7.0, device=dev)
     db = torch.full((32,), 7.0, device=dev)
-    ops.conv1_wgrad_c4(c4.contiguous(), gd, torch.from_numpy(k).to(dev), dw=dw, db=db)
+    ops.conv1_wgrad_c4(c4.contiguous(), gd, torch.from_numpy(pack_argmax2(k)).to(dev), dw=dw, db=db)
     assert_close(dw.cpu().numpy(), wk.grad.numpy(), 1e-6, 2e-5, what='conv1 dw')
     assert_close(db.cpu().numpy(), dz.sum(axis=(0, 1, 2)), 1e-6, 2e-5, what='conv1 db')
-    ops.conv1_wgrad_c4(c4.contiguous(), gd, torch.from_numpy(k).to(dev), dw=dw, db=db, accumulate=True)
+    ops.conv1_wgrad_c4(c4.contiguous(), gd, torch.from_numpy(pack_argmax2(k)).to(dev), dw=dw, db=db, accumulate=True)
     assert_close(dw.cpu().numpy(), 2 * wk.grad.numpy(), 1e-6, 4e-5, what='conv1 dw, accumulated')
     # input gradient from the same pooled gradient (conv1_dgrad_pooled_kernel): autograd w.r.t. the image, bf16-rounded kernel
     cx = c.clone().requires_grad_(True)
     wb = _bf16_round(wk.detach().numpy())
     (T.conv2d(cx, wb, None) * to64(dz)).sum().backward()
-    dc = ops.conv1_dgrad_pooled(gd, torch.from_numpy(k).to(dev), g(wk.detach().numpy(), dev))
+    dc = ops.conv1_dgrad_pooled(gd, torch.from_numpy(pack_argmax2(k)).to(dev), g(wk.detach().numpy(), dev))
     assert_close(dc.cpu().numpy(), cx.grad.numpy(), 1e-6, 2e-5, what='conv1 input gradient')
 
 

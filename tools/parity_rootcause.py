@@ -30,7 +30,9 @@ sys.path.insert(0, os.path.join(ROOT, 'tools'))
 
 
 def run(tp, ops, dev, mode, recipe, pool, held, args, seed):
-    ops.set_compute(mode)
+    # mode 'bf16s32': bf16 matrix operands, FAN- / UNet-internal tensors STORED as float32 (ops.STORE_BF16 off)
+    ops.STORE_BF16 = mode != 'bf16s32'
+    ops.set_compute('bf16' if mode.startswith('bf16') else mode)
     wf = tp.make_flow(dev, args.raw_patch)
     t0 = time.time()
     tp.pretrain_nip(wf, pool, args.pretrain, args.pretrain_lr, args.batch, seed=11)
@@ -84,7 +86,7 @@ def main():
             entry = {'recipe': recipe, 'seed': seed, 'trajectory': {}}
             for mode in args.modes.split(','):
                 wfs[mode], entry['trajectory'][mode] = run(tp, ops, dev, mode, recipe, pool, held, args, seed)
-            if len(wfs) == 2:
+            if set(wfs) == {'bf16', 'f32'}:
                 entry['parity'] = tp.compare(wfs, held, args.batch)
                 print(recipe, seed, 'PARITY', json.dumps({k: v for k, v in entry['parity'].items() if not isinstance(v, dict)}),
                       flush=True)
