@@ -415,7 +415,12 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
     auto kern = conv_fwd_kernel<KS, STRIDE, TH, TW, NB, TN, CK, VEC>;
     static bool attr_set = false;   // opt in to > 64 KiB dynamic LDS once per instantiation
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        // the 6x6 ... 11x11 tiles take 93 - 121 KB: a part with less LDS than gfx950's 160 KB refuses here - report the
+        // configuration as unsupported instead of failing at the launch
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return NIMG_ERR_ARG;
+        }
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, q);

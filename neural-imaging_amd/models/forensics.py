@@ -325,8 +325,10 @@ class FAN(TFModel):
             ops.join_side_stream()
             P.grads_pending = False
         else:
-            # the weight gradients are still in flight on the side streams - whoever reads the gradient buffer next
-            # (ParamStore.adam, GradientBucket.launch, a test) has to join first; ops.nan_flag / ops.join_side_stream clear the mark
+            # the weight gradients are still in flight on the side streams: whoever reads the gradient buffer next joins first.
+            # ParamStore.adam and parallel.GradientBucket.launch call ops.join_side_stream() unconditionally (a no-op once the
+            # side streams are clean: ops keeps the set of dirty streams); a test or tool that reads P.flat_grad directly after
+            # backward(join=False) must do the same.  The attribute is informational (cleared by adam and backward(join=True)).
             P.grads_pending = True
         return loss, dx
 

@@ -69,9 +69,11 @@ class ParamStore(object):
     def adam(self, lr, step=None, grad_scale=1.0, skip_flag=None, lr_t_dev=None):
         """One Keras-Adam update over the whole buffer (beta1 .9, beta2 .999, eps 1e-7)."""
         self.ensure_adam()
-        if getattr(self, 'grads_pending', False):       # a backward(join=False) left weight gradients on the side streams
-            ops.join_side_stream()
-            self.grads_pending = False
+        # a backward(join=False) may have left weight gradients running on the side streams.  The pending state lives in ops (the
+        # set of side streams with work since the last join): joining is a no-op when it is empty, so every reader of the gradient
+        # buffer - this update, parallel.GradientBucket.launch, ops.nan_flag's callers - simply joins (ADVICE r05)
+        ops.join_side_stream()
+        self.grads_pending = False
         if step is None:
             self.step += 1
             step = self.step

@@ -604,7 +604,8 @@ def rows_conv_ok(x, x2, ks, stride, cout, out_hw, pads, pad_mode, out, out2, act
     n, h, wd, c1 = x.shape
     c2 = 0 if x2 is None else x2.shape[3]
     if ROWS_CONV and ROWS_LEVEL2 and ks == 3 and stride == 1 and wd == 64 and h % 4 == 0 and h >= 4 and tuple(out_hw) == (h, wd) and \
-            tuple(pads) == (1, 1) and pad_mode == 0 and _is_bf16(x) and x2 is None and act in (None, 'leaky_relu'):
+            tuple(pads) == (1, 1) and pad_mode == 0 and _is_bf16(x) and x2 is None and act in (None, 'leaky_relu') and \
+            n * h * wd * max(c1, 64) * 2 < (1 << 31) - 65536:        # 32-bit buffer descriptors, as the C entry checks
         # the UNet's second level: 32 | 64 -> 64 channels at 64-pixel rows, one bf16 tensor out
         return cout == 64 and c1 in (32, 64) and out2 is None and _is_bf16(out) and out.shape[3] == 64 and \
             (act_mask is None or (_is_bf16(act_mask) and tuple(act_mask.shape) == (n, h, wd, 64)))

@@ -208,6 +208,8 @@ class _Awgn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, noise, mask = ctx.saved_tensors
+        if ctx.needs_input_grad[1]:        # forward-only input (module docstring): refuse instead of cutting the graph silently
+            raise RuntimeError('nimg::awgn: the noise tensor is a forward-only input (no gradient is defined for it)')
         return ops.awgn_bwd(x, noise, gy.contiguous(), mask, ctx.s), None, None
 
 
@@ -237,7 +239,9 @@ class _ConvT2x2(torch.autograd.Function):
         x, w = ctx.saved_tensors
         gy = gy.contiguous()
         dx = ops.convt2x2_dgrad(gy, w) if ctx.needs_input_grad[0] else None
-        return dx, ops.convt2x2_wgrad(x, gy), ops.bias_grad(gy)
+        dw = ops.convt2x2_wgrad(x, gy) if ctx.needs_input_grad[1] else None
+        db = ops.bias_grad(gy) if ctx.needs_input_grad[2] else None
+        return dx, dw, db
 
 
 class _D2SClip(torch.autograd.Function):
@@ -290,7 +294,8 @@ class _Mse255(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gl):
         (g,) = ctx.saved_tensors
-        return g * gl, None
+        ga = g * gl                        # d loss / d a; the loss is symmetric in a - b, so d loss / d b = -ga
+        return (ga if ctx.needs_input_grad[0] else None), (-ga if ctx.needs_input_grad[1] else None)
 
 
 class _FanHead(torch.autograd.Function):
@@ -303,10 +308,12 @@ class _FanHead(torch.autograd.Function):
         act, w, b = act.contiguous(), w.contiguous(), b.contiguous()
         n = act.shape[0]
         gap, probs, loss_per, dlogits = ops.fan_head_fwd(act, w, b, labels.to(torch.int32).contiguous(), 1.0 / n)
+        ctx.mark_non_differentiable(probs)
+        if not any(ctx.needs_input_grad[:3]):          # inference through the CUDA key: the loss only, no gradient kernels
+            return loss_per.mean().reshape(()), probs      # (glue outside the hot path, like the g * gl products below)
         dw, db = torch.empty_like(w), torch.empty_like(b)
         dact, loss = ops.fan_head_bwd(act, gap, w, dlogits, loss_per, 1.0 / n, dw, db, alpha=1.0)    # slope 1: no LeakyReLU' folded in
         ctx.save_for_backward(dact, dw, db)
-        ctx.mark_non_differentiable(probs)
         return loss.reshape(()), probs
 
     @staticmethod

@@ -60,11 +60,20 @@ def train_nip_model(model, camera_name, n_epochs=10000, lr_schedule=None, valida
                            ('Patch size', patch_size), ('Batch size', batch_size),
                            ('Validation schedule', validation_schedule), ('Start epoch', start_epoch),
                            ('Saved checkpoint', None), ('Output directory', out_directory)])
+    # the rate in force at the first epoch trained: the entry of the largest schedule key <= start_epoch (a resumed run never meets
+    # key 0 inside the loop; the reference then falls back to 1e-4 whatever the schedule says - ADVICE r05)
     learning_rate = 1e-4
+    for k in sorted(lr_schedule):
+        if k <= start_epoch:
+            learning_rate = lr_schedule[k]
     epoch = start_epoch
     world, rank = parallel.world_size(), parallel.rank()
     if batch_size % world:
         raise ValueError('batch_size {} does not split over {} ranks'.format(batch_size, world))
+    if start_epoch >= n_epochs:
+        # resuming a finished run trains nothing: leave its progress file and checkpoint as they are (no checkpoint under an epoch
+        # that was never trained, no 'Epoch' that grows with every call)
+        return out_directory
     for epoch in range(start_epoch, n_epochs):
         if epoch in lr_schedule:
             learning_rate = lr_schedule[epoch]

@@ -1529,6 +1529,13 @@ def test_nip_pretraining_harness(dev, tmp_path, feed):
     prog2 = json.load(open(os.path.join(out, 'progress.json')))
     assert prog2['summary']['Start epoch'] == 6 and len(prog2['performance']['loss']['training']) == 8
     assert prog2['performance']['loss']['training'][6] < perf['loss']['training'][0]            # resumed, not restarted
+    # resuming a FINISHED run trains nothing and leaves progress file and checkpoint alone (no epoch label that grows per call)
+    stamp = os.path.getmtime(os.path.join(out, 'unet.h5'))
+    tp.train_nip_model(net2, 'synthetic', n_epochs=8, validation_schedule=2, patch_size=32, batch_size=4, data=data,
+                       out_directory_root=str(tmp_path), resume=True, discard=None)
+    prog3 = json.load(open(os.path.join(out, 'progress.json')))
+    assert prog3['summary']['Epoch'] == prog2['summary']['Epoch'] == 7 and os.path.getmtime(os.path.join(out, 'unet.h5')) == stamp
+    assert len(prog3['performance']['loss']['training']) == 8
     with pytest.raises(ValueError):
         tp.train_nip_model(net, 'synthetic', patch_size=32, batch_size=16, data=data, out_directory_root=str(tmp_path))
     with pytest.raises(FileNotFoundError):              # resume without a progress.json to resume from (training/pipeline.py:141-142)
