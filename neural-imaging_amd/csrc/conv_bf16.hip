@@ -177,7 +177,32 @@ __device__ __forceinline__ EpiBias epi_bias_preload(const ConvParamsB& p, int la
     return r;
 }
 
-template <int KS, int TH, int TW, int NB, int MI, int NI>
+// Which tile pixel row P of the workgroup's M dimension is (fragment P >> 5, lane P & 31).  PMAP 0: row-major over (image, y, x) -
+// a fragment = 32 consecutive tile pixels (two rows of a 16-wide tile).  PMAP 1 (conv3_dma_kernel's plane layout): a 16 x 16
+// tile's fragment = 8 columns x 4 rows (fragment = column half + 2 x row group), an 8 x 8 x 4-image tile's fragment = ONE row
+// of all four images (lane = 8 image + x) - the maps whose 16-lane ds_read_b128 groups meet 16 different bank quads.
+template <int TH, int TW, int NB, int PMAP>
+__device__ __forceinline__ void tile_pixel(int P, int& img, int& dy, int& dx) {
+    if constexpr (PMAP == 0) {
+        img = P / (TH * TW);
+        const int rem = P % (TH * TW);
+        dy = rem / TW;
+        dx = rem % TW;
+    } else if constexpr (NB == 1) {
+        static_assert(TH == 16 && TW == 16, "plane layout: 16 x 16 tile");
+        const int f = P >> 5, l = P & 31;
+        img = 0;
+        dy = 4 * (f >> 1) + (l >> 3);
+        dx = 8 * (f & 1) + (l & 7);
+    } else {
+        static_assert(TH == 8 && TW == 8 && NB == 4, "plane layout: 8 x 8 x 4 tile");
+        img = (P & 31) >> 3;
+        dy = P >> 5;
+        dx = P & 7;
+    }
+}
+
+template <int KS, int TH, int TW, int NB, int MI, int NI, int PMAP = 0>
 __device__ __forceinline__ void conv_epilogue_vec(const f32x16 (&acc)[MI][NI], const ConvParamsB& p, unsigned char* smem_raw,
                                                   int wave, int lane, int wm, int wn, int co0, int Cout, int ty0, int tx0,
                                                   int grp, int phase, const EpiBias& pre_) {
@@ -207,8 +232,9 @@ __device__ __forceinline__ void conv_epilogue_vec(const f32x16 (&acc)[MI][NI], c
                 const int co = co0 + wn * NI * 32 + c;
                 if (co >= Cout) return;
                 const int P = (wm * MI + mi) * 32 + row;
-                const int img = P / (TH * TW), rem = P % (TH * TW);
-                const int oy = ty0 + rem / TW, ox = tx0 + rem % TW, n = grp * NB + img;
+                int img, dy_, dx_;
+                tile_pixel<TH, TW, NB, PMAP>(P, img, dy_, dx_);
+                const int oy = ty0 + dy_, ox = tx0 + dx_, n = grp * NB + img;
                 if (n >= p.N || oy >= p.Hout || ox >= p.Wout) return;
                 const float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                 const long W2 = 2L * p.Wout;
@@ -251,8 +277,9 @@ __device__ __forceinline__ void conv_epilogue_vec(const f32x16 (&acc)[MI][NI], c
                 const int co = co0 + wn * NI * 32 + c;
                 if (co >= Cout) return;
                 const int P = (wm * MI + mi) * 32 + row;
-                const int img = P / (TH * TW), rem = P % (TH * TW);
-                const int oy = ty0 + rem / TW, ox = tx0 + rem % TW, n = grp * NB + img;
+                int img, dy_, dx_;
+                tile_pixel<TH, TW, NB, PMAP>(P, img, dy_, dx_);
+                const int oy = ty0 + dy_, ox = tx0 + dx_, n = grp * NB + img;
                 if (n >= p.N || oy >= p.Hout || ox >= p.Wout) return;
                 const int blk = co / cd, cc = co - blk * cd, ph = 3 - blk;
                 const long o = (((long)n * 2 * p.Hout + 2 * oy + (ph >> 1)) * (2 * p.Wout) + 2 * ox + (ph & 1)) * cd + cc;
@@ -274,8 +301,9 @@ __device__ __forceinline__ void conv_epilogue_vec(const f32x16 (&acc)[MI][NI], c
                 const int co = co0 + wn * NI * 32 + c;
                 if (co >= Cout) return;
                 const int P = (wm * MI + mi) * 32 + row;
-                const int img = P / (TH * TW), rem = P % (TH * TW);
-                const int oy = ty0 + rem / TW, ox = tx0 + rem % TW, n = grp * NB + img;
+                int img, dy_, dx_;
+                tile_pixel<TH, TW, NB, PMAP>(P, img, dy_, dx_);
+                const int oy = ty0 + dy_, ox = tx0 + dx_, n = grp * NB + img;
                 if (n >= p.N || oy >= p.Hout || ox >= p.Wout) return;
                 const long pixoff = (KS == 1 && p.convt)
                     ? ((long)n * 2 * p.Hout + 2 * oy + (phase >> 1)) * (2 * p.Wout) + 2 * ox + (phase & 1)
@@ -303,7 +331,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const f32x16 (&acc)[MI][NI], c
             });
             // NIMG_POOL_ALSO: the 2x2 max-pooled tensor next to the full one (the UNet's encoder keeps the full tensor for its skip
             // connection and feeds the pooled one to the next level): a fragment = two rows of 16 pixels = 8 windows per channel
-            if constexpr (TW == 16 && NB == 1)
+            if constexpr (TW == 16 && NB == 1 && PMAP == 0)
                 if (p.pool_out) {
                     const int Hp = p.Hout >> 1, Wp = p.Wout >> 1, py = (ty0 >> 1) + wm * MI + mi;
                     pool_in_regs8<NI>(acc[mi], elds, lane, p.act == 1 ? p.alpha : 1.0f,
@@ -327,8 +355,9 @@ __device__ __forceinline__ void conv_epilogue_vec(const f32x16 (&acc)[MI][NI], c
             const int co = co0 + wn * NI * 32 + c;
             if (co >= Cout) return;
             const int P = (wm * MI + mi) * 32 + row;
-            const int img = P / (TH * TW), rem = P % (TH * TW);
-            const int oy = ty0 + rem / TW, ox = tx0 + rem % TW, n = grp * NB + img;
+            int img, dy_, dx_;
+            tile_pixel<TH, TW, NB, PMAP>(P, img, dy_, dx_);
+            const int oy = ty0 + dy_, ox = tx0 + dx_, n = grp * NB + img;
             if (n >= p.N || oy >= p.Hout || ox >= p.Wout) return;
             const long pixoff = (KS == 1 && p.convt)
                 ? ((long)n * 2 * p.Hout + 2 * oy + (phase >> 1)) * (2 * p.Wout) + 2 * ox + (phase & 1)
@@ -1098,20 +1127,28 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : (TN == 32 ? 3 : 2)) void con
 // registers, no write pass, one barrier per chunk.  LDS images are lane-linear per 1 KB piece; the XOR swizzle of the 16-byte
 // halves (conflict-free ds_read_b128, as in the generic kernel) is applied on the source address.  Same tiles, fragment reads
 // and epilogue as conv_fwd_bf16_kernel<3, 1, TH, TW, NB, TN, true, ...>: the results are bit-identical.
-template <int TH, int TW, int NB, int TN, int NS = 2>
+// LAY 1: the halo tile as two PLANES (k-half 0 / 1) of 16 B per pixel - row pitch 24 entries for the 16 x 16 tile (18 used),
+// 10 for the 8 x 8 x 4 tile with an image stride of 104 - and the fragment -> pixel maps of tile_pixel<..., 1>: every 16-lane
+// group of a ds_read_b128 meets 16 different 16-byte bank quads at every tap shift (the pixel-major tile with its one XOR bit
+// cannot: profiles/r06_conv3_stages_pipe.txt, SQ_LDS_BANK_CONFLICT = 0.57 of the LDS cycles on the 8 x 8 x 4 tile).
+template <int TH, int TW, int NB, int TN, int NS = 2, int LAY = 0>
 struct Dma3Geom {
     static constexpr int THH = TH + 2, TWH = TW + 2, NPIXH = NB * THH * TWH;
-    static constexpr int A_PIECES = (NPIXH * 2 + 63) / 64, B_PIECES = 9 * TN * 2 / 64;
+    static constexpr int PITCH = NB == 1 ? 24 : TWH, IMGS = NB == 1 ? THH * PITCH : 104;        // LAY 1: entries
+    static constexpr int PLANE = ((NB * IMGS + 63) / 64) * 64;                                  // LAY 1: whole 1 KB pieces
+    static constexpr int A_PIECES = LAY ? 2 * PLANE / 64 : (NPIXH * 2 + 63) / 64, B_PIECES = 9 * TN * 2 / 64;
     static constexpr int A_ENT = A_PIECES * 64, B_ENT = 9 * TN * 2;                     // uint4 entries of one buffer
     static constexpr int APW = (A_PIECES + 3) / 4, BPW = (B_PIECES + 3) / 4;            // pieces per wave
     static constexpr size_t LDS_TILES = (size_t)NS * (A_ENT + B_ENT) * sizeof(uint4);
     static constexpr size_t LDS_EPI = (size_t)4 * 32 * (TN + EPI_PAD) * sizeof(float);
     static constexpr size_t LDS = LDS_TILES > LDS_EPI ? LDS_TILES : LDS_EPI;
+    static_assert(!LAY || (NB == 1 && TH == 16 && TW == 16) || (NB == 4 && TH == 8 && TW == 8), "plane layout: two tile shapes");
+    static_assert(!LAY || THH * TWH <= IMGS, "image stride");
 };
 
-template <int TH, int TW, int NB, int TN, int NS = 2, bool PIPE = false>
+template <int TH, int TW, int NB, int TN, int NS = 2, bool PIPE = false, int LAY = 0>
 __global__ __launch_bounds__(256) void conv3_dma_kernel(const ConvParamsB p) {
-    using G = Dma3Geom<TH, TW, NB, TN, NS>;
+    using G = Dma3Geom<TH, TW, NB, TN, NS, LAY>;
     constexpr int THH = G::THH, TWH = G::TWH, NPIXH = G::NPIXH;
     constexpr int MFRAGS = NB * TH * TW / 32, NFRAGS = TN / 32;
     constexpr int WAVES_M = MFRAGS >= 4 ? 4 : MFRAGS, WAVES_N = 4 / WAVES_M;
@@ -1143,8 +1180,14 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const ConvParamsB p) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int P = (wm * MI + mi) * 32 + (lane & 31);
-        const int img = P / (TH * TW), rem = P % (TH * TW);
-        abase[mi] = img * (THH * TWH) + (rem / TW) * TWH + (rem % TW);
+        if constexpr (LAY) {
+            int img, dy, dx;
+            tile_pixel<TH, TW, NB, 1>(P, img, dy, dx);
+            abase[mi] = (lane >> 5) * G::PLANE + img * G::IMGS + dy * G::PITCH + dx;      // the lane's k-half plane included
+        } else {
+            const int img = P / (TH * TW), rem = P % (TH * TW);
+            abase[mi] = img * (THH * TWH) + (rem / TW) * TWH + (rem % TW);
+        }
     }
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -1159,12 +1202,29 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const ConvParamsB p) {
     unsigned aoff1[G::APW], aoff2[G::APW];
 #pragma unroll
     for (int j = 0; j < G::APW; ++j) {
-        const int item = (wave + 4 * j) * 64 + lane, pix = item >> 1;
-        const int h = (item & 1) ^ ((pix >> 3) & 1);
-        const int img = pix / (THH * TWH), rem = pix % (THH * TWH);
-        int gy = iy0 + rem / TWH, gx = ix0 + rem % TWH;
+        const int item = (wave + 4 * j) * 64 + lane;
+        int h, img, ry, rx;
+        bool in_tile;
+        if constexpr (LAY) {               // entry = (plane, image, row, column); pad entries read nothing (zeros)
+            h = item / G::PLANE;
+            const int r = item % G::PLANE;
+            img = r / G::IMGS;
+            const int q = r % G::IMGS;
+            ry = q / G::PITCH;
+            rx = q % G::PITCH;
+            in_tile = (item < 2 * G::PLANE) & (img < NB) & (ry < THH) & (rx < TWH);
+        } else {
+            const int pix = item >> 1;
+            h = (item & 1) ^ ((pix >> 3) & 1);
+            img = pix / (THH * TWH);
+            const int rem = pix % (THH * TWH);
+            ry = rem / TWH;
+            rx = rem % TWH;
+            in_tile = item < NPIXH * 2;
+        }
+        int gy = iy0 + ry, gx = ix0 + rx;
         const int n = grp * NB + img;
-        const bool ok = (item < NPIXH * 2) & (n < p.N) & map_coord(gy, p.H, p.pad_mode) & map_coord(gx, p.W, p.pad_mode);
+        const bool ok = in_tile & (n < p.N) & map_coord(gy, p.H, p.pad_mode) & map_coord(gx, p.W, p.pad_mode);
         const unsigned apix = (unsigned)((n * p.H + gy) * p.W + gx);
         aoff1[j] = ok ? (apix * (unsigned)p.C1 + 8u * h) * 2u : 0x80000000u;
         aoff2[j] = ok ? (apix * (unsigned)p.C2 + 8u * h) * 2u : 0x80000000u;
@@ -1203,6 +1263,13 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const ConvParamsB p) {
             }
         }
     };
+    auto ldA = [&](const uint4* tA, int mi, int ky, int kx) -> uint4 {
+        if constexpr (LAY) return tA[abase[mi] + ky * G::PITCH + kx];          // tap shift = an immediate offset
+        else {
+            const int pix = abase[mi] + ky * TWH + kx;
+            return tA[pix * 2 + (half ^ ((pix >> 3) & 1))];
+        }
+    };
     // NS-slot ring, chunk c + NS - 1 requested while chunk c multiplies: a request has NS - 1 chunks' worth of matrix
     // instructions (18 ... 36 per wave and chunk) to come back from L2 / HBM instead of one.  NS = 2 is the original double buffer.
 #pragma unroll
@@ -1222,7 +1289,6 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const ConvParamsB p) {
             bf16x8 a[9][MI], b[9][NI];
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
-                const int toff = (tap / 3) * TWH + tap % 3;
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                     const int row = tap * TN + (wn * NI + ni) * 32 + (lane & 31);
@@ -1231,8 +1297,7 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const ConvParamsB p) {
                 }
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
-                    const int pix = abase[mi] + toff;
-                    const uint4 v = tA[pix * 2 + (half ^ ((pix >> 3) & 1))];
+                    const uint4 v = ldA(tA, mi, tap / 3, tap % 3);
                     a[tap][mi] = *reinterpret_cast<const bf16x8*>(&v);
                 }
             }
@@ -1250,12 +1315,11 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const ConvParamsB p) {
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const int tap = ky * 3 + kx, toff = ky * TWH + kx;
+                const int tap = ky * 3 + kx;
                 bf16x8 a[MI], b[NI];
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
-                    const int pix = abase[mi] + toff;
-                    const uint4 v = tA[pix * 2 + (half ^ ((pix >> 3) & 1))];
+                    const uint4 v = ldA(tA, mi, ky, kx);
                     a[mi] = *reinterpret_cast<const bf16x8*>(&v);
                 }
 #pragma unroll
@@ -1283,19 +1347,28 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const ConvParamsB p) {
         buf = buf + 1 == NS ? 0 : buf + 1;
         nbuf = nbuf + 1 == NS ? 0 : nbuf + 1;
     }
-    conv_epilogue_vec<3, TH, TW, NB, MI, NI>(acc, p, smem_raw, wave, lane, wm, wn, co0, Cout, ty0, tx0, grp, 0, epi_pre);
+    conv_epilogue_vec<3, TH, TW, NB, MI, NI, LAY>(acc, p, smem_raw, wave, lane, wm, wn, co0, Cout, ty0, tx0, grp, 0, epi_pre);
 }
 
-template <int TH, int TW, int NB, int TN, int NS = 2, bool PIPE = false>
+template <int TH, int TW, int NB, int TN, int NS = 2, bool PIPE = false, int LAY = 0>
 int launch_conv3_dma(const ConvParamsB& p, hipStream_t stream) {
-    using G = Dma3Geom<TH, TW, NB, TN, NS>;
-    if constexpr (NS == 2 && !PIPE) {
+    using G = Dma3Geom<TH, TW, NB, TN, NS, LAY>;
+    if constexpr (NS == 2 && !PIPE && LAY == 0) {
         // NIMG_CONV3_STAGES=3 (three-slot ring: a chunk's transfers get two chunks of matrix work to land), NIMG_CONV3_PIPE=1 (all
         // operand fragments of a chunk requested from LDS before its first matrix instruction): A/B switches, both measured
         // NEGATIVE on the UNet's layers (profiles/r06_conv3_stages_pipe.txt: the layers are bound by neither latency:
         // the LDS bank conflicts of the pixel-major halo tile and the 2 x 1 fragment block of the 32-channel tiles are)
         static const int stages = getenv("NIMG_CONV3_STAGES") ? atoi(getenv("NIMG_CONV3_STAGES")) : 2;
         static const int pipe = getenv("NIMG_CONV3_PIPE") ? atoi(getenv("NIMG_CONV3_PIPE")) : 0;
+        // NIMG_CONV3_PLANES=0|1|2: the conflict-free plane layout of the halo tile (Dma3Geom LAY 1).  Default 1 = on the 8 x 8 x 4
+        // tile only (the UNet's 8 x 8 level: -6 %); 2 = on the 16 x 16 tile too, where it is 1 - 3 % slower (three pieces more
+        // per chunk, nothing gained: profiles/r06_conv3_planes.txt).  Its fragment -> pixel map has no fused-pooling epilogue:
+        // those layers keep the pixel-major tile
+        static const int planes = getenv("NIMG_CONV3_PLANES") ? atoi(getenv("NIMG_CONV3_PLANES")) : 1;
+        if ((planes == 2 || (planes == 1 && NB == 4)) && !p.pool_out && stages != 3) {
+            if (pipe) return launch_conv3_dma<TH, TW, NB, TN, 2, true, 1>(p, stream);
+            return launch_conv3_dma<TH, TW, NB, TN, 2, false, 1>(p, stream);
+        }
         if (stages == 3) return pipe ? launch_conv3_dma<TH, TW, NB, TN, 3, true>(p, stream) : launch_conv3_dma<TH, TW, NB, TN, 3, false>(p, stream);
         if (pipe) return launch_conv3_dma<TH, TW, NB, TN, 2, true>(p, stream);
     }
@@ -1303,7 +1376,7 @@ int launch_conv3_dma(const ConvParamsB& p, hipStream_t stream) {
     q.tiles_y = cdiv(p.Hout, TH);
     q.tiles_x = cdiv(p.Wout, TW);
     const long blocks = (long)cdiv(p.O1 + p.O2, TN) * q.tiles_y * q.tiles_x * cdiv(p.N, NB);
-    auto kern = conv3_dma_kernel<TH, TW, NB, TN, NS, PIPE>;
+    auto kern = conv3_dma_kernel<TH, TW, NB, TN, NS, PIPE, LAY>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), G::LDS, stream, q);
     NIMG_CHECK_LAUNCH();
