@@ -1146,8 +1146,20 @@ struct Dma3Geom {
     static_assert(!LAY || THH * TWH <= IMGS, "image stride");
 };
 
-template <int TH, int TW, int NB, int TN, int NS = 2, bool PIPE = false, int LAY = 0>
-__global__ __launch_bounds__(256) void conv3_dma_kernel(const ConvParamsB p) {
+#ifdef NIMG_CONV3_TIMING
+// Diagnostic build (tools/build_variant.sh timing "-DNIMG_CONV3_TIMING" conv_bf16; tools/conv3_timing.py): per-wave s_memtime sums
+// of the K loop's segments - [0] transfer issue, [1] operand reads + matrix instructions, [2] wait for the next chunk's
+// transfers, [3] barrier, [4] prologue (kernel start -> first chunk ready), [5] epilogue, [6] chunks - of workgroups 0 .. 63.
+__device__ unsigned long long g_conv3_timing[64 * 4 * 8];
+#define T3_NOW() ({ unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_; })
+#endif
+// LDR: a FIFTH wave does nothing but request the tiles (all pieces of chunk c + 1 while the four others multiply chunk c) and waits
+// for them in front of the chunk's barrier.  tools/conv3_timing.py: a wave that requests its share of a chunk in front of the
+// taps spends 440 - 490 cycles per chunk there (the 22 - 32 pieces of the workgroup queue up in the CU's one address unit at
+// 64 B / clock), with its SIMD's matrix pipe idle when it is the only wave on it; behind the taps' matrix instructions the
+// pieces cost the same (ILV).  The loader takes that time off the multiplying waves' loop.
+template <int TH, int TW, int NB, int TN, int NS = 2, bool PIPE = false, int LAY = 0, bool ILV = false, bool LDR = false>
+__global__ __launch_bounds__(LDR ? 320 : 256) void conv3_dma_kernel(const ConvParamsB p) {
     using G = Dma3Geom<TH, TW, NB, TN, NS, LAY>;
     constexpr int THH = G::THH, TWH = G::TWH, NPIXH = G::NPIXH;
     constexpr int MFRAGS = NB * TH * TW / 32, NFRAGS = TN / 32;
@@ -1155,12 +1167,21 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const ConvParamsB p) {
     constexpr int MI = MFRAGS / WAVES_M, NI = NFRAGS / WAVES_N;
     static_assert(NI >= 1 && MFRAGS % WAVES_M == 0, "bad tile configuration");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+#ifdef NIMG_CONV3_TIMING
+    const unsigned long long tk0 = T3_NOW();
+    unsigned long long tsum[4] = {0, 0, 0, 0};
+#endif
     uint4* sA = reinterpret_cast<uint4*>(smem_raw);                  // [NS][A_ENT] then [NS][B_ENT]
     uint4* sB = sA + NS * G::A_ENT;
     const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)smem_raw;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+    const int wm = wave % WAVES_M, wn = (wave / WAVES_M) % WAVES_N;
+    static_assert(!LDR || (NS == 2 && !PIPE && !ILV), "loader wave: two tile buffers, plain tap loop");
+    constexpr int NLW = LDR ? 1 : 4;                                   // waves that request tiles, lw = this wave's index among them
+    const bool is_loader = LDR ? wave == 4 : true;
+    const int lw = LDR ? 0 : wave;
+    constexpr int APW_L = (G::A_PIECES + NLW - 1) / NLW, BPW_L = (G::B_PIECES + NLW - 1) / NLW;
     const int Cin = p.C1 + p.C2, Cout = p.O1 + p.O2;
     const int cot = (Cout + TN - 1) / TN;
     int bid = xcd_order(blockIdx.x);
@@ -1199,10 +1220,11 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const ConvParamsB p) {
 
     // halo tile: piece k = wave + 4 j, lane l -> item 64 k + l = (pixel, 16-byte slot); the slot holds the channel half
     // slot ^ (pixel >> 3 & 1).  The pixel's element index in the tensors is resolved once; per chunk only the scalar offset moves.
-    unsigned aoff1[G::APW], aoff2[G::APW];
+    unsigned aoff1[APW_L], aoff2[APW_L];
+    if (is_loader)
 #pragma unroll
-    for (int j = 0; j < G::APW; ++j) {
-        const int item = (wave + 4 * j) * 64 + lane;
+    for (int j = 0; j < APW_L; ++j) {
+        const int item = (lw + NLW * j) * 64 + lane;
         int h, img, ry, rx;
         bool in_tile;
         if constexpr (LAY) {               // entry = (plane, image, row, column); pad entries read nothing (zeros)
@@ -1245,16 +1267,16 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const ConvParamsB p) {
         const r_u32x4 ra = first ? ra1 : ra2;
         const int soff = (first ? c0 : c0 - p.C1) * 2;
 #pragma unroll
-        for (int j = 0; j < G::APW; ++j) {
-            const int k = wave + 4 * j;
-            if (G::A_PIECES % 4 == 0 || k < G::A_PIECES)
+        for (int j = 0; j < APW_L; ++j) {
+            const int k = lw + NLW * j;
+            if (G::A_PIECES % NLW == 0 || k < G::A_PIECES)
                 glds16(ra, lds0 + (unsigned)((buf * G::A_ENT + k * 64) * 16), first ? aoff1[j] : aoff2[j], soff);
         }
         const int chunk = c0 >> 4;
 #pragma unroll
-        for (int j = 0; j < G::BPW; ++j) {
-            const int k = wave + 4 * j;
-            if (G::B_PIECES % 4 == 0 || k < G::B_PIECES) {
+        for (int j = 0; j < BPW_L; ++j) {
+            const int k = lw + NLW * j;
+            if (G::B_PIECES % NLW == 0 || k < G::B_PIECES) {
                 const int tap = k / NB32, nb = k % NB32;
                 // rows beyond Cout (a partial last channel tile) read the next tap's rows or run out of range (zeros): their
                 // products land in accumulator columns the epilogue never stores
@@ -1263,6 +1285,23 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const ConvParamsB p) {
             }
         }
     };
+    // ILV: the same pieces one at a time, each behind the matrix instructions of one tap (conv3_timing: a wave spends ~100 cycles
+    // per piece in the issue; in front of the taps that is 490 cycles per chunk during which its SIMD's matrix pipe idles)
+    auto issue_one = [&](int c0, int buf, int idx) {
+        const bool first = c0 < p.C1;
+        if (idx < G::APW) {
+            const int k = wave + 4 * idx;
+            if (G::A_PIECES % 4 == 0 || k < G::A_PIECES)
+                glds16(first ? ra1 : ra2, lds0 + (unsigned)((buf * G::A_ENT + k * 64) * 16), first ? aoff1[idx] : aoff2[idx],
+                       (first ? c0 : c0 - p.C1) * 2);
+        } else if (idx < G::APW + G::BPW) {
+            const int k = wave + 4 * (idx - G::APW);
+            if (G::B_PIECES % 4 == 0 || k < G::B_PIECES)
+                glds16(rb, lds0 + (unsigned)((NS * G::A_ENT + buf * G::B_ENT + k * 64) * 16), bvoff,
+                       (((c0 >> 4) * 9 + k / NB32) * Cout + (k % NB32) * 32) * 32);
+        }
+    };
+    static_assert(!ILV || (G::APW + G::BPW <= 9 && NS == 2 && !PIPE), "one piece per tap");
     auto ldA = [&](const uint4* tA, int mi, int ky, int kx) -> uint4 {
         if constexpr (LAY) return tA[abase[mi] + ky * G::PITCH + kx];          // tap shift = an immediate offset
         else {
@@ -1274,14 +1313,26 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const ConvParamsB p) {
     // instructions (18 ... 36 per wave and chunk) to come back from L2 / HBM instead of one.  NS = 2 is the original double buffer.
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
-        if (s * 16 < Cin) issue(s * 16, s);
+        if (s * 16 < Cin && is_loader) issue(s * 16, s);
     dma_wait();
     __syncthreads();
+#ifdef NIMG_CONV3_TIMING
+    const unsigned long long tk1 = T3_NOW();
+#endif
     for (int c0 = 0, buf = 0, nbuf = NS - 1; c0 < Cin; c0 += 16) {
         const bool more = c0 + (NS - 1) * 16 < Cin;
-        if (more) issue(c0 + (NS - 1) * 16, nbuf);
+#ifdef NIMG_CONV3_TIMING
+        const unsigned long long t0 = T3_NOW();
+#endif
+        if constexpr (!ILV) { if (more && is_loader) issue(c0 + (NS - 1) * 16, nbuf); }
+#ifdef NIMG_CONV3_TIMING
+        const unsigned long long t1 = T3_NOW();
+#endif
         const uint4* tA = sA + buf * G::A_ENT;
         const uint4* tB = sB + buf * G::B_ENT;
+        if (LDR && wave == 4) {
+            // the loader multiplies nothing
+        } else
         if constexpr (PIPE) {
             // every operand fragment of the chunk is requested from LDS BEFORE the first matrix instruction (9 (MI + NI) x 4
             // registers); the waits in front of the matrix instructions then count down one queue instead of each tap paying
@@ -1311,7 +1362,7 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const ConvParamsB p) {
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tap][mi], b[tap][ni], acc[mi][ni], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         } else
-#pragma unroll(TN == 32 ? 3 : 1)
+#pragma unroll((TN == 32 || ILV) ? 3 : 1)
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
@@ -1333,7 +1384,12 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const ConvParamsB p) {
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                if constexpr (ILV) { if (more) issue_one(c0 + 16, nbuf, tap); }
             }
+#ifdef NIMG_CONV3_TIMING
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long t2 = T3_NOW();
+#endif
         // chunk c + 1 has landed (the NS - 2 younger ones may still be in flight: loads retire in order) ...
         if constexpr (NS == 2) dma_wait();
         else {
@@ -1343,42 +1399,80 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const ConvParamsB p) {
             else if (short_by == 1) dma_wait_leave<FULL - (NS - 2)>();
             else dma_wait_leave<FULL - 2 * (NS - 2)>();
         }
+#ifdef NIMG_CONV3_TIMING
+        const unsigned long long t3 = T3_NOW();
+#endif
         __syncthreads();                               // ... and everyone is done with this one
+#ifdef NIMG_CONV3_TIMING
+        const unsigned long long t4 = T3_NOW();
+        tsum[0] += t1 - t0; tsum[1] += t2 - t1; tsum[2] += t3 - t2; tsum[3] += t4 - t3;
+#endif
         buf = buf + 1 == NS ? 0 : buf + 1;
         nbuf = nbuf + 1 == NS ? 0 : nbuf + 1;
     }
+#ifdef NIMG_CONV3_TIMING
+    const unsigned long long tk2 = T3_NOW();
+#endif
+    if (LDR && wave == 4) {
+        __syncthreads();                   // the epilogue's one barrier (the scratch aliases the tiles)
+        return;
+    }
     conv_epilogue_vec<3, TH, TW, NB, MI, NI, LAY>(acc, p, smem_raw, wave, lane, wm, wn, co0, Cout, ty0, tx0, grp, 0, epi_pre);
+#ifdef NIMG_CONV3_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long tk3 = T3_NOW();
+    if (blockIdx.x < 64 && lane == 0 && wave < 4) {
+        unsigned long long* d = g_conv3_timing + (blockIdx.x * 4 + wave) * 8;
+        d[0] = tsum[0]; d[1] = tsum[1]; d[2] = tsum[2]; d[3] = tsum[3]; d[4] = tk1 - tk0; d[5] = tk3 - tk2; d[6] = Cin / 16; d[7] = tk3 - tk0;
+    }
+#endif
 }
 
-template <int TH, int TW, int NB, int TN, int NS = 2, bool PIPE = false, int LAY = 0>
+template <int TH, int TW, int NB, int TN, int NS = 2, bool PIPE = false, int LAY = 0, bool ILV = false, bool LDR = false>
 int launch_conv3_dma(const ConvParamsB& p, hipStream_t stream) {
     using G = Dma3Geom<TH, TW, NB, TN, NS, LAY>;
-    if constexpr (NS == 2 && !PIPE && LAY == 0) {
-        // NIMG_CONV3_STAGES=3 (three-slot ring: a chunk's transfers get two chunks of matrix work to land), NIMG_CONV3_PIPE=1 (all
-        // operand fragments of a chunk requested from LDS before its first matrix instruction): A/B switches, both measured
-        // NEGATIVE on the UNet's layers (profiles/r06_conv3_stages_pipe.txt: the layers are bound by neither latency:
-        // the LDS bank conflicts of the pixel-major halo tile and the 2 x 1 fragment block of the 32-channel tiles are)
+    if constexpr (NS == 2 && !PIPE && LAY == 0 && !ILV && !LDR) {
+        // The conflict-free plane layout of the halo tile (Dma3Geom LAY 1) on the 8 x 8 x 4 tile - the UNet's 8 x 8 level, -6 %
+        // (profiles/r06_conv3_planes.txt); NIMG_CONV3_PLANES=0 switches it off.  Its fragment -> pixel map has no fused-pooling
+        // epilogue: those layers keep the pixel-major tile.
+        static const int planes = getenv("NIMG_CONV3_PLANES") ? atoi(getenv("NIMG_CONV3_PLANES")) : 1;
+#ifdef NIMG_CONV3_VARIANTS
+        // Round-6 experiments on what the K loop waits for, all measured NEGATIVE (profiles/r06_conv3_stages_pipe.txt,
+        // r06_conv3_planes.txt, r06_conv3_loop_anatomy.txt); instantiated in A/B builds only
+        // (tools/build_variant.sh v "-DNIMG_CONV3_VARIANTS" conv_bf16):
+        //   NIMG_CONV3_STAGES=3   three-slot ring (a chunk's transfers get two chunks of matrix work to land)
+        //   NIMG_CONV3_PIPE=1     all operand fragments of a chunk requested from LDS before its first matrix instruction
+        //   NIMG_CONV3_PLANES=2   the plane layout on the 16 x 16 tile too
+        //   NIMG_CONV3_ILV=1      the next chunk's transfers issued one piece per tap behind that tap's matrix instructions
+        //   NIMG_CONV3_LOADER=1   a fifth wave requests the tiles
         static const int stages = getenv("NIMG_CONV3_STAGES") ? atoi(getenv("NIMG_CONV3_STAGES")) : 2;
         static const int pipe = getenv("NIMG_CONV3_PIPE") ? atoi(getenv("NIMG_CONV3_PIPE")) : 0;
-        // NIMG_CONV3_PLANES=0|1|2: the conflict-free plane layout of the halo tile (Dma3Geom LAY 1).  Default 1 = on the 8 x 8 x 4
-        // tile only (the UNet's 8 x 8 level: -6 %); 2 = on the 16 x 16 tile too, where it is 1 - 3 % slower (three pieces more
-        // per chunk, nothing gained: profiles/r06_conv3_planes.txt).  Its fragment -> pixel map has no fused-pooling epilogue:
-        // those layers keep the pixel-major tile
-        static const int planes = getenv("NIMG_CONV3_PLANES") ? atoi(getenv("NIMG_CONV3_PLANES")) : 1;
+        static const int ilv = getenv("NIMG_CONV3_ILV") ? atoi(getenv("NIMG_CONV3_ILV")) : 0;
+        static const int loader = getenv("NIMG_CONV3_LOADER") ? atoi(getenv("NIMG_CONV3_LOADER")) : 0;
+        const bool plain = stages != 3 && !pipe && !ilv;
         if ((planes == 2 || (planes == 1 && NB == 4)) && !p.pool_out && stages != 3) {
             if (pipe) return launch_conv3_dma<TH, TW, NB, TN, 2, true, 1>(p, stream);
+            if (ilv) return launch_conv3_dma<TH, TW, NB, TN, 2, false, 1, true>(p, stream);
+            if (loader) return launch_conv3_dma<TH, TW, NB, TN, 2, false, 1, false, true>(p, stream);
             return launch_conv3_dma<TH, TW, NB, TN, 2, false, 1>(p, stream);
         }
+        if (ilv && stages != 3 && !pipe) return launch_conv3_dma<TH, TW, NB, TN, 2, false, 0, true>(p, stream);
+        if (loader && plain) return launch_conv3_dma<TH, TW, NB, TN, 2, false, 0, false, true>(p, stream);
         if (stages == 3) return pipe ? launch_conv3_dma<TH, TW, NB, TN, 3, true>(p, stream) : launch_conv3_dma<TH, TW, NB, TN, 3, false>(p, stream);
         if (pipe) return launch_conv3_dma<TH, TW, NB, TN, 2, true>(p, stream);
+#else
+        if constexpr (NB == 4) {
+            if (planes && !p.pool_out) return launch_conv3_dma<TH, TW, NB, TN, 2, false, 1>(p, stream);
+        }
+#endif
     }
     ConvParamsB q = p;
     q.tiles_y = cdiv(p.Hout, TH);
     q.tiles_x = cdiv(p.Wout, TW);
     const long blocks = (long)cdiv(p.O1 + p.O2, TN) * q.tiles_y * q.tiles_x * cdiv(p.N, NB);
-    auto kern = conv3_dma_kernel<TH, TW, NB, TN, NS, PIPE, LAY>;
+    auto kern = conv3_dma_kernel<TH, TW, NB, TN, NS, PIPE, LAY, ILV, LDR>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), G::LDS, stream, q);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(LDR ? 320 : 256), G::LDS, stream, q);
     NIMG_CHECK_LAUNCH();
     return NIMG_OK;
 }
@@ -2975,3 +3069,9 @@ int nimg_conv2d_dgrad_fewin_pooled_bf16_ex(const float* g, const unsigned char* 
 }
 
 }  // extern "C"
+
+#ifdef NIMG_CONV3_TIMING
+extern "C" int nimg_debug_conv3_timing(unsigned long long* host, int n_words) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_conv3_timing), (size_t)n_words * 8) == hipSuccess ? 0 : -2;
+}
+#endif
