@@ -88,6 +88,12 @@ class Workload(object):
     def finish(self):
         pass
 
+    def flush(self):
+        """Issue whatever a step left for the next one (the workflow's pipelined FAN update); a no-op otherwise."""
+        wf = getattr(self, 'wf', None)
+        if wf is not None and hasattr(wf, 'finish_pending'):
+            wf.finish_pending()
+
 
 class ChannelJPEG(Workload):
     key = 'c4'
@@ -113,7 +119,8 @@ class ChannelJPEG(Workload):
         kw = self.step_args()
         self.eager = lambda: self.wf.training_step(self.bx, self.by, **kw)
         self.graph = False
-        if self.args.graph and world_size() == 1:          # the data-parallel step is not captured (RCCL launches stay eager)
+        # (a pipelined FAN update carries work across the step boundary: such a step is not captured)
+        if self.args.graph and world_size() == 1 and not getattr(self.wf, '_pipeline_fan', False):     # the data-parallel step is not captured (RCCL launches stay eager)
             from neural_imaging_amd import graphs
             self.runner = graphs.CapturedStep(self.wf, self.bx, self.by, **kw)
             self.graph = True
@@ -321,8 +328,8 @@ def _pmc_traffic(fname, key, n, stamped=False):
         return None, {'file': 'profiles/' + fname, 'status': 'missing'}
 
 
-PMC_RING = 'r05_pmc_ring_kernel.json'            # tools/pmc_ring.sh on the final build of the round
-PMC_STEP = 'r05_pmc_step_total.json'             # tools/pmc_step_total.py, same
+PMC_RING = 'r06_pmc_ring_kernel.json'            # tools/pmc_ring.sh on the final build of the round
+PMC_STEP = 'r06_pmc_step_total.json'             # tools/pmc_step_total.py, same
 
 
 def time_conv5_dominant(dev, n, reps=20):
@@ -700,6 +707,7 @@ def main():
     nblk = 5 if args.steps >= 5 else 1
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(nblk + 1)]
     edges = [round(i * args.steps / nblk) for i in range(nblk + 1)]
+    wl.flush()                                 # pipelined FAN update: nothing of the warm-up steps is carried into the timed region ...
     barrier()
     t0 = time.perf_counter()
     host_cpu = 0.0                             # CPU time this thread spends ISSUING the steps (host cost of the launch path; the
@@ -721,6 +729,7 @@ def main():
         if args.stall_probe:
             faulthandler.cancel_dump_traceback_later()
             host_step_ms.append(1e3 * (time.perf_counter() - t_s))
+    wl.flush()                                 # ... and the last timed step's deferred part runs inside it: K whole steps
     marks[nblk].record()
     host_cpu_ms = 1e3 * host_cpu / max(args.steps, 1)
     barrier()

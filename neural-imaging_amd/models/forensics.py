@@ -190,12 +190,15 @@ class FAN(TFModel):
         t['gap'], t['probs'], t['loss_per'], t['dlogits'], t['loss_scale'] = gap, probs, loss_per, dlogits, ls
         return probs, (t if training else None)
 
-    def backward(self, t, need_input_grad=False, join=True):
+    def backward(self, t, need_input_grad=False, join=True, defer=None):
         """Fills the gradient buffer; returns (loss[1], d loss / d x or None).
         join=False: the caller joins the side streams itself (ops.join_side_stream / ops.nan_flag / the Adam step) - with
         LATE_PARAMS the weight gradients of the fused conv + pool layers are ISSUED behind the whole input-gradient chain, so
-        they run beside whatever the caller launches next instead of beside the (equally chip-filling) input-gradient kernels."""
-        late = [] if (LATE_PARAMS and not join) else None
+        they run beside whatever the caller launches next instead of beside the (equally chip-filling) input-gradient kernels.
+        defer (a list, with join=False): those launches are not issued at all but appended to the list as closures - the caller
+        runs them later (the workflow's pipelined FAN update issues them beside the NEXT step's UNet forward)."""
+        late = [] if ((LATE_PARAMS or defer is not None) and not join) else None
+        self._defer = defer if late is not None else None
         def params(fn, layer=0):           # a parameter-gradient launch: now, or behind the input-gradient chain
             if late is None or not (LATE_MASK >> layer) & 1:
                 fn()
@@ -319,8 +322,12 @@ class FAN(TFModel):
             d_pool = conv.backward_input(P, dz, hw(inp), act_mask=prev_mask, out_bf16=g_bf16(i - 1))
         params(lambda g=d_pool: self._constrained.backward_params(P, t['x'], g))
         dx = self._constrained.backward_input(t['nf'], d_pool) if need_input_grad else None
-        for fn in late or ():
-            fn()
+        if getattr(self, '_defer', None) is not None:
+            self._defer.extend(late or ())
+            self._defer = None
+        else:
+            for fn in late or ():
+                fn()
         if join:
             ops.join_side_stream()
             P.grads_pending = False

@@ -13,6 +13,8 @@ Build-side additions: explicit backward pass (no tape), device-side NaN guard, d
 """
 from collections import OrderedDict
 
+import os
+
 import numpy as np
 import torch
 
@@ -25,7 +27,7 @@ from ..models import forensics, jpeg, pipelines
 class ManipulationClassification(object):
 
     def __init__(self, nip_model, manipulations=None, distribution=None, fan_args=None, trainable=None,
-                 raw_patch_size=128, loss_metric='L2', device=None, nan_check='eager'):
+                 raw_patch_size=128, loss_metric='L2', device=None, nan_check='eager', pipeline_fan_update=None):
         if raw_patch_size < 16 or raw_patch_size > 512:
             raise ValueError('The patch size ({}) looks incorrect, typical values should be >= 16 and <= 512'.format(
                 raw_patch_size))
@@ -118,6 +120,18 @@ class ManipulationClassification(object):
         self._labels_cache = {}
         self._lr_t_dev = None
         self._bucket = parallel.GradientBucket()
+        # pipeline_fan_update (single process, gradients flowing upstream, nan_check='deferred'): the FAN's chip-filling weight
+        # gradients and its Adam update are not issued inside the step that produced them but at the START of the next one,
+        # beside that step's UNet forward / manipulations / codec (latency- and byte-bound kernels on an otherwise idle chip),
+        # and are joined in front of its FAN forward.  Same kernels on the same operands in the same update order: the weights
+        # after finish_pending() are bit-identical to the unpipelined run (tests/test_gpu_models.py).  What changes: the FAN's
+        # weights / gradient buffer are one update behind between steps until finish_pending() is called (run_* / check_nan /
+        # the summaries call it), and a NaN in the FAN's weight gradients gates the FAN's update only (it is seen after the
+        # upstream models' updates of that step were decided).
+        if pipeline_fan_update is None:           # NIMG_PIPELINE_FAN=1: default for workflows built without the argument (A/B runs)
+            pipeline_fan_update = os.environ.get('NIMG_PIPELINE_FAN', '0') == '1'
+        self._pipeline_fan = bool(pipeline_fan_update)
+        self._pending_fan = None
 
     # ------------------------------------------------------------------------------------------------------------
     @property
@@ -199,6 +213,7 @@ class ManipulationClassification(object):
     # -- reference surface ---------------------------------------------------------------------------------------
     def run_workflow(self, batch_x, augment=False, training=False):
         """Returns batch_Y, batch_c, batch_C, entropy, probabilities (workflows/...:162-176)."""
+        self.finish_pending()
         x = to_device(batch_x, self.device)
         Y = self.nip.forward(x)[0]
         m, _ = self._manipulations(Y, augment)
@@ -243,6 +258,7 @@ class ManipulationClassification(object):
         return self._codec_forward(c)[0].cpu().numpy()
 
     def run_rgb_to_probabilities(self, batch_Y):
+        self.finish_pending()
         C = torch.from_numpy(self.run_rgb_to_fan(batch_Y)).to(self.device)
         return self.fan.forward(C)[0].cpu().numpy()
 
@@ -266,6 +282,9 @@ class ManipulationClassification(object):
         need_upstream = train_nip or train_dcn
         world = parallel.world_size()
 
+        # ---- the previous step's FAN weight gradients (pipelined update): on the side streams, beside this step's forward
+        self._launch_pending_fan()
+
         # ---- forward
         m = None
         if getattr(self.nip, 'writes_into', False):       # develop straight into the first slice of the class batch (saves a copy)
@@ -277,6 +296,7 @@ class ManipulationClassification(object):
         m, mctxs = self._manipulations(Y, augment, training=train_nip, m=m)
         c = self._downsampling(m)
         C, entropy, cctx = self._codec_forward(c, training=need_upstream)
+        self._finish_pending_fan()               # ... joined, checked and applied before the FAN is used again
         _, fctx = self.fan.forward(C, self._device_labels(b), training=True)
 
         # ---- backward
@@ -290,7 +310,12 @@ class ManipulationClassification(object):
         # config 5 another 1 % and stay where they were.)
         late_fan = forensics.LATE_PARAMS and need_upstream and not parallel.is_distributed() and \
             C.shape[0] >= forensics.LATE_MIN_IMAGES
-        loss_ce, dC = self.fan.backward(fctx, need_input_grad=need_upstream, join=not late_fan)
+        pipelined = self._pipeline_fan and need_upstream and not parallel.is_distributed() and self._nan_check == 'deferred' and \
+            self._lr_t_dev is None              # (a captured step replays fixed buffers: no work may cross its boundary)
+        deferred = [] if pipelined else None
+        if pipelined:
+            late_fan = True
+        loss_ce, dC = self.fan.backward(fctx, need_input_grad=need_upstream, join=not late_fan, defer=deferred)
         if not late_fan:
             ops.nan_flag(self.fan._model.flat_grad, self._nan_flag)
             self._bucket.launch(self.fan._model.flat_grad)          # overlaps with the rest of the backward pass
@@ -368,7 +393,7 @@ class ManipulationClassification(object):
                 self._bucket.launch(self.nip._model.flat_grad)
         else:
             loss_nip, _ = self.nip._loss_fn(Y, target)
-        if late_fan:
+        if late_fan and not pipelined:
             ops.nan_flag(self.fan._model.flat_grad, self._nan_flag)         # joins the side streams
             self._bucket.launch(self.fan._model.flat_grad)
         parallel.all_reduce_flag(self._nan_flag)
@@ -383,7 +408,12 @@ class ManipulationClassification(object):
         self._step += 1
         gscale = 1.0 / world
         rate = self._lr_t_dev              # None, or the device-resident rate of a captured step (graphs.CapturedStep)
-        self.fan._model.adam(learning_rate, self._step, gscale, skip_flag=self._nan_flag, lr_t_dev=rate)
+        if pipelined:
+            # the FAN's part of this step - the deferred weight-gradient launches, its NaN check (on top of this step's flag, which
+            # stays in _nan_flag until the next backward pass resets it) and its Adam update - waits for the next step
+            self._pending_fan = (deferred, learning_rate, self._step, gscale)
+        else:
+            self.fan._model.adam(learning_rate, self._step, gscale, skip_flag=self._nan_flag, lr_t_dev=rate)
         if train_nip:
             self.nip._model.adam(learning_rate, self._step, gscale, skip_flag=self._nan_flag, lr_t_dev=rate)
         if train_dcn:
@@ -398,7 +428,29 @@ class ManipulationClassification(object):
                          dcn_value if loss_dcn is not None else None, float(lambda_dcn))
         return loss, {'ce': DeviceArray(loss_ce), 'nip': DeviceArray(loss_nip), 'dcn': dcn_value}
 
+    def _launch_pending_fan(self):
+        if self._pending_fan is not None and self._pending_fan[0] is not None:
+            for fn in self._pending_fan[0]:
+                fn()
+            self._pending_fan = (None,) + self._pending_fan[1:]
+
+    def _finish_pending_fan(self):
+        if self._pending_fan is None:
+            return
+        self._launch_pending_fan()
+        _, lr, step, gscale = self._pending_fan
+        self._pending_fan = None
+        ops.nan_flag(self.fan._model.flat_grad, self._nan_flag)             # joins the side streams
+        ops.int_max_(self._nan_seen, self._nan_flag)
+        self.fan._model.adam(lr, step, gscale, skip_flag=self._nan_flag)
+
+    def finish_pending(self):
+        """Pipelined FAN update (constructor): issue and apply what the last training step left for the next one.  Call before
+        reading the FAN's weights or gradients outside training_step; the run_* methods, check_nan and the summaries do."""
+        self._finish_pending_fan()
+
     def check_nan(self):
+        self.finish_pending()
         """Deferred NaN guard (nan_check='deferred'): raises if any step since the last check produced NaN grads (those
         steps' Adam updates were skipped on the device)."""
         seen = int(self._nan_seen.item())

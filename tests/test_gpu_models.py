@@ -1682,6 +1682,47 @@ def test_late_fan_weight_gradients_are_the_same_gradients(dev, mode, monkeypatch
         ops.set_compute('f32')
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+def test_pipelined_fan_update_gives_the_same_weights(dev, mode):
+    """ManipulationClassification(pipeline_fan_update=True): the FAN's weight gradients and Adam update of step n are issued at the
+    start of step n + 1, beside its UNet forward.  Same kernels, same operands, same update order: after finish_pending() the
+    losses of every step, both gradient buffers and both models' weights are bit-identical to the unpipelined run; between steps
+    the FAN is one update behind until finish_pending() (which run_workflow calls)."""
+    from neural_imaging_amd import ops
+    from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
+    ops.set_compute(mode)
+    try:
+        dist = {'downsampling': 'none', 'compression': 'jpeg', 'compression_params': {'quality': 80, 'codec': 'soft'}}
+        rgb = natural_images(4, 64, 64, seed=41)
+        raw = bayer_from_rgb(rgb)
+        batches = [(torch.from_numpy(raw[i:i + 2]).to(dev), torch.from_numpy(rgb[i:i + 2]).to(dev)) for i in (0, 2)]
+        state = []
+        for piped in (True, False):
+            wf = ManipulationClassification('UNet', distribution=dist, trainable={'nip'}, raw_patch_size=32, device=dev,
+                                            nan_check='deferred', pipeline_fan_update=piped)
+            losses = []
+            for k in range(5):
+                loss, _ = wf.training_step(*batches[k % 2], lambda_nip=0.1, learning_rate=1e-3)
+                losses.append(loss)
+            if piped:
+                assert wf._pending_fan is not None
+                behind = wf.fan._model.flat.clone()
+            probs = wf.run_workflow(batches[0][0])[-1].numpy()            # finishes the pending update first
+            assert wf._pending_fan is None
+            if piped:
+                assert not torch.equal(behind, wf.fan._model.flat)
+            wf.check_nan()
+            state.append(([float(v) for v in losses], probs, wf.fan._model.flat_grad.clone(), wf.nip._model.flat_grad.clone(),
+                          wf.fan._model.flat.clone(), wf.nip._model.flat.clone(), wf.fan._model.m.clone(), wf.fan._model.v.clone()))
+        assert state[0][0] == state[1][0]
+        assert np.array_equal(state[0][1], state[1][1])
+        for a, b in zip(state[0][2:], state[1][2:]):
+            assert torch.equal(a, b)
+    finally:
+        ops.set_compute('f32')
+
+
 def test_fused_head_gradient_gives_the_same_step(dev, monkeypatch):
     """The workflow's one-pass hand-over to the UNet backward (UNet.head_gradient) against the three separate passes: same
     loss, bit-identical gradients and parameters after two steps."""
