@@ -52,9 +52,10 @@ extern "C" {
                               3 - b = channel block b written to pixel (2 y + dy, 2 x + dx); the bias repeats per block */
 #define NIMG_POOL_ALSO 256 /* internal to nimg_conv2d_fwd_pool_also_bf16: the pooled tensor is written next to out1, not instead of it */
 
-/* library / ABI version, bumped on any signature change of an existing entry point (3: nimg_conv2d_fwd_bf16_res gained
- * out_bf16_copy and stride).  A binding compares nimg_abi_version() with the NIMG_ABI_VERSION it was written against. */
-#define NIMG_ABI_VERSION 4
+/* library / ABI version, bumped on any change of an existing entry point's signature or data layout (3: nimg_conv2d_fwd_bf16_res
+ * gained out_bf16_copy and stride; 5: the arg-max of nimg_conv1_pool_fwd_c4 / nimg_conv1_wgrad_c4 / nimg_conv1_dgrad_pooled is 2 bits
+ * per value).  A binding compares nimg_abi_version() with the NIMG_ABI_VERSION it was written against. */
+#define NIMG_ABI_VERSION 5
 int nimg_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------------

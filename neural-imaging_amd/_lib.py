@@ -187,7 +187,7 @@ ERRORS = {-1: 'NIMG_ERR_ARG (invalid argument / unsupported configuration)',
 _lib = None
 
 
-ABI_VERSION = 4         # include/nimg.h NIMG_ABI_VERSION
+ABI_VERSION = 5         # include/nimg.h NIMG_ABI_VERSION
 TICKET_BYTES = 64 * 1024        # include/nimg.h NIMG_TICKET_BYTES
 
 
