@@ -1,6 +1,7 @@
-"""Where the K loop of conv3_dma_kernel spends a wave's time (diagnostic build: tools/build_variant.sh timing "-DNIMG_CONV3_TIMING"
+"""Where the K loop of conv3_dma_kernel spends a wave's time (diagnostic build: tools/build_variant.sh timing "-DNIMG_CONV3_TIMING -DNIMG_CONV3_VARIANTS"
 conv_bf16, then NIMG_LIBPATH=neural-imaging_amd/libnimg_timing.so python tools/conv3_timing.py [h cin cout]): s_memtime sums per
-wave of workgroups 0 .. 63, in cycles of the 100 MHz reference clock -> ns."""
+wave of workgroups 0 .. 63.  s_memtime counts SHADER cycles on gfx950: the 'ns' columns below are cycles x 10 (divide by 10 for
+cycles; ~2.1 cycles per ns at the clock these kernels sustain)."""
 import ctypes, importlib, os, sys
 import numpy as np
 import torch
