@@ -1,7 +1,7 @@
 """Where the K loop of conv3_dma_kernel spends a wave's time (diagnostic build: tools/build_variant.sh timing "-DNIMG_CONV3_TIMING -DNIMG_CONV3_VARIANTS"
 conv_bf16, then NIMG_LIBPATH=neural-imaging_amd/libnimg_timing.so python tools/conv3_timing.py [h cin cout]): s_memtime sums per
-wave of workgroups 0 .. 63.  s_memtime counts SHADER cycles on gfx950: the 'ns' columns below are cycles x 10 (divide by 10 for
-cycles; ~2.1 cycles per ns at the clock these kernels sustain)."""
+wave of workgroups 0 .. 63, in shader cycles (what s_memtime counts on gfx950; ~2.1 cycles per ns at the clock these kernels
+sustain)."""
 import ctypes, importlib, os, sys
 import numpy as np
 import torch
@@ -25,10 +25,10 @@ buf = np.zeros(64 * 4 * 8, np.uint64)
 rc = lib.nimg_debug_conv3_timing(buf.ctypes.data_as(ctypes.c_void_p), buf.size)
 assert rc == 0, rc
 t = buf.reshape(64, 4, 8).astype(np.float64)
-tick_ns = 10.0            # s_memtime counts the 100 MHz constant clock on gfx9-family parts
+tick_ns = 1.0             # unit = one s_memtime tick = one shader cycle
 names = ['transfer issue', 'reads + matrix', 'wait transfers', 'barrier', 'prologue', 'epilogue', 'chunks', 'kernel']
 chunks = t[0, 0, 6]
-print('%d^2, %d -> %d: %d chunks; per wave, averaged over 64 workgroups (ns)' % (h, cin, cout, chunks))
+print('%d^2, %d -> %d: %d chunks; per wave, averaged over 64 workgroups (shader cycles)' % (h, cin, cout, chunks))
 for wv in range(4):
     print('  wave %d: ' % wv + ' | '.join('%s %7.0f' % (names[k], t[:, wv, k].mean() * tick_ns) for k in (0, 1, 2, 3, 4, 5, 7)))
-print('  per chunk (ns): ' + ' | '.join('%s %6.1f' % (names[k], t[:, :, k].mean() * tick_ns / chunks) for k in range(4)))
+print('  per chunk (cycles): ' + ' | '.join('%s %6.1f' % (names[k], t[:, :, k].mean() * tick_ns / chunks) for k in range(4)))
