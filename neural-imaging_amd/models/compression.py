@@ -27,6 +27,8 @@ from .tfmodel import ParamStore, TFModel
 _NO_BF16_COPY = bool(os.environ.get('NIMG_NO_BF16_COPY'))
 _NO_S2D_CHAIN = bool(os.environ.get('NIMG_NO_S2D_CHAIN'))
 
+CODEC_FORK_GROUPS = os.environ.get('NIMG_CODEC_FORK_GROUPS') is not None
+
 class _Shape(object):
     def __init__(self, shape):
         self.shape = tuple(shape)
@@ -332,28 +334,34 @@ class TwitterDCN(DCN):
         et, dt = ctx
         L, P = self._layers, self._model
         hw = lambda a: (a.shape[1], a.shape[2])
+        # ops.ParamGroup: the weight gradients of a block behind ONE fork of the launch stream.  OFF here (every launch forks for
+        # itself, as before): config 3 loses 3 % with the groups (9425 -> 9150 patches/s, profiles/r06_fork_markers.txt) - the codec's
+        # step ends with this chain, and weight gradients that start a kernel later end a kernel later.  NIMG_CODEC_FORK_GROUPS=1.
+        grp = ops.ParamGroup(defer=CODEC_FORK_GROUPS)
         # ---- decoder
         dz = ops.d2s_clip_bwd(dy, 0.5)
-        L['d12'].backward_params(P, dt['i4'], dz)
+        grp.add(lambda dz=dz: L['d12'].backward_params(P, dt['i4'], dz))
         # LeakyReLU' of the d256 layer is taken on its depth-to-space image i4 (same signs, permuted), in the epilogue of
         # this input gradient; the space_to_depth of the result is then the gradient at d256's output
         bf = self._bf16_inner()
         dz = L['d12'].backward_input(P, dz, hw(dt['i4']), act_mask=dt['i4'], s2d_out=True, out_bf16=bf)
-        L['d256'].backward_params(P, dt['d256in'], dz)
+        grp.add(lambda dz=dz: L['d256'].backward_params(P, dt['d256in'], dz))
         d_net = L['d256'].backward_input(P, dz, hw(dt['i3']), bf16_copy=bf)
         d_net, d_net_b = d_net if bf else (d_net, None)
         for b in (3, 2, 1):
             a, inp = dt['dr{}a'.format(b)], dt['dr{}in'.format(b)]
             dzs = self._operand(d_net, d_net_b)         # the matrix-core operand form of the stream's gradient
-            L['dr{}b'.format(b)].backward_params(P, a, dzs)
+            grp.add(lambda b=b, a=a, dzs=dzs: L['dr{}b'.format(b)].backward_params(P, a, dzs))
             dza = L['dr{}b'.format(b)].backward_input(P, dzs, hw(a), act_mask=a, out_bf16=bf)
-            L['dr{}a'.format(b)].backward_params(P, inp, dza)
+            grp.add(lambda b=b, inp=inp, dza=dza: L['dr{}a'.format(b)].backward_params(P, inp, dza))
+            grp.flush()
             if b > 1:
                 d_net = L['dr{}a'.format(b)].backward_input(P, dza, hw(inp), residual=d_net, bf16_copy=bf)
                 d_net, d_net_b = d_net if bf else (d_net, None)
             else:       # the gradient leaves the blocks through the depth_to_space behind d512: written as its space_to_depth
                 dz = L['dr1a'].backward_input(P, dza, hw(inp), residual=d_net, s2d_out=True, out_bf16=bf)
-        L['d512'].backward_params(P, dt['latent'], dz)
+        grp.add(lambda dz=dz: L['d512'].backward_params(P, dt['latent'], dz))
+        grp.flush()
         d_lat = L['d512'].backward_input(P, dz, hw(dt['latent']))
         # ---- latent
         soft = self._h.rounding == 'soft-codebook'
@@ -362,17 +370,18 @@ class TwitterDCN(DCN):
                              rounding='identity' if soft else self._h.rounding)
         # ---- encoder
         if 'n3s' in et:
-            L['elat'].backward_params_s2d(P, et['n3s'], dzl)
+            grp.add(lambda dzl=dzl: L['elat'].backward_params_s2d(P, et['n3s'], dzl))
             d_net, d_net_b = L['elat'].backward_input(P, dzl, (2 * et['n3s'].shape[1], 2 * et['n3s'].shape[2])), None
         else:
-            L['elat'].backward_params(P, et['n3'], dzl)
+            grp.add(lambda dzl=dzl: L['elat'].backward_params(P, et['n3'], dzl))
             d_net, d_net_b = L['elat'].backward_input(P, dzl, hw(et['n3'])), None
         for b in (3, 2, 1):
             a, inp = et['er{}a'.format(b)], et['er{}in'.format(b)]
             dzs = self._operand(d_net, d_net_b)
-            L['er{}b'.format(b)].backward_params(P, a, dzs)
+            grp.add(lambda b=b, a=a, dzs=dzs: L['er{}b'.format(b)].backward_params(P, a, dzs))
             dza = L['er{}b'.format(b)].backward_input(P, dzs, hw(a), act_mask=a, out_bf16=bf)
-            L['er{}a'.format(b)].backward_params(P, inp, dza)
+            grp.add(lambda b=b, inp=inp, dza=dza: L['er{}a'.format(b)].backward_params(P, inp, dza))
+            grp.flush()
             # block 1 was fed LeakyReLU(e2): its input gradient goes through that activation (mask by sign of e2)
             d_net = L['er{}a'.format(b)].backward_input(P, dza, hw(inp), act_mask=et['e2'] if b == 1 else None,
                                                         residual=d_net, bf16_copy=bf, mask_activation='leaky_relu')
@@ -380,13 +389,14 @@ class TwitterDCN(DCN):
         # e1's gradient only feeds matrix-core operands (e1's weight / input gradient): stored as bf16
         if 'e1s' in et:
             e1s = et['e1s']
-            L['e2'].backward_params_s2d(P, e1s, self._operand(d_net, d_net_b))
+            grp.add(lambda e1s=e1s, g=self._operand(d_net, d_net_b): L['e2'].backward_params_s2d(P, e1s, g))
             dz1 = L['e2'].backward_input(P, self._operand(d_net, d_net_b), (2 * e1s.shape[1], 2 * e1s.shape[2]), act_mask=e1s,
                                          out_bf16=bf, mask_s2d=True)
         else:
-            L['e2'].backward_params(P, et['e1'], d_net)
+            grp.add(lambda d_net=d_net: L['e2'].backward_params(P, et['e1'], d_net))
             dz1 = L['e2'].backward_input(P, self._operand(d_net, d_net_b), hw(et['e1']), act_mask=et['e1'], out_bf16=bf)
-        L['e1'].backward_params_image(P, et['x0'], dz1)
+        grp.add(lambda dz1=dz1: L['e1'].backward_params_image(P, et['x0'], dz1))
+        grp.flush()
         dx = L['e1'].backward_input_image(P, dz1, self._in_hw, 2.0) if need_input_grad else None
         ops.join_side_stream()
         return dx

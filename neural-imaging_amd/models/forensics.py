@@ -326,8 +326,9 @@ class FAN(TFModel):
             self._defer.extend(late or ())
             self._defer = None
         else:
-            for fn in late or ():
-                fn()
+            with ops.one_fork():           # the late launches depend on nothing queued after this point: one marker for all
+                for fn in late or ():
+                    fn()
         if join:
             ops.join_side_stream()
             P.grads_pending = False

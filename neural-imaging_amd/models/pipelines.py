@@ -227,30 +227,36 @@ class UNet(NIPModel):
         # head: d2s + clip are straight-through
         dz = ops.d2s_clip_bwd(dy, 1.0) if dz_head is None else dz_head
         last = 'dc{}2'.format(ns - 1)
-        L['dc{}'.format(ns)].backward_params(P, t[last], dz)
+        # the weight gradients of a level are issued on the side streams behind ONE fork, after that level's input gradients
+        # are queued (ops.ParamGroup: a fork is a marker packet between two kernels of the launch stream, 6 - 8 us each)
+        grp = ops.ParamGroup()
+        grp.add(lambda dz=dz: L['dc{}'.format(ns)].backward_params(P, t[last], dz))
         dz = L['dc{}'.format(ns)].backward_input(P, dz, hw(t[last]), act_mask=t[last], out_bf16=sb)   # dZ of dc{ns-1}2
         d_skip = {}
         for n in range(ns - 1, 0, -1):
             a1, up, skip = t['dc{}1'.format(n)], t['dct{}'.format(n)], t['ec{}2'.format(ns - n)]
-            L['dc{}2'.format(n)].backward_params(P, a1, dz)
+            grp.add(lambda n=n, a1=a1, dz=dz: L['dc{}2'.format(n)].backward_params(P, a1, dz))
             dz1 = L['dc{}2'.format(n)].backward_input(P, dz, hw(a1), act_mask=a1, out_bf16=sb)      # dZ of dc{n}1
-            L['dc{}1'.format(n)].backward_params(P, up, dz1, x2=skip)
+            grp.add(lambda n=n, up=up, dz1=dz1, skip=skip: L['dc{}1'.format(n)].backward_params(P, up, dz1, x2=skip))
             d_up = torch.empty_like(up)
             d_sk = torch.empty_like(skip)
             L['dc{}1'.format(n)].backward_input(P, dz1, hw(up), out=d_up, out2=d_sk)
             d_skip[ns - n] = d_sk
             prev = t['dc{}2'.format(n - 1)]
-            L['dct{}'.format(n)].backward_params(P, prev, d_up)
+            grp.add(lambda n=n, prev=prev, d_up=d_up: L['dct{}'.format(n)].backward_params(P, prev, d_up))
+            grp.flush()                    # (in front of the level's last input gradient: everything the group reads is queued)
             dz = L['dct{}'.format(n)].backward_input(P, d_up, act_mask=prev, out_bf16=sb,
                                                      mask_activation=self._h.activation)          # dZ of dc{n-1}2 / ec{ns}2
+        grp.flush()
         if on_decoder_done is not None:
             on_decoder_done()
         for n in range(ns, 0, -1):
             a1, inp = t['ec{}1'.format(n)], t['ep{}'.format(n - 1)]
-            L['ec{}2'.format(n)].backward_params(P, a1, dz)
+            grp.add(lambda n=n, a1=a1, dz=dz: L['ec{}2'.format(n)].backward_params(P, a1, dz))
             # the first layer's weight gradient (4 input channels: the (tap, ci)-packed kernel) stages float32
             dz1 = L['ec{}2'.format(n)].backward_input(P, dz, hw(a1), act_mask=a1, out_bf16=sb and n > 1)
-            L['ec{}1'.format(n)].backward_params(P, inp, dz1)
+            grp.add(lambda n=n, inp=inp, dz1=dz1: L['ec{}1'.format(n)].backward_params(P, inp, dz1))
+            grp.flush()
             if n > 1:
                 prev = t['ec{}2'.format(n - 1)]
                 w1 = P.p['ec{}1/kernel'.format(n)]

@@ -304,7 +304,11 @@ class _on_side_stream(object):
             streams[k] = _new_side_stream(dev)
         side = streams[k]
         self.prev = torch.cuda.current_stream(dev)
-        side.wait_stream(self.prev)
+        fork = _SIDE.get('fork')
+        if fork is not None and fork[1] == self.prev:
+            side.wait_event(fork[0])            # inside `with one_fork()`: the group's single marker on the launch stream
+        else:
+            side.wait_stream(self.prev)
         for t in self.tensors:
             t.record_stream(side)
         torch.cuda.set_stream(side)             # (torch.cuda.stream(side) does the same behind two more Python layers)
@@ -314,6 +318,56 @@ class _on_side_stream(object):
     def __exit__(self, *exc):
         torch.cuda.set_stream(self.prev)
         return False
+
+
+# Every fork costs the LAUNCH stream: side.wait_stream(launch) records an event there - a marker packet between two of its
+# kernels - and the next kernel starts 6 - 8 us after the previous one ended instead of ~2 (profiles/r06_fork_markers.txt: 25 such
+# gaps in the UNet's input-gradient chain, eager launches and graph replay alike).  `with one_fork():` records ONE event; every
+# side-stream block entered inside waits on it.  Contract: nothing launched inside may depend on launch-stream work queued after
+# the fork - i.e. the body consists of side-stream launches only (parameter gradients deferred by their model, see
+# models/pipelines.py UNet.backward).  NIMG_NO_FORK_GROUPS=1: every block forks for itself, as before round 6.
+FORK_GROUPS = _os.environ.get('NIMG_NO_FORK_GROUPS') is None
+
+
+class one_fork(object):
+    def __enter__(self):
+        if FORK_GROUPS and _SIDE['enabled'] and _SIDE.get('fork') is None and torch.cuda.is_available():
+            cur = torch.cuda.current_stream()
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            _SIDE['fork'] = (ev, cur)
+            self.mine = True
+        else:
+            self.mine = False
+        return self
+
+    def __exit__(self, *exc):
+        if self.mine:
+            _SIDE['fork'] = None
+        return False
+
+
+class ParamGroup(object):
+    """Parameter-gradient launches of a few consecutive layers, deferred and issued behind ONE fork:
+        g = ops.ParamGroup(); g.add(lambda: layer.backward_params(...)); ...input-gradient launches...; g.flush()
+    The closures must hold tensors no later launch-stream kernel of the group overwrites."""
+
+    def __init__(self, defer=True):
+        self.fns = []
+        self.defer = defer
+
+    def add(self, fn):
+        if self.defer and FORK_GROUPS and _SIDE['enabled']:
+            self.fns.append(fn)
+        else:
+            fn()
+
+    def flush(self):
+        if self.fns:
+            with one_fork():
+                for fn in self.fns:
+                    fn()
+            self.fns = []
 
 
 class side_stream(object):

@@ -430,8 +430,9 @@ class ManipulationClassification(object):
 
     def _launch_pending_fan(self):
         if self._pending_fan is not None and self._pending_fan[0] is not None:
-            for fn in self._pending_fan[0]:
-                fn()
+            with ops.one_fork():
+                for fn in self._pending_fan[0]:
+                    fn()
             self._pending_fan = (None,) + self._pending_fan[1:]
 
     def _finish_pending_fan(self):
