@@ -425,6 +425,33 @@ def _flush_deferred(k, on_its_stream=True):
     _SIDE['ws'][k].release()
 
 
+# NIMG_REDUCE_STREAM=1: the split-K slab reduction of a side=True weight gradient runs on a stream of its OWN (one per side stream),
+# behind an event of the side stream, instead of between two weight gradients on the side stream: the next weight gradient starts
+# as soon as its predecessor ends, the reduction (a small grid that waits long for free CUs beside the chip-filling kernels: 28 us
+# on average inside a C4 step against 7 us alone) runs beside it.  Every pending weight gradient keeps its own piece of the side
+# stream's arena until the join.  Same kernels, same sums.
+REDUCE_STREAM = _os.environ.get('NIMG_REDUCE_STREAM', '0') == '1'
+_RSTREAM = {'streams': {}, 'dirty': set()}
+
+
+def _reduce_behind(k, entry, device):
+    """Issue the reduction described by `entry` (owed by the launch just made on side stream k, the current stream) on k's
+    reduction stream."""
+    side = torch.cuda.current_stream(device)
+    rs = _RSTREAM['streams'].get(k)
+    if rs is None or rs.device != device:
+        rs = _RSTREAM['streams'][k] = torch.cuda.Stream(device=device)
+    ev = torch.cuda.Event()
+    ev.record(side)
+    rs.wait_event(ev)
+    torch.cuda.set_stream(rs)
+    try:
+        _lib.call('nimg_reduce_slabs_batch', entry, 1, _stream())
+    finally:
+        torch.cuda.set_stream(side)
+    _RSTREAM['dirty'].add(k)
+
+
 def join_side_stream():
     """Make the current stream wait for the parameter-gradient kernels launched on the side streams."""
     for k in sorted(_SIDE['dirty']):
@@ -433,6 +460,11 @@ def join_side_stream():
             _flush_deferred(k)
             torch.cuda.current_stream(st.device).wait_stream(st)
     _SIDE['dirty'].clear()
+    for k in sorted(_RSTREAM['dirty']):
+        rs = _RSTREAM['streams'][k]
+        torch.cuda.current_stream(rs.device).wait_stream(rs)
+        _SIDE['ws'][k].release()           # every later user of the arena is ordered behind this join
+    _RSTREAM['dirty'].clear()
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -756,6 +788,9 @@ def conv2d_wgrad(x, dz, ks, x2=None, stride=1, padding='SAME', pad_mode=0, pads=
         if _defer_k is not None and DEFER_REDUCE and not accumulate:
             _wgrad_deferred(_defer_k, x, c1, x2, c2, dz, None, cout, dw, db, n, h, wd, ks, stride, pt, pl, pad_mode, ho, wo, need, flags)
             return dw
+        if _defer_k is not None and REDUCE_STREAM and not accumulate:
+            _wgrad_reduce_stream(_defer_k, x, c1, x2, c2, dz, None, cout, dw, db, n, h, wd, ks, stride, pt, pl, pad_mode, ho, wo, need, flags)
+            return dw
         if _defer_k is not None:
             _flush_deferred(_defer_k, on_its_stream=False)      # an accumulating launch follows the pending ones of its stream
         ws = _ws_current(x.device).get(need, x.device)
@@ -782,6 +817,17 @@ def _wgrad_deferred(k, x, c1, x2, c2, dz, idx, cout, dw, db, n, h, wd, ks, strid
     _lib.call('nimg_conv2d_wgrad_bf16_deferred', _p(x), c1, _p(x2), c2, _p(dz), _p(idx), cout, _p(dw), _p(db), n, h, wd, ks, stride,
               pt, pl, pad_mode, ho, wo, _p(ws), ws.numel(), flags, entry, _stream())
     st['n'] += 1
+
+
+def _wgrad_reduce_stream(k, x, c1, x2, c2, dz, idx, cout, dw, db, n, h, wd, ks, stride, pt, pl, pad_mode, ho, wo, need, flags):
+    """One weight gradient on side stream k (the current stream) whose slab reduction goes to k's reduction stream."""
+    import ctypes
+    nb = int(_lib.load().nimg_reduce_entry_bytes())
+    entry = (ctypes.c_char * nb)()
+    ws = _SIDE['ws'][k].claim(need, x.device)
+    _lib.call('nimg_conv2d_wgrad_bf16_deferred', _p(x), c1, _p(x2), c2, _p(dz), _p(idx), cout, _p(dw), _p(db), n, h, wd, ks, stride,
+              pt, pl, pad_mode, ho, wo, _p(ws), ws.numel(), flags, entry, _stream())
+    _reduce_behind(k, entry, x.device)
 
 
 def bias_grad(dz, db=None, accumulate=False, side=False):
@@ -1026,6 +1072,9 @@ def conv2d_wgrad_unpool(x, g, idx, ks, dw, db=None, side=False, _defer_k=None):
     need = _lib.load().nimg_conv2d_wgrad_bf16_workspace_bytes(cin, cout, ks, ks, n, h, wd)
     if _defer_k is not None and DEFER_REDUCE and ks == 5 and h % 2 == 0 and wd % 2 == 0:
         _wgrad_deferred(_defer_k, x, cin, None, 0, g, idx, cout, dw, db, n, h, wd, ks, 1, 2, 2, 0, h, wd, need, BF16_IN | BF16_DZ)
+        return dw
+    if _defer_k is not None and REDUCE_STREAM and ks == 5 and h % 2 == 0 and wd % 2 == 0:
+        _wgrad_reduce_stream(_defer_k, x, cin, None, 0, g, idx, cout, dw, db, n, h, wd, ks, 1, 2, 2, 0, h, wd, need, BF16_IN | BF16_DZ)
         return dw
     ws = _ws_current(x.device).get(need, x.device)
     _lib.call('nimg_conv2d_wgrad_bf16_unpool', _p(x), cin, _p(g), _p(idx), cout, _p(dw), _p(db), n, h, wd, ks, 0, _p(ws),
