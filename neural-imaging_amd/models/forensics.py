@@ -25,6 +25,7 @@ from .tfmodel import ParamStore, TFModel, glorot_uniform_
 # manipulation / UNet backward): NIMG_NO_LATE_PARAMS=1 = beside the input gradients, as rounds 1 - 3 (A/B runs).
 LATE_PARAMS = os.environ.get('NIMG_NO_LATE_PARAMS') is None
 LATE_MIN_IMAGES = int(os.environ.get('NIMG_LATE_MIN_IMAGES', '160'))      # FAN batch from which the late order pays
+DEFER_MASK = int(os.environ.get('NIMG_PIPELINE_FAN_MASK', '255'))     # pipelined FAN update: the layers whose weight gradients wait for the next step
 LATE_MASK = int(os.environ.get('NIMG_LATE_MASK', '255'))      # bit 0: constrained filter, bit i: convolution i (A/B runs)
 
 
@@ -202,6 +203,8 @@ class FAN(TFModel):
         def params(fn, layer=0):           # a parameter-gradient launch: now, or behind the input-gradient chain
             if late is None or not (LATE_MASK >> layer) & 1:
                 fn()
+            elif self._defer is not None and (DEFER_MASK >> layer) & 1:
+                self._defer.append(fn)     # ... or not in this step at all (the workflow's pipelined FAN update)
             else:
                 late.append(fn)
         P = self._model
@@ -322,13 +325,10 @@ class FAN(TFModel):
             d_pool = conv.backward_input(P, dz, hw(inp), act_mask=prev_mask, out_bf16=g_bf16(i - 1))
         params(lambda g=d_pool: self._constrained.backward_params(P, t['x'], g))
         dx = self._constrained.backward_input(t['nf'], d_pool) if need_input_grad else None
-        if getattr(self, '_defer', None) is not None:
-            self._defer.extend(late or ())
-            self._defer = None
-        else:
-            with ops.one_fork():           # the late launches depend on nothing queued after this point: one marker for all
-                for fn in late or ():
-                    fn()
+        self._defer = None
+        with ops.one_fork():               # the late launches depend on nothing queued after this point: one marker for all
+            for fn in late or ():
+                fn()
         if join:
             ops.join_side_stream()
             P.grads_pending = False
