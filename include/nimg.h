@@ -419,6 +419,15 @@ int nimg_conv2d_wgrad_bf16_deferred(const void* in1, int c1, const void* in2, in
                                     int cout, float* dw, float* db, int n, int h, int wd, int ks, int stride, int pad_t, int pad_l,
                                     int pad_mode, int hout, int wout, void* workspace, size_t workspace_bytes, int flags,
                                     void* entry, void* stream);
+/* Chained form: the same call, which ALSO runs the reduction owed by a previous deferred / chained call on this stream (pre_entry:
+ * the entry that call filled, or NULL) - in the prologue of this call's own kernel where that kernel can (the 3x3 all-taps and the
+ * generic bf16 weight-gradient kernels), as a separate launch in front of it otherwise.  The previous call's workspace must stay
+ * untouched until this call has been issued; the last entry of a chain goes to nimg_reduce_slabs_batch.  Sums bit-identical to the
+ * per-layer reduction.  entry may alias pre_entry. */
+int nimg_conv2d_wgrad_bf16_chained(const void* in1, int c1, const void* in2, int c2, const void* dz, const unsigned char* idx,
+                                   int cout, float* dw, float* db, int n, int h, int wd, int ks, int stride, int pad_t, int pad_l,
+                                   int pad_mode, int hout, int wout, void* workspace, size_t workspace_bytes, int flags,
+                                   const void* pre_entry, void* entry, void* stream);
 size_t nimg_reduce_entry_bytes(void);
 int nimg_reduce_batch_max(void);
 int nimg_reduce_slabs_batch(const void* entries, int n, void* stream);

@@ -57,6 +57,8 @@ PROTOTYPES = {
     'nimg_conv3_rows_d2s_bf16': (c_int, [P, c_int, P, P, P, c_int, c_int, c_int, P]),
     'nimg_conv2d_wgrad_bf16_deferred': (c_int, [P, c_int, P, c_int, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                                 c_int, c_int, c_int, P, c_size_t, c_int, P, P]),
+    'nimg_conv2d_wgrad_bf16_chained': (c_int, [P, c_int, P, c_int, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                               c_int, c_int, c_int, P, c_size_t, c_int, P, P, P]),
     'nimg_reduce_entry_bytes': (c_size_t, []),
     'nimg_reduce_batch_max': (c_int, []),
     'nimg_reduce_slabs_batch': (c_int, [P, c_int, P]),

@@ -360,6 +360,59 @@ static inline void fill_reduce_entry(ReduceEntry* e, const float* p1, float* d1,
     e->accumulate = accumulate; e->blocks1 = reduce_grid(n1);
 }
 
+// ---- chained form: the reduction a weight gradient owes, run in the PROLOGUE of the next weight-gradient kernel of its stream
+// (nimg_conv2d_wgrad_bf16_chained): every thread of every workgroup takes float4 columns gtid, gtid + nthreads, ... and performs
+// reduce_slabs()'s additions for that column in reduce_slabs()'s order - segment sums r_seg = a0 + a1 with a0 += slabs seg, seg + 32,
+// ..., a1 += slabs seg + 16, seg + 48, ..., then r_0 + r_1 + ... + r_15, then the accumulate term - so the result is bit-identical
+// to the separate launch, without its launch, its wait for free CUs beside the chip-filling kernels, or a second pass of barriers.
+// The slabs were written by the previous kernel of the same stream: visible at the kernel boundary.
+__device__ __forceinline__ void reduce_seq(const float* __restrict__ partial, float* __restrict__ dst, long count, int splits,
+                                           int accumulate, long gtid, long nthreads) {
+    if ((count & 3) == 0) {
+        const long c4 = count >> 2;
+        for (long i = gtid; i < c4; i += nthreads) {
+            const float4* src = reinterpret_cast<const float4*>(partial) + i;
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int seg = 0; seg < 16; ++seg) {
+                float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+                for (int k = seg; k < splits; k += 32) {
+                    const float4 v0 = src[(long)k * c4];
+                    a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+                    if (k + 16 < splits) {
+                        const float4 v1 = src[(long)(k + 16) * c4];
+                        a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+                    }
+                }
+                const float4 sg = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+                if (seg == 0) r = sg;
+                else { r.x += sg.x; r.y += sg.y; r.z += sg.z; r.w += sg.w; }
+            }
+            float4* d = reinterpret_cast<float4*>(dst) + i;
+            if (accumulate) { const float4 o = *d; r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
+            *d = r;
+        }
+        return;
+    }
+    for (long i = gtid; i < count; i += nthreads) {
+        float sacc = 0.f;
+        for (int k = 0; k < splits; ++k) sacc += partial[(long)k * count + i];
+        dst[i] = accumulate ? dst[i] + sacc : sacc;
+    }
+}
+// one-dimensional grids and workgroups only (what the weight-gradient kernels launch)
+__device__ __forceinline__ void reduce_entry_inline(const ReduceEntry& e) {
+    if (e.n1 <= 0 || !e.p1 || !e.d1) return;
+    const long gtid = (long)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (long)gridDim.x * blockDim.x;
+    reduce_seq(e.p1, e.d1, e.n1, e.splits1, e.accumulate, gtid, nthreads);
+    if (e.p2 && e.d2 && e.n2 > 0) reduce_seq(e.p2, e.d2, e.n2, e.splits2, e.accumulate, gtid, nthreads);
+}
+static inline ReduceEntry empty_reduce_entry() {
+    ReduceEntry e;
+    fill_reduce_entry(&e, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, 0, 0);
+    e.blocks1 = 0;
+    return e;
+}
+
 // ---- in-kernel finish of a split-K sum by the LAST-ARRIVING workgroup.  The separate
 // reduce_slabs2 launch behind every weight gradient (~32 per training step) read slabs that were still in the Infinity Cache,
 // but each cost a launch on the side stream and a pass over every slab by a handful of workgroups.  Here the workgroups

@@ -19,7 +19,7 @@ int nimg_internal_wgrad5_alltaps(const void* in, int cin, const void* g, const u
 // defined in wgrad3.hip: same contract for the UNet's 3x3 layers (bf16 input(s) and output gradient)
 int nimg_internal_wgrad3_alltaps(const void* in1, int c1, const void* in2, int c2, const void* dz, int cout, float* partial,
                                  float* db_partial, int n, int h, int wd, int max_slabs, hipStream_t stream, float* dw, float* db,
-                                 int accumulate);
+                                 int accumulate, const void* pre);
 // defined in conv_small.hip
 size_t nimg_internal_wgrad_tiny_bytes(int ks, int cin, int cout);
 int nimg_internal_conv_wgrad_tiny(const float* in, const float* dz, float* dw, int cin, int cout, int n, int h, int wd,
@@ -1644,6 +1644,7 @@ struct WgradParamsB {
     float* dw;
     float* db;
     int group, accumulate;
+    nimg::ReduceEntry pre;         // the reduction the PREVIOUS weight gradient of this stream owes (chained mode), or empty
 };
 
 constexpr int B_TH = 8, B_TW = 16, B_CI = 32, B_CO = 64;
@@ -1683,6 +1684,7 @@ constexpr int B_ZS = 192;      // dz tile row stride in bytes (64 co bf16 = 128 
 // each with its own zero halo in the input tile ([10][2 x 10] pixels) - the lanes of the second K half read 2 pixels further on.
 template <int KS, int STRIDE, int NW, bool INB, bool DZB, int TH, bool UNP = false, int NCO = 2, bool PAIR = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_bf16_kernel(const WgradParamsB p) {
+    nimg::reduce_entry_inline(p.pre);
     constexpr int TCO = 32 * NCO, ZS = NCO == 2 ? B_ZS : 64, ZI = 4 * NCO;      // dz tile: channels, row stride, 16-byte items per pixel
     static_assert(NCO == 1 || NCO == 2, "one or two output fragments");
     static_assert(!UNP || NCO == 2, "un-pooling dz: 64-wide tile");
@@ -2135,6 +2137,10 @@ size_t nimg_conv2d_wgrad_bf16_workspace_bytes(int cin, int cout, int ks_h, int k
 // deferred mode (nimg_conv2d_wgrad_bf16_deferred): the partial-sum kernel is launched, the reduction it owes is described in
 // *g_defer instead of being launched (common.h ReduceEntry); one thread-local pointer, set around the call
 static thread_local nimg::ReduceEntry* g_defer = nullptr;
+// chained mode (nimg_conv2d_wgrad_bf16_chained): the reduction the PREVIOUS deferred weight gradient of the stream owes; the kernel
+// launched by this call runs it in its prologue (conv3_wgrad_alltaps_kernel, conv_wgrad_bf16_kernel), any other path launches it
+// as a separate reduction first
+static thread_local const nimg::ReduceEntry* g_pre = nullptr;
 static inline void finish_reduce2(const float* p1, float* d1, long n1, int splits1, const float* p2, float* d2, long n2,
                                   int splits2, int accumulate, hipStream_t s) {
     if (g_defer) nimg::fill_reduce_entry(g_defer, p1, d1, n1, splits1, p2, d2, n2, splits2, accumulate);
@@ -2155,12 +2161,24 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
     if ((c2 > 0 && !in2) || hout <= 0 || wout <= 0 || !workspace || pad_mode < 0 || pad_mode > 2) return NIMG_ERR_ARG;
     const int cin = c1 + c2;
     if (workspace_bytes < nimg_conv2d_wgrad_bf16_workspace_bytes(cin, cout, ks, ks, n, hout, wout)) return NIMG_ERR_WORKSPACE;
+    const nimg::ReduceEntry* pre = g_pre;          // consumed by exactly one of the paths below
+    g_pre = nullptr;
+    auto pre_alone = [&]() {                       // a path whose kernel cannot run it: as its own launch, now
+        if (pre && pre->n1 > 0 && pre->p1 && pre->d1)
+            launch_reduce2(pre->p1, pre->d1, pre->n1, pre->splits1, pre->p2, pre->d2, pre->n2, pre->splits2, pre->accumulate,
+                           (hipStream_t)stream);
+        pre = nullptr;
+    };
     if (c2 == 0 && c1 == 3 && cout == 3 && stride == 1 && (ks == 3 || ks == 5) && hout == h && wout == wd &&
-        pad_t == (ks - 1) / 2 && pad_l == pad_t && !db)              // tiny filter: its own kernels (conv_small.hip)
+        pad_t == (ks - 1) / 2 && pad_l == pad_t && !db) {            // tiny filter: its own kernels (conv_small.hip)
+        pre_alone();
         return nimg_internal_conv_wgrad_tiny(in1, dz, dw, c1, cout, n, h, wd, ks, pad_t, pad_mode, accumulate, workspace,
                                              (hipStream_t)stream, true);          // throughput mode: bf16 matrix operands
+    }
     if (c2 == 0 && (c1 == 3 || c1 == 4) && stride == 1 && (ks == 3 || ks == 5)) {      // (tap, ci)-packed M dimension
+        pre_alone();
         WgradParamsB q;
+        q.pre = nimg::empty_reduce_entry();
         q.in1 = in1; q.in2 = nullptr; q.dz = dz; q.dz_idx = dz_idx; q.partial = (float*)workspace; q.db_partial = nullptr;
         q.flags = flags;
         q.tickets = nullptr; q.dw = nullptr; q.db = nullptr; q.group = 1; q.accumulate = accumulate;
@@ -2206,8 +2224,9 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
         NIMG_CHECK_LAUNCH();
         return NIMG_OK;
     }
-    if ((c1 % 4) || (c2 % 4) || (cout % 4) || (c2 > 0 && (c1 % 8))) return NIMG_ERR_ARG;
+    if ((c1 % 4) || (c2 % 4) || (cout % 4) || (c2 > 0 && (c1 % 8))) { pre_alone(); return NIMG_ERR_ARG; }
     WgradParamsB p;
+    p.pre = nimg::empty_reduce_entry();
     p.in1 = in1; p.in2 = in2; p.dz = dz; p.dz_idx = dz_idx; p.partial = (float*)workspace; p.db_partial = nullptr;
     p.flags = flags;
     p.tickets = nullptr; p.dw = dw; p.db = db; p.group = 1; p.accumulate = accumulate;
@@ -2231,6 +2250,7 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
     hipStream_t s = (hipStream_t)stream;
     if (dz_idx && ks == 5 && stride == 1 && c2 == 0 && pad_t == 2 && pad_l == 2 && hout == h && wout == wd && pad_mode == 0) {
         // the FAN's conv2..4: all 25 taps in one wave (wgrad5.hip); slabs laid out inside the same workspace bound
+        pre_alone();
         const int max_slabs = splits_for(cin, cout, n, hout, wout);
         float* dbp = db ? (float*)workspace + (size_t)max_slabs * count : nullptr;
         const int slabs = nimg_internal_wgrad5_alltaps(in1, cin, dz, dz_idx, cout, (float*)workspace, dbp, n, h, wd, max_slabs, s);
@@ -2247,7 +2267,8 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
         const int max_slabs = splits_for(cin, cout, n, hout, wout);
         float* dbp = db ? (float*)workspace + (size_t)max_slabs * count : nullptr;
         const int slabs = nimg_internal_wgrad3_alltaps(in1, c1, in2, c2, dz, cout, (float*)workspace, dbp, n, h, wd, max_slabs, s,
-                                                       g_defer ? nullptr : dw, db, accumulate);
+                                                       g_defer ? nullptr : dw, db, accumulate, pre);
+        if (slabs != 0) pre = nullptr;                        // launched: its prologue runs the chained reduction
         if (slabs == -1) return NIMG_ERR_LAUNCH;
         if (slabs < -1) return NIMG_OK;                       // finished in the kernel by the last-arriving workgroups
         if (slabs > 0) {
@@ -2271,6 +2292,7 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
         auto k = conv_wgrad_bf16_kernel<3, 1, 4, true, true, B_TH, false, 2, true>;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         want_tickets(p);
+        if (pre) { p.pre = *pre; pre = nullptr; }
         hipLaunchKernelGGL(k, dim3((unsigned)pblocks), dim3(256), lds, s, p);
         NIMG_CHECK_LAUNCH();
         if (p.tickets) return NIMG_OK;
@@ -2282,6 +2304,7 @@ static int wgrad_bf16_impl(const float* in1, int c1, const float* in2, int c2, c
     if (db) p.db_partial = p.partial + (size_t)p.splits * count;
     const long blocks = (long)cdiv(cin, B_CI) * cdiv(cout, B_CO) * p.splits;
     want_tickets(p);
+    if (pre) { p.pre = *pre; pre = nullptr; }
 #define NIMG_WGB1(KS_, ST_, NW_, INB_, DZB_, TH_)                                                               \
     do {                                                                                                      \
         constexpr int THH = (TH_ - 1) * ST_ + KS_, TWH = (B_TW - 1) * ST_ + KS_;                              \
@@ -2370,6 +2393,31 @@ int nimg_conv2d_wgrad_bf16_deferred(const void* in1, int c1, const void* in2, in
     const int rc = wgrad_bf16_impl((const float*)in1, c1, (const float*)in2, c2, (const float*)dz, idx, cout, dw, db, n, h, wd, ks,
                                    stride, pad_t, pad_l, pad_mode, hout, wout, 0, workspace, workspace_bytes, flags, stream);
     g_defer = nullptr;
+    return rc;
+}
+
+/* nimg_conv2d_wgrad_bf16_deferred that also runs the reduction a PREVIOUS deferred / chained call on the same stream owes
+ * (pre_entry, may be NULL): in the prologue of this call's kernel where that kernel can (the UNet's 3x3 all-taps kernel, the generic
+ * bf16 kernel), as a separate launch in front of it otherwise.  Bit-identical sums (common.h reduce_seq). */
+int nimg_conv2d_wgrad_bf16_chained(const void* in1, int c1, const void* in2, int c2, const void* dz, const unsigned char* idx,
+                                   int cout, float* dw, float* db, int n, int h, int wd, int ks, int stride, int pad_t, int pad_l,
+                                   int pad_mode, int hout, int wout, void* workspace, size_t workspace_bytes, int flags,
+                                   const void* pre_entry, void* entry, void* stream) {
+    if (!entry) return NIMG_ERR_ARG;
+    nimg::ReduceEntry pre_copy;
+    if (pre_entry) { pre_copy = *reinterpret_cast<const nimg::ReduceEntry*>(pre_entry); g_pre = &pre_copy; }   // (entry may alias pre_entry)
+    nimg::ReduceEntry* e = reinterpret_cast<nimg::ReduceEntry*>(entry);
+    *e = nimg::empty_reduce_entry();
+    g_defer = e;
+    const int rc = wgrad_bf16_impl((const float*)in1, c1, (const float*)in2, c2, (const float*)dz, idx, cout, dw, db, n, h, wd, ks,
+                                   stride, pad_t, pad_l, pad_mode, hout, wout, 0, workspace, workspace_bytes, flags, stream);
+    g_defer = nullptr;
+    if (g_pre) {                   // an argument check returned before any path took it: do not lose the reduction
+        const nimg::ReduceEntry* p = g_pre;
+        g_pre = nullptr;
+        if (p->n1 > 0 && p->p1 && p->d1)
+            nimg::launch_reduce2(p->p1, p->d1, p->n1, p->splits1, p->p2, p->d2, p->n2, p->splits2, p->accumulate, (hipStream_t)stream);
+    }
     return rc;
 }
 

@@ -43,6 +43,7 @@ struct Wg3Params {
     float* dw;
     float* db;
     int splits, group, accumulate;
+    ReduceEntry pre;               // the reduction the PREVIOUS weight gradient of this stream owes (common.h reduce_entry_inline), or empty
 };
 
 template <int NB, int TH>
@@ -67,6 +68,7 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_alltaps_kernel(const Wg3Pa
     using G = Wg3Geom<NB, TH>;
     constexpr int KG = G::KG, CB = G::CB, ZS = G::ZS, IRS = G::IRS, ZRS = G::ZRS, IP = G::IP, ZP = G::ZP, ST = G::ST;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    reduce_entry_inline(p.pre);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ai = wave & 1, bj = (wave >> 1) % NB, kg = (wave >> 1) / NB;
@@ -339,7 +341,7 @@ int launch(Wg3Params p, int max_slabs, hipStream_t stream) {
 // counters bound to the stream the sums are FINISHED in the kernel (dw / db written or accumulated into): returns -2 - slabs.
 int nimg_internal_wgrad3_alltaps(const void* in1, int c1, const void* in2, int c2, const void* dz, int cout, float* partial,
                                  float* db_partial, int n, int h, int wd, int max_slabs, hipStream_t stream, float* dw, float* db,
-                                 int accumulate) {
+                                 int accumulate, const void* pre) {
     if (getenv("NIMG_NO_WGRAD3_ALLTAPS") != nullptr) return 0;
     if ((c1 % 32) || (c2 % 32) || (cout % 32) || (wd % 16) || (h % 8) || max_slabs < 1 || (c2 > 0 && !in2)) return 0;
     const long px = (long)n * h * wd;
@@ -349,6 +351,7 @@ int nimg_internal_wgrad3_alltaps(const void* in1, int c1, const void* in2, int c
     p.C1 = c1; p.C2 = c2; p.Cout = cout; p.N = n; p.H = h; p.W = wd;
     p.tiles_y = p.tiles_x = p.work_per_split = 0;
     p.tickets = nullptr; p.dw = dw; p.db = db_partial ? db : nullptr; p.splits = p.group = 0; p.accumulate = accumulate;
+    p.pre = pre ? *reinterpret_cast<const ReduceEntry*>(pre) : empty_reduce_entry();
     // output channels per workgroup: 32 NB.  A/B: NIMG_WGRAD3_NB = 1 | 2 | 4 forces the block width (read per call)
     const char* nb_env = getenv("NIMG_WGRAD3_NB");
     int nb = nb_env ? atoi(nb_env) : 0;

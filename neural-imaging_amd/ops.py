@@ -430,6 +430,11 @@ def _flush_deferred(k, on_its_stream=True):
 # as soon as its predecessor ends, the reduction (a small grid that waits long for free CUs beside the chip-filling kernels: 28 us
 # on average inside a C4 step against 7 us alone) runs beside it.  Every pending weight gradient keeps its own piece of the side
 # stream's arena until the join.  Same kernels, same sums.
+# NIMG_CHAIN_REDUCE=0|1: the slab reduction of a side=True weight gradient runs in the PROLOGUE of the next weight-gradient kernel of its
+# side stream (nimg_conv2d_wgrad_bf16_chained; the last one of a chain as a launch of its own at the join): ~25 launches fewer per
+# step on the side queues, which end later than the launch queue in the UNet's backward pass (profiles/r06_fork_markers.txt).
+CHAIN_REDUCE = _os.environ.get('NIMG_CHAIN_REDUCE', '0') == '1'
+_CHAIN = {}                                   # side stream index -> the entry its last chained launch filled (ctypes buffer)
 REDUCE_STREAM = _os.environ.get('NIMG_REDUCE_STREAM', '0') == '1'
 _RSTREAM = {'streams': {}, 'dirty': set()}
 
@@ -452,12 +457,28 @@ def _reduce_behind(k, entry, device):
     _RSTREAM['dirty'].add(k)
 
 
+def _flush_chain(k):
+    """The reduction the last chained weight gradient of side stream k still owes: as a launch of its own, on that stream."""
+    entry = _CHAIN.pop(k, None)
+    if entry is None:
+        return
+    side = _SIDE['streams'][k]
+    prev = torch.cuda.current_stream(side.device)
+    torch.cuda.set_stream(side)
+    try:
+        _lib.call('nimg_reduce_slabs_batch', entry, 1, _stream())
+    finally:
+        torch.cuda.set_stream(prev)
+    _SIDE['ws'][k].release()               # (later users of the arena are ordered behind the join that called this)
+
+
 def join_side_stream():
     """Make the current stream wait for the parameter-gradient kernels launched on the side streams."""
     for k in sorted(_SIDE['dirty']):
         st = _SIDE['streams'][k]
         if st is not None:
             _flush_deferred(k)
+            _flush_chain(k)
             torch.cuda.current_stream(st.device).wait_stream(st)
     _SIDE['dirty'].clear()
     for k in sorted(_RSTREAM['dirty']):
@@ -791,6 +812,11 @@ def conv2d_wgrad(x, dz, ks, x2=None, stride=1, padding='SAME', pad_mode=0, pads=
         if _defer_k is not None and REDUCE_STREAM and not accumulate:
             _wgrad_reduce_stream(_defer_k, x, c1, x2, c2, dz, None, cout, dw, db, n, h, wd, ks, stride, pt, pl, pad_mode, ho, wo, need, flags)
             return dw
+        if _defer_k is not None and CHAIN_REDUCE and not accumulate:
+            _wgrad_chained(_defer_k, x, c1, x2, c2, dz, None, cout, dw, db, n, h, wd, ks, stride, pt, pl, pad_mode, ho, wo, need, flags)
+            return dw
+        if _defer_k is not None and CHAIN_REDUCE:
+            _flush_chain_here(_defer_k)        # an accumulating launch follows the chain of its stream
         if _defer_k is not None:
             _flush_deferred(_defer_k, on_its_stream=False)      # an accumulating launch follows the pending ones of its stream
         ws = _ws_current(x.device).get(need, x.device)
@@ -817,6 +843,25 @@ def _wgrad_deferred(k, x, c1, x2, c2, dz, idx, cout, dw, db, n, h, wd, ks, strid
     _lib.call('nimg_conv2d_wgrad_bf16_deferred', _p(x), c1, _p(x2), c2, _p(dz), _p(idx), cout, _p(dw), _p(db), n, h, wd, ks, stride,
               pt, pl, pad_mode, ho, wo, _p(ws), ws.numel(), flags, entry, _stream())
     st['n'] += 1
+
+
+def _flush_chain_here(k):
+    entry = _CHAIN.pop(k, None)
+    if entry is not None:
+        _lib.call('nimg_reduce_slabs_batch', entry, 1, _stream())
+
+
+def _wgrad_chained(k, x, c1, x2, c2, dz, idx, cout, dw, db, n, h, wd, ks, stride, pt, pl, pad_mode, ho, wo, need, flags):
+    """One weight gradient on side stream k (the current stream): it runs the reduction its predecessor on k owes and leaves its
+    own to its successor (or to the join)."""
+    import ctypes
+    nb = int(_lib.load().nimg_reduce_entry_bytes())
+    pre = _CHAIN.get(k)
+    entry = (ctypes.c_char * nb)()
+    ws = _SIDE['ws'][k].claim(need, x.device)
+    _lib.call('nimg_conv2d_wgrad_bf16_chained', _p(x), c1, _p(x2), c2, _p(dz), _p(idx), cout, _p(dw), _p(db), n, h, wd, ks, stride,
+              pt, pl, pad_mode, ho, wo, _p(ws), ws.numel(), flags, pre, entry, _stream())
+    _CHAIN[k] = entry
 
 
 def _wgrad_reduce_stream(k, x, c1, x2, c2, dz, idx, cout, dw, db, n, h, wd, ks, stride, pt, pl, pad_mode, ho, wo, need, flags):
@@ -1072,6 +1117,9 @@ def conv2d_wgrad_unpool(x, g, idx, ks, dw, db=None, side=False, _defer_k=None):
     need = _lib.load().nimg_conv2d_wgrad_bf16_workspace_bytes(cin, cout, ks, ks, n, h, wd)
     if _defer_k is not None and DEFER_REDUCE and ks == 5 and h % 2 == 0 and wd % 2 == 0:
         _wgrad_deferred(_defer_k, x, cin, None, 0, g, idx, cout, dw, db, n, h, wd, ks, 1, 2, 2, 0, h, wd, need, BF16_IN | BF16_DZ)
+        return dw
+    if _defer_k is not None and CHAIN_REDUCE and ks == 5 and h % 2 == 0 and wd % 2 == 0:
+        _wgrad_chained(_defer_k, x, cin, None, 0, g, idx, cout, dw, db, n, h, wd, ks, 1, 2, 2, 0, h, wd, need, BF16_IN | BF16_DZ)
         return dw
     if _defer_k is not None and REDUCE_STREAM and ks == 5 and h % 2 == 0 and wd % 2 == 0:
         _wgrad_reduce_stream(_defer_k, x, cin, None, 0, g, idx, cout, dw, db, n, h, wd, ks, 1, 2, 2, 0, h, wd, need, BF16_IN | BF16_DZ)

@@ -1140,6 +1140,40 @@ def test_deferred_slab_reductions_give_the_same_gradients(dev, monkeypatch):
             assert np.array_equal(res[False][part][k], res[True][part][k]), (part, k)
 
 
+@pytest.mark.parametrize('raw_patch', [32, 64])
+def test_chained_slab_reductions_give_the_same_gradients(dev, monkeypatch, raw_patch):
+    """ops.CHAIN_REDUCE: the split-K reduction of a side-stream weight gradient runs in the prologue of the NEXT weight-gradient kernel
+    of its stream (nimg_conv2d_wgrad_bf16_chained; common.h reduce_seq restates reduce_slabs' additions per column, in its order),
+    the last one of a chain at the join - the same sums to the bit as one reduction launch per layer, UNet, FAN and a codec step."""
+    from neural_imaging_amd import ops
+    from neural_imaging_amd.models import compression
+    from neural_imaging_amd.workflows.manipulation_classification import ManipulationClassification
+    dist = {'downsampling': 'none', 'compression': 'jpeg', 'compression_params': {'quality': 80, 'codec': 'soft'}}
+    rgb = natural_images(4, 2 * raw_patch, 2 * raw_patch, seed=78)
+    raw = bayer_from_rgb(rgb)
+    res = {}
+    try:
+        ops.set_compute('bf16')
+        for chain in (False, True):
+            monkeypatch.setattr(ops, 'CHAIN_REDUCE', chain)
+            wf = ManipulationClassification('UNet', distribution=dist, trainable={'nip'}, raw_patch_size=raw_patch, device=dev)
+            for _ in range(2):
+                loss, _ = wf.training_step(raw, rgb, lambda_nip=0.1, learning_rate=1e-4)
+            torch.cuda.synchronize()
+            dcn = compression.TwitterDCN(patch_size=2 * raw_patch, device=dev)
+            dcn.training_step(rgb, 1e-4)
+            torch.cuda.synchronize()
+            res[chain] = (float(loss), {k: v.copy() for k, v in grads_of(wf.nip).items()}, {k: v.copy() for k, v in grads_of(wf.fan).items()},
+                          wf.nip.state_dict(), wf.fan.state_dict(), {k: v.copy() for k, v in grads_of(dcn).items()})
+            assert not ops._CHAIN                                   # every chain ended at a join
+    finally:
+        ops.set_compute('f32')
+    assert res[False][0] == res[True][0]
+    for part in (1, 2, 3, 4, 5):
+        for k in res[False][part]:
+            assert np.array_equal(res[False][part][k], res[True][part][k]), (part, k)
+
+
 def test_twitter_dcn_forward_backward(dev):
     """TwitterDCN-32C (models/compression.py:197-279): reconstruction, hard latent indices (exact), entropy, loss and
     every parameter gradient against the float64 oracle; then the reference's training_step contract."""
