@@ -306,7 +306,9 @@ class _on_side_stream(object):
         self.prev = torch.cuda.current_stream(dev)
         fork = _SIDE.get('fork')
         if fork is not None and fork[1] == self.prev:
-            side.wait_event(fork[0])            # inside `with one_fork()`: the group's single marker on the launch stream
+            if k not in fork[2]:                # inside `with one_fork()`: the group's single marker on the launch stream,
+                side.wait_event(fork[0])        # waited for ONCE per side stream (its later launches are behind that wait)
+                fork[2].add(k)
         else:
             side.wait_stream(self.prev)
         for t in self.tensors:
@@ -335,7 +337,7 @@ class one_fork(object):
             cur = torch.cuda.current_stream()
             ev = torch.cuda.Event()
             ev.record(cur)
-            _SIDE['fork'] = (ev, cur)
+            _SIDE['fork'] = (ev, cur, set())
             self.mine = True
         else:
             self.mine = False
