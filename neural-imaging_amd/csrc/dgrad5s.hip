@@ -247,6 +247,184 @@ __global__ __launch_bounds__(256, 2) void conv5_dgrad_sparse_kernel(const Dg5sPa
     }
 }
 
+
+// ---- 16-accumulator form (round 6): one workgroup per CU, a wave holds 4 x 4 fragments = TWO 16 x 16 pooled sub-tiles' share
+// against all four parity classes: per window 16 matrix instructions for the same 24 KB weight slab the 8-accumulator form
+// streams for 8 (profiles/r06_conv3_loop_anatomy.txt: a wave spends ~100 cycles per LDS-DMA piece it requests, 600 cycles per
+// slab - what bounds the 8-accumulator form at half the pipe).  The two sub-tiles are neighbours in the linear (image, tile) order:
+// side by side in an image, or the same tile of consecutive images (16 x 16 pooled layers); each keeps its own 18 x 18 halo.
+constexpr int W_NT = 2;                                                   // sub-tiles per workgroup
+constexpr int W_APLANE = W_NT * S_NPIX * 16, W_ABUF = 2 * W_APLANE + 2 * W_NT * S_NPIX * 4;
+constexpr int W_LDS_TILES = 2 * S_SLAB + 2 * W_ABUF;
+constexpr int W_LDS_EPI = 4 * 32 * (128 + EPI_PAD) * 4;
+constexpr int W_LDS = W_LDS_TILES > W_LDS_EPI ? W_LDS_TILES : W_LDS_EPI;
+
+__global__ __launch_bounds__(256, 1) void conv5_dgrad_sparse16_kernel(const Dg5sParams p) {
+    constexpr int MI = 4, NI = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned char* sB = smem_raw;
+    unsigned char* sA = smem_raw + 2 * S_SLAB;
+    const unsigned sB_addr = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)smem_raw;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, nl = lane & 31;
+    const int nts = p.Ci / 32, chunks = p.Cz / 8;
+    int bid = xcd_order(blockIdx.x);
+    const int nt = bid % nts;
+    bid /= nts;
+    const int tiles = p.tiles_y * p.tiles_x;
+    const long total = (long)p.N * tiles;                 // sub-tiles in all
+    const long L0 = (long)W_NT * bid;                     // this workgroup's first sub-tile
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[mi][ni][j] = 0.0f;
+
+    // ---- A tile staging: items = halo pixels of both sub-tiles
+    constexpr int NPIX2 = W_NT * S_NPIX;
+    constexpr int AP = (NPIX2 + 255) / 256;
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.g), 0,
+                                                                        (int)((long)p.N * p.Hp * p.Wp * p.Cz * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.idx), 0,
+                                                                        (int)((long)p.N * p.Hp * p.Wp * p.Cz), 0x00020000);
+    unsigned aoff[AP];
+#pragma unroll
+    for (int q = 0; q < AP; ++q) {
+        const int item = tid + q * 256, sub = item / S_NPIX, pix = item % S_NPIX;
+        const long L = L0 + sub;
+        const int n = (int)(L / tiles), tile = (int)(L % tiles);
+        const int gy = (tile / p.tiles_x) * S_TP - 1 + pix / S_HP, gx = (tile % p.tiles_x) * S_TP - 1 + pix % S_HP;
+        const bool ok = (item < NPIX2) & (L < total) & ((unsigned)gy < (unsigned)p.Hp) & ((unsigned)gx < (unsigned)p.Wp);
+        aoff[q] = ok ? (unsigned)(((n * p.Hp + gy) * p.Wp + gx) * p.Cz) : 0x40000000u;
+    }
+    u32x4 preG[AP];
+    u32x2 preK[AP];
+    auto fetchA = [&](int c) {
+#pragma unroll
+        for (int q = 0; q < AP; ++q) {
+            preG[q] = __builtin_amdgcn_raw_buffer_load_b128(rg, aoff[q] >= 0x40000000u ? 0x80000000u : (aoff[q] + c * 8) * 2, 0, 0);
+            preK[q] = __builtin_amdgcn_raw_buffer_load_b64(rk, aoff[q] >= 0x40000000u ? 0x80000000u : aoff[q] + c * 8, 0, 0);
+        }
+    };
+    auto commitA = [&](unsigned char* buf) {
+#pragma unroll
+        for (int q = 0; q < AP; ++q) {
+            const int pix = tid + q * 256;                 // = sub * S_NPIX + halo pixel: the planes hold both sub-tiles back to back
+            if (pix < NPIX2) {
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const unsigned v0 = preG[q][2 * hh], v1 = preG[q][2 * hh + 1], k = preK[q][hh] & 0x03030303u;
+                    u32x4 c4;
+                    c4[0] = v0 & 0xffffu; c4[1] = v0 >> 16; c4[2] = v1 & 0xffffu; c4[3] = v1 >> 16;
+                    *reinterpret_cast<u32x4*>(buf + hh * W_APLANE + pix * 16) = c4;
+                    const unsigned iw = (k & 3u) | ((k >> 4) & 0x30u) | ((k >> 8) & 0x300u) | ((k >> 12) & 0x3000u);
+                    *reinterpret_cast<unsigned*>(buf + 2 * W_APLANE + (hh * NPIX2 + pix) * 4) = iw;
+                }
+            }
+        }
+    };
+    const unsigned long img_addr = (unsigned long)p.img;
+    const r_u32x4 rb = {(unsigned)img_addr, (unsigned)(img_addr >> 32) & 0xffffu, (unsigned)((long)nts * chunks * 3 * S_SLAB), 0x00020000u};
+    auto gldsB = [&](int c, int wy, int slot) {
+        const unsigned soff = (unsigned)((((long)nt * chunks + c) * 3 + wy) * S_SLAB);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int k = wave + 4 * j;
+            glds16(rb, sB_addr + (unsigned)(slot * S_SLAB + k * 1024), (unsigned)(lane * 16), soff + (unsigned)(k * 1024));
+        }
+    };
+
+    int abase[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int P = (wave * MI + mi) * 32 + nl;          // 0 .. 511: sub-tile P >> 8, pixel P & 255 of it
+        const int loc = P & 255;
+        abase[mi] = (P >> 8) * S_NPIX + (loc / S_TP) * S_HP + (loc % S_TP);
+    }
+    const int bbase = h * 2 * 2048 + nl * 16;
+
+    gldsB(0, 0, 0);
+    fetchA(0);
+    commitA(sA);
+    dma_wait();
+    __syncthreads();
+    for (int c = 0; c < chunks; ++c) {
+        const unsigned char* ab = sA + (c & 1) * W_ABUF;
+        const bool more = c + 1 < chunks;
+#pragma unroll
+        for (int wy = 0; wy < 3; ++wy) {
+            const int slot = (c + wy) & 1;
+            if (wy < 2) gldsB(c, wy + 1, slot ^ 1);
+            else if (more) gldsB(c + 1, 0, slot ^ 1);
+            if (wy == 0 && more) fetchA(c + 1);
+            const unsigned char* bs = sB + slot * S_SLAB + bbase;
+#pragma unroll
+            for (int wx = 0; wx < 3; ++wx) {
+                bf16x8 a[MI];
+                int ix[MI];
+                bf16x16 b[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int hp = abase[mi] + wy * S_HP + wx;
+                    a[mi] = *reinterpret_cast<const bf16x8*>(ab + h * W_APLANE + hp * 16);
+                    ix[mi] = *reinterpret_cast<const int*>(ab + 2 * W_APLANE + (h * NPIX2 + hp) * 4);
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const u32x4 lo = *reinterpret_cast<const u32x4*>(bs + wx * 8192 + ni * 512);
+                    const u32x4 hi = *reinterpret_cast<const u32x4*>(bs + wx * 8192 + ni * 512 + 2048);
+                    unsigned t[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    b[ni] = *reinterpret_cast<const bf16x16*>(t);
+                }
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_smfmac_f32_32x32x32_bf16(a[mi], b[ni], acc[mi][ni], ix[mi], 0, 0);
+            }
+            if (wy == 2 && more) commitA(sA + ((c + 1) & 1) * W_ABUF);
+            dma_wait();
+            __syncthreads();
+        }
+    }
+    float* elds = reinterpret_cast<float*>(smem_raw) + wave * (32 * (NI * 32 + EPI_PAD));
+    const int H = 2 * p.Hp, W = 2 * p.Wp;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        epilogue_via_lds<NI, false>(acc[mi], elds, lane, [&](int row, int c, float4 v) {
+            const int P = (wave * MI + mi) * 32 + row, loc = P & 255;
+            const long L = L0 + (P >> 8);
+            if (L >= total) return;
+            const int n = (int)(L / tiles), tile = (int)(L % tiles);
+            const int a_ = (tile / p.tiles_x) * S_TP + loc / S_TP, b_ = (tile % p.tiles_x) * S_TP + loc % S_TP, cls = c >> 5;
+            if (a_ >= p.Hp || b_ >= p.Wp) return;
+            const long o = (((long)n * H + 2 * a_ + (cls >> 1)) * W + 2 * b_ + (cls & 1)) * p.Ci + nt * 32 + (c & 31);
+            if (p.act) {
+                float4 m;
+                if (p.flags & NIMG_BF16_MASK) {
+                    const bf16x4 mb = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(p.act) + o);
+                    m = make_float4((float)mb[0], (float)mb[1], (float)mb[2], (float)mb[3]);
+                } else {
+                    m = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.act) + o);
+                }
+                v.x *= m.x > 0.f ? 1.0f : p.alpha; v.y *= m.y > 0.f ? 1.0f : p.alpha;
+                v.z *= m.z > 0.f ? 1.0f : p.alpha; v.w *= m.w > 0.f ? 1.0f : p.alpha;
+            }
+            if (p.flags & NIMG_BF16_OUT) {
+                bf16x4 ob;
+                ob[0] = (__bf16)v.x; ob[1] = (__bf16)v.y; ob[2] = (__bf16)v.z; ob[3] = (__bf16)v.w;
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.out) + o) = ob;
+            } else {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) = v;
+            }
+        });
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -280,6 +458,16 @@ int nimg_conv5_dgrad_sparse(const void* g, const unsigned char* idx, int cout, c
     p.tiles_y = nimg::cdiv(p.Hp, S_TP);
     p.tiles_x = nimg::cdiv(p.Wp, S_TP);
     const long blocks = (long)(cin / 32) * p.tiles_y * p.tiles_x * n;
+    // NIMG_DGRAD5S_ACC16=1: the 16-accumulator form (two sub-tiles per workgroup, one workgroup per CU)
+    static const bool acc16 = getenv("NIMG_DGRAD5S_ACC16") != nullptr;
+    if (acc16) {
+        const long subtiles = (long)p.tiles_y * p.tiles_x * n;
+        const long blocks16 = (long)(cin / 32) * ((subtiles + W_NT - 1) / W_NT);
+        (void)hipFuncSetAttribute((const void*)conv5_dgrad_sparse16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS);
+        hipLaunchKernelGGL(conv5_dgrad_sparse16_kernel, dim3((unsigned)blocks16), dim3(256), W_LDS, (hipStream_t)stream, p);
+        NIMG_CHECK_LAUNCH();
+        return NIMG_OK;
+    }
     static const bool block42 = getenv("NIMG_DGRAD5S_BLOCK42") != nullptr;        // A/B: the 4 x 2 fragment block (round 6, slower)
     auto kern = block42 ? conv5_dgrad_sparse_kernel<4> : conv5_dgrad_sparse_kernel<2>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS);
